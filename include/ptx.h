@@ -1,0 +1,396 @@
+/*
+ * ptx.h -- C-ABI of the MI355X wavefront path-tracing backend.
+ *
+ * This is the drop-in boundary for ONE hot path of piotrprzybyszdev/Path-Tracing:
+ * the vkCmdTraceRaysKHR(W,H,1) pass recorded by Renderer::RecordPathTracingCommands
+ * (Path-Tracing/Renderer/Renderer.cpp:892-926) and the scene upload that feeds it
+ * (Renderer::UpdateSceneData, Renderer.cpp:238-439).  The reference has no FFI; the
+ * seam is the static C++ class `Renderer` (Renderer/Renderer.h:39-85).  Every entry
+ * point below names the reference call it stands in for.
+ *
+ * Rules of the ABI: plain pointers and sizes, no C++ types, no exceptions; every
+ * function returns a PtxStatus (0 = OK) and ptx_last_error() gives the message
+ * (the reference throws PathTracing::error, Core/Core.h:117-122).  A handle is NOT
+ * thread-safe; one host thread per handle, one handle per GPU.
+ *
+ * All structs in the "data contract" block are byte-compatible with the reference's
+ * host/device shared headers (Path-Tracing/Shaders/ShaderTypes.incl and
+ * ShaderRendererTypes.incl); sizes are checked by PTX_STATIC_ASSERTs (the
+ * equivalent of the reference's PaddingTest.cpp).
+ */
+#ifndef PTX_H
+#define PTX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#define PTX_STATIC_ASSERT(c, m) static_assert(c, m)
+#else
+#define PTX_STATIC_ASSERT(c, m) _Static_assert(c, m)
+#endif
+
+#if defined(_WIN32)
+#define PTX_API
+#else
+#define PTX_API __attribute__((visibility("default")))
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* Data contract                                                             */
+/* ------------------------------------------------------------------------- */
+
+/* ShaderTypes.incl:18-33 */
+enum {
+    PTX_DEFAULT_COLOR_TEXTURE_INDEX = 0,
+    PTX_DEFAULT_NORMAL_TEXTURE_INDEX = 1,
+    PTX_DEFAULT_ROUGHNESS_TEXTURE_INDEX = 2,
+    PTX_DEFAULT_METALLIC_TEXTURE_INDEX = 3,
+    PTX_DEFAULT_EMISSIVE_TEXTURE_INDEX = 4,
+    PTX_DEFAULT_SPECULAR_TEXTURE_INDEX = 5,
+    PTX_DEFAULT_GLOSSINESS_TEXTURE_INDEX = 6,
+    PTX_DEFAULT_SHININESS_TEXTURE_INDEX = 7,
+    PTX_PLACEHOLDER_TEXTURE_INDEX = 8,
+    PTX_SCENE_TEXTURE_OFFSET = 9,
+    PTX_MAX_TEXTURE_COUNT = 1024,
+    PTX_MAX_LIGHT_COUNT = 64
+};
+
+/* ShaderTypes.incl:143-145 */
+enum {
+    PTX_MATERIAL_TYPE_METALLIC_ROUGHNESS = 0,
+    PTX_MATERIAL_TYPE_SPECULAR_GLOSSINESS = 1,
+    PTX_MATERIAL_TYPE_PHONG = 2
+};
+
+/* ShaderTypes.incl:41-48 -- 14 floats, unpadded, read by GLSL as vec2[7] (common.glsl:27-46) */
+typedef struct PtxVertex {
+    float Position[3];
+    float TexCoords[2];
+    float Normal[3];
+    float Tangent[3];
+    float Bitangent[3];
+} PtxVertex;
+PTX_STATIC_ASSERT(sizeof(PtxVertex) == 56, "Vertex is 56 B");
+
+/* ShaderTypes.incl:61-80 */
+typedef struct PtxMetallicRoughnessMaterial {
+    float EmissiveColor[3];
+    float EmissiveIntensity;
+    float Color[4];
+    float Roughness;
+    float Metalness;
+    float Ior;
+    float Transmission;
+    float AttenuationColor[3];
+    float AttenuationDistance;
+    float pad0, pad1, pad2;
+    uint32_t EmissiveIdx;
+    uint32_t ColorIdx;
+    uint32_t NormalIdx;
+    uint32_t RoughnessIdx;
+    uint32_t MetallicIdx;
+} PtxMetallicRoughnessMaterial;
+PTX_STATIC_ASSERT(sizeof(PtxMetallicRoughnessMaterial) == 96, "MR material is 96 B");
+
+/* ShaderTypes.incl:82-99 */
+typedef struct PtxSpecularGlossinessMaterial {
+    float EmissiveColor[3];
+    float EmissiveIntensity;
+    float Color[4];
+    float Specular[3];
+    float Glossiness;
+    float AttenuationColor[3];
+    float AttenuationDistance;
+    float Ior;
+    float Transmission;
+    uint32_t EmissiveIdx;
+    uint32_t ColorIdx;
+    uint32_t NormalIdx;
+    uint32_t SpecularIdx;
+    uint32_t GlossinessIdx;
+    float pad0;
+} PtxSpecularGlossinessMaterial;
+PTX_STATIC_ASSERT(sizeof(PtxSpecularGlossinessMaterial) == 96, "SG material is 96 B");
+
+/* ShaderTypes.incl:101-118 */
+typedef struct PtxPhongMaterial {
+    float EmissiveColor[3];
+    float EmissiveIntensity;
+    float Color[4];
+    float Specular[3];
+    float Shininess;
+    float AttenuationColor[3];
+    float AttenuationDistance;
+    float Ior;
+    float Transmission;
+    uint32_t EmissiveIdx;
+    uint32_t ColorIdx;
+    uint32_t NormalIdx;
+    uint32_t SpecularIdx;
+    uint32_t ShininessIdx;
+    float pad0;
+} PtxPhongMaterial;
+PTX_STATIC_ASSERT(sizeof(PtxPhongMaterial) == 96, "Phong material is 96 B");
+
+/* ShaderTypes.incl:120-126 */
+typedef struct PtxDirectionalLight {
+    float Color[3];
+    float pad0;
+    float Direction[3];
+    float pad1;
+} PtxDirectionalLight;
+PTX_STATIC_ASSERT(sizeof(PtxDirectionalLight) == 32, "DirectionalLight is 32 B");
+
+/* ShaderTypes.incl:128-138 */
+typedef struct PtxPointLight {
+    float Color[3];
+    float pad0;
+    float Position[3];
+    float pad1;
+    float AttenuationConstant;
+    float AttenuationLinear;
+    float AttenuationQuadratic;
+    float pad2;
+} PtxPointLight;
+PTX_STATIC_ASSERT(sizeof(PtxPointLight) == 48, "PointLight is 48 B");
+
+/* closestHit.rchit:32-36 with the offsets of Renderer.h:152-156:
+ * uint count @0, DirectionalLight @16, PointLight[64] @48. */
+typedef struct PtxLightsUbo {
+    uint32_t LightCount;
+    uint32_t pad[3];
+    PtxDirectionalLight Directional;
+    PtxPointLight Lights[PTX_MAX_LIGHT_COUNT];
+} PtxLightsUbo;
+PTX_STATIC_ASSERT(sizeof(PtxLightsUbo) == 48 + 64 * 48, "lights UBO is 3120 B");
+
+/* ShaderRendererTypes.incl:26-34 (Camera = ShaderTypes.incl:35-39).  Matrices are
+ * glm column-major: element [col*4 + row]. */
+typedef struct PtxRaygenUniformData {
+    float ViewInverse[16];
+    float ProjInverse[16];
+    uint32_t BounceCount;
+    float LensRadius;
+    float FocalDistance;
+    uint32_t SampleCount;  /* samples added by this launch                      */
+    uint32_t TotalSamples; /* samples accumulated BEFORE this launch = RNG frame */
+} PtxRaygenUniformData;
+PTX_STATIC_ASSERT(sizeof(PtxRaygenUniformData) == 148, "RaygenUniformData is 148 B");
+
+/* Scene.h:63-71 */
+typedef struct PtxGeometry {
+    uint32_t VertexOffset;
+    uint32_t VertexLength;
+    uint32_t IndexOffset;
+    uint32_t IndexLength;
+    uint8_t IsOpaque;
+    uint8_t IsAnimated;
+    uint8_t pad[2];
+} PtxGeometry;
+PTX_STATIC_ASSERT(sizeof(PtxGeometry) == 20, "Geometry is 20 B");
+
+/* ShaderRendererTypes.incl:42-47 (SBTBuffer); one per mesh, in model-then-mesh order
+ * (Renderer.cpp:378-399).  Record index = Model.MeshOffset + geometry index inside
+ * the model's BLAS (AccelerationStructure.cpp:270-274). */
+typedef struct PtxMeshRecord {
+    uint32_t GeometryIndex;
+    uint32_t MaterialId; /* (index << 8) | type, ShaderTypes.incl:155-168 */
+    uint32_t TransformIndex;
+} PtxMeshRecord;
+PTX_STATIC_ASSERT(sizeof(PtxMeshRecord) == 12, "SBTBuffer is 12 B");
+
+/* glm::mat3x4 as used for Scene::GetTransforms() and VkTransformMatrixKHR
+ * (closestHit.rchit:12-14): 3 rows of the affine matrix, 4 floats each. */
+typedef struct PtxTransform {
+    float m[12];
+} PtxTransform;
+PTX_STATIC_ASSERT(sizeof(PtxTransform) == 48, "mat3x4 is 48 B");
+
+/* Scene.h:96-100 flattened: the meshes of model i are records
+ * [MeshOffset, MeshOffset + MeshCount). */
+typedef struct PtxModel {
+    uint32_t MeshOffset;
+    uint32_t MeshCount;
+} PtxModel;
+
+/* Scene.h:102-107; Transform = first 3 rows of the instance's affine matrix
+ * (AccelerationStructure.cpp:271). */
+typedef struct PtxModelInstance {
+    uint32_t ModelIndex;
+    PtxTransform Transform;
+} PtxModelInstance;
+
+enum {
+    PTX_SKYBOX_CLEAR_COLOR = 0, /* miss.rmiss:37: constant (0.08, 0.09, 0.10) */
+    PTX_SKYBOX_2D = 1,          /* MissFlagsSkybox2D  -- next row N1          */
+    PTX_SKYBOX_CUBE = 2         /* MissFlagsSkyboxCube -- next row N1         */
+};
+
+/* What Renderer::UpdateSceneData pulls through the Scene getters
+ * (Scene.h:182-207).  The caller keeps ownership; ptx_scene_upload copies. */
+typedef struct PtxSceneDesc {
+    const PtxVertex *vertices;
+    uint64_t vertexCount;
+    const uint32_t *indices; /* relative to the geometry's VertexOffset */
+    uint64_t indexCount;
+    const PtxTransform *transforms; /* [0] = identity (Scene.h:306,312) */
+    uint32_t transformCount;
+    const PtxGeometry *geometries;
+    uint32_t geometryCount;
+    const PtxMetallicRoughnessMaterial *metallicRoughnessMaterials;
+    uint32_t metallicRoughnessMaterialCount;
+    const PtxSpecularGlossinessMaterial *specularGlossinessMaterials;
+    uint32_t specularGlossinessMaterialCount;
+    const PtxPhongMaterial *phongMaterials;
+    uint32_t phongMaterialCount;
+    const PtxMeshRecord *meshes;
+    uint32_t meshCount;
+    const PtxModel *models;
+    uint32_t modelCount;
+    const PtxModelInstance *instances;
+    uint32_t instanceCount;
+    uint32_t skyboxKind;       /* PTX_SKYBOX_*; PathTracingPipelineConfig.MissFlags */
+    uint32_t dxNormalTextures; /* HitFlagsDxNormalTextures, ShaderRendererTypes.incl:96-99 */
+} PtxSceneDesc;
+
+/* ------------------------------------------------------------------------- */
+/* Renderer                                                                  */
+/* ------------------------------------------------------------------------- */
+
+typedef enum PtxStatus {
+    PTX_OK = 0,
+    PTX_ERROR_INVALID_ARGUMENT = 1,
+    PTX_ERROR_NO_DEVICE = 2,
+    PTX_ERROR_OUT_OF_MEMORY = 3,
+    PTX_ERROR_DEVICE = 4,
+    PTX_ERROR_NOT_READY = 5
+} PtxStatus;
+
+typedef enum PtxBackend {
+    PTX_BACKEND_WAVEFRONT = 0,  /* queue-per-stage kernels (production path)            */
+    PTX_BACKEND_MEGAKERNEL = 1  /* one thread per pixel running raygen.rgen's loop 1:1  */
+} PtxBackend;
+
+typedef struct PtxDeviceDesc {
+    int32_t deviceIndex;  /* HIP device ordinal                                        */
+    uint32_t backend;     /* PtxBackend                                                */
+    void *stream;         /* hipStream_t to launch on, or NULL for an internal stream  */
+} PtxDeviceDesc;
+
+/* Pixel-tile shard of a frame: the image is cut into tileSize x tileSize
+ * tiles, numbered row-major; this renderer owns tiles with (tile % worldSize) == rank.
+ * rank 0 / worldSize 1 = whole frame. */
+typedef struct PtxTileShard {
+    uint32_t rank;
+    uint32_t worldSize;
+    uint32_t tileSize;
+} PtxTileShard;
+
+/* Counters of the last ptx_render() (all deterministic given the RNG schedule). */
+typedef struct PtxStats {
+    uint64_t pathSamples;    /* pixel-samples completed (incl. NaN/Inf retries)     */
+    uint64_t segments;       /* closest-hit queries traced                          */
+    uint64_t shadowRays;     /* occlusion queries traced                            */
+    uint64_t retries;        /* NaN/Inf sample restarts (raygen.rgen:99-112)        */
+    uint64_t triangles;      /* flattened world-space triangles in the LBVH         */
+    uint64_t bvhNodes;       /* internal LBVH nodes                                 */
+    double lastRenderMs;     /* device time of the last ptx_render (HIP events)     */
+    double lastTraceMs;      /* ... spent in the traversal kernels                  */
+    double lastBuildMs;      /* device time of the last ptx_build_accel             */
+    uint64_t traceLaunches;  /* number of traversal kernel launches in last render  */
+} PtxStats;
+
+typedef struct PtxRenderer PtxRenderer;
+
+/* Renderer::Init / Renderer::Shutdown (Renderer.cpp:77-218) */
+PTX_API int ptx_create(const PtxDeviceDesc *desc, PtxRenderer **out);
+PTX_API void ptx_destroy(PtxRenderer *r);
+PTX_API const char *ptx_last_error(const PtxRenderer *r);
+PTX_API int ptx_device_count(void);
+
+/* Renderer::UpdateSceneData (Renderer.cpp:238-439): copy the scene to HBM. */
+PTX_API int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *scene);
+/* AccelerationStructure::Build (AccelerationStructure.cpp:26-46; BLAS :64-247, TLAS
+ * :250-301), replaced by a software LBVH over the flattened world-space triangles. */
+PTX_API int ptx_build_accel(PtxRenderer *r);
+
+/* Renderer::OnResize / CreateSceneRenderingResources: (re)allocate the RGBA32F
+ * accumulation image (Renderer.cpp:1284-1287) and the wavefront path state. */
+PTX_API int ptx_resize(PtxRenderer *r, uint32_t width, uint32_t height);
+PTX_API int ptx_set_tile_shard(PtxRenderer *r, const PtxTileShard *shard);
+PTX_API int ptx_set_backend(PtxRenderer *r, uint32_t backend);
+
+/* Renderer::ResetAccumulationImage (Renderer.cpp:801-808, clear at :1734-1748). */
+PTX_API int ptx_reset_accumulation(PtxRenderer *r);
+
+/* Renderer::Render's uniform fill + RecordPathTracingCommands (Renderer.cpp:1686-1726,
+ * 892-926): adds uniform->SampleCount samples per owned pixel, RNG frame =
+ * uniform->TotalSamples, into the accumulation image.  Asynchronous on the stream. */
+PTX_API int ptx_render(PtxRenderer *r, const PtxRaygenUniformData *uniform, const PtxLightsUbo *lights);
+/* Convenience for the canonical schedule: `frames` launches with
+ * SampleCount = 1 and TotalSamples = firstFrame .. firstFrame+frames-1, issued as ONE
+ * wavefront batch; the result is bit-identical to `frames` ptx_render calls. */
+PTX_API int ptx_render_frames(PtxRenderer *r, const PtxRaygenUniformData *uniform, const PtxLightsUbo *lights,
+                              uint32_t firstFrame, uint32_t frames);
+
+PTX_API int ptx_synchronize(PtxRenderer *r);
+/* imageLoad of the accumulation image: device -> host, W*H*4 floats (running SUM). */
+PTX_API int ptx_readback(PtxRenderer *r, float *rgba, size_t bytes);
+/* Device pointer of the accumulation image (for the RCCL gather) and its size. */
+PTX_API void *ptx_device_accum_ptr(PtxRenderer *r);
+PTX_API size_t ptx_accum_bytes(const PtxRenderer *r);
+/* Pack / unpack this shard's tiles to/from a dense tile-major buffer of
+ * ptx_shard_bytes() bytes (the message of the single gather). */
+PTX_API size_t ptx_shard_bytes(const PtxRenderer *r, uint32_t rank);
+PTX_API int ptx_pack_shard(PtxRenderer *r, void *devDst);
+PTX_API int ptx_unpack_shard(PtxRenderer *r, uint32_t rank, const void *devSrc);
+
+PTX_API int ptx_get_stats(PtxRenderer *r, PtxStats *stats);
+
+/* ------------------------------------------------------------------------- */
+/* Function-level entry (mirrors Path-Tracing-Tests/TestRenderer.cpp:79-105:   */
+/* run one production shading function over n packed inputs on the device).    */
+/* ------------------------------------------------------------------------- */
+typedef enum PtxTestFunction {
+    /* ShadingTestShaderTypes.incl:19-27 */
+    PTX_FN_GGX_DISTRIBUTION = 0,    /* in: H.xyz, alpha            out: result                  */
+    PTX_FN_LAMBDA = 1,              /* in: V.xyz, alpha            out: result                  */
+    PTX_FN_GGX_SMITH = 2,           /* in: V.xyz, alpha            out: result                  */
+    PTX_FN_DIELECTRIC_FRESNEL = 3,  /* in: VdotH, eta              out: result                  */
+    PTX_FN_SCHLICK_FRESNEL = 4,     /* in: VdotH                   out: result                  */
+    PTX_FN_EVALUATE_REFLECTION = 5, /* in: V, L, F, alpha (10)     out: result.xyz, pdf         */
+    PTX_FN_EVALUATE_REFRACTION = 6, /* in: V, L, F, alpha, eta(11) out: result.xyz, pdf         */
+    PTX_FN_SAMPLE_GGX = 7,          /* in: u.xy, V.xyz, alpha      out: result.xyz              */
+    /* BsdfTestShaderTypes.incl:13 */
+    PTX_FN_SAMPLE_LOBE_PDFS = 8,    /* in: metalness, transmission, F   out: 4 lobe weights     */
+    /* additional coverage of bsdf.glsl / common.glsl / sampling.glsl / ray.glsl */
+    PTX_FN_EVALUATE_BSDF = 9,       /* in: material(8) V L (14)    out: bsdf.xyz, pdf           */
+    PTX_FN_SAMPLE_BSDF = 10,        /* in: material(8) V rng (12)  out: dir.xyz pdf color.xyz rng (8) */
+    PTX_FN_RNG = 11,                /* in: px py w frame (as u32)  out: state0, 4 draws (5)     */
+    PTX_FN_DISK = 12,               /* in: u.xy                    out: d.xy                    */
+    PTX_FN_COS_HEMISPHERE = 13,     /* in: u.xy                    out: d.xyz                   */
+    PTX_FN_TANGENT_SPACE = 14,      /* in: n.xyz                   out: 9 (columns T,B,N)       */
+    PTX_FN_OFFSET_SELF_INTERSECTION = 15, /* in: origin.xyz normal.xyz  out: p.xyz              */
+    PTX_FN_PRIMARY_RAY = 16,        /* in: px py w h u.xy + 32 matrix floats (38)  out: o.xyz d.xyz */
+    PTX_FN_SINCOS = 17,             /* in: x                       out: sin, cos                */
+    PTX_FN_POW = 18,                /* in: x, y                    out: pow(x, y)               */
+    PTX_FN_SAMPLE_LIGHT = 19,       /* in: u.xyz pos.xyz count(u32) dirColor dirDir 2x(color pos att) (31)
+                                       out: dir.xyz dist color.xyz atten pdf (9)                 */
+    PTX_FN_SHADOW_TERMINATOR = 20,  /* in: P, (P,N)x3, bary.xyz, isRefracted (25)  out: origin.xyz */
+    PTX_FN_PRIMARY_RAY_LENS = 21,   /* in: px py w h u.xy u2.xy lensRadius focalDistance + 32 (42) out: o d */
+    PTX_FN_COUNT = 22
+} PtxTestFunction;
+
+/* Material block used by PTX_FN_EVALUATE_BSDF / PTX_FN_SAMPLE_BSDF:
+ * color.rgb, roughness, metalness, transmission, eta (7 floats + 1 pad). */
+
+PTX_API int ptx_test_input_stride(uint32_t fn);
+PTX_API int ptx_test_output_stride(uint32_t fn);
+PTX_API int ptx_test_eval(PtxRenderer *r, uint32_t fn, const float *in, float *out, uint32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTX_H */

@@ -1,0 +1,1588 @@
+/*
+ * pt_oracle.c -- CPU ORACLE for the path-tracing hot path.  TEST INFRASTRUCTURE ONLY
+ * (see pt_oracle.h for the rules, the parity pin and the arithmetic conventions).
+ *
+ * Build: oracle/Makefile  (gcc -O2 -ffp-contract=off -fopenmp).
+ */
+#include "pt_oracle.h"
+#include "pt_oracle_math.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ======================================================================== */
+/* common.glsl                                                              */
+/* ======================================================================== */
+
+/* common.glsl:12-15 */
+static inline float maxComponent(v3 rgb) { return f_max(rgb.x, f_max(rgb.y, rgb.z)); }
+
+/* common.glsl:133-141 */
+static inline uint32_t jenkinsHash(uint32_t x)
+{
+    x += x << 10;
+    x ^= x >> 6;
+    x += x << 3;
+    x ^= x >> 11;
+    x += x << 15;
+    return x;
+}
+
+/* common.glsl:143-147 -- dot(uvec2, uvec2) goes through float */
+static inline uint32_t initRng(uint32_t px, uint32_t py, uint32_t resX, uint32_t frame)
+{
+    const float d = (float)px * 1.0f + (float)py * (float)resX;
+    const uint32_t rngState = (uint32_t)d ^ jenkinsHash(frame);
+    return jenkinsHash(rngState);
+}
+
+/* common.glsl:149-152 */
+static inline float uintToFloat(uint32_t x) { return u2f(0x3f800000u | (x >> 9)) - 1.0f; }
+
+/* common.glsl:154-160 */
+static inline uint32_t xorshift(uint32_t *rngState)
+{
+    *rngState ^= *rngState << 13;
+    *rngState ^= *rngState >> 17;
+    *rngState ^= *rngState << 5;
+    return *rngState;
+}
+
+/* common.glsl:162-165 */
+static inline float rnd(uint32_t *rngState) { return uintToFloat(xorshift(rngState)); }
+
+/* common.glsl:168-184 */
+static inline v2 sampleUniformDiskConcentric(v2 u)
+{
+    v2 offset = { 2.0f * u.x - 1.0f, 2.0f * u.y - 1.0f };
+    v2 r = { 0.0f, 0.0f };
+    if (offset.x == 0.0f && offset.y == 0.0f)
+        return r;
+    float s, c;
+    if (fabsf(offset.x) > fabsf(offset.y))
+    {
+        const float theta = (PTO_PI / 4) * (offset.y / offset.x);
+        pto_sincosf(theta, &s, &c);
+        r.x = offset.x * c;
+        r.y = offset.x * s;
+    }
+    else
+    {
+        const float theta = PTO_PI / 2 - (PTO_PI / 4) * (offset.x / offset.y);
+        pto_sincosf(theta, &s, &c);
+        r.x = offset.y * c;
+        r.y = offset.y * s;
+    }
+    return r;
+}
+
+/* common.glsl:186-191 */
+static inline v3 sampleCosineHemisphere(v2 u)
+{
+    const v2 d = sampleUniformDiskConcentric(u);
+    const float z = sqrtf(1 - d.x * d.x - d.y * d.y);
+    return V3(d.x, d.y, z);
+}
+
+/* common.glsl:193-202 */
+static inline m3 computeTangentSpace(v3 normal)
+{
+    const v3 t1 = v_cross(normal, V3(1.0f, 0.0f, 0.0f));
+    const v3 t2 = v_cross(normal, V3(0.0f, 1.0f, 0.0f));
+    const v3 tangent = v_length(t1) > v_length(t2) ? t1 : t2;
+    const v3 bitangent = v_cross(normal, tangent);
+    m3 m;
+    m.c0 = v_normalize(tangent);
+    m.c1 = v_normalize(bitangent);
+    m.c2 = normal;
+    return m;
+}
+
+/* ======================================================================== */
+/* shading.glsl                                                             */
+/* ======================================================================== */
+
+/* shading.glsl:3-14 -- note the max(denom, 1): D is clamped to <= 1 (kept quirk) */
+static inline float GGXDistribution(v3 H, float alpha)
+{
+    const float Hx2 = H.x * H.x;
+    const float Hy2 = H.y * H.y;
+    const float Hz2 = H.z * H.z;
+    const float alpha2 = alpha * alpha;
+    const float b = Hx2 / alpha2 + Hy2 / alpha2 + Hz2;
+    const float denom = PTO_PI * alpha2 * (b * b);
+    return 1.0f / f_max(denom, 1.0f);
+}
+
+/* shading.glsl:16-27 */
+static inline float Lambda(v3 V, float alpha)
+{
+    const float Vx2 = V.x * V.x;
+    const float Vy2 = V.y * V.y;
+    const float Vz2 = fabsf(V.z) * fabsf(V.z);
+    const float alpha2 = alpha * alpha;
+    const float nom = sqrtf(1.0f + (alpha2 * Vx2 + alpha2 * Vy2) / Vz2) - 1.0f;
+    return nom / 2.0f;
+}
+
+/* shading.glsl:29-32 */
+static inline float GGXSmith(v3 V, float alpha) { return 1.0f / (1.0f + Lambda(V, alpha)); }
+
+/* shading.glsl:34-48 */
+static inline float DielectricFresnel(float VdotH, float eta)
+{
+    const float cosThetaI = VdotH;
+    const float sinThetaT2 = eta * eta * (1.0f - cosThetaI * cosThetaI);
+    if (sinThetaT2 > 1.0f)
+        return 1.0f;
+    const float cosThetaT = sqrtf(f_max(1.0f - sinThetaT2, 0.0f));
+    const float rs = (eta * cosThetaT - cosThetaI) / (eta * cosThetaT + cosThetaI);
+    const float rp = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
+    return (rs * rs + rp * rp) / 2.0f;
+}
+
+/* shading.glsl:50-53 -- pow(x, 5) = x2*x2*x */
+static inline float SchlickFresnel(float VdotH)
+{
+    const float x = f_clamp(1.0f - VdotH, 0.0f, 1.0f);
+    const float x2 = x * x;
+    return x2 * x2 * x;
+}
+
+/* shading.glsl:56-77 */
+static inline v3 EvaluateReflection(v3 V, v3 L, v3 F, float alpha, float *pdf)
+{
+    if (L.z < 0.00001f)
+    {
+        *pdf = 0.0f;
+        return v3s(0.0f);
+    }
+    const v3 H = v_normalize(v_add(V, L));
+    const float VdotH = v_dot(V, H);
+    const float D = GGXDistribution(H, alpha);
+    const float Gv = GGXSmith(V, alpha);
+    const float Gl = GGXSmith(L, alpha);
+    const float G = Gv * Gl;
+    const float Dv = (Gv * f_max(VdotH, 0.0f) * D) / V.z;
+    *pdf = Dv / (4.0f * VdotH);
+    return v_div(v_scale(F, D * G), 4.0f * V.z);
+}
+
+/* shading.glsl:80-108 -- pow(x, 2) = x*x */
+static inline v3 EvaluateRefraction(v3 V, v3 L, v3 F, float alpha, float eta, float *pdf)
+{
+    if (L.z > -0.00001f)
+    {
+        *pdf = 0.0f;
+        return v3s(0.0f);
+    }
+    v3 H = v_normalize(v_add(v_scale(V, eta), L));
+    if (H.z < 0.0f)
+        H = v_neg(H);
+    const float VdotH = v_dot(V, H);
+    const float LdotH = v_dot(L, H);
+    const float D = GGXDistribution(H, alpha);
+    const float Gv = GGXSmith(V, alpha);
+    const float Gl = GGXSmith(L, alpha);
+    const float G = Gv * Gl;
+    const float Dv = (Gv * fabsf(VdotH) * D) / V.z;
+    const float denominator = LdotH + eta * VdotH;
+    const float jacobian = ((eta * eta) * fabsf(LdotH)) / (denominator * denominator);
+    *pdf = Dv * jacobian;
+    return v_scale(v_scale(v_scale(F, D * G), fabsf(VdotH) / fabsf(V.z)), jacobian);
+}
+
+/* shading.glsl:111-129 */
+static inline v3 SampleGGX(v2 u, v3 V, float alpha)
+{
+    const v3 Vh = v_normalize(V3(alpha * V.x, alpha * V.y, fabsf(V.z)));
+    const float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
+    const v3 T1 = lensq > 0 ? v_scale(V3(-Vh.y, Vh.x, 0), 1.0f / sqrtf(lensq)) : V3(1, 0, 0);
+    const v3 T2 = v_cross(Vh, T1);
+    const float r = sqrtf(u.x);
+    const float phi = 2.0f * PTO_PI * u.y;
+    float sn, cs;
+    pto_sincosf(phi, &sn, &cs);
+    const float t1 = r * cs;
+    float t2 = r * sn;
+    const float s = 0.5f * (1.0f + Vh.z);
+    t2 = (1.0f - s) * sqrtf(1.0f - t1 * t1) + s * t2;
+    const v3 Nh =
+        v_add(v_add(v_scale(T1, t1), v_scale(T2, t2)), v_scale(Vh, sqrtf(f_max(0.0f, 1.0f - t1 * t1 - t2 * t2))));
+    return v_normalize(V3(alpha * Nh.x, alpha * Nh.y, f_max(0.0f, Nh.z)));
+}
+
+/* ======================================================================== */
+/* bsdf.glsl                                                                */
+/* ======================================================================== */
+
+/* ShaderRendererTypes.incl:129-140 */
+typedef struct MaterialSample
+{
+    v3 EmissiveColor;
+    v3 Color;
+    v3 Normal;
+    float Roughness;
+    float Metalness;
+    float Transmission;
+    float Eta;
+    v3 AttenuationColor;
+    float AttenuationDistance;
+} MaterialSample;
+
+typedef struct BSDFSample
+{
+    v3 Direction;
+    float Pdf;
+    v3 Color;
+} BSDFSample;
+
+typedef struct LobePdfs
+{
+    float Diffuse, Glossy, Metallic, Transmissive;
+} LobePdfs;
+
+/* bsdf.glsl:11-15 */
+static inline v3 evaluateDiffuseBRDF(const MaterialSample *m, v3 V, v3 L, float *pdf)
+{
+    (void)V;
+    *pdf = L.z * 1.0f / PTO_PI;
+    return v_div(v_scale(m->Color, L.z), PTO_PI);
+}
+
+/* bsdf.glsl:22-25 */
+static inline v3 evaluateGlossyBSDF(const MaterialSample *m, v3 V, v3 L, float *pdf)
+{
+    return EvaluateReflection(V, L, v3s(1.0f), m->Roughness * m->Roughness, pdf);
+}
+
+/* bsdf.glsl:32-37 */
+static inline v3 evaluateMetallicBRDF(const MaterialSample *m, v3 V, v3 L, float *pdf)
+{
+    const v3 H = v_normalize(v_add(V, L));
+    const v3 F0 = v_mix(m->Color, v3s(1.0f), SchlickFresnel(v_dot(V, H)));
+    return EvaluateReflection(V, L, F0, m->Roughness * m->Roughness, pdf);
+}
+
+/* bsdf.glsl:44-47 */
+static inline v3 evaluateBTDF(const MaterialSample *m, v3 V, v3 L, float *pdf)
+{
+    return EvaluateRefraction(V, L, m->Color, m->Roughness * m->Roughness, m->Eta, pdf);
+}
+
+/* bsdf.glsl:62-70 */
+static inline LobePdfs sampleLobePdfs(const MaterialSample *m, float F)
+{
+    LobePdfs p;
+    p.Diffuse = (1.0f - m->Metalness) * (1.0f - F) * (1.0f - m->Transmission);
+    p.Glossy = (1.0f - m->Metalness) * F;
+    p.Metallic = m->Metalness;
+    p.Transmissive = (1.0f - m->Metalness) * (1.0f - F) * m->Transmission;
+    return p;
+}
+
+/* bsdf.glsl:72-103 */
+static inline v3 evaluateBSDF(const MaterialSample *m, v3 V, v3 L, float *outPdf)
+{
+    const int isReflection = L.z > 0.0f;
+    const v3 H = isReflection ? v_normalize(v_add(V, L)) : v_normalize(v_add(v_scale(V, m->Eta), L));
+    const float FD = DielectricFresnel(fabsf(v_dot(V, H)), m->Eta);
+    const LobePdfs pdfs = sampleLobePdfs(m, FD);
+
+    v3 bsdf = v3s(0.0f);
+    *outPdf = 0.0f;
+    float pdf;
+    if (isReflection)
+    {
+        bsdf = v_add(bsdf, v_scale(evaluateDiffuseBRDF(m, V, L, &pdf), pdfs.Diffuse));
+        *outPdf += pdf * pdfs.Diffuse;
+        bsdf = v_add(bsdf, v_scale(evaluateGlossyBSDF(m, V, L, &pdf), pdfs.Glossy));
+        *outPdf += pdf * pdfs.Glossy;
+        bsdf = v_add(bsdf, v_scale(evaluateMetallicBRDF(m, V, L, &pdf), pdfs.Metallic));
+        *outPdf += pdf * pdfs.Metallic;
+    }
+    else
+    {
+        bsdf = v_add(bsdf, v_scale(evaluateBTDF(m, V, L, &pdf), pdfs.Transmissive));
+        *outPdf += pdf * pdfs.Transmissive;
+    }
+    return bsdf;
+}
+
+/* bsdf.glsl:105-132 -- nested conditional draws; the draw order is part of the contract */
+static inline BSDFSample sampleBSDF(const MaterialSample *m, v3 V, uint32_t *rngState)
+{
+    const float alpha = m->Roughness * m->Roughness;
+    v2 u;
+    u.x = rnd(rngState);
+    u.y = rnd(rngState);
+    const v3 H = SampleGGX(u, V, alpha);
+    const float FD = DielectricFresnel(fabsf(v_dot(V, H)), m->Eta);
+
+    v3 L;
+    if (rnd(rngState) < m->Metalness)
+        L = v_normalize(v_reflect(v_neg(V), H)); /* bsdf.glsl:39-42 */
+    else
+    {
+        if (rnd(rngState) < FD)
+            L = v_normalize(v_reflect(v_neg(V), H)); /* bsdf.glsl:27-30 */
+        else
+        {
+            if (rnd(rngState) < m->Transmission)
+                L = v_normalize(v_refract(v_neg(V), H, m->Eta)); /* bsdf.glsl:49-52 */
+            else
+            {
+                v2 u2;
+                u2.x = rnd(rngState);
+                u2.y = rnd(rngState);
+                L = sampleCosineHemisphere(u2); /* bsdf.glsl:17-20 */
+            }
+        }
+    }
+
+    BSDFSample ret;
+    ret.Direction = L;
+    ret.Color = evaluateBSDF(m, V, L, &ret.Pdf);
+    return ret;
+}
+
+/* ======================================================================== */
+/* ray.glsl                                                                 */
+/* ======================================================================== */
+
+typedef struct Ray
+{
+    v3 Origin;
+    float tmin;
+    v3 Direction;
+    float tmax;
+} Ray;
+
+/* ray.glsl:58-85 (pinhole).  rx/ry offset rays feed only textureGrad and are not
+ * produced here. */
+static inline Ray constructPrimaryRay(uint32_t px, uint32_t py, uint32_t resX, uint32_t resY, const float *ViewInverse,
+                                      const float *ProjInverse, v2 u)
+{
+    const float pcx = (float)px + u.x;
+    const float pcy = (float)py + u.y;
+    const float inUVx = pcx / (float)resX;
+    const float inUVy = pcy / (float)resY;
+    const float dx = inUVx * 2.0f - 1.0f;
+    const float dy = inUVy * 2.0f - 1.0f;
+
+    const v4 origin = m4_mul(ViewInverse, 0, 0, 0, 1);
+    const v4 target = m4_mul(ProjInverse, dx, dy, 1, 1);
+    const v3 nt = v_normalize(V3(target.x, target.y, target.z));
+    const v4 direction = m4_mul(ViewInverse, nt.x, nt.y, nt.z, 0);
+
+    Ray r;
+    r.Origin = V3(origin.x, origin.y, origin.z);
+    r.tmin = 0.00001f;
+    r.Direction = V3(direction.x, direction.y, direction.z);
+    r.tmax = 10000.0f;
+    return r;
+}
+
+/* ray.glsl:16-56 (thin lens) */
+static inline Ray constructPrimaryRayLens(uint32_t px, uint32_t py, uint32_t resX, uint32_t resY,
+                                          const float *ViewInverse, const float *ProjInverse, v2 u, v2 u2,
+                                          float lensRadius, float focalDistance)
+{
+    const float pcx = (float)px + u.x;
+    const float pcy = (float)py + u.y;
+    const v2 disk = sampleUniformDiskConcentric(u2);
+    const v2 pLens = { lensRadius * disk.x, lensRadius * disk.y };
+    const float inUVx = pcx / (float)resX;
+    const float inUVy = pcy / (float)resY;
+    const float dx = inUVx * 2.0f - 1.0f;
+    const float dy = inUVy * 2.0f - 1.0f;
+
+    const v3 originCameraSpace = V3(pLens.x, pLens.y, 0);
+    const v4 origin = m4_mul(ViewInverse, originCameraSpace.x, originCameraSpace.y, originCameraSpace.z, 1);
+    const v4 target = m4_mul(ProjInverse, dx, dy, 1, 1);
+    const float ft = focalDistance / target.z;
+    const v3 pFocus = v_scale(V3(target.x, target.y, target.z), ft);
+    const v3 nd = v_normalize(v_sub(pFocus, originCameraSpace));
+    const v4 direction = m4_mul(ViewInverse, nd.x, nd.y, nd.z, 0);
+
+    Ray r;
+    r.Origin = V3(origin.x, origin.y, origin.z);
+    r.tmin = 0.00001f;
+    r.Direction = V3(direction.x, direction.y, direction.z);
+    r.tmax = 10000.0f;
+    return r;
+}
+
+/* ray.glsl:93-106 (Waechter-Binder) */
+static inline float offsetComponent(float o, float n)
+{
+    const float origin_const = 1.0f / 32.0f;
+    const float float_scale = 1.0f / 65536.0f;
+    const float int_scale = 256.0f;
+    const int32_t of_i = (int32_t)(int_scale * n);
+    const uint32_t bits = f2u(o) + (uint32_t)((o < 0) ? -of_i : of_i);
+    const float p_i = u2f(bits);
+    return (fabsf(o) < origin_const) ? o + float_scale * n : p_i;
+}
+static inline v3 offsetRayOriginSelfIntersection(v3 origin, v3 normal)
+{
+    return V3(offsetComponent(origin.x, normal.x), offsetComponent(origin.y, normal.y),
+              offsetComponent(origin.z, normal.z));
+}
+
+typedef struct Vtx
+{
+    v3 Position;
+    v2 TexCoords;
+    v3 Normal, Tangent, Bitangent;
+} Vtx;
+
+/* ray.glsl:109-131 (Hanika shadow terminator) */
+static inline v3 offsetRayOriginShadowTerminator(const Vtx *vertex, const Vtx *v0, const Vtx *v1, const Vtx *v2,
+                                                 v3 bary, int isRefracted)
+{
+    v3 tmpu = v_sub(vertex->Position, v0->Position);
+    v3 tmpv = v_sub(vertex->Position, v1->Position);
+    v3 tmpw = v_sub(vertex->Position, v2->Position);
+    v3 n0 = v0->Normal, n1 = v1->Normal, n2 = v2->Normal;
+    if (isRefracted)
+    {
+        n0 = v_neg(n0);
+        n1 = v_neg(n1);
+        n2 = v_neg(n2);
+    }
+    const float dotu = f_min(0.0f, v_dot(tmpu, n0));
+    const float dotv = f_min(0.0f, v_dot(tmpv, n1));
+    const float dotw = f_min(0.0f, v_dot(tmpw, n2));
+    tmpu = v_sub(tmpu, v_scale(n0, dotu));
+    tmpv = v_sub(tmpv, v_scale(n1, dotv));
+    tmpw = v_sub(tmpw, v_scale(n2, dotw));
+    return v_add(v_add(v_add(vertex->Position, v_scale(tmpu, bary.x)), v_scale(tmpv, bary.y)), v_scale(tmpw, bary.z));
+}
+
+/* ======================================================================== */
+/* sampling.glsl                                                            */
+/* ======================================================================== */
+
+typedef struct LightSample
+{
+    v3 Direction;
+    float Distance;
+    v3 Color;
+    float Attenuation;
+} LightSample;
+
+/* sampling.glsl:25-56 */
+static inline LightSample sampleLight(const PtxLightsUbo *ubo, v3 u, v3 position, float *pdf)
+{
+    const uint32_t lightCount = ubo->LightCount;
+    const uint32_t lightIndex = (uint32_t)(u.x * (float)(lightCount + 1));
+    *pdf = 1.0f / (float)(lightCount + 1);
+    LightSample ret;
+    v2 uyz = { u.y, u.z };
+
+    if (lightIndex >= lightCount)
+    {
+        const v2 d2 = sampleUniformDiskConcentric(uyz);
+        const v3 diskPoint = v_scale(V3(d2.x, d2.y, 0.0f), 0.001f);
+        const v3 direction =
+            v_normalize(V3(ubo->Directional.Direction[0], ubo->Directional.Direction[1], ubo->Directional.Direction[2]));
+        ret.Direction = v_normalize(v_add(direction, m3_mul(computeTangentSpace(direction), diskPoint)));
+        ret.Color = V3(ubo->Directional.Color[0], ubo->Directional.Color[1], ubo->Directional.Color[2]);
+        ret.Distance = 100000.0f; /* sampling.glsl:3 */
+        ret.Attenuation = 1.0f;
+        return ret;
+    }
+
+    const PtxPointLight *light = &ubo->Lights[lightIndex];
+    const v3 lpos = V3(light->Position[0], light->Position[1], light->Position[2]);
+    const v2 d2 = sampleUniformDiskConcentric(uyz);
+    const v3 diskPoint = v_scale(V3(d2.x, d2.y, 0.0f), 0.1f);
+    const v3 direction = v_normalize(v_sub(position, lpos));
+    const v3 newPosition = v_add(lpos, m3_mul(computeTangentSpace(direction), diskPoint));
+
+    ret.Distance = v_length(v_sub(position, newPosition));
+    ret.Direction = v_normalize(v_sub(position, newPosition));
+    ret.Color = V3(light->Color[0], light->Color[1], light->Color[2]);
+    const float attenuation = 1.0f / (light->AttenuationConstant + ret.Distance * light->AttenuationLinear +
+                                      ret.Distance * ret.Distance * light->AttenuationQuadratic);
+    ret.Attenuation = f_clamp(attenuation, 0.0f, 1.0f);
+    return ret;
+}
+
+/* ======================================================================== */
+/* Scene: flattened world-space triangles (stand-in for BLAS/TLAS)          */
+/* ======================================================================== */
+
+typedef struct Pair /* one (instance, mesh) */
+{
+    float M[12];   /* A_instance * A_mesh, 3 rows x 4 (sampling.glsl:5-15 derivation) */
+    m3 Rinv;       /* inverse of the linear part, for the normal transform             */
+    uint32_t vertexOffset, indexOffset, materialId, firstTri;
+} Pair;
+
+typedef struct BvhNode
+{
+    float lo[3], hi[3];
+    uint32_t left;  /* internal: left child index, right = left + 1; leaf: first tri slot */
+    uint32_t count; /* 0 = internal                                                       */
+} BvhNode;
+
+struct PtoScene
+{
+    PtxSceneDesc d; /* deep copies */
+    Pair *pairs;
+    uint32_t pairCount;
+    uint64_t triCount;
+    float *v0, *e1, *e2; /* 3 floats per triangle, world space */
+    uint32_t *triPair, *triPrim;
+    BvhNode *nodes;
+    uint32_t nodeCount;
+    uint32_t *bvhTris; /* triangle ids in leaf order */
+};
+
+static void *dupmem(const void *p, size_t n)
+{
+    if (!n)
+        return NULL;
+    void *q = malloc(n);
+    memcpy(q, p, n);
+    return q;
+}
+
+/* world = A_instance * A_mesh * x (sampling.glsl:7) */
+static void composeTransform(const float *Ai, const float *Am, float *M)
+{
+    for (int r = 0; r < 3; r++)
+    {
+        for (int c = 0; c < 3; c++)
+            M[r * 4 + c] = (Ai[r * 4 + 0] * Am[0 * 4 + c] + Ai[r * 4 + 1] * Am[1 * 4 + c]) + Ai[r * 4 + 2] * Am[2 * 4 + c];
+        M[r * 4 + 3] =
+            ((Ai[r * 4 + 0] * Am[0 * 4 + 3] + Ai[r * 4 + 1] * Am[1 * 4 + 3]) + Ai[r * 4 + 2] * Am[2 * 4 + 3]) + Ai[r * 4 + 3];
+    }
+}
+
+static inline v3 xformPoint(const float *M, v3 p)
+{
+    return V3(((p.x * M[0] + p.y * M[1]) + p.z * M[2]) + M[3], ((p.x * M[4] + p.y * M[5]) + p.z * M[6]) + M[7],
+              ((p.x * M[8] + p.y * M[9]) + p.z * M[10]) + M[11]);
+}
+static inline v3 xformVector(const float *M, v3 p)
+{
+    return V3((p.x * M[0] + p.y * M[1]) + p.z * M[2], (p.x * M[4] + p.y * M[5]) + p.z * M[6],
+              (p.x * M[8] + p.y * M[9]) + p.z * M[10]);
+}
+
+static void buildBvh(PtoScene *s);
+
+PtoScene *pto_scene_create(const PtxSceneDesc *desc, int wantBvh)
+{
+    PtoScene *s = (PtoScene *)calloc(1, sizeof(PtoScene));
+    s->d = *desc;
+    s->d.vertices = (const PtxVertex *)dupmem(desc->vertices, desc->vertexCount * sizeof(PtxVertex));
+    s->d.indices = (const uint32_t *)dupmem(desc->indices, desc->indexCount * 4);
+    s->d.transforms = (const PtxTransform *)dupmem(desc->transforms, desc->transformCount * sizeof(PtxTransform));
+    s->d.geometries = (const PtxGeometry *)dupmem(desc->geometries, desc->geometryCount * sizeof(PtxGeometry));
+    s->d.metallicRoughnessMaterials = (const PtxMetallicRoughnessMaterial *)dupmem(
+        desc->metallicRoughnessMaterials, desc->metallicRoughnessMaterialCount * sizeof(PtxMetallicRoughnessMaterial));
+    s->d.specularGlossinessMaterials = (const PtxSpecularGlossinessMaterial *)dupmem(
+        desc->specularGlossinessMaterials, desc->specularGlossinessMaterialCount * sizeof(PtxSpecularGlossinessMaterial));
+    s->d.phongMaterials =
+        (const PtxPhongMaterial *)dupmem(desc->phongMaterials, desc->phongMaterialCount * sizeof(PtxPhongMaterial));
+    s->d.meshes = (const PtxMeshRecord *)dupmem(desc->meshes, desc->meshCount * sizeof(PtxMeshRecord));
+    s->d.models = (const PtxModel *)dupmem(desc->models, desc->modelCount * sizeof(PtxModel));
+    s->d.instances = (const PtxModelInstance *)dupmem(desc->instances, desc->instanceCount * sizeof(PtxModelInstance));
+
+    /* pairs in instance-then-mesh order; global triangle id = running primitive count */
+    uint32_t pairCount = 0;
+    uint64_t triCount = 0;
+    for (uint32_t i = 0; i < desc->instanceCount; i++)
+    {
+        const PtxModel *m = &desc->models[desc->instances[i].ModelIndex];
+        pairCount += m->MeshCount;
+        for (uint32_t k = 0; k < m->MeshCount; k++)
+            triCount += desc->geometries[desc->meshes[m->MeshOffset + k].GeometryIndex].IndexLength / 3;
+    }
+    s->pairCount = pairCount;
+    s->triCount = triCount;
+    s->pairs = (Pair *)calloc(pairCount ? pairCount : 1, sizeof(Pair));
+    s->v0 = (float *)malloc((triCount ? triCount : 1) * 12);
+    s->e1 = (float *)malloc((triCount ? triCount : 1) * 12);
+    s->e2 = (float *)malloc((triCount ? triCount : 1) * 12);
+    s->triPair = (uint32_t *)malloc((triCount ? triCount : 1) * 4);
+    s->triPrim = (uint32_t *)malloc((triCount ? triCount : 1) * 4);
+
+    uint32_t p = 0;
+    uint64_t t = 0;
+    for (uint32_t i = 0; i < desc->instanceCount; i++)
+    {
+        const PtxModelInstance *inst = &desc->instances[i];
+        const PtxModel *m = &desc->models[inst->ModelIndex];
+        for (uint32_t k = 0; k < m->MeshCount; k++, p++)
+        {
+            const PtxMeshRecord *rec = &desc->meshes[m->MeshOffset + k];
+            const PtxGeometry *g = &desc->geometries[rec->GeometryIndex];
+            Pair *pr = &s->pairs[p];
+            composeTransform(inst->Transform.m, desc->transforms[rec->TransformIndex].m, pr->M);
+            m3 R;
+            R.c0 = V3(pr->M[0], pr->M[4], pr->M[8]);
+            R.c1 = V3(pr->M[1], pr->M[5], pr->M[9]);
+            R.c2 = V3(pr->M[2], pr->M[6], pr->M[10]);
+            pr->Rinv = m3_inverse(R);
+            pr->vertexOffset = g->VertexOffset;
+            pr->indexOffset = g->IndexOffset;
+            pr->materialId = rec->MaterialId;
+            pr->firstTri = (uint32_t)t;
+            const uint32_t nprim = g->IndexLength / 3;
+            for (uint32_t q = 0; q < nprim; q++, t++)
+            {
+                v3 w[3];
+                for (int c = 0; c < 3; c++)
+                {
+                    const uint32_t idx = desc->indices[g->IndexOffset + q * 3 + c];
+                    const PtxVertex *vx = &desc->vertices[g->VertexOffset + idx];
+                    w[c] = xformPoint(pr->M, V3(vx->Position[0], vx->Position[1], vx->Position[2]));
+                }
+                const v3 a = v_sub(w[1], w[0]), b = v_sub(w[2], w[0]);
+                s->v0[t * 3 + 0] = w[0].x; s->v0[t * 3 + 1] = w[0].y; s->v0[t * 3 + 2] = w[0].z;
+                s->e1[t * 3 + 0] = a.x; s->e1[t * 3 + 1] = a.y; s->e1[t * 3 + 2] = a.z;
+                s->e2[t * 3 + 0] = b.x; s->e2[t * 3 + 1] = b.y; s->e2[t * 3 + 2] = b.z;
+                s->triPair[t] = p;
+                s->triPrim[t] = q;
+            }
+        }
+    }
+    if (wantBvh && triCount)
+        buildBvh(s);
+    return s;
+}
+
+void pto_scene_destroy(PtoScene *s)
+{
+    if (!s)
+        return;
+    free((void *)s->d.vertices); free((void *)s->d.indices); free((void *)s->d.transforms);
+    free((void *)s->d.geometries); free((void *)s->d.metallicRoughnessMaterials);
+    free((void *)s->d.specularGlossinessMaterials); free((void *)s->d.phongMaterials);
+    free((void *)s->d.meshes); free((void *)s->d.models); free((void *)s->d.instances);
+    free(s->pairs); free(s->v0); free(s->e1); free(s->e2); free(s->triPair); free(s->triPrim);
+    free(s->nodes); free(s->bvhTris);
+    free(s);
+}
+
+uint64_t pto_scene_triangle_count(const PtoScene *s) { return s->triCount; }
+
+/* ======================================================================== */
+/* Ray / triangle (Moeller-Trumbore on v0,e1,e2) and the two queries        */
+/* ======================================================================== */
+
+/* The driver's ray-triangle test is unspecified; this is the fixed stand-in used by
+ * both the oracle and the HIP kernels.  Hit iff det != 0, 0<=u<=1, v>=0, u+v<=1 and
+ * tmin < t < tmax.  Returns barycentrics in Vulkan's hitAttribute convention. */
+static inline int intersectTri(const float *v0, const float *e1, const float *e2, v3 o, v3 d, float tmin, float tmax,
+                               float *t, float *u, float *v)
+{
+    const v3 E1 = V3(e1[0], e1[1], e1[2]), E2 = V3(e2[0], e2[1], e2[2]);
+    const v3 pvec = v_cross(d, E2);
+    const float det = v_dot(E1, pvec);
+    if (!(det != 0.0f))
+        return 0;
+    const float inv = 1.0f / det;
+    const v3 tvec = v_sub(o, V3(v0[0], v0[1], v0[2]));
+    const float uu = v_dot(tvec, pvec) * inv;
+    if (!(uu >= 0.0f && uu <= 1.0f))
+        return 0;
+    const v3 qvec = v_cross(tvec, E1);
+    const float vv = v_dot(d, qvec) * inv;
+    if (!(vv >= 0.0f && uu + vv <= 1.0f))
+        return 0;
+    const float tt = v_dot(E2, qvec) * inv;
+    if (!(tt > tmin && tt < tmax))
+        return 0;
+    *t = tt;
+    *u = uu;
+    *v = vv;
+    return 1;
+}
+
+/* closest hit: min t, ties broken by the smaller global triangle id */
+static inline void considerTri(const PtoScene *s, uint32_t tri, v3 o, v3 d, float tmin, float tmax, PtoHit *best)
+{
+    float t, u, v;
+    const float lim = best->tri == 0xffffffffu ? tmax : best->t;
+    /* accept t == best.t only for a smaller id: test against nextafter(lim) via <= below */
+    if (!intersectTri(&s->v0[tri * 3], &s->e1[tri * 3], &s->e2[tri * 3], o, d, tmin, tmax, &t, &u, &v))
+        return;
+    if (best->tri == 0xffffffffu || t < lim || (t == lim && tri < best->tri))
+    {
+        best->t = t;
+        best->u = u;
+        best->v = v;
+        best->tri = tri;
+    }
+}
+
+/* ---- binned-SAH BVH (CPU baseline accelerator) ---- */
+
+typedef struct BuildCtx
+{
+    PtoScene *s;
+    float *blo, *bhi, *cen; /* per-triangle bounds and centroid */
+    uint32_t *ids;
+    uint32_t nodeCap;
+} BuildCtx;
+
+static void triBounds(const PtoScene *s, uint32_t t, float *lo, float *hi)
+{
+    for (int a = 0; a < 3; a++)
+    {
+        const float p0 = s->v0[t * 3 + a], p1 = p0 + s->e1[t * 3 + a], p2 = p0 + s->e2[t * 3 + a];
+        float l = f_min(p0, f_min(p1, p2)), h = f_max(p0, f_max(p1, p2));
+        /* conservative padding so the slab test can never reject a ray the triangle test accepts */
+        const float pad = 1e-5f * f_max(fabsf(l), fabsf(h)) + 1e-7f;
+        lo[a] = l - pad;
+        hi[a] = h + pad;
+    }
+}
+
+static float areaOf(const float *lo, const float *hi)
+{
+    const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+static void buildRec(BuildCtx *c, uint32_t node, uint32_t first, uint32_t count)
+{
+    PtoScene *s = c->s;
+    BvhNode *n = &s->nodes[node];
+    float clo[3] = { 1e30f, 1e30f, 1e30f }, chi[3] = { -1e30f, -1e30f, -1e30f };
+    for (int a = 0; a < 3; a++)
+    {
+        n->lo[a] = 1e30f;
+        n->hi[a] = -1e30f;
+    }
+    for (uint32_t i = first; i < first + count; i++)
+    {
+        const uint32_t t = c->ids[i];
+        for (int a = 0; a < 3; a++)
+        {
+            n->lo[a] = f_min(n->lo[a], c->blo[t * 3 + a]);
+            n->hi[a] = f_max(n->hi[a], c->bhi[t * 3 + a]);
+            clo[a] = f_min(clo[a], c->cen[t * 3 + a]);
+            chi[a] = f_max(chi[a], c->cen[t * 3 + a]);
+        }
+    }
+    if (count <= 4)
+    {
+        n->left = first;
+        n->count = count;
+        return;
+    }
+    enum { NB = 16 };
+    int bestAxis = -1, bestSplit = 0;
+    float bestCost = 1e30f;
+    for (int a = 0; a < 3; a++)
+    {
+        const float ext = chi[a] - clo[a];
+        if (!(ext > 0.0f))
+            continue;
+        uint32_t cnt[NB] = { 0 };
+        float lo[NB][3], hi[NB][3];
+        for (int b = 0; b < NB; b++)
+            for (int k = 0; k < 3; k++)
+            {
+                lo[b][k] = 1e30f;
+                hi[b][k] = -1e30f;
+            }
+        const float sc = (float)NB / ext;
+        for (uint32_t i = first; i < first + count; i++)
+        {
+            const uint32_t t = c->ids[i];
+            int b = (int)((c->cen[t * 3 + a] - clo[a]) * sc);
+            if (b >= NB) b = NB - 1;
+            if (b < 0) b = 0;
+            cnt[b]++;
+            for (int k = 0; k < 3; k++)
+            {
+                lo[b][k] = f_min(lo[b][k], c->blo[t * 3 + k]);
+                hi[b][k] = f_max(hi[b][k], c->bhi[t * 3 + k]);
+            }
+        }
+        float rightArea[NB];
+        uint32_t rightCnt[NB];
+        float rl[3] = { 1e30f, 1e30f, 1e30f }, rh[3] = { -1e30f, -1e30f, -1e30f };
+        uint32_t rc = 0;
+        for (int b = NB - 1; b > 0; b--)
+        {
+            for (int k = 0; k < 3; k++)
+            {
+                rl[k] = f_min(rl[k], lo[b][k]);
+                rh[k] = f_max(rh[k], hi[b][k]);
+            }
+            rc += cnt[b];
+            rightArea[b] = rc ? areaOf(rl, rh) : 0.0f;
+            rightCnt[b] = rc;
+        }
+        float ll[3] = { 1e30f, 1e30f, 1e30f }, lh[3] = { -1e30f, -1e30f, -1e30f };
+        uint32_t lc = 0;
+        for (int b = 0; b < NB - 1; b++)
+        {
+            for (int k = 0; k < 3; k++)
+            {
+                ll[k] = f_min(ll[k], lo[b][k]);
+                lh[k] = f_max(lh[k], hi[b][k]);
+            }
+            lc += cnt[b];
+            if (!lc || !rightCnt[b + 1])
+                continue;
+            const float cost = areaOf(ll, lh) * (float)lc + rightArea[b + 1] * (float)rightCnt[b + 1];
+            if (cost < bestCost)
+            {
+                bestCost = cost;
+                bestAxis = a;
+                bestSplit = b;
+            }
+        }
+    }
+    uint32_t mid;
+    if (bestAxis < 0)
+        mid = first + count / 2; /* all centroids coincide: split in the middle */
+    else
+    {
+        const float ext = chi[bestAxis] - clo[bestAxis];
+        const float sc = (float)NB / ext;
+        uint32_t i = first, j = first + count;
+        while (i < j)
+        {
+            const uint32_t t = c->ids[i];
+            int b = (int)((c->cen[t * 3 + bestAxis] - clo[bestAxis]) * sc);
+            if (b >= NB) b = NB - 1;
+            if (b < 0) b = 0;
+            if (b <= bestSplit)
+                i++;
+            else
+            {
+                j--;
+                c->ids[i] = c->ids[j];
+                c->ids[j] = t;
+            }
+        }
+        mid = i;
+        if (mid == first || mid == first + count)
+            mid = first + count / 2;
+    }
+    const uint32_t l = s->nodeCount;
+    s->nodeCount += 2;
+    n = &s->nodes[node]; /* (nodes is preallocated; pointer stays valid) */
+    n->left = l;
+    n->count = 0;
+    buildRec(c, l, first, mid - first);
+    buildRec(c, l + 1, mid, first + count - mid);
+}
+
+static void buildBvh(PtoScene *s)
+{
+    const uint32_t n = (uint32_t)s->triCount;
+    BuildCtx c;
+    c.s = s;
+    c.blo = (float *)malloc((size_t)n * 12);
+    c.bhi = (float *)malloc((size_t)n * 12);
+    c.cen = (float *)malloc((size_t)n * 12);
+    c.ids = (uint32_t *)malloc((size_t)n * 4);
+    for (uint32_t t = 0; t < n; t++)
+    {
+        triBounds(s, t, &c.blo[t * 3], &c.bhi[t * 3]);
+        for (int a = 0; a < 3; a++)
+            c.cen[t * 3 + a] = 0.5f * (c.blo[t * 3 + a] + c.bhi[t * 3 + a]);
+        c.ids[t] = t;
+    }
+    s->nodes = (BvhNode *)malloc((size_t)(2 * n + 2) * sizeof(BvhNode));
+    s->nodeCount = 1;
+    buildRec(&c, 0, 0, n);
+    s->bvhTris = c.ids;
+    free(c.blo);
+    free(c.bhi);
+    free(c.cen);
+}
+
+static inline int slab(const BvhNode *n, v3 o, v3 id, float tmin, float tmax, float *tnear)
+{
+    float t0 = (n->lo[0] - o.x) * id.x, t1 = (n->hi[0] - o.x) * id.x;
+    float lo = fminf(t0, t1), hi = fmaxf(t0, t1);
+    t0 = (n->lo[1] - o.y) * id.y;
+    t1 = (n->hi[1] - o.y) * id.y;
+    lo = fmaxf(lo, fminf(t0, t1));
+    hi = fminf(hi, fmaxf(t0, t1));
+    t0 = (n->lo[2] - o.z) * id.z;
+    t1 = (n->hi[2] - o.z) * id.z;
+    lo = fmaxf(lo, fminf(t0, t1));
+    hi = fminf(hi, fmaxf(t0, t1));
+    lo = fmaxf(lo, tmin);
+    hi = fminf(hi, tmax);
+    *tnear = lo;
+    return lo <= hi * 1.0000004f;
+}
+
+static PtoHit traceClosest(const PtoScene *s, v3 o, v3 d, float tmin, float tmax, int brute, PtoStats *st)
+{
+    PtoHit best;
+    best.t = tmax;
+    best.u = best.v = 0.0f;
+    best.tri = 0xffffffffu;
+    if (brute || !s->nodes)
+    {
+        for (uint32_t t = 0; t < s->triCount; t++)
+            considerTri(s, t, o, d, tmin, tmax, &best);
+        if (st)
+            st->trisTested += s->triCount;
+        return best;
+    }
+    const v3 id = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    uint32_t stack[128];
+    int sp = 0;
+    stack[sp++] = 0;
+    while (sp)
+    {
+        const BvhNode *n = &s->nodes[stack[--sp]];
+        float tn;
+        /* <= on the current best so equal-t candidates are still visited (id tie-break) */
+        if (!slab(n, o, id, tmin, best.tri == 0xffffffffu ? tmax : best.t, &tn))
+            continue;
+        if (st)
+            st->nodesVisited++;
+        if (n->count)
+        {
+            for (uint32_t i = 0; i < n->count; i++)
+                considerTri(s, s->bvhTris[n->left + i], o, d, tmin, tmax, &best);
+            if (st)
+                st->trisTested += n->count;
+        }
+        else
+        {
+            stack[sp++] = n->left;
+            stack[sp++] = n->left + 1;
+        }
+    }
+    return best;
+}
+
+static int traceAny(const PtoScene *s, v3 o, v3 d, float tmin, float tmax, int brute, PtoStats *st)
+{
+    float t, u, v;
+    if (brute || !s->nodes)
+    {
+        for (uint32_t i = 0; i < s->triCount; i++)
+            if (intersectTri(&s->v0[i * 3], &s->e1[i * 3], &s->e2[i * 3], o, d, tmin, tmax, &t, &u, &v))
+                return 1;
+        return 0;
+    }
+    const v3 id = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    uint32_t stack[128];
+    int sp = 0;
+    stack[sp++] = 0;
+    while (sp)
+    {
+        const BvhNode *n = &s->nodes[stack[--sp]];
+        float tn;
+        if (!slab(n, o, id, tmin, tmax, &tn))
+            continue;
+        if (st)
+            st->nodesVisited++;
+        if (n->count)
+        {
+            for (uint32_t i = 0; i < n->count; i++)
+            {
+                const uint32_t tr = s->bvhTris[n->left + i];
+                if (intersectTri(&s->v0[tr * 3], &s->e1[tr * 3], &s->e2[tr * 3], o, d, tmin, tmax, &t, &u, &v))
+                    return 1;
+            }
+        }
+        else
+        {
+            stack[sp++] = n->left;
+            stack[sp++] = n->left + 1;
+        }
+    }
+    return 0;
+}
+
+void pto_trace_closest(const PtoScene *s, const float *rays, uint32_t n, PtoHit *hits, int brute)
+{
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < (int64_t)n; i++)
+    {
+        const float *r = &rays[i * 8];
+        hits[i] = traceClosest(s, V3(r[0], r[1], r[2]), V3(r[4], r[5], r[6]), r[3], r[7], brute, NULL);
+    }
+}
+
+void pto_trace_any(const PtoScene *s, const float *rays, uint32_t n, uint32_t *occluded, int brute)
+{
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < (int64_t)n; i++)
+    {
+        const float *r = &rays[i * 8];
+        occluded[i] = (uint32_t)traceAny(s, V3(r[0], r[1], r[2]), V3(r[4], r[5], r[6]), r[3], r[7], brute, NULL);
+    }
+}
+
+/* ======================================================================== */
+/* material.glsl with the 1x1 default textures                              */
+/* ======================================================================== */
+
+/* Texels of the fixed slots 0..8 after format decode (ShaderRendererTypes.incl:49-56,
+ * formats TextureUploader.cpp:571-594: Color/Specular/Emissive sRGB, others UNORM).
+ * Scene textures (index >= 9) are the next row N1; until then they sample as the white
+ * placeholder, like a texture that has not finished loading (Renderer.cpp:421-429). */
+static inline v4 sampleTexture(uint32_t idx)
+{
+    v4 w = { 1.0f, 1.0f, 1.0f, 1.0f };
+    switch (idx)
+    {
+    case PTX_DEFAULT_NORMAL_TEXTURE_INDEX: /* 0xffff8080 UNORM */
+        w.x = 128.0f / 255.0f;
+        w.y = 128.0f / 255.0f;
+        return w;
+    case PTX_DEFAULT_EMISSIVE_TEXTURE_INDEX: /* 0x00000000 */
+    case PTX_DEFAULT_GLOSSINESS_TEXTURE_INDEX:
+    case PTX_DEFAULT_SHININESS_TEXTURE_INDEX:
+        w.x = w.y = w.z = w.w = 0.0f;
+        return w;
+    default:
+        return w;
+    }
+}
+
+/* material.glsl:55-60 */
+static inline v3 ReconstructNormalFromXY(v3 n)
+{
+    n = V3(2.0f * n.x - 1.0f, 2.0f * n.y - 1.0f, 2.0f * n.z - 1.0f);
+    return V3(n.x, n.y, sqrtf(f_max(1 - n.x * n.x - n.y * n.y, 0.0f)));
+}
+
+static inline v3 rgb(v4 t) { return V3(t.x, t.y, t.z); }
+
+/* material.glsl:144-171 dispatching to :62-142 */
+static MaterialSample sampleMaterial(const PtoScene *s, uint32_t materialId, int isHitFromInside, int flipNormalY)
+{
+    const uint32_t materialType = materialId & 0xffu; /* ShaderTypes.incl:164-168 */
+    const uint32_t materialIndex = materialId >> 8;
+    MaterialSample ret;
+    memset(&ret, 0, sizeof(ret));
+    switch (materialType)
+    {
+    case PTX_MATERIAL_TYPE_METALLIC_ROUGHNESS: {
+        const PtxMetallicRoughnessMaterial *m = &s->d.metallicRoughnessMaterials[materialIndex];
+        ret.EmissiveColor = v_scale(v_add(rgb(sampleTexture(m->EmissiveIdx)), V3(m->EmissiveColor[0], m->EmissiveColor[1], m->EmissiveColor[2])), m->EmissiveIntensity);
+        ret.Color = v_mul(rgb(sampleTexture(m->ColorIdx)), V3(m->Color[0], m->Color[1], m->Color[2]));
+        ret.Normal = ReconstructNormalFromXY(rgb(sampleTexture(m->NormalIdx)));
+        ret.Roughness = sampleTexture(m->RoughnessIdx).y * m->Roughness;
+        ret.Metalness = sampleTexture(m->MetallicIdx).z * m->Metalness;
+        ret.Transmission = m->Transmission;
+        ret.AttenuationColor = V3(m->AttenuationColor[0], m->AttenuationColor[1], m->AttenuationColor[2]);
+        ret.AttenuationDistance = m->AttenuationDistance;
+        ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
+        break;
+    }
+    case PTX_MATERIAL_TYPE_SPECULAR_GLOSSINESS: {
+        const PtxSpecularGlossinessMaterial *m = &s->d.specularGlossinessMaterials[materialIndex];
+        ret.EmissiveColor = v_scale(v_add(rgb(sampleTexture(m->EmissiveIdx)), V3(m->EmissiveColor[0], m->EmissiveColor[1], m->EmissiveColor[2])), m->EmissiveIntensity);
+        ret.Color = v_mul(rgb(sampleTexture(m->ColorIdx)), V3(m->Color[0], m->Color[1], m->Color[2]));
+        ret.Normal = ReconstructNormalFromXY(rgb(sampleTexture(m->NormalIdx)));
+        ret.Transmission = m->Transmission;
+        ret.AttenuationColor = V3(m->AttenuationColor[0], m->AttenuationColor[1], m->AttenuationColor[2]);
+        ret.AttenuationDistance = m->AttenuationDistance;
+        ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
+        const v3 specular = v_mul(rgb(sampleTexture(m->SpecularIdx)), V3(m->Specular[0], m->Specular[1], m->Specular[2]));
+        const float glossiness = sampleTexture(m->GlossinessIdx).w * m->Glossiness;
+        ret.Roughness = 1.0f - glossiness;
+        const v3 diff = V3(f_max(specular.x - 0.04f, 0.0f) / ((ret.Color.x - 0.04f) + 0.00001f),
+                           f_max(specular.y - 0.04f, 0.0f) / ((ret.Color.y - 0.04f) + 0.00001f),
+                           f_max(specular.z - 0.04f, 0.0f) / ((ret.Color.z - 0.04f) + 0.00001f));
+        ret.Metalness = (diff.x + diff.y + diff.z) / 3.0f;
+        break;
+    }
+    case PTX_MATERIAL_TYPE_PHONG: {
+        const PtxPhongMaterial *m = &s->d.phongMaterials[materialIndex];
+        ret.EmissiveColor = v_scale(v_add(rgb(sampleTexture(m->EmissiveIdx)), V3(m->EmissiveColor[0], m->EmissiveColor[1], m->EmissiveColor[2])), m->EmissiveIntensity);
+        ret.Color = v_mul(rgb(sampleTexture(m->ColorIdx)), V3(m->Color[0], m->Color[1], m->Color[2]));
+        ret.Normal = ReconstructNormalFromXY(rgb(sampleTexture(m->NormalIdx)));
+        ret.Transmission = m->Transmission;
+        ret.AttenuationColor = V3(m->AttenuationColor[0], m->AttenuationColor[1], m->AttenuationColor[2]);
+        ret.AttenuationDistance = m->AttenuationDistance;
+        ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
+        const v3 specular = v_mul(rgb(sampleTexture(m->SpecularIdx)), V3(m->Specular[0], m->Specular[1], m->Specular[2]));
+        const float shininess = sampleTexture(m->ShininessIdx).w * m->Shininess;
+        ret.Roughness = 1.0f - shininess;
+        const v3 diff = V3(f_max(specular.x - 0.04f, 0.0f) / ((ret.Color.x - 0.04f) + 0.00001f),
+                           f_max(specular.y - 0.04f, 0.0f) / ((ret.Color.y - 0.04f) + 0.00001f),
+                           f_max(specular.z - 0.04f, 0.0f) / ((ret.Color.z - 0.04f) + 0.00001f));
+        ret.Metalness = (diff.x + diff.y + diff.z) / 3.0f;
+        break;
+    }
+    default: /* material.glsl:163-166 */
+        ret.Color = V3(1.0f, 0.0f, 0.0f);
+        ret.EmissiveColor = V3(1.0f, 0.0f, 0.0f);
+        break;
+    }
+    if (flipNormalY)
+        ret.Normal.y *= -1;
+    return ret;
+}
+
+/* ======================================================================== */
+/* closestHit.rchit / miss.rmiss                                            */
+/* ======================================================================== */
+
+/* ShaderRendererTypes.incl:101-118 (ray differentials omitted, quirk 10) */
+typedef struct Payload
+{
+    v3 Position;
+    v3 Direction;
+    float MaxRoughness;
+    v3 Bsdf;
+    float Pdf;
+    v3 Emissive;
+    uint32_t RngState;
+    v3 DirectLight;
+    float DirectLightPdf;
+    v3 LightDirection;
+    float LightDistance;
+} Payload;
+
+/* common.glsl:27-46 */
+static inline Vtx getVertex(const PtoScene *s, const Pair *pr, uint32_t offset)
+{
+    const uint32_t index = s->d.indices[pr->indexOffset + offset];
+    const PtxVertex *p = &s->d.vertices[pr->vertexOffset + index];
+    Vtx v;
+    v.Position = V3(p->Position[0], p->Position[1], p->Position[2]);
+    v.TexCoords.x = p->TexCoords[0];
+    v.TexCoords.y = p->TexCoords[1];
+    v.Normal = V3(p->Normal[0], p->Normal[1], p->Normal[2]);
+    v.Tangent = V3(p->Tangent[0], p->Tangent[1], p->Tangent[2]);
+    v.Bitangent = V3(p->Bitangent[0], p->Bitangent[1], p->Bitangent[2]);
+    return v;
+}
+
+/* common.glsl:107-110 */
+static inline v3 interp3(v3 a, v3 b, v3 c, v3 bc)
+{
+    return v_add(v_add(v_scale(a, bc.x), v_scale(b, bc.y)), v_scale(c, bc.z));
+}
+
+/* sampling.glsl:5-15: M = A_instance * A_mesh; the normal goes through inverse-transpose */
+static inline Vtx transformVertex(const Pair *pr, Vtx v)
+{
+    v.Position = xformPoint(pr->M, v.Position);
+    v.Tangent = v_normalize(xformVector(pr->M, v.Tangent));
+    v.Bitangent = v_normalize(xformVector(pr->M, v.Bitangent));
+    v.Normal = v_normalize(V3(v_dot(v.Normal, pr->Rinv.c0), v_dot(v.Normal, pr->Rinv.c1), v_dot(v.Normal, pr->Rinv.c2)));
+    return v;
+}
+
+/* closestHit.rchit:52-161 */
+static void closestHit(const PtoScene *s, const PtxLightsUbo *lights, v3 rayOriginW, v3 rayDirW, const PtoHit *hit,
+                       Payload *payload)
+{
+    (void)rayOriginW;
+    const v3 bary = V3(1.0f - hit->u - hit->v, hit->u, hit->v); /* common.glsl:22-25 */
+    const Pair *pr = &s->pairs[s->triPair[hit->tri]];
+    const uint32_t prim = s->triPrim[hit->tri];
+
+    const Vtx o0 = getVertex(s, pr, prim * 3), o1 = getVertex(s, pr, prim * 3 + 1), o2 = getVertex(s, pr, prim * 3 + 2);
+    Vtx ov; /* common.glsl:112-130 */
+    ov.Position = interp3(o0.Position, o1.Position, o2.Position, bary);
+    ov.TexCoords.x = o0.TexCoords.x * bary.x + o1.TexCoords.x * bary.y + o2.TexCoords.x * bary.z;
+    ov.TexCoords.y = o0.TexCoords.y * bary.x + o1.TexCoords.y * bary.y + o2.TexCoords.y * bary.z;
+    ov.Normal = interp3(o0.Normal, o1.Normal, o2.Normal, bary);
+    ov.Tangent = interp3(o0.Tangent, o1.Tangent, o2.Tangent, bary);
+    ov.Bitangent = interp3(o0.Bitangent, o1.Bitangent, o2.Bitangent, bary);
+    Vtx vertex = transformVertex(pr, ov);
+
+    const Vtx v0 = transformVertex(pr, o0), v1 = transformVertex(pr, o1), v2 = transformVertex(pr, o2);
+
+    const v3 edge1 = v_sub(v1.Position, v0.Position);
+    const v3 edge2 = v_sub(v2.Position, v0.Position);
+    v3 geometricNormal = v_normalize(v_cross(edge1, edge2));
+
+    const int isHitFromInside = v_dot(geometricNormal, rayDirW) > 0.0f;
+    if (isHitFromInside)
+    {
+        geometricNormal = v_neg(geometricNormal);
+        vertex.Normal = v_neg(vertex.Normal);
+        vertex.Tangent = v_neg(vertex.Tangent);
+        vertex.Bitangent = v_neg(vertex.Bitangent);
+    }
+
+    MaterialSample material = sampleMaterial(s, pr->materialId, isHitFromInside, s->d.dxNormalTextures != 0);
+
+    /* :105-106 decals: never taken for opaque geometry (DirectLightPdf == -1 on entry) */
+
+    payload->MaxRoughness = f_max(material.Roughness, payload->MaxRoughness); /* :109 */
+    material.Roughness = f_max(payload->MaxRoughness, 0.01f);                 /* :112 */
+
+    m3 geometryTBN;
+    geometryTBN.c0 = vertex.Tangent;
+    geometryTBN.c1 = vertex.Bitangent;
+    geometryTBN.c2 = vertex.Normal;
+    const v3 N = v_normalize(v_add(vertex.Normal, m3_mul(geometryTBN, material.Normal)));
+    const m3 TBN = computeTangentSpace(N);
+    const m3 invTBN = m3_inverse(TBN);
+    const v3 V = v_normalize(m3_mul(invTBN, v_normalize(v_neg(rayDirW))));
+
+    uint32_t rngState = payload->RngState;
+    BSDFSample bsdf = sampleBSDF(&material, V, &rngState);
+
+    if (isHitFromInside) /* :123-128 Beer-Lambert over this segment */
+    {
+        const float e = hit->t / material.AttenuationDistance;
+        bsdf.Color.x *= pto_powf(material.AttenuationColor.x, e);
+        bsdf.Color.y *= pto_powf(material.AttenuationColor.y, e);
+        bsdf.Color.z *= pto_powf(material.AttenuationColor.z, e);
+    }
+
+    const int isRefracted = bsdf.Direction.z < 0.0f;
+    const v3 rayOrigin = offsetRayOriginShadowTerminator(&vertex, &v0, &v1, &v2, bary, isRefracted);
+
+    float lightPdf, lightSmplPdf;
+    v3 u3;
+    u3.x = rnd(&rngState);
+    u3.y = rnd(&rngState);
+    u3.z = rnd(&rngState);
+    const LightSample light = sampleLight(lights, u3, rayOrigin, &lightPdf);
+    const v3 L = v_normalize(m3_mul(invTBN, v_neg(light.Direction)));
+    const v3 lightBsdf = evaluateBSDF(&material, V, L, &lightSmplPdf);
+
+    payload->Direction = v_normalize(m3_mul(TBN, bsdf.Direction));
+    if (isRefracted)
+        payload->Position = offsetRayOriginSelfIntersection(vertex.Position, v_neg(geometricNormal));
+    else
+        payload->Position = rayOrigin;
+    payload->Bsdf = bsdf.Color;
+    payload->Pdf = bsdf.Pdf;
+    payload->Emissive = material.EmissiveColor;
+    payload->RngState = rngState;
+    payload->DirectLight = v_mul(v_scale(light.Color, light.Attenuation), lightBsdf);
+    payload->DirectLightPdf = lightPdf;
+    payload->LightDirection = light.Direction;
+    payload->LightDistance = light.Distance;
+}
+
+/* miss.rmiss:16-39, MissFlagsNone branch (skybox textures are next row N1) */
+static inline void missShader(Payload *payload)
+{
+    payload->Emissive = V3(0.08f, 0.09f, 0.1f);
+    payload->Pdf = -1.0f;
+}
+
+/* ======================================================================== */
+/* raygen.rgen                                                              */
+/* ======================================================================== */
+
+/* raygen.rgen:22-34 */
+static inline int checkOccluded(const PtoScene *s, v3 lightDir, v3 position, float dist, int brute, PtoStats *st)
+{
+    const v3 direction = v_neg(v_normalize(lightDir));
+    st->shadowRays++;
+    return traceAny(s, position, direction, 0.00001f, dist, brute, st);
+}
+
+/* raygen.rgen:36-118 for one pixel */
+static void raygenPixel(const PtoScene *s, const PtxRaygenUniformData *U, const PtxLightsUbo *lights, uint32_t px,
+                        uint32_t py, uint32_t W, uint32_t H, float *accum, int brute, PtoStats *st)
+{
+    uint32_t rngState = initRng(px, py, W, U->TotalSamples);
+    v3 radiance = v3s(0.0f);
+    Payload payload;
+    memset(&payload, 0, sizeof(payload));
+
+    for (int smpl = 0; smpl < (int)U->SampleCount; smpl++)
+    {
+        v3 throughput = v3s(1.0f);
+        v2 u;
+        u.x = rnd(&rngState);
+        u.y = rnd(&rngState);
+        Ray ray;
+        if (U->LensRadius > 0)
+        {
+            v2 u2;
+            u2.x = rnd(&rngState);
+            u2.y = rnd(&rngState);
+            ray = constructPrimaryRayLens(px, py, W, H, U->ViewInverse, U->ProjInverse, u, u2, U->LensRadius,
+                                          U->FocalDistance);
+        }
+        else
+            ray = constructPrimaryRay(px, py, W, H, U->ViewInverse, U->ProjInverse, u);
+
+        payload.MaxRoughness = 0.0f;
+
+        for (uint32_t bounce = 0; bounce < U->BounceCount; bounce++)
+        {
+            payload.RngState = rngState;
+            payload.DirectLightPdf = -1.0f;
+            payload.LightDirection = v3s(0.0f);
+            payload.LightDistance = 0.0f;
+            st->segments++;
+            const PtoHit hit = traceClosest(s, ray.Origin, ray.Direction, ray.tmin, ray.tmax, brute, st);
+            if (hit.tri == 0xffffffffu)
+                missShader(&payload);
+            else
+                closestHit(s, lights, ray.Origin, ray.Direction, &hit, &payload);
+            rngState = payload.RngState;
+
+            if (payload.Pdf == -1.0f)
+            {
+                radiance = v_add(radiance, v_mul(throughput, payload.Emissive));
+                break;
+            }
+
+            radiance = v_add(radiance, v_mul(throughput, payload.Emissive));
+
+            if (payload.DirectLightPdf > 0.0f)
+                if (!checkOccluded(s, payload.LightDirection, payload.Position, payload.LightDistance, brute, st))
+                    radiance = v_add(radiance, v_div(v_mul(throughput, payload.DirectLight), payload.DirectLightPdf));
+
+            if (payload.Pdf > 0.001f)
+                throughput = v_mul(throughput, v_div(payload.Bsdf, payload.Pdf));
+
+            const float prob = f_min(maxComponent(throughput), 1.0f);
+            if (prob < 0.001f)
+                break;
+            if (prob < rnd(&rngState))
+                break;
+            throughput = v_div(throughput, prob);
+
+            ray.Origin = payload.Position;
+            ray.Direction = payload.Direction;
+        }
+
+        st->pathSamples++;
+        /* :99-112 NaN / Inf sample rejection restarts the whole sample loop */
+        if (isnan(radiance.x) || isnan(radiance.y) || isnan(radiance.z) || isinf(radiance.x) || isinf(radiance.y) ||
+            isinf(radiance.z))
+        {
+            radiance = v3s(0.0f);
+            smpl = -1;
+            st->retries++;
+            continue;
+        }
+    }
+
+    float *p = &accum[((size_t)py * W + px) * 4]; /* :115-117 */
+    p[0] = radiance.x + p[0];
+    p[1] = radiance.y + p[1];
+    p[2] = radiance.z + p[2];
+    p[3] = 1.0f;
+}
+
+int pto_render(const PtoScene *s, const PtxRaygenUniformData *U, const PtxLightsUbo *lights, uint32_t W, uint32_t H,
+               uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, const PtxTileShard *shard, float *accum, int threads,
+               int brute, PtoStats *stats)
+{
+    if (!s || !U || !lights || !accum || x1 > W || y1 > H)
+        return 1;
+    PtoStats total;
+    memset(&total, 0, sizeof(total));
+    total.triangles = s->triCount;
+#ifdef _OPENMP
+    if (threads > 0)
+        omp_set_num_threads(threads);
+#else
+    (void)threads;
+#endif
+    const uint32_t ts = shard && shard->tileSize ? shard->tileSize : 16;
+    const uint32_t tilesX = (W + ts - 1) / ts, tilesY = (H + ts - 1) / ts;
+    const int64_t ntiles = (int64_t)tilesX * tilesY;
+#pragma omp parallel
+    {
+        PtoStats st;
+        memset(&st, 0, sizeof(st));
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t tile = 0; tile < ntiles; tile++)
+        {
+            if (shard && shard->worldSize > 1 && (uint32_t)(tile % shard->worldSize) != shard->rank)
+                continue;
+            const uint32_t tx = (uint32_t)(tile % tilesX), ty = (uint32_t)(tile / tilesX);
+            for (uint32_t y = ty * ts; y < (ty + 1) * ts && y < H; y++)
+                for (uint32_t x = tx * ts; x < (tx + 1) * ts && x < W; x++)
+                    if (x >= x0 && x < x1 && y >= y0 && y < y1)
+                        raygenPixel(s, U, lights, x, y, W, H, accum, brute, &st);
+        }
+#pragma omp critical
+        {
+            total.pathSamples += st.pathSamples;
+            total.segments += st.segments;
+            total.shadowRays += st.shadowRays;
+            total.retries += st.retries;
+            total.nodesVisited += st.nodesVisited;
+            total.trisTested += st.trisTested;
+        }
+    }
+    if (stats)
+        *stats = total;
+    return 0;
+}
+
+/* ======================================================================== */
+/* Function-level entry (packing documented in include/ptx.h)               */
+/* ======================================================================== */
+
+static const int kInStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42 };
+static const int kOutStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 6, 2, 1, 9, 3, 6 };
+
+static MaterialSample unpackMaterial(const float *p)
+{
+    MaterialSample m;
+    memset(&m, 0, sizeof(m));
+    m.Color = V3(p[0], p[1], p[2]);
+    m.Roughness = p[3];
+    m.Metalness = p[4];
+    m.Transmission = p[5];
+    m.Eta = p[6];
+    return m;
+}
+
+int pto_test_eval(uint32_t fn, const float *in, float *out, uint32_t n)
+{
+    if (fn >= PTX_FN_COUNT)
+        return 1;
+    for (uint32_t i = 0; i < n; i++)
+    {
+        const float *a = &in[(size_t)i * kInStride[fn]];
+        float *o = &out[(size_t)i * kOutStride[fn]];
+        switch (fn)
+        {
+        case PTX_FN_GGX_DISTRIBUTION: o[0] = GGXDistribution(V3(a[0], a[1], a[2]), a[3]); break;
+        case PTX_FN_LAMBDA: o[0] = Lambda(V3(a[0], a[1], a[2]), a[3]); break;
+        case PTX_FN_GGX_SMITH: o[0] = GGXSmith(V3(a[0], a[1], a[2]), a[3]); break;
+        case PTX_FN_DIELECTRIC_FRESNEL: o[0] = DielectricFresnel(a[0], a[1]); break;
+        case PTX_FN_SCHLICK_FRESNEL: o[0] = SchlickFresnel(a[0]); break;
+        case PTX_FN_EVALUATE_REFLECTION: {
+            float pdf;
+            const v3 r = EvaluateReflection(V3(a[0], a[1], a[2]), V3(a[3], a[4], a[5]), V3(a[6], a[7], a[8]), a[9], &pdf);
+            o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = pdf;
+            break;
+        }
+        case PTX_FN_EVALUATE_REFRACTION: {
+            float pdf;
+            const v3 r = EvaluateRefraction(V3(a[0], a[1], a[2]), V3(a[3], a[4], a[5]), V3(a[6], a[7], a[8]), a[9], a[10], &pdf);
+            o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = pdf;
+            break;
+        }
+        case PTX_FN_SAMPLE_GGX: {
+            v2 u = { a[0], a[1] };
+            const v3 r = SampleGGX(u, V3(a[2], a[3], a[4]), a[5]);
+            o[0] = r.x; o[1] = r.y; o[2] = r.z;
+            break;
+        }
+        case PTX_FN_SAMPLE_LOBE_PDFS: {
+            MaterialSample m;
+            memset(&m, 0, sizeof(m));
+            m.Metalness = a[0];
+            m.Transmission = a[1];
+            const LobePdfs p = sampleLobePdfs(&m, a[2]);
+            o[0] = p.Diffuse; o[1] = p.Glossy; o[2] = p.Metallic; o[3] = p.Transmissive;
+            break;
+        }
+        case PTX_FN_EVALUATE_BSDF: {
+            const MaterialSample m = unpackMaterial(a);
+            float pdf;
+            const v3 r = evaluateBSDF(&m, V3(a[8], a[9], a[10]), V3(a[11], a[12], a[13]), &pdf);
+            o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = pdf;
+            break;
+        }
+        case PTX_FN_SAMPLE_BSDF: {
+            const MaterialSample m = unpackMaterial(a);
+            uint32_t rng = f2u(a[11]);
+            const BSDFSample r = sampleBSDF(&m, V3(a[8], a[9], a[10]), &rng);
+            o[0] = r.Direction.x; o[1] = r.Direction.y; o[2] = r.Direction.z; o[3] = r.Pdf;
+            o[4] = r.Color.x; o[5] = r.Color.y; o[6] = r.Color.z; o[7] = u2f(rng);
+            break;
+        }
+        case PTX_FN_RNG: {
+            uint32_t st = initRng(f2u(a[0]), f2u(a[1]), f2u(a[2]), f2u(a[3]));
+            o[0] = u2f(st);
+            for (int k = 0; k < 4; k++)
+                o[1 + k] = rnd(&st);
+            break;
+        }
+        case PTX_FN_DISK: {
+            v2 u = { a[0], a[1] };
+            const v2 d = sampleUniformDiskConcentric(u);
+            o[0] = d.x; o[1] = d.y;
+            break;
+        }
+        case PTX_FN_COS_HEMISPHERE: {
+            v2 u = { a[0], a[1] };
+            const v3 d = sampleCosineHemisphere(u);
+            o[0] = d.x; o[1] = d.y; o[2] = d.z;
+            break;
+        }
+        case PTX_FN_TANGENT_SPACE: {
+            const m3 m = computeTangentSpace(V3(a[0], a[1], a[2]));
+            o[0] = m.c0.x; o[1] = m.c0.y; o[2] = m.c0.z;
+            o[3] = m.c1.x; o[4] = m.c1.y; o[5] = m.c1.z;
+            o[6] = m.c2.x; o[7] = m.c2.y; o[8] = m.c2.z;
+            break;
+        }
+        case PTX_FN_OFFSET_SELF_INTERSECTION: {
+            const v3 r = offsetRayOriginSelfIntersection(V3(a[0], a[1], a[2]), V3(a[3], a[4], a[5]));
+            o[0] = r.x; o[1] = r.y; o[2] = r.z;
+            break;
+        }
+        case PTX_FN_PRIMARY_RAY: {
+            v2 u = { a[4], a[5] };
+            const Ray r = constructPrimaryRay(f2u(a[0]), f2u(a[1]), f2u(a[2]), f2u(a[3]), &a[6], &a[22], u);
+            o[0] = r.Origin.x; o[1] = r.Origin.y; o[2] = r.Origin.z;
+            o[3] = r.Direction.x; o[4] = r.Direction.y; o[5] = r.Direction.z;
+            break;
+        }
+        case PTX_FN_SINCOS: pto_sincosf(a[0], &o[0], &o[1]); break;
+        case PTX_FN_POW: o[0] = pto_powf(a[0], a[1]); break;
+        case PTX_FN_SAMPLE_LIGHT: {
+            PtxLightsUbo ubo;
+            memset(&ubo, 0, sizeof(ubo));
+            ubo.LightCount = f2u(a[6]);
+            memcpy(ubo.Directional.Color, &a[7], 12);
+            memcpy(ubo.Directional.Direction, &a[10], 12);
+            for (int k = 0; k < 2; k++)
+            {
+                memcpy(ubo.Lights[k].Color, &a[13 + 9 * k], 12);
+                memcpy(ubo.Lights[k].Position, &a[16 + 9 * k], 12);
+                ubo.Lights[k].AttenuationConstant = a[19 + 9 * k];
+                ubo.Lights[k].AttenuationLinear = a[20 + 9 * k];
+                ubo.Lights[k].AttenuationQuadratic = a[21 + 9 * k];
+            }
+            float pdf;
+            const LightSample l = sampleLight(&ubo, V3(a[0], a[1], a[2]), V3(a[3], a[4], a[5]), &pdf);
+            o[0] = l.Direction.x; o[1] = l.Direction.y; o[2] = l.Direction.z; o[3] = l.Distance;
+            o[4] = l.Color.x; o[5] = l.Color.y; o[6] = l.Color.z; o[7] = l.Attenuation; o[8] = pdf;
+            break;
+        }
+        case PTX_FN_SHADOW_TERMINATOR: {
+            Vtx vx, q0, q1, q2;
+            memset(&vx, 0, sizeof(vx)); memset(&q0, 0, sizeof(q0)); memset(&q1, 0, sizeof(q1)); memset(&q2, 0, sizeof(q2));
+            vx.Position = V3(a[0], a[1], a[2]);
+            q0.Position = V3(a[3], a[4], a[5]); q0.Normal = V3(a[6], a[7], a[8]);
+            q1.Position = V3(a[9], a[10], a[11]); q1.Normal = V3(a[12], a[13], a[14]);
+            q2.Position = V3(a[15], a[16], a[17]); q2.Normal = V3(a[18], a[19], a[20]);
+            const v3 r = offsetRayOriginShadowTerminator(&vx, &q0, &q1, &q2, V3(a[21], a[22], a[23]), a[24] != 0.0f);
+            o[0] = r.x; o[1] = r.y; o[2] = r.z;
+            break;
+        }
+        case PTX_FN_PRIMARY_RAY_LENS: {
+            v2 u = { a[4], a[5] }, u2 = { a[6], a[7] };
+            const Ray r = constructPrimaryRayLens(f2u(a[0]), f2u(a[1]), f2u(a[2]), f2u(a[3]), &a[10], &a[26], u, u2, a[8], a[9]);
+            o[0] = r.Origin.x; o[1] = r.Origin.y; o[2] = r.Origin.z;
+            o[3] = r.Direction.x; o[4] = r.Direction.y; o[5] = r.Direction.z;
+            break;
+        }
+        default: return 1;
+        }
+    }
+    return 0;
+}

@@ -1,0 +1,83 @@
+/*
+ * pt_oracle.h -- CPU ORACLE for the path-tracing hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library.  The product (path-tracing_amd/) never includes, links or calls anything
+ * in oracle/.
+ *
+ * It is a plain-C restatement of the reference's GLSL ray-tracing stages
+ *   Path-Tracing/Shaders/{raygen.rgen, closestHit.rchit, miss.rmiss, occlusion.rmiss,
+ *   common.glsl, shading.glsl, bsdf.glsl, sampling.glsl, ray.glsl, material.glsl,
+ *   tracing.glsl}
+ * with a brute-force / binned-SAH BVH closest-hit query standing in for the driver's
+ * traceRayEXT.  Every function cites the file:line it follows.
+ *
+ * PARITY PIN: the pure-math functions are pinned to the reference by golden vectors
+ * generated from the reference's own GLSL sources (tools/gen_golden.py compiles
+ * shading.glsl / bsdf.glsl / common.glsl / ray.glsl / sampling.glsl / tracing.glsl as
+ * C++ through a builtin shim; vectors in tests/golden/).  Image-level parity is
+ * UNPINNED by the reference: it holds no reference image, its tests assert finiteness
+ * only, and it cannot be built here (Vulkan RT + 11 absent submodules) -- see
+ * DESIGN.md "Oracle".
+ *
+ * Arithmetic conventions (GLSL leaves these implementation-defined; both this oracle
+ * and the HIP kernels fix them identically so images can be compared bit-for-bit):
+ *   - IEEE binary32, round-to-nearest, no contraction (-ffp-contract=off), fma only
+ *     where the GLSL says fma();
+ *   - dot(a,b) = (a.x*b.x + a.y*b.y) + a.z*b.z;  length = sqrt(dot);
+ *     normalize(v) = v * (1/sqrt(dot(v,v)));  cross, reflect, refract, mix, clamp as
+ *     in the GLSL 4.60 spec 8.5; mat3*vec3 = (c0*x + c1*y) + c2*z; inverse(mat3) by
+ *     cofactors * (1/det);
+ *   - pow(x,2) = x*x, pow(x,5) = x2*x2*x; general pow/sin/cos by the fixed polynomial
+ *     kernels pto_powf / pto_sincosf below.
+ */
+#ifndef PT_ORACLE_H
+#define PT_ORACLE_H
+
+#include "../include/ptx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct PtoScene PtoScene;
+
+typedef struct PtoStats {
+    uint64_t pathSamples;
+    uint64_t segments;
+    uint64_t shadowRays;
+    uint64_t retries;
+    uint64_t triangles;
+    uint64_t nodesVisited;
+    uint64_t trisTested;
+} PtoStats;
+
+typedef struct PtoHit {
+    float t, u, v;
+    uint32_t tri; /* global flattened triangle id, 0xffffffff = miss */
+} PtoHit;
+
+/* Flatten instances x meshes x primitives to world space (the stand-in for the
+ * BLAS/TLAS build, AccelerationStructure.cpp:64-301); buildBvh != 0 adds a binned-SAH
+ * BVH, otherwise queries are brute force. */
+PTX_API PtoScene *pto_scene_create(const PtxSceneDesc *desc, int buildBvh);
+PTX_API void pto_scene_destroy(PtoScene *s);
+PTX_API uint64_t pto_scene_triangle_count(const PtoScene *s);
+
+/* One launch of raygen.rgen over pixels [x0,x1) x [y0,y1) of a W x H image; adds into
+ * accum (W*H*4 floats, alpha set to 1).  tileShard may be NULL (whole region). */
+PTX_API int pto_render(const PtoScene *s, const PtxRaygenUniformData *u, const PtxLightsUbo *lights, uint32_t W,
+                       uint32_t H, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, const PtxTileShard *tileShard,
+                       float *accum, int threads, int bruteForce, PtoStats *stats);
+
+/* traceRayEXT stand-ins over rays packed as (ox,oy,oz,tmin, dx,dy,dz,tmax). */
+PTX_API void pto_trace_closest(const PtoScene *s, const float *rays, uint32_t n, PtoHit *hits, int bruteForce);
+PTX_API void pto_trace_any(const PtoScene *s, const float *rays, uint32_t n, uint32_t *occluded, int bruteForce);
+
+/* Function-level entry, same packing as ptx_test_eval (include/ptx.h). */
+PTX_API int pto_test_eval(uint32_t fn, const float *in, float *out, uint32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

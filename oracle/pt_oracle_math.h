@@ -1,0 +1,194 @@
+/*
+ * pt_oracle_math.h -- vector helpers and the GLSL builtins the shaders use, with the
+ * arithmetic conventions fixed in pt_oracle.h.  ORACLE ONLY (test infrastructure).
+ */
+#ifndef PT_ORACLE_MATH_H
+#define PT_ORACLE_MATH_H
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+typedef struct v2 { float x, y; } v2;
+typedef struct v3 { float x, y, z; } v3;
+typedef struct v4 { float x, y, z, w; } v4;
+typedef struct m3 { v3 c0, c1, c2; } m3; /* columns, like GLSL mat3 */
+
+#define PTO_PI 3.14159265359f /* common.glsl:3 */
+
+static inline float f_min(float a, float b) { return (b < a) ? b : a; } /* GLSL min: y < x ? y : x */
+static inline float f_max(float a, float b) { return (a < b) ? b : a; } /* GLSL max: x < y ? y : x */
+static inline float f_clamp(float x, float lo, float hi) { return f_min(f_max(x, lo), hi); }
+
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+static inline v3 V3(float x, float y, float z) { v3 r = { x, y, z }; return r; }
+static inline v3 v3s(float s) { return V3(s, s, s); }
+static inline v3 v_add(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 v_sub(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 v_mul(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline v3 v_scale(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+static inline v3 v_div(v3 a, float s) { return V3(a.x / s, a.y / s, a.z / s); }
+static inline v3 v_neg(v3 a) { return V3(-a.x, -a.y, -a.z); }
+static inline float v_dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline v3 v_cross(v3 a, v3 b)
+{
+    return V3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
+}
+static inline float v_length(v3 a) { return sqrtf(v_dot(a, a)); }
+static inline v3 v_normalize(v3 a) { return v_scale(a, 1.0f / sqrtf(v_dot(a, a))); }
+/* reflect(I, N) = I - 2 * dot(N, I) * N */
+static inline v3 v_reflect(v3 I, v3 N) { return v_sub(I, v_scale(N, 2.0f * v_dot(N, I))); }
+/* refract(I, N, eta), GLSL 4.60 8.5 */
+static inline v3 v_refract(v3 I, v3 N, float eta)
+{
+    const float d = v_dot(N, I);
+    const float k = 1.0f - eta * eta * (1.0f - d * d);
+    if (k < 0.0f)
+        return V3(0.0f, 0.0f, 0.0f);
+    return v_sub(v_scale(I, eta), v_scale(N, eta * d + sqrtf(k)));
+}
+/* mix(x, y, a) = x * (1 - a) + y * a */
+static inline v3 v_mix(v3 x, v3 y, float a) { return v_add(v_scale(x, 1.0f - a), v_scale(y, a)); }
+
+static inline v3 m3_mul(m3 m, v3 v)
+{
+    return V3((m.c0.x * v.x + m.c1.x * v.y) + m.c2.x * v.z, (m.c0.y * v.x + m.c1.y * v.y) + m.c2.y * v.z,
+              (m.c0.z * v.x + m.c1.z * v.y) + m.c2.z * v.z);
+}
+
+/* inverse(mat3): cofactors times 1/det, element [col][row] */
+static inline m3 m3_inverse(m3 m)
+{
+    const float m00 = m.c0.x, m01 = m.c0.y, m02 = m.c0.z;
+    const float m10 = m.c1.x, m11 = m.c1.y, m12 = m.c1.z;
+    const float m20 = m.c2.x, m21 = m.c2.y, m22 = m.c2.z;
+    const float det = (m00 * (m11 * m22 - m21 * m12) - m10 * (m01 * m22 - m21 * m02)) + m20 * (m01 * m12 - m11 * m02);
+    const float id = 1.0f / det;
+    m3 r;
+    r.c0.x = (m11 * m22 - m21 * m12) * id;
+    r.c1.x = -(m10 * m22 - m20 * m12) * id;
+    r.c2.x = (m10 * m21 - m20 * m11) * id;
+    r.c0.y = -(m01 * m22 - m21 * m02) * id;
+    r.c1.y = (m00 * m22 - m20 * m02) * id;
+    r.c2.y = -(m00 * m21 - m20 * m01) * id;
+    r.c0.z = (m01 * m12 - m11 * m02) * id;
+    r.c1.z = -(m00 * m12 - m10 * m02) * id;
+    r.c2.z = (m00 * m11 - m10 * m01) * id;
+    return r;
+}
+
+/* mat4 (glm column-major, element [c*4+r]) times vec4 */
+static inline v4 m4_mul(const float *m, float x, float y, float z, float w)
+{
+    v4 r;
+    r.x = ((m[0] * x + m[4] * y) + m[8] * z) + m[12] * w;
+    r.y = ((m[1] * x + m[5] * y) + m[9] * z) + m[13] * w;
+    r.z = ((m[2] * x + m[6] * y) + m[10] * z) + m[14] * w;
+    r.w = ((m[3] * x + m[7] * y) + m[11] * z) + m[15] * w;
+    return r;
+}
+
+/* ---- fixed transcendental kernels (shared definition with the HIP kernels) ---- */
+
+/* sin and cos for |x| <= ~8 (the shaders call them on [-pi/4, 2pi]): Cody-Waite
+ * reduction by pi/2 in three float pieces, then the degree-7/8 minimax polynomials. */
+static inline void pto_sincosf(float x, float *s, float *c)
+{
+    const float fk = floorf(x * 0.636619772f + 0.5f);
+    const int k = (int)fk;
+    float r = x - fk * 1.5703125f;
+    r = r - fk * 4.837512969970703125e-4f;
+    r = r - fk * 7.54978995489188216e-8f;
+    const float z = r * r;
+    const float ps = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+    float pc = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z;
+    pc = pc - 0.5f * z;
+    pc = pc + 1.0f;
+    switch (k & 3)
+    {
+    case 0: *s = ps; *c = pc; break;
+    case 1: *s = pc; *c = -ps; break;
+    case 2: *s = -ps; *c = -pc; break;
+    default: *s = -pc; *c = ps; break;
+    }
+}
+
+/* log2 of a positive, finite, normal double */
+static inline double pto_log2(double x)
+{
+    uint64_t bits;
+    memcpy(&bits, &x, 8);
+    int e = (int)((bits >> 52) & 0x7ff) - 1023;
+    bits = (bits & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+    double m;
+    memcpy(&m, &bits, 8);
+    if (m > 1.4142135623730951)
+    {
+        m = m * 0.5;
+        e = e + 1;
+    }
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    double p = 1.0 / 21.0;
+    p = p * z + 1.0 / 19.0;
+    p = p * z + 1.0 / 17.0;
+    p = p * z + 1.0 / 15.0;
+    p = p * z + 1.0 / 13.0;
+    p = p * z + 1.0 / 11.0;
+    p = p * z + 1.0 / 9.0;
+    p = p * z + 1.0 / 7.0;
+    p = p * z + 1.0 / 5.0;
+    p = p * z + 1.0 / 3.0;
+    p = p * z + 1.0;
+    const double ln = 2.0 * s * p;
+    return (double)e + ln * 1.4426950408889634;
+}
+
+/* 2^t for |t| <= 300 */
+static inline double pto_exp2(double t)
+{
+    const double k = floor(t + 0.5);
+    const double r = (t - k) * 0.6931471805599453;
+    double p = 1.0 / 6227020800.0;
+    p = p * r + 1.0 / 479001600.0;
+    p = p * r + 1.0 / 39916800.0;
+    p = p * r + 1.0 / 3628800.0;
+    p = p * r + 1.0 / 362880.0;
+    p = p * r + 1.0 / 40320.0;
+    p = p * r + 1.0 / 5040.0;
+    p = p * r + 1.0 / 720.0;
+    p = p * r + 1.0 / 120.0;
+    p = p * r + 1.0 / 24.0;
+    p = p * r + 1.0 / 6.0;
+    p = p * r + 0.5;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
+    const uint64_t bits = (uint64_t)((int64_t)k + 1023) << 52;
+    double sc;
+    memcpy(&sc, &bits, 8);
+    return p * sc;
+}
+
+/* pow(x, y) for x >= 0 (GLSL leaves x < 0 undefined; NaN here) */
+static inline float pto_powf(float x, float y)
+{
+    if (y == 0.0f || x == 1.0f)
+        return 1.0f;
+    if (x != x || y != y || x < 0.0f)
+        return u2f(0x7fc00000u);
+    if (x == 0.0f)
+        return y > 0.0f ? 0.0f : u2f(0x7f800000u);
+    if (x == u2f(0x7f800000u))
+        return y > 0.0f ? u2f(0x7f800000u) : 0.0f;
+    double t = (double)y * pto_log2((double)x);
+    if (t > 300.0)
+        t = 300.0;
+    if (t < -300.0)
+        t = -300.0;
+    return (float)pto_exp2(t);
+}
+
+#endif

@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.json from the REFERENCE's own GLSL sources.
+
+Runs only in the build container (needs /root/reference).  The reference cannot be
+built (Vulkan RT + absent submodules), but its pure-math shader headers compile as C++
+once the GLSL builtins are supplied by tools/glsl_shim.hpp.  This script
+
+  1. reads the listed line ranges of Path-Tracing/Shaders/*.glsl / *.incl,
+  2. applies five mechanical rewrites (out/inout -> references, float-literal suffix,
+     swizzle -> method, drop #include/#version, braces around rand() argument lists so
+     C++ keeps GLSL's left-to-right evaluation),
+  3. writes the result into a TEMP directory (reference text is never copied into the
+     repo), appends tools/golden_main.inc and compiles with g++ -ffp-contract=off,
+  4. runs it twice -- libm transcendentals (golden_libm.json) and the fixed polynomial
+     kernels (-DSHIM_FIXED, golden_fixed.json) -- and stores the vectors.
+
+Only inputs/outputs (uint32 bit patterns) are committed.
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+REF = "/root/reference/Path-Tracing/Shaders"
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "..", "tests", "golden")
+
+# (file, [(first_line, last_line), ...])  1-based inclusive
+SOURCES = [
+    ("common.glsl", [(3, 25), (102, 122), (133, 202)]),
+    ("shading.glsl", [(3, 129)]),
+    ("bsdf.glsl", [(4, 132)]),
+    ("ray.glsl", [(3, 131)]),
+    ("sampling.glsl", [(3, 3), (17, 56)]),
+]
+STRUCTS = [
+    ("ShaderTypes.incl", ["Camera", "Vertex", "DirectionalLight", "PointLight"]),
+    ("ShaderRendererTypes.incl", ["MaterialSample"]),
+]
+
+FLOAT_LIT = re.compile(r"(?<![A-Za-z_0-9.])((?:\d+\.\d*|\.\d+)(?:[eE][+-]?\d+)?|\d+[eE][+-]?\d+)(?![fF0-9A-Za-z_.])")
+
+
+def rewrite(text: str) -> str:
+    text = re.sub(r"^\s*#(include|version|extension).*$", "", text, flags=re.M)
+    text = re.sub(r"\binout\s+(\w+)\s+(\w+)", r"\1& \2", text)
+    text = re.sub(r"\bout\s+(\w+)\s+(\w+)", r"\1& \2", text)
+    text = FLOAT_LIT.sub(r"\1f", text)
+    text = re.sub(r"\.(xyz|xy|yz|zw|rgb)\b", r".\1()", text)
+    # GLSL evaluates call arguments left to right (GLSL 4.60 6.1.1); C++ only does so
+    # for braced initialisers, and the draw order of rand() is part of the contract.
+    text = re.sub(r"\bvec([23])\(((?:rand\(rngState\)(?:,\s*)?)+)\)", r"vec\1{\2}", text)
+    return text
+
+
+def lines(path, ranges):
+    src = open(path).read().split("\n")
+    out = []
+    for a, b in ranges:
+        out += src[a - 1:b]
+    return "\n".join(out)
+
+
+def extract_struct(path, name):
+    src = open(path).read()
+    m = re.search(r"struct\s+%s\s*\{.*?\};" % name, src, flags=re.S)
+    if not m:
+        raise SystemExit(f"struct {name} not found in {path}")
+    return m.group(0)
+
+
+def main():
+    if not os.path.isdir(REF):
+        raise SystemExit("reference not present; golden vectors can only be regenerated in the build container")
+    os.makedirs(OUT, exist_ok=True)
+    with tempfile.TemporaryDirectory(prefix="ptgolden_") as tmp:
+        parts = ['#include "%s/glsl_shim.hpp"' % HERE, "namespace glsl {", "const uint MaxLightCount = 64u;"]
+        for f, names in STRUCTS:
+            for n in names:
+                parts.append(extract_struct(os.path.join(REF, f), n))
+        parts.append("uint u_LightCount; DirectionalLight u_DirectionalLight; PointLight u_Lights[MaxLightCount];")
+        for f, ranges in SOURCES:
+            parts.append("// ---- %s" % f)
+            parts.append(rewrite(lines(os.path.join(REF, f), ranges)))
+        parts.append("} // namespace glsl")
+        parts.append('#include "%s/golden_main.inc"' % HERE)
+        cpp = os.path.join(tmp, "golden.cpp")
+        open(cpp, "w").write("\n".join(parts))
+        for mode, flag in (("libm", []), ("fixed", ["-DSHIM_FIXED"])):
+            exe = os.path.join(tmp, "golden_" + mode)
+            cmd = ["g++", "-std=c++20", "-O1", "-ffp-contract=off", "-fno-fast-math", "-w"] + flag + [cpp, "-o", exe, "-lm"]
+            subprocess.check_call(cmd)
+            data = subprocess.check_output([exe])
+            dst = os.path.join(OUT, "golden_%s.json" % mode)
+            open(dst, "wb").write(data)
+            print("wrote", os.path.relpath(dst), len(data), "bytes")
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,174 @@
+// glsl_shim.hpp -- minimal GLSL-builtin shim so the reference's pure-math shader
+// headers (shading.glsl, bsdf.glsl, parts of common/ray/sampling.glsl) compile as C++.
+//
+// Used ONLY by tools/gen_golden.py in the build container to produce the golden
+// vectors under tests/golden/.  It never travels into the product, and the shader text
+// it is applied to stays in /tmp (reference sources are not copied into this repo).
+//
+// Builtins follow the arithmetic conventions written in oracle/pt_oracle.h.  With
+// -DSHIM_FIXED the transcendental builtins use the fixed polynomial kernels
+// (bit-exact structure check); without it they use glibc's libm (independent check of
+// those kernels, compared within a few ULP).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#include "../oracle/pt_oracle_math.h"
+
+namespace glsl
+{
+typedef unsigned int uint;
+
+struct uvec2
+{
+    uint x, y;
+    uvec2() {}
+    uvec2(uint a, uint b) : x(a), y(b) {}
+};
+struct vec2
+{
+    union { struct { float x, y; }; struct { float r, g; }; };
+    vec2() {}
+    explicit vec2(float s) : x(s), y(s) {}
+    vec2(float a, float b) : x(a), y(b) {}
+    explicit vec2(uvec2 u) : x((float)u.x), y((float)u.y) {}
+    vec2 xy() const { return *this; }
+};
+struct vec3
+{
+    union { struct { float x, y, z; }; struct { float r, g, b; }; };
+    vec3() {}
+    explicit vec3(float s) : x(s), y(s), z(s) {}
+    vec3(float a, float b_, float c) : x(a), y(b_), z(c) {}
+    vec3(vec2 a, float c) : x(a.x), y(a.y), z(c) {}
+    vec3(float a, vec2 bc) : x(a), y(bc.x), z(bc.y) {}
+    vec3 xyz() const { return *this; }
+    vec3 rgb() const { return *this; }
+    vec2 xy() const { return vec2(x, y); }
+    vec2 yz() const { return vec2(y, z); }
+    vec3 &operator+=(vec3 o) { x = x + o.x; y = y + o.y; z = z + o.z; return *this; }
+    vec3 &operator-=(vec3 o) { x = x - o.x; y = y - o.y; z = z - o.z; return *this; }
+    vec3 &operator*=(float s) { x = x * s; y = y * s; z = z * s; return *this; }
+    vec3 &operator*=(vec3 o) { x = x * o.x; y = y * o.y; z = z * o.z; return *this; }
+    vec3 &operator/=(float s) { x = x / s; y = y / s; z = z / s; return *this; }
+};
+struct ivec3
+{
+    int x, y, z;
+    ivec3() {}
+    explicit ivec3(vec3 v) : x((int)v.x), y((int)v.y), z((int)v.z) {}
+};
+struct vec4
+{
+    union { struct { float x, y, z, w; }; struct { float r, g, b, a; }; };
+    vec4() {}
+    explicit vec4(float s) : x(s), y(s), z(s), w(s) {}
+    vec4(float a_, float b_, float c, float d) : x(a_), y(b_), z(c), w(d) {}
+    vec4(vec3 v, float d) : x(v.x), y(v.y), z(v.z), w(d) {}
+    vec3 xyz() const { return vec3(x, y, z); }
+    vec3 rgb() const { return vec3(x, y, z); }
+    vec2 xy() const { return vec2(x, y); }
+    vec2 zw() const { return vec2(z, w); }
+};
+struct mat3
+{
+    vec3 c[3];
+    mat3() {}
+    mat3(vec3 a, vec3 b, vec3 d) { c[0] = a; c[1] = b; c[2] = d; }
+};
+struct mat4
+{
+    float m[16]; // [col*4+row]
+};
+
+// ---- operators -------------------------------------------------------------
+inline vec2 operator+(vec2 a, vec2 b) { return vec2(a.x + b.x, a.y + b.y); }
+inline vec2 operator+(uvec2 a, vec2 b) { return vec2((float)a.x + b.x, (float)a.y + b.y); }
+inline vec2 operator-(vec2 a, vec2 b) { return vec2(a.x - b.x, a.y - b.y); }
+inline vec2 operator-(vec2 a, float s) { return vec2(a.x - s, a.y - s); }
+inline vec2 operator*(vec2 a, float s) { return vec2(a.x * s, a.y * s); }
+inline vec2 operator*(float s, vec2 a) { return vec2(s * a.x, s * a.y); }
+inline vec2 operator/(vec2 a, vec2 b) { return vec2(a.x / b.x, a.y / b.y); }
+inline vec2 operator/(vec2 a, uvec2 b) { return vec2(a.x / (float)b.x, a.y / (float)b.y); }
+inline bool operator==(vec2 a, vec2 b) { return a.x == b.x && a.y == b.y; }
+
+inline vec3 operator+(vec3 a, vec3 b) { return vec3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline vec3 operator-(vec3 a, vec3 b) { return vec3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline vec3 operator-(vec3 a, float s) { return vec3(a.x - s, a.y - s, a.z - s); }
+inline vec3 operator+(vec3 a, float s) { return vec3(a.x + s, a.y + s, a.z + s); }
+inline vec3 operator-(vec3 a) { return vec3(-a.x, -a.y, -a.z); }
+inline vec3 operator*(vec3 a, vec3 b) { return vec3(a.x * b.x, a.y * b.y, a.z * b.z); }
+inline vec3 operator*(vec3 a, float s) { return vec3(a.x * s, a.y * s, a.z * s); }
+inline vec3 operator*(float s, vec3 a) { return vec3(s * a.x, s * a.y, s * a.z); }
+inline vec3 operator/(vec3 a, float s) { return vec3(a.x / s, a.y / s, a.z / s); }
+inline vec3 operator/(vec3 a, vec3 b) { return vec3(a.x / b.x, a.y / b.y, a.z / b.z); }
+
+inline vec3 operator*(const mat3 &m, vec3 v)
+{
+    return vec3((m.c[0].x * v.x + m.c[1].x * v.y) + m.c[2].x * v.z, (m.c[0].y * v.x + m.c[1].y * v.y) + m.c[2].y * v.z,
+                (m.c[0].z * v.x + m.c[1].z * v.y) + m.c[2].z * v.z);
+}
+inline vec4 operator*(const mat4 &m, vec4 v)
+{
+    const v4 r = m4_mul(m.m, v.x, v.y, v.z, v.w);
+    return vec4(r.x, r.y, r.z, r.w);
+}
+
+// ---- builtins --------------------------------------------------------------
+inline float abs(float x) { return fabsf(x); }
+inline float sqrt(float x) { return sqrtf(x); }
+inline float inversesqrt(float x) { return 1.0f / sqrtf(x); }
+inline float min(float a, float b) { return f_min(a, b); }
+inline float max(float a, float b) { return f_max(a, b); }
+inline vec3 max(vec3 a, float b) { return vec3(f_max(a.x, b), f_max(a.y, b), f_max(a.z, b)); }
+inline float clamp(float x, float lo, float hi) { return f_clamp(x, lo, hi); }
+inline bool isinf(float x) { return std::isinf(x); }
+inline bool isnan(float x) { return std::isnan(x); }
+inline float fma(float a, float b, float c) { return fmaf(a, b, c); }
+inline int floatBitsToInt(float f) { int i; memcpy(&i, &f, 4); return i; }
+inline float intBitsToFloat(int i) { float f; memcpy(&f, &i, 4); return f; }
+inline float uintBitsToFloat(uint u) { float f; memcpy(&f, &u, 4); return f; }
+
+#ifdef SHIM_FIXED
+inline float cos(float x) { float s, c; pto_sincosf(x, &s, &c); return c; }
+inline float sin(float x) { float s, c; pto_sincosf(x, &s, &c); return s; }
+inline float pow(float x, float y)
+{
+    if (y == 2.0f) return x * x;
+    if (y == 5.0f) { const float x2 = x * x; return x2 * x2 * x; }
+    return pto_powf(x, y);
+}
+#else
+inline float cos(float x) { return cosf(x); }
+inline float sin(float x) { return sinf(x); }
+inline float pow(float x, float y) { return powf(x, y); }
+#endif
+inline float pow(float x, int y) { return pow(x, (float)y); }
+
+inline float dot(vec3 a, vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline float dot(uvec2 a, uvec2 b) { return (float)a.x * (float)b.x + (float)a.y * (float)b.y; }
+inline vec3 cross(vec3 a, vec3 b) { return vec3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
+inline float length(vec3 a) { return sqrtf(dot(a, a)); }
+inline float distance(vec3 a, vec3 b) { return length(a - b); }
+inline vec3 normalize(vec3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+inline vec3 reflect(vec3 I, vec3 N) { return I - N * (2.0f * dot(N, I)); }
+inline vec3 refract(vec3 I, vec3 N, float eta)
+{
+    const float d = dot(N, I);
+    const float k = 1.0f - eta * eta * (1.0f - d * d);
+    if (k < 0.0f)
+        return vec3(0.0f);
+    return I * eta - N * (eta * d + sqrtf(k));
+}
+inline vec3 mix(vec3 x, vec3 y, float a) { return x * (1.0f - a) + y * a; }
+inline mat3 inverse(const mat3 &m)
+{
+    m3 a;
+    a.c0 = V3(m.c[0].x, m.c[0].y, m.c[0].z);
+    a.c1 = V3(m.c[1].x, m.c[1].y, m.c[1].z);
+    a.c2 = V3(m.c[2].x, m.c[2].y, m.c[2].z);
+    const m3 r = m3_inverse(a);
+    return mat3(vec3(r.c0.x, r.c0.y, r.c0.z), vec3(r.c1.x, r.c1.y, r.c1.z), vec3(r.c2.x, r.c2.y, r.c2.z));
+}
+} // namespace glsl
