@@ -349,6 +349,16 @@ PTX_API int ptx_unpack_shard(PtxRenderer *r, uint32_t rank, const void *devSrc);
 
 PTX_API int ptx_get_stats(PtxRenderer *r, PtxStats *stats);
 
+/* Use caller-owned device memory (width*height*16 bytes, e.g. a torch tensor that takes
+ * part in the RCCL gather) as the accumulation image; NULL returns to the internal one. */
+PTX_API int ptx_bind_accumulation(PtxRenderer *r, void *devPtr, size_t bytes);
+
+/* traceRayEXT stand-in on explicit rays, 8 floats each (ox,oy,oz,tmin, dx,dy,dz,tmax):
+ * closest hit (anyHit = 0, gl_RayFlagsNoneEXT, raygen.rgen:68) or occlusion (anyHit = 1,
+ * TerminateOnFirstHit, raygen.rgen:31).  hits: 4 floats per ray (t, u, v, hit ? 1 : 0);
+ * ids: 2 uints per ray ((instance,mesh) pair index, primitive index; 0xffffffff = miss). */
+PTX_API int ptx_trace_rays(PtxRenderer *r, const float *rays, uint32_t n, int anyHit, float *hits, uint32_t *ids);
+
 /* ------------------------------------------------------------------------- */
 /* Function-level entry (mirrors Path-Tracing-Tests/TestRenderer.cpp:79-105:   */
 /* run one production shading function over n packed inputs on the device).    */

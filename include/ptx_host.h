@@ -1,0 +1,42 @@
+/*
+ * ptx_host.h -- small C-ABI over the C++ host mirror (path-tracing_amd/host/: Scene,
+ * SceneBuilder, Camera, ExampleScenes) so that tests, bench.py and non-C++ callers can
+ * obtain the same PtxSceneDesc / RaygenUniformData / lights UBO the reference's host
+ * side would hand to its Renderer (Scene.h:182-207, Renderer.cpp:1686-1726).
+ * No GPU is needed for anything here.
+ */
+#ifndef PTX_HOST_H
+#define PTX_HOST_H
+
+#include "ptx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct PthScene PthScene;
+
+/* comma-separated registry: default, roughness_cubes, attenuation_blob, chess_like, ... */
+PTX_API const char *pth_scene_names(void);
+/* detail in (0,1] scales tessellation of the procedural stand-ins; seed 0 = scene default */
+PTX_API PthScene *pth_scene_create(const char *name, float detail, uint32_t seed);
+PTX_API void pth_scene_destroy(PthScene *s);
+PTX_API const char *pth_last_error(void);
+
+/* Scene getters as one POD; pointers stay valid until pth_scene_destroy */
+PTX_API int pth_scene_desc(PthScene *s, PtxSceneDesc *out);
+PTX_API int pth_scene_lights(PthScene *s, PtxLightsUbo *out);
+PTX_API uint64_t pth_scene_triangle_count(PthScene *s); /* instanced (flattened) count */
+
+/* Camera::OnResize + Renderer::Render's uniform fill (Renderer.cpp:1684-1694) */
+PTX_API int pth_scene_raygen_uniform(PthScene *s, uint32_t width, uint32_t height, uint32_t bounceCount,
+                                     float lensRadius, float focalDistance, uint32_t sampleCount,
+                                     uint32_t totalSamples, PtxRaygenUniformData *out);
+/* -1 = the InputCamera (Scene.h:259-260), >= 0 = scene camera */
+PTX_API int pth_scene_set_active_camera(PthScene *s, int32_t cameraId);
+PTX_API int pth_scene_set_camera_pose(PthScene *s, const float position[3], const float direction[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

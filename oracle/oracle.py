@@ -1,0 +1,106 @@
+"""ctypes wrapper of the CPU ORACLE (oracle/libpt_oracle.so).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the
+product package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libpt_oracle.so")
+
+
+class OracleStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("pathSamples", "segments", "shadowRays", "retries", "triangles", "nodesVisited", "trisTested")]
+
+
+class OracleHit(C.Structure):
+    _fields_ = [("t", C.c_float), ("u", C.c_float), ("v", C.c_float), ("tri", C.c_uint32)]
+
+
+def build(force: bool = False) -> None:
+    src = [os.path.join(HERE, f) for f in ("pt_oracle.c", "pt_oracle.h", "pt_oracle_math.h")]
+    if force or not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in src):
+        subprocess.check_call(["make", "-C", HERE, "-B" if force else "-s", "libpt_oracle.so"])
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        lib = C.CDLL(LIB)
+        P = C.c_void_p
+        lib.pto_scene_create.restype = P
+        lib.pto_scene_create.argtypes = [P, C.c_int]
+        lib.pto_scene_destroy.argtypes = [P]
+        lib.pto_scene_triangle_count.restype = C.c_uint64
+        lib.pto_scene_triangle_count.argtypes = [P]
+        lib.pto_render.argtypes = [P, P, P] + [C.c_uint32] * 6 + [P, P, C.c_int, C.c_int, P]
+        lib.pto_trace_closest.argtypes = [P, P, C.c_uint32, P, C.c_int]
+        lib.pto_trace_any.argtypes = [P, P, C.c_uint32, P, C.c_int]
+        lib.pto_test_eval.argtypes = [C.c_uint32, P, P, C.c_uint32]
+        _lib = lib
+    return _lib
+
+
+class OracleScene:
+    def __init__(self, desc, build_bvh: bool = True):
+        """desc: a ctypes image of PtxSceneDesc (anything with ctypes.byref support)."""
+        self.lib = load()
+        self._desc = desc  # keep alive
+        self.handle = self.lib.pto_scene_create(C.addressof(desc), int(build_bvh))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.pto_scene_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    @property
+    def triangle_count(self) -> int:
+        return int(self.lib.pto_scene_triangle_count(self.handle))
+
+    def render(self, uniform, lights, width, height, accum=None, region=None, shard=None, threads=0,
+               brute_force=False):
+        if accum is None:
+            accum = np.zeros((height, width, 4), np.float32)
+        x0, y0, x1, y1 = region if region else (0, 0, width, height)
+        stats = OracleStats()
+        shard_p = C.addressof(shard) if shard is not None else None
+        rc = self.lib.pto_render(self.handle, C.addressof(uniform), C.addressof(lights), width, height, x0, y0, x1, y1,
+                                 shard_p, accum.ctypes.data, threads, int(brute_force), C.addressof(stats))
+        if rc:
+            raise RuntimeError("pto_render failed")
+        return accum, stats
+
+    def trace_closest(self, rays: np.ndarray, brute_force: bool = False):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        hits = np.zeros(rays.shape[0], dtype=[("t", "f4"), ("u", "f4"), ("v", "f4"), ("tri", "u4")])
+        self.lib.pto_trace_closest(self.handle, rays.ctypes.data, rays.shape[0], hits.ctypes.data, int(brute_force))
+        return hits
+
+    def trace_any(self, rays: np.ndarray, brute_force: bool = False):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        occ = np.zeros(rays.shape[0], np.uint32)
+        self.lib.pto_trace_any(self.handle, rays.ctypes.data, rays.shape[0], occ.ctypes.data, int(brute_force))
+        return occ
+
+
+def test_eval(fn: int, inputs: np.ndarray, nout: int) -> np.ndarray:
+    lib = load()
+    inputs = np.ascontiguousarray(inputs).view(np.uint32)
+    n = inputs.shape[0]
+    out = np.zeros((n, nout), np.uint32)
+    rc = lib.pto_test_eval(fn, inputs.ctypes.data, out.ctypes.data, n)
+    if rc:
+        raise RuntimeError("pto_test_eval failed")
+    return out

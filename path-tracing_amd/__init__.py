@@ -1,0 +1,398 @@
+"""path-tracing_amd -- Python plumbing over the C-ABIs of the MI355X path-tracing backend.
+
+This package holds NO rendering logic: it only loads
+  * libptx_hip.so   (include/ptx.h)       HIP kernels + renderer   -- the product
+  * libptx_host.so  (include/ptx_host.h)  C++ mirror of the reference's Scene/SceneBuilder/
+                                          Camera/ExampleScenes (CPU only)
+through ctypes, mirroring the call sequence of the reference's Renderer
+(Path-Tracing/Renderer/Renderer.h:42-85): create -> scene_upload -> build_accel -> resize ->
+render ... -> readback.
+
+The directory name contains a hyphen, so import it with `load_package()` from
+`__graft_entry__` / `tests/conftest.py` (importlib by path) under the module name
+`path_tracing_amd`.
+
+There is deliberately no CPU fallback: `Renderer()` raises if the HIP library is missing or no
+GPU is visible.  The CPU oracle lives in /oracle and is test infrastructure only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_DIR = os.path.dirname(PKG_DIR)
+HIP_LIB = os.path.join(PKG_DIR, "libptx_hip.so")
+HOST_LIB = os.path.join(PKG_DIR, "libptx_host.so")
+
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "-ffp-contract=off", "-fno-fast-math",  # arithmetic conventions of csrc/pt_device.hpp
+    "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
+]
+HOST_FLAGS = ["-std=c++20", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-fvisibility=hidden"]
+
+# every symbol include/ptx.h and include/ptx_host.h declare
+PTX_SYMBOLS = [
+    "ptx_create", "ptx_destroy", "ptx_last_error", "ptx_device_count", "ptx_scene_upload", "ptx_build_accel",
+    "ptx_resize", "ptx_set_tile_shard", "ptx_set_backend", "ptx_reset_accumulation", "ptx_render",
+    "ptx_render_frames", "ptx_synchronize", "ptx_readback", "ptx_device_accum_ptr", "ptx_accum_bytes",
+    "ptx_shard_bytes", "ptx_pack_shard", "ptx_unpack_shard", "ptx_get_stats", "ptx_bind_accumulation",
+    "ptx_trace_rays", "ptx_test_input_stride", "ptx_test_output_stride", "ptx_test_eval",
+]
+PTH_SYMBOLS = [
+    "pth_scene_names", "pth_scene_create", "pth_scene_destroy", "pth_last_error", "pth_scene_desc",
+    "pth_scene_lights", "pth_scene_triangle_count", "pth_scene_raygen_uniform", "pth_scene_set_active_camera",
+    "pth_scene_set_camera_pose",
+]
+
+BACKEND_WAVEFRONT = 0
+BACKEND_MEGAKERNEL = 1
+
+
+# ---------------------------------------------------------------------------------------
+# ctypes images of the PODs in include/ptx.h
+# ---------------------------------------------------------------------------------------
+class SceneDesc(C.Structure):
+    _fields_ = [
+        ("vertices", C.c_void_p), ("vertexCount", C.c_uint64),
+        ("indices", C.c_void_p), ("indexCount", C.c_uint64),
+        ("transforms", C.c_void_p), ("transformCount", C.c_uint32),
+        ("geometries", C.c_void_p), ("geometryCount", C.c_uint32),
+        ("metallicRoughnessMaterials", C.c_void_p), ("metallicRoughnessMaterialCount", C.c_uint32),
+        ("specularGlossinessMaterials", C.c_void_p), ("specularGlossinessMaterialCount", C.c_uint32),
+        ("phongMaterials", C.c_void_p), ("phongMaterialCount", C.c_uint32),
+        ("meshes", C.c_void_p), ("meshCount", C.c_uint32),
+        ("models", C.c_void_p), ("modelCount", C.c_uint32),
+        ("instances", C.c_void_p), ("instanceCount", C.c_uint32),
+        ("skyboxKind", C.c_uint32), ("dxNormalTextures", C.c_uint32),
+    ]
+
+
+class RaygenUniformData(C.Structure):
+    _fields_ = [
+        ("ViewInverse", C.c_float * 16), ("ProjInverse", C.c_float * 16), ("BounceCount", C.c_uint32),
+        ("LensRadius", C.c_float), ("FocalDistance", C.c_float), ("SampleCount", C.c_uint32),
+        ("TotalSamples", C.c_uint32),
+    ]
+
+
+class DirectionalLight(C.Structure):
+    _fields_ = [("Color", C.c_float * 3), ("pad0", C.c_float), ("Direction", C.c_float * 3), ("pad1", C.c_float)]
+
+
+class PointLight(C.Structure):
+    _fields_ = [
+        ("Color", C.c_float * 3), ("pad0", C.c_float), ("Position", C.c_float * 3), ("pad1", C.c_float),
+        ("AttenuationConstant", C.c_float), ("AttenuationLinear", C.c_float), ("AttenuationQuadratic", C.c_float),
+        ("pad2", C.c_float),
+    ]
+
+
+class LightsUbo(C.Structure):
+    _fields_ = [("LightCount", C.c_uint32), ("pad", C.c_uint32 * 3), ("Directional", DirectionalLight),
+                ("Lights", PointLight * 64)]
+
+
+class DeviceDesc(C.Structure):
+    _fields_ = [("deviceIndex", C.c_int32), ("backend", C.c_uint32), ("stream", C.c_void_p)]
+
+
+class TileShard(C.Structure):
+    _fields_ = [("rank", C.c_uint32), ("worldSize", C.c_uint32), ("tileSize", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("pathSamples", C.c_uint64), ("segments", C.c_uint64), ("shadowRays", C.c_uint64), ("retries", C.c_uint64),
+        ("triangles", C.c_uint64), ("bvhNodes", C.c_uint64), ("lastRenderMs", C.c_double), ("lastTraceMs", C.c_double),
+        ("lastBuildMs", C.c_double), ("traceLaunches", C.c_uint64),
+    ]
+
+
+assert C.sizeof(RaygenUniformData) == 148 and C.sizeof(LightsUbo) == 3120 and C.sizeof(PointLight) == 48
+
+FN = {
+    "GGXDistribution": 0, "Lambda": 1, "GGXSmith": 2, "DielectricFresnel": 3, "SchlickFresnel": 4,
+    "EvaluateReflection": 5, "EvaluateRefraction": 6, "SampleGGX": 7, "sampleLobePdfs": 8, "evaluateBSDF": 9,
+    "sampleBSDF": 10, "rng": 11, "sampleUniformDiskConcentric": 12, "sampleCosineHemisphere": 13,
+    "computeTangentSpace": 14, "offsetRayOriginSelfIntersection": 15, "constructPrimaryRay": 16, "sincos": 17,
+    "pow": 18, "sampleLight": 19, "offsetRayOriginShadowTerminator": 20, "constructPrimaryRayLens": 21,
+}
+
+
+# ---------------------------------------------------------------------------------------
+# build (used by __graft_entry__.build)
+# ---------------------------------------------------------------------------------------
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build(force: bool = False, verbose: bool = True) -> None:
+    """Compile the HIP extension for gfx950 and the C++ host mirror, in-tree."""
+    csrc = os.path.join(PKG_DIR, "csrc")
+    hip_src = [os.path.join(csrc, f) for f in ("pt_kernels.hip", "pt_bvh.hpp", "pt_device.hpp")] + [
+        os.path.join(REPO_DIR, "include", "ptx.h")]
+    if force or _newer(HIP_LIB, hip_src):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        cmd = [hipcc] + HIPCC_FLAGS + ["-o", HIP_LIB, hip_src[0]]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    host = os.path.join(PKG_DIR, "host")
+    host_src = [os.path.join(host, f) for f in ("Scene.cpp", "Camera.cpp", "ExampleScenes.cpp", "host_capi.cpp")]
+    host_dep = host_src + [os.path.join(host, f) for f in ("Scene.h", "Camera.h", "ExampleScenes.h", "Math.h")] + [
+        os.path.join(REPO_DIR, "include", "ptx_host.h"), os.path.join(REPO_DIR, "include", "ptx.h")]
+    if force or _newer(HOST_LIB, host_dep):
+        cmd = ["g++"] + HOST_FLAGS + ["-o", HOST_LIB] + host_src
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+
+# ---------------------------------------------------------------------------------------
+# library loading
+# ---------------------------------------------------------------------------------------
+_hip = None
+_host = None
+
+
+def load_host() -> C.CDLL:
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB):
+            raise RuntimeError(f"{HOST_LIB} missing: run __graft_entry__.build()")
+        lib = C.CDLL(HOST_LIB)
+        lib.pth_scene_names.restype = C.c_char_p
+        lib.pth_last_error.restype = C.c_char_p
+        lib.pth_scene_create.restype = C.c_void_p
+        lib.pth_scene_create.argtypes = [C.c_char_p, C.c_float, C.c_uint32]
+        lib.pth_scene_destroy.argtypes = [C.c_void_p]
+        lib.pth_scene_desc.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
+        lib.pth_scene_lights.argtypes = [C.c_void_p, C.POINTER(LightsUbo)]
+        lib.pth_scene_triangle_count.restype = C.c_uint64
+        lib.pth_scene_triangle_count.argtypes = [C.c_void_p]
+        lib.pth_scene_raygen_uniform.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float,
+                                                 C.c_uint32, C.c_uint32, C.POINTER(RaygenUniformData)]
+        lib.pth_scene_set_active_camera.argtypes = [C.c_void_p, C.c_int32]
+        lib.pth_scene_set_camera_pose.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        _host = lib
+    return _host
+
+
+def load_hip() -> C.CDLL:
+    """Load the HIP renderer.  If torch is in use, import it BEFORE calling this so both share
+    one HIP runtime (the soname libamdhip64.so.7 is resolved to the copy already loaded)."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_LIB):
+            raise RuntimeError(f"{HIP_LIB} missing: the HIP extension is not built (run __graft_entry__.build())")
+        lib = C.CDLL(HIP_LIB)
+        P = C.c_void_p
+        lib.ptx_create.argtypes = [C.POINTER(DeviceDesc), C.POINTER(P)]
+        lib.ptx_destroy.argtypes = [P]
+        lib.ptx_destroy.restype = None
+        lib.ptx_last_error.argtypes = [P]
+        lib.ptx_last_error.restype = C.c_char_p
+        lib.ptx_scene_upload.argtypes = [P, C.POINTER(SceneDesc)]
+        lib.ptx_build_accel.argtypes = [P]
+        lib.ptx_resize.argtypes = [P, C.c_uint32, C.c_uint32]
+        lib.ptx_set_tile_shard.argtypes = [P, C.POINTER(TileShard)]
+        lib.ptx_set_backend.argtypes = [P, C.c_uint32]
+        lib.ptx_reset_accumulation.argtypes = [P]
+        lib.ptx_render.argtypes = [P, C.POINTER(RaygenUniformData), C.POINTER(LightsUbo)]
+        lib.ptx_render_frames.argtypes = [P, C.POINTER(RaygenUniformData), C.POINTER(LightsUbo), C.c_uint32, C.c_uint32]
+        lib.ptx_synchronize.argtypes = [P]
+        lib.ptx_readback.argtypes = [P, P, C.c_size_t]
+        lib.ptx_device_accum_ptr.argtypes = [P]
+        lib.ptx_device_accum_ptr.restype = P
+        lib.ptx_accum_bytes.argtypes = [P]
+        lib.ptx_accum_bytes.restype = C.c_size_t
+        lib.ptx_shard_bytes.argtypes = [P, C.c_uint32]
+        lib.ptx_shard_bytes.restype = C.c_size_t
+        lib.ptx_pack_shard.argtypes = [P, P]
+        lib.ptx_unpack_shard.argtypes = [P, C.c_uint32, P]
+        lib.ptx_get_stats.argtypes = [P, C.POINTER(Stats)]
+        lib.ptx_bind_accumulation.argtypes = [P, P, C.c_size_t]
+        lib.ptx_trace_rays.argtypes = [P, P, C.c_uint32, C.c_int, P, P]
+        lib.ptx_test_input_stride.argtypes = [C.c_uint32]
+        lib.ptx_test_output_stride.argtypes = [C.c_uint32]
+        lib.ptx_test_eval.argtypes = [P, C.c_uint32, P, P, C.c_uint32]
+        _hip = lib
+    return _hip
+
+
+class PtxError(RuntimeError):
+    pass
+
+
+# ---------------------------------------------------------------------------------------
+# thin object wrappers
+# ---------------------------------------------------------------------------------------
+class Scene:
+    """A host-side scene (PathTracing::Scene built by ExampleScenes::CreateScene)."""
+
+    def __init__(self, name: str = "default", detail: float = 1.0, seed: int = 0):
+        self.lib = load_host()
+        self.name = name
+        self.handle = self.lib.pth_scene_create(name.encode(), float(detail), int(seed))
+        if not self.handle:
+            raise PtxError(self.lib.pth_last_error().decode())
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.pth_scene_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    @property
+    def desc(self) -> SceneDesc:
+        d = SceneDesc()
+        if self.lib.pth_scene_desc(self.handle, C.byref(d)):
+            raise PtxError("pth_scene_desc failed")
+        return d
+
+    @property
+    def lights(self) -> LightsUbo:
+        l = LightsUbo()
+        self.lib.pth_scene_lights(self.handle, C.byref(l))
+        return l
+
+    @property
+    def triangle_count(self) -> int:
+        return int(self.lib.pth_scene_triangle_count(self.handle))
+
+    def uniform(self, width, height, bounces=4, sample_count=1, total_samples=0, lens_radius=0.0,
+                focal_distance=10.0) -> RaygenUniformData:
+        u = RaygenUniformData()
+        rc = self.lib.pth_scene_raygen_uniform(self.handle, width, height, bounces, lens_radius, focal_distance,
+                                               sample_count, total_samples, C.byref(u))
+        if rc:
+            raise PtxError("pth_scene_raygen_uniform failed")
+        return u
+
+    def set_active_camera(self, camera_id: int):
+        if self.lib.pth_scene_set_active_camera(self.handle, camera_id):
+            raise PtxError("bad camera id")
+
+    def set_camera_pose(self, position, direction):
+        p = (C.c_float * 3)(*position)
+        d = (C.c_float * 3)(*direction)
+        self.lib.pth_scene_set_camera_pose(self.handle, p, d)
+
+
+class Renderer:
+    """include/ptx.h as an object.  Raises PtxError (with ptx_last_error) on any failure."""
+
+    def __init__(self, device: int = 0, backend: int = BACKEND_WAVEFRONT, stream: int | None = None):
+        self.lib = load_hip()
+        self.handle = C.c_void_p()
+        desc = DeviceDesc(device, backend, stream)
+        rc = self.lib.ptx_create(C.byref(desc), C.byref(self.handle))
+        if rc:
+            self.handle = None
+            raise PtxError(f"ptx_create failed with status {rc} (no HIP device? there is no CPU fallback)")
+        self.width = self.height = 0
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.ptx_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc:
+            raise PtxError(f"status {rc}: {self.lib.ptx_last_error(self.handle).decode()}")
+
+    def upload(self, scene: Scene | SceneDesc):
+        d = scene.desc if isinstance(scene, Scene) else scene
+        self._check(self.lib.ptx_scene_upload(self.handle, C.byref(d)))
+        self._check(self.lib.ptx_build_accel(self.handle))
+
+    def resize(self, width: int, height: int):
+        self._check(self.lib.ptx_resize(self.handle, width, height))
+        self.width, self.height = width, height
+
+    def set_tile_shard(self, rank: int, world: int, tile: int = 32):
+        s = TileShard(rank, world, tile)
+        self._check(self.lib.ptx_set_tile_shard(self.handle, C.byref(s)))
+
+    def set_backend(self, backend: int):
+        self._check(self.lib.ptx_set_backend(self.handle, backend))
+
+    def reset(self):
+        self._check(self.lib.ptx_reset_accumulation(self.handle))
+
+    def render(self, uniform: RaygenUniformData, lights: LightsUbo):
+        self._check(self.lib.ptx_render(self.handle, C.byref(uniform), C.byref(lights)))
+
+    def render_frames(self, uniform: RaygenUniformData, lights: LightsUbo, first_frame: int, frames: int):
+        self._check(self.lib.ptx_render_frames(self.handle, C.byref(uniform), C.byref(lights), first_frame, frames))
+
+    def synchronize(self):
+        self._check(self.lib.ptx_synchronize(self.handle))
+
+    def readback(self) -> np.ndarray:
+        img = np.empty((self.height, self.width, 4), dtype=np.float32)
+        self._check(self.lib.ptx_readback(self.handle, img.ctypes.data, img.nbytes))
+        return img
+
+    def stats(self) -> Stats:
+        s = Stats()
+        self._check(self.lib.ptx_get_stats(self.handle, C.byref(s)))
+        return s
+
+    def accum_ptr(self) -> int:
+        return int(self.lib.ptx_device_accum_ptr(self.handle) or 0)
+
+    def bind_accumulation(self, dev_ptr: int, nbytes: int):
+        self._check(self.lib.ptx_bind_accumulation(self.handle, dev_ptr, nbytes))
+
+    def shard_bytes(self, rank: int) -> int:
+        return int(self.lib.ptx_shard_bytes(self.handle, rank))
+
+    def pack_shard(self, dev_dst: int):
+        self._check(self.lib.ptx_pack_shard(self.handle, dev_dst))
+
+    def unpack_shard(self, rank: int, dev_src: int):
+        self._check(self.lib.ptx_unpack_shard(self.handle, rank, dev_src))
+
+    def trace_rays(self, rays: np.ndarray, any_hit: bool = False):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = rays.shape[0]
+        hits = np.zeros((n, 4), np.float32)
+        ids = np.zeros((n, 2), np.uint32)
+        self._check(self.lib.ptx_trace_rays(self.handle, rays.ctypes.data, n, int(any_hit), hits.ctypes.data,
+                                            ids.ctypes.data))
+        return hits, ids
+
+    def test_eval(self, fn: int, inputs: np.ndarray) -> np.ndarray:
+        nin, nout = self.lib.ptx_test_input_stride(fn), self.lib.ptx_test_output_stride(fn)
+        inputs = np.ascontiguousarray(inputs).view(np.uint32).reshape(-1, nin)
+        out = np.zeros((inputs.shape[0], nout), np.uint32)
+        self._check(self.lib.ptx_test_eval(self.handle, fn, inputs.ctypes.data, out.ctypes.data, inputs.shape[0]))
+        return out
+
+
+def owned_tiles(width: int, height: int, rank: int, world: int, tile: int = 32):
+    """Tile ids (row-major) a rank owns under the round-robin pixel-tile shard."""
+    tiles_x = (width + tile - 1) // tile
+    tiles_y = (height + tile - 1) // tile
+    return list(range(rank, tiles_x * tiles_y, world))
+
+
+def shard_mask(width: int, height: int, rank: int, world: int, tile: int = 32) -> np.ndarray:
+    """Boolean H x W mask of the pixels a rank owns."""
+    tiles_x = (width + tile - 1) // tile
+    ys, xs = np.mgrid[0:height, 0:width]
+    tid = (ys // tile) * tiles_x + (xs // tile)
+    return (tid % world) == rank

@@ -1,0 +1,878 @@
+// pt_device.hpp -- device-side shading arithmetic of the HIP path tracer (gfx950).
+//
+// Hand-written HIP restatement of the reference's GLSL headers
+//   Path-Tracing/Shaders/{common,shading,bsdf,sampling,ray,material}.glsl
+// and of closestHit.rchit / miss.rmiss, used by both backends (wavefront kernels and
+// the bring-up megakernel) in pt_kernels.hip.  Each function cites the GLSL it follows.
+//
+// Arithmetic conventions (fixed so results are reproducible bit for bit; GLSL leaves
+// them implementation-defined): IEEE binary32 round-to-nearest, no contraction
+// (compiled with -ffp-contract=off), fma only where the GLSL writes fma();
+// dot = (x*x' + y*y') + z*z'; normalize(v) = v * (1/sqrt(dot(v,v))); mat3*vec3 =
+// (c0*x + c1*y) + c2*z; inverse(mat3) by cofactors * (1/det); min/max as the GLSL
+// select forms (NaN behaviour of "y < x ? y : x"); pow(x,2) = x*x, pow(x,5) = x2*x2*x;
+// sin/cos/pow by the fixed polynomial kernels below (no ocml calls: their results are
+// not specified to the bit).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ptx.h"
+
+#define PT_DEV __device__ __forceinline__
+#define PT_PI 3.14159265359f // common.glsl:3
+
+namespace ptd
+{
+
+struct f2 { float x, y; };
+struct f3 { float x, y, z; };
+struct f4 { float x, y, z, w; };
+struct mat3 { f3 c0, c1, c2; }; // columns
+
+PT_DEV f3 F3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+PT_DEV f3 F3s(float s) { return F3(s, s, s); }
+PT_DEV f3 operator+(f3 a, f3 b) { return F3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_DEV f3 operator-(f3 a, f3 b) { return F3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_DEV f3 operator*(f3 a, f3 b) { return F3(a.x * b.x, a.y * b.y, a.z * b.z); }
+PT_DEV f3 operator*(f3 a, float s) { return F3(a.x * s, a.y * s, a.z * s); }
+PT_DEV f3 operator/(f3 a, float s) { return F3(a.x / s, a.y / s, a.z / s); }
+PT_DEV f3 operator-(f3 a) { return F3(-a.x, -a.y, -a.z); }
+
+PT_DEV float fmin_(float a, float b) { return (b < a) ? b : a; } // GLSL min
+PT_DEV float fmax_(float a, float b) { return (a < b) ? b : a; } // GLSL max
+PT_DEV float clamp_(float x, float lo, float hi) { return fmin_(fmax_(x, lo), hi); }
+PT_DEV float abs_(float x) { return __builtin_fabsf(x); }
+PT_DEV float sqrt_(float x) { return __builtin_sqrtf(x); } // correctly rounded (hipcc default)
+
+PT_DEV float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+PT_DEV f3 cross(f3 a, f3 b) { return F3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
+PT_DEV float length(f3 a) { return sqrt_(dot(a, a)); }
+PT_DEV f3 normalize(f3 a) { return a * (1.0f / sqrt_(dot(a, a))); }
+PT_DEV f3 reflect(f3 I, f3 N) { return I - N * (2.0f * dot(N, I)); }
+PT_DEV f3 refract(f3 I, f3 N, float eta)
+{
+    const float d = dot(N, I);
+    const float k = 1.0f - eta * eta * (1.0f - d * d);
+    if (k < 0.0f)
+        return F3s(0.0f);
+    return I * eta - N * (eta * d + sqrt_(k));
+}
+PT_DEV f3 mix(f3 x, f3 y, float a) { return x * (1.0f - a) + y * a; }
+
+PT_DEV f3 mul(const mat3 &m, f3 v)
+{
+    return F3((m.c0.x * v.x + m.c1.x * v.y) + m.c2.x * v.z, (m.c0.y * v.x + m.c1.y * v.y) + m.c2.y * v.z,
+              (m.c0.z * v.x + m.c1.z * v.y) + m.c2.z * v.z);
+}
+
+PT_DEV mat3 inverse(const mat3 &m)
+{
+    const float m00 = m.c0.x, m01 = m.c0.y, m02 = m.c0.z;
+    const float m10 = m.c1.x, m11 = m.c1.y, m12 = m.c1.z;
+    const float m20 = m.c2.x, m21 = m.c2.y, m22 = m.c2.z;
+    const float det = (m00 * (m11 * m22 - m21 * m12) - m10 * (m01 * m22 - m21 * m02)) + m20 * (m01 * m12 - m11 * m02);
+    const float id = 1.0f / det;
+    mat3 r;
+    r.c0.x = (m11 * m22 - m21 * m12) * id;
+    r.c1.x = -(m10 * m22 - m20 * m12) * id;
+    r.c2.x = (m10 * m21 - m20 * m11) * id;
+    r.c0.y = -(m01 * m22 - m21 * m02) * id;
+    r.c1.y = (m00 * m22 - m20 * m02) * id;
+    r.c2.y = -(m00 * m21 - m20 * m01) * id;
+    r.c0.z = (m01 * m12 - m11 * m02) * id;
+    r.c1.z = -(m00 * m12 - m10 * m02) * id;
+    r.c2.z = (m00 * m11 - m10 * m01) * id;
+    return r;
+}
+
+// mat4 (glm column-major [c*4+r]) * vec4
+PT_DEV f4 mul4(const float *m, float x, float y, float z, float w)
+{
+    f4 r;
+    r.x = ((m[0] * x + m[4] * y) + m[8] * z) + m[12] * w;
+    r.y = ((m[1] * x + m[5] * y) + m[9] * z) + m[13] * w;
+    r.z = ((m[2] * x + m[6] * y) + m[10] * z) + m[14] * w;
+    r.w = ((m[3] * x + m[7] * y) + m[11] * z) + m[15] * w;
+    return r;
+}
+
+// ---- fixed transcendental kernels -------------------------------------------------
+
+// sin & cos on roughly [-pi/4, 2pi]: 3-piece Cody-Waite reduction by pi/2, then the
+// degree-7 / degree-8 minimax polynomials.
+PT_DEV void sincos_(float x, float &s, float &c)
+{
+    const float fk = __builtin_floorf(x * 0.636619772f + 0.5f);
+    const int k = (int)fk;
+    float r = x - fk * 1.5703125f;
+    r = r - fk * 4.837512969970703125e-4f;
+    r = r - fk * 7.54978995489188216e-8f;
+    const float z = r * r;
+    const float ps = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+    float pc = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z;
+    pc = pc - 0.5f * z;
+    pc = pc + 1.0f;
+    const int q = k & 3;
+    s = (q == 0) ? ps : (q == 1) ? pc : (q == 2) ? -ps : -pc;
+    c = (q == 0) ? pc : (q == 1) ? -ps : (q == 2) ? -pc : ps;
+}
+
+PT_DEV double log2_(double x) // positive, finite, normal
+{
+    unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+    int e = (int)((bits >> 52) & 0x7ff) - 1023;
+    bits = (bits & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+    double m = __longlong_as_double((long long)bits);
+    if (m > 1.4142135623730951)
+    {
+        m = m * 0.5;
+        e = e + 1;
+    }
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    double p = 1.0 / 21.0;
+    p = p * z + 1.0 / 19.0;
+    p = p * z + 1.0 / 17.0;
+    p = p * z + 1.0 / 15.0;
+    p = p * z + 1.0 / 13.0;
+    p = p * z + 1.0 / 11.0;
+    p = p * z + 1.0 / 9.0;
+    p = p * z + 1.0 / 7.0;
+    p = p * z + 1.0 / 5.0;
+    p = p * z + 1.0 / 3.0;
+    p = p * z + 1.0;
+    const double ln = 2.0 * s * p;
+    return (double)e + ln * 1.4426950408889634;
+}
+
+PT_DEV double exp2_(double t) // |t| <= 300
+{
+    const double k = __builtin_floor(t + 0.5);
+    const double r = (t - k) * 0.6931471805599453;
+    double p = 1.0 / 6227020800.0;
+    p = p * r + 1.0 / 479001600.0;
+    p = p * r + 1.0 / 39916800.0;
+    p = p * r + 1.0 / 3628800.0;
+    p = p * r + 1.0 / 362880.0;
+    p = p * r + 1.0 / 40320.0;
+    p = p * r + 1.0 / 5040.0;
+    p = p * r + 1.0 / 720.0;
+    p = p * r + 1.0 / 120.0;
+    p = p * r + 1.0 / 24.0;
+    p = p * r + 1.0 / 6.0;
+    p = p * r + 0.5;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
+    const unsigned long long bits = (unsigned long long)((long long)k + 1023) << 52;
+    return p * __longlong_as_double((long long)bits);
+}
+
+PT_DEV float pow_(float x, float y) // x >= 0
+{
+    if (y == 0.0f || x == 1.0f)
+        return 1.0f;
+    if (x != x || y != y || x < 0.0f)
+        return __uint_as_float(0x7fc00000u);
+    if (x == 0.0f)
+        return y > 0.0f ? 0.0f : __uint_as_float(0x7f800000u);
+    if (x == __uint_as_float(0x7f800000u))
+        return y > 0.0f ? __uint_as_float(0x7f800000u) : 0.0f;
+    double t = (double)y * log2_((double)x);
+    if (t > 300.0)
+        t = 300.0;
+    if (t < -300.0)
+        t = -300.0;
+    return (float)exp2_(t);
+}
+
+// ---- common.glsl --------------------------------------------------------------------
+
+PT_DEV float maxComponent(f3 rgb) { return fmax_(rgb.x, fmax_(rgb.y, rgb.z)); } // :12-15
+
+PT_DEV uint32_t jenkinsHash(uint32_t x) // :133-141
+{
+    x += x << 10;
+    x ^= x >> 6;
+    x += x << 3;
+    x ^= x >> 11;
+    x += x << 15;
+    return x;
+}
+
+PT_DEV uint32_t initRng(uint32_t px, uint32_t py, uint32_t resX, uint32_t frame) // :143-147
+{
+    const float d = (float)px * 1.0f + (float)py * (float)resX;
+    const uint32_t rngState = (uint32_t)d ^ jenkinsHash(frame);
+    return jenkinsHash(rngState);
+}
+
+PT_DEV float rnd(uint32_t &rngState) // :149-165
+{
+    rngState ^= rngState << 13;
+    rngState ^= rngState >> 17;
+    rngState ^= rngState << 5;
+    return __uint_as_float(0x3f800000u | (rngState >> 9)) - 1.0f;
+}
+
+PT_DEV f2 sampleUniformDiskConcentric(f2 u) // :168-184
+{
+    f2 offset;
+    offset.x = 2.0f * u.x - 1.0f;
+    offset.y = 2.0f * u.y - 1.0f;
+    f2 r;
+    r.x = 0.0f;
+    r.y = 0.0f;
+    if (offset.x == 0.0f && offset.y == 0.0f)
+        return r;
+    float s, c;
+    if (abs_(offset.x) > abs_(offset.y))
+    {
+        const float theta = (PT_PI / 4) * (offset.y / offset.x);
+        sincos_(theta, s, c);
+        r.x = offset.x * c;
+        r.y = offset.x * s;
+    }
+    else
+    {
+        const float theta = PT_PI / 2 - (PT_PI / 4) * (offset.x / offset.y);
+        sincos_(theta, s, c);
+        r.x = offset.y * c;
+        r.y = offset.y * s;
+    }
+    return r;
+}
+
+PT_DEV f3 sampleCosineHemisphere(f2 u) // :186-191
+{
+    const f2 d = sampleUniformDiskConcentric(u);
+    const float z = sqrt_(1 - d.x * d.x - d.y * d.y);
+    return F3(d.x, d.y, z);
+}
+
+PT_DEV mat3 computeTangentSpace(f3 normal) // :193-202
+{
+    const f3 t1 = cross(normal, F3(1.0f, 0.0f, 0.0f));
+    const f3 t2 = cross(normal, F3(0.0f, 1.0f, 0.0f));
+    const f3 tangent = length(t1) > length(t2) ? t1 : t2;
+    const f3 bitangent = cross(normal, tangent);
+    mat3 m;
+    m.c0 = normalize(tangent);
+    m.c1 = normalize(bitangent);
+    m.c2 = normal;
+    return m;
+}
+
+// ---- shading.glsl ---------------------------------------------------------------------
+
+PT_DEV float GGXDistribution(f3 H, float alpha) // :3-14 (D clamped to <= 1: kept quirk)
+{
+    const float Hx2 = H.x * H.x;
+    const float Hy2 = H.y * H.y;
+    const float Hz2 = H.z * H.z;
+    const float alpha2 = alpha * alpha;
+    const float b = Hx2 / alpha2 + Hy2 / alpha2 + Hz2;
+    const float denom = PT_PI * alpha2 * (b * b);
+    return 1.0f / fmax_(denom, 1.0f);
+}
+
+PT_DEV float Lambda(f3 V, float alpha) // :16-27
+{
+    const float Vx2 = V.x * V.x;
+    const float Vy2 = V.y * V.y;
+    const float Vz2 = abs_(V.z) * abs_(V.z);
+    const float alpha2 = alpha * alpha;
+    const float nom = sqrt_(1.0f + (alpha2 * Vx2 + alpha2 * Vy2) / Vz2) - 1.0f;
+    return nom / 2.0f;
+}
+
+PT_DEV float GGXSmith(f3 V, float alpha) { return 1.0f / (1.0f + Lambda(V, alpha)); } // :29-32
+
+PT_DEV float DielectricFresnel(float VdotH, float eta) // :34-48
+{
+    const float cosThetaI = VdotH;
+    const float sinThetaT2 = eta * eta * (1.0f - cosThetaI * cosThetaI);
+    if (sinThetaT2 > 1.0f)
+        return 1.0f;
+    const float cosThetaT = sqrt_(fmax_(1.0f - sinThetaT2, 0.0f));
+    const float rs = (eta * cosThetaT - cosThetaI) / (eta * cosThetaT + cosThetaI);
+    const float rp = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
+    return (rs * rs + rp * rp) / 2.0f;
+}
+
+PT_DEV float SchlickFresnel(float VdotH) // :50-53
+{
+    const float x = clamp_(1.0f - VdotH, 0.0f, 1.0f);
+    const float x2 = x * x;
+    return x2 * x2 * x;
+}
+
+PT_DEV f3 EvaluateReflection(f3 V, f3 L, f3 F, float alpha, float &pdf) // :56-77
+{
+    if (L.z < 0.00001f)
+    {
+        pdf = 0.0f;
+        return F3s(0.0f);
+    }
+    const f3 H = normalize(V + L);
+    const float VdotH = dot(V, H);
+    const float D = GGXDistribution(H, alpha);
+    const float Gv = GGXSmith(V, alpha);
+    const float Gl = GGXSmith(L, alpha);
+    const float G = Gv * Gl;
+    const float Dv = (Gv * fmax_(VdotH, 0.0f) * D) / V.z;
+    pdf = Dv / (4.0f * VdotH);
+    return (F * (D * G)) / (4.0f * V.z);
+}
+
+PT_DEV f3 EvaluateRefraction(f3 V, f3 L, f3 F, float alpha, float eta, float &pdf) // :80-108
+{
+    if (L.z > -0.00001f)
+    {
+        pdf = 0.0f;
+        return F3s(0.0f);
+    }
+    f3 H = normalize(V * eta + L);
+    if (H.z < 0.0f)
+        H = -H;
+    const float VdotH = dot(V, H);
+    const float LdotH = dot(L, H);
+    const float D = GGXDistribution(H, alpha);
+    const float Gv = GGXSmith(V, alpha);
+    const float Gl = GGXSmith(L, alpha);
+    const float G = Gv * Gl;
+    const float Dv = (Gv * abs_(VdotH) * D) / V.z;
+    const float denominator = LdotH + eta * VdotH;
+    const float jacobian = ((eta * eta) * abs_(LdotH)) / (denominator * denominator);
+    pdf = Dv * jacobian;
+    return ((F * (D * G)) * (abs_(VdotH) / abs_(V.z))) * jacobian;
+}
+
+PT_DEV f3 SampleGGX(f2 u, f3 V, float alpha) // :111-129
+{
+    const f3 Vh = normalize(F3(alpha * V.x, alpha * V.y, abs_(V.z)));
+    const float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
+    const f3 T1 = lensq > 0 ? F3(-Vh.y, Vh.x, 0) * (1.0f / sqrt_(lensq)) : F3(1, 0, 0);
+    const f3 T2 = cross(Vh, T1);
+    const float r = sqrt_(u.x);
+    const float phi = 2.0f * PT_PI * u.y;
+    float sn, cs;
+    sincos_(phi, sn, cs);
+    const float t1 = r * cs;
+    float t2 = r * sn;
+    const float s = 0.5f * (1.0f + Vh.z);
+    t2 = (1.0f - s) * sqrt_(1.0f - t1 * t1) + s * t2;
+    const f3 Nh = (T1 * t1 + T2 * t2) + Vh * sqrt_(fmax_(0.0f, 1.0f - t1 * t1 - t2 * t2));
+    return normalize(F3(alpha * Nh.x, alpha * Nh.y, fmax_(0.0f, Nh.z)));
+}
+
+// ---- bsdf.glsl --------------------------------------------------------------------------
+
+struct MaterialSample // ShaderRendererTypes.incl:129-140
+{
+    f3 EmissiveColor;
+    f3 Color;
+    f3 Normal;
+    float Roughness;
+    float Metalness;
+    float Transmission;
+    float Eta;
+    f3 AttenuationColor;
+    float AttenuationDistance;
+};
+
+struct BSDFSample
+{
+    f3 Direction;
+    float Pdf;
+    f3 Color;
+};
+
+PT_DEV f3 evaluateBSDF(const MaterialSample &m, f3 V, f3 L, float &outPdf) // :72-103
+{
+    const bool isReflection = L.z > 0.0f;
+    const f3 H = isReflection ? normalize(V + L) : normalize(V * m.Eta + L);
+    const float FD = DielectricFresnel(abs_(dot(V, H)), m.Eta);
+    // sampleLobePdfs, :62-70
+    const float pDiffuse = (1.0f - m.Metalness) * (1.0f - FD) * (1.0f - m.Transmission);
+    const float pGlossy = (1.0f - m.Metalness) * FD;
+    const float pMetallic = m.Metalness;
+    const float pTransmissive = (1.0f - m.Metalness) * (1.0f - FD) * m.Transmission;
+    const float alpha = m.Roughness * m.Roughness;
+
+    f3 bsdf = F3s(0.0f);
+    outPdf = 0.0f;
+    float pdf;
+    if (isReflection)
+    {
+        // evaluateDiffuseBRDF, :11-15
+        pdf = L.z * 1.0f / PT_PI;
+        bsdf = bsdf + ((m.Color * L.z) / PT_PI) * pDiffuse;
+        outPdf += pdf * pDiffuse;
+        // evaluateGlossyBSDF, :22-25
+        bsdf = bsdf + EvaluateReflection(V, L, F3s(1.0f), alpha, pdf) * pGlossy;
+        outPdf += pdf * pGlossy;
+        // evaluateMetallicBRDF, :32-37
+        const f3 Hm = normalize(V + L);
+        const f3 F0 = mix(m.Color, F3s(1.0f), SchlickFresnel(dot(V, Hm)));
+        bsdf = bsdf + EvaluateReflection(V, L, F0, alpha, pdf) * pMetallic;
+        outPdf += pdf * pMetallic;
+    }
+    else
+    {
+        // evaluateBTDF, :44-47
+        bsdf = bsdf + EvaluateRefraction(V, L, m.Color, alpha, m.Eta, pdf) * pTransmissive;
+        outPdf += pdf * pTransmissive;
+    }
+    return bsdf;
+}
+
+PT_DEV BSDFSample sampleBSDF(const MaterialSample &m, f3 V, uint32_t &rngState) // :105-132
+{
+    const float alpha = m.Roughness * m.Roughness;
+    f2 u;
+    u.x = rnd(rngState);
+    u.y = rnd(rngState);
+    const f3 H = SampleGGX(u, V, alpha);
+    const float FD = DielectricFresnel(abs_(dot(V, H)), m.Eta);
+
+    f3 L;
+    if (rnd(rngState) < m.Metalness)
+        L = normalize(reflect(-V, H));
+    else
+    {
+        if (rnd(rngState) < FD)
+            L = normalize(reflect(-V, H));
+        else
+        {
+            if (rnd(rngState) < m.Transmission)
+                L = normalize(refract(-V, H, m.Eta));
+            else
+            {
+                f2 u2;
+                u2.x = rnd(rngState);
+                u2.y = rnd(rngState);
+                L = sampleCosineHemisphere(u2);
+            }
+        }
+    }
+    BSDFSample ret;
+    ret.Direction = L;
+    ret.Color = evaluateBSDF(m, V, L, ret.Pdf);
+    return ret;
+}
+
+// ---- ray.glsl ------------------------------------------------------------------------------
+
+PT_DEV void constructPrimaryRay(uint32_t px, uint32_t py, uint32_t resX, uint32_t resY, const float *ViewInverse,
+                                const float *ProjInverse, f2 u, f3 &origin, f3 &direction) // :58-85
+{
+    const float pcx = (float)px + u.x;
+    const float pcy = (float)py + u.y;
+    const float inUVx = pcx / (float)resX;
+    const float inUVy = pcy / (float)resY;
+    const float dx = inUVx * 2.0f - 1.0f;
+    const float dy = inUVy * 2.0f - 1.0f;
+    const f4 o = mul4(ViewInverse, 0, 0, 0, 1);
+    const f4 target = mul4(ProjInverse, dx, dy, 1, 1);
+    const f3 nt = normalize(F3(target.x, target.y, target.z));
+    const f4 d = mul4(ViewInverse, nt.x, nt.y, nt.z, 0);
+    origin = F3(o.x, o.y, o.z);
+    direction = F3(d.x, d.y, d.z);
+}
+
+PT_DEV void constructPrimaryRayLens(uint32_t px, uint32_t py, uint32_t resX, uint32_t resY, const float *ViewInverse,
+                                    const float *ProjInverse, f2 u, f2 u2, float lensRadius, float focalDistance,
+                                    f3 &origin, f3 &direction) // :16-56
+{
+    const float pcx = (float)px + u.x;
+    const float pcy = (float)py + u.y;
+    const f2 disk = sampleUniformDiskConcentric(u2);
+    const float plx = lensRadius * disk.x, ply = lensRadius * disk.y;
+    const float inUVx = pcx / (float)resX;
+    const float inUVy = pcy / (float)resY;
+    const float dx = inUVx * 2.0f - 1.0f;
+    const float dy = inUVy * 2.0f - 1.0f;
+    const f3 originCameraSpace = F3(plx, ply, 0);
+    const f4 o = mul4(ViewInverse, originCameraSpace.x, originCameraSpace.y, originCameraSpace.z, 1);
+    const f4 target = mul4(ProjInverse, dx, dy, 1, 1);
+    const float ft = focalDistance / target.z;
+    const f3 pFocus = F3(target.x, target.y, target.z) * ft;
+    const f3 nd = normalize(pFocus - originCameraSpace);
+    const f4 d = mul4(ViewInverse, nd.x, nd.y, nd.z, 0);
+    origin = F3(o.x, o.y, o.z);
+    direction = F3(d.x, d.y, d.z);
+}
+
+PT_DEV float offsetComponent(float o, float n) // :93-106 (Waechter-Binder)
+{
+    const float origin_const = 1.0f / 32.0f;
+    const float float_scale = 1.0f / 65536.0f;
+    const float int_scale = 256.0f;
+    const int32_t of_i = (int32_t)(int_scale * n);
+    const uint32_t bits = __float_as_uint(o) + (uint32_t)((o < 0) ? -of_i : of_i);
+    const float p_i = __uint_as_float(bits);
+    return (abs_(o) < origin_const) ? o + float_scale * n : p_i;
+}
+PT_DEV f3 offsetRayOriginSelfIntersection(f3 origin, f3 normal)
+{
+    return F3(offsetComponent(origin.x, normal.x), offsetComponent(origin.y, normal.y), offsetComponent(origin.z, normal.z));
+}
+
+PT_DEV f3 offsetRayOriginShadowTerminator(f3 P, f3 p0, f3 n0, f3 p1, f3 n1, f3 p2, f3 n2, f3 bary, bool isRefracted) // :109-131
+{
+    f3 tmpu = P - p0;
+    f3 tmpv = P - p1;
+    f3 tmpw = P - p2;
+    if (isRefracted)
+    {
+        n0 = -n0;
+        n1 = -n1;
+        n2 = -n2;
+    }
+    const float dotu = fmin_(0.0f, dot(tmpu, n0));
+    const float dotv = fmin_(0.0f, dot(tmpv, n1));
+    const float dotw = fmin_(0.0f, dot(tmpw, n2));
+    tmpu = tmpu - n0 * dotu;
+    tmpv = tmpv - n1 * dotv;
+    tmpw = tmpw - n2 * dotw;
+    return ((P + tmpu * bary.x) + tmpv * bary.y) + tmpw * bary.z;
+}
+
+// ---- sampling.glsl ---------------------------------------------------------------------------
+
+struct LightSample
+{
+    f3 Direction;
+    float Distance;
+    f3 Color;
+    float Attenuation;
+};
+
+PT_DEV LightSample sampleLight(const PtxLightsUbo *ubo, f3 u, f3 position, float &pdf) // :25-56
+{
+    const uint32_t lightCount = ubo->LightCount;
+    const uint32_t lightIndex = (uint32_t)(u.x * (float)(lightCount + 1));
+    pdf = 1.0f / (float)(lightCount + 1);
+    LightSample ret;
+    f2 uyz;
+    uyz.x = u.y;
+    uyz.y = u.z;
+    if (lightIndex >= lightCount)
+    {
+        const f2 d2 = sampleUniformDiskConcentric(uyz);
+        const f3 diskPoint = F3(d2.x, d2.y, 0.0f) * 0.001f;
+        const f3 direction = normalize(F3(ubo->Directional.Direction[0], ubo->Directional.Direction[1], ubo->Directional.Direction[2]));
+        ret.Direction = normalize(direction + mul(computeTangentSpace(direction), diskPoint));
+        ret.Color = F3(ubo->Directional.Color[0], ubo->Directional.Color[1], ubo->Directional.Color[2]);
+        ret.Distance = 100000.0f;
+        ret.Attenuation = 1.0f;
+        return ret;
+    }
+    const PtxPointLight *light = &ubo->Lights[lightIndex];
+    const f3 lpos = F3(light->Position[0], light->Position[1], light->Position[2]);
+    const f2 d2 = sampleUniformDiskConcentric(uyz);
+    const f3 diskPoint = F3(d2.x, d2.y, 0.0f) * 0.1f;
+    const f3 direction = normalize(position - lpos);
+    const f3 newPosition = lpos + mul(computeTangentSpace(direction), diskPoint);
+    ret.Distance = length(position - newPosition);
+    ret.Direction = normalize(position - newPosition);
+    ret.Color = F3(light->Color[0], light->Color[1], light->Color[2]);
+    const float attenuation = 1.0f / (light->AttenuationConstant + ret.Distance * light->AttenuationLinear +
+                                      ret.Distance * ret.Distance * light->AttenuationQuadratic);
+    ret.Attenuation = clamp_(attenuation, 0.0f, 1.0f);
+    return ret;
+}
+
+// ---- material.glsl with the fixed 1x1 default textures ------------------------------------------
+
+// Texels of slots 0..8 after format decode (ShaderRendererTypes.incl:49-56; sRGB for
+// Color/Specular/Emissive, UNORM otherwise: TextureUploader.cpp:571-594).  Scene
+// textures (index >= 9) are the next row N1 and sample as the white placeholder.
+PT_DEV f4 sampleTexture(uint32_t idx)
+{
+    f4 w;
+    w.x = w.y = w.z = w.w = 1.0f;
+    if (idx == PTX_DEFAULT_NORMAL_TEXTURE_INDEX)
+    {
+        w.x = 128.0f / 255.0f;
+        w.y = 128.0f / 255.0f;
+    }
+    else if (idx == PTX_DEFAULT_EMISSIVE_TEXTURE_INDEX || idx == PTX_DEFAULT_GLOSSINESS_TEXTURE_INDEX ||
+             idx == PTX_DEFAULT_SHININESS_TEXTURE_INDEX)
+        w.x = w.y = w.z = w.w = 0.0f;
+    return w;
+}
+
+PT_DEV f3 ReconstructNormalFromXY(f3 n) // :55-60
+{
+    n = F3(2.0f * n.x - 1.0f, 2.0f * n.y - 1.0f, 2.0f * n.z - 1.0f);
+    return F3(n.x, n.y, sqrt_(fmax_(1 - n.x * n.x - n.y * n.y, 0.0f)));
+}
+
+PT_DEV f3 rgb(f4 t) { return F3(t.x, t.y, t.z); }
+PT_DEV f3 ld3(const float *p) { return F3(p[0], p[1], p[2]); }
+
+struct SceneView // read-only device views of the uploaded scene
+{
+    const PtxVertex *vertices;
+    const uint32_t *indices;
+    const PtxMetallicRoughnessMaterial *mr;
+    const PtxSpecularGlossinessMaterial *sg;
+    const PtxPhongMaterial *phong;
+    const struct DevPair *pairs;
+    const PtxLightsUbo *lights;
+    uint32_t dxNormalTextures;
+};
+
+// one (instance, mesh): world = A_instance * A_mesh * x (sampling.glsl:5-15); Rinv is
+// the inverse of the linear part, for the inverse-transpose normal transform
+struct DevPair
+{
+    float M[12];
+    float Rinv[9]; // columns c0, c1, c2
+    uint32_t vertexOffset, indexOffset, materialId;
+};
+
+PT_DEV f3 specGlossMetalness(f3 specular, f3 color) // material.glsl:109-110, :138-139
+{
+    return F3(fmax_(specular.x - 0.04f, 0.0f) / ((color.x - 0.04f) + 0.00001f),
+              fmax_(specular.y - 0.04f, 0.0f) / ((color.y - 0.04f) + 0.00001f),
+              fmax_(specular.z - 0.04f, 0.0f) / ((color.z - 0.04f) + 0.00001f));
+}
+
+PT_DEV MaterialSample sampleMaterial(const SceneView &sv, uint32_t materialId, bool isHitFromInside) // :144-171
+{
+    const uint32_t materialType = materialId & 0xffu;
+    const uint32_t materialIndex = materialId >> 8;
+    MaterialSample ret;
+    ret.EmissiveColor = ret.Color = ret.Normal = ret.AttenuationColor = F3s(0.0f);
+    ret.Roughness = ret.Metalness = ret.Transmission = ret.Eta = ret.AttenuationDistance = 0.0f;
+    if (materialType == PTX_MATERIAL_TYPE_METALLIC_ROUGHNESS) // :62-84
+    {
+        const PtxMetallicRoughnessMaterial *m = &sv.mr[materialIndex];
+        ret.EmissiveColor = (rgb(sampleTexture(m->EmissiveIdx)) + ld3(m->EmissiveColor)) * m->EmissiveIntensity;
+        ret.Color = rgb(sampleTexture(m->ColorIdx)) * ld3(m->Color);
+        ret.Normal = ReconstructNormalFromXY(rgb(sampleTexture(m->NormalIdx)));
+        ret.Roughness = sampleTexture(m->RoughnessIdx).y * m->Roughness;
+        ret.Metalness = sampleTexture(m->MetallicIdx).z * m->Metalness;
+        ret.Transmission = m->Transmission;
+        ret.AttenuationColor = ld3(m->AttenuationColor);
+        ret.AttenuationDistance = m->AttenuationDistance;
+        ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
+    }
+    else if (materialType == PTX_MATERIAL_TYPE_SPECULAR_GLOSSINESS) // :86-113
+    {
+        const PtxSpecularGlossinessMaterial *m = &sv.sg[materialIndex];
+        ret.EmissiveColor = (rgb(sampleTexture(m->EmissiveIdx)) + ld3(m->EmissiveColor)) * m->EmissiveIntensity;
+        ret.Color = rgb(sampleTexture(m->ColorIdx)) * ld3(m->Color);
+        ret.Normal = ReconstructNormalFromXY(rgb(sampleTexture(m->NormalIdx)));
+        ret.Transmission = m->Transmission;
+        ret.AttenuationColor = ld3(m->AttenuationColor);
+        ret.AttenuationDistance = m->AttenuationDistance;
+        ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
+        const f3 specular = rgb(sampleTexture(m->SpecularIdx)) * ld3(m->Specular);
+        const float glossiness = sampleTexture(m->GlossinessIdx).w * m->Glossiness;
+        ret.Roughness = 1.0f - glossiness;
+        const f3 diff = specGlossMetalness(specular, ret.Color);
+        ret.Metalness = (diff.x + diff.y + diff.z) / 3.0f;
+    }
+    else if (materialType == PTX_MATERIAL_TYPE_PHONG) // :115-142
+    {
+        const PtxPhongMaterial *m = &sv.phong[materialIndex];
+        ret.EmissiveColor = (rgb(sampleTexture(m->EmissiveIdx)) + ld3(m->EmissiveColor)) * m->EmissiveIntensity;
+        ret.Color = rgb(sampleTexture(m->ColorIdx)) * ld3(m->Color);
+        ret.Normal = ReconstructNormalFromXY(rgb(sampleTexture(m->NormalIdx)));
+        ret.Transmission = m->Transmission;
+        ret.AttenuationColor = ld3(m->AttenuationColor);
+        ret.AttenuationDistance = m->AttenuationDistance;
+        ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
+        const f3 specular = rgb(sampleTexture(m->SpecularIdx)) * ld3(m->Specular);
+        const float shininess = sampleTexture(m->ShininessIdx).w * m->Shininess;
+        ret.Roughness = 1.0f - shininess;
+        const f3 diff = specGlossMetalness(specular, ret.Color);
+        ret.Metalness = (diff.x + diff.y + diff.z) / 3.0f;
+    }
+    else // :163-166
+    {
+        ret.Color = F3(1.0f, 0.0f, 0.0f);
+        ret.EmissiveColor = F3(1.0f, 0.0f, 0.0f);
+    }
+    if (sv.dxNormalTextures)
+        ret.Normal.y *= -1;
+    return ret;
+}
+
+// ---- closestHit.rchit ---------------------------------------------------------------------------
+
+struct Vtx
+{
+    f3 Position;
+    f3 Normal, Tangent, Bitangent;
+};
+
+PT_DEV f3 xformPoint(const float *M, f3 p)
+{
+    return F3(((p.x * M[0] + p.y * M[1]) + p.z * M[2]) + M[3], ((p.x * M[4] + p.y * M[5]) + p.z * M[6]) + M[7],
+              ((p.x * M[8] + p.y * M[9]) + p.z * M[10]) + M[11]);
+}
+PT_DEV f3 xformVector(const float *M, f3 p)
+{
+    return F3((p.x * M[0] + p.y * M[1]) + p.z * M[2], (p.x * M[4] + p.y * M[5]) + p.z * M[6],
+              (p.x * M[8] + p.y * M[9]) + p.z * M[10]);
+}
+
+PT_DEV Vtx transformVertex(const DevPair &pr, Vtx v) // sampling.glsl:5-15
+{
+    v.Position = xformPoint(pr.M, v.Position);
+    v.Tangent = normalize(xformVector(pr.M, v.Tangent));
+    v.Bitangent = normalize(xformVector(pr.M, v.Bitangent));
+    v.Normal = normalize(F3(dot(v.Normal, F3(pr.Rinv[0], pr.Rinv[1], pr.Rinv[2])), dot(v.Normal, F3(pr.Rinv[3], pr.Rinv[4], pr.Rinv[5])),
+                            dot(v.Normal, F3(pr.Rinv[6], pr.Rinv[7], pr.Rinv[8]))));
+    return v;
+}
+
+PT_DEV Vtx loadVertex(const PtxVertex *p) // common.glsl:27-46
+{
+    Vtx v;
+    v.Position = ld3(p->Position);
+    v.Normal = ld3(p->Normal);
+    v.Tangent = ld3(p->Tangent);
+    v.Bitangent = ld3(p->Bitangent);
+    return v;
+}
+
+PT_DEV f3 interp3(f3 a, f3 b, f3 c, f3 bc) { return (a * bc.x + b * bc.y) + c * bc.z; } // common.glsl:107-110
+
+// What closestHit.rchit writes into the payload (ShaderRendererTypes.incl:101-118; ray
+// differentials feed only textureGrad and are not carried while textures are 1x1).
+struct HitOut
+{
+    f3 Position;
+    f3 Direction;
+    float MaxRoughness;
+    f3 Bsdf;
+    float Pdf;
+    f3 Emissive;
+    f3 DirectLight;
+    float DirectLightPdf;
+    f3 LightDirection;
+    float LightDistance;
+};
+
+// closestHit.rchit:52-161.  (u, v) = hitAttributeEXT barycentrics, t = gl_RayTmaxEXT.
+PT_DEV void closestHit(const SceneView &sv, f3 rayDirW, float t, float hu, float hv, uint32_t pairIdx, uint32_t prim,
+                       float maxRoughnessIn, uint32_t &rngState, HitOut &out)
+{
+    const f3 bary = F3(1.0f - hu - hv, hu, hv);
+    const DevPair pr = sv.pairs[pairIdx];
+    const uint32_t *ix = sv.indices + pr.indexOffset + prim * 3;
+    const PtxVertex *vb = sv.vertices + pr.vertexOffset;
+    const Vtx o0 = loadVertex(vb + ix[0]), o1 = loadVertex(vb + ix[1]), o2 = loadVertex(vb + ix[2]);
+
+    Vtx ov; // getInterpolatedVertex, common.glsl:112-130 (TexCoords unused with 1x1 textures)
+    ov.Position = interp3(o0.Position, o1.Position, o2.Position, bary);
+    ov.Normal = interp3(o0.Normal, o1.Normal, o2.Normal, bary);
+    ov.Tangent = interp3(o0.Tangent, o1.Tangent, o2.Tangent, bary);
+    ov.Bitangent = interp3(o0.Bitangent, o1.Bitangent, o2.Bitangent, bary);
+    Vtx vertex = transformVertex(pr, ov);
+
+    const Vtx v0 = transformVertex(pr, o0), v1 = transformVertex(pr, o1), v2 = transformVertex(pr, o2);
+
+    const f3 edge1 = v1.Position - v0.Position;
+    const f3 edge2 = v2.Position - v0.Position;
+    f3 geometricNormal = normalize(cross(edge1, edge2));
+
+    const bool isHitFromInside = dot(geometricNormal, rayDirW) > 0.0f;
+    if (isHitFromInside)
+    {
+        geometricNormal = -geometricNormal;
+        vertex.Normal = -vertex.Normal;
+        vertex.Tangent = -vertex.Tangent;
+        vertex.Bitangent = -vertex.Bitangent;
+    }
+
+    MaterialSample material = sampleMaterial(sv, pr.materialId, isHitFromInside);
+
+    // :105-106 decal mix: never taken for opaque geometry
+
+    out.MaxRoughness = fmax_(material.Roughness, maxRoughnessIn); // :109
+    material.Roughness = fmax_(out.MaxRoughness, 0.01f);          // :112
+
+    mat3 geometryTBN;
+    geometryTBN.c0 = vertex.Tangent;
+    geometryTBN.c1 = vertex.Bitangent;
+    geometryTBN.c2 = vertex.Normal;
+    const f3 N = normalize(vertex.Normal + mul(geometryTBN, material.Normal));
+    const mat3 TBN = computeTangentSpace(N);
+    const mat3 invTBN = inverse(TBN);
+    const f3 V = normalize(mul(invTBN, normalize(-rayDirW)));
+
+    BSDFSample bsdf = sampleBSDF(material, V, rngState);
+
+    if (isHitFromInside) // :123-128
+    {
+        const float e = t / material.AttenuationDistance;
+        bsdf.Color.x *= pow_(material.AttenuationColor.x, e);
+        bsdf.Color.y *= pow_(material.AttenuationColor.y, e);
+        bsdf.Color.z *= pow_(material.AttenuationColor.z, e);
+    }
+
+    const bool isRefracted = bsdf.Direction.z < 0.0f;
+    const f3 rayOrigin = offsetRayOriginShadowTerminator(vertex.Position, v0.Position, v0.Normal, v1.Position, v1.Normal,
+                                                         v2.Position, v2.Normal, bary, isRefracted);
+
+    float lightPdf, lightSmplPdf;
+    f3 u3;
+    u3.x = rnd(rngState);
+    u3.y = rnd(rngState);
+    u3.z = rnd(rngState);
+    const LightSample light = sampleLight(sv.lights, u3, rayOrigin, lightPdf);
+    const f3 L = normalize(mul(invTBN, -light.Direction));
+    const f3 lightBsdf = evaluateBSDF(material, V, L, lightSmplPdf);
+
+    out.Direction = normalize(mul(TBN, bsdf.Direction));
+    if (isRefracted)
+        out.Position = offsetRayOriginSelfIntersection(vertex.Position, -geometricNormal);
+    else
+        out.Position = rayOrigin;
+    out.Bsdf = bsdf.Color;
+    out.Pdf = bsdf.Pdf;
+    out.Emissive = material.EmissiveColor;
+    out.DirectLight = (light.Color * light.Attenuation) * lightBsdf;
+    out.DirectLightPdf = lightPdf;
+    out.LightDirection = light.Direction;
+    out.LightDistance = light.Distance;
+}
+
+// ---- ray / triangle --------------------------------------------------------------------------------
+
+// Moeller-Trumbore on (v0, e1, e2): the fixed stand-in for the driver's unspecified
+// ray-triangle test.  Hit iff det != 0, 0 <= u <= 1, v >= 0, u+v <= 1, tmin < t < tmax.
+PT_DEV bool intersectTri(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float tmin, float tmax, float &t, float &u, float &v)
+{
+    const f3 pvec = cross(d, e2);
+    const float det = dot(e1, pvec);
+    if (!(det != 0.0f))
+        return false;
+    const float inv = 1.0f / det;
+    const f3 tvec = o - v0;
+    const float uu = dot(tvec, pvec) * inv;
+    if (!(uu >= 0.0f && uu <= 1.0f))
+        return false;
+    const f3 qvec = cross(tvec, e1);
+    const float vv = dot(d, qvec) * inv;
+    if (!(vv >= 0.0f && uu + vv <= 1.0f))
+        return false;
+    const float tt = dot(e2, qvec) * inv;
+    if (!(tt > tmin && tt < tmax))
+        return false;
+    t = tt;
+    u = uu;
+    v = vv;
+    return true;
+}
+
+} // namespace ptd

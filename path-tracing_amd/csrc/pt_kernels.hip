@@ -1,0 +1,1389 @@
+// pt_kernels.hip -- HIP kernels of the path-tracing pass for gfx950 (MI355X) and the
+// C-ABI of include/ptx.h.
+//
+// The reference runs ONE ray-tracing pipeline dispatch per frame,
+//   vkCmdTraceRaysKHR(W, H, 1)            (Renderer/Renderer.cpp:911-917)
+// whose raygen shader (Shaders/raygen.rgen:36-118) loops over samples and bounces and
+// calls traceRayEXT twice per bounce (closest hit :68, occlusion :31).  Recursion depth
+// is 1, i.e. the path is an iterative loop in raygen: that loop is cut here at the two
+// traceRayEXT calls into a queue-per-stage WAVEFRONT:
+//
+//   k_generate        raygen.rgen:38-60   RNG seed, primary ray
+//   k_trace_closest   raygen.rgen:68      closest-hit query over the active queue
+//   k_shade           closestHit.rchit / miss.rmiss + raygen.rgen:71-96 bookkeeping
+//   k_trace_shadow    raygen.rgen:22-34,79-81  occlusion query + NEE add, path finish
+//   k_accumulate      raygen.rgen:115-117  image += radiance, in frame order
+//
+// Every path slot is (frame, pixel); its state lives in SoA arrays in HBM; queues hold
+// slot indices and are compacted by wave-aggregated atomics.  A bring-up MEGAKERNEL
+// (one thread per slot running the loop 1:1) shares all device functions and is kept as
+// the in-tree A/B reference of the wavefront.
+//
+// No CPU fallback exists: without a HIP device ptx_create fails.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pt_bvh.hpp"
+
+using namespace ptd;
+
+// =====================================================================================
+// Launch parameters
+// =====================================================================================
+
+struct Wavefront // device pointers of the per-slot state (SoA)
+{
+    float4 *rayO;   // origin.xyz, w = MaxRoughness (payload.MaxRoughness)
+    float4 *rayD;   // direction.xyz
+    float4 *thr;    // throughput.rgb
+    float4 *rad;    // radiance.rgb accumulated over the samples of this launch
+    uint4 *meta;    // x = rngState, y = pixel (y*W+x) or 0xffffffff, z = bounce | smpl<<16, w = frame
+    float4 *hit;    // t, u, v, prim (bits)
+    uint32_t *hitPair;
+    float4 *shO;    // shadow origin.xyz, w = tmax (LightDistance)
+    float4 *shD;    // shadow direction.xyz, w = 1 if the path ends after this bounce
+    float4 *shC;    // NEE contribution throughput * DirectLight / DirectLightPdf
+    float4 *slotRad; // final radiance of the slot (consumed by k_accumulate)
+    uint32_t *queue[2];
+    uint32_t *shadowQueue;
+    uint32_t *counters; // see enum Counter
+};
+
+enum Counter
+{
+    C_ACTIVE0 = 0,
+    C_ACTIVE1 = 1,
+    C_SHADOW = 2,
+    C_HITS = 3,      // closest-hit shader invocations (= occlusion queries of the reference)
+    C_SAMPLES = 4,   // completed pixel-samples incl. retries
+    C_RETRIES = 5,
+    C_SEGMENTS = 6,  // megakernel only
+    C_OVERFLOW = 7,
+    C_COUNT = 8
+};
+
+struct LaunchParams
+{
+    PtxRaygenUniformData u;
+    uint32_t width, height;
+    uint32_t rank, worldSize, tileSize, tilesX, numTiles, ownedTiles;
+    uint32_t slotsPerFrame; // ownedTiles * tileSize^2
+    uint32_t frames, firstFrame;
+    uint32_t numSlots;
+};
+
+// slot -> pixel.  Owned tiles are rank, rank+world, ...; inside a tile pixels are laid
+// out in 8x8 blocks so that one wave64 = one 8x8 pixel block (coherent primary rays).
+PT_DEV uint32_t slotPixel(const LaunchParams &p, uint32_t slotInFrame)
+{
+    const uint32_t ts = p.tileSize, perTile = ts * ts;
+    const uint32_t k = slotInFrame / perTile, o = slotInFrame % perTile;
+    const uint32_t tile = p.rank + k * p.worldSize;
+    const uint32_t bpr = ts / 8, blk = o / 64, ib = o % 64;
+    const uint32_t x = (tile % p.tilesX) * ts + (blk % bpr) * 8 + (ib % 8);
+    const uint32_t y = (tile / p.tilesX) * ts + (blk / bpr) * 8 + (ib / 8);
+    if (tile >= p.numTiles || x >= p.width || y >= p.height)
+        return 0xffffffffu;
+    return y * p.width + x;
+}
+
+// raygen.rgen:44-60: start one sample of a slot (jitter draws, primary ray)
+PT_DEV void startSample(const LaunchParams &p, uint32_t pixel, uint32_t &rng, f3 &origin, f3 &direction)
+{
+    f2 u;
+    u.x = rnd(rng);
+    u.y = rnd(rng);
+    const uint32_t px = pixel % p.width, py = pixel / p.width;
+    if (p.u.LensRadius > 0)
+    {
+        f2 u2;
+        u2.x = rnd(rng);
+        u2.y = rnd(rng);
+        constructPrimaryRayLens(px, py, p.width, p.height, p.u.ViewInverse, p.u.ProjInverse, u, u2, p.u.LensRadius,
+                                p.u.FocalDistance, origin, direction);
+    }
+    else
+        constructPrimaryRay(px, py, p.width, p.height, p.u.ViewInverse, p.u.ProjInverse, u, origin, direction);
+}
+
+PT_DEV bool badRadiance(f3 r) // raygen.rgen:101,107
+{
+    return __builtin_isnan(r.x) || __builtin_isnan(r.y) || __builtin_isnan(r.z) || __builtin_isinf(r.x) ||
+           __builtin_isinf(r.y) || __builtin_isinf(r.z);
+}
+
+// =====================================================================================
+// Wavefront kernels
+// =====================================================================================
+
+constexpr int kBlock = 256;
+
+__global__ void __launch_bounds__(kBlock) k_generate(LaunchParams p, Wavefront wf)
+{
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < p.numSlots; slot += gridDim.x * blockDim.x)
+    {
+        const uint32_t f = slot / p.slotsPerFrame, s = slot % p.slotsPerFrame;
+        const uint32_t pixel = slotPixel(p, s);
+        const uint32_t frame = p.firstFrame + f;
+        uint4 meta = make_uint4(0u, pixel, 0u, frame);
+        if (pixel != 0xffffffffu)
+        {
+            uint32_t rng = initRng(pixel % p.width, pixel / p.width, p.width, frame); // raygen.rgen:38
+            f3 o, d;
+            startSample(p, pixel, rng, o, d);
+            meta.x = rng;
+            wf.rayO[slot] = make_float4(o.x, o.y, o.z, 0.0f); // MaxRoughness = 0, raygen.rgen:60
+            wf.rayD[slot] = make_float4(d.x, d.y, d.z, 0.0f);
+            wf.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+            wf.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const uint32_t qi = atomicAdd(&wf.counters[C_ACTIVE0], 1u);
+            wf.queue[0][qi] = slot;
+        }
+        else
+            wf.slotRad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        wf.meta[slot] = meta;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_trace_closest(TraceScene sc, Wavefront wf, int qin)
+{
+    __shared__ uint32_t s_stack[kLdsStack][kBlock];
+    Stack st;
+    st.lds = &s_stack[0][threadIdx.x];
+    st.stride = kBlock;
+    const uint32_t count = wf.counters[qin];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
+    {
+        const uint32_t slot = wf.queue[qin][i];
+        const float4 o = wf.rayO[slot], d = wf.rayD[slot];
+        Hit h;
+        // ray.glsl:79-80: tmin = 1e-5, tmax = 1e4 on every segment
+        traceRay<false>(sc, F3(o.x, o.y, o.z), F3(d.x, d.y, d.z), 0.00001f, 10000.0f, st, h);
+        wf.hit[slot] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
+        wf.hitPair[slot] = h.pair;
+    }
+}
+
+// raygen.rgen:99-112 + sample loop control for a slot whose path has ended.
+// Returns true if the slot continues (new primary ray written, caller enqueues it).
+PT_DEV bool finishSample(const LaunchParams &p, const Wavefront &wf, uint32_t slot, uint4 &meta, f3 &radiance)
+{
+    uint32_t smpl = meta.z >> 16;
+    atomicAdd(&wf.counters[C_SAMPLES], 1u);
+    if (badRadiance(radiance))
+    {
+        radiance = F3s(0.0f);
+        smpl = 0; // "smpl = -1; continue" restarts ALL samples of the launch, RNG carried on
+        atomicAdd(&wf.counters[C_RETRIES], 1u);
+    }
+    else
+        smpl = smpl + 1;
+    if (smpl < p.u.SampleCount)
+    {
+        f3 o, d;
+        startSample(p, meta.y, meta.x, o, d);
+        meta.z = smpl << 16; // bounce = 0
+        wf.rayO[slot] = make_float4(o.x, o.y, o.z, 0.0f);
+        wf.rayD[slot] = make_float4(d.x, d.y, d.z, 0.0f);
+        wf.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        wf.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+        return true;
+    }
+    wf.slotRad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+    return false;
+}
+
+__global__ void __launch_bounds__(kBlock) k_shade(LaunchParams p, SceneView sv, Wavefront wf, int qin)
+{
+    const int qout = qin ^ 1;
+    const uint32_t count = wf.counters[qin];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
+    {
+        const uint32_t slot = wf.queue[qin][i];
+        uint4 meta = wf.meta[slot];
+        const float4 hit = wf.hit[slot];
+        const uint32_t pair = wf.hitPair[slot];
+        const float4 r4 = wf.rad[slot], t4 = wf.thr[slot];
+        f3 radiance = F3(r4.x, r4.y, r4.z), throughput = F3(t4.x, t4.y, t4.z);
+
+        if (pair == 0xffffffffu)
+        {
+            // miss.rmiss:37-39 (MissFlagsNone): constant sky, Pdf = -1 -> raygen.rgen:71-75
+            radiance = radiance + throughput * F3(0.08f, 0.09f, 0.1f);
+            if (finishSample(p, wf, slot, meta, radiance))
+                wf.queue[qout][atomicAdd(&wf.counters[qout], 1u)] = slot;
+            wf.meta[slot] = meta;
+            continue;
+        }
+
+        const float4 o4 = wf.rayO[slot], d4 = wf.rayD[slot];
+        HitOut out;
+        closestHit(sv, F3(d4.x, d4.y, d4.z), hit.x, hit.y, hit.z, pair, __float_as_uint(hit.w), o4.w, meta.x, out);
+        atomicAdd(&wf.counters[C_HITS], 1u);
+
+        radiance = radiance + throughput * out.Emissive; // raygen.rgen:77
+
+        // raygen.rgen:79-81, evaluated with the pre-update throughput
+        f3 contribution = F3s(0.0f);
+        bool wantShadow = false;
+        if (out.DirectLightPdf > 0.0f)
+        {
+            contribution = (throughput * out.DirectLight) / out.DirectLightPdf;
+            // adding an exact zero cannot change radiance (it is never -0): skip the query
+            wantShadow = !(contribution.x == 0.0f && contribution.y == 0.0f && contribution.z == 0.0f);
+        }
+
+        if (out.Pdf > 0.001f) // :83-84
+            throughput = throughput * (out.Bsdf / out.Pdf);
+
+        bool finished = false;
+        const float prob = fmin_(maxComponent(throughput), 1.0f); // :86
+        uint32_t bounce = meta.z & 0xffffu;
+        if (prob < 0.001f)
+            finished = true;
+        else if (prob < rnd(meta.x)) // :90
+            finished = true;
+        else
+        {
+            throughput = throughput / prob; // :93
+            bounce = bounce + 1;
+            if (bounce >= p.u.BounceCount)
+                finished = true;
+        }
+        meta.z = (meta.z & 0xffff0000u) | bounce;
+
+        if (wantShadow)
+        {
+            const f3 sd = -normalize(out.LightDirection); // raygen.rgen:24
+            wf.shO[slot] = make_float4(out.Position.x, out.Position.y, out.Position.z, out.LightDistance);
+            wf.shD[slot] = make_float4(sd.x, sd.y, sd.z, finished ? 1.0f : 0.0f);
+            wf.shC[slot] = make_float4(contribution.x, contribution.y, contribution.z, 0.0f);
+            wf.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+            if (!finished)
+            {
+                wf.rayO[slot] = make_float4(out.Position.x, out.Position.y, out.Position.z, out.MaxRoughness);
+                wf.rayD[slot] = make_float4(out.Direction.x, out.Direction.y, out.Direction.z, 0.0f);
+                wf.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, 0.0f);
+            }
+            wf.shadowQueue[atomicAdd(&wf.counters[C_SHADOW], 1u)] = slot;
+        }
+        else if (finished)
+        {
+            if (finishSample(p, wf, slot, meta, radiance))
+                wf.queue[qout][atomicAdd(&wf.counters[qout], 1u)] = slot;
+        }
+        else
+        {
+            wf.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+            wf.rayO[slot] = make_float4(out.Position.x, out.Position.y, out.Position.z, out.MaxRoughness);
+            wf.rayD[slot] = make_float4(out.Direction.x, out.Direction.y, out.Direction.z, 0.0f);
+            wf.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, 0.0f);
+            wf.queue[qout][atomicAdd(&wf.counters[qout], 1u)] = slot;
+        }
+        wf.meta[slot] = meta;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_trace_shadow(LaunchParams p, TraceScene sc, Wavefront wf, int qout)
+{
+    __shared__ uint32_t s_stack[kLdsStack][kBlock];
+    Stack st;
+    st.lds = &s_stack[0][threadIdx.x];
+    st.stride = kBlock;
+    const uint32_t count = wf.counters[C_SHADOW];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
+    {
+        const uint32_t slot = wf.shadowQueue[i];
+        const float4 o = wf.shO[slot], d = wf.shD[slot];
+        Hit h;
+        // raygen.rgen:26-31: tmin = 1e-5, tmax = LightDistance, terminate on first hit
+        const bool occluded = traceRay<true>(sc, F3(o.x, o.y, o.z), F3(d.x, d.y, d.z), 0.00001f, o.w, st, h);
+        float4 r4 = wf.rad[slot];
+        if (!occluded)
+        {
+            const float4 c = wf.shC[slot];
+            r4.x = r4.x + c.x;
+            r4.y = r4.y + c.y;
+            r4.z = r4.z + c.z;
+        }
+        if (d.w != 0.0f)
+        {
+            uint4 meta = wf.meta[slot];
+            f3 radiance = F3(r4.x, r4.y, r4.z);
+            if (finishSample(p, wf, slot, meta, radiance))
+                wf.queue[qout][atomicAdd(&wf.counters[qout], 1u)] = slot;
+            wf.meta[slot] = meta;
+        }
+        else
+        {
+            wf.rad[slot] = r4;
+            wf.queue[qout][atomicAdd(&wf.counters[qout], 1u)] = slot;
+        }
+    }
+}
+
+// raygen.rgen:115-117 for `frames` launches in frame order: bit-identical to issuing the
+// launches one after another.
+__global__ void __launch_bounds__(kBlock) k_accumulate(LaunchParams p, const float4 *__restrict__ slotRad, float4 *__restrict__ image)
+{
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < p.slotsPerFrame; s += gridDim.x * blockDim.x)
+    {
+        const uint32_t pixel = slotPixel(p, s);
+        if (pixel == 0xffffffffu)
+            continue;
+        float4 acc = image[pixel];
+        for (uint32_t f = 0; f < p.frames; f++)
+        {
+            const float4 r = slotRad[f * p.slotsPerFrame + s];
+            acc.x = r.x + acc.x;
+            acc.y = r.y + acc.y;
+            acc.z = r.z + acc.z;
+        }
+        acc.w = 1.0f;
+        image[pixel] = acc;
+    }
+}
+
+// =====================================================================================
+// Megakernel (bring-up / A-B reference): raygen.rgen:36-118 one thread per slot
+// =====================================================================================
+
+__global__ void __launch_bounds__(kBlock) k_megakernel(LaunchParams p, SceneView sv, TraceScene sc, float4 *__restrict__ slotRad,
+                                                        uint32_t *__restrict__ counters)
+{
+    __shared__ uint32_t s_stack[kLdsStack][kBlock];
+    Stack st;
+    st.lds = &s_stack[0][threadIdx.x];
+    st.stride = kBlock;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= p.numSlots)
+        return;
+    const uint32_t f = slot / p.slotsPerFrame, s = slot % p.slotsPerFrame;
+    const uint32_t pixel = slotPixel(p, s);
+    if (pixel == 0xffffffffu)
+    {
+        slotRad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        return;
+    }
+    uint32_t rng = initRng(pixel % p.width, pixel / p.width, p.width, p.firstFrame + f);
+    f3 radiance = F3s(0.0f);
+    uint32_t nSeg = 0, nHit = 0, nSmp = 0, nRetry = 0;
+    for (int smpl = 0; smpl < (int)p.u.SampleCount; smpl++)
+    {
+        f3 throughput = F3s(1.0f);
+        f3 ro, rd;
+        startSample(p, pixel, rng, ro, rd);
+        float maxRoughness = 0.0f;
+        for (uint32_t bounce = 0; bounce < p.u.BounceCount; bounce++)
+        {
+            Hit h;
+            nSeg++;
+            if (!traceRay<false>(sc, ro, rd, 0.00001f, 10000.0f, st, h))
+            {
+                radiance = radiance + throughput * F3(0.08f, 0.09f, 0.1f);
+                break;
+            }
+            HitOut out;
+            closestHit(sv, rd, h.t, h.u, h.v, h.pair, h.prim, maxRoughness, rng, out);
+            nHit++;
+            maxRoughness = out.MaxRoughness;
+            radiance = radiance + throughput * out.Emissive;
+            if (out.DirectLightPdf > 0.0f)
+            {
+                const f3 c = (throughput * out.DirectLight) / out.DirectLightPdf;
+                if (!(c.x == 0.0f && c.y == 0.0f && c.z == 0.0f))
+                {
+                    Hit sh;
+                    if (!traceRay<true>(sc, out.Position, -normalize(out.LightDirection), 0.00001f, out.LightDistance, st, sh))
+                        radiance = radiance + c;
+                }
+            }
+            if (out.Pdf > 0.001f)
+                throughput = throughput * (out.Bsdf / out.Pdf);
+            const float prob = fmin_(maxComponent(throughput), 1.0f);
+            if (prob < 0.001f)
+                break;
+            if (prob < rnd(rng))
+                break;
+            throughput = throughput / prob;
+            ro = out.Position;
+            rd = out.Direction;
+        }
+        nSmp++;
+        if (badRadiance(radiance))
+        {
+            radiance = F3s(0.0f);
+            smpl = -1;
+            nRetry++;
+            continue;
+        }
+    }
+    slotRad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+    atomicAdd(&counters[C_SEGMENTS], nSeg);
+    atomicAdd(&counters[C_HITS], nHit);
+    atomicAdd(&counters[C_SAMPLES], nSmp);
+    atomicAdd(&counters[C_RETRIES], nRetry);
+}
+
+// =====================================================================================
+// Utility kernels
+// =====================================================================================
+
+// traceRayEXT stand-in over explicit rays (o.xyz, tmin, d.xyz, tmax): traversal parity tests
+__global__ void __launch_bounds__(kBlock) k_trace_rays(TraceScene sc, const float4 *__restrict__ rays, uint32_t n, int anyHit,
+                                                        float4 *__restrict__ outHit, uint2 *__restrict__ outIds)
+{
+    __shared__ uint32_t s_stack[kLdsStack][kBlock];
+    Stack st;
+    st.lds = &s_stack[0][threadIdx.x];
+    st.stride = kBlock;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    {
+        const float4 o = rays[2 * i], d = rays[2 * i + 1];
+        Hit h;
+        bool hitAny;
+        if (anyHit)
+            hitAny = traceRay<true>(sc, F3(o.x, o.y, o.z), F3(d.x, d.y, d.z), o.w, d.w, st, h);
+        else
+            hitAny = traceRay<false>(sc, F3(o.x, o.y, o.z), F3(d.x, d.y, d.z), o.w, d.w, st, h);
+        outHit[i] = make_float4(h.t, h.u, h.v, hitAny ? 1.0f : 0.0f);
+        outIds[i] = make_uint2(h.pair, h.prim);
+    }
+}
+
+// shard pack / unpack: tile-major dense buffer [ownedTile][tileSize^2] of RGBA32F
+__global__ void k_pack_shard(LaunchParams p, const float4 *__restrict__ image, float4 *__restrict__ dst)
+{
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < p.slotsPerFrame; s += gridDim.x * blockDim.x)
+    {
+        const uint32_t pixel = slotPixel(p, s);
+        dst[s] = pixel == 0xffffffffu ? make_float4(0, 0, 0, 0) : image[pixel];
+    }
+}
+__global__ void k_unpack_shard(LaunchParams p, const float4 *__restrict__ src, float4 *__restrict__ image)
+{
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < p.slotsPerFrame; s += gridDim.x * blockDim.x)
+    {
+        const uint32_t pixel = slotPixel(p, s);
+        if (pixel != 0xffffffffu)
+            image[pixel] = src[s];
+    }
+}
+
+// function-level entry (Path-Tracing-Tests/TestRenderer.cpp:79-105 dispatches a compute
+// shader that calls the production functions; packing documented in include/ptx.h)
+__constant__ int c_inStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42 };
+__constant__ int c_outStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 6, 2, 1, 9, 3, 6 };
+static const int h_inStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42 };
+static const int h_outStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 6, 2, 1, 9, 3, 6 };
+
+PT_DEV MaterialSample unpackMaterial(const float *p)
+{
+    MaterialSample m;
+    m.EmissiveColor = m.Normal = m.AttenuationColor = F3s(0.0f);
+    m.AttenuationDistance = 0.0f;
+    m.Color = F3(p[0], p[1], p[2]);
+    m.Roughness = p[3];
+    m.Metalness = p[4];
+    m.Transmission = p[5];
+    m.Eta = p[6];
+    return m;
+}
+
+__global__ void k_test_eval(uint32_t fn, const float *__restrict__ in, float *__restrict__ out, uint32_t n, PtxLightsUbo *scratchUbo)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const float *a = in + (size_t)i * c_inStride[fn];
+    float *o = out + (size_t)i * c_outStride[fn];
+    switch (fn)
+    {
+    case PTX_FN_GGX_DISTRIBUTION: o[0] = GGXDistribution(F3(a[0], a[1], a[2]), a[3]); break;
+    case PTX_FN_LAMBDA: o[0] = Lambda(F3(a[0], a[1], a[2]), a[3]); break;
+    case PTX_FN_GGX_SMITH: o[0] = GGXSmith(F3(a[0], a[1], a[2]), a[3]); break;
+    case PTX_FN_DIELECTRIC_FRESNEL: o[0] = DielectricFresnel(a[0], a[1]); break;
+    case PTX_FN_SCHLICK_FRESNEL: o[0] = SchlickFresnel(a[0]); break;
+    case PTX_FN_EVALUATE_REFLECTION: {
+        float pdf;
+        const f3 r = EvaluateReflection(F3(a[0], a[1], a[2]), F3(a[3], a[4], a[5]), F3(a[6], a[7], a[8]), a[9], pdf);
+        o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = pdf;
+        break;
+    }
+    case PTX_FN_EVALUATE_REFRACTION: {
+        float pdf;
+        const f3 r = EvaluateRefraction(F3(a[0], a[1], a[2]), F3(a[3], a[4], a[5]), F3(a[6], a[7], a[8]), a[9], a[10], pdf);
+        o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = pdf;
+        break;
+    }
+    case PTX_FN_SAMPLE_GGX: {
+        f2 u; u.x = a[0]; u.y = a[1];
+        const f3 r = SampleGGX(u, F3(a[2], a[3], a[4]), a[5]);
+        o[0] = r.x; o[1] = r.y; o[2] = r.z;
+        break;
+    }
+    case PTX_FN_SAMPLE_LOBE_PDFS: { // bsdf.glsl:62-70
+        const float metal = a[0], trans = a[1], F = a[2];
+        o[0] = (1.0f - metal) * (1.0f - F) * (1.0f - trans);
+        o[1] = (1.0f - metal) * F;
+        o[2] = metal;
+        o[3] = (1.0f - metal) * (1.0f - F) * trans;
+        break;
+    }
+    case PTX_FN_EVALUATE_BSDF: {
+        const MaterialSample m = unpackMaterial(a);
+        float pdf;
+        const f3 r = evaluateBSDF(m, F3(a[8], a[9], a[10]), F3(a[11], a[12], a[13]), pdf);
+        o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = pdf;
+        break;
+    }
+    case PTX_FN_SAMPLE_BSDF: {
+        const MaterialSample m = unpackMaterial(a);
+        uint32_t rng = __float_as_uint(a[11]);
+        const BSDFSample r = sampleBSDF(m, F3(a[8], a[9], a[10]), rng);
+        o[0] = r.Direction.x; o[1] = r.Direction.y; o[2] = r.Direction.z; o[3] = r.Pdf;
+        o[4] = r.Color.x; o[5] = r.Color.y; o[6] = r.Color.z; o[7] = __uint_as_float(rng);
+        break;
+    }
+    case PTX_FN_RNG: {
+        uint32_t stt = initRng(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3]));
+        o[0] = __uint_as_float(stt);
+        for (int k = 0; k < 4; k++)
+            o[1 + k] = rnd(stt);
+        break;
+    }
+    case PTX_FN_DISK: {
+        f2 u; u.x = a[0]; u.y = a[1];
+        const f2 d = sampleUniformDiskConcentric(u);
+        o[0] = d.x; o[1] = d.y;
+        break;
+    }
+    case PTX_FN_COS_HEMISPHERE: {
+        f2 u; u.x = a[0]; u.y = a[1];
+        const f3 d = sampleCosineHemisphere(u);
+        o[0] = d.x; o[1] = d.y; o[2] = d.z;
+        break;
+    }
+    case PTX_FN_TANGENT_SPACE: {
+        const mat3 m = computeTangentSpace(F3(a[0], a[1], a[2]));
+        o[0] = m.c0.x; o[1] = m.c0.y; o[2] = m.c0.z;
+        o[3] = m.c1.x; o[4] = m.c1.y; o[5] = m.c1.z;
+        o[6] = m.c2.x; o[7] = m.c2.y; o[8] = m.c2.z;
+        break;
+    }
+    case PTX_FN_OFFSET_SELF_INTERSECTION: {
+        const f3 r = offsetRayOriginSelfIntersection(F3(a[0], a[1], a[2]), F3(a[3], a[4], a[5]));
+        o[0] = r.x; o[1] = r.y; o[2] = r.z;
+        break;
+    }
+    case PTX_FN_PRIMARY_RAY: {
+        f2 u; u.x = a[4]; u.y = a[5];
+        f3 ro, rd;
+        constructPrimaryRay(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3]), &a[6], &a[22], u, ro, rd);
+        o[0] = ro.x; o[1] = ro.y; o[2] = ro.z; o[3] = rd.x; o[4] = rd.y; o[5] = rd.z;
+        break;
+    }
+    case PTX_FN_SINCOS: sincos_(a[0], o[0], o[1]); break;
+    case PTX_FN_POW: o[0] = pow_(a[0], a[1]); break;
+    case PTX_FN_SAMPLE_LIGHT: {
+        PtxLightsUbo *ubo = &scratchUbo[i];
+        ubo->LightCount = __float_as_uint(a[6]);
+        for (int k = 0; k < 3; k++)
+        {
+            ubo->Directional.Color[k] = a[7 + k];
+            ubo->Directional.Direction[k] = a[10 + k];
+        }
+        for (int l = 0; l < 2; l++)
+        {
+            for (int k = 0; k < 3; k++)
+            {
+                ubo->Lights[l].Color[k] = a[13 + 9 * l + k];
+                ubo->Lights[l].Position[k] = a[16 + 9 * l + k];
+            }
+            ubo->Lights[l].AttenuationConstant = a[19 + 9 * l];
+            ubo->Lights[l].AttenuationLinear = a[20 + 9 * l];
+            ubo->Lights[l].AttenuationQuadratic = a[21 + 9 * l];
+        }
+        float pdf;
+        const LightSample ls = sampleLight(ubo, F3(a[0], a[1], a[2]), F3(a[3], a[4], a[5]), pdf);
+        o[0] = ls.Direction.x; o[1] = ls.Direction.y; o[2] = ls.Direction.z; o[3] = ls.Distance;
+        o[4] = ls.Color.x; o[5] = ls.Color.y; o[6] = ls.Color.z; o[7] = ls.Attenuation; o[8] = pdf;
+        break;
+    }
+    case PTX_FN_SHADOW_TERMINATOR: {
+        const f3 r = offsetRayOriginShadowTerminator(F3(a[0], a[1], a[2]), F3(a[3], a[4], a[5]), F3(a[6], a[7], a[8]), F3(a[9], a[10], a[11]),
+                                                     F3(a[12], a[13], a[14]), F3(a[15], a[16], a[17]), F3(a[18], a[19], a[20]),
+                                                     F3(a[21], a[22], a[23]), a[24] != 0.0f);
+        o[0] = r.x; o[1] = r.y; o[2] = r.z;
+        break;
+    }
+    case PTX_FN_PRIMARY_RAY_LENS: {
+        f2 u, u2; u.x = a[4]; u.y = a[5]; u2.x = a[6]; u2.y = a[7];
+        f3 ro, rd;
+        constructPrimaryRayLens(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3]), &a[10], &a[26],
+                                u, u2, a[8], a[9], ro, rd);
+        o[0] = ro.x; o[1] = ro.y; o[2] = ro.z; o[3] = rd.x; o[4] = rd.y; o[5] = rd.z;
+        break;
+    }
+    default: break;
+    }
+}
+
+// =====================================================================================
+// Host side: the renderer object behind the C-ABI
+// =====================================================================================
+
+template <typename T> struct DevBuf
+{
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count)
+    {
+        if (count <= n && p)
+            return hipSuccess;
+        release();
+        const hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), (count ? count : 1) * sizeof(T));
+        if (e == hipSuccess)
+            n = count;
+        else
+            p = nullptr;
+        return e;
+    }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+struct PtxRenderer
+{
+    int device = 0;
+    uint32_t backend = PTX_BACKEND_WAVEFRONT;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    std::string error;
+
+    // scene (HBM copies of the Scene getters)
+    DevBuf<PtxVertex> vertices;
+    DevBuf<uint32_t> indices;
+    DevBuf<PtxMetallicRoughnessMaterial> mr;
+    DevBuf<PtxSpecularGlossinessMaterial> sg;
+    DevBuf<PtxPhongMaterial> phong;
+    DevBuf<DevPair> pairs;
+    DevBuf<uint32_t> pairFirst;
+    DevBuf<PtxLightsUbo> lights;
+    uint32_t pairCount = 0, triCount = 0, dxNormalTextures = 0;
+    bool sceneReady = false, accelReady = false;
+
+    // accel
+    DevBuf<BvhNode> nodes;
+    DevBuf<Tri> tris;
+
+    // frame
+    uint32_t width = 0, height = 0;
+    PtxTileShard shard = { 0, 1, 32 };
+    DevBuf<float4> image;
+    float4 *boundImage = nullptr; // external accumulation buffer, if bound
+
+    // wavefront state
+    size_t slotCapacity = 0;
+    DevBuf<float4> rayO, rayD, thr, rad, hit, shO, shD, shC, slotRad;
+    DevBuf<uint4> meta;
+    DevBuf<uint32_t> hitPair, queue0, queue1, shadowQueue, counters;
+    uint32_t *hostCounters = nullptr; // pinned
+
+    DevBuf<float> testIn, testOut;
+    DevBuf<PtxLightsUbo> testUbo;
+
+    hipEvent_t evA = nullptr, evB = nullptr, evT0 = nullptr, evT1 = nullptr;
+    PtxStats stats = {};
+};
+
+static int fail(PtxRenderer *r, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (r)
+        r->error = buf;
+    return code;
+}
+
+#define HIP_TRY(r, expr)                                                                                                   \
+    do                                                                                                                     \
+    {                                                                                                                      \
+        const hipError_t e_ = (expr);                                                                                      \
+        if (e_ != hipSuccess)                                                                                              \
+            return fail(r, e_ == hipErrorOutOfMemory ? PTX_ERROR_OUT_OF_MEMORY : PTX_ERROR_DEVICE, "%s: %s", #expr,       \
+                        hipGetErrorString(e_));                                                                            \
+    } while (0)
+
+static float4 *imagePtr(PtxRenderer *r)
+{
+    return r->boundImage ? r->boundImage : r->image.p;
+}
+
+static uint32_t gridFor(size_t n, uint32_t block = kBlock, uint32_t cap = 256 * 8)
+{
+    size_t g = (n + block - 1) / block;
+    if (g < 1)
+        g = 1;
+    if (g > cap)
+        g = cap;
+    return static_cast<uint32_t>(g);
+}
+
+static LaunchParams makeParams(const PtxRenderer *r, const PtxRaygenUniformData *u, uint32_t firstFrame, uint32_t frames)
+{
+    LaunchParams p;
+    std::memset(&p, 0, sizeof(p));
+    if (u)
+        p.u = *u;
+    p.width = r->width;
+    p.height = r->height;
+    p.rank = r->shard.rank;
+    p.worldSize = r->shard.worldSize;
+    p.tileSize = r->shard.tileSize;
+    p.tilesX = (r->width + p.tileSize - 1) / p.tileSize;
+    const uint32_t tilesY = (r->height + p.tileSize - 1) / p.tileSize;
+    p.numTiles = p.tilesX * tilesY;
+    p.ownedTiles = p.numTiles > p.rank ? (p.numTiles - p.rank + p.worldSize - 1) / p.worldSize : 0;
+    p.slotsPerFrame = p.ownedTiles * p.tileSize * p.tileSize;
+    p.frames = frames;
+    p.firstFrame = firstFrame;
+    p.numSlots = p.slotsPerFrame * frames;
+    return p;
+}
+
+extern "C" {
+
+int ptx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+int ptx_create(const PtxDeviceDesc *desc, PtxRenderer **out)
+{
+    if (!out)
+        return PTX_ERROR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return PTX_ERROR_NO_DEVICE; // no CPU fallback: the product path needs a HIP device
+    PtxRenderer *r = new PtxRenderer;
+    r->device = desc ? desc->deviceIndex : 0;
+    r->backend = desc ? desc->backend : PTX_BACKEND_WAVEFRONT;
+    if (r->device < 0 || r->device >= n || hipSetDevice(r->device) != hipSuccess)
+    {
+        delete r;
+        return PTX_ERROR_NO_DEVICE;
+    }
+    if (desc && desc->stream)
+        r->stream = static_cast<hipStream_t>(desc->stream);
+    else
+    {
+        if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess)
+        {
+            delete r;
+            return PTX_ERROR_DEVICE;
+        }
+        r->ownStream = true;
+    }
+    (void)hipEventCreate(&r->evA);
+    (void)hipEventCreate(&r->evB);
+    (void)hipEventCreate(&r->evT0);
+    (void)hipEventCreate(&r->evT1);
+    (void)hipHostMalloc(reinterpret_cast<void **>(&r->hostCounters), C_COUNT * sizeof(uint32_t), hipHostMallocDefault);
+    if (r->counters.alloc(C_COUNT) != hipSuccess || r->lights.alloc(1) != hipSuccess || !r->hostCounters)
+    {
+        ptx_destroy(r);
+        return PTX_ERROR_OUT_OF_MEMORY;
+    }
+    *out = r;
+    return PTX_OK;
+}
+
+void ptx_destroy(PtxRenderer *r)
+{
+    if (!r)
+        return;
+    (void)hipSetDevice(r->device);
+    if (r->stream)
+        (void)hipStreamSynchronize(r->stream);
+    r->vertices.release(); r->indices.release(); r->mr.release(); r->sg.release(); r->phong.release();
+    r->pairs.release(); r->pairFirst.release(); r->lights.release(); r->nodes.release(); r->tris.release();
+    r->image.release(); r->rayO.release(); r->rayD.release(); r->thr.release(); r->rad.release(); r->hit.release();
+    r->shO.release(); r->shD.release(); r->shC.release(); r->slotRad.release(); r->meta.release(); r->hitPair.release();
+    r->queue0.release(); r->queue1.release(); r->shadowQueue.release(); r->counters.release();
+    r->testIn.release(); r->testOut.release(); r->testUbo.release();
+    if (r->hostCounters)
+        (void)hipHostFree(r->hostCounters);
+    if (r->evA) (void)hipEventDestroy(r->evA);
+    if (r->evB) (void)hipEventDestroy(r->evB);
+    if (r->evT0) (void)hipEventDestroy(r->evT0);
+    if (r->evT1) (void)hipEventDestroy(r->evT1);
+    if (r->ownStream && r->stream)
+        (void)hipStreamDestroy(r->stream);
+    delete r;
+}
+
+const char *ptx_last_error(const PtxRenderer *r)
+{
+    return r ? r->error.c_str() : "null renderer";
+}
+
+int ptx_set_backend(PtxRenderer *r, uint32_t backend)
+{
+    if (!r || backend > PTX_BACKEND_MEGAKERNEL)
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_set_backend: bad backend %u", backend);
+    r->backend = backend;
+    return PTX_OK;
+}
+
+} // extern "C"
+
+// world = A_instance * A_mesh * x (sampling.glsl:7)
+static void composeTransform(const float *Ai, const float *Am, float *M)
+{
+    for (int r = 0; r < 3; r++)
+    {
+        for (int c = 0; c < 3; c++)
+            M[r * 4 + c] = (Ai[r * 4 + 0] * Am[0 * 4 + c] + Ai[r * 4 + 1] * Am[1 * 4 + c]) + Ai[r * 4 + 2] * Am[2 * 4 + c];
+        M[r * 4 + 3] = ((Ai[r * 4 + 0] * Am[0 * 4 + 3] + Ai[r * 4 + 1] * Am[1 * 4 + 3]) + Ai[r * 4 + 2] * Am[2 * 4 + 3]) + Ai[r * 4 + 3];
+    }
+}
+
+// inverse of the 3x3 linear part by cofactors * (1/det), columns out
+static void inverseLinear(const float *M, float *Rinv)
+{
+    const float m00 = M[0], m01 = M[4], m02 = M[8]; // column 0 of the math matrix
+    const float m10 = M[1], m11 = M[5], m12 = M[9];
+    const float m20 = M[2], m21 = M[6], m22 = M[10];
+    const float det = (m00 * (m11 * m22 - m21 * m12) - m10 * (m01 * m22 - m21 * m02)) + m20 * (m01 * m12 - m11 * m02);
+    const float id = 1.0f / det;
+    Rinv[0] = (m11 * m22 - m21 * m12) * id;
+    Rinv[3] = -(m10 * m22 - m20 * m12) * id;
+    Rinv[6] = (m10 * m21 - m20 * m11) * id;
+    Rinv[1] = -(m01 * m22 - m21 * m02) * id;
+    Rinv[4] = (m00 * m22 - m20 * m02) * id;
+    Rinv[7] = -(m00 * m21 - m20 * m01) * id;
+    Rinv[2] = (m01 * m12 - m11 * m02) * id;
+    Rinv[5] = -(m00 * m12 - m10 * m02) * id;
+    Rinv[8] = (m00 * m11 - m10 * m01) * id;
+}
+
+template <typename T> static int upload(PtxRenderer *r, DevBuf<T> &buf, const T *src, size_t count)
+{
+    HIP_TRY(r, buf.alloc(count));
+    if (count)
+        HIP_TRY(r, hipMemcpyAsync(buf.p, src, count * sizeof(T), hipMemcpyHostToDevice, r->stream));
+    return PTX_OK;
+}
+
+extern "C" {
+
+int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *s)
+{
+    if (!r || !s)
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_scene_upload: null argument");
+    HIP_TRY(r, hipSetDevice(r->device));
+    r->sceneReady = r->accelReady = false;
+
+    // validate indices the kernels will dereference (the reference trusts its importer)
+    for (uint32_t i = 0; i < s->instanceCount; i++)
+        if (s->instances[i].ModelIndex >= s->modelCount)
+            return fail(r, PTX_ERROR_INVALID_ARGUMENT, "instance %u: model index out of range", i);
+    for (uint32_t m = 0; m < s->modelCount; m++)
+        if ((uint64_t)s->models[m].MeshOffset + s->models[m].MeshCount > s->meshCount)
+            return fail(r, PTX_ERROR_INVALID_ARGUMENT, "model %u: mesh range out of bounds", m);
+    for (uint32_t k = 0; k < s->meshCount; k++)
+    {
+        const PtxMeshRecord &rec = s->meshes[k];
+        if (rec.GeometryIndex >= s->geometryCount || rec.TransformIndex >= s->transformCount)
+            return fail(r, PTX_ERROR_INVALID_ARGUMENT, "mesh %u: geometry/transform index out of range", k);
+        const uint32_t type = rec.MaterialId & 0xffu, index = rec.MaterialId >> 8;
+        const uint32_t limit = type == PTX_MATERIAL_TYPE_METALLIC_ROUGHNESS    ? s->metallicRoughnessMaterialCount
+                               : type == PTX_MATERIAL_TYPE_SPECULAR_GLOSSINESS ? s->specularGlossinessMaterialCount
+                               : type == PTX_MATERIAL_TYPE_PHONG               ? s->phongMaterialCount
+                                                                               : 0xffffffffu;
+        if (type <= PTX_MATERIAL_TYPE_PHONG && index >= limit)
+            return fail(r, PTX_ERROR_INVALID_ARGUMENT, "mesh %u: material index out of range", k);
+    }
+    for (uint32_t g = 0; g < s->geometryCount; g++)
+    {
+        const PtxGeometry &geo = s->geometries[g];
+        if ((uint64_t)geo.VertexOffset + geo.VertexLength > s->vertexCount || (uint64_t)geo.IndexOffset + geo.IndexLength > s->indexCount)
+            return fail(r, PTX_ERROR_INVALID_ARGUMENT, "geometry %u: vertex/index range out of bounds", g);
+        for (uint32_t k = 0; k < geo.IndexLength; k++)
+            if (s->indices[geo.IndexOffset + k] >= geo.VertexLength)
+                return fail(r, PTX_ERROR_INVALID_ARGUMENT, "geometry %u: index %u beyond its vertex range", g, k);
+    }
+
+    // (instance, mesh) pairs in instance-then-mesh order; global triangle id = running prim count
+    std::vector<DevPair> pairs;
+    std::vector<uint32_t> pairFirst;
+    uint64_t tri = 0;
+    for (uint32_t i = 0; i < s->instanceCount; i++)
+    {
+        const PtxModelInstance &inst = s->instances[i];
+        const PtxModel &model = s->models[inst.ModelIndex];
+        for (uint32_t k = 0; k < model.MeshCount; k++)
+        {
+            const PtxMeshRecord &rec = s->meshes[model.MeshOffset + k];
+            const PtxGeometry &geo = s->geometries[rec.GeometryIndex];
+            DevPair pr;
+            composeTransform(inst.Transform.m, s->transforms[rec.TransformIndex].m, pr.M);
+            inverseLinear(pr.M, pr.Rinv);
+            pr.vertexOffset = geo.VertexOffset;
+            pr.indexOffset = geo.IndexOffset;
+            pr.materialId = rec.MaterialId;
+            pairs.push_back(pr);
+            pairFirst.push_back(static_cast<uint32_t>(tri));
+            tri += geo.IndexLength / 3;
+        }
+    }
+    if (tri >= 0x7fffffffull)
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "scene has %llu triangles; limit is 2^31-1", (unsigned long long)tri);
+    pairFirst.push_back(static_cast<uint32_t>(tri));
+    r->pairCount = static_cast<uint32_t>(pairs.size());
+    r->triCount = static_cast<uint32_t>(tri);
+    r->dxNormalTextures = s->dxNormalTextures;
+
+    int rc;
+    if ((rc = upload(r, r->vertices, s->vertices, s->vertexCount)) != PTX_OK) return rc;
+    if ((rc = upload(r, r->indices, s->indices, s->indexCount)) != PTX_OK) return rc;
+    if ((rc = upload(r, r->mr, s->metallicRoughnessMaterials, s->metallicRoughnessMaterialCount)) != PTX_OK) return rc;
+    if ((rc = upload(r, r->sg, s->specularGlossinessMaterials, s->specularGlossinessMaterialCount)) != PTX_OK) return rc;
+    if ((rc = upload(r, r->phong, s->phongMaterials, s->phongMaterialCount)) != PTX_OK) return rc;
+    if ((rc = upload(r, r->pairs, pairs.data(), pairs.size())) != PTX_OK) return rc;
+    if ((rc = upload(r, r->pairFirst, pairFirst.data(), pairFirst.size())) != PTX_OK) return rc;
+    HIP_TRY(r, hipStreamSynchronize(r->stream)); // the host vectors above go out of scope
+    r->sceneReady = true;
+    r->stats.triangles = tri;
+    return PTX_OK;
+}
+
+int ptx_build_accel(PtxRenderer *r)
+{
+    if (!r || !r->sceneReady)
+        return fail(r, PTX_ERROR_NOT_READY, "ptx_build_accel: no scene uploaded");
+    HIP_TRY(r, hipSetDevice(r->device));
+    const uint32_t n = r->triCount;
+    r->stats.bvhNodes = n > 1 ? n - 1 : (n ? 1 : 0);
+    HIP_TRY(r, r->nodes.alloc(n > 1 ? n - 1 : 1));
+    HIP_TRY(r, r->tris.alloc(n ? n : 1));
+    if (n == 0)
+    {
+        r->accelReady = true;
+        r->stats.lastBuildMs = 0.0;
+        return PTX_OK;
+    }
+    // build temporaries (freed at the end: the build is outside the steady-state path)
+    DevBuf<Tri> triTmp;
+    DevBuf<float4> boxLo, boxHi, nodeLo, nodeHi;
+    DevBuf<uint32_t> sceneBounds, vals0, vals1, hist, flags;
+    DevBuf<uint64_t> keys0, keys1;
+    DevBuf<int2> children;
+    DevBuf<int> parentOfNode, parentOfLeaf;
+    const uint32_t numTiles = (n + kSortTile - 1) / kSortTile;
+    auto freeAll = [&]() {
+        triTmp.release(); boxLo.release(); boxHi.release(); nodeLo.release(); nodeHi.release(); sceneBounds.release();
+        vals0.release(); vals1.release(); hist.release(); flags.release(); keys0.release(); keys1.release();
+        children.release(); parentOfNode.release(); parentOfLeaf.release();
+    };
+#define BUILD_TRY(expr)                                                                                                    \
+    do                                                                                                                     \
+    {                                                                                                                      \
+        const hipError_t e_ = (expr);                                                                                      \
+        if (e_ != hipSuccess)                                                                                              \
+        {                                                                                                                  \
+            freeAll();                                                                                                     \
+            return fail(r, e_ == hipErrorOutOfMemory ? PTX_ERROR_OUT_OF_MEMORY : PTX_ERROR_DEVICE, "%s: %s", #expr,       \
+                        hipGetErrorString(e_));                                                                            \
+        }                                                                                                                  \
+    } while (0)
+    BUILD_TRY(triTmp.alloc(n)); BUILD_TRY(boxLo.alloc(n)); BUILD_TRY(boxHi.alloc(n)); BUILD_TRY(nodeLo.alloc(n)); BUILD_TRY(nodeHi.alloc(n));
+    BUILD_TRY(sceneBounds.alloc(6)); BUILD_TRY(vals0.alloc(n)); BUILD_TRY(vals1.alloc(n)); BUILD_TRY(hist.alloc((size_t)256 * numTiles));
+    BUILD_TRY(flags.alloc(n)); BUILD_TRY(keys0.alloc(n)); BUILD_TRY(keys1.alloc(n)); BUILD_TRY(children.alloc(n));
+    BUILD_TRY(parentOfNode.alloc(n)); BUILD_TRY(parentOfLeaf.alloc(n));
+
+    const uint32_t initBounds[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
+    BUILD_TRY(hipMemcpyAsync(sceneBounds.p, initBounds, sizeof(initBounds), hipMemcpyHostToDevice, r->stream));
+    BUILD_TRY(hipMemsetAsync(flags.p, 0, (size_t)n * 4, r->stream));
+    BUILD_TRY(hipEventRecord(r->evA, r->stream));
+
+    const uint32_t blocks = (n + 255) / 256;
+    k_tri_setup<<<blocks, 256, 0, r->stream>>>(n, r->pairCount, r->pairFirst.p, r->pairs.p, r->vertices.p, r->indices.p, triTmp.p,
+                                               boxLo.p, boxHi.p, sceneBounds.p);
+    k_morton<<<blocks, 256, 0, r->stream>>>(n, boxLo.p, boxHi.p, sceneBounds.p, keys0.p, vals0.p);
+    uint64_t *kin = keys0.p, *kout = keys1.p;
+    uint32_t *vin = vals0.p, *vout = vals1.p;
+    for (uint32_t shift = 0; shift < 64; shift += 8) // 63-bit keys: 8 passes
+    {
+        k_sort_hist<<<numTiles, 64, 0, r->stream>>>(n, kin, shift, numTiles, hist.p);
+        k_scan_exclusive<<<1, 1024, 0, r->stream>>>(256 * numTiles, hist.p);
+        k_sort_scatter<<<numTiles, 64, 0, r->stream>>>(n, kin, vin, kout, vout, shift, numTiles, hist.p);
+        std::swap(kin, kout);
+        std::swap(vin, vout);
+    }
+    if (n == 1)
+        k_single_leaf_root<<<1, 1, 0, r->stream>>>(boxLo.p, boxHi.p, triTmp.p, r->nodes.p, r->tris.p);
+    else
+    {
+        k_karras<<<blocks, 256, 0, r->stream>>>((int)n, kin, children.p, parentOfNode.p, parentOfLeaf.p);
+        k_refit<<<blocks, 256, 0, r->stream>>>((int)n, vin, boxLo.p, boxHi.p, children.p, parentOfNode.p, parentOfLeaf.p, nodeLo.p,
+                                               nodeHi.p, flags.p);
+        k_emit<<<blocks, 256, 0, r->stream>>>((int)n, vin, boxLo.p, boxHi.p, children.p, nodeLo.p, nodeHi.p, triTmp.p, r->nodes.p,
+                                              r->tris.p);
+    }
+    BUILD_TRY(hipEventRecord(r->evB, r->stream));
+    BUILD_TRY(hipStreamSynchronize(r->stream));
+    BUILD_TRY(hipGetLastError());
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, r->evA, r->evB);
+    r->stats.lastBuildMs = ms;
+    freeAll();
+#undef BUILD_TRY
+    r->accelReady = true;
+    return PTX_OK;
+}
+
+int ptx_resize(PtxRenderer *r, uint32_t width, uint32_t height)
+{
+    if (!r || !width || !height || (uint64_t)width * height > 0x7fffffffull)
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_resize: bad extent %ux%u", width, height);
+    HIP_TRY(r, hipSetDevice(r->device));
+    r->width = width;
+    r->height = height;
+    r->boundImage = nullptr;
+    HIP_TRY(r, r->image.alloc((size_t)width * height));
+    return ptx_reset_accumulation(r);
+}
+
+int ptx_set_tile_shard(PtxRenderer *r, const PtxTileShard *s)
+{
+    if (!r || !s || !s->worldSize || s->rank >= s->worldSize || !s->tileSize || (s->tileSize % 8) != 0 || s->tileSize > 1024)
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_set_tile_shard: need rank < worldSize and tileSize a multiple of 8");
+    r->shard = *s;
+    return PTX_OK;
+}
+
+int ptx_reset_accumulation(PtxRenderer *r)
+{
+    if (!r || !imagePtr(r))
+        return fail(r, PTX_ERROR_NOT_READY, "ptx_reset_accumulation: no accumulation image (call ptx_resize)");
+    HIP_TRY(r, hipMemsetAsync(imagePtr(r), 0, (size_t)r->width * r->height * sizeof(float4), r->stream));
+    return PTX_OK;
+}
+
+} // extern "C"
+
+static int ensureSlots(PtxRenderer *r, size_t slots)
+{
+    if (slots <= r->slotCapacity)
+        return PTX_OK;
+    HIP_TRY(r, r->slotRad.alloc(slots));
+    HIP_TRY(r, r->rayO.alloc(slots)); HIP_TRY(r, r->rayD.alloc(slots)); HIP_TRY(r, r->thr.alloc(slots)); HIP_TRY(r, r->rad.alloc(slots));
+    HIP_TRY(r, r->hit.alloc(slots)); HIP_TRY(r, r->shO.alloc(slots)); HIP_TRY(r, r->shD.alloc(slots)); HIP_TRY(r, r->shC.alloc(slots));
+    HIP_TRY(r, r->meta.alloc(slots)); HIP_TRY(r, r->hitPair.alloc(slots));
+    HIP_TRY(r, r->queue0.alloc(slots)); HIP_TRY(r, r->queue1.alloc(slots)); HIP_TRY(r, r->shadowQueue.alloc(slots));
+    r->slotCapacity = slots;
+    return PTX_OK;
+}
+
+static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const PtxLightsUbo *lights, uint32_t firstFrame, uint32_t frames)
+{
+    if (!r || !uniform || !lights)
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_render: null argument");
+    if (!r->accelReady || !imagePtr(r))
+        return fail(r, PTX_ERROR_NOT_READY, "ptx_render: need ptx_scene_upload, ptx_build_accel and ptx_resize first");
+    if (uniform->SampleCount == 0 || uniform->SampleCount > 0xffffu || uniform->BounceCount > 0xffffu || frames == 0)
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_render: SampleCount must be in [1, 65535], BounceCount <= 65535");
+    if (lights->LightCount > PTX_MAX_LIGHT_COUNT)
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_render: LightCount %u exceeds MaxLightCount", lights->LightCount);
+    HIP_TRY(r, hipSetDevice(r->device));
+
+    const LaunchParams p = makeParams(r, uniform, firstFrame, frames);
+    if ((uint64_t)p.slotsPerFrame * frames > 0x7fffffffull)
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_render: too many path slots in one batch");
+    const int rc = ensureSlots(r, p.numSlots);
+    if (rc != PTX_OK)
+        return rc;
+
+    HIP_TRY(r, hipMemcpyAsync(r->lights.p, lights, sizeof(PtxLightsUbo), hipMemcpyHostToDevice, r->stream));
+    HIP_TRY(r, hipMemsetAsync(r->counters.p, 0, C_COUNT * sizeof(uint32_t), r->stream));
+
+    SceneView sv;
+    sv.vertices = r->vertices.p; sv.indices = r->indices.p; sv.mr = r->mr.p; sv.sg = r->sg.p; sv.phong = r->phong.p;
+    sv.pairs = r->pairs.p; sv.lights = r->lights.p; sv.dxNormalTextures = r->dxNormalTextures;
+    TraceScene sc;
+    sc.nodes = r->nodes.p; sc.tris = r->tris.p; sc.triCount = r->triCount;
+
+    r->stats.pathSamples = r->stats.segments = r->stats.shadowRays = r->stats.retries = 0;
+    r->stats.traceLaunches = 0;
+    r->stats.lastTraceMs = 0.0;
+    HIP_TRY(r, hipEventRecord(r->evA, r->stream));
+
+    if (p.numSlots == 0)
+    {
+        HIP_TRY(r, hipEventRecord(r->evB, r->stream));
+        return PTX_OK;
+    }
+
+    if (r->backend == PTX_BACKEND_MEGAKERNEL)
+    {
+        k_megakernel<<<(p.numSlots + kBlock - 1) / kBlock, kBlock, 0, r->stream>>>(p, sv, sc, r->slotRad.p, r->counters.p);
+        k_accumulate<<<gridFor(p.slotsPerFrame), kBlock, 0, r->stream>>>(p, r->slotRad.p, imagePtr(r));
+        HIP_TRY(r, hipMemcpyAsync(r->hostCounters, r->counters.p, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
+        HIP_TRY(r, hipEventRecord(r->evB, r->stream));
+        HIP_TRY(r, hipStreamSynchronize(r->stream));
+        HIP_TRY(r, hipGetLastError());
+        r->stats.segments = r->hostCounters[C_SEGMENTS];
+        r->stats.shadowRays = r->hostCounters[C_HITS];
+        r->stats.pathSamples = r->hostCounters[C_SAMPLES];
+        r->stats.retries = r->hostCounters[C_RETRIES];
+        return PTX_OK;
+    }
+
+    Wavefront wf;
+    wf.rayO = r->rayO.p; wf.rayD = r->rayD.p; wf.thr = r->thr.p; wf.rad = r->rad.p; wf.meta = r->meta.p; wf.hit = r->hit.p;
+    wf.hitPair = r->hitPair.p; wf.shO = r->shO.p; wf.shD = r->shD.p; wf.shC = r->shC.p; wf.slotRad = r->slotRad.p;
+    wf.queue[0] = r->queue0.p; wf.queue[1] = r->queue1.p; wf.shadowQueue = r->shadowQueue.p; wf.counters = r->counters.p;
+
+    k_generate<<<gridFor(p.numSlots), kBlock, 0, r->stream>>>(p, wf);
+    HIP_TRY(r, hipMemcpyAsync(r->hostCounters, r->counters.p, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(r, hipStreamSynchronize(r->stream));
+    uint32_t active = r->hostCounters[C_ACTIVE0];
+    int qin = 0;
+    double traceMs = 0.0;
+    // every iteration advances each active path by one bounce; NaN/Inf restarts
+    // (raygen.rgen:99-112) can add iterations but a path that never yields a finite
+    // sample would spin forever (it hangs the GPU in the reference): give up instead
+    const uint64_t maxIterations = ((uint64_t)uniform->BounceCount + 1) * uniform->SampleCount * 64 + 64;
+    uint64_t iteration = 0;
+    while (active)
+    {
+        if (++iteration > maxIterations)
+            return fail(r, PTX_ERROR_DEVICE, "ptx_render: %u paths still active after %llu bounce iterations", active,
+                        (unsigned long long)maxIterations);
+        const int qout = qin ^ 1;
+        const uint32_t zero2[2] = { 0u, 0u };
+        (void)zero2;
+        HIP_TRY(r, hipMemsetAsync(&r->counters.p[qout], 0, sizeof(uint32_t), r->stream));
+        HIP_TRY(r, hipMemsetAsync(&r->counters.p[C_SHADOW], 0, sizeof(uint32_t), r->stream));
+        HIP_TRY(r, hipEventRecord(r->evT0, r->stream));
+        k_trace_closest<<<gridFor(active), kBlock, 0, r->stream>>>(sc, wf, qin);
+        HIP_TRY(r, hipEventRecord(r->evT1, r->stream));
+        k_shade<<<gridFor(active), kBlock, 0, r->stream>>>(p, sv, wf, qin);
+        // shadow queue size is unknown on the host: size the grid for the upper bound
+        k_trace_shadow<<<gridFor(active), kBlock, 0, r->stream>>>(p, sc, wf, qout);
+        HIP_TRY(r, hipMemcpyAsync(r->hostCounters, r->counters.p, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
+        HIP_TRY(r, hipStreamSynchronize(r->stream));
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, r->evT0, r->evT1);
+        traceMs += ms;
+        r->stats.segments += active;
+        r->stats.traceLaunches += 2;
+        active = r->hostCounters[qout];
+        qin = qout;
+    }
+    k_accumulate<<<gridFor(p.slotsPerFrame), kBlock, 0, r->stream>>>(p, r->slotRad.p, imagePtr(r));
+    HIP_TRY(r, hipEventRecord(r->evB, r->stream));
+    HIP_TRY(r, hipGetLastError());
+    r->stats.shadowRays = r->hostCounters[C_HITS];
+    r->stats.pathSamples = r->hostCounters[C_SAMPLES];
+    r->stats.retries = r->hostCounters[C_RETRIES];
+    r->stats.lastTraceMs = traceMs;
+    return PTX_OK;
+}
+
+extern "C" {
+
+int ptx_render(PtxRenderer *r, const PtxRaygenUniformData *uniform, const PtxLightsUbo *lights)
+{
+    return renderImpl(r, uniform, lights, uniform ? uniform->TotalSamples : 0, 1);
+}
+
+int ptx_render_frames(PtxRenderer *r, const PtxRaygenUniformData *uniform, const PtxLightsUbo *lights, uint32_t firstFrame, uint32_t frames)
+{
+    if (!uniform)
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_render_frames: null uniform");
+    PtxRaygenUniformData u = *uniform;
+    u.SampleCount = 1; // canonical schedule: one sample per launch, RNG frame = launch index
+    u.TotalSamples = firstFrame;
+    return renderImpl(r, &u, lights, firstFrame, frames);
+}
+
+int ptx_synchronize(PtxRenderer *r)
+{
+    if (!r)
+        return PTX_ERROR_INVALID_ARGUMENT;
+    HIP_TRY(r, hipStreamSynchronize(r->stream));
+    return PTX_OK;
+}
+
+int ptx_readback(PtxRenderer *r, float *rgba, size_t bytes)
+{
+    if (!r || !rgba || !imagePtr(r) || bytes != (size_t)r->width * r->height * sizeof(float4))
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_readback: buffer must be width*height*16 bytes");
+    HIP_TRY(r, hipMemcpyAsync(rgba, imagePtr(r), bytes, hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(r, hipStreamSynchronize(r->stream));
+    return PTX_OK;
+}
+
+void *ptx_device_accum_ptr(PtxRenderer *r)
+{
+    return r ? imagePtr(r) : nullptr;
+}
+
+size_t ptx_accum_bytes(const PtxRenderer *r)
+{
+    return r ? (size_t)r->width * r->height * sizeof(float4) : 0;
+}
+
+size_t ptx_shard_bytes(const PtxRenderer *r, uint32_t rank)
+{
+    if (!r || !r->width || rank >= r->shard.worldSize)
+        return 0;
+    PtxRenderer tmp;
+    tmp.width = r->width;
+    tmp.height = r->height;
+    tmp.shard = r->shard;
+    tmp.shard.rank = rank;
+    const LaunchParams p = makeParams(&tmp, nullptr, 0, 1);
+    return (size_t)p.slotsPerFrame * sizeof(float4);
+}
+
+int ptx_pack_shard(PtxRenderer *r, void *devDst)
+{
+    if (!r || !devDst || !imagePtr(r))
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_pack_shard: null argument");
+    const LaunchParams p = makeParams(r, nullptr, 0, 1);
+    if (p.slotsPerFrame)
+        k_pack_shard<<<gridFor(p.slotsPerFrame), kBlock, 0, r->stream>>>(p, imagePtr(r), static_cast<float4 *>(devDst));
+    HIP_TRY(r, hipGetLastError());
+    return PTX_OK;
+}
+
+int ptx_unpack_shard(PtxRenderer *r, uint32_t rank, const void *devSrc)
+{
+    if (!r || !devSrc || !imagePtr(r) || rank >= r->shard.worldSize)
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_unpack_shard: bad argument");
+    PtxRenderer tmp;
+    tmp.width = r->width;
+    tmp.height = r->height;
+    tmp.shard = r->shard;
+    tmp.shard.rank = rank;
+    const LaunchParams p = makeParams(&tmp, nullptr, 0, 1);
+    if (p.slotsPerFrame)
+        k_unpack_shard<<<gridFor(p.slotsPerFrame), kBlock, 0, r->stream>>>(p, static_cast<const float4 *>(devSrc), imagePtr(r));
+    HIP_TRY(r, hipGetLastError());
+    return PTX_OK;
+}
+
+int ptx_get_stats(PtxRenderer *r, PtxStats *stats)
+{
+    if (!r || !stats)
+        return PTX_ERROR_INVALID_ARGUMENT;
+    HIP_TRY(r, hipStreamSynchronize(r->stream));
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, r->evA, r->evB) == hipSuccess)
+        r->stats.lastRenderMs = ms;
+    *stats = r->stats;
+    return PTX_OK;
+}
+
+int ptx_test_input_stride(uint32_t fn)
+{
+    return fn < PTX_FN_COUNT ? h_inStride[fn] : -1;
+}
+
+int ptx_test_output_stride(uint32_t fn)
+{
+    return fn < PTX_FN_COUNT ? h_outStride[fn] : -1;
+}
+
+int ptx_test_eval(PtxRenderer *r, uint32_t fn, const float *in, float *out, uint32_t n)
+{
+    if (!r || fn >= PTX_FN_COUNT || !in || !out)
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_test_eval: bad argument");
+    if (!n)
+        return PTX_OK;
+    HIP_TRY(r, hipSetDevice(r->device));
+    const size_t ni = (size_t)n * h_inStride[fn], no = (size_t)n * h_outStride[fn];
+    HIP_TRY(r, r->testIn.alloc(ni));
+    HIP_TRY(r, r->testOut.alloc(no));
+    if (fn == PTX_FN_SAMPLE_LIGHT)
+        HIP_TRY(r, r->testUbo.alloc(n));
+    HIP_TRY(r, hipMemcpyAsync(r->testIn.p, in, ni * 4, hipMemcpyHostToDevice, r->stream));
+    HIP_TRY(r, hipMemsetAsync(r->testOut.p, 0, no * 4, r->stream));
+    k_test_eval<<<(n + 63) / 64, 64, 0, r->stream>>>(fn, r->testIn.p, r->testOut.p, n, r->testUbo.p);
+    HIP_TRY(r, hipMemcpyAsync(out, r->testOut.p, no * 4, hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(r, hipStreamSynchronize(r->stream));
+    HIP_TRY(r, hipGetLastError());
+    return PTX_OK;
+}
+
+int ptx_trace_rays(PtxRenderer *r, const float *rays, uint32_t n, int anyHit, float *hits, uint32_t *ids)
+{
+    if (!r || !rays || !hits || !ids)
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_trace_rays: null argument");
+    if (!r->accelReady)
+        return fail(r, PTX_ERROR_NOT_READY, "ptx_trace_rays: no acceleration structure");
+    if (!n)
+        return PTX_OK;
+    HIP_TRY(r, hipSetDevice(r->device));
+    DevBuf<float4> dRays, dHits;
+    DevBuf<uint2> dIds;
+    HIP_TRY(r, dRays.alloc((size_t)n * 2));
+    HIP_TRY(r, dHits.alloc(n));
+    HIP_TRY(r, dIds.alloc(n));
+    TraceScene sc;
+    sc.nodes = r->nodes.p; sc.tris = r->tris.p; sc.triCount = r->triCount;
+    hipError_t e = hipMemcpyAsync(dRays.p, rays, (size_t)n * 32, hipMemcpyHostToDevice, r->stream);
+    if (e == hipSuccess)
+    {
+        (void)hipEventRecord(r->evT0, r->stream);
+        k_trace_rays<<<gridFor(n), kBlock, 0, r->stream>>>(sc, dRays.p, n, anyHit, dHits.p, dIds.p);
+        (void)hipEventRecord(r->evT1, r->stream);
+        e = hipMemcpyAsync(hits, dHits.p, (size_t)n * 16, hipMemcpyDeviceToHost, r->stream);
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(ids, dIds.p, (size_t)n * 8, hipMemcpyDeviceToHost, r->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(r->stream);
+    if (e == hipSuccess)
+        e = hipGetLastError();
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, r->evT0, r->evT1);
+    r->stats.lastTraceMs = ms;
+    dRays.release(); dHits.release(); dIds.release();
+    if (e != hipSuccess)
+        return fail(r, PTX_ERROR_DEVICE, "ptx_trace_rays: %s", hipGetErrorString(e));
+    return PTX_OK;
+}
+
+int ptx_bind_accumulation(PtxRenderer *r, void *devPtr, size_t bytes)
+{
+    if (!r || !r->width)
+        return fail(r, PTX_ERROR_NOT_READY, "ptx_bind_accumulation: call ptx_resize first");
+    if (devPtr && bytes != (size_t)r->width * r->height * sizeof(float4))
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_bind_accumulation: buffer must be width*height*16 bytes");
+    r->boundImage = static_cast<float4 *>(devPtr);
+    return PTX_OK;
+}
+
+} // extern "C"

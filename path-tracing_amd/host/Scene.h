@@ -1,0 +1,301 @@
+// Scene.h -- host-side mirror of the reference's Scene / SceneBuilder
+// (Path-Tracing/Scene.h:63-361, Scene.cpp) for the part the path-tracing pass consumes.
+// Same class and method names, same argument meaning, so scene-construction code
+// written against the reference (ExampleScenes.cpp) reads the same here.  Differences:
+// no glm (Math.h), textures are carried as descriptors only (software texturing is the
+// next row N1), skeletal animation is out of scope (N3).
+#pragma once
+
+#include <memory>
+#include <span>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/ptx.h"
+
+#include "Camera.h"
+#include "Math.h"
+
+namespace PathTracing
+{
+
+// Core/Core.h:117-122
+class error : public std::runtime_error
+{
+public:
+    explicit error(const std::string &message) : std::runtime_error(message) {}
+};
+
+namespace Shaders
+{
+using Vertex = PtxVertex;
+using MetallicRoughnessMaterial = PtxMetallicRoughnessMaterial;
+using SpecularGlossinessMaterial = PtxSpecularGlossinessMaterial;
+using PhongMaterial = PtxPhongMaterial;
+using DirectionalLight = PtxDirectionalLight;
+using PointLight = PtxPointLight;
+using MaterialId = uint32_t;
+
+inline constexpr uint32_t SceneTextureOffset = PTX_SCENE_TEXTURE_OFFSET;
+inline constexpr uint32_t MaxTextureCount = PTX_MAX_TEXTURE_COUNT;
+inline constexpr uint32_t MaxLightCount = PTX_MAX_LIGHT_COUNT;
+inline constexpr uint32_t MaxMaterialCount = 1u << 24;
+inline constexpr uint32_t MaterialTypeMetallicRoughness = PTX_MATERIAL_TYPE_METALLIC_ROUGHNESS;
+inline constexpr uint32_t MaterialTypeSpecularGlossiness = PTX_MATERIAL_TYPE_SPECULAR_GLOSSINESS;
+inline constexpr uint32_t MaterialTypePhong = PTX_MATERIAL_TYPE_PHONG;
+
+// ShaderTypes.incl:150-158
+inline uint32_t GetSceneTextureIndex(uint32_t textureIndex) { return SceneTextureOffset + textureIndex; }
+inline uint32_t CreateMaterialId(uint32_t materialIndex, uint32_t materialType) { return (materialIndex << 8) | materialType; }
+}
+
+// Scene.h:22-33
+enum class TextureType : uint8_t
+{
+    Emisive,
+    Color,
+    Normal,
+    Roughness,
+    Metallic,
+    Specular,
+    Glossiness,
+    Shininess,
+    Skybox,
+};
+
+// Scene.h:48-59, descriptor only
+struct TextureInfo
+{
+    TextureType Type;
+    uint32_t Width = 1, Height = 1;
+    std::string Name;
+};
+
+using Geometry = PtxGeometry; // Scene.h:63-71
+
+// Scene.h:73-78
+enum class MaterialType : uint8_t
+{
+    MetallicRoughness,
+    SpecularGlossiness,
+    Phong,
+};
+
+// Scene.h:80-86; Transform = glm::mat3x4 = 3 rows of the affine matrix
+struct MeshInfo
+{
+    uint32_t GeometryIndex;
+    uint32_t MaterialIndex; // a MaterialId as returned by AddMaterial
+    MaterialType ShaderMaterialType;
+    PtxTransform Transform;
+};
+
+// Scene.h:88-100
+struct Mesh
+{
+    uint32_t GeometryIndex;
+    uint32_t MaterialIndex;
+    MaterialType ShaderMaterialType;
+    uint32_t TransformBufferOffset;
+};
+struct Model
+{
+    std::vector<Mesh> Meshes;
+    uint32_t MeshOffset;
+};
+
+// Scene.h:102-107
+struct ModelInstance
+{
+    uint32_t ModelIndex;
+    uint32_t SceneNodeIndex;
+    Mat4 Transform;
+};
+
+// SceneGraph.h:13-18
+struct SceneNode
+{
+    uint32_t Parent;
+    Mat4 Transform;
+    Mat4 CurrentTransform;
+};
+
+struct LightInfo
+{
+    uint32_t SceneNodeIndex;
+    Vec3 Position;
+};
+struct DirectionalLightInfo
+{
+    uint32_t SceneNodeIndex;
+    Vec3 Direction;
+};
+
+// Scene.h:146-155
+struct CameraInfo
+{
+    float VerticalFOV;
+    float NearClip;
+    float FarClip;
+    Vec3 Position;
+    Vec3 Direction;
+    Vec3 UpDirection;
+    uint32_t SceneNodeIndex;
+};
+
+using CameraId = int32_t;
+
+inline PtxTransform IdentityTransform()
+{
+    PtxTransform t = { { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 } };
+    return t;
+}
+
+class Scene
+{
+public:
+    Scene() = default;
+
+    // Scene::Update (Scene.cpp:52-83): advances the scene graph (static here) and
+    // refreshes instance transforms and light positions from it.
+    bool Update(float timeStep);
+
+    [[nodiscard]] const std::string &GetName() const { return m_Name; }
+
+    [[nodiscard]] std::span<const Shaders::Vertex> GetVertices() const { return m_Vertices; }
+    [[nodiscard]] std::span<const uint32_t> GetIndices() const { return m_Indices; }
+    [[nodiscard]] std::span<const PtxTransform> GetTransforms() const { return m_Transforms; }
+    [[nodiscard]] std::span<const Geometry> GetGeometries() const { return m_Geometries; }
+    [[nodiscard]] std::span<const Shaders::MetallicRoughnessMaterial> GetMetallicRoughnessMaterials() const { return m_MetallicRoughnessMaterials; }
+    [[nodiscard]] std::span<const Shaders::SpecularGlossinessMaterial> GetSpecularGlossinessMaterials() const { return m_SpecularGlossinessMaterials; }
+    [[nodiscard]] std::span<const Shaders::PhongMaterial> GetPhongMaterials() const { return m_PhongMaterials; }
+    [[nodiscard]] std::span<const TextureInfo> GetTextures() const { return m_Textures; }
+    [[nodiscard]] std::span<const Model> GetModels() const { return m_Models; }
+    [[nodiscard]] std::span<const ModelInstance> GetModelInstances() const { return m_ModelInstances; }
+    [[nodiscard]] bool HasDxNormalTextures() const { return m_HasDxNormalTextures; }
+    [[nodiscard]] std::span<const Shaders::PointLight> GetPointLights() const { return m_PointLights; }
+    [[nodiscard]] const Shaders::DirectionalLight &GetDirectionalLight() const { return m_DirectionalLight; }
+
+    [[nodiscard]] uint32_t GetSceneCamerasCount() const { return static_cast<uint32_t>(m_SceneCameras.size()); }
+    [[nodiscard]] CameraId GetActiveCameraId() const { return m_ActiveCameraId; }
+    [[nodiscard]] Camera &GetActiveCamera();
+    void SetActiveCamera(CameraId id);
+
+    inline static const CameraId g_InputCameraId = -1;
+
+    [[nodiscard]] static uint32_t GetDefaultTextureIndex(TextureType type);
+
+    // What Renderer::UpdateSceneData pulls through the getters above, as the POD the
+    // C-ABI takes (include/ptx.h PtxSceneDesc).  Pointers stay valid while the Scene lives.
+    [[nodiscard]] PtxSceneDesc GetDesc() const;
+    // Lights UBO image as uploaded every frame (Renderer.cpp:1719-1726).
+    [[nodiscard]] PtxLightsUbo GetLightsUbo() const;
+
+private:
+    friend class SceneBuilder;
+
+    std::string m_Name;
+    std::vector<Shaders::Vertex> m_Vertices;
+    std::vector<uint32_t> m_Indices;
+    std::vector<PtxTransform> m_Transforms;
+    std::vector<Geometry> m_Geometries;
+    std::vector<Shaders::MetallicRoughnessMaterial> m_MetallicRoughnessMaterials;
+    std::vector<Shaders::SpecularGlossinessMaterial> m_SpecularGlossinessMaterials;
+    std::vector<Shaders::PhongMaterial> m_PhongMaterials;
+    std::vector<TextureInfo> m_Textures;
+    bool m_HasDxNormalTextures = false;
+    std::vector<Model> m_Models;
+    std::vector<ModelInstance> m_ModelInstances;
+    std::vector<SceneNode> m_SceneNodes;
+    std::vector<bool> m_IsRelativeTransform;
+    std::vector<LightInfo> m_LightInfos;
+    std::vector<Shaders::PointLight> m_PointLights;
+    DirectionalLightInfo m_DirectionalLightInfo;
+    Shaders::DirectionalLight m_DirectionalLight;
+
+    // flattened views handed to the C-ABI
+    std::vector<PtxMeshRecord> m_MeshRecords;
+    std::vector<PtxModel> m_ModelRanges;
+    mutable std::vector<PtxModelInstance> m_InstanceRecords;
+
+    // Scene.h:259-260
+    InputCamera m_InputCamera = InputCamera(45.0f, 100.0f, 0.1f, Vec3(3.0f, 1.0f, 0.0f), Vec3(-1.0f, 0.0f, 0.0f));
+    std::vector<AnimatedCamera> m_SceneCameras;
+    CameraId m_ActiveCameraId = g_InputCameraId;
+
+    void UpdateTransforms(); // SceneGraph.cpp:36-60
+};
+
+class SceneBuilder
+{
+public:
+    /* SceneNodes have to be added in pre-order sequence */
+    uint32_t AddSceneNode(SceneNode &&node);
+
+    uint32_t AddGeometry(Geometry &&geometry);
+    uint32_t AddModel(std::span<const MeshInfo> meshInfos);
+    uint32_t AddModelInstance(uint32_t modelIndex, uint32_t sceneNodeIndex);
+
+    uint32_t AddTexture(TextureInfo &&texture);
+    Shaders::MaterialId AddMaterial(std::string name, Shaders::MetallicRoughnessMaterial material);
+    Shaders::MaterialId AddMaterial(std::string name, Shaders::SpecularGlossinessMaterial material);
+    Shaders::MaterialId AddMaterial(std::string name, Shaders::PhongMaterial material);
+
+    std::vector<Shaders::Vertex> &GetVertices() { return m_Vertices; }
+    std::vector<uint32_t> &GetIndices() { return m_Indices; }
+
+    void SetAbsoluteTransform(uint32_t sceneNodeIndex);
+
+    void AddLight(Shaders::PointLight &&light, uint32_t sceneNodeIndex);
+    void SetDirectionalLight(Shaders::DirectionalLight &&light, uint32_t sceneNodeIndex);
+
+    void AddCamera(CameraInfo &&camera);
+
+    void SetDxNormalTextures() { m_HasDxNormalTextures = true; }
+    [[nodiscard]] std::shared_ptr<Scene> CreateSceneShared(const std::string &name);
+
+public:
+    static inline constexpr uint32_t IdentityTransformIndex = 0;
+    static inline constexpr uint32_t RootNodeIndex = 0;
+
+    SceneBuilder();
+
+private:
+    std::vector<Shaders::Vertex> m_Vertices;
+    std::vector<uint32_t> m_Indices;
+    std::vector<PtxTransform> m_Transforms;
+    std::vector<Geometry> m_Geometries;
+
+    std::vector<Shaders::MetallicRoughnessMaterial> m_MetallicRoughnessMaterials;
+    std::unordered_map<std::string, uint32_t> m_MetallicRoughnessMaterialIds;
+    std::vector<Shaders::SpecularGlossinessMaterial> m_SpecularGlossinessMaterials;
+    std::unordered_map<std::string, uint32_t> m_SpecularGlossinessMaterialIds;
+    std::vector<Shaders::PhongMaterial> m_PhongMaterials;
+    std::unordered_map<std::string, uint32_t> m_PhongMaterialIds;
+
+    std::vector<TextureInfo> m_Textures;
+    std::unordered_map<std::string, uint32_t> m_TextureIndices;
+    bool m_HasDxNormalTextures = false;
+
+    std::vector<Model> m_Models;
+    std::vector<std::pair<uint32_t, uint32_t>> m_ModelInstanceInfos;
+
+    std::vector<SceneNode> m_SceneNodes;
+    std::vector<bool> m_IsRelativeTransform;
+
+    std::vector<LightInfo> m_LightInfos;
+    std::vector<Shaders::PointLight> m_PointLights;
+    DirectionalLightInfo m_DirectionalLightInfo;
+    Shaders::DirectionalLight m_DirectionalLight;
+
+    std::vector<CameraInfo> m_CameraInfos;
+
+    uint32_t m_MeshOffset = 0;
+
+    void Reset();
+    Model CreateModel(std::span<const MeshInfo> meshInfos);
+};
+
+}

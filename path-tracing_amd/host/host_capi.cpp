@@ -1,0 +1,114 @@
+// host_capi.cpp -- include/ptx_host.h over the C++ host mirror.
+#include "../../include/ptx_host.h"
+
+#include <string>
+
+#include "ExampleScenes.h"
+
+using namespace PathTracing;
+
+struct PthScene
+{
+    std::shared_ptr<Scene> scene;
+};
+
+static thread_local std::string g_error;
+
+extern "C" {
+
+const char *pth_scene_names(void)
+{
+    return ExampleScenes::GetSceneNames();
+}
+
+const char *pth_last_error(void)
+{
+    return g_error.c_str();
+}
+
+PthScene *pth_scene_create(const char *name, float detail, uint32_t seed)
+{
+    try
+    {
+        if (!(detail > 0.0f))
+            detail = 1.0f;
+        auto *s = new PthScene;
+        s->scene = ExampleScenes::CreateScene(name ? name : "default", detail, seed);
+        return s;
+    }
+    catch (const std::exception &e)
+    {
+        g_error = e.what();
+        return nullptr;
+    }
+}
+
+void pth_scene_destroy(PthScene *s)
+{
+    delete s;
+}
+
+int pth_scene_desc(PthScene *s, PtxSceneDesc *out)
+{
+    if (!s || !out)
+        return PTX_ERROR_INVALID_ARGUMENT;
+    *out = s->scene->GetDesc();
+    return PTX_OK;
+}
+
+int pth_scene_lights(PthScene *s, PtxLightsUbo *out)
+{
+    if (!s || !out)
+        return PTX_ERROR_INVALID_ARGUMENT;
+    *out = s->scene->GetLightsUbo();
+    return PTX_OK;
+}
+
+uint64_t pth_scene_triangle_count(PthScene *s)
+{
+    if (!s)
+        return 0;
+    uint64_t n = 0;
+    const auto models = s->scene->GetModels();
+    const auto geometries = s->scene->GetGeometries();
+    for (const auto &instance : s->scene->GetModelInstances())
+        for (const auto &mesh : models[instance.ModelIndex].Meshes)
+            n += geometries[mesh.GeometryIndex].IndexLength / 3;
+    return n;
+}
+
+int pth_scene_raygen_uniform(PthScene *s, uint32_t width, uint32_t height, uint32_t bounceCount, float lensRadius,
+                             float focalDistance, uint32_t sampleCount, uint32_t totalSamples, PtxRaygenUniformData *out)
+{
+    if (!s || !out || !width || !height)
+        return PTX_ERROR_INVALID_ARGUMENT;
+    Camera &camera = s->scene->GetActiveCamera();
+    camera.OnResize(width, height);
+    ToColumnMajor(camera.GetInvViewMatrix(), out->ViewInverse);
+    ToColumnMajor(camera.GetInvProjectionMatrix(), out->ProjInverse);
+    out->BounceCount = bounceCount;
+    out->LensRadius = lensRadius;
+    out->FocalDistance = focalDistance;
+    out->SampleCount = sampleCount;
+    out->TotalSamples = totalSamples;
+    return PTX_OK;
+}
+
+int pth_scene_set_active_camera(PthScene *s, int32_t cameraId)
+{
+    if (!s || cameraId < -1 || cameraId >= static_cast<int32_t>(s->scene->GetSceneCamerasCount()))
+        return PTX_ERROR_INVALID_ARGUMENT;
+    s->scene->SetActiveCamera(cameraId);
+    s->scene->Update(0.0f);
+    return PTX_OK;
+}
+
+int pth_scene_set_camera_pose(PthScene *s, const float position[3], const float direction[3])
+{
+    if (!s || !position || !direction)
+        return PTX_ERROR_INVALID_ARGUMENT;
+    s->scene->SetActiveCamera(Scene::g_InputCameraId);
+    s->scene->GetActiveCamera().SetPose(Vec3(position[0], position[1], position[2]), Vec3(direction[0], direction[1], direction[2]));
+    return PTX_OK;
+}
+}

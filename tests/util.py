@@ -1,0 +1,81 @@
+"""Helpers shared by the tests."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+GEOMETRY_DT = np.dtype([("VertexOffset", "u4"), ("VertexLength", "u4"), ("IndexOffset", "u4"), ("IndexLength", "u4"),
+                        ("IsOpaque", "u1"), ("IsAnimated", "u1"), ("pad", "u1", 2)])
+MESH_DT = np.dtype([("GeometryIndex", "u4"), ("MaterialId", "u4"), ("TransformIndex", "u4")])
+MODEL_DT = np.dtype([("MeshOffset", "u4"), ("MeshCount", "u4")])
+INSTANCE_DT = np.dtype([("ModelIndex", "u4"), ("Transform", "f4", 12)])
+
+
+def _view(ptr, count, dtype):
+    if not ptr or not count:
+        return np.zeros(0, dtype)
+    buf = (C.c_uint8 * (count * dtype.itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=count)
+
+
+def desc_arrays(desc):
+    return {
+        "vertices": _view(desc.vertices, desc.vertexCount * 14, np.dtype("f4")).reshape(-1, 14),
+        "indices": _view(desc.indices, desc.indexCount, np.dtype("u4")),
+        "transforms": _view(desc.transforms, desc.transformCount * 12, np.dtype("f4")).reshape(-1, 12),
+        "geometries": _view(desc.geometries, desc.geometryCount, GEOMETRY_DT),
+        "meshes": _view(desc.meshes, desc.meshCount, MESH_DT),
+        "models": _view(desc.models, desc.modelCount, MODEL_DT),
+        "instances": _view(desc.instances, desc.instanceCount, INSTANCE_DT),
+    }
+
+
+def pair_first(desc):
+    """First global triangle id of every (instance, mesh) pair, in instance-then-mesh order --
+    the numbering both the oracle (global id) and the HIP path ((pair, prim)) use."""
+    a = desc_arrays(desc)
+    first, tri = [], 0
+    for inst in a["instances"]:
+        m = a["models"][inst["ModelIndex"]]
+        for k in range(m["MeshCount"]):
+            rec = a["meshes"][m["MeshOffset"] + k]
+            first.append(tri)
+            tri += int(a["geometries"][rec["GeometryIndex"]]["IndexLength"]) // 3
+    first.append(tri)
+    return np.array(first, dtype=np.int64)
+
+
+def load_golden(mode):
+    with open(os.path.join(GOLDEN_DIR, f"golden_{mode}.json")) as f:
+        g = json.load(f)
+    out = {}
+    for name, c in g.items():
+        out[name] = (c["fn"], np.array(c["in"], dtype=np.uint32).reshape(-1, c["nin"]),
+                     np.array(c["out"], dtype=np.uint32).reshape(-1, c["nout"]))
+    return out
+
+
+def bits_equal_or_both_nan(a_u32, b_u32):
+    af, bf = a_u32.view(np.float32), b_u32.view(np.float32)
+    return (a_u32 == b_u32) | (np.isnan(af) & np.isnan(bf))
+
+
+def rel_l2(img, ref):
+    return float(np.linalg.norm((img[..., :3] - ref[..., :3]).astype(np.float64)) /
+                 max(np.linalg.norm(ref[..., :3].astype(np.float64)), 1e-30))
+
+
+def random_rays(rng, n, lo, hi, tmax=1e4):
+    """Rays with origins in the box [lo,hi] pointing in random directions (float32, 8 per ray)."""
+    o = rng.uniform(lo, hi, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0:3] = o
+    rays[:, 3] = 1e-5
+    rays[:, 4:7] = d
+    rays[:, 7] = tmax
+    return rays
