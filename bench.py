@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the path-tracing hot path on MI355X.
+
+Metric (BASELINE.json): Msamples/s = W*H*spp / wall-seconds / 1e6 at 1920x1080, 8 spp, depth 8.
+A "step" is one pass of the hot path over one frame batch: reset the accumulation image, add
+`spp` samples per pixel (canonical schedule: one sample per launch, RNG frame = launch index,
+SURVEY.md 8a) and -- with N > 1 GPUs -- gather the pixel-tile shards to rank 0 (the single RCCL
+exchange of SURVEY.md 8e).  Scene upload and the LBVH build are outside the timed region (the
+reference builds its acceleration structures in UpdateSceneData, not in Render).  Inputs are
+resident in HBM when the timed region starts.
+
+Workload at N = 1: BASELINE configs[1] "ABeautifulGame, 1920x1080, 8 spp, depth 8" through its
+procedural stand-in `chess_like` (the glTF assets are downloaded at CMake time by the reference
+and do not exist offline).
+
+Launch:  python bench.py --gpus N --steps K --warmup W           (N = 1)
+         python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes_per_closest_ray(n_tris: int) -> int:
+    """DESIGN.md 'Roofline': k_trace_closest per ray = L(N)*B_node + B_tri + the
+    state the kernel must move: queue index 4 B + ray 32 B read + hit record 20 B written."""
+    L = max(1, math.ceil(math.log2(max(n_tris, 2))))
+    return 32 * L + 36 + 4 + 32 + 20
+
+
+def cpu_baseline(orc, pkg, scene, width, height, depth, seconds, tile):
+    """The oracle (a scalar C port of the shader path, OpenMP over pixel tiles, binned-SAH BVH) on
+    the host cores, on a bounded sample of the same workload: tiles `t % 8 == 0` of the frame,
+    one sample per launch, as many frames as fit in `seconds`."""
+    import ctypes as C
+
+    desc = scene.desc
+    lights = scene.lights
+    t0 = time.time()
+    osc = orc.OracleScene(desc, build_bvh=True)
+    build_s = time.time() - t0
+    shard = pkg.TileShard(0, 8, tile)
+    mask = pkg.shard_mask(width, height, 0, 8, tile)
+    px = int(mask.sum())
+    acc = np.zeros((height, width, 4), np.float32)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    frames = 0
+    t0 = time.time()
+    while True:
+        u = scene.uniform(width, height, bounces=depth, sample_count=1, total_samples=frames)
+        osc.render(u, lights, width, height, accum=acc, shard=shard, threads=cores)
+        frames += 1
+        el = time.time() - t0
+        if el >= seconds or frames >= 8:
+            break
+    return {
+        "value": px * frames / el / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+        "sample": f"oracle (C, OpenMP, SAH BVH) on 1/8 of the 32x32 tiles of the same {width}x{height} frame, "
+                  f"{frames} spp, depth {depth}, {el:.1f} s; BVH build {build_s:.1f} s excluded",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="chess_like")
+    ap.add_argument("--detail", type=float, default=1.0)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=8)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--tile", type=int, default=32)
+    ap.add_argument("--backend", default="wavefront", choices=["wavefront", "megakernel"])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch through torch.distributed.run",
+                  file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    pkg = graft.load_package()  # after torch: one HIP runtime in the process
+    W, H = args.width, args.height
+    scene = pkg.Scene(args.scene, args.detail)
+    lights = scene.lights
+    backend = pkg.BACKEND_WAVEFRONT if args.backend == "wavefront" else pkg.BACKEND_MEGAKERNEL
+    r = pkg.Renderer(device=local_rank, backend=backend)
+    t0 = time.time()
+    r.upload(scene)
+    r.synchronize()
+    upload_build_s = time.time() - t0
+    r.resize(W, H)
+    r.set_tile_shard(rank, world, args.tile)
+    u = scene.uniform(W, H, bounces=args.depth)
+    build_ms = r.stats().lastBuildMs
+    n_tris = scene.triangle_count
+
+    # gather plumbing (N > 1): equal-size padded shard buffers, one all_gather
+    if world > 1:
+        shard_floats = max(r.shard_bytes(k) for k in range(world)) // 4
+        send = torch.zeros(shard_floats, dtype=torch.float32, device="cuda")
+        recv = torch.zeros(world * shard_floats, dtype=torch.float32, device="cuda") if True else None
+
+    def step():
+        r.reset()
+        r.render_frames(u, lights, 0, args.spp)
+        if world > 1:
+            r.pack_shard(send.data_ptr())
+            r.synchronize()
+            dist.all_gather_into_tensor(recv, send)
+            if rank == 0:
+                torch.cuda.current_stream().synchronize()
+                for k in range(world):
+                    r.unpack_shard(k, recv.data_ptr() + k * shard_floats * 4)
+        r.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        r.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    trace_ms = 0.0
+    trace_launches = 0
+    closest_rays = 0
+    segments = shadow = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        st = r.stats()
+        trace_ms += st.lastTraceMs
+        trace_launches += st.traceLaunches // 2
+        closest_rays += st.segments
+        segments, shadow = st.segments, st.shadowRays
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        samples = W * H * args.spp * args.steps
+        value = samples / elapsed / 1e6
+        out = {
+            "metric": "Msamples/s (paths*spp/s) at 1920x1080, 8spp, depth 8",
+            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong",  # one fixed 1080p frame is split into pixel tiles over the N GPUs
+            "vs_baseline": None,   # the reference publishes no number for this metric
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"{args.scene} (procedural stand-in for BASELINE configs[1] 'Khronos ABeautifulGame'), "
+                            f"{W}x{H}, {args.spp} spp, depth {args.depth}",
+                "triangles": n_tris, "backend": args.backend, "tile": args.tile,
+                "parallelism": f"pixel-tile shard x{world}" + (", 1 RCCL all_gather" if world > 1 else ""),
+                "segments_per_sample": segments / (W * H * args.spp / world) if world else None,
+                "lbvh_build_ms": build_ms, "upload_plus_build_s": upload_build_s,
+            },
+        }
+        if args.backend == "wavefront" and trace_ms > 0:
+            bpr = algorithmic_bytes_per_closest_ray(n_tris)
+            achieved = closest_rays * bpr / (trace_ms * 1e-3) / 1e9
+            out["roofline"] = {
+                "bound": "hbm", "kernel": "k_trace_closest", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "bytes_per_ray": bpr, "rays_per_launch": closest_rays / max(trace_launches, 1),
+                "avg_launch_ms": trace_ms / max(trace_launches, 1), "launches": trace_launches,
+                "grays_per_s": closest_rays / (trace_ms * 1e-3) / 1e9,
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            orc = graft.load_oracle()
+            out["cpu_baseline"] = cpu_baseline(orc, pkg, scene, W, H, args.depth, args.cpu_seconds, args.tile)
+        print(json.dumps(out), flush=True)
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
