@@ -123,14 +123,46 @@ PT_DEV bool badRadiance(f3 r) // raygen.rgen:101,107
 
 constexpr int kBlock = 256;
 
+// Queue append with ONE atomic per wave: ballot the pushing lanes, the first of them
+// reserves popcount slots, every lane takes base + its rank.  Must be reached by all lanes
+// of the wave that are still in the (wave-uniform) loop.
+PT_DEV void wavePush(uint32_t *__restrict__ queue, uint32_t *__restrict__ counter, bool push, uint32_t value)
+{
+    const uint64_t mask = __ballot(push);
+    if (mask == 0)
+        return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int leader = __ffsll((unsigned long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader)
+        base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    if (push)
+        queue[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = value;
+}
+
+// statistics: lanes count in registers, one atomic per wave at kernel exit
+PT_DEV void waveAddCounter(uint32_t *__restrict__ counter, uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_down(v, off);
+    if ((threadIdx.x & 63u) == 0 && v)
+        atomicAdd(counter, v);
+}
+
 __global__ void __launch_bounds__(kBlock) k_generate(LaunchParams p, Wavefront wf)
 {
-    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < p.numSlots; slot += gridDim.x * blockDim.x)
+    for (uint32_t base = blockIdx.x * blockDim.x; base < p.numSlots; base += gridDim.x * blockDim.x)
     {
+        const uint32_t slot = base + threadIdx.x;
+        const bool valid = slot < p.numSlots;
         const uint32_t f = slot / p.slotsPerFrame, s = slot % p.slotsPerFrame;
-        const uint32_t pixel = slotPixel(p, s);
+        const uint32_t pixel = valid ? slotPixel(p, s) : 0xffffffffu;
         const uint32_t frame = p.firstFrame + f;
         uint4 meta = make_uint4(0u, pixel, 0u, frame);
+        wavePush(wf.queue[0], &wf.counters[C_ACTIVE0], pixel != 0xffffffffu, slot);
+        if (!valid)
+            continue;
         if (pixel != 0xffffffffu)
         {
             uint32_t rng = initRng(pixel % p.width, pixel / p.width, p.width, frame); // raygen.rgen:38
@@ -141,8 +173,6 @@ __global__ void __launch_bounds__(kBlock) k_generate(LaunchParams p, Wavefront w
             wf.rayD[slot] = make_float4(d.x, d.y, d.z, 0.0f);
             wf.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
             wf.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            const uint32_t qi = atomicAdd(&wf.counters[C_ACTIVE0], 1u);
-            wf.queue[0][qi] = slot;
         }
         else
             wf.slotRad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -171,15 +201,16 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(TraceScene sc, Wavefro
 
 // raygen.rgen:99-112 + sample loop control for a slot whose path has ended.
 // Returns true if the slot continues (new primary ray written, caller enqueues it).
-PT_DEV bool finishSample(const LaunchParams &p, const Wavefront &wf, uint32_t slot, uint4 &meta, f3 &radiance)
+PT_DEV bool finishSample(const LaunchParams &p, const Wavefront &wf, uint32_t slot, uint4 &meta, f3 &radiance,
+                         uint32_t &nSamples, uint32_t &nRetries)
 {
     uint32_t smpl = meta.z >> 16;
-    atomicAdd(&wf.counters[C_SAMPLES], 1u);
+    nSamples++;
     if (badRadiance(radiance))
     {
         radiance = F3s(0.0f);
         smpl = 0; // "smpl = -1; continue" restarts ALL samples of the launch, RNG carried on
-        atomicAdd(&wf.counters[C_RETRIES], 1u);
+        nRetries++;
     }
     else
         smpl = smpl + 1;
@@ -202,91 +233,94 @@ __global__ void __launch_bounds__(kBlock) k_shade(LaunchParams p, SceneView sv, 
 {
     const int qout = qin ^ 1;
     const uint32_t count = wf.counters[qin];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
+    uint32_t nHits = 0, nSamples = 0, nRetries = 0;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x)
     {
-        const uint32_t slot = wf.queue[qin][i];
-        uint4 meta = wf.meta[slot];
-        const float4 hit = wf.hit[slot];
-        const uint32_t pair = wf.hitPair[slot];
-        const float4 r4 = wf.rad[slot], t4 = wf.thr[slot];
-        f3 radiance = F3(r4.x, r4.y, r4.z), throughput = F3(t4.x, t4.y, t4.z);
-
-        if (pair == 0xffffffffu)
+        const uint32_t i = base + threadIdx.x;
+        const bool valid = i < count;
+        bool pushNext = false, pushShadow = false;
+        uint32_t slot = 0;
+        if (valid)
         {
-            // miss.rmiss:37-39 (MissFlagsNone): constant sky, Pdf = -1 -> raygen.rgen:71-75
-            radiance = radiance + throughput * F3(0.08f, 0.09f, 0.1f);
-            if (finishSample(p, wf, slot, meta, radiance))
-                wf.queue[qout][atomicAdd(&wf.counters[qout], 1u)] = slot;
-            wf.meta[slot] = meta;
-            continue;
-        }
+            slot = wf.queue[qin][i];
+            uint4 meta = wf.meta[slot];
+            const float4 hit = wf.hit[slot];
+            const uint32_t pair = wf.hitPair[slot];
+            const float4 r4 = wf.rad[slot], t4 = wf.thr[slot];
+            f3 radiance = F3(r4.x, r4.y, r4.z), throughput = F3(t4.x, t4.y, t4.z);
 
-        const float4 o4 = wf.rayO[slot], d4 = wf.rayD[slot];
-        HitOut out;
-        closestHit(sv, F3(d4.x, d4.y, d4.z), hit.x, hit.y, hit.z, pair, __float_as_uint(hit.w), o4.w, meta.x, out);
-        atomicAdd(&wf.counters[C_HITS], 1u);
-
-        radiance = radiance + throughput * out.Emissive; // raygen.rgen:77
-
-        // raygen.rgen:79-81, evaluated with the pre-update throughput
-        f3 contribution = F3s(0.0f);
-        bool wantShadow = false;
-        if (out.DirectLightPdf > 0.0f)
-        {
-            contribution = (throughput * out.DirectLight) / out.DirectLightPdf;
-            // adding an exact zero cannot change radiance (it is never -0): skip the query
-            wantShadow = !(contribution.x == 0.0f && contribution.y == 0.0f && contribution.z == 0.0f);
-        }
-
-        if (out.Pdf > 0.001f) // :83-84
-            throughput = throughput * (out.Bsdf / out.Pdf);
-
-        bool finished = false;
-        const float prob = fmin_(maxComponent(throughput), 1.0f); // :86
-        uint32_t bounce = meta.z & 0xffffu;
-        if (prob < 0.001f)
-            finished = true;
-        else if (prob < rnd(meta.x)) // :90
-            finished = true;
-        else
-        {
-            throughput = throughput / prob; // :93
-            bounce = bounce + 1;
-            if (bounce >= p.u.BounceCount)
-                finished = true;
-        }
-        meta.z = (meta.z & 0xffff0000u) | bounce;
-
-        if (wantShadow)
-        {
-            const f3 sd = -normalize(out.LightDirection); // raygen.rgen:24
-            wf.shO[slot] = make_float4(out.Position.x, out.Position.y, out.Position.z, out.LightDistance);
-            wf.shD[slot] = make_float4(sd.x, sd.y, sd.z, finished ? 1.0f : 0.0f);
-            wf.shC[slot] = make_float4(contribution.x, contribution.y, contribution.z, 0.0f);
-            wf.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-            if (!finished)
+            if (pair == 0xffffffffu)
             {
-                wf.rayO[slot] = make_float4(out.Position.x, out.Position.y, out.Position.z, out.MaxRoughness);
-                wf.rayD[slot] = make_float4(out.Direction.x, out.Direction.y, out.Direction.z, 0.0f);
-                wf.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, 0.0f);
+                // miss.rmiss:37-39 (MissFlagsNone): constant sky, Pdf = -1 -> raygen.rgen:71-75
+                radiance = radiance + throughput * F3(0.08f, 0.09f, 0.1f);
+                pushNext = finishSample(p, wf, slot, meta, radiance, nSamples, nRetries);
             }
-            wf.shadowQueue[atomicAdd(&wf.counters[C_SHADOW], 1u)] = slot;
+            else
+            {
+                const float4 o4 = wf.rayO[slot], d4 = wf.rayD[slot];
+                HitOut out;
+                closestHit(sv, F3(d4.x, d4.y, d4.z), hit.x, hit.y, hit.z, pair, __float_as_uint(hit.w), o4.w, meta.x, out);
+                nHits++;
+
+                radiance = radiance + throughput * out.Emissive; // raygen.rgen:77
+
+                // raygen.rgen:79-81, evaluated with the pre-update throughput
+                f3 contribution = F3s(0.0f);
+                if (out.DirectLightPdf > 0.0f)
+                {
+                    contribution = (throughput * out.DirectLight) / out.DirectLightPdf;
+                    // adding an exact zero cannot change radiance (it is never -0): skip the query
+                    pushShadow = !(contribution.x == 0.0f && contribution.y == 0.0f && contribution.z == 0.0f);
+                }
+
+                if (out.Pdf > 0.001f) // :83-84
+                    throughput = throughput * (out.Bsdf / out.Pdf);
+
+                bool finished = false;
+                const float prob = fmin_(maxComponent(throughput), 1.0f); // :86
+                uint32_t bounce = meta.z & 0xffffu;
+                if (prob < 0.001f)
+                    finished = true;
+                else if (prob < rnd(meta.x)) // :90
+                    finished = true;
+                else
+                {
+                    throughput = throughput / prob; // :93
+                    bounce = bounce + 1;
+                    if (bounce >= p.u.BounceCount)
+                        finished = true;
+                }
+                meta.z = (meta.z & 0xffff0000u) | bounce;
+
+                if (pushShadow)
+                {
+                    const f3 sd = -normalize(out.LightDirection); // raygen.rgen:24
+                    wf.shO[slot] = make_float4(out.Position.x, out.Position.y, out.Position.z, out.LightDistance);
+                    wf.shD[slot] = make_float4(sd.x, sd.y, sd.z, finished ? 1.0f : 0.0f);
+                    wf.shC[slot] = make_float4(contribution.x, contribution.y, contribution.z, 0.0f);
+                }
+                if (finished && !pushShadow)
+                    pushNext = finishSample(p, wf, slot, meta, radiance, nSamples, nRetries);
+                else
+                {
+                    wf.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+                    if (!finished)
+                    {
+                        wf.rayO[slot] = make_float4(out.Position.x, out.Position.y, out.Position.z, out.MaxRoughness);
+                        wf.rayD[slot] = make_float4(out.Direction.x, out.Direction.y, out.Direction.z, 0.0f);
+                        wf.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, 0.0f);
+                        pushNext = !pushShadow; // with a shadow query pending, k_trace_shadow forwards the slot
+                    }
+                }
+            }
+            wf.meta[slot] = meta;
         }
-        else if (finished)
-        {
-            if (finishSample(p, wf, slot, meta, radiance))
-                wf.queue[qout][atomicAdd(&wf.counters[qout], 1u)] = slot;
-        }
-        else
-        {
-            wf.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-            wf.rayO[slot] = make_float4(out.Position.x, out.Position.y, out.Position.z, out.MaxRoughness);
-            wf.rayD[slot] = make_float4(out.Direction.x, out.Direction.y, out.Direction.z, 0.0f);
-            wf.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, 0.0f);
-            wf.queue[qout][atomicAdd(&wf.counters[qout], 1u)] = slot;
-        }
-        wf.meta[slot] = meta;
+        wavePush(wf.shadowQueue, &wf.counters[C_SHADOW], pushShadow, slot);
+        wavePush(wf.queue[qout], &wf.counters[qout], pushNext, slot);
     }
+    waveAddCounter(&wf.counters[C_HITS], nHits);
+    waveAddCounter(&wf.counters[C_SAMPLES], nSamples);
+    waveAddCounter(&wf.counters[C_RETRIES], nRetries);
 }
 
 __global__ void __launch_bounds__(kBlock) k_trace_shadow(LaunchParams p, TraceScene sc, Wavefront wf, int qout)
@@ -296,35 +330,44 @@ __global__ void __launch_bounds__(kBlock) k_trace_shadow(LaunchParams p, TraceSc
     st.lds = &s_stack[0][threadIdx.x];
     st.stride = kBlock;
     const uint32_t count = wf.counters[C_SHADOW];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
+    uint32_t nSamples = 0, nRetries = 0;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x)
     {
-        const uint32_t slot = wf.shadowQueue[i];
-        const float4 o = wf.shO[slot], d = wf.shD[slot];
-        Hit h;
-        // raygen.rgen:26-31: tmin = 1e-5, tmax = LightDistance, terminate on first hit
-        const bool occluded = traceRay<true>(sc, F3(o.x, o.y, o.z), F3(d.x, d.y, d.z), 0.00001f, o.w, st, h);
-        float4 r4 = wf.rad[slot];
-        if (!occluded)
+        const uint32_t i = base + threadIdx.x;
+        bool pushNext = false;
+        uint32_t slot = 0;
+        if (i < count)
         {
-            const float4 c = wf.shC[slot];
-            r4.x = r4.x + c.x;
-            r4.y = r4.y + c.y;
-            r4.z = r4.z + c.z;
+            slot = wf.shadowQueue[i];
+            const float4 o = wf.shO[slot], d = wf.shD[slot];
+            Hit h;
+            // raygen.rgen:26-31: tmin = 1e-5, tmax = LightDistance, terminate on first hit
+            const bool occluded = traceRay<true>(sc, F3(o.x, o.y, o.z), F3(d.x, d.y, d.z), 0.00001f, o.w, st, h);
+            float4 r4 = wf.rad[slot];
+            if (!occluded)
+            {
+                const float4 c = wf.shC[slot];
+                r4.x = r4.x + c.x;
+                r4.y = r4.y + c.y;
+                r4.z = r4.z + c.z;
+            }
+            if (d.w != 0.0f)
+            {
+                uint4 meta = wf.meta[slot];
+                f3 radiance = F3(r4.x, r4.y, r4.z);
+                pushNext = finishSample(p, wf, slot, meta, radiance, nSamples, nRetries);
+                wf.meta[slot] = meta;
+            }
+            else
+            {
+                wf.rad[slot] = r4;
+                pushNext = true;
+            }
         }
-        if (d.w != 0.0f)
-        {
-            uint4 meta = wf.meta[slot];
-            f3 radiance = F3(r4.x, r4.y, r4.z);
-            if (finishSample(p, wf, slot, meta, radiance))
-                wf.queue[qout][atomicAdd(&wf.counters[qout], 1u)] = slot;
-            wf.meta[slot] = meta;
-        }
-        else
-        {
-            wf.rad[slot] = r4;
-            wf.queue[qout][atomicAdd(&wf.counters[qout], 1u)] = slot;
-        }
+        wavePush(wf.queue[qout], &wf.counters[qout], pushNext, slot);
     }
+    waveAddCounter(&wf.counters[C_SAMPLES], nSamples);
+    waveAddCounter(&wf.counters[C_RETRIES], nRetries);
 }
 
 // raygen.rgen:115-117 for `frames` launches in frame order: bit-identical to issuing the
@@ -361,19 +404,13 @@ __global__ void __launch_bounds__(kBlock) k_megakernel(LaunchParams p, SceneView
     st.lds = &s_stack[0][threadIdx.x];
     st.stride = kBlock;
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= p.numSlots)
-        return;
     const uint32_t f = slot / p.slotsPerFrame, s = slot % p.slotsPerFrame;
-    const uint32_t pixel = slotPixel(p, s);
-    if (pixel == 0xffffffffu)
-    {
-        slotRad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        return;
-    }
-    uint32_t rng = initRng(pixel % p.width, pixel / p.width, p.width, p.firstFrame + f);
+    const uint32_t pixel = slot < p.numSlots ? slotPixel(p, s) : 0xffffffffu;
+    const bool live = pixel != 0xffffffffu;
+    uint32_t rng = live ? initRng(pixel % p.width, pixel / p.width, p.width, p.firstFrame + f) : 0u;
     f3 radiance = F3s(0.0f);
     uint32_t nSeg = 0, nHit = 0, nSmp = 0, nRetry = 0;
-    for (int smpl = 0; smpl < (int)p.u.SampleCount; smpl++)
+    for (int smpl = 0; live && smpl < (int)p.u.SampleCount; smpl++)
     {
         f3 throughput = F3s(1.0f);
         f3 ro, rd;
@@ -423,11 +460,12 @@ __global__ void __launch_bounds__(kBlock) k_megakernel(LaunchParams p, SceneView
             continue;
         }
     }
-    slotRad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-    atomicAdd(&counters[C_SEGMENTS], nSeg);
-    atomicAdd(&counters[C_HITS], nHit);
-    atomicAdd(&counters[C_SAMPLES], nSmp);
-    atomicAdd(&counters[C_RETRIES], nRetry);
+    if (slot < p.numSlots)
+        slotRad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+    waveAddCounter(&counters[C_SEGMENTS], nSeg);
+    waveAddCounter(&counters[C_HITS], nHit);
+    waveAddCounter(&counters[C_SAMPLES], nSmp);
+    waveAddCounter(&counters[C_RETRIES], nRetry);
 }
 
 // =====================================================================================
