@@ -42,6 +42,19 @@ def algorithmic_bytes_per_closest_ray(n_tris: int) -> int:
     return 32 * L + 36 + 4 + 32 + 20
 
 
+def effective_cores() -> int:
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (the
+    GPU box exposes 256 logical CPUs but grants a 16-CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(orc, pkg, scene, width, height, depth, seconds):
     """The oracle (a scalar C port of the shader path: OpenMP over 16x16 pixel tiles, binned-SAH BVH)
     on the host cores, on a bounded sample of the same workload: the same full frame, one sample
@@ -52,7 +65,7 @@ def cpu_baseline(orc, pkg, scene, width, height, depth, seconds):
     osc = orc.OracleScene(desc, build_bvh=True)
     build_s = time.time() - t0
     acc = np.zeros((height, width, 4), np.float32)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = effective_cores()
     frames = 0
     t0 = time.time()
     while True:
@@ -84,6 +97,8 @@ def main():
     ap.add_argument("--backend", default="wavefront", choices=["wavefront", "megakernel"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-json", default=None,
+                    help="per-kernel HBM bytes per launch from tools/pmc_traffic.py (default: newest profiles/r*_traffic.json)")
     args = ap.parse_args()
 
     import torch
@@ -195,6 +210,18 @@ def main():
                 "avg_launch_ms": trace_ms / max(trace_launches, 1), "launches": trace_launches,
                 "grays_per_s": closest_rays / (trace_ms * 1e-3) / 1e9,
             }
+            # HBM traffic comes from separate rocprofv3 --pmc passes of this same command (PMC counters
+            # cannot be read from inside the process); the committed summary is attached when the
+            # workload is the default one it was collected on.
+            import glob
+            tj = args.traffic_json or (sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic.json"))) or [None])[-1]
+            default_workload = (args.scene, args.detail, W, H, args.spp, args.depth, world) == ("chess_like", 1.0, 1920, 1080, 8, 8, 1)
+            if tj and os.path.exists(tj) and default_workload:
+                t = json.load(open(tj)).get("k_trace_closest")
+                if t:
+                    out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = os.path.relpath(tj, REPO) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, (2*FETCH+WRITE)*1024)"
+                    out["roofline"]["algorithmic_bytes_per_launch"] = bpr * closest_rays / max(trace_launches, 1)
         if world == 1 and not args.no_cpu_baseline:
             orc = graft.load_oracle()
             out["cpu_baseline"] = cpu_baseline(orc, pkg, scene, W, H, args.depth, args.cpu_seconds)

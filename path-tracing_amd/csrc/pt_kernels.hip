@@ -24,6 +24,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -75,6 +76,7 @@ struct LaunchParams
     uint32_t slotsPerFrame; // ownedTiles * tileSize^2
     uint32_t frames, firstFrame;
     uint32_t numSlots;
+    uint32_t ownedPixels; // slots of one frame that map to a pixel inside the image
 };
 
 // slot -> pixel.  Owned tiles are rank, rank+world, ...; inside a tile pixels are laid
@@ -150,19 +152,19 @@ PT_DEV void waveAddCounter(uint32_t *__restrict__ counter, uint32_t v)
         atomicAdd(counter, v);
 }
 
+constexpr uint32_t kDeadPair = 0xfffffffeu; // hitPair of a slot outside the image (ragged edge tiles)
+
+// No queue atomics here: queue 0 is the identity over all slots (the host sets its count);
+// slots of edge tiles that fall outside the image are flagged dead through rayD.w < 0.
 __global__ void __launch_bounds__(kBlock) k_generate(LaunchParams p, Wavefront wf)
 {
-    for (uint32_t base = blockIdx.x * blockDim.x; base < p.numSlots; base += gridDim.x * blockDim.x)
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < p.numSlots; slot += gridDim.x * blockDim.x)
     {
-        const uint32_t slot = base + threadIdx.x;
-        const bool valid = slot < p.numSlots;
         const uint32_t f = slot / p.slotsPerFrame, s = slot % p.slotsPerFrame;
-        const uint32_t pixel = valid ? slotPixel(p, s) : 0xffffffffu;
+        const uint32_t pixel = slotPixel(p, s);
         const uint32_t frame = p.firstFrame + f;
         uint4 meta = make_uint4(0u, pixel, 0u, frame);
-        wavePush(wf.queue[0], &wf.counters[C_ACTIVE0], pixel != 0xffffffffu, slot);
-        if (!valid)
-            continue;
+        wf.queue[0][slot] = slot;
         if (pixel != 0xffffffffu)
         {
             uint32_t rng = initRng(pixel % p.width, pixel / p.width, p.width, frame); // raygen.rgen:38
@@ -175,7 +177,10 @@ __global__ void __launch_bounds__(kBlock) k_generate(LaunchParams p, Wavefront w
             wf.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
         else
+        {
+            wf.rayD[slot] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
             wf.slotRad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
         wf.meta[slot] = meta;
     }
 }
@@ -190,7 +195,13 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(TraceScene sc, Wavefro
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
     {
         const uint32_t slot = wf.queue[qin][i];
-        const float4 o = wf.rayO[slot], d = wf.rayD[slot];
+        const float4 d = wf.rayD[slot];
+        if (d.w < 0.0f)
+        {
+            wf.hitPair[slot] = kDeadPair;
+            continue;
+        }
+        const float4 o = wf.rayO[slot];
         Hit h;
         // ray.glsl:79-80: tmin = 1e-5, tmax = 1e4 on every segment
         traceRay<false>(sc, F3(o.x, o.y, o.z), F3(d.x, d.y, d.z), 0.00001f, 10000.0f, st, h);
@@ -231,21 +242,24 @@ PT_DEV bool finishSample(const LaunchParams &p, const Wavefront &wf, uint32_t sl
 
 __global__ void __launch_bounds__(kBlock) k_shade(LaunchParams p, SceneView sv, Wavefront wf, int qin)
 {
+    __shared__ uint32_t s_cnt[2], s_base[2];
     const int qout = qin ^ 1;
     const uint32_t count = wf.counters[qin];
     uint32_t nHits = 0, nSamples = 0, nRetries = 0;
     for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x)
     {
         const uint32_t i = base + threadIdx.x;
-        const bool valid = i < count;
         bool pushNext = false, pushShadow = false;
-        uint32_t slot = 0;
-        if (valid)
+        uint32_t slot = 0, pair = kDeadPair;
+        if (i < count)
         {
             slot = wf.queue[qin][i];
+            pair = wf.hitPair[slot];
+        }
+        if (pair != kDeadPair)
+        {
             uint4 meta = wf.meta[slot];
             const float4 hit = wf.hit[slot];
-            const uint32_t pair = wf.hitPair[slot];
             const float4 r4 = wf.rad[slot], t4 = wf.thr[slot];
             f3 radiance = F3(r4.x, r4.y, r4.z), throughput = F3(t4.x, t4.y, t4.z);
 
@@ -309,14 +323,38 @@ __global__ void __launch_bounds__(kBlock) k_shade(LaunchParams p, SceneView sv, 
                         wf.rayO[slot] = make_float4(out.Position.x, out.Position.y, out.Position.z, out.MaxRoughness);
                         wf.rayD[slot] = make_float4(out.Direction.x, out.Direction.y, out.Direction.z, 0.0f);
                         wf.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, 0.0f);
-                        pushNext = !pushShadow; // with a shadow query pending, k_trace_shadow forwards the slot
+                        pushNext = true; // a pending shadow query only adds to rad[slot] before the next bounce
                     }
                 }
             }
             wf.meta[slot] = meta;
         }
-        wavePush(wf.shadowQueue, &wf.counters[C_SHADOW], pushShadow, slot);
-        wavePush(wf.queue[qout], &wf.counters[qout], pushNext, slot);
+        // queue appends with ONE global atomic per block and queue: same-address atomics
+        // serialise at ~11 ns each on MI355X, so per-wave appends would cost more than the shading
+        if (threadIdx.x < 2)
+            s_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint64_t maskS = __ballot(pushShadow), maskN = __ballot(pushNext);
+        uint32_t waveS = 0, waveN = 0;
+        if (lane == 0)
+        {
+            if (maskS)
+                waveS = atomicAdd(&s_cnt[0], (uint32_t)__popcll(maskS));
+            if (maskN)
+                waveN = atomicAdd(&s_cnt[1], (uint32_t)__popcll(maskN));
+        }
+        waveS = __shfl(waveS, 0);
+        waveN = __shfl(waveN, 0);
+        __syncthreads();
+        if (threadIdx.x < 2 && s_cnt[threadIdx.x])
+            s_base[threadIdx.x] = atomicAdd(&wf.counters[threadIdx.x == 0 ? (int)C_SHADOW : qout], s_cnt[threadIdx.x]);
+        __syncthreads();
+        const uint64_t below = (1ull << lane) - 1ull;
+        if (pushShadow)
+            wf.shadowQueue[s_base[0] + waveS + (uint32_t)__popcll(maskS & below)] = slot;
+        if (pushNext)
+            wf.queue[qout][s_base[1] + waveN + (uint32_t)__popcll(maskN & below)] = slot;
     }
     waveAddCounter(&wf.counters[C_HITS], nHits);
     waveAddCounter(&wf.counters[C_SAMPLES], nSamples);
@@ -359,12 +397,9 @@ __global__ void __launch_bounds__(kBlock) k_trace_shadow(LaunchParams p, TraceSc
                 wf.meta[slot] = meta;
             }
             else
-            {
-                wf.rad[slot] = r4;
-                pushNext = true;
-            }
+                wf.rad[slot] = r4; // the slot is already in the next queue (k_shade)
         }
-        wavePush(wf.queue[qout], &wf.counters[qout], pushNext, slot);
+        wavePush(wf.queue[qout], &wf.counters[qout], pushNext, slot); // rare: new sample / NaN restart
     }
     waveAddCounter(&wf.counters[C_SAMPLES], nSamples);
     waveAddCounter(&wf.counters[C_RETRIES], nRetries);
@@ -800,6 +835,13 @@ static LaunchParams makeParams(const PtxRenderer *r, const PtxRaygenUniformData 
     p.frames = frames;
     p.firstFrame = firstFrame;
     p.numSlots = p.slotsPerFrame * frames;
+    for (uint32_t t = p.rank; t < p.numTiles; t += p.worldSize)
+    {
+        const uint32_t x0 = (t % p.tilesX) * p.tileSize, y0 = (t / p.tilesX) * p.tileSize;
+        const uint32_t w = r->width - x0 < p.tileSize ? r->width - x0 : p.tileSize;
+        const uint32_t h = r->height - y0 < p.tileSize ? r->height - y0 : p.tileSize;
+        p.ownedPixels += w * h;
+    }
     return p;
 }
 
@@ -1034,13 +1076,13 @@ int ptx_build_accel(PtxRenderer *r)
     DevBuf<float4> boxLo, boxHi, nodeLo, nodeHi;
     DevBuf<uint32_t> sceneBounds, vals0, vals1, hist, flags;
     DevBuf<uint64_t> keys0, keys1;
-    DevBuf<int2> children;
+    DevBuf<int2> children, ranges;
     DevBuf<int> parentOfNode, parentOfLeaf;
     const uint32_t numTiles = (n + kSortTile - 1) / kSortTile;
     auto freeAll = [&]() {
         triTmp.release(); boxLo.release(); boxHi.release(); nodeLo.release(); nodeHi.release(); sceneBounds.release();
         vals0.release(); vals1.release(); hist.release(); flags.release(); keys0.release(); keys1.release();
-        children.release(); parentOfNode.release(); parentOfLeaf.release();
+        children.release(); ranges.release(); parentOfNode.release(); parentOfLeaf.release();
     };
 #define BUILD_TRY(expr)                                                                                                    \
     do                                                                                                                     \
@@ -1055,7 +1097,7 @@ int ptx_build_accel(PtxRenderer *r)
     } while (0)
     BUILD_TRY(triTmp.alloc(n)); BUILD_TRY(boxLo.alloc(n)); BUILD_TRY(boxHi.alloc(n)); BUILD_TRY(nodeLo.alloc(n)); BUILD_TRY(nodeHi.alloc(n));
     BUILD_TRY(sceneBounds.alloc(6)); BUILD_TRY(vals0.alloc(n)); BUILD_TRY(vals1.alloc(n)); BUILD_TRY(hist.alloc((size_t)256 * numTiles));
-    BUILD_TRY(flags.alloc(n)); BUILD_TRY(keys0.alloc(n)); BUILD_TRY(keys1.alloc(n)); BUILD_TRY(children.alloc(n));
+    BUILD_TRY(flags.alloc(n)); BUILD_TRY(keys0.alloc(n)); BUILD_TRY(keys1.alloc(n)); BUILD_TRY(children.alloc(n)); BUILD_TRY(ranges.alloc(n));
     BUILD_TRY(parentOfNode.alloc(n)); BUILD_TRY(parentOfLeaf.alloc(n));
 
     const uint32_t initBounds[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
@@ -1063,6 +1105,9 @@ int ptx_build_accel(PtxRenderer *r)
     BUILD_TRY(hipMemsetAsync(flags.p, 0, (size_t)n * 4, r->stream));
     BUILD_TRY(hipEventRecord(r->evA, r->stream));
 
+    int leafTris = kDefaultLeafTris; // PTX_LEAF_TRIS: tuning knob for experiments
+    if (const char *e = getenv("PTX_LEAF_TRIS"))
+        leafTris = atoi(e) > 0 ? atoi(e) : leafTris;
     const uint32_t blocks = (n + 255) / 256;
     k_tri_setup<<<blocks, 256, 0, r->stream>>>(n, r->pairCount, r->pairFirst.p, r->pairs.p, r->vertices.p, r->indices.p, triTmp.p,
                                                boxLo.p, boxHi.p, sceneBounds.p);
@@ -1081,11 +1126,11 @@ int ptx_build_accel(PtxRenderer *r)
         k_single_leaf_root<<<1, 1, 0, r->stream>>>(boxLo.p, boxHi.p, triTmp.p, r->nodes.p, r->tris.p);
     else
     {
-        k_karras<<<blocks, 256, 0, r->stream>>>((int)n, kin, children.p, parentOfNode.p, parentOfLeaf.p);
+        k_karras<<<blocks, 256, 0, r->stream>>>((int)n, kin, children.p, parentOfNode.p, parentOfLeaf.p, ranges.p);
         k_refit<<<blocks, 256, 0, r->stream>>>((int)n, vin, boxLo.p, boxHi.p, children.p, parentOfNode.p, parentOfLeaf.p, nodeLo.p,
                                                nodeHi.p, flags.p);
-        k_emit<<<blocks, 256, 0, r->stream>>>((int)n, vin, boxLo.p, boxHi.p, children.p, nodeLo.p, nodeHi.p, triTmp.p, r->nodes.p,
-                                              r->tris.p);
+        k_emit<<<blocks, 256, 0, r->stream>>>((int)n, vin, boxLo.p, boxHi.p, children.p, ranges.p, nodeLo.p, nodeHi.p, triTmp.p,
+                                              r->nodes.p, r->tris.p, leafTris);
     }
     BUILD_TRY(hipEventRecord(r->evB, r->stream));
     BUILD_TRY(hipStreamSynchronize(r->stream));
@@ -1202,9 +1247,8 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
     wf.queue[0] = r->queue0.p; wf.queue[1] = r->queue1.p; wf.shadowQueue = r->shadowQueue.p; wf.counters = r->counters.p;
 
     k_generate<<<gridFor(p.numSlots), kBlock, 0, r->stream>>>(p, wf);
-    HIP_TRY(r, hipMemcpyAsync(r->hostCounters, r->counters.p, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
-    HIP_TRY(r, hipStreamSynchronize(r->stream));
-    uint32_t active = r->hostCounters[C_ACTIVE0];
+    HIP_TRY(r, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&r->counters.p[C_ACTIVE0]), (int)p.numSlots, 1, r->stream));
+    uint32_t active = p.numSlots;
     int qin = 0;
     double traceMs = 0.0;
     // every iteration advances each active path by one bounce; NaN/Inf restarts
@@ -1233,7 +1277,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
         float ms = 0.0f;
         (void)hipEventElapsedTime(&ms, r->evT0, r->evT1);
         traceMs += ms;
-        r->stats.segments += active;
+        r->stats.segments += iteration == 1 ? p.ownedPixels * frames : active;
         r->stats.traceLaunches += 2;
         active = r->hostCounters[qout];
         qin = qout;
