@@ -297,9 +297,11 @@ typedef struct PtxStats {
     uint64_t triangles;      /* flattened world-space triangles in the LBVH         */
     uint64_t bvhNodes;       /* internal LBVH nodes                                 */
     double lastRenderMs;     /* device time of the last ptx_render (HIP events)     */
-    double lastTraceMs;      /* ... spent in the traversal kernels                  */
+    double lastTraceMs;      /* ... spent in k_trace_closest (HIP events on the stream) */
     double lastBuildMs;      /* device time of the last ptx_build_accel             */
     uint64_t traceLaunches;  /* number of traversal kernel launches in last render  */
+    double lastShadeMs;      /* ... spent in k_shade                                */
+    double lastShadowMs;     /* ... spent in k_trace_shadow                         */
 } PtxStats;
 
 typedef struct PtxRenderer PtxRenderer;

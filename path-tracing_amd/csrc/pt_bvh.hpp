@@ -12,9 +12,14 @@
 // transform, no two-level walk.
 //
 // Layout in HBM
-//   BvhNode   64 B  both children's AABBs + child refs: one fetch = 4 x dwordx4
+//   BvhNode   64 B  FOUR children: node origin + per-axis power-of-two scale, 8-bit
+//                   quantised child boxes (conservative: they only grow), 4 child refs.
+//                   One visit = 4 x dwordx4 for four boxes -- half the bytes per child of a
+//                   binary node and half the depth.  Measured reason: with binary 64-B nodes
+//                   the traversal kernels were bound by the per-CU address/L1 pipeline (every
+//                   lane fetches its own node: 4 divergent dwordx4 per visit), not by HBM.
 //   Tri       48 B  v0, e1, e2 (Moeller-Trumbore form) + (pair, prim) ids, in leaf order
-// child ref >= 0: internal node index; < 0: leaf, triangle slot = ~ref.
+// child ref >= 0: internal node index; < 0: leaf, triangle slot = ~ref; kEmptyRef: no child.
 #pragma once
 
 #include "pt_device.hpp"
@@ -24,12 +29,13 @@ namespace ptd
 
 struct BvhNode
 {
-    float4 a; // c0.lo.xyz, c0.hi.x
-    float4 b; // c0.hi.yz, c1.lo.xy
-    float4 c; // c1.lo.z, c1.hi.xyz
-    int4 d;   // child0, child1, leaf triangle counts of child0 / child1
+    float4 a; // origin.xyz, w = bits: biased exponents ex | ey << 8 | ez << 16 (scale = 2^(e-127))
+    int4 refs; // child refs
+    uint4 q0; // x = lo.x bytes of children 0..3, y = hi.x bytes, z = lo.y bytes, w = hi.y bytes
+    uint4 q1; // x = lo.z bytes, y = hi.z bytes, z, w unused
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode is 64 B");
+constexpr int kEmptyRef = 0x7ffffffe;
 
 struct Tri
 {
@@ -255,7 +261,7 @@ PT_DEV int karrasDelta(const uint64_t *keys, int n, int i, int j)
 }
 
 __global__ void k_karras(int n, const uint64_t *__restrict__ keys, int2 *__restrict__ children, int *__restrict__ parentOfNode,
-                         int *__restrict__ parentOfLeaf, int2 *__restrict__ ranges)
+                         int *__restrict__ parentOfLeaf)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1)
@@ -284,7 +290,6 @@ __global__ void k_karras(int n, const uint64_t *__restrict__ keys, int2 *__restr
     const int left = (lo == gamma) ? ~gamma : gamma;            // leaf refs are ~index
     const int right = (hi == gamma + 1) ? ~(gamma + 1) : gamma + 1;
     children[i] = make_int2(left, right);
-    ranges[i] = make_int2(lo, hi); // sorted-leaf range covered by this node (inclusive)
     if (left < 0)
         parentOfLeaf[~left] = i;
     else
@@ -332,55 +337,161 @@ __global__ void k_refit(int n, const uint32_t *__restrict__ vals, const float4 *
     }
 }
 
-// Final layout: 64-B nodes holding both children's boxes; triangles in leaf order.  A
-// child subtree of at most kMaxLeafTris triangles becomes ONE leaf (its triangles are
-// contiguous in Morton order): ref = ~first, count in d.z / d.w.
-constexpr int kDefaultLeafTris = 1; // measured on MI355X: 1 -> 591, 2 -> 573, 4 -> 518, 8 -> 437 Msamples/s (chess_like 1080p)
+// Final layout.  Every binary LBVH node i becomes one 4-wide node: start from its two
+// children and, twice, replace the internal child with the largest surface area by that
+// child's two children (greedy SAH-style collapse).  Nodes that end up inside another
+// node's expansion are simply never referenced (the tree is walked from node 0), so the
+// collapse needs no top-down pass.  Child boxes are quantised to 8 bits inside the node's
+// own box with a per-axis power-of-two scale; quantisation is conservative and is checked
+// against the exact decode arithmetic of the traversal (o + q * scale).
+constexpr int kDefaultLeafTris = 1;
+
+struct ChildBox
+{
+    float lo[3], hi[3];
+    int ref;
+};
+
+PT_DEV void fetchChild(int ref, const uint32_t *vals, const float4 *boxLo, const float4 *boxHi, const float4 *nodeLo,
+                       const float4 *nodeHi, ChildBox &c)
+{
+    float4 l, h;
+    if (ref < 0) { const uint32_t g = vals[~ref]; l = boxLo[g]; h = boxHi[g]; }
+    else { l = nodeLo[ref]; h = nodeHi[ref]; }
+    c.lo[0] = l.x; c.lo[1] = l.y; c.lo[2] = l.z;
+    c.hi[0] = h.x; c.hi[1] = h.y; c.hi[2] = h.z;
+    c.ref = ref;
+}
+
+PT_DEV float childArea(const ChildBox &c)
+{
+    const float dx = c.hi[0] - c.lo[0], dy = c.hi[1] - c.lo[1], dz = c.hi[2] - c.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+PT_DEV float decodeQ(float o, uint32_t q, float scale) { return o + (float)q * scale; }
 
 __global__ void k_emit(int n, const uint32_t *__restrict__ vals, const float4 *__restrict__ boxLo,
-                       const float4 *__restrict__ boxHi, const int2 *__restrict__ children, const int2 *__restrict__ ranges,
-                       const float4 *__restrict__ nodeLo, const float4 *__restrict__ nodeHi, const Tri *__restrict__ triTmp,
-                       BvhNode *__restrict__ nodes, Tri *__restrict__ tris, int kMaxLeafTris)
+                       const float4 *__restrict__ boxHi, const int2 *__restrict__ children, const float4 *__restrict__ nodeLo,
+                       const float4 *__restrict__ nodeHi, const Tri *__restrict__ triTmp, BvhNode *__restrict__ nodes,
+                       Tri *__restrict__ tris)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n)
         tris[i] = triTmp[vals[i]];
     if (i >= n - 1)
         return;
-    const int2 ch = children[i];
-    float4 l0, h0, l1, h1;
-    if (ch.x < 0) { const uint32_t g = vals[~ch.x]; l0 = boxLo[g]; h0 = boxHi[g]; }
-    else { l0 = nodeLo[ch.x]; h0 = nodeHi[ch.x]; }
-    if (ch.y < 0) { const uint32_t g = vals[~ch.y]; l1 = boxLo[g]; h1 = boxHi[g]; }
-    else { l1 = nodeLo[ch.y]; h1 = nodeHi[ch.y]; }
-    int ref0 = ch.x, ref1 = ch.y, cnt0 = 1, cnt1 = 1;
-    if (ref0 >= 0)
+    ChildBox c[4];
+    int count = 2;
     {
-        const int2 rg = ranges[ref0];
-        if (rg.y - rg.x + 1 <= kMaxLeafTris) { cnt0 = rg.y - rg.x + 1; ref0 = ~rg.x; }
+        const int2 ch = children[i];
+        fetchChild(ch.x, vals, boxLo, boxHi, nodeLo, nodeHi, c[0]);
+        fetchChild(ch.y, vals, boxLo, boxHi, nodeLo, nodeHi, c[1]);
     }
-    if (ref1 >= 0)
+    for (int round = 0; round < 2; round++)
     {
-        const int2 rg = ranges[ref1];
-        if (rg.y - rg.x + 1 <= kMaxLeafTris) { cnt1 = rg.y - rg.x + 1; ref1 = ~rg.x; }
+        int pick = -1;
+        float best = -1.0f;
+        for (int k = 0; k < 4; k++)
+            if (k < count && c[k].ref >= 0)
+            {
+                const float a = childArea(c[k]);
+                if (a > best) { best = a; pick = k; }
+            }
+        if (pick < 0)
+            break;
+        const int2 ch = children[c[pick].ref];
+        ChildBox a, b;
+        fetchChild(ch.x, vals, boxLo, boxHi, nodeLo, nodeHi, a);
+        fetchChild(ch.y, vals, boxLo, boxHi, nodeLo, nodeHi, b);
+        for (int k = 0; k < 4; k++) // no dynamic register indexing
+            if (k == pick)
+                c[k] = a;
+        for (int k = 0; k < 4; k++)
+            if (k == count)
+                c[k] = b;
+        count++;
+    }
+
+    const float4 nl = nodeLo[i], nh = nodeHi[i];
+    const float o[3] = { nl.x, nl.y, nl.z }, top[3] = { nh.x, nh.y, nh.z };
+    uint32_t ebits[3], qlo[3] = { 0, 0, 0 }, qhi[3] = { 0, 0, 0 };
+    for (int a = 0; a < 3; a++)
+    {
+        // smallest power of two with 255 * scale >= extent, then grow until every child box
+        // survives the round trip through the traversal's decode
+        const float ext = top[a] - o[a];
+        int e = 1;
+        if (ext > 0.0f)
+        {
+            const int be = (int)((__float_as_uint(ext / 255.0f) >> 23) & 0xffu); // floor(log2) + 127
+            e = be + 1;
+            if (e < 1) e = 1;
+            if (e > 254) e = 254;
+        }
+        for (;;)
+        {
+            const float scale = __uint_as_float((uint32_t)e << 23);
+            bool ok = true;
+            uint32_t wl = 0, wh = 0;
+            for (int k = 0; k < 4; k++)
+            {
+                uint32_t ql = 255, qh = 0; // empty slot: inverted box, never hit
+                if (k < count)
+                {
+                    float f = floorf((c[k].lo[a] - o[a]) / scale);
+                    ql = f < 0.0f ? 0u : (f > 255.0f ? 255u : (uint32_t)f);
+                    while (ql > 0 && decodeQ(o[a], ql, scale) > c[k].lo[a])
+                        ql--;
+                    if (decodeQ(o[a], ql, scale) > c[k].lo[a])
+                        ok = false;
+                    f = ceilf((c[k].hi[a] - o[a]) / scale);
+                    qh = f < 0.0f ? 0u : (f > 255.0f ? 255u : (uint32_t)f);
+                    while (qh < 255 && decodeQ(o[a], qh, scale) < c[k].hi[a])
+                        qh++;
+                    if (decodeQ(o[a], qh, scale) < c[k].hi[a])
+                        ok = false;
+                }
+                wl |= ql << (8 * k);
+                wh |= qh << (8 * k);
+            }
+            if (ok || e >= 254)
+            {
+                ebits[a] = (uint32_t)e;
+                qlo[a] = wl;
+                qhi[a] = wh;
+                break;
+            }
+            e++;
+        }
     }
     BvhNode nd;
-    nd.a = make_float4(l0.x, l0.y, l0.z, h0.x);
-    nd.b = make_float4(h0.y, h0.z, l1.x, l1.y);
-    nd.c = make_float4(l1.z, h1.x, h1.y, h1.z);
-    nd.d = make_int4(ref0, ref1, cnt0, cnt1);
+    nd.a = make_float4(o[0], o[1], o[2], __uint_as_float(ebits[0] | (ebits[1] << 8) | (ebits[2] << 16)));
+    nd.refs = make_int4(c[0].ref, c[1].ref, count > 2 ? c[2].ref : kEmptyRef, count > 3 ? c[3].ref : kEmptyRef);
+    nd.q0 = make_uint4(qlo[0], qhi[0], qlo[1], qhi[1]);
+    nd.q1 = make_uint4(qlo[2], qhi[2], 0u, 0u);
     nodes[i] = nd;
 }
 
-// a one-triangle scene has no internal node: give it a root whose second child is empty
+// a one-triangle scene has no internal node: give it a root with one leaf child
 __global__ void k_single_leaf_root(const float4 *boxLo, const float4 *boxHi, const Tri *triTmp, BvhNode *nodes, Tri *tris)
 {
     tris[0] = triTmp[0];
     BvhNode nd;
-    nd.a = make_float4(boxLo[0].x, boxLo[0].y, boxLo[0].z, boxHi[0].x);
-    nd.b = make_float4(boxHi[0].y, boxHi[0].z, 1e30f, 1e30f);
-    nd.c = make_float4(1e30f, -1e30f, -1e30f, -1e30f);
-    nd.d = make_int4(~0, ~0, 1, 0);
+    // origin below the box, scale covering it: child 0 spans the whole quantised range
+    const float lo[3] = { boxLo[0].x, boxLo[0].y, boxLo[0].z }, hi[3] = { boxHi[0].x, boxHi[0].y, boxHi[0].z };
+    uint32_t eb[3];
+    for (int a = 0; a < 3; a++)
+    {
+        int e = 1;
+        while (e < 254 && decodeQ(lo[a], 255u, __uint_as_float((uint32_t)e << 23)) < hi[a])
+            e++;
+        eb[a] = (uint32_t)e;
+    }
+    nd.a = make_float4(lo[0], lo[1], lo[2], __uint_as_float(eb[0] | (eb[1] << 8) | (eb[2] << 16)));
+    nd.refs = make_int4(~0, kEmptyRef, kEmptyRef, kEmptyRef);
+    nd.q0 = make_uint4(0xffffff00u, 0x000000ffu, 0xffffff00u, 0x000000ffu);
+    nd.q1 = make_uint4(0xffffff00u, 0x000000ffu, 0u, 0u);
     nodes[0] = nd;
 }
 
@@ -388,8 +499,13 @@ __global__ void k_single_leaf_root(const float4 *boxLo, const float4 *boxHi, con
 // Traversal
 // ---------------------------------------------------------------------------------
 
-constexpr int kLdsStack = 24;   // entries per lane kept in LDS (lane-interleaved: no bank conflicts)
-constexpr int kSpillStack = 72; // rest of the worst-case LBVH depth (63 Morton bits + 32 tie-break bits)
+#ifndef PT_LDS_STACK
+#define PT_LDS_STACK 16 // measured flat from 8 to 24 (889 +- 4 Msamples/s); 16 leaves LDS room
+#endif
+constexpr int kLdsStack = PT_LDS_STACK; // entries per lane kept in LDS (lane-interleaved: no bank conflicts)
+constexpr int kLdsStackMega = 64;       // the megakernel runs 2 blocks/CU anyway (195 VGPRs): deep LDS stack, no spill
+constexpr int kGlobalSpill = 128;       // overflow entries per persistent thread, in a global buffer
+constexpr uint32_t kMaxPersistentThreads = 2048u * 256u;
 constexpr uint32_t kMaxNodeVisits = 1u << 20;
 
 struct TraceScene
@@ -399,28 +515,53 @@ struct TraceScene
     uint32_t triCount;
 };
 
+// explicit LDS address space: through a generic pointer hipcc emits flat_load/flat_store
+// (checked in the ISA), which go down the vector-memory path instead of ds_read/ds_write
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
+// Traversal stack: LDS first, then an explicit GLOBAL overflow region [entry][thread].
+// Deliberately no private (scratch) array: a 724-B/lane scratch segment cut the traversal
+// kernels' throughput by ~30 % on MI355X (fewer resident waves), measured.
 struct Stack
 {
-    uint32_t *lds; // &s_stack[0][lane]
+    lds_u32 *lds; // &s_stack[0][lane]
     uint32_t stride;
-    uint32_t spill[kSpillStack];
-    int sp;
+    int ldsDepth;
+    uint32_t *spill; // &spillBuffer[thread] or nullptr
+    uint32_t spillStride;
+    int spillDepth;
+    int sp = 0;
+    bool overflow = false;
     PT_DEV void push(uint32_t v)
     {
-        if (sp < kLdsStack)
+        if (sp < ldsDepth)
             lds[sp * stride] = v;
-        else if (sp - kLdsStack < kSpillStack)
-            spill[sp - kLdsStack] = v;
+        else if (sp - ldsDepth < spillDepth)
+            spill[(size_t)(sp - ldsDepth) * spillStride] = v;
+        else
+            overflow = true;
         sp++;
     }
     PT_DEV uint32_t pop()
     {
         sp--;
-        if (sp < kLdsStack)
+        if (sp < ldsDepth)
             return lds[sp * stride];
-        return (sp - kLdsStack < kSpillStack) ? spill[sp - kLdsStack] : 0u;
+        if (sp - ldsDepth < spillDepth)
+            return spill[(size_t)(sp - ldsDepth) * spillStride];
+        return 0xffffffffu; // overflow: a harmless leaf (the launch reports the overflow)
     }
 };
+
+#define PT_DECLARE_STACK(st, DEPTH, spillPtr)                                                                              \
+    __shared__ uint32_t s_stack[DEPTH][kBlock];                                                                            \
+    Stack st;                                                                                                              \
+    st.lds = (lds_u32 *)&s_stack[0][threadIdx.x];                                                                          \
+    st.stride = kBlock;                                                                                                    \
+    st.ldsDepth = DEPTH;                                                                                                   \
+    st.spill = (spillPtr) ? (spillPtr) + (blockIdx.x * blockDim.x + threadIdx.x) : nullptr;                                \
+    st.spillStride = gridDim.x * blockDim.x;                                                                               \
+    st.spillDepth = (spillPtr) ? kGlobalSpill : 0;
 
 // slab test against one child box; returns entry distance in tn
 PT_DEV bool slab(float lx, float ly, float lz, float hx, float hy, float hz, f3 o, f3 id, float tmin, float tmax, float &tn)
@@ -433,18 +574,67 @@ PT_DEV bool slab(float lx, float ly, float lz, float hx, float hy, float hz, f3 
     hi = fminf(hi, fmaxf(t0, t1));
     t0 = (lz - o.z) * id.z;
     t1 = (hz - o.z) * id.z;
+    lo = fmaxf(lo, tmin);
     lo = fmaxf(lo, fminf(t0, t1));
     hi = fminf(hi, fmaxf(t0, t1));
-    lo = fmaxf(lo, tmin);
     hi = fminf(hi, tmax);
     tn = lo;
     return lo <= hi * 1.0000004f;
 }
 
+#define PT_BYTE(w, k) ((float)(((w) >> (8 * (k))) & 0xffu))
+
+// One visit of a 4-wide node: decode + slab-test the four children, then order the hit ones
+// by entry distance (r0 nearest).  Returns the number of children hit.
+PT_DEV int visitNode(const BvhNode *__restrict__ np, f3 o, f3 id, float tmin, float lim, int &r0, int &r1, int &r2, int &r3)
+{
+    const float4 na = np->a;
+    const int4 refs = np->refs;
+    const uint4 q0 = np->q0, q1 = np->q1;
+    const uint32_t eb = __float_as_uint(na.w);
+    const float sx = __uint_as_float((eb & 0xffu) << 23), sy = __uint_as_float(((eb >> 8) & 0xffu) << 23),
+                sz = __uint_as_float(((eb >> 16) & 0xffu) << 23);
+    float t0, t1, t2, t3;
+    bool h0 = slab(na.x + PT_BYTE(q0.x, 0) * sx, na.y + PT_BYTE(q0.z, 0) * sy, na.z + PT_BYTE(q1.x, 0) * sz,
+                         na.x + PT_BYTE(q0.y, 0) * sx, na.y + PT_BYTE(q0.w, 0) * sy, na.z + PT_BYTE(q1.y, 0) * sz, o, id, tmin, lim, t0);
+    bool h1 = slab(na.x + PT_BYTE(q0.x, 1) * sx, na.y + PT_BYTE(q0.z, 1) * sy, na.z + PT_BYTE(q1.x, 1) * sz,
+                         na.x + PT_BYTE(q0.y, 1) * sx, na.y + PT_BYTE(q0.w, 1) * sy, na.z + PT_BYTE(q1.y, 1) * sz, o, id, tmin, lim, t1);
+    bool h2 = slab(na.x + PT_BYTE(q0.x, 2) * sx, na.y + PT_BYTE(q0.z, 2) * sy, na.z + PT_BYTE(q1.x, 2) * sz,
+                         na.x + PT_BYTE(q0.y, 2) * sx, na.y + PT_BYTE(q0.w, 2) * sy, na.z + PT_BYTE(q1.y, 2) * sz, o, id, tmin, lim, t2);
+    bool h3 = slab(na.x + PT_BYTE(q0.x, 3) * sx, na.y + PT_BYTE(q0.z, 3) * sy, na.z + PT_BYTE(q1.x, 3) * sz,
+                         na.x + PT_BYTE(q0.y, 3) * sx, na.y + PT_BYTE(q0.w, 3) * sy, na.z + PT_BYTE(q1.y, 3) * sz, o, id, tmin, lim, t3);
+    h0 = h0 && refs.x != kEmptyRef; // an inverted box is not a miss for the min/max slab form
+    h1 = h1 && refs.y != kEmptyRef;
+    h2 = h2 && refs.z != kEmptyRef;
+    h3 = h3 && refs.w != kEmptyRef;
+    const float inf = __uint_as_float(0x7f800000u);
+    float k0 = h0 ? t0 : inf, k1 = h1 ? t1 : inf, k2 = h2 ? t2 : inf, k3 = h3 ? t3 : inf;
+    r0 = refs.x; r1 = refs.y; r2 = refs.z; r3 = refs.w;
+    // 5-comparator sorting network on (key, ref); misses carry +inf and sink to the end
+#define PT_CSWAP(ka, ra, kb, rb)                                                                                           \
+    {                                                                                                                      \
+        const bool sw = kb < ka;                                                                                           \
+        const float tk = sw ? kb : ka;                                                                                     \
+        kb = sw ? ka : kb;                                                                                                 \
+        ka = tk;                                                                                                           \
+        const int tr = sw ? rb : ra;                                                                                       \
+        rb = sw ? ra : rb;                                                                                                 \
+        ra = tr;                                                                                                           \
+    }
+    PT_CSWAP(k0, r0, k1, r1)
+    PT_CSWAP(k2, r2, k3, r3)
+    PT_CSWAP(k0, r0, k2, r2)
+    PT_CSWAP(k1, r1, k3, r3)
+    PT_CSWAP(k1, r1, k2, r2)
+#undef PT_CSWAP
+    return (int)h0 + (int)h1 + (int)h2 + (int)h3;
+}
+
 // Closest hit = min t over all triangles the ray hits in (tmin, tmax); ties go to the
 // smaller (pair, prim), i.e. the smaller global triangle id -- independent of tree shape.
-template <bool ANY_HIT>
-PT_DEV bool traceRay(const TraceScene &sc, f3 o, f3 d, float tmin, float tmax, Stack &st, Hit &best)
+template <bool ANY_HIT, bool STATS = false>
+PT_DEV bool traceRay(const TraceScene &sc, f3 o, f3 d, float tmin, float tmax, Stack &st, Hit &best, uint32_t *nodeVisits = nullptr,
+                     uint32_t *triTests = nullptr)
 {
     best.t = tmax;
     best.u = best.v = 0.0f;
@@ -454,68 +644,189 @@ PT_DEV bool traceRay(const TraceScene &sc, f3 o, f3 d, float tmin, float tmax, S
         return false;
     const f3 id = F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     st.sp = 0;
-    int node = 0;
+    int ref = 0;
     // a legitimate ray visits a few hundred nodes; the bound only turns a corrupted tree
     // into a wrong pixel instead of a hung GPU
     for (uint32_t visits = 0; visits < kMaxNodeVisits; visits++)
     {
-        const BvhNode *np = &sc.nodes[node];
-        const float4 na = np->a, nb = np->b, nc = np->c;
-        const int4 nd = np->d;
-        const float lim = best.t; // == tmax until something is hit
-        float tn0, tn1;
-        bool h0 = slab(na.x, na.y, na.z, na.w, nb.x, nb.y, o, id, tmin, lim, tn0);
-        bool h1 = slab(nb.z, nb.w, nc.x, nc.y, nc.z, nc.w, o, id, tmin, lim, tn1);
-#pragma unroll
-        for (int k = 0; k < 2; k++)
+        if (ref >= 0)
         {
-            const int ref = k ? nd.y : nd.x;
-            const bool h = k ? h1 : h0;
-            if (h && ref < 0)
+            if (STATS)
+                (*nodeVisits)++;
+            int r0, r1, r2, r3;
+            const int h = visitNode(&sc.nodes[ref], o, id, tmin, best.t, r0, r1, r2, r3);
+            if (h > 3) st.push((uint32_t)r3);
+            if (h > 2) st.push((uint32_t)r2);
+            if (h > 1) st.push((uint32_t)r1);
+            if (h > 0)
+                ref = r0;
+            else
             {
-                const int cnt = k ? nd.w : nd.z;
-                const Tri *tp = &sc.tris[~ref];
-                for (int q = 0; q < cnt; q++, tp++)
-                {
-                    const float4 ta = tp->a, tb = tp->b, tc = tp->c;
-                    float t, u, v;
-                    if (intersectTri(F3(ta.x, ta.y, ta.z), F3(ta.w, tb.x, tb.y), F3(tb.z, tb.w, tc.x), o, d, tmin, tmax, t, u, v))
-                    {
-                        if (ANY_HIT)
-                            return true;
-                        const uint32_t pair = __float_as_uint(tc.y), prim = __float_as_uint(tc.z);
-                        if (t < best.t || (t == best.t && (pair < best.pair || (pair == best.pair && prim < best.prim))))
-                        {
-                            best.t = t;
-                            best.u = u;
-                            best.v = v;
-                            best.pair = pair;
-                            best.prim = prim;
-                        }
-                    }
-                }
+                if (st.sp == 0)
+                    break;
+                ref = (int)st.pop();
             }
         }
-        h0 = h0 && nd.x >= 0;
-        h1 = h1 && nd.y >= 0;
-        if (h0 && h1)
-        {
-            const bool firstIs0 = tn0 <= tn1;
-            st.push((uint32_t)(firstIs0 ? nd.y : nd.x));
-            node = firstIs0 ? nd.x : nd.y;
-        }
-        else if (h0)
-            node = nd.x;
-        else if (h1)
-            node = nd.y;
         else
         {
+            if (STATS)
+                (*triTests)++;
+            const Tri *tp = &sc.tris[~ref];
+            const float4 ta = tp->a, tb = tp->b, tc = tp->c;
+            float t, u, v;
+            if (intersectTri(F3(ta.x, ta.y, ta.z), F3(ta.w, tb.x, tb.y), F3(tb.z, tb.w, tc.x), o, d, tmin, tmax, t, u, v))
+            {
+                const uint32_t pair = __float_as_uint(tc.y), prim = __float_as_uint(tc.z);
+                if (ANY_HIT)
+                {
+                    best.pair = pair;
+                    best.prim = prim;
+                    return true;
+                }
+                if (t < best.t || (t == best.t && (pair < best.pair || (pair == best.pair && prim < best.prim))))
+                {
+                    best.t = t;
+                    best.u = u;
+                    best.v = v;
+                    best.pair = pair;
+                    best.prim = prim;
+                }
+            }
             if (st.sp == 0)
                 break;
-            node = (int)st.pop();
+            ref = (int)st.pop();
         }
     }
     return best.pair != 0xffffffffu;
+}
+
+// ---------------------------------------------------------------------------------
+// Persistent-threads traversal with per-lane ray refill
+// ---------------------------------------------------------------------------------
+// A wave keeps all 64 lanes busy: a lane whose ray is finished takes the next ray of the
+// wave's current chunk (a contiguous run of kTraceChunk queue entries, so neighbouring
+// lanes still hold neighbouring pixels); only when the chunk is used up does lane 0 grab a
+// new one with ONE global atomic.  Per-ray atomics would serialise at ~11 ns each on
+// MI355X (same address), hence chunks.  Each round runs up to kNodeStepsPerRound node
+// visits per lane, then one leaf phase for every lane that reached a leaf, then the
+// refill -- so the triangle code is issued once per round, not once per node visit.
+//
+// IO supplies the queue: bool load(item, o, d, tmin, tmax) (false = nothing to trace,
+// e.g. a dead slot) and void store(item, hit, anyHit).
+constexpr uint32_t kTraceChunk = 128;
+constexpr int kNodeStepsPerRound = 6;
+constexpr int kRefDone = 0x7fffffff;
+
+template <bool ANY_HIT, typename IO>
+PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32_t *__restrict__ chunkCounter, Stack &st)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t below = (1ull << lane) - 1ull;
+    uint32_t cursor = 0, end = 0; // wave-uniform
+    bool exhausted = false;       // wave-uniform
+    bool have = false;
+    uint32_t item = 0;
+    f3 o = F3s(0.0f), d = F3s(0.0f), id = F3s(0.0f);
+    float tmin = 0.0f, tmax = 0.0f;
+    Hit best;
+    best.t = 0.0f; best.u = best.v = 0.0f; best.pair = best.prim = 0xffffffffu;
+    int ref = kRefDone;
+    st.sp = 0;
+    st.overflow = false;
+
+    for (;;)
+    {
+        // ---- refill idle lanes from the wave's chunk
+        const uint64_t idleMask = __ballot(!have);
+        if (idleMask)
+        {
+            if (cursor == end && !exhausted)
+            {
+                uint32_t c = 0;
+                if (lane == 0)
+                    c = atomicAdd(chunkCounter, kTraceChunk);
+                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+                if (c >= count)
+                    exhausted = true;
+                else
+                {
+                    cursor = c;
+                    end = c + kTraceChunk < count ? c + kTraceChunk : count;
+                }
+            }
+            if (cursor < end)
+            {
+                const uint32_t want = (uint32_t)__popcll(idleMask), avail = end - cursor;
+                const uint32_t take = want < avail ? want : avail;
+                const uint32_t rank = (uint32_t)__popcll(idleMask & below);
+                if (!have && rank < take)
+                {
+                    item = cursor + rank;
+                    if (io.load(item, o, d, tmin, tmax))
+                    {
+                        have = true;
+                        id = F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        best.t = tmax;
+                        best.u = best.v = 0.0f;
+                        best.pair = best.prim = 0xffffffffu;
+                        st.sp = 0;
+                        ref = sc.triCount ? 0 : kRefDone;
+                    }
+                }
+                cursor += take;
+            }
+            else if (exhausted && __ballot(have) == 0)
+                break;
+        }
+
+        // ---- node phase: a few visits per lane; lanes at a leaf (ref < 0) wait for the leaf phase
+        for (int step = 0; step < kNodeStepsPerRound; step++)
+        {
+            if (have && ref >= 0 && ref != kRefDone)
+            {
+                int r0, r1, r2, r3;
+                const int h = visitNode(&sc.nodes[ref], o, id, tmin, best.t, r0, r1, r2, r3);
+                if (h > 3) st.push((uint32_t)r3);
+                if (h > 2) st.push((uint32_t)r2);
+                if (h > 1) st.push((uint32_t)r1);
+                ref = h > 0 ? r0 : (st.sp ? (int)st.pop() : kRefDone);
+            }
+        }
+
+        // ---- leaf phase (single-triangle leaves: ref = ~slot)
+        if (have && ref < 0)
+        {
+            const Tri *tp = &sc.tris[~ref];
+            const float4 ta = tp->a, tb = tp->b, tc = tp->c;
+            float t, u, v;
+            ref = st.sp ? (int)st.pop() : kRefDone;
+            if (intersectTri(F3(ta.x, ta.y, ta.z), F3(ta.w, tb.x, tb.y), F3(tb.z, tb.w, tc.x), o, d, tmin, tmax, t, u, v))
+            {
+                const uint32_t pair = __float_as_uint(tc.y), prim = __float_as_uint(tc.z);
+                if (ANY_HIT)
+                {
+                    best.pair = pair;
+                    best.prim = prim;
+                    ref = kRefDone;
+                }
+                else if (t < best.t || (t == best.t && (pair < best.pair || (pair == best.pair && prim < best.prim))))
+                {
+                    best.t = t;
+                    best.u = u;
+                    best.v = v;
+                    best.pair = pair;
+                    best.prim = prim;
+                }
+            }
+        }
+
+        // ---- retire finished rays
+        if (have && ref == kRefDone)
+        {
+            io.store(item, best, best.pair != 0xffffffffu);
+            have = false;
+        }
+    }
 }
 
 } // namespace ptd

@@ -53,6 +53,7 @@ struct Wavefront // device pointers of the per-slot state (SoA)
     uint32_t *queue[2];
     uint32_t *shadowQueue;
     uint32_t *counters; // see enum Counter
+    uint32_t *spill;    // traversal stack overflow region [kGlobalSpill][kMaxPersistentThreads]
 };
 
 enum Counter
@@ -65,7 +66,8 @@ enum Counter
     C_RETRIES = 5,
     C_SEGMENTS = 6,  // megakernel only
     C_OVERFLOW = 7,
-    C_COUNT = 8
+    C_CHUNK = 8, // +0 closest, +1 shadow: next unclaimed queue entry of the persistent traversal kernels
+    C_COUNT = 10
 };
 
 struct LaunchParams
@@ -185,29 +187,41 @@ __global__ void __launch_bounds__(kBlock) k_generate(LaunchParams p, Wavefront w
     }
 }
 
-__global__ void __launch_bounds__(kBlock) k_trace_closest(TraceScene sc, Wavefront wf, int qin)
+struct ClosestIO
 {
-    __shared__ uint32_t s_stack[kLdsStack][kBlock];
-    Stack st;
-    st.lds = &s_stack[0][threadIdx.x];
-    st.stride = kBlock;
-    const uint32_t count = wf.counters[qin];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
+    const Wavefront &wf;
+    const uint32_t *queue;
+    uint32_t slot;
+    PT_DEV bool load(uint32_t item, f3 &o, f3 &d, float &tmin, float &tmax)
     {
-        const uint32_t slot = wf.queue[qin][i];
-        const float4 d = wf.rayD[slot];
-        if (d.w < 0.0f)
+        slot = queue[item];
+        const float4 d4 = wf.rayD[slot];
+        if (d4.w < 0.0f)
         {
             wf.hitPair[slot] = kDeadPair;
-            continue;
+            return false;
         }
-        const float4 o = wf.rayO[slot];
-        Hit h;
-        // ray.glsl:79-80: tmin = 1e-5, tmax = 1e4 on every segment
-        traceRay<false>(sc, F3(o.x, o.y, o.z), F3(d.x, d.y, d.z), 0.00001f, 10000.0f, st, h);
+        const float4 o4 = wf.rayO[slot];
+        o = F3(o4.x, o4.y, o4.z);
+        d = F3(d4.x, d4.y, d4.z);
+        tmin = 0.00001f; // ray.glsl:79-80: tmin = 1e-5, tmax = 1e4 on every segment
+        tmax = 10000.0f;
+        return true;
+    }
+    PT_DEV void store(uint32_t, const Hit &h, bool)
+    {
         wf.hit[slot] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
         wf.hitPair[slot] = h.pair;
     }
+};
+
+__global__ void __launch_bounds__(kBlock) k_trace_closest(TraceScene sc, Wavefront wf, int qin)
+{
+    PT_DECLARE_STACK(st, kLdsStack, wf.spill)
+    ClosestIO io = { wf, wf.queue[qin], 0u };
+    persistentTrace<false>(sc, io, wf.counters[qin], &wf.counters[C_CHUNK], st);
+    if (st.overflow)
+        atomicAdd(&wf.counters[C_OVERFLOW], 1u);
 }
 
 // raygen.rgen:99-112 + sample loop control for a slot whose path has ended.
@@ -361,48 +375,58 @@ __global__ void __launch_bounds__(kBlock) k_shade(LaunchParams p, SceneView sv, 
     waveAddCounter(&wf.counters[C_RETRIES], nRetries);
 }
 
+struct ShadowIO
+{
+    const LaunchParams &p;
+    const Wavefront &wf;
+    int qout;
+    uint32_t slot;
+    float finished;
+    uint32_t nSamples, nRetries;
+    PT_DEV bool load(uint32_t item, f3 &o, f3 &d, float &tmin, float &tmax)
+    {
+        slot = wf.shadowQueue[item];
+        const float4 o4 = wf.shO[slot], d4 = wf.shD[slot];
+        o = F3(o4.x, o4.y, o4.z);
+        d = F3(d4.x, d4.y, d4.z);
+        tmin = 0.00001f; // raygen.rgen:26-31: tmin = 1e-5, tmax = LightDistance, terminate on first hit
+        tmax = o4.w;
+        finished = d4.w;
+        return true;
+    }
+    PT_DEV void store(uint32_t, const Hit &, bool occluded)
+    {
+        float4 r4 = wf.rad[slot];
+        if (!occluded)
+        {
+            const float4 c = wf.shC[slot];
+            r4.x = r4.x + c.x;
+            r4.y = r4.y + c.y;
+            r4.z = r4.z + c.z;
+        }
+        if (finished != 0.0f)
+        {
+            uint4 meta = wf.meta[slot];
+            f3 radiance = F3(r4.x, r4.y, r4.z);
+            // rare (new sample of a multi-sample launch / NaN restart): plain per-lane append
+            if (finishSample(p, wf, slot, meta, radiance, nSamples, nRetries))
+                wf.queue[qout][atomicAdd(&wf.counters[qout], 1u)] = slot;
+            wf.meta[slot] = meta;
+        }
+        else
+            wf.rad[slot] = r4; // the slot is already in the next queue (k_shade)
+    }
+};
+
 __global__ void __launch_bounds__(kBlock) k_trace_shadow(LaunchParams p, TraceScene sc, Wavefront wf, int qout)
 {
-    __shared__ uint32_t s_stack[kLdsStack][kBlock];
-    Stack st;
-    st.lds = &s_stack[0][threadIdx.x];
-    st.stride = kBlock;
-    const uint32_t count = wf.counters[C_SHADOW];
-    uint32_t nSamples = 0, nRetries = 0;
-    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x)
-    {
-        const uint32_t i = base + threadIdx.x;
-        bool pushNext = false;
-        uint32_t slot = 0;
-        if (i < count)
-        {
-            slot = wf.shadowQueue[i];
-            const float4 o = wf.shO[slot], d = wf.shD[slot];
-            Hit h;
-            // raygen.rgen:26-31: tmin = 1e-5, tmax = LightDistance, terminate on first hit
-            const bool occluded = traceRay<true>(sc, F3(o.x, o.y, o.z), F3(d.x, d.y, d.z), 0.00001f, o.w, st, h);
-            float4 r4 = wf.rad[slot];
-            if (!occluded)
-            {
-                const float4 c = wf.shC[slot];
-                r4.x = r4.x + c.x;
-                r4.y = r4.y + c.y;
-                r4.z = r4.z + c.z;
-            }
-            if (d.w != 0.0f)
-            {
-                uint4 meta = wf.meta[slot];
-                f3 radiance = F3(r4.x, r4.y, r4.z);
-                pushNext = finishSample(p, wf, slot, meta, radiance, nSamples, nRetries);
-                wf.meta[slot] = meta;
-            }
-            else
-                wf.rad[slot] = r4; // the slot is already in the next queue (k_shade)
-        }
-        wavePush(wf.queue[qout], &wf.counters[qout], pushNext, slot); // rare: new sample / NaN restart
-    }
-    waveAddCounter(&wf.counters[C_SAMPLES], nSamples);
-    waveAddCounter(&wf.counters[C_RETRIES], nRetries);
+    PT_DECLARE_STACK(st, kLdsStack, wf.spill)
+    ShadowIO io = { p, wf, qout, 0u, 0.0f, 0u, 0u };
+    persistentTrace<true>(sc, io, wf.counters[C_SHADOW], &wf.counters[C_CHUNK + 1], st);
+    if (st.overflow)
+        atomicAdd(&wf.counters[C_OVERFLOW], 1u);
+    waveAddCounter(&wf.counters[C_SAMPLES], io.nSamples);
+    waveAddCounter(&wf.counters[C_RETRIES], io.nRetries);
 }
 
 // raygen.rgen:115-117 for `frames` launches in frame order: bit-identical to issuing the
@@ -434,10 +458,7 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(LaunchParams p, const flo
 __global__ void __launch_bounds__(kBlock) k_megakernel(LaunchParams p, SceneView sv, TraceScene sc, float4 *__restrict__ slotRad,
                                                         uint32_t *__restrict__ counters)
 {
-    __shared__ uint32_t s_stack[kLdsStack][kBlock];
-    Stack st;
-    st.lds = &s_stack[0][threadIdx.x];
-    st.stride = kBlock;
+    PT_DECLARE_STACK(st, kLdsStackMega, (uint32_t *)nullptr)
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t f = slot / p.slotsPerFrame, s = slot % p.slotsPerFrame;
     const uint32_t pixel = slot < p.numSlots ? slotPixel(p, s) : 0xffffffffu;
@@ -497,6 +518,8 @@ __global__ void __launch_bounds__(kBlock) k_megakernel(LaunchParams p, SceneView
     }
     if (slot < p.numSlots)
         slotRad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+    if (st.overflow)
+        atomicAdd(&counters[C_OVERFLOW], 1u);
     waveAddCounter(&counters[C_SEGMENTS], nSeg);
     waveAddCounter(&counters[C_HITS], nHit);
     waveAddCounter(&counters[C_SAMPLES], nSmp);
@@ -508,25 +531,49 @@ __global__ void __launch_bounds__(kBlock) k_megakernel(LaunchParams p, SceneView
 // =====================================================================================
 
 // traceRayEXT stand-in over explicit rays (o.xyz, tmin, d.xyz, tmax): traversal parity tests
-__global__ void __launch_bounds__(kBlock) k_trace_rays(TraceScene sc, const float4 *__restrict__ rays, uint32_t n, int anyHit,
-                                                        float4 *__restrict__ outHit, uint2 *__restrict__ outIds)
+struct RaysIO
 {
-    __shared__ uint32_t s_stack[kLdsStack][kBlock];
-    Stack st;
-    st.lds = &s_stack[0][threadIdx.x];
-    st.stride = kBlock;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    const float4 *rays;
+    float4 *outHit;
+    uint2 *outIds;
+    PT_DEV bool load(uint32_t item, f3 &o, f3 &d, float &tmin, float &tmax)
     {
-        const float4 o = rays[2 * i], d = rays[2 * i + 1];
-        Hit h;
-        bool hitAny;
-        if (anyHit)
-            hitAny = traceRay<true>(sc, F3(o.x, o.y, o.z), F3(d.x, d.y, d.z), o.w, d.w, st, h);
-        else
-            hitAny = traceRay<false>(sc, F3(o.x, o.y, o.z), F3(d.x, d.y, d.z), o.w, d.w, st, h);
-        outHit[i] = make_float4(h.t, h.u, h.v, hitAny ? 1.0f : 0.0f);
-        outIds[i] = make_uint2(h.pair, h.prim);
+        const float4 o4 = rays[2 * item], d4 = rays[2 * item + 1];
+        o = F3(o4.x, o4.y, o4.z);
+        d = F3(d4.x, d4.y, d4.z);
+        tmin = o4.w;
+        tmax = d4.w;
+        return true;
     }
+    PT_DEV void store(uint32_t item, const Hit &h, bool hitAny)
+    {
+        outHit[item] = make_float4(h.t, h.u, h.v, hitAny ? 1.0f : 0.0f);
+        outIds[item] = make_uint2(h.pair, h.prim);
+    }
+};
+
+__global__ void __launch_bounds__(kBlock) k_trace_rays(TraceScene sc, const float4 *__restrict__ rays, uint32_t n, int anyHit,
+                                                        float4 *__restrict__ outHit, uint2 *__restrict__ outIds, uint32_t *chunkCounter, uint32_t *spill)
+{
+    PT_DECLARE_STACK(st, kLdsStack, spill)
+    if (anyHit == 2) // diagnostics: closest hit, returning (node visits, triangle tests) instead of ids
+    {
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        {
+            const float4 o = rays[2 * i], d = rays[2 * i + 1];
+            Hit h;
+            uint32_t nv = 0, nt = 0;
+            const bool hitAny = traceRay<false, true>(sc, F3(o.x, o.y, o.z), F3(d.x, d.y, d.z), o.w, d.w, st, h, &nv, &nt);
+            outHit[i] = make_float4(h.t, h.u, h.v, hitAny ? 1.0f : 0.0f);
+            outIds[i] = make_uint2(nv, nt);
+        }
+        return;
+    }
+    RaysIO io = { rays, outHit, outIds };
+    if (anyHit)
+        persistentTrace<true>(sc, io, n, chunkCounter, st);
+    else
+        persistentTrace<false>(sc, io, n, chunkCounter, st);
 }
 
 // shard pack / unpack: tile-major dense buffer [ownedTile][tileSize^2] of RGBA32F
@@ -770,13 +817,13 @@ struct PtxRenderer
     size_t slotCapacity = 0;
     DevBuf<float4> rayO, rayD, thr, rad, hit, shO, shD, shC, slotRad;
     DevBuf<uint4> meta;
-    DevBuf<uint32_t> hitPair, queue0, queue1, shadowQueue, counters;
+    DevBuf<uint32_t> hitPair, queue0, queue1, shadowQueue, counters, spill;
     uint32_t *hostCounters = nullptr; // pinned
 
     DevBuf<float> testIn, testOut;
     DevBuf<PtxLightsUbo> testUbo;
 
-    hipEvent_t evA = nullptr, evB = nullptr, evT0 = nullptr, evT1 = nullptr;
+    hipEvent_t evA = nullptr, evB = nullptr, evT0 = nullptr, evT1 = nullptr, evT2 = nullptr, evT3 = nullptr;
     PtxStats stats = {};
 };
 
@@ -886,8 +933,11 @@ int ptx_create(const PtxDeviceDesc *desc, PtxRenderer **out)
     (void)hipEventCreate(&r->evB);
     (void)hipEventCreate(&r->evT0);
     (void)hipEventCreate(&r->evT1);
+    (void)hipEventCreate(&r->evT2);
+    (void)hipEventCreate(&r->evT3);
     (void)hipHostMalloc(reinterpret_cast<void **>(&r->hostCounters), C_COUNT * sizeof(uint32_t), hipHostMallocDefault);
-    if (r->counters.alloc(C_COUNT) != hipSuccess || r->lights.alloc(1) != hipSuccess || !r->hostCounters)
+    if (r->counters.alloc(C_COUNT) != hipSuccess || r->lights.alloc(1) != hipSuccess || !r->hostCounters ||
+        r->spill.alloc((size_t)kGlobalSpill * kMaxPersistentThreads) != hipSuccess)
     {
         ptx_destroy(r);
         return PTX_ERROR_OUT_OF_MEMORY;
@@ -907,7 +957,7 @@ void ptx_destroy(PtxRenderer *r)
     r->pairs.release(); r->pairFirst.release(); r->lights.release(); r->nodes.release(); r->tris.release();
     r->image.release(); r->rayO.release(); r->rayD.release(); r->thr.release(); r->rad.release(); r->hit.release();
     r->shO.release(); r->shD.release(); r->shC.release(); r->slotRad.release(); r->meta.release(); r->hitPair.release();
-    r->queue0.release(); r->queue1.release(); r->shadowQueue.release(); r->counters.release();
+    r->queue0.release(); r->queue1.release(); r->shadowQueue.release(); r->counters.release(); r->spill.release();
     r->testIn.release(); r->testOut.release(); r->testUbo.release();
     if (r->hostCounters)
         (void)hipHostFree(r->hostCounters);
@@ -915,6 +965,8 @@ void ptx_destroy(PtxRenderer *r)
     if (r->evB) (void)hipEventDestroy(r->evB);
     if (r->evT0) (void)hipEventDestroy(r->evT0);
     if (r->evT1) (void)hipEventDestroy(r->evT1);
+    if (r->evT2) (void)hipEventDestroy(r->evT2);
+    if (r->evT3) (void)hipEventDestroy(r->evT3);
     if (r->ownStream && r->stream)
         (void)hipStreamDestroy(r->stream);
     delete r;
@@ -1076,13 +1128,13 @@ int ptx_build_accel(PtxRenderer *r)
     DevBuf<float4> boxLo, boxHi, nodeLo, nodeHi;
     DevBuf<uint32_t> sceneBounds, vals0, vals1, hist, flags;
     DevBuf<uint64_t> keys0, keys1;
-    DevBuf<int2> children, ranges;
+    DevBuf<int2> children;
     DevBuf<int> parentOfNode, parentOfLeaf;
     const uint32_t numTiles = (n + kSortTile - 1) / kSortTile;
     auto freeAll = [&]() {
         triTmp.release(); boxLo.release(); boxHi.release(); nodeLo.release(); nodeHi.release(); sceneBounds.release();
         vals0.release(); vals1.release(); hist.release(); flags.release(); keys0.release(); keys1.release();
-        children.release(); ranges.release(); parentOfNode.release(); parentOfLeaf.release();
+        children.release(); parentOfNode.release(); parentOfLeaf.release();
     };
 #define BUILD_TRY(expr)                                                                                                    \
     do                                                                                                                     \
@@ -1097,7 +1149,7 @@ int ptx_build_accel(PtxRenderer *r)
     } while (0)
     BUILD_TRY(triTmp.alloc(n)); BUILD_TRY(boxLo.alloc(n)); BUILD_TRY(boxHi.alloc(n)); BUILD_TRY(nodeLo.alloc(n)); BUILD_TRY(nodeHi.alloc(n));
     BUILD_TRY(sceneBounds.alloc(6)); BUILD_TRY(vals0.alloc(n)); BUILD_TRY(vals1.alloc(n)); BUILD_TRY(hist.alloc((size_t)256 * numTiles));
-    BUILD_TRY(flags.alloc(n)); BUILD_TRY(keys0.alloc(n)); BUILD_TRY(keys1.alloc(n)); BUILD_TRY(children.alloc(n)); BUILD_TRY(ranges.alloc(n));
+    BUILD_TRY(flags.alloc(n)); BUILD_TRY(keys0.alloc(n)); BUILD_TRY(keys1.alloc(n)); BUILD_TRY(children.alloc(n));
     BUILD_TRY(parentOfNode.alloc(n)); BUILD_TRY(parentOfLeaf.alloc(n));
 
     const uint32_t initBounds[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
@@ -1105,9 +1157,6 @@ int ptx_build_accel(PtxRenderer *r)
     BUILD_TRY(hipMemsetAsync(flags.p, 0, (size_t)n * 4, r->stream));
     BUILD_TRY(hipEventRecord(r->evA, r->stream));
 
-    int leafTris = kDefaultLeafTris; // PTX_LEAF_TRIS: tuning knob for experiments
-    if (const char *e = getenv("PTX_LEAF_TRIS"))
-        leafTris = atoi(e) > 0 ? atoi(e) : leafTris;
     const uint32_t blocks = (n + 255) / 256;
     k_tri_setup<<<blocks, 256, 0, r->stream>>>(n, r->pairCount, r->pairFirst.p, r->pairs.p, r->vertices.p, r->indices.p, triTmp.p,
                                                boxLo.p, boxHi.p, sceneBounds.p);
@@ -1126,11 +1175,11 @@ int ptx_build_accel(PtxRenderer *r)
         k_single_leaf_root<<<1, 1, 0, r->stream>>>(boxLo.p, boxHi.p, triTmp.p, r->nodes.p, r->tris.p);
     else
     {
-        k_karras<<<blocks, 256, 0, r->stream>>>((int)n, kin, children.p, parentOfNode.p, parentOfLeaf.p, ranges.p);
+        k_karras<<<blocks, 256, 0, r->stream>>>((int)n, kin, children.p, parentOfNode.p, parentOfLeaf.p);
         k_refit<<<blocks, 256, 0, r->stream>>>((int)n, vin, boxLo.p, boxHi.p, children.p, parentOfNode.p, parentOfLeaf.p, nodeLo.p,
                                                nodeHi.p, flags.p);
-        k_emit<<<blocks, 256, 0, r->stream>>>((int)n, vin, boxLo.p, boxHi.p, children.p, ranges.p, nodeLo.p, nodeHi.p, triTmp.p,
-                                              r->nodes.p, r->tris.p, leafTris);
+        k_emit<<<blocks, 256, 0, r->stream>>>((int)n, vin, boxLo.p, boxHi.p, children.p, nodeLo.p, nodeHi.p, triTmp.p, r->nodes.p,
+                                              r->tris.p);
     }
     BUILD_TRY(hipEventRecord(r->evB, r->stream));
     BUILD_TRY(hipStreamSynchronize(r->stream));
@@ -1218,6 +1267,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
     r->stats.pathSamples = r->stats.segments = r->stats.shadowRays = r->stats.retries = 0;
     r->stats.traceLaunches = 0;
     r->stats.lastTraceMs = 0.0;
+    r->stats.lastShadeMs = r->stats.lastShadowMs = 0.0;
     HIP_TRY(r, hipEventRecord(r->evA, r->stream));
 
     if (p.numSlots == 0)
@@ -1234,6 +1284,8 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
         HIP_TRY(r, hipEventRecord(r->evB, r->stream));
         HIP_TRY(r, hipStreamSynchronize(r->stream));
         HIP_TRY(r, hipGetLastError());
+        if (r->hostCounters[C_OVERFLOW])
+            return fail(r, PTX_ERROR_DEVICE, "ptx_render: traversal stack overflow in the megakernel (depth > %d)", kLdsStackMega);
         r->stats.segments = r->hostCounters[C_SEGMENTS];
         r->stats.shadowRays = r->hostCounters[C_HITS];
         r->stats.pathSamples = r->hostCounters[C_SAMPLES];
@@ -1244,7 +1296,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
     Wavefront wf;
     wf.rayO = r->rayO.p; wf.rayD = r->rayD.p; wf.thr = r->thr.p; wf.rad = r->rad.p; wf.meta = r->meta.p; wf.hit = r->hit.p;
     wf.hitPair = r->hitPair.p; wf.shO = r->shO.p; wf.shD = r->shD.p; wf.shC = r->shC.p; wf.slotRad = r->slotRad.p;
-    wf.queue[0] = r->queue0.p; wf.queue[1] = r->queue1.p; wf.shadowQueue = r->shadowQueue.p; wf.counters = r->counters.p;
+    wf.queue[0] = r->queue0.p; wf.queue[1] = r->queue1.p; wf.shadowQueue = r->shadowQueue.p; wf.counters = r->counters.p; wf.spill = r->spill.p;
 
     k_generate<<<gridFor(p.numSlots), kBlock, 0, r->stream>>>(p, wf);
     HIP_TRY(r, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&r->counters.p[C_ACTIVE0]), (int)p.numSlots, 1, r->stream));
@@ -1254,6 +1306,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
     // every iteration advances each active path by one bounce; NaN/Inf restarts
     // (raygen.rgen:99-112) can add iterations but a path that never yields a finite
     // sample would spin forever (it hangs the GPU in the reference): give up instead
+    const bool verbose = getenv("PTX_VERBOSE") != nullptr;
     const uint64_t maxIterations = ((uint64_t)uniform->BounceCount + 1) * uniform->SampleCount * 64 + 64;
     uint64_t iteration = 0;
     while (active)
@@ -1266,19 +1319,37 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
         (void)zero2;
         HIP_TRY(r, hipMemsetAsync(&r->counters.p[qout], 0, sizeof(uint32_t), r->stream));
         HIP_TRY(r, hipMemsetAsync(&r->counters.p[C_SHADOW], 0, sizeof(uint32_t), r->stream));
+        HIP_TRY(r, hipMemsetAsync(&r->counters.p[C_CHUNK], 0, 2 * sizeof(uint32_t), r->stream));
         HIP_TRY(r, hipEventRecord(r->evT0, r->stream));
         k_trace_closest<<<gridFor(active), kBlock, 0, r->stream>>>(sc, wf, qin);
         HIP_TRY(r, hipEventRecord(r->evT1, r->stream));
         k_shade<<<gridFor(active), kBlock, 0, r->stream>>>(p, sv, wf, qin);
+        HIP_TRY(r, hipEventRecord(r->evT2, r->stream));
         // shadow queue size is unknown on the host: size the grid for the upper bound
         k_trace_shadow<<<gridFor(active), kBlock, 0, r->stream>>>(p, sc, wf, qout);
+        HIP_TRY(r, hipEventRecord(r->evT3, r->stream));
         HIP_TRY(r, hipMemcpyAsync(r->hostCounters, r->counters.p, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
         HIP_TRY(r, hipStreamSynchronize(r->stream));
         float ms = 0.0f;
         (void)hipEventElapsedTime(&ms, r->evT0, r->evT1);
         traceMs += ms;
+        (void)hipEventElapsedTime(&ms, r->evT1, r->evT2);
+        r->stats.lastShadeMs += ms;
+        (void)hipEventElapsedTime(&ms, r->evT2, r->evT3);
+        r->stats.lastShadowMs += ms;
+        if (verbose)
+        {
+            float a = 0, b = 0;
+            (void)hipEventElapsedTime(&a, r->evT0, r->evT1);
+            (void)hipEventElapsedTime(&b, r->evT1, r->evT2);
+            fprintf(stderr, "[ptx] bounce %llu: %u rays closest %.3f ms (%.2f Grays/s) | shade %.3f ms | %u shadow rays %.3f ms (%.2f Grays/s)\n",
+                    (unsigned long long)iteration, active, a, active / a / 1e6, b, r->hostCounters[C_SHADOW], ms,
+                    r->hostCounters[C_SHADOW] / ms / 1e6);
+        }
         r->stats.segments += iteration == 1 ? p.ownedPixels * frames : active;
         r->stats.traceLaunches += 2;
+        if (r->hostCounters[C_OVERFLOW])
+            return fail(r, PTX_ERROR_DEVICE, "ptx_render: traversal stack overflow (tree deeper than %d levels)", kLdsStack + kGlobalSpill);
         active = r->hostCounters[qout];
         qin = qout;
     }
@@ -1439,7 +1510,8 @@ int ptx_trace_rays(PtxRenderer *r, const float *rays, uint32_t n, int anyHit, fl
     if (e == hipSuccess)
     {
         (void)hipEventRecord(r->evT0, r->stream);
-        k_trace_rays<<<gridFor(n), kBlock, 0, r->stream>>>(sc, dRays.p, n, anyHit, dHits.p, dIds.p);
+        (void)hipMemsetAsync(&r->counters.p[C_CHUNK], 0, sizeof(uint32_t), r->stream);
+        k_trace_rays<<<gridFor(n), kBlock, 0, r->stream>>>(sc, dRays.p, n, anyHit, dHits.p, dIds.p, &r->counters.p[C_CHUNK], r->spill.p);
         (void)hipEventRecord(r->evT1, r->stream);
         e = hipMemcpyAsync(hits, dHits.p, (size_t)n * 16, hipMemcpyDeviceToHost, r->stream);
     }
