@@ -162,7 +162,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    trace_ms = shade_ms = shadow_ms = 0.0
+    trace_ms = shade_ms = shadow_ms = tail_ms = 0.0
     trace_launches = 0
     closest_rays = 0
     segments = shadow = 0
@@ -173,6 +173,7 @@ def main():
         trace_ms += st.lastTraceMs
         shade_ms += st.lastShadeMs
         shadow_ms += st.lastShadowMs
+        tail_ms += st.lastTailMs
         trace_launches += st.traceLaunches // 2
         closest_rays += st.segments
         segments, shadow = st.segments, st.shadowRays
@@ -201,7 +202,7 @@ def main():
                 "segments_per_sample": segments / (W * H * args.spp / world) if world else None,
                 "lbvh_build_ms": build_ms, "upload_plus_build_s": upload_build_s,
                 "kernel_ms_per_step": {"k_trace_closest": trace_ms / args.steps, "k_shade": shade_ms / args.steps,
-                                       "k_trace_shadow": shadow_ms / args.steps},
+                                       "k_trace_shadow": shadow_ms / args.steps, "k_tail": tail_ms / args.steps},
             },
         }
         if args.backend == "wavefront" and trace_ms > 0:

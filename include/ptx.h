@@ -302,6 +302,7 @@ typedef struct PtxStats {
     uint64_t traceLaunches;  /* number of traversal kernel launches in last render  */
     double lastShadeMs;      /* ... spent in k_shade                                */
     double lastShadowMs;     /* ... spent in k_trace_shadow                         */
+    double lastTailMs;       /* ... spent in k_tail (fused late bounces)            */
 } PtxStats;
 
 typedef struct PtxRenderer PtxRenderer;

@@ -369,7 +369,9 @@ PT_DEV float childArea(const ChildBox &c)
     return dx * dy + dy * dz + dz * dx;
 }
 
-PT_DEV float decodeQ(float o, uint32_t q, float scale) { return o + (float)q * scale; }
+// exact value of o + q * scale (24 + 8 significant bits fit a double): the quantised box must
+// contain the child box in REAL arithmetic, whatever rounding the traversal's slab test applies
+PT_DEV double decodeQ(float o, uint32_t q, float scale) { return (double)o + (double)q * (double)scale; }
 
 __global__ void k_emit(int n, const uint32_t *__restrict__ vals, const float4 *__restrict__ boxLo,
                        const float4 *__restrict__ boxHi, const int2 *__restrict__ children, const float4 *__restrict__ nodeLo,
@@ -441,15 +443,15 @@ __global__ void k_emit(int n, const uint32_t *__restrict__ vals, const float4 *_
                 {
                     float f = floorf((c[k].lo[a] - o[a]) / scale);
                     ql = f < 0.0f ? 0u : (f > 255.0f ? 255u : (uint32_t)f);
-                    while (ql > 0 && decodeQ(o[a], ql, scale) > c[k].lo[a])
+                    while (ql > 0 && decodeQ(o[a], ql, scale) > (double)c[k].lo[a])
                         ql--;
-                    if (decodeQ(o[a], ql, scale) > c[k].lo[a])
+                    if (decodeQ(o[a], ql, scale) > (double)c[k].lo[a])
                         ok = false;
                     f = ceilf((c[k].hi[a] - o[a]) / scale);
                     qh = f < 0.0f ? 0u : (f > 255.0f ? 255u : (uint32_t)f);
-                    while (qh < 255 && decodeQ(o[a], qh, scale) < c[k].hi[a])
+                    while (qh < 255 && decodeQ(o[a], qh, scale) < (double)c[k].hi[a])
                         qh++;
-                    if (decodeQ(o[a], qh, scale) < c[k].hi[a])
+                    if (decodeQ(o[a], qh, scale) < (double)c[k].hi[a])
                         ok = false;
                 }
                 wl |= ql << (8 * k);
@@ -484,7 +486,7 @@ __global__ void k_single_leaf_root(const float4 *boxLo, const float4 *boxHi, con
     for (int a = 0; a < 3; a++)
     {
         int e = 1;
-        while (e < 254 && decodeQ(lo[a], 255u, __uint_as_float((uint32_t)e << 23)) < hi[a])
+        while (e < 254 && decodeQ(lo[a], 255u, __uint_as_float((uint32_t)e << 23)) < (double)hi[a])
             e++;
         eb[a] = (uint32_t)e;
     }
@@ -584,25 +586,40 @@ PT_DEV bool slab(float lx, float ly, float lz, float hx, float hy, float hz, f3 
 
 #define PT_BYTE(w, k) ((float)(((w) >> (8 * (k))) & 0xffu))
 
-// One visit of a 4-wide node: decode + slab-test the four children, then order the hit ones
-// by entry distance (r0 nearest).  Returns the number of children hit.
+// One visit of a 4-wide node: slab-test the four children, then order the hit ones by
+// entry distance (r0 nearest).  Returns the number of children hit.
+// The quantised planes are never decoded: with A = scale * id and B = (origin - o) * id
+// (per node and axis) every plane distance is ONE fma, t = q * A + B.  Box tests only have
+// to be conservative (section "Arithmetic" of DESIGN.md): the builder guarantees the real
+// box o + q * scale contains the child, leaf boxes are padded by 1e-5 relative, and the
+// interval test keeps the (1 + 2^-21) slack.  NaNs (0 * inf for axis-parallel rays) drop out
+// of fminf / fmaxf, which only makes the test more permissive.
 PT_DEV int visitNode(const BvhNode *__restrict__ np, f3 o, f3 id, float tmin, float lim, int &r0, int &r1, int &r2, int &r3)
 {
     const float4 na = np->a;
     const int4 refs = np->refs;
     const uint4 q0 = np->q0, q1 = np->q1;
     const uint32_t eb = __float_as_uint(na.w);
-    const float sx = __uint_as_float((eb & 0xffu) << 23), sy = __uint_as_float(((eb >> 8) & 0xffu) << 23),
-                sz = __uint_as_float(((eb >> 16) & 0xffu) << 23);
+    const float ax = __uint_as_float((eb & 0xffu) << 23) * id.x, ay = __uint_as_float(((eb >> 8) & 0xffu) << 23) * id.y,
+                az = __uint_as_float(((eb >> 16) & 0xffu) << 23) * id.z;
+    const float bx = (na.x - o.x) * id.x, by = (na.y - o.y) * id.y, bz = (na.z - o.z) * id.z;
     float t0, t1, t2, t3;
-    bool h0 = slab(na.x + PT_BYTE(q0.x, 0) * sx, na.y + PT_BYTE(q0.z, 0) * sy, na.z + PT_BYTE(q1.x, 0) * sz,
-                         na.x + PT_BYTE(q0.y, 0) * sx, na.y + PT_BYTE(q0.w, 0) * sy, na.z + PT_BYTE(q1.y, 0) * sz, o, id, tmin, lim, t0);
-    bool h1 = slab(na.x + PT_BYTE(q0.x, 1) * sx, na.y + PT_BYTE(q0.z, 1) * sy, na.z + PT_BYTE(q1.x, 1) * sz,
-                         na.x + PT_BYTE(q0.y, 1) * sx, na.y + PT_BYTE(q0.w, 1) * sy, na.z + PT_BYTE(q1.y, 1) * sz, o, id, tmin, lim, t1);
-    bool h2 = slab(na.x + PT_BYTE(q0.x, 2) * sx, na.y + PT_BYTE(q0.z, 2) * sy, na.z + PT_BYTE(q1.x, 2) * sz,
-                         na.x + PT_BYTE(q0.y, 2) * sx, na.y + PT_BYTE(q0.w, 2) * sy, na.z + PT_BYTE(q1.y, 2) * sz, o, id, tmin, lim, t2);
-    bool h3 = slab(na.x + PT_BYTE(q0.x, 3) * sx, na.y + PT_BYTE(q0.z, 3) * sy, na.z + PT_BYTE(q1.x, 3) * sz,
-                         na.x + PT_BYTE(q0.y, 3) * sx, na.y + PT_BYTE(q0.w, 3) * sy, na.z + PT_BYTE(q1.y, 3) * sz, o, id, tmin, lim, t3);
+    bool h0, h1, h2, h3;
+#define PT_CHILD(k, tn, hk)                                                                                                \
+    {                                                                                                                      \
+        const float lx = __builtin_fmaf(PT_BYTE(q0.x, k), ax, bx), hx = __builtin_fmaf(PT_BYTE(q0.y, k), ax, bx);          \
+        const float ly = __builtin_fmaf(PT_BYTE(q0.z, k), ay, by), hy = __builtin_fmaf(PT_BYTE(q0.w, k), ay, by);          \
+        const float lz = __builtin_fmaf(PT_BYTE(q1.x, k), az, bz), hz = __builtin_fmaf(PT_BYTE(q1.y, k), az, bz);          \
+        const float lo = fmaxf(fmaxf(fminf(lx, hx), fminf(ly, hy)), fmaxf(fminf(lz, hz), tmin));                           \
+        const float hi = fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fminf(fmaxf(lz, hz), lim));                            \
+        tn = lo;                                                                                                           \
+        hk = lo <= hi * 1.0000004f;                                                                                        \
+    }
+    PT_CHILD(0, t0, h0)
+    PT_CHILD(1, t1, h1)
+    PT_CHILD(2, t2, h2)
+    PT_CHILD(3, t3, h3)
+#undef PT_CHILD
     h0 = h0 && refs.x != kEmptyRef; // an inverted box is not a miss for the min/max slab form
     h1 = h1 && refs.y != kEmptyRef;
     h2 = h2 && refs.z != kEmptyRef;
@@ -713,8 +730,14 @@ PT_DEV bool traceRay(const TraceScene &sc, f3 o, f3 d, float tmin, float tmax, S
 //
 // IO supplies the queue: bool load(item, o, d, tmin, tmax) (false = nothing to trace,
 // e.g. a dead slot) and void store(item, hit, anyHit).
-constexpr uint32_t kTraceChunk = 128;
-constexpr int kNodeStepsPerRound = 6;
+#ifndef PT_TRACE_CHUNK
+#define PT_TRACE_CHUNK 128
+#endif
+#ifndef PT_NODE_STEPS
+#define PT_NODE_STEPS 2 // measured: 1 -> 1040, 2 -> 1064, 3 -> 1055, 4 -> 1034, 6 -> 975, 10 -> 872 Msamples/s
+#endif
+constexpr uint32_t kTraceChunk = PT_TRACE_CHUNK;
+constexpr int kNodeStepsPerRound = PT_NODE_STEPS;
 constexpr int kRefDone = 0x7fffffff;
 
 template <bool ANY_HIT, typename IO>

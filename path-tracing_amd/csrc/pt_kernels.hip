@@ -452,30 +452,40 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(LaunchParams p, const flo
 }
 
 // =====================================================================================
-// Megakernel (bring-up / A-B reference): raygen.rgen:36-118 one thread per slot
+// Fused path loop: raygen.rgen:36-118 as one device function.  Used by
+//   * k_megakernel  -- one thread per slot from the first sample (bring-up / A-B reference)
+//   * k_tail        -- finishes the paths still alive once the wavefront has thinned out:
+//                      late bounces have few rays and every per-bounce kernel then costs the
+//                      latency of its LONGEST ray (~0.4 ms measured) whatever the ray count
 // =====================================================================================
 
-__global__ void __launch_bounds__(kBlock) k_megakernel(LaunchParams p, SceneView sv, TraceScene sc, float4 *__restrict__ slotRad,
-                                                        uint32_t *__restrict__ counters)
+struct PathCounters
 {
-    PT_DECLARE_STACK(st, kLdsStackMega, (uint32_t *)nullptr)
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t f = slot / p.slotsPerFrame, s = slot % p.slotsPerFrame;
-    const uint32_t pixel = slot < p.numSlots ? slotPixel(p, s) : 0xffffffffu;
-    const bool live = pixel != 0xffffffffu;
-    uint32_t rng = live ? initRng(pixel % p.width, pixel / p.width, p.width, p.firstFrame + f) : 0u;
-    f3 radiance = F3s(0.0f);
     uint32_t nSeg = 0, nHit = 0, nSmp = 0, nRetry = 0;
-    for (int smpl = 0; live && smpl < (int)p.u.SampleCount; smpl++)
+};
+
+// Runs a slot to the end of its launch.  `fresh` = start with a new sample (primary ray);
+// otherwise continue the current sample at `bounce` with the given ray / throughput.
+PT_DEV f3 runPath(const LaunchParams &p, const SceneView &sv, const TraceScene &sc, Stack &st, uint32_t pixel, uint32_t &rng,
+                  f3 radiance, f3 throughput, f3 ro, f3 rd, float maxRoughness, uint32_t bounce, int smpl, bool fresh,
+                  PathCounters &pc)
+{
+    for (;;)
     {
-        f3 throughput = F3s(1.0f);
-        f3 ro, rd;
-        startSample(p, pixel, rng, ro, rd);
-        float maxRoughness = 0.0f;
-        for (uint32_t bounce = 0; bounce < p.u.BounceCount; bounce++)
+        if (fresh)
+        {
+            if (smpl >= (int)p.u.SampleCount)
+                break;
+            throughput = F3s(1.0f);
+            startSample(p, pixel, rng, ro, rd);
+            maxRoughness = 0.0f;
+            bounce = 0;
+            fresh = false;
+        }
+        for (; bounce < p.u.BounceCount; bounce++)
         {
             Hit h;
-            nSeg++;
+            pc.nSeg++;
             if (!traceRay<false>(sc, ro, rd, 0.00001f, 10000.0f, st, h))
             {
                 radiance = radiance + throughput * F3(0.08f, 0.09f, 0.1f);
@@ -483,7 +493,7 @@ __global__ void __launch_bounds__(kBlock) k_megakernel(LaunchParams p, SceneView
             }
             HitOut out;
             closestHit(sv, rd, h.t, h.u, h.v, h.pair, h.prim, maxRoughness, rng, out);
-            nHit++;
+            pc.nHit++;
             maxRoughness = out.MaxRoughness;
             radiance = radiance + throughput * out.Emissive;
             if (out.DirectLightPdf > 0.0f)
@@ -507,23 +517,70 @@ __global__ void __launch_bounds__(kBlock) k_megakernel(LaunchParams p, SceneView
             ro = out.Position;
             rd = out.Direction;
         }
-        nSmp++;
-        if (badRadiance(radiance))
+        pc.nSmp++;
+        if (badRadiance(radiance)) // raygen.rgen:99-112: restart ALL samples, RNG carried on
         {
             radiance = F3s(0.0f);
-            smpl = -1;
-            nRetry++;
-            continue;
+            smpl = 0;
+            pc.nRetry++;
         }
+        else
+            smpl++;
+        fresh = true;
+    }
+    return radiance;
+}
+
+__global__ void __launch_bounds__(kBlock) k_megakernel(LaunchParams p, SceneView sv, TraceScene sc, float4 *__restrict__ slotRad,
+                                                        uint32_t *__restrict__ counters)
+{
+    PT_DECLARE_STACK(st, kLdsStackMega, (uint32_t *)nullptr)
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t f = slot / p.slotsPerFrame, s = slot % p.slotsPerFrame;
+    const uint32_t pixel = slot < p.numSlots ? slotPixel(p, s) : 0xffffffffu;
+    PathCounters pc;
+    f3 radiance = F3s(0.0f);
+    if (pixel != 0xffffffffu)
+    {
+        uint32_t rng = initRng(pixel % p.width, pixel / p.width, p.width, p.firstFrame + f);
+        radiance = runPath(p, sv, sc, st, pixel, rng, F3s(0.0f), F3s(1.0f), F3s(0.0f), F3s(0.0f), 0.0f, 0u, 0, true, pc);
     }
     if (slot < p.numSlots)
         slotRad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
     if (st.overflow)
         atomicAdd(&counters[C_OVERFLOW], 1u);
-    waveAddCounter(&counters[C_SEGMENTS], nSeg);
-    waveAddCounter(&counters[C_HITS], nHit);
-    waveAddCounter(&counters[C_SAMPLES], nSmp);
-    waveAddCounter(&counters[C_RETRIES], nRetry);
+    waveAddCounter(&counters[C_SEGMENTS], pc.nSeg);
+    waveAddCounter(&counters[C_HITS], pc.nHit);
+    waveAddCounter(&counters[C_SAMPLES], pc.nSmp);
+    waveAddCounter(&counters[C_RETRIES], pc.nRetry);
+}
+
+// The slots of queue `qin` sit at a bounce boundary (ray, throughput, radiance, RNG and
+// bounce/sample counters in the SoA state, no shadow query pending): run each to the end.
+__global__ void __launch_bounds__(kBlock) k_tail(LaunchParams p, SceneView sv, TraceScene sc, Wavefront wf, int qin, uint32_t count)
+{
+    PT_DECLARE_STACK(st, kLdsStackMega, (uint32_t *)nullptr)
+    PathCounters pc;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x)
+    {
+        const uint32_t i = base + threadIdx.x;
+        if (i < count)
+        {
+            const uint32_t slot = wf.queue[qin][i];
+            const uint4 meta = wf.meta[slot];
+            const float4 o4 = wf.rayO[slot], d4 = wf.rayD[slot], t4 = wf.thr[slot], r4 = wf.rad[slot];
+            uint32_t rng = meta.x;
+            const f3 radiance = runPath(p, sv, sc, st, meta.y, rng, F3(r4.x, r4.y, r4.z), F3(t4.x, t4.y, t4.z), F3(o4.x, o4.y, o4.z),
+                                        F3(d4.x, d4.y, d4.z), o4.w, meta.z & 0xffffu, (int)(meta.z >> 16), false, pc);
+            wf.slotRad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+        }
+    }
+    if (st.overflow)
+        atomicAdd(&wf.counters[C_OVERFLOW], 1u);
+    waveAddCounter(&wf.counters[C_SEGMENTS], pc.nSeg);
+    waveAddCounter(&wf.counters[C_HITS], pc.nHit);
+    waveAddCounter(&wf.counters[C_SAMPLES], pc.nSmp);
+    waveAddCounter(&wf.counters[C_RETRIES], pc.nRetry);
 }
 
 // =====================================================================================
@@ -1267,7 +1324,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
     r->stats.pathSamples = r->stats.segments = r->stats.shadowRays = r->stats.retries = 0;
     r->stats.traceLaunches = 0;
     r->stats.lastTraceMs = 0.0;
-    r->stats.lastShadeMs = r->stats.lastShadowMs = 0.0;
+    r->stats.lastShadeMs = r->stats.lastShadowMs = r->stats.lastTailMs = 0.0;
     HIP_TRY(r, hipEventRecord(r->evA, r->stream));
 
     if (p.numSlots == 0)
@@ -1309,8 +1366,31 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
     const bool verbose = getenv("PTX_VERBOSE") != nullptr;
     const uint64_t maxIterations = ((uint64_t)uniform->BounceCount + 1) * uniform->SampleCount * 64 + 64;
     uint64_t iteration = 0;
+    // below this many live paths the remaining bounces run fused in k_tail
+    uint32_t tailThreshold = 300000; // measured: flat from 100 K to 400 K live paths, worse beyond
+    if (const char *e = getenv("PTX_TAIL_THRESHOLD"))
+        tailThreshold = (uint32_t)strtoul(e, nullptr, 10);
+    bool tailDone = false;
     while (active)
     {
+        if (iteration >= 1 && active <= tailThreshold)
+        {
+            HIP_TRY(r, hipEventRecord(r->evT0, r->stream));
+            k_tail<<<gridFor(active, kBlock, 1u << 20), kBlock, 0, r->stream>>>(p, sv, sc, wf, qin, active);
+            HIP_TRY(r, hipEventRecord(r->evT1, r->stream));
+            HIP_TRY(r, hipMemcpyAsync(r->hostCounters, r->counters.p, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
+            HIP_TRY(r, hipStreamSynchronize(r->stream));
+            float ms = 0.0f;
+            (void)hipEventElapsedTime(&ms, r->evT0, r->evT1);
+            r->stats.lastTailMs = ms;
+            if (verbose)
+                fprintf(stderr, "[ptx] tail: %u paths, %u segments, %.3f ms\n", active, r->hostCounters[C_SEGMENTS], ms);
+            if (r->hostCounters[C_OVERFLOW])
+                return fail(r, PTX_ERROR_DEVICE, "ptx_render: traversal stack overflow in k_tail (depth > %d)", kLdsStackMega);
+            r->stats.segments += r->hostCounters[C_SEGMENTS];
+            tailDone = true;
+            break;
+        }
         if (++iteration > maxIterations)
             return fail(r, PTX_ERROR_DEVICE, "ptx_render: %u paths still active after %llu bounce iterations", active,
                         (unsigned long long)maxIterations);
@@ -1353,6 +1433,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
         active = r->hostCounters[qout];
         qin = qout;
     }
+    (void)tailDone;
     k_accumulate<<<gridFor(p.slotsPerFrame), kBlock, 0, r->stream>>>(p, r->slotRad.p, imagePtr(r));
     HIP_TRY(r, hipEventRecord(r->evB, r->stream));
     HIP_TRY(r, hipGetLastError());
