@@ -52,6 +52,7 @@ struct Wavefront // device pointers of the per-slot state (SoA)
     float4 *slotRad; // final radiance of the slot (consumed by k_accumulate)
     uint32_t *queue[2];
     uint32_t *shadowQueue;
+    uint32_t *restartQueue;
     uint32_t *counters; // see enum Counter
     uint32_t *spill;    // traversal stack overflow region [kGlobalSpill][kMaxPersistentThreads]
 };
@@ -67,7 +68,8 @@ enum Counter
     C_SEGMENTS = 6,  // megakernel only
     C_OVERFLOW = 7,
     C_CHUNK = 8, // +0 closest, +1 shadow: next unclaimed queue entry of the persistent traversal kernels
-    C_COUNT = 10
+    C_RESTART = 10, // slots re-queued by k_trace_shadow (new sample / NaN restart), drained after the bounce loop
+    C_COUNT = 12
 };
 
 struct LaunchParams
@@ -215,11 +217,11 @@ struct ClosestIO
     }
 };
 
-__global__ void __launch_bounds__(kBlock) k_trace_closest(TraceScene sc, Wavefront wf, int qin)
+__global__ void __launch_bounds__(kBlock) k_trace_closest(TraceScene sc, Wavefront wf, int qin, uint32_t count)
 {
     PT_DECLARE_STACK(st, kLdsStack, wf.spill)
     ClosestIO io = { wf, wf.queue[qin], 0u };
-    persistentTrace<false>(sc, io, wf.counters[qin], &wf.counters[C_CHUNK], st);
+    persistentTrace<false>(sc, io, count, &wf.counters[C_CHUNK], st);
     if (st.overflow)
         atomicAdd(&wf.counters[C_OVERFLOW], 1u);
 }
@@ -408,9 +410,10 @@ struct ShadowIO
         {
             uint4 meta = wf.meta[slot];
             f3 radiance = F3(r4.x, r4.y, r4.z);
-            // rare (new sample of a multi-sample launch / NaN restart): plain per-lane append
+            // new sample of a multi-sample launch / NaN restart: the slot joins the restart queue
+            // (k_trace_closest of the next bounce may already be consuming the next queue)
             if (finishSample(p, wf, slot, meta, radiance, nSamples, nRetries))
-                wf.queue[qout][atomicAdd(&wf.counters[qout], 1u)] = slot;
+                wf.restartQueue[atomicAdd(&wf.counters[C_RESTART], 1u)] = slot;
             wf.meta[slot] = meta;
         }
         else
@@ -418,11 +421,11 @@ struct ShadowIO
     }
 };
 
-__global__ void __launch_bounds__(kBlock) k_trace_shadow(LaunchParams p, TraceScene sc, Wavefront wf, int qout)
+__global__ void __launch_bounds__(kBlock) k_trace_shadow(LaunchParams p, TraceScene sc, Wavefront wf, int qout, uint32_t count)
 {
     PT_DECLARE_STACK(st, kLdsStack, wf.spill)
     ShadowIO io = { p, wf, qout, 0u, 0.0f, 0u, 0u };
-    persistentTrace<true>(sc, io, wf.counters[C_SHADOW], &wf.counters[C_CHUNK + 1], st);
+    persistentTrace<true>(sc, io, count, &wf.counters[C_CHUNK + 1], st);
     if (st.overflow)
         atomicAdd(&wf.counters[C_OVERFLOW], 1u);
     waveAddCounter(&wf.counters[C_SAMPLES], io.nSamples);
@@ -845,6 +848,7 @@ struct PtxRenderer
     int device = 0;
     uint32_t backend = PTX_BACKEND_WAVEFRONT;
     hipStream_t stream = nullptr;
+    hipStream_t aux = nullptr; // k_trace_shadow(b) runs here, beside k_trace_closest(b+1) on `stream`
     bool ownStream = false;
     std::string error;
 
@@ -874,13 +878,14 @@ struct PtxRenderer
     size_t slotCapacity = 0;
     DevBuf<float4> rayO, rayD, thr, rad, hit, shO, shD, shC, slotRad;
     DevBuf<uint4> meta;
-    DevBuf<uint32_t> hitPair, queue0, queue1, shadowQueue, counters, spill;
+    DevBuf<uint32_t> hitPair, queue0, queue1, shadowQueue, restartQueue, counters, spill, spillAux;
     uint32_t *hostCounters = nullptr; // pinned
 
     DevBuf<float> testIn, testOut;
     DevBuf<PtxLightsUbo> testUbo;
 
     hipEvent_t evA = nullptr, evB = nullptr, evT0 = nullptr, evT1 = nullptr, evT2 = nullptr, evT3 = nullptr;
+    hipEvent_t evShade = nullptr, evShadow[2] = { nullptr, nullptr }, evX0[2] = { nullptr, nullptr };
     PtxStats stats = {};
 };
 
@@ -992,9 +997,18 @@ int ptx_create(const PtxDeviceDesc *desc, PtxRenderer **out)
     (void)hipEventCreate(&r->evT1);
     (void)hipEventCreate(&r->evT2);
     (void)hipEventCreate(&r->evT3);
+    (void)hipEventCreateWithFlags(&r->evShade, hipEventDisableTiming);
+    for (int k = 0; k < 2; k++)
+    {
+        (void)hipEventCreate(&r->evShadow[k]);
+        (void)hipEventCreate(&r->evX0[k]);
+    }
+    if (hipStreamCreateWithFlags(&r->aux, hipStreamNonBlocking) != hipSuccess)
+        r->aux = nullptr;
     (void)hipHostMalloc(reinterpret_cast<void **>(&r->hostCounters), C_COUNT * sizeof(uint32_t), hipHostMallocDefault);
     if (r->counters.alloc(C_COUNT) != hipSuccess || r->lights.alloc(1) != hipSuccess || !r->hostCounters ||
-        r->spill.alloc((size_t)kGlobalSpill * kMaxPersistentThreads) != hipSuccess)
+        r->spill.alloc((size_t)kGlobalSpill * kMaxPersistentThreads) != hipSuccess ||
+        r->spillAux.alloc((size_t)kGlobalSpill * kMaxPersistentThreads) != hipSuccess)
     {
         ptx_destroy(r);
         return PTX_ERROR_OUT_OF_MEMORY;
@@ -1014,7 +1028,7 @@ void ptx_destroy(PtxRenderer *r)
     r->pairs.release(); r->pairFirst.release(); r->lights.release(); r->nodes.release(); r->tris.release();
     r->image.release(); r->rayO.release(); r->rayD.release(); r->thr.release(); r->rad.release(); r->hit.release();
     r->shO.release(); r->shD.release(); r->shC.release(); r->slotRad.release(); r->meta.release(); r->hitPair.release();
-    r->queue0.release(); r->queue1.release(); r->shadowQueue.release(); r->counters.release(); r->spill.release();
+    r->queue0.release(); r->queue1.release(); r->shadowQueue.release(); r->counters.release(); r->spill.release(); r->spillAux.release(); r->restartQueue.release();
     r->testIn.release(); r->testOut.release(); r->testUbo.release();
     if (r->hostCounters)
         (void)hipHostFree(r->hostCounters);
@@ -1024,6 +1038,17 @@ void ptx_destroy(PtxRenderer *r)
     if (r->evT1) (void)hipEventDestroy(r->evT1);
     if (r->evT2) (void)hipEventDestroy(r->evT2);
     if (r->evT3) (void)hipEventDestroy(r->evT3);
+    if (r->evShade) (void)hipEventDestroy(r->evShade);
+    for (int k = 0; k < 2; k++)
+    {
+        if (r->evShadow[k]) (void)hipEventDestroy(r->evShadow[k]);
+        if (r->evX0[k]) (void)hipEventDestroy(r->evX0[k]);
+    }
+    if (r->aux)
+    {
+        (void)hipStreamSynchronize(r->aux);
+        (void)hipStreamDestroy(r->aux);
+    }
     if (r->ownStream && r->stream)
         (void)hipStreamDestroy(r->stream);
     delete r;
@@ -1289,6 +1314,7 @@ static int ensureSlots(PtxRenderer *r, size_t slots)
     HIP_TRY(r, r->hit.alloc(slots)); HIP_TRY(r, r->shO.alloc(slots)); HIP_TRY(r, r->shD.alloc(slots)); HIP_TRY(r, r->shC.alloc(slots));
     HIP_TRY(r, r->meta.alloc(slots)); HIP_TRY(r, r->hitPair.alloc(slots));
     HIP_TRY(r, r->queue0.alloc(slots)); HIP_TRY(r, r->queue1.alloc(slots)); HIP_TRY(r, r->shadowQueue.alloc(slots));
+    HIP_TRY(r, r->restartQueue.alloc(slots));
     r->slotCapacity = slots;
     return PTX_OK;
 }
@@ -1353,7 +1379,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
     Wavefront wf;
     wf.rayO = r->rayO.p; wf.rayD = r->rayD.p; wf.thr = r->thr.p; wf.rad = r->rad.p; wf.meta = r->meta.p; wf.hit = r->hit.p;
     wf.hitPair = r->hitPair.p; wf.shO = r->shO.p; wf.shD = r->shD.p; wf.shC = r->shC.p; wf.slotRad = r->slotRad.p;
-    wf.queue[0] = r->queue0.p; wf.queue[1] = r->queue1.p; wf.shadowQueue = r->shadowQueue.p; wf.counters = r->counters.p; wf.spill = r->spill.p;
+    wf.queue[0] = r->queue0.p; wf.queue[1] = r->queue1.p; wf.shadowQueue = r->shadowQueue.p; wf.restartQueue = r->restartQueue.p; wf.counters = r->counters.p; wf.spill = r->spill.p;
 
     k_generate<<<gridFor(p.numSlots), kBlock, 0, r->stream>>>(p, wf);
     HIP_TRY(r, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&r->counters.p[C_ACTIVE0]), (int)p.numSlots, 1, r->stream));
@@ -1370,11 +1396,49 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
     uint32_t tailThreshold = 300000; // measured: flat from 100 K to 400 K live paths, worse beyond
     if (const char *e = getenv("PTX_TAIL_THRESHOLD"))
         tailThreshold = (uint32_t)strtoul(e, nullptr, 10);
-    bool tailDone = false;
-    while (active)
+    // k_trace_shadow(b) only adds into rad[slot]; k_trace_closest(b+1) never touches rad.  So the
+    // shadow query of a bounce runs on the aux stream beside the closest-hit query of the next
+    // one; k_shade(b+1) -- which reads rad -- waits for it.  In late bounces both kernels are
+    // bound by the latency of their longest ray, so the overlap is almost free.
+    Wavefront wfAux = wf;
+    wfAux.spill = r->spillAux.p;
+    hipStream_t sx = r->aux ? r->aux : r->stream;
+    bool shadowPending = false;
+    int shadowSlot = 0;
+    double shadowMs = 0.0;
+    auto drainShadow = [&](bool wait) -> hipError_t {
+        if (!shadowPending)
+            return hipSuccess;
+        if (wait)
+        {
+            const hipError_t e = hipEventSynchronize(r->evShadow[shadowSlot]);
+            if (e != hipSuccess)
+                return e;
+        }
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, r->evX0[shadowSlot], r->evShadow[shadowSlot]) == hipSuccess)
+            shadowMs += ms;
+        shadowPending = false;
+        return hipSuccess;
+    };
+    for (;;)
     {
+        if (!active)
+        {
+            // paths re-queued by the shadow kernel (next sample of a multi-sample launch, NaN restart)
+            HIP_TRY(r, drainShadow(true));
+            HIP_TRY(r, hipMemcpyAsync(r->hostCounters, r->counters.p, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
+            HIP_TRY(r, hipStreamSynchronize(r->stream));
+            const uint32_t restarts = r->hostCounters[C_RESTART];
+            if (!restarts)
+                break;
+            HIP_TRY(r, hipMemcpyAsync(wf.queue[qin], wf.restartQueue, (size_t)restarts * sizeof(uint32_t), hipMemcpyDeviceToDevice, r->stream));
+            HIP_TRY(r, hipMemsetAsync(&r->counters.p[C_RESTART], 0, sizeof(uint32_t), r->stream));
+            active = restarts;
+        }
         if (iteration >= 1 && active <= tailThreshold)
         {
+            HIP_TRY(r, drainShadow(true)); // k_tail continues from rad[slot]
             HIP_TRY(r, hipEventRecord(r->evT0, r->stream));
             k_tail<<<gridFor(active, kBlock, 1u << 20), kBlock, 0, r->stream>>>(p, sv, sc, wf, qin, active);
             HIP_TRY(r, hipEventRecord(r->evT1, r->stream));
@@ -1382,50 +1446,54 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
             HIP_TRY(r, hipStreamSynchronize(r->stream));
             float ms = 0.0f;
             (void)hipEventElapsedTime(&ms, r->evT0, r->evT1);
-            r->stats.lastTailMs = ms;
+            r->stats.lastTailMs += ms;
             if (verbose)
                 fprintf(stderr, "[ptx] tail: %u paths, %u segments, %.3f ms\n", active, r->hostCounters[C_SEGMENTS], ms);
             if (r->hostCounters[C_OVERFLOW])
                 return fail(r, PTX_ERROR_DEVICE, "ptx_render: traversal stack overflow in k_tail (depth > %d)", kLdsStackMega);
             r->stats.segments += r->hostCounters[C_SEGMENTS];
-            tailDone = true;
-            break;
+            HIP_TRY(r, hipMemsetAsync(&r->counters.p[C_SEGMENTS], 0, sizeof(uint32_t), r->stream));
+            active = 0; // every path of the queue ran to the end of the launch
+            continue;
         }
         if (++iteration > maxIterations)
             return fail(r, PTX_ERROR_DEVICE, "ptx_render: %u paths still active after %llu bounce iterations", active,
                         (unsigned long long)maxIterations);
         const int qout = qin ^ 1;
-        const uint32_t zero2[2] = { 0u, 0u };
-        (void)zero2;
         HIP_TRY(r, hipMemsetAsync(&r->counters.p[qout], 0, sizeof(uint32_t), r->stream));
         HIP_TRY(r, hipMemsetAsync(&r->counters.p[C_SHADOW], 0, sizeof(uint32_t), r->stream));
-        HIP_TRY(r, hipMemsetAsync(&r->counters.p[C_CHUNK], 0, 2 * sizeof(uint32_t), r->stream));
+        HIP_TRY(r, hipMemsetAsync(&r->counters.p[C_CHUNK], 0, sizeof(uint32_t), r->stream));
         HIP_TRY(r, hipEventRecord(r->evT0, r->stream));
-        k_trace_closest<<<gridFor(active), kBlock, 0, r->stream>>>(sc, wf, qin);
+        k_trace_closest<<<gridFor(active), kBlock, 0, r->stream>>>(sc, wf, qin, active);
         HIP_TRY(r, hipEventRecord(r->evT1, r->stream));
+        if (shadowPending) // k_shade reads rad[slot]: the previous bounce's shadow adds must have landed
+            HIP_TRY(r, hipStreamWaitEvent(r->stream, r->evShadow[shadowSlot], 0));
         k_shade<<<gridFor(active), kBlock, 0, r->stream>>>(p, sv, wf, qin);
         HIP_TRY(r, hipEventRecord(r->evT2, r->stream));
-        // shadow queue size is unknown on the host: size the grid for the upper bound
-        k_trace_shadow<<<gridFor(active), kBlock, 0, r->stream>>>(p, sc, wf, qout);
-        HIP_TRY(r, hipEventRecord(r->evT3, r->stream));
+        HIP_TRY(r, hipEventRecord(r->evShade, r->stream));
         HIP_TRY(r, hipMemcpyAsync(r->hostCounters, r->counters.p, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
         HIP_TRY(r, hipStreamSynchronize(r->stream));
+        HIP_TRY(r, drainShadow(false)); // its event completed before k_shade started
         float ms = 0.0f;
         (void)hipEventElapsedTime(&ms, r->evT0, r->evT1);
         traceMs += ms;
+        const float closestMs = ms;
         (void)hipEventElapsedTime(&ms, r->evT1, r->evT2);
         r->stats.lastShadeMs += ms;
-        (void)hipEventElapsedTime(&ms, r->evT2, r->evT3);
-        r->stats.lastShadowMs += ms;
-        if (verbose)
+        const uint32_t shadowCount = r->hostCounters[C_SHADOW];
+        if (shadowCount)
         {
-            float a = 0, b = 0;
-            (void)hipEventElapsedTime(&a, r->evT0, r->evT1);
-            (void)hipEventElapsedTime(&b, r->evT1, r->evT2);
-            fprintf(stderr, "[ptx] bounce %llu: %u rays closest %.3f ms (%.2f Grays/s) | shade %.3f ms | %u shadow rays %.3f ms (%.2f Grays/s)\n",
-                    (unsigned long long)iteration, active, a, active / a / 1e6, b, r->hostCounters[C_SHADOW], ms,
-                    r->hostCounters[C_SHADOW] / ms / 1e6);
+            shadowSlot ^= 1;
+            HIP_TRY(r, hipStreamWaitEvent(sx, r->evShade, 0));
+            HIP_TRY(r, hipMemsetAsync(&r->counters.p[C_CHUNK + 1], 0, sizeof(uint32_t), sx));
+            HIP_TRY(r, hipEventRecord(r->evX0[shadowSlot], sx));
+            k_trace_shadow<<<gridFor(shadowCount), kBlock, 0, sx>>>(p, sc, wfAux, qout, shadowCount);
+            HIP_TRY(r, hipEventRecord(r->evShadow[shadowSlot], sx));
+            shadowPending = true;
         }
+        if (verbose)
+            fprintf(stderr, "[ptx] bounce %llu: %u rays closest %.3f ms (%.2f Grays/s) | shade %.3f ms | %u shadow rays\n",
+                    (unsigned long long)iteration, active, closestMs, active / closestMs / 1e6, ms, shadowCount);
         r->stats.segments += iteration == 1 ? p.ownedPixels * frames : active;
         r->stats.traceLaunches += 2;
         if (r->hostCounters[C_OVERFLOW])
@@ -1433,7 +1501,13 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
         active = r->hostCounters[qout];
         qin = qout;
     }
-    (void)tailDone;
+    r->stats.lastShadowMs = shadowMs;
+    if (r->aux) // later work on `stream` (accumulate, readback) is ordered after everything on aux
+        HIP_TRY(r, hipStreamSynchronize(r->aux));
+    HIP_TRY(r, hipMemcpyAsync(r->hostCounters, r->counters.p, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(r, hipStreamSynchronize(r->stream));
+    if (r->hostCounters[C_OVERFLOW])
+        return fail(r, PTX_ERROR_DEVICE, "ptx_render: traversal stack overflow");
     k_accumulate<<<gridFor(p.slotsPerFrame), kBlock, 0, r->stream>>>(p, r->slotRad.p, imagePtr(r));
     HIP_TRY(r, hipEventRecord(r->evB, r->stream));
     HIP_TRY(r, hipGetLastError());
