@@ -603,15 +603,19 @@ PT_DEV int visitNode(const BvhNode *__restrict__ np, f3 o, f3 id, float tmin, fl
     const float ax = __uint_as_float((eb & 0xffu) << 23) * id.x, ay = __uint_as_float(((eb >> 8) & 0xffu) << 23) * id.y,
                 az = __uint_as_float(((eb >> 16) & 0xffu) << 23) * id.z;
     const float bx = (na.x - o.x) * id.x, by = (na.y - o.y) * id.y, bz = (na.z - o.z) * id.z;
+    // entry / exit plane per axis from the sign of the direction: no per-child min/max pairs
+    const bool ngx = id.x < 0.0f, ngy = id.y < 0.0f, ngz = id.z < 0.0f;
+    const uint32_t nx = ngx ? q0.y : q0.x, fx = ngx ? q0.x : q0.y;
+    const uint32_t ny = ngy ? q0.w : q0.z, fy = ngy ? q0.z : q0.w;
+    const uint32_t nz = ngz ? q1.y : q1.x, fz = ngz ? q1.x : q1.y;
     float t0, t1, t2, t3;
     bool h0, h1, h2, h3;
 #define PT_CHILD(k, tn, hk)                                                                                                \
     {                                                                                                                      \
-        const float lx = __builtin_fmaf(PT_BYTE(q0.x, k), ax, bx), hx = __builtin_fmaf(PT_BYTE(q0.y, k), ax, bx);          \
-        const float ly = __builtin_fmaf(PT_BYTE(q0.z, k), ay, by), hy = __builtin_fmaf(PT_BYTE(q0.w, k), ay, by);          \
-        const float lz = __builtin_fmaf(PT_BYTE(q1.x, k), az, bz), hz = __builtin_fmaf(PT_BYTE(q1.y, k), az, bz);          \
-        const float lo = fmaxf(fmaxf(fminf(lx, hx), fminf(ly, hy)), fmaxf(fminf(lz, hz), tmin));                           \
-        const float hi = fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fminf(fmaxf(lz, hz), lim));                            \
+        const float lo = fmaxf(fmaxf(__builtin_fmaf(PT_BYTE(nx, k), ax, bx), __builtin_fmaf(PT_BYTE(ny, k), ay, by)),      \
+                               fmaxf(__builtin_fmaf(PT_BYTE(nz, k), az, bz), tmin));                                       \
+        const float hi = fminf(fminf(__builtin_fmaf(PT_BYTE(fx, k), ax, bx), __builtin_fmaf(PT_BYTE(fy, k), ay, by)),      \
+                               fminf(__builtin_fmaf(PT_BYTE(fz, k), az, bz), lim));                                        \
         tn = lo;                                                                                                           \
         hk = lo <= hi * 1.0000004f;                                                                                        \
     }
@@ -647,6 +651,20 @@ PT_DEV int visitNode(const BvhNode *__restrict__ np, f3 o, f3 id, float tmin, fl
     return (int)h0 + (int)h1 + (int)h2 + (int)h3;
 }
 
+// A ray whose origin/direction is not finite, whose direction is zero or whose interval is
+// empty hits nothing (the triangle test rejects it); without this early-out its NaN plane
+// distances would drop out of every fminf/fmaxf and it would walk the whole tree.
+PT_DEV bool rayIsTraceable(f3 o, f3 d, float tmin, float tmax)
+{
+    const float s = (o.x + o.y + o.z) + (d.x + d.y + d.z); // NaN or inf if any component is
+    const bool finite = abs_(s) < __uint_as_float(0x7f800000u);
+    const bool nonzero = d.x != 0.0f || d.y != 0.0f || d.z != 0.0f;
+    return finite && nonzero && tmax > tmin;
+}
+
+// 1/d for the slab tests only (never for the triangle test): v_rcp_f32, 1 ulp
+PT_DEV f3 fastInverse(f3 d) { return F3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)); }
+
 // Closest hit = min t over all triangles the ray hits in (tmin, tmax); ties go to the
 // smaller (pair, prim), i.e. the smaller global triangle id -- independent of tree shape.
 template <bool ANY_HIT, bool STATS = false>
@@ -657,9 +675,9 @@ PT_DEV bool traceRay(const TraceScene &sc, f3 o, f3 d, float tmin, float tmax, S
     best.u = best.v = 0.0f;
     best.pair = 0xffffffffu;
     best.prim = 0xffffffffu;
-    if (sc.triCount == 0)
+    if (sc.triCount == 0 || !rayIsTraceable(o, d, tmin, tmax))
         return false;
-    const f3 id = F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const f3 id = fastInverse(d);
     st.sp = 0;
     int ref = 0;
     // a legitimate ray visits a few hundred nodes; the bound only turns a corrupted tree
@@ -788,12 +806,12 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
                     if (io.load(item, o, d, tmin, tmax))
                     {
                         have = true;
-                        id = F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        id = fastInverse(d);
                         best.t = tmax;
                         best.u = best.v = 0.0f;
                         best.pair = best.prim = 0xffffffffu;
                         st.sp = 0;
-                        ref = sc.triCount ? 0 : kRefDone;
+                        ref = (sc.triCount && rayIsTraceable(o, d, tmin, tmax)) ? 0 : kRefDone;
                     }
                 }
                 cursor += take;
