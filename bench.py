@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--backend", default="wavefront", choices=["wavefront", "megakernel"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --single-device lets the N > 1 code path be exercised on a 1-GPU box (testing only)")
+    ap.add_argument("--single-device", action="store_true", help="testing only: every rank uses cuda:0")
     ap.add_argument("--traffic-json", default=None,
                     help="per-kernel HBM bytes per launch from tools/pmc_traffic.py (default: newest profiles/r*_traffic.json)")
     args = ap.parse_args()
@@ -113,10 +116,15 @@ def main():
                   file=sys.stderr)
         if world == 1 and args.gpus > 1:
             sys.exit(2)
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     pkg = graft.load_package()  # after torch: one HIP runtime in the process
     W, H = args.width, args.height
@@ -146,7 +154,12 @@ def main():
         if world > 1:
             r.pack_shard(send.data_ptr())
             r.synchronize()
-            dist.all_gather_into_tensor(recv, send)
+            if args.dist_backend == "nccl":
+                dist.all_gather_into_tensor(recv, send)  # RCCL: every shard straight over its own xGMI link
+            else:  # gloo (testing): staged through the host
+                parts = [torch.empty(shard_floats) for _ in range(world)]
+                dist.all_gather(parts, send.cpu())
+                recv.copy_(torch.cat(parts))
             if rank == 0:
                 torch.cuda.current_stream().synchronize()
                 for k in range(world):
@@ -180,10 +193,14 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    checksum = None
+    if rank == 0 and os.environ.get("BENCH_CHECKSUM"):
+        img = r.readback()
+        checksum = [float(img[..., :3].astype(np.float64).sum()), int(np.isfinite(img).all()), int((img[..., 3] == 1).all())]
     if rank == 0:
         samples = W * H * args.spp * args.steps
         value = samples / elapsed / 1e6
@@ -205,6 +222,8 @@ def main():
                                        "k_trace_shadow": shadow_ms / args.steps, "k_tail": tail_ms / args.steps},
             },
         }
+        if checksum is not None:
+            out["config"]["frame_checksum"] = checksum
         if args.backend == "wavefront" and trace_ms > 0:
             bpr = algorithmic_bytes_per_closest_ray(n_tris)
             achieved = closest_rays * bpr / (trace_ms * 1e-3) / 1e9
