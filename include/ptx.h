@@ -393,7 +393,14 @@ typedef enum PtxTestFunction {
                                        out: dir.xyz dist color.xyz atten pdf (9)                 */
     PTX_FN_SHADOW_TERMINATOR = 20,  /* in: P, (P,N)x3, bary.xyz, isRefracted (25)  out: origin.xyz */
     PTX_FN_PRIMARY_RAY_LENS = 21,   /* in: px py w h u.xy u2.xy lensRadius focalDistance + 32 (42) out: o d */
-    PTX_FN_COUNT = 22
+    /* tracing.glsl (ray differentials -> texture footprint) */
+    PTX_FN_DPN_DUV = 22,            /* in: (P,N,uv)x3 (24), vertex T,B (6) = 30   out: dpdu dpdv dndu dndv (12)  */
+    PTX_FN_DP_DXY = 23,             /* in: p o d rxO rxD ryO ryD n (24)           out: dpdx dpdy (6)             */
+    PTX_FN_DERIVATIVES = 24,        /* in: dpdx dpdy dpdu dpdv (12)               out: dudx dvdx dudy dvdy (4)   */
+    PTX_FN_REFLECTED_DIFFERENTIALS = 25, /* in: deriv(4) n p wo wi dndu dndv rxO rxD ryO ryD (34)  out: rxO rxD ryO ryD (12) */
+    PTX_FN_REFRACTED_DIFFERENTIALS = 26, /* in: same + eta (35)                   out: rxO rxD ryO ryD (12)      */
+    PTX_FN_COMPUTE_LOD = 27,        /* in: derivatives (4)                        out: lod                       */
+    PTX_FN_COUNT = 28
 } PtxTestFunction;
 
 /* Material block used by PTX_FN_EVALUATE_BSDF / PTX_FN_SAMPLE_BSDF:

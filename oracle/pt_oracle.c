@@ -514,6 +514,151 @@ static inline LightSample sampleLight(const PtxLightsUbo *ubo, v3 u, v3 position
 }
 
 /* ======================================================================== */
+/* tracing.glsl -- ray differentials and texture footprint                  */
+/* (feed only textureGrad; not carried by the render path while every        */
+/* texture is 1x1; restated and tested for row N1)       */
+/* ======================================================================== */
+
+/* tracing.glsl:2-28 */
+static inline void computeDpnDuv(const v3 p[3], const v3 n[3], const v2 uv[3], v3 vtxTangent, v3 vtxBitangent, v3 *dpdu,
+                                 v3 *dpdv, v3 *dndu, v3 *dndv)
+{
+    const v3 e1 = v_sub(p[1], p[0]), e2 = v_sub(p[2], p[0]);
+    const v3 en1 = v_sub(n[1], n[0]), en2 = v_sub(n[2], n[0]);
+    const v2 duv1 = { uv[1].x - uv[0].x, uv[1].y - uv[0].y }, duv2 = { uv[2].x - uv[0].x, uv[2].y - uv[0].y };
+    const float det = duv1.x * duv2.y - duv2.x * duv1.y;
+    if (fabsf(det) < 1e-8f)
+    {
+        *dpdu = vtxTangent;
+        *dpdv = vtxBitangent;
+        *dndu = v3s(0.0f);
+        *dndv = v3s(0.0f);
+    }
+    else
+    {
+        const float invDet = 1.0f / det;
+        *dpdu = v_scale(v_sub(v_scale(e1, duv2.y), v_scale(e2, duv1.y)), invDet);
+        *dpdv = v_scale(v_add(v_scale(e1, -duv2.x), v_scale(e2, duv1.x)), invDet);
+        *dndu = v_scale(v_sub(v_scale(en1, duv2.y), v_scale(en2, duv1.y)), invDet);
+        *dndv = v_scale(v_add(v_scale(en1, -duv2.x), v_scale(en2, duv1.x)), invDet);
+    }
+}
+
+/* tracing.glsl:31-41 */
+static inline void computeDpDxy(v3 p, v3 origin, v3 direction, v3 rxOrigin, v3 rxDirection, v3 ryOrigin, v3 ryDirection, v3 n,
+                                v3 *dpdx, v3 *dpdy)
+{
+    (void)origin;
+    (void)direction;
+    const float d = -v_dot(n, p);
+    const float tx = (-v_dot(n, rxOrigin) - d) / v_dot(n, rxDirection);
+    const v3 px = v_add(rxOrigin, v_scale(rxDirection, tx));
+    const float ty = (-v_dot(n, ryOrigin) - d) / v_dot(n, ryDirection);
+    const v3 py = v_add(ryOrigin, v_scale(ryDirection, ty));
+    *dpdx = v_sub(px, p);
+    *dpdy = v_sub(py, p);
+}
+
+/* tracing.glsl:44-50 -- the GLSL calls fma() explicitly: a real fused op on both sides */
+static inline float differenceOfProducts(float a, float b, float c, float d)
+{
+    const float cd = c * d;
+    const float dop = fmaf(a, b, -cd);
+    const float error = fmaf(-c, d, cd);
+    return dop + error;
+}
+
+static inline float clampInf(float x) { return isinf(x) ? 0.0f : f_clamp(x, -1e8f, 1e8f); }
+
+/* tracing.glsl:53-78 */
+static inline v4 computeDerivatives(v3 dpdx, v3 dpdy, v3 dpdu, v3 dpdv)
+{
+    const float ata00 = v_dot(dpdu, dpdu);
+    const float ata01 = v_dot(dpdu, dpdv);
+    const float ata11 = v_dot(dpdv, dpdv);
+    float invDet = 1 / differenceOfProducts(ata00, ata11, ata01, ata01);
+    invDet = isinf(invDet) ? 0.0f : invDet;
+    const float atb0x = v_dot(dpdu, dpdx);
+    const float atb1x = v_dot(dpdv, dpdx);
+    const float atb0y = v_dot(dpdu, dpdy);
+    const float atb1y = v_dot(dpdv, dpdy);
+    v4 r;
+    r.x = clampInf(differenceOfProducts(ata11, atb0x, ata01, atb1x) * invDet);
+    r.y = clampInf(differenceOfProducts(ata00, atb1x, ata01, atb0x) * invDet);
+    r.z = clampInf(differenceOfProducts(ata11, atb0y, ata01, atb1y) * invDet);
+    r.w = clampInf(differenceOfProducts(ata00, atb1y, ata01, atb0y) * invDet);
+    return r;
+}
+
+typedef struct DiffRays
+{
+    v3 rxOrigin, rxDirection, ryOrigin, ryDirection;
+} DiffRays;
+
+/* tracing.glsl:81-108 */
+static inline void computeReflectedDifferentialRays(v4 derivatives, v3 n, v3 p, v3 viewDir, v3 reflectedDir, v3 dndu, v3 dndv,
+                                                    DiffRays *r)
+{
+    const float dudx = derivatives.x, dvdx = derivatives.y, dudy = derivatives.z, dvdy = derivatives.w;
+    const v3 dndx = v_add(v_scale(dndu, dudx), v_scale(dndv, dvdx));
+    const v3 dndy = v_add(v_scale(dndu, dudy), v_scale(dndv, dvdy));
+    const float d = -v_dot(n, p);
+    const float tx = (-v_dot(n, r->rxOrigin) - d) / v_dot(n, r->rxDirection);
+    const v3 px = v_add(r->rxOrigin, v_scale(r->rxDirection, tx));
+    const float ty = (-v_dot(n, r->ryOrigin) - d) / v_dot(n, r->ryDirection);
+    const v3 py = v_add(r->ryOrigin, v_scale(r->ryDirection, ty));
+    const v3 dwodx = v_sub(v_neg(r->rxDirection), viewDir);
+    const v3 dwody = v_sub(v_neg(r->ryDirection), viewDir);
+    r->rxOrigin = px;
+    r->ryOrigin = py;
+    const float dwoDotn_dx = v_dot(dwodx, n) + v_dot(viewDir, dndx);
+    const float dwoDotn_dy = v_dot(dwody, n) + v_dot(viewDir, dndy);
+    const float vn = v_dot(viewDir, n);
+    r->rxDirection = v_normalize(v_add(v_sub(reflectedDir, dwodx), v_scale(v_add(v_scale(dndx, vn), v_scale(n, dwoDotn_dx)), 2)));
+    r->ryDirection = v_normalize(v_add(v_sub(reflectedDir, dwody), v_scale(v_add(v_scale(dndy, vn), v_scale(n, dwoDotn_dy)), 2)));
+}
+
+/* tracing.glsl:111-148 */
+static inline void computeRefractedDifferentialRays(v4 derivatives, v3 n, v3 p, v3 viewDir, v3 refractedDir, v3 dndu, v3 dndv,
+                                                    float eta, DiffRays *r)
+{
+    const float dudx = derivatives.x, dvdx = derivatives.y, dudy = derivatives.z, dvdy = derivatives.w;
+    v3 dndx = v_add(v_scale(dndu, dudx), v_scale(dndv, dvdx));
+    v3 dndy = v_add(v_scale(dndu, dudy), v_scale(dndv, dvdy));
+    const float d = -v_dot(n, p);
+    const float tx = (-v_dot(n, r->rxOrigin) - d) / v_dot(n, r->rxDirection);
+    const v3 px = v_add(r->rxOrigin, v_scale(r->rxDirection, tx));
+    const float ty = (-v_dot(n, r->ryOrigin) - d) / v_dot(n, r->ryDirection);
+    const v3 py = v_add(r->ryOrigin, v_scale(r->ryDirection, ty));
+    const v3 dwodx = v_sub(v_neg(r->rxDirection), viewDir);
+    const v3 dwody = v_sub(v_neg(r->ryDirection), viewDir);
+    r->rxOrigin = px;
+    r->ryOrigin = py;
+    if (v_dot(viewDir, n) < 0.0f)
+    {
+        n = v_neg(n);
+        dndx = v_neg(dndx);
+        dndy = v_neg(dndy);
+    }
+    const float dwoDotn_dx = v_dot(dwodx, n) + v_dot(viewDir, dndx);
+    const float dwoDotn_dy = v_dot(dwody, n) + v_dot(viewDir, dndy);
+    const float mu = v_dot(viewDir, n) / eta - fabsf(v_dot(refractedDir, n));
+    const float dmudx = dwoDotn_dx * (1.0f / eta + 1.0f / (eta * eta) * v_dot(viewDir, n) / v_dot(refractedDir, n));
+    const float dmudy = dwoDotn_dy * (1.0f / eta + 1.0f / (eta * eta) * v_dot(viewDir, n) / v_dot(refractedDir, n));
+    r->rxDirection = v_normalize(v_add(v_sub(refractedDir, v_scale(dwodx, eta)), v_add(v_scale(dndx, mu), v_scale(n, dmudx))));
+    r->ryDirection = v_normalize(v_add(v_sub(refractedDir, v_scale(dwody, eta)), v_add(v_scale(dndy, mu), v_scale(n, dmudy))));
+}
+
+/* tracing.glsl:151-161 -- log2 through the fixed kernel */
+static inline float computeLod(v4 derivatives)
+{
+    const float sx = sqrtf(derivatives.x * derivatives.x + derivatives.y * derivatives.y);
+    const float sy = sqrtf(derivatives.z * derivatives.z + derivatives.w * derivatives.w);
+    const float smax = f_max(sx, sy);
+    return smax == 0.0f ? 0.0f : (float)pto_log2((double)smax);
+}
+
+/* ======================================================================== */
 /* Scene: flattened world-space triangles (stand-in for BLAS/TLAS)          */
 /* ======================================================================== */
 
@@ -1431,8 +1576,8 @@ int pto_render(const PtoScene *s, const PtxRaygenUniformData *U, const PtxLights
 /* Function-level entry (packing documented in include/ptx.h)               */
 /* ======================================================================== */
 
-static const int kInStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42 };
-static const int kOutStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 6, 2, 1, 9, 3, 6 };
+static const int kInStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4 };
+static const int kOutStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 6, 2, 1, 9, 3, 6, 12, 6, 4, 12, 12, 1 };
 
 static MaterialSample unpackMaterial(const float *p)
 {
@@ -1579,6 +1724,54 @@ int pto_test_eval(uint32_t fn, const float *in, float *out, uint32_t n)
             const Ray r = constructPrimaryRayLens(f2u(a[0]), f2u(a[1]), f2u(a[2]), f2u(a[3]), &a[10], &a[26], u, u2, a[8], a[9]);
             o[0] = r.Origin.x; o[1] = r.Origin.y; o[2] = r.Origin.z;
             o[3] = r.Direction.x; o[4] = r.Direction.y; o[5] = r.Direction.z;
+            break;
+        }
+        case PTX_FN_DPN_DUV: {
+            v3 P[3], N[3];
+            v2 UV[3];
+            for (int k = 0; k < 3; k++)
+            {
+                P[k] = V3(a[8 * k], a[8 * k + 1], a[8 * k + 2]);
+                N[k] = V3(a[8 * k + 3], a[8 * k + 4], a[8 * k + 5]);
+                UV[k].x = a[8 * k + 6];
+                UV[k].y = a[8 * k + 7];
+            }
+            v3 r[4];
+            computeDpnDuv(P, N, UV, V3(a[24], a[25], a[26]), V3(a[27], a[28], a[29]), &r[0], &r[1], &r[2], &r[3]);
+            for (int k = 0; k < 4; k++) { o[3 * k] = r[k].x; o[3 * k + 1] = r[k].y; o[3 * k + 2] = r[k].z; }
+            break;
+        }
+        case PTX_FN_DP_DXY: {
+            v3 dx, dy;
+            computeDpDxy(V3(a[0], a[1], a[2]), V3(a[3], a[4], a[5]), V3(a[6], a[7], a[8]), V3(a[9], a[10], a[11]), V3(a[12], a[13], a[14]),
+                         V3(a[15], a[16], a[17]), V3(a[18], a[19], a[20]), V3(a[21], a[22], a[23]), &dx, &dy);
+            o[0] = dx.x; o[1] = dx.y; o[2] = dx.z; o[3] = dy.x; o[4] = dy.y; o[5] = dy.z;
+            break;
+        }
+        case PTX_FN_DERIVATIVES: {
+            const v4 r = computeDerivatives(V3(a[0], a[1], a[2]), V3(a[3], a[4], a[5]), V3(a[6], a[7], a[8]), V3(a[9], a[10], a[11]));
+            o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w;
+            break;
+        }
+        case PTX_FN_REFLECTED_DIFFERENTIALS:
+        case PTX_FN_REFRACTED_DIFFERENTIALS: {
+            v4 dv = { a[0], a[1], a[2], a[3] };
+            DiffRays r;
+            r.rxOrigin = V3(a[22], a[23], a[24]); r.rxDirection = V3(a[25], a[26], a[27]);
+            r.ryOrigin = V3(a[28], a[29], a[30]); r.ryDirection = V3(a[31], a[32], a[33]);
+            if (fn == PTX_FN_REFLECTED_DIFFERENTIALS)
+                computeReflectedDifferentialRays(dv, V3(a[4], a[5], a[6]), V3(a[7], a[8], a[9]), V3(a[10], a[11], a[12]), V3(a[13], a[14], a[15]),
+                                                 V3(a[16], a[17], a[18]), V3(a[19], a[20], a[21]), &r);
+            else
+                computeRefractedDifferentialRays(dv, V3(a[4], a[5], a[6]), V3(a[7], a[8], a[9]), V3(a[10], a[11], a[12]), V3(a[13], a[14], a[15]),
+                                                 V3(a[16], a[17], a[18]), V3(a[19], a[20], a[21]), a[34], &r);
+            o[0] = r.rxOrigin.x; o[1] = r.rxOrigin.y; o[2] = r.rxOrigin.z; o[3] = r.rxDirection.x; o[4] = r.rxDirection.y; o[5] = r.rxDirection.z;
+            o[6] = r.ryOrigin.x; o[7] = r.ryOrigin.y; o[8] = r.ryOrigin.z; o[9] = r.ryDirection.x; o[10] = r.ryDirection.y; o[11] = r.ryDirection.z;
+            break;
+        }
+        case PTX_FN_COMPUTE_LOD: {
+            v4 dv = { a[0], a[1], a[2], a[3] };
+            o[0] = computeLod(dv);
             break;
         }
         default: return 1;

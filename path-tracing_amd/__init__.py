@@ -122,6 +122,8 @@ FN = {
     "sampleBSDF": 10, "rng": 11, "sampleUniformDiskConcentric": 12, "sampleCosineHemisphere": 13,
     "computeTangentSpace": 14, "offsetRayOriginSelfIntersection": 15, "constructPrimaryRay": 16, "sincos": 17,
     "pow": 18, "sampleLight": 19, "offsetRayOriginShadowTerminator": 20, "constructPrimaryRayLens": 21,
+    "computeDpnDuv": 22, "computeDpDxy": 23, "computeDerivatives": 24, "computeReflectedDifferentialRays": 25,
+    "computeRefractedDifferentialRays": 26, "computeLod": 27,
 }
 
 

@@ -847,6 +847,139 @@ PT_DEV void closestHit(const SceneView &sv, f3 rayDirW, float t, float hu, float
     out.LightDistance = light.Distance;
 }
 
+// ---- tracing.glsl: ray differentials and texture footprint ------------------------------------------
+// These feed only textureGrad.  While every texture is 1x1 they cannot change radiance and the
+// wavefront does not carry them; they are restated, and tested against the
+// reference's GLSL vectors, for the texture row N1.
+
+PT_DEV void computeDpnDuv(const f3 *p, const f3 *n, const f2 *uv, f3 vtxTangent, f3 vtxBitangent, f3 &dpdu, f3 &dpdv, f3 &dndu,
+                          f3 &dndv) // :2-28
+{
+    const f3 e1 = p[1] - p[0], e2 = p[2] - p[0];
+    const f3 en1 = n[1] - n[0], en2 = n[2] - n[0];
+    const float du1 = uv[1].x - uv[0].x, dv1 = uv[1].y - uv[0].y, du2 = uv[2].x - uv[0].x, dv2 = uv[2].y - uv[0].y;
+    const float det = du1 * dv2 - du2 * dv1;
+    if (abs_(det) < 1e-8f)
+    {
+        dpdu = vtxTangent;
+        dpdv = vtxBitangent;
+        dndu = F3s(0.0f);
+        dndv = F3s(0.0f);
+    }
+    else
+    {
+        const float invDet = 1.0f / det;
+        dpdu = (e1 * dv2 - e2 * dv1) * invDet;
+        dpdv = (e1 * (-du2) + e2 * du1) * invDet;
+        dndu = (en1 * dv2 - en2 * dv1) * invDet;
+        dndv = (en1 * (-du2) + en2 * du1) * invDet;
+    }
+}
+
+PT_DEV void computeDpDxy(f3 p, f3 rxOrigin, f3 rxDirection, f3 ryOrigin, f3 ryDirection, f3 n, f3 &dpdx, f3 &dpdy) // :31-41
+{
+    const float d = -dot(n, p);
+    const float tx = (-dot(n, rxOrigin) - d) / dot(n, rxDirection);
+    const f3 px = rxOrigin + rxDirection * tx;
+    const float ty = (-dot(n, ryOrigin) - d) / dot(n, ryDirection);
+    const f3 py = ryOrigin + ryDirection * ty;
+    dpdx = px - p;
+    dpdy = py - p;
+}
+
+PT_DEV float differenceOfProducts(float a, float b, float c, float d) // :44-50 (explicit fma in the GLSL)
+{
+    const float cd = c * d;
+    const float dop = __builtin_fmaf(a, b, -cd);
+    const float error = __builtin_fmaf(-c, d, cd);
+    return dop + error;
+}
+
+PT_DEV float clampInf(float x) { return __builtin_isinf(x) ? 0.0f : clamp_(x, -1e8f, 1e8f); }
+
+PT_DEV f4 computeDerivatives(f3 dpdx, f3 dpdy, f3 dpdu, f3 dpdv) // :53-78
+{
+    const float ata00 = dot(dpdu, dpdu);
+    const float ata01 = dot(dpdu, dpdv);
+    const float ata11 = dot(dpdv, dpdv);
+    float invDet = 1 / differenceOfProducts(ata00, ata11, ata01, ata01);
+    invDet = __builtin_isinf(invDet) ? 0.0f : invDet;
+    const float atb0x = dot(dpdu, dpdx);
+    const float atb1x = dot(dpdv, dpdx);
+    const float atb0y = dot(dpdu, dpdy);
+    const float atb1y = dot(dpdv, dpdy);
+    f4 r;
+    r.x = clampInf(differenceOfProducts(ata11, atb0x, ata01, atb1x) * invDet);
+    r.y = clampInf(differenceOfProducts(ata00, atb1x, ata01, atb0x) * invDet);
+    r.z = clampInf(differenceOfProducts(ata11, atb0y, ata01, atb1y) * invDet);
+    r.w = clampInf(differenceOfProducts(ata00, atb1y, ata01, atb0y) * invDet);
+    return r;
+}
+
+struct DiffRays
+{
+    f3 rxOrigin, rxDirection, ryOrigin, ryDirection;
+};
+
+PT_DEV void computeReflectedDifferentialRays(f4 derivatives, f3 n, f3 p, f3 viewDir, f3 reflectedDir, f3 dndu, f3 dndv, DiffRays &r) // :81-108
+{
+    const float dudx = derivatives.x, dvdx = derivatives.y, dudy = derivatives.z, dvdy = derivatives.w;
+    const f3 dndx = dndu * dudx + dndv * dvdx;
+    const f3 dndy = dndu * dudy + dndv * dvdy;
+    const float d = -dot(n, p);
+    const float tx = (-dot(n, r.rxOrigin) - d) / dot(n, r.rxDirection);
+    const f3 px = r.rxOrigin + r.rxDirection * tx;
+    const float ty = (-dot(n, r.ryOrigin) - d) / dot(n, r.ryDirection);
+    const f3 py = r.ryOrigin + r.ryDirection * ty;
+    const f3 dwodx = -r.rxDirection - viewDir;
+    const f3 dwody = -r.ryDirection - viewDir;
+    r.rxOrigin = px;
+    r.ryOrigin = py;
+    const float dwoDotn_dx = dot(dwodx, n) + dot(viewDir, dndx);
+    const float dwoDotn_dy = dot(dwody, n) + dot(viewDir, dndy);
+    const float vn = dot(viewDir, n);
+    r.rxDirection = normalize((reflectedDir - dwodx) + (dndx * vn + n * dwoDotn_dx) * 2.0f);
+    r.ryDirection = normalize((reflectedDir - dwody) + (dndy * vn + n * dwoDotn_dy) * 2.0f);
+}
+
+PT_DEV void computeRefractedDifferentialRays(f4 derivatives, f3 n, f3 p, f3 viewDir, f3 refractedDir, f3 dndu, f3 dndv, float eta,
+                                             DiffRays &r) // :111-148
+{
+    const float dudx = derivatives.x, dvdx = derivatives.y, dudy = derivatives.z, dvdy = derivatives.w;
+    f3 dndx = dndu * dudx + dndv * dvdx;
+    f3 dndy = dndu * dudy + dndv * dvdy;
+    const float d = -dot(n, p);
+    const float tx = (-dot(n, r.rxOrigin) - d) / dot(n, r.rxDirection);
+    const f3 px = r.rxOrigin + r.rxDirection * tx;
+    const float ty = (-dot(n, r.ryOrigin) - d) / dot(n, r.ryDirection);
+    const f3 py = r.ryOrigin + r.ryDirection * ty;
+    const f3 dwodx = -r.rxDirection - viewDir;
+    const f3 dwody = -r.ryDirection - viewDir;
+    r.rxOrigin = px;
+    r.ryOrigin = py;
+    if (dot(viewDir, n) < 0.0f)
+    {
+        n = -n;
+        dndx = -dndx;
+        dndy = -dndy;
+    }
+    const float dwoDotn_dx = dot(dwodx, n) + dot(viewDir, dndx);
+    const float dwoDotn_dy = dot(dwody, n) + dot(viewDir, dndy);
+    const float mu = dot(viewDir, n) / eta - abs_(dot(refractedDir, n));
+    const float dmudx = dwoDotn_dx * (1.0f / eta + 1.0f / (eta * eta) * dot(viewDir, n) / dot(refractedDir, n));
+    const float dmudy = dwoDotn_dy * (1.0f / eta + 1.0f / (eta * eta) * dot(viewDir, n) / dot(refractedDir, n));
+    r.rxDirection = normalize((refractedDir - dwodx * eta) + (dndx * mu + n * dmudx));
+    r.ryDirection = normalize((refractedDir - dwody * eta) + (dndy * mu + n * dmudy));
+}
+
+PT_DEV float computeLod(f4 derivatives) // :151-161, log2 through the fixed kernel
+{
+    const float sx = sqrt_(derivatives.x * derivatives.x + derivatives.y * derivatives.y);
+    const float sy = sqrt_(derivatives.z * derivatives.z + derivatives.w * derivatives.w);
+    const float smax = fmax_(sx, sy);
+    return smax == 0.0f ? 0.0f : (float)log2_((double)smax);
+}
+
 // ---- ray / triangle --------------------------------------------------------------------------------
 
 // Moeller-Trumbore on (v0, e1, e2): the fixed stand-in for the driver's unspecified

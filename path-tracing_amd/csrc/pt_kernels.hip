@@ -657,10 +657,10 @@ __global__ void k_unpack_shard(LaunchParams p, const float4 *__restrict__ src, f
 
 // function-level entry (Path-Tracing-Tests/TestRenderer.cpp:79-105 dispatches a compute
 // shader that calls the production functions; packing documented in include/ptx.h)
-__constant__ int c_inStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42 };
-__constant__ int c_outStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 6, 2, 1, 9, 3, 6 };
-static const int h_inStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42 };
-static const int h_outStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 6, 2, 1, 9, 3, 6 };
+__constant__ int c_inStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4 };
+__constant__ int c_outStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 6, 2, 1, 9, 3, 6, 12, 6, 4, 12, 12, 1 };
+static const int h_inStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4 };
+static const int h_outStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 6, 2, 1, 9, 3, 6, 12, 6, 4, 12, 12, 1 };
 
 PT_DEV MaterialSample unpackMaterial(const float *p)
 {
@@ -808,6 +808,55 @@ __global__ void k_test_eval(uint32_t fn, const float *__restrict__ in, float *__
         constructPrimaryRayLens(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3]), &a[10], &a[26],
                                 u, u2, a[8], a[9], ro, rd);
         o[0] = ro.x; o[1] = ro.y; o[2] = ro.z; o[3] = rd.x; o[4] = rd.y; o[5] = rd.z;
+        break;
+    }
+    case PTX_FN_DPN_DUV: {
+        f3 P[3], N[3];
+        f2 UV[3];
+        for (int k = 0; k < 3; k++)
+        {
+            P[k] = F3(a[8 * k], a[8 * k + 1], a[8 * k + 2]);
+            N[k] = F3(a[8 * k + 3], a[8 * k + 4], a[8 * k + 5]);
+            UV[k].x = a[8 * k + 6];
+            UV[k].y = a[8 * k + 7];
+        }
+        f3 r0, r1, r2, r3;
+        computeDpnDuv(P, N, UV, F3(a[24], a[25], a[26]), F3(a[27], a[28], a[29]), r0, r1, r2, r3);
+        o[0] = r0.x; o[1] = r0.y; o[2] = r0.z; o[3] = r1.x; o[4] = r1.y; o[5] = r1.z;
+        o[6] = r2.x; o[7] = r2.y; o[8] = r2.z; o[9] = r3.x; o[10] = r3.y; o[11] = r3.z;
+        break;
+    }
+    case PTX_FN_DP_DXY: {
+        f3 dx, dy;
+        computeDpDxy(F3(a[0], a[1], a[2]), F3(a[9], a[10], a[11]), F3(a[12], a[13], a[14]), F3(a[15], a[16], a[17]), F3(a[18], a[19], a[20]),
+                     F3(a[21], a[22], a[23]), dx, dy);
+        o[0] = dx.x; o[1] = dx.y; o[2] = dx.z; o[3] = dy.x; o[4] = dy.y; o[5] = dy.z;
+        break;
+    }
+    case PTX_FN_DERIVATIVES: {
+        const f4 r = computeDerivatives(F3(a[0], a[1], a[2]), F3(a[3], a[4], a[5]), F3(a[6], a[7], a[8]), F3(a[9], a[10], a[11]));
+        o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w;
+        break;
+    }
+    case PTX_FN_REFLECTED_DIFFERENTIALS:
+    case PTX_FN_REFRACTED_DIFFERENTIALS: {
+        f4 dv; dv.x = a[0]; dv.y = a[1]; dv.z = a[2]; dv.w = a[3];
+        DiffRays r;
+        r.rxOrigin = F3(a[22], a[23], a[24]); r.rxDirection = F3(a[25], a[26], a[27]);
+        r.ryOrigin = F3(a[28], a[29], a[30]); r.ryDirection = F3(a[31], a[32], a[33]);
+        if (fn == PTX_FN_REFLECTED_DIFFERENTIALS)
+            computeReflectedDifferentialRays(dv, F3(a[4], a[5], a[6]), F3(a[7], a[8], a[9]), F3(a[10], a[11], a[12]), F3(a[13], a[14], a[15]),
+                                             F3(a[16], a[17], a[18]), F3(a[19], a[20], a[21]), r);
+        else
+            computeRefractedDifferentialRays(dv, F3(a[4], a[5], a[6]), F3(a[7], a[8], a[9]), F3(a[10], a[11], a[12]), F3(a[13], a[14], a[15]),
+                                             F3(a[16], a[17], a[18]), F3(a[19], a[20], a[21]), a[34], r);
+        o[0] = r.rxOrigin.x; o[1] = r.rxOrigin.y; o[2] = r.rxOrigin.z; o[3] = r.rxDirection.x; o[4] = r.rxDirection.y; o[5] = r.rxDirection.z;
+        o[6] = r.ryOrigin.x; o[7] = r.ryOrigin.y; o[8] = r.ryOrigin.z; o[9] = r.ryDirection.x; o[10] = r.ryDirection.y; o[11] = r.ryDirection.z;
+        break;
+    }
+    case PTX_FN_COMPUTE_LOD: {
+        f4 dv; dv.x = a[0]; dv.y = a[1]; dv.z = a[2]; dv.w = a[3];
+        o[0] = computeLod(dv);
         break;
     }
     default: break;

@@ -33,6 +33,7 @@ SOURCES = [
     ("bsdf.glsl", [(4, 132)]),
     ("ray.glsl", [(3, 131)]),
     ("sampling.glsl", [(3, 3), (17, 56)]),
+    ("tracing.glsl", [(1, 161)]),
 ]
 STRUCTS = [
     ("ShaderTypes.incl", ["Camera", "Vertex", "DirectionalLight", "PointLight"]),

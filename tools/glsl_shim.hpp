@@ -145,6 +145,11 @@ inline float sin(float x) { return sinf(x); }
 inline float pow(float x, float y) { return powf(x, y); }
 #endif
 inline float pow(float x, int y) { return pow(x, (float)y); }
+#ifdef SHIM_FIXED
+inline float log2(float x) { return (float)pto_log2((double)x); }
+#else
+inline float log2(float x) { return log2f(x); }
+#endif
 
 inline float dot(vec3 a, vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 inline float dot(uvec2 a, uvec2 b) { return (float)a.x * (float)b.x + (float)a.y * (float)b.y; }
