@@ -506,7 +506,7 @@ __global__ void k_single_leaf_root(const float4 *boxLo, const float4 *boxHi, con
 #endif
 constexpr int kLdsStack = PT_LDS_STACK; // entries per lane kept in LDS (lane-interleaved: no bank conflicts)
 constexpr int kLdsStackMega = 64;       // the megakernel runs 2 blocks/CU anyway (195 VGPRs): deep LDS stack, no spill
-constexpr int kGlobalSpill = 128;       // overflow entries per persistent thread, in a global buffer
+constexpr int kGlobalSpill = 80;        // overflow entries per persistent thread, in a global buffer (LDS 16 + 80 >= 3 x 32 levels)
 constexpr uint32_t kMaxPersistentThreads = 2048u * 256u;
 constexpr uint32_t kMaxNodeVisits = 1u << 20;
 

@@ -935,6 +935,20 @@ struct PtxRenderer
 
     hipEvent_t evA = nullptr, evB = nullptr, evT0 = nullptr, evT1 = nullptr, evT2 = nullptr, evT3 = nullptr;
     hipEvent_t evShade = nullptr, evShadow[2] = { nullptr, nullptr }, evX0[2] = { nullptr, nullptr };
+
+    // sub-batches of one ptx_render_frames call, driven as interleaved state machines
+    struct BatchRes
+    {
+        hipStream_t s = nullptr, x = nullptr; // closest + shade + tail | shadow
+        hipEvent_t evReady = nullptr, evShade = nullptr, evShadow[2] = { nullptr, nullptr }, evX0[2] = { nullptr, nullptr };
+        hipEvent_t evT0 = nullptr, evT1 = nullptr, evT2 = nullptr, evDone = nullptr;
+        uint32_t *dCounters = nullptr, *hCounters = nullptr;
+        uint32_t *spill = nullptr, *spillAux = nullptr;
+    };
+    static constexpr int kMaxBatches = 4;
+    BatchRes batch[kMaxBatches];
+    int batchesReady = 0;
+    hipEvent_t evStart = nullptr;
     PtxStats stats = {};
 };
 
@@ -1079,6 +1093,22 @@ void ptx_destroy(PtxRenderer *r)
     r->shO.release(); r->shD.release(); r->shC.release(); r->slotRad.release(); r->meta.release(); r->hitPair.release();
     r->queue0.release(); r->queue1.release(); r->shadowQueue.release(); r->counters.release(); r->spill.release(); r->spillAux.release(); r->restartQueue.release();
     r->testIn.release(); r->testOut.release(); r->testUbo.release();
+    for (int b = 0; b < r->batchesReady; b++)
+    {
+        PtxRenderer::BatchRes &q = r->batch[b];
+        if (q.s) { (void)hipStreamSynchronize(q.s); (void)hipStreamDestroy(q.s); }
+        if (q.x) { (void)hipStreamSynchronize(q.x); (void)hipStreamDestroy(q.x); }
+        hipEvent_t evs[] = { q.evReady, q.evShade, q.evShadow[0], q.evShadow[1], q.evX0[0], q.evX0[1], q.evT0, q.evT1, q.evT2, q.evDone };
+        for (hipEvent_t e : evs)
+            if (e)
+                (void)hipEventDestroy(e);
+        if (q.dCounters) (void)hipFree(q.dCounters);
+        if (q.hCounters) (void)hipHostFree(q.hCounters);
+        if (q.spill) (void)hipFree(q.spill);
+        if (q.spillAux) (void)hipFree(q.spillAux);
+    }
+    if (r->evStart)
+        (void)hipEventDestroy(r->evStart);
     if (r->hostCounters)
         (void)hipHostFree(r->hostCounters);
     if (r->evA) (void)hipEventDestroy(r->evA);
@@ -1368,6 +1398,35 @@ static int ensureSlots(PtxRenderer *r, size_t slots)
     return PTX_OK;
 }
 
+static int ensureBatches(PtxRenderer *r, int nb)
+{
+    for (int b = r->batchesReady; b < nb; b++)
+    {
+        PtxRenderer::BatchRes &q = r->batch[b];
+        HIP_TRY(r, hipStreamCreateWithFlags(&q.s, hipStreamNonBlocking));
+        HIP_TRY(r, hipStreamCreateWithFlags(&q.x, hipStreamNonBlocking));
+        HIP_TRY(r, hipEventCreateWithFlags(&q.evReady, hipEventDisableTiming));
+        HIP_TRY(r, hipEventCreateWithFlags(&q.evShade, hipEventDisableTiming));
+        HIP_TRY(r, hipEventCreateWithFlags(&q.evDone, hipEventDisableTiming));
+        for (int k = 0; k < 2; k++)
+        {
+            HIP_TRY(r, hipEventCreate(&q.evShadow[k]));
+            HIP_TRY(r, hipEventCreate(&q.evX0[k]));
+        }
+        HIP_TRY(r, hipEventCreate(&q.evT0));
+        HIP_TRY(r, hipEventCreate(&q.evT1));
+        HIP_TRY(r, hipEventCreate(&q.evT2));
+        HIP_TRY(r, hipMalloc(reinterpret_cast<void **>(&q.dCounters), C_COUNT * sizeof(uint32_t)));
+        HIP_TRY(r, hipHostMalloc(reinterpret_cast<void **>(&q.hCounters), C_COUNT * sizeof(uint32_t), hipHostMallocDefault));
+        HIP_TRY(r, hipMalloc(reinterpret_cast<void **>(&q.spill), (size_t)kGlobalSpill * kMaxPersistentThreads * sizeof(uint32_t)));
+        HIP_TRY(r, hipMalloc(reinterpret_cast<void **>(&q.spillAux), (size_t)kGlobalSpill * kMaxPersistentThreads * sizeof(uint32_t)));
+        r->batchesReady = b + 1;
+    }
+    if (!r->evStart)
+        HIP_TRY(r, hipEventCreateWithFlags(&r->evStart, hipEventDisableTiming));
+    return PTX_OK;
+}
+
 static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const PtxLightsUbo *lights, uint32_t firstFrame, uint32_t frames)
 {
     if (!r || !uniform || !lights)
@@ -1425,144 +1484,266 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
         return PTX_OK;
     }
 
-    Wavefront wf;
-    wf.rayO = r->rayO.p; wf.rayD = r->rayD.p; wf.thr = r->thr.p; wf.rad = r->rad.p; wf.meta = r->meta.p; wf.hit = r->hit.p;
-    wf.hitPair = r->hitPair.p; wf.shO = r->shO.p; wf.shD = r->shD.p; wf.shC = r->shC.p; wf.slotRad = r->slotRad.p;
-    wf.queue[0] = r->queue0.p; wf.queue[1] = r->queue1.p; wf.shadowQueue = r->shadowQueue.p; wf.restartQueue = r->restartQueue.p; wf.counters = r->counters.p; wf.spill = r->spill.p;
-
-    k_generate<<<gridFor(p.numSlots), kBlock, 0, r->stream>>>(p, wf);
-    HIP_TRY(r, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&r->counters.p[C_ACTIVE0]), (int)p.numSlots, 1, r->stream));
-    uint32_t active = p.numSlots;
-    int qin = 0;
-    double traceMs = 0.0;
+    // ---- wavefront: the bounce loop is a small state machine per sub-batch (whole frames each)
+    // on its own stream pair; every bounce ends in a 48-B counter read-back.  PTX_BATCHES > 1
+    // splits the frames of the call into interleaved sub-batches.  Measured on MI355X
+    // (chess_like 1080p x 8): 1 -> 1204, 2 -> 1017, 3 -> 1006, 4 -> 733 Msamples/s -- sub-batches
+    // pass through their throughput-bound and latency-bound phases in lockstep, so nothing
+    // complementary overlaps and co-resident persistent kernels interfere.  Default: 1.
+    int nb = 1;
+    if (const char *e = getenv("PTX_BATCHES"))
+        nb = atoi(e);
+    if (nb < 1) nb = 1;
+    if (nb > PtxRenderer::kMaxBatches) nb = PtxRenderer::kMaxBatches;
+    if ((uint32_t)nb > frames) nb = (int)frames;
+    {
+        const int rcb = ensureBatches(r, nb);
+        if (rcb != PTX_OK)
+            return rcb;
+    }
+    const bool verbose = getenv("PTX_VERBOSE") != nullptr;
     // every iteration advances each active path by one bounce; NaN/Inf restarts
     // (raygen.rgen:99-112) can add iterations but a path that never yields a finite
     // sample would spin forever (it hangs the GPU in the reference): give up instead
-    const bool verbose = getenv("PTX_VERBOSE") != nullptr;
     const uint64_t maxIterations = ((uint64_t)uniform->BounceCount + 1) * uniform->SampleCount * 64 + 64;
-    uint64_t iteration = 0;
-    // below this many live paths the remaining bounces run fused in k_tail
+    // below this many live paths the remaining bounces of a sub-batch run fused in k_tail
     uint32_t tailThreshold = 300000; // measured: flat from 100 K to 400 K live paths, worse beyond
     if (const char *e = getenv("PTX_TAIL_THRESHOLD"))
         tailThreshold = (uint32_t)strtoul(e, nullptr, 10);
-    // k_trace_shadow(b) only adds into rad[slot]; k_trace_closest(b+1) never touches rad.  So the
-    // shadow query of a bounce runs on the aux stream beside the closest-hit query of the next
-    // one; k_shade(b+1) -- which reads rad -- waits for it.  In late bounces both kernels are
-    // bound by the latency of their longest ray, so the overlap is almost free.
-    Wavefront wfAux = wf;
-    wfAux.spill = r->spillAux.p;
-    hipStream_t sx = r->aux ? r->aux : r->stream;
-    bool shadowPending = false;
-    int shadowSlot = 0;
-    double shadowMs = 0.0;
-    auto drainShadow = [&](bool wait) -> hipError_t {
-        if (!shadowPending)
-            return hipSuccess;
-        if (wait)
-        {
-            const hipError_t e = hipEventSynchronize(r->evShadow[shadowSlot]);
-            if (e != hipSuccess)
-                return e;
-        }
-        float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, r->evX0[shadowSlot], r->evShadow[shadowSlot]) == hipSuccess)
-            shadowMs += ms;
-        shadowPending = false;
-        return hipSuccess;
+
+    enum Phase { PH_ISSUE, PH_WAIT_BOUNCE, PH_WAIT_TAIL, PH_WAIT_DRAIN, PH_DONE };
+    struct Batch
+    {
+        LaunchParams p;
+        Wavefront wf, wfAux;
+        PtxRenderer::BatchRes *res;
+        uint32_t active = 0;
+        int qin = 0;
+        uint64_t iteration = 0;
+        bool shadowPending = false;
+        int shadowSlot = 0;
+        Phase phase = PH_ISSUE;
+        double traceMs = 0, shadeMs = 0, shadowMs = 0, tailMs = 0;
+        uint64_t segments = 0, launches = 0;
     };
+    Batch B[PtxRenderer::kMaxBatches];
+
+    HIP_TRY(r, hipEventRecord(r->evStart, r->stream)); // lights upload, earlier resets
+    for (int b = 0; b < nb; b++)
+    {
+        const uint32_t f0 = (uint32_t)((uint64_t)frames * b / nb), f1 = (uint32_t)((uint64_t)frames * (b + 1) / nb);
+        Batch &bt = B[b];
+        bt.res = &r->batch[b];
+        bt.p = makeParams(r, uniform, firstFrame + f0, f1 - f0);
+        const size_t off = (size_t)f0 * p.slotsPerFrame;
+        Wavefront &wf = bt.wf;
+        wf.rayO = r->rayO.p + off; wf.rayD = r->rayD.p + off; wf.thr = r->thr.p + off; wf.rad = r->rad.p + off;
+        wf.meta = r->meta.p + off; wf.hit = r->hit.p + off; wf.hitPair = r->hitPair.p + off;
+        wf.shO = r->shO.p + off; wf.shD = r->shD.p + off; wf.shC = r->shC.p + off; wf.slotRad = r->slotRad.p + off;
+        wf.queue[0] = r->queue0.p + off; wf.queue[1] = r->queue1.p + off; wf.shadowQueue = r->shadowQueue.p + off;
+        wf.restartQueue = r->restartQueue.p + off;
+        wf.counters = bt.res->dCounters;
+        wf.spill = bt.res->spill;
+        bt.wfAux = wf;
+        bt.wfAux.spill = bt.res->spillAux;
+        HIP_TRY(r, hipStreamWaitEvent(bt.res->s, r->evStart, 0));
+        HIP_TRY(r, hipMemsetAsync(bt.res->dCounters, 0, C_COUNT * sizeof(uint32_t), bt.res->s));
+        k_generate<<<gridFor(bt.p.numSlots), kBlock, 0, bt.res->s>>>(bt.p, wf);
+        HIP_TRY(r, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&bt.res->dCounters[C_ACTIVE0]), (int)bt.p.numSlots, 1, bt.res->s));
+        bt.active = bt.p.numSlots;
+        bt.phase = bt.active ? PH_ISSUE : PH_DONE;
+    }
+
+    auto readShadowTime = [&](Batch &bt) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, bt.res->evX0[bt.shadowSlot], bt.res->evShadow[bt.shadowSlot]) == hipSuccess)
+            bt.shadowMs += ms;
+    };
+    // one bounce: closest -> (wait previous shadow) -> shade -> counters to the host
+    auto issueBounce = [&](Batch &bt) -> int {
+        PtxRenderer::BatchRes &q = *bt.res;
+        if (++bt.iteration > maxIterations)
+            return fail(r, PTX_ERROR_DEVICE, "ptx_render: %u paths still active after %llu bounce iterations", bt.active,
+                        (unsigned long long)maxIterations);
+        const int qout = bt.qin ^ 1;
+        HIP_TRY(r, hipMemsetAsync(&q.dCounters[qout], 0, sizeof(uint32_t), q.s));
+        HIP_TRY(r, hipMemsetAsync(&q.dCounters[C_SHADOW], 0, sizeof(uint32_t), q.s));
+        HIP_TRY(r, hipMemsetAsync(&q.dCounters[C_CHUNK], 0, sizeof(uint32_t), q.s));
+        HIP_TRY(r, hipEventRecord(q.evT0, q.s));
+        k_trace_closest<<<gridFor(bt.active), kBlock, 0, q.s>>>(sc, bt.wf, bt.qin, bt.active);
+        HIP_TRY(r, hipEventRecord(q.evT1, q.s));
+        if (bt.shadowPending) // k_shade reads rad[slot]: the previous bounce's shadow adds must have landed
+            HIP_TRY(r, hipStreamWaitEvent(q.s, q.evShadow[bt.shadowSlot], 0));
+        k_shade<<<gridFor(bt.active), kBlock, 0, q.s>>>(bt.p, sv, bt.wf, bt.qin);
+        HIP_TRY(r, hipEventRecord(q.evT2, q.s));
+        HIP_TRY(r, hipEventRecord(q.evShade, q.s));
+        HIP_TRY(r, hipMemcpyAsync(q.hCounters, q.dCounters, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, q.s));
+        HIP_TRY(r, hipEventRecord(q.evReady, q.s));
+        bt.phase = PH_WAIT_BOUNCE;
+        return PTX_OK;
+    };
+    auto issueDrain = [&](Batch &bt) -> int {
+        PtxRenderer::BatchRes &q = *bt.res;
+        if (bt.shadowPending)
+            HIP_TRY(r, hipStreamWaitEvent(q.s, q.evShadow[bt.shadowSlot], 0));
+        HIP_TRY(r, hipMemcpyAsync(q.hCounters, q.dCounters, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, q.s));
+        HIP_TRY(r, hipEventRecord(q.evReady, q.s));
+        bt.phase = PH_WAIT_DRAIN;
+        return PTX_OK;
+    };
+    auto next = [&](Batch &bt) -> int { // choose what follows a completed bounce / tail / drain
+        PtxRenderer::BatchRes &q = *bt.res;
+        if (!bt.active)
+            return issueDrain(bt);
+        if (bt.iteration >= 1 && bt.active <= tailThreshold)
+        {
+            if (bt.shadowPending) // k_tail continues from rad[slot]
+                HIP_TRY(r, hipStreamWaitEvent(q.s, q.evShadow[bt.shadowSlot], 0));
+            HIP_TRY(r, hipEventRecord(q.evT0, q.s));
+            k_tail<<<gridFor(bt.active, kBlock, 1u << 20), kBlock, 0, q.s>>>(bt.p, sv, sc, bt.wf, bt.qin, bt.active);
+            HIP_TRY(r, hipEventRecord(q.evT1, q.s));
+            HIP_TRY(r, hipMemcpyAsync(q.hCounters, q.dCounters, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, q.s));
+            HIP_TRY(r, hipEventRecord(q.evReady, q.s));
+            bt.phase = PH_WAIT_TAIL;
+            return PTX_OK;
+        }
+        return issueBounce(bt);
+    };
+    auto advance = [&](Batch &bt, int index) -> int {
+        PtxRenderer::BatchRes &q = *bt.res;
+        float ms = 0.0f;
+        switch (bt.phase)
+        {
+        case PH_ISSUE:
+            return issueBounce(bt);
+        case PH_WAIT_BOUNCE: {
+            if (bt.shadowPending) // its event completed before k_shade started
+            {
+                readShadowTime(bt);
+                bt.shadowPending = false;
+            }
+            (void)hipEventElapsedTime(&ms, q.evT0, q.evT1);
+            bt.traceMs += ms;
+            const float closestMs = ms;
+            (void)hipEventElapsedTime(&ms, q.evT1, q.evT2);
+            bt.shadeMs += ms;
+            const int qout = bt.qin ^ 1;
+            const uint32_t shadowCount = q.hCounters[C_SHADOW];
+            if (q.hCounters[C_OVERFLOW])
+                return fail(r, PTX_ERROR_DEVICE, "ptx_render: traversal stack overflow (tree deeper than %d levels)", kLdsStack + kGlobalSpill);
+            if (shadowCount)
+            {
+                bt.shadowSlot ^= 1;
+                HIP_TRY(r, hipStreamWaitEvent(q.x, q.evShade, 0));
+                HIP_TRY(r, hipMemsetAsync(&q.dCounters[C_CHUNK + 1], 0, sizeof(uint32_t), q.x));
+                HIP_TRY(r, hipEventRecord(q.evX0[bt.shadowSlot], q.x));
+                k_trace_shadow<<<gridFor(shadowCount), kBlock, 0, q.x>>>(bt.p, sc, bt.wfAux, qout, shadowCount);
+                HIP_TRY(r, hipEventRecord(q.evShadow[bt.shadowSlot], q.x));
+                bt.shadowPending = true;
+            }
+            if (verbose)
+                fprintf(stderr, "[ptx] batch %d bounce %llu: %u rays closest %.3f ms (%.2f Grays/s) | shade %.3f ms | %u shadow rays\n", index,
+                        (unsigned long long)bt.iteration, bt.active, closestMs, bt.active / closestMs / 1e6, ms, shadowCount);
+            bt.segments += bt.iteration == 1 ? (uint64_t)bt.p.ownedPixels * bt.p.frames : bt.active;
+            bt.launches += 2;
+            bt.active = q.hCounters[qout];
+            bt.qin = qout;
+            return next(bt);
+        }
+        case PH_WAIT_TAIL:
+            (void)hipEventElapsedTime(&ms, q.evT0, q.evT1);
+            bt.tailMs += ms;
+            if (verbose)
+                fprintf(stderr, "[ptx] batch %d tail: %u paths, %u segments, %.3f ms\n", index, bt.active, q.hCounters[C_SEGMENTS], ms);
+            if (q.hCounters[C_OVERFLOW])
+                return fail(r, PTX_ERROR_DEVICE, "ptx_render: traversal stack overflow in k_tail (depth > %d)", kLdsStackMega);
+            bt.segments += q.hCounters[C_SEGMENTS];
+            HIP_TRY(r, hipMemsetAsync(&q.dCounters[C_SEGMENTS], 0, sizeof(uint32_t), q.s));
+            bt.active = 0; // every path of the queue ran to the end of the launch
+            return next(bt);
+        case PH_WAIT_DRAIN: {
+            if (bt.shadowPending)
+            {
+                readShadowTime(bt);
+                bt.shadowPending = false;
+            }
+            if (q.hCounters[C_OVERFLOW])
+                return fail(r, PTX_ERROR_DEVICE, "ptx_render: traversal stack overflow");
+            // paths re-queued by the shadow kernel (next sample of a multi-sample launch, NaN restart)
+            const uint32_t restarts = q.hCounters[C_RESTART];
+            if (!restarts)
+            {
+                HIP_TRY(r, hipEventRecord(q.evDone, q.s));
+                bt.phase = PH_DONE;
+                return PTX_OK;
+            }
+            HIP_TRY(r, hipMemcpyAsync(bt.wf.queue[bt.qin], bt.wf.restartQueue, (size_t)restarts * sizeof(uint32_t), hipMemcpyDeviceToDevice, q.s));
+            HIP_TRY(r, hipMemsetAsync(&q.dCounters[C_RESTART], 0, sizeof(uint32_t), q.s));
+            bt.active = restarts;
+            return next(bt);
+        }
+        default:
+            return PTX_OK;
+        }
+    };
+
     for (;;)
     {
-        if (!active)
+        int pending = 0;
+        bool progressed = false;
+        for (int b = 0; b < nb; b++)
         {
-            // paths re-queued by the shadow kernel (next sample of a multi-sample launch, NaN restart)
-            HIP_TRY(r, drainShadow(true));
-            HIP_TRY(r, hipMemcpyAsync(r->hostCounters, r->counters.p, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
-            HIP_TRY(r, hipStreamSynchronize(r->stream));
-            const uint32_t restarts = r->hostCounters[C_RESTART];
-            if (!restarts)
-                break;
-            HIP_TRY(r, hipMemcpyAsync(wf.queue[qin], wf.restartQueue, (size_t)restarts * sizeof(uint32_t), hipMemcpyDeviceToDevice, r->stream));
-            HIP_TRY(r, hipMemsetAsync(&r->counters.p[C_RESTART], 0, sizeof(uint32_t), r->stream));
-            active = restarts;
+            Batch &bt = B[b];
+            if (bt.phase == PH_DONE)
+                continue;
+            pending++;
+            if (bt.phase != PH_ISSUE)
+            {
+                const hipError_t q = hipEventQuery(bt.res->evReady);
+                if (q == hipErrorNotReady)
+                    continue;
+                HIP_TRY(r, q);
+            }
+            const int rca = advance(bt, b);
+            if (rca != PTX_OK)
+            {
+                for (int k = 0; k < nb; k++) // leave no work in flight behind an error
+                {
+                    (void)hipStreamSynchronize(r->batch[k].s);
+                    (void)hipStreamSynchronize(r->batch[k].x);
+                }
+                return rca;
+            }
+            progressed = true;
         }
-        if (iteration >= 1 && active <= tailThreshold)
-        {
-            HIP_TRY(r, drainShadow(true)); // k_tail continues from rad[slot]
-            HIP_TRY(r, hipEventRecord(r->evT0, r->stream));
-            k_tail<<<gridFor(active, kBlock, 1u << 20), kBlock, 0, r->stream>>>(p, sv, sc, wf, qin, active);
-            HIP_TRY(r, hipEventRecord(r->evT1, r->stream));
-            HIP_TRY(r, hipMemcpyAsync(r->hostCounters, r->counters.p, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
-            HIP_TRY(r, hipStreamSynchronize(r->stream));
-            float ms = 0.0f;
-            (void)hipEventElapsedTime(&ms, r->evT0, r->evT1);
-            r->stats.lastTailMs += ms;
-            if (verbose)
-                fprintf(stderr, "[ptx] tail: %u paths, %u segments, %.3f ms\n", active, r->hostCounters[C_SEGMENTS], ms);
-            if (r->hostCounters[C_OVERFLOW])
-                return fail(r, PTX_ERROR_DEVICE, "ptx_render: traversal stack overflow in k_tail (depth > %d)", kLdsStackMega);
-            r->stats.segments += r->hostCounters[C_SEGMENTS];
-            HIP_TRY(r, hipMemsetAsync(&r->counters.p[C_SEGMENTS], 0, sizeof(uint32_t), r->stream));
-            active = 0; // every path of the queue ran to the end of the launch
-            continue;
-        }
-        if (++iteration > maxIterations)
-            return fail(r, PTX_ERROR_DEVICE, "ptx_render: %u paths still active after %llu bounce iterations", active,
-                        (unsigned long long)maxIterations);
-        const int qout = qin ^ 1;
-        HIP_TRY(r, hipMemsetAsync(&r->counters.p[qout], 0, sizeof(uint32_t), r->stream));
-        HIP_TRY(r, hipMemsetAsync(&r->counters.p[C_SHADOW], 0, sizeof(uint32_t), r->stream));
-        HIP_TRY(r, hipMemsetAsync(&r->counters.p[C_CHUNK], 0, sizeof(uint32_t), r->stream));
-        HIP_TRY(r, hipEventRecord(r->evT0, r->stream));
-        k_trace_closest<<<gridFor(active), kBlock, 0, r->stream>>>(sc, wf, qin, active);
-        HIP_TRY(r, hipEventRecord(r->evT1, r->stream));
-        if (shadowPending) // k_shade reads rad[slot]: the previous bounce's shadow adds must have landed
-            HIP_TRY(r, hipStreamWaitEvent(r->stream, r->evShadow[shadowSlot], 0));
-        k_shade<<<gridFor(active), kBlock, 0, r->stream>>>(p, sv, wf, qin);
-        HIP_TRY(r, hipEventRecord(r->evT2, r->stream));
-        HIP_TRY(r, hipEventRecord(r->evShade, r->stream));
-        HIP_TRY(r, hipMemcpyAsync(r->hostCounters, r->counters.p, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
-        HIP_TRY(r, hipStreamSynchronize(r->stream));
-        HIP_TRY(r, drainShadow(false)); // its event completed before k_shade started
-        float ms = 0.0f;
-        (void)hipEventElapsedTime(&ms, r->evT0, r->evT1);
-        traceMs += ms;
-        const float closestMs = ms;
-        (void)hipEventElapsedTime(&ms, r->evT1, r->evT2);
-        r->stats.lastShadeMs += ms;
-        const uint32_t shadowCount = r->hostCounters[C_SHADOW];
-        if (shadowCount)
-        {
-            shadowSlot ^= 1;
-            HIP_TRY(r, hipStreamWaitEvent(sx, r->evShade, 0));
-            HIP_TRY(r, hipMemsetAsync(&r->counters.p[C_CHUNK + 1], 0, sizeof(uint32_t), sx));
-            HIP_TRY(r, hipEventRecord(r->evX0[shadowSlot], sx));
-            k_trace_shadow<<<gridFor(shadowCount), kBlock, 0, sx>>>(p, sc, wfAux, qout, shadowCount);
-            HIP_TRY(r, hipEventRecord(r->evShadow[shadowSlot], sx));
-            shadowPending = true;
-        }
-        if (verbose)
-            fprintf(stderr, "[ptx] bounce %llu: %u rays closest %.3f ms (%.2f Grays/s) | shade %.3f ms | %u shadow rays\n",
-                    (unsigned long long)iteration, active, closestMs, active / closestMs / 1e6, ms, shadowCount);
-        r->stats.segments += iteration == 1 ? p.ownedPixels * frames : active;
-        r->stats.traceLaunches += 2;
-        if (r->hostCounters[C_OVERFLOW])
-            return fail(r, PTX_ERROR_DEVICE, "ptx_render: traversal stack overflow (tree deeper than %d levels)", kLdsStack + kGlobalSpill);
-        active = r->hostCounters[qout];
-        qin = qout;
+        if (!pending)
+            break;
+        if (!progressed)
+            __builtin_ia32_pause();
     }
-    r->stats.lastShadowMs = shadowMs;
-    if (r->aux) // later work on `stream` (accumulate, readback) is ordered after everything on aux
-        HIP_TRY(r, hipStreamSynchronize(r->aux));
-    HIP_TRY(r, hipMemcpyAsync(r->hostCounters, r->counters.p, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
-    HIP_TRY(r, hipStreamSynchronize(r->stream));
-    if (r->hostCounters[C_OVERFLOW])
-        return fail(r, PTX_ERROR_DEVICE, "ptx_render: traversal stack overflow");
+    double traceMs = 0.0;
+    uint64_t hits = 0, samples = 0, retries = 0;
+    for (int b = 0; b < nb; b++)
+    {
+        const Batch &bt = B[b];
+        traceMs += bt.traceMs;
+        r->stats.lastShadeMs += bt.shadeMs;
+        r->stats.lastShadowMs += bt.shadowMs;
+        r->stats.lastTailMs += bt.tailMs;
+        r->stats.segments += bt.segments;
+        r->stats.traceLaunches += bt.launches;
+        // every counter block was copied to the host by the sub-batch's final drain
+        hits += bt.res->hCounters[C_HITS];
+        samples += bt.res->hCounters[C_SAMPLES];
+        retries += bt.res->hCounters[C_RETRIES];
+        HIP_TRY(r, hipStreamWaitEvent(r->stream, bt.res->evDone, 0)); // k_accumulate follows every sub-batch
+    }
     k_accumulate<<<gridFor(p.slotsPerFrame), kBlock, 0, r->stream>>>(p, r->slotRad.p, imagePtr(r));
     HIP_TRY(r, hipEventRecord(r->evB, r->stream));
     HIP_TRY(r, hipGetLastError());
-    r->stats.shadowRays = r->hostCounters[C_HITS];
-    r->stats.pathSamples = r->hostCounters[C_SAMPLES];
-    r->stats.retries = r->hostCounters[C_RETRIES];
+    r->stats.shadowRays = hits;
+    r->stats.pathSamples = samples;
+    r->stats.retries = retries;
     r->stats.lastTraceMs = traceMs;
     return PTX_OK;
 }

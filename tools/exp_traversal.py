@@ -66,3 +66,12 @@ s = b.copy(); s[:, 4:7] = L; s[:, 7] = 1e5
 bench("shadow any-hit (coherent)", s, True)
 sh = b.copy(); sh[:, 7] = 1e5
 bench("shadow any-hit (incoherent)", sh, True)
+
+if os.environ.get("EXP_HEATMAP"):
+    hs, stt = r.trace_rays(rays, 2)
+    img = np.zeros((H, W), np.float32)
+    img[py, px] = stt[:, 0]
+    np.save("gpurun_out/visits.npy", img[::2, ::2].astype(np.uint16))
+    v = stt[:, 0]
+    print("visit percentiles 50/90/99/99.9/99.99/max:", [int(np.percentile(v, q)) for q in (50, 90, 99, 99.9, 99.99)], int(v.max()))
+    print("share of all visits spent in rays with > 60 visits:", float(v[v > 60].sum() / v.sum()), "ray share", float((v > 60).mean()))
