@@ -222,6 +222,24 @@ typedef struct PtxModelInstance {
     PtxTransform Transform;
 } PtxModelInstance;
 
+/* Scene textures (row N1).  Texture i of the scene has shader index PTX_SCENE_TEXTURE_OFFSET + i
+ * (Scene.cpp:125-141).  8-bit data is RGBA8; the image format follows the texture TYPE as in
+ * TextureUploader::GetImageFormat (TextureUploader.cpp:571-594): sRGB for Color / Specular /
+ * Emissive / Skybox, UNORM otherwise.  The full mip chain (floor(log2(max(w,h))) + 1 levels,
+ * Image.cpp:14-17) is generated level by level with a linear 2:1 blit (Image.cpp:264-300). */
+typedef enum PtxTextureFormat {
+    PTX_TEXTURE_RGBA8_UNORM = 0,
+    PTX_TEXTURE_RGBA8_SRGB = 1,
+    PTX_TEXTURE_RGBA32F = 2
+} PtxTextureFormat;
+
+typedef struct PtxTextureDesc {
+    uint32_t width, height;
+    uint32_t format;   /* PtxTextureFormat */
+    uint32_t reserved;
+    const void *data;  /* level 0, row-major, width*height texels */
+} PtxTextureDesc;
+
 enum {
     PTX_SKYBOX_CLEAR_COLOR = 0, /* miss.rmiss:37: constant (0.08, 0.09, 0.10) */
     PTX_SKYBOX_2D = 1,          /* MissFlagsSkybox2D  -- next row N1          */
@@ -253,6 +271,9 @@ typedef struct PtxSceneDesc {
     uint32_t instanceCount;
     uint32_t skyboxKind;       /* PTX_SKYBOX_*; PathTracingPipelineConfig.MissFlags */
     uint32_t dxNormalTextures; /* HitFlagsDxNormalTextures, ShaderRendererTypes.incl:96-99 */
+    const PtxTextureDesc *textures; /* Scene::GetTextures(); may be NULL: indices >= 9 then sample the white placeholder */
+    uint32_t textureCount;
+    uint32_t reserved;
 } PtxSceneDesc;
 
 /* ------------------------------------------------------------------------- */
@@ -405,6 +426,11 @@ typedef enum PtxTestFunction {
 
 /* Material block used by PTX_FN_EVALUATE_BSDF / PTX_FN_SAMPLE_BSDF:
  * color.rgb, roughness, metalness, transmission, eta (7 floats + 1 pad). */
+
+/* textureGrad (implicitLod = 0; material.glsl:72-76) or texture() at LOD 0 (implicitLod = 1, the
+ * any-hit shaders: anyhit.rahit:48) of the uploaded scene's textures.  in: 7 floats per sample
+ * (texture index as uint bits, u, v, dudx, dvdx, dudy, dvdy); out: rgba. */
+PTX_API int ptx_test_texture(PtxRenderer *r, const float *in, float *out, uint32_t n, int implicitLod);
 
 PTX_API int ptx_test_input_stride(uint32_t fn);
 PTX_API int ptx_test_output_stride(uint32_t fn);

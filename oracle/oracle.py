@@ -47,6 +47,7 @@ def load() -> C.CDLL:
         lib.pto_trace_closest.argtypes = [P, P, C.c_uint32, P, C.c_int]
         lib.pto_trace_any.argtypes = [P, P, C.c_uint32, P, C.c_int]
         lib.pto_test_eval.argtypes = [C.c_uint32, P, P, C.c_uint32]
+        lib.pto_test_texture.argtypes = [P, P, P, C.c_uint32, C.c_int]
         _lib = lib
     return _lib
 
@@ -81,6 +82,12 @@ class OracleScene:
         if rc:
             raise RuntimeError("pto_render failed")
         return accum, stats
+
+    def test_texture(self, inputs: np.ndarray, implicit_lod: bool = False) -> np.ndarray:
+        inputs = np.ascontiguousarray(inputs).view(np.uint32).reshape(-1, 7)
+        out = np.zeros((inputs.shape[0], 4), np.uint32)
+        self.lib.pto_test_texture(self.handle, inputs.ctypes.data, out.ctypes.data, inputs.shape[0], int(implicit_lod))
+        return out
 
     def trace_closest(self, rays: np.ndarray, brute_force: bool = False):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)

@@ -687,7 +687,19 @@ struct PtoScene
     BvhNode *nodes;
     uint32_t nodeCount;
     uint32_t *bvhTris; /* triangle ids in leaf order */
+    /* scene textures (row N1) */
+    struct OTexture *textures;
+    uint32_t textureCount;
+    uint32_t *texels8; /* RGBA8 pool, all levels of all 8-bit textures */
+    float *texelsF;    /* RGBA32F pool */
+    float srgbLut[256];
 };
+
+typedef struct OTexture
+{
+    uint32_t width, height, levels, format;
+    size_t levelOffset[16]; /* in texels, into the pool of its format */
+} OTexture;
 
 static void *dupmem(const void *p, size_t n)
 {
@@ -722,6 +734,7 @@ static inline v3 xformVector(const float *M, v3 p)
 }
 
 static void buildBvh(PtoScene *s);
+static void uploadTextures(PtoScene *s, const PtxSceneDesc *desc);
 
 PtoScene *pto_scene_create(const PtxSceneDesc *desc, int wantBvh)
 {
@@ -800,6 +813,8 @@ PtoScene *pto_scene_create(const PtxSceneDesc *desc, int wantBvh)
             }
         }
     }
+    uploadTextures(s, desc);
+    s->d.textures = NULL; /* the caller's array is not retained */
     if (wantBvh && triCount)
         buildBvh(s);
     return s;
@@ -815,6 +830,7 @@ void pto_scene_destroy(PtoScene *s)
     free((void *)s->d.meshes); free((void *)s->d.models); free((void *)s->d.instances);
     free(s->pairs); free(s->v0); free(s->e1); free(s->e2); free(s->triPair); free(s->triPrim);
     free(s->nodes); free(s->bvhTris);
+    free(s->textures); free(s->texels8); free(s->texelsF);
     free(s);
 }
 
@@ -1172,6 +1188,195 @@ void pto_trace_any(const PtoScene *s, const float *rays, uint32_t n, uint32_t *o
         const float *r = &rays[i * 8];
         occluded[i] = (uint32_t)traceAny(s, V3(r[0], r[1], r[2]), V3(r[4], r[5], r[6]), r[3], r[7], brute, NULL);
     }
+}
+
+/* ======================================================================== */
+/* Software sampler: what the Vulkan sampler of Renderer.cpp:103-112 does     */
+/* (linear min/mag/mip, repeat addressing) restated with fixed arithmetic.    */
+/* Anisotropic filtering (implementation-defined in Vulkan) is NOT modelled:  */
+/* textureGrad is isotropic trilinear.                                        */
+/* ======================================================================== */
+
+static inline uint32_t levelDim(uint32_t d, uint32_t level) { const uint32_t v = d >> level; return v ? v : 1u; }
+
+/* sRGB EOTF / inverse through the fixed pow kernel (shared definition with the HIP kernels) */
+static inline float srgbToLinear(float c) { return c <= 0.04045f ? c / 12.92f : pto_powf((c + 0.055f) / 1.055f, 2.4f); }
+static inline float linearToSrgb(float c) { return c <= 0.0031308f ? 12.92f * c : 1.055f * pto_powf(c, 1.0f / 2.4f) - 0.055f; }
+static inline uint32_t quantize8(float x)
+{
+    if (!(x > 0.0f))
+        return 0u;
+    if (x > 1.0f)
+        x = 1.0f;
+    return (uint32_t)floorf(x * 255.0f + 0.5f);
+}
+
+static inline v4 fetchTexel(const PtoScene *s, const OTexture *t, uint32_t level, uint32_t x, uint32_t y)
+{
+    const size_t idx = t->levelOffset[level] + (size_t)y * levelDim(t->width, level) + x;
+    v4 r;
+    if (t->format == PTX_TEXTURE_RGBA32F)
+    {
+        r.x = s->texelsF[idx * 4]; r.y = s->texelsF[idx * 4 + 1]; r.z = s->texelsF[idx * 4 + 2]; r.w = s->texelsF[idx * 4 + 3];
+        return r;
+    }
+    const uint32_t p = s->texels8[idx];
+    if (t->format == PTX_TEXTURE_RGBA8_SRGB)
+    {
+        r.x = s->srgbLut[p & 255u]; r.y = s->srgbLut[(p >> 8) & 255u]; r.z = s->srgbLut[(p >> 16) & 255u];
+    }
+    else
+    {
+        r.x = (float)(p & 255u) / 255.0f; r.y = (float)((p >> 8) & 255u) / 255.0f; r.z = (float)((p >> 16) & 255u) / 255.0f;
+    }
+    r.w = (float)(p >> 24) / 255.0f;
+    return r;
+}
+
+static inline v4 v4_lerp(v4 a, v4 b, float t)
+{
+    v4 r = { a.x * (1.0f - t) + b.x * t, a.y * (1.0f - t) + b.y * t, a.z * (1.0f - t) + b.z * t, a.w * (1.0f - t) + b.w * t };
+    return r;
+}
+
+/* repeat addressing: floor(x) mod n, in float so that CPU and GPU agree for any finite x */
+static inline uint32_t wrapRepeat(float x0, uint32_t n)
+{
+    const float fn = (float)n;
+    float m = x0 - floorf(x0 / fn) * fn;
+    if (!(m >= 0.0f)) m = 0.0f;
+    uint32_t i = (uint32_t)m;
+    return i >= n ? n - 1 : i;
+}
+
+/* bilinear sample of one level, normalised coordinates */
+static v4 sampleLevel(const PtoScene *s, const OTexture *t, uint32_t level, float u, float v)
+{
+    const uint32_t w = levelDim(t->width, level), h = levelDim(t->height, level);
+    if (w == 1 && h == 1) /* exact for 1x1 (hardware weights are fixed point and sum to 1) */
+        return fetchTexel(s, t, level, 0, 0);
+    if (!(fabsf(u) < 1e9f)) u = 0.0f;
+    if (!(fabsf(v) < 1e9f)) v = 0.0f;
+    const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    const float x0 = floorf(x), y0 = floorf(y);
+    const float ax = x - x0, ay = y - y0;
+    const uint32_t ix0 = wrapRepeat(x0, w), ix1 = wrapRepeat(x0 + 1.0f, w), iy0 = wrapRepeat(y0, h), iy1 = wrapRepeat(y0 + 1.0f, h);
+    const v4 top = v4_lerp(fetchTexel(s, t, level, ix0, iy0), fetchTexel(s, t, level, ix1, iy0), ax);
+    const v4 bot = v4_lerp(fetchTexel(s, t, level, ix0, iy1), fetchTexel(s, t, level, ix1, iy1), ax);
+    return v4_lerp(top, bot, ay);
+}
+
+/* textureGrad: LOD from the gradients (Vulkan 1.3 spec 16.5.7, isotropic), trilinear */
+static v4 textureGradSample(const PtoScene *s, const OTexture *t, float u, float v, float dudx, float dvdx, float dudy, float dvdy)
+{
+    if (t->levels <= 1)
+        return sampleLevel(s, t, 0, u, v);
+    const float mux = dudx * (float)t->width, mvx = dvdx * (float)t->height;
+    const float muy = dudy * (float)t->width, mvy = dvdy * (float)t->height;
+    const float rx = sqrtf(mux * mux + mvx * mvx), ry = sqrtf(muy * muy + mvy * mvy);
+    const float rho = f_max(rx, ry);
+    float lod = rho > 0.0f ? (float)pto_log2((double)rho) : 0.0f;
+    const float q = (float)(t->levels - 1);
+    if (!(lod >= 0.0f)) lod = 0.0f;
+    if (lod > q) lod = q;
+    const float d0 = floorf(lod), f = lod - d0;
+    const uint32_t l0 = (uint32_t)d0, l1 = l0 + 1 < t->levels ? l0 + 1 : t->levels - 1;
+    const v4 c0 = sampleLevel(s, t, l0, u, v);
+    if (f == 0.0f || l1 == l0)
+        return c0;
+    return v4_lerp(c0, sampleLevel(s, t, l1, u, v), f);
+}
+
+/* mip chain: each level is a linear blit of the previous one (Image.cpp:264-300): decode,
+ * bilinear at the destination texel centre with clamp-to-edge, re-encode in the image format */
+static void generateMips(PtoScene *s, OTexture *t)
+{
+    for (uint32_t l = 1; l < t->levels; l++)
+    {
+        const uint32_t sw = levelDim(t->width, l - 1), sh = levelDim(t->height, l - 1);
+        const uint32_t dw = levelDim(t->width, l), dh = levelDim(t->height, l);
+        for (uint32_t j = 0; j < dh; j++)
+            for (uint32_t i = 0; i < dw; i++)
+            {
+                const float x = ((float)i + 0.5f) * ((float)sw / (float)dw) - 0.5f, y = ((float)j + 0.5f) * ((float)sh / (float)dh) - 0.5f;
+                const float x0 = floorf(x), y0 = floorf(y), ax = x - x0, ay = y - y0;
+                const float cx0 = f_clamp(x0, 0.0f, (float)(sw - 1)), cx1 = f_clamp(x0 + 1.0f, 0.0f, (float)(sw - 1));
+                const float cy0 = f_clamp(y0, 0.0f, (float)(sh - 1)), cy1 = f_clamp(y0 + 1.0f, 0.0f, (float)(sh - 1));
+                const v4 top = v4_lerp(fetchTexel(s, t, l - 1, (uint32_t)cx0, (uint32_t)cy0), fetchTexel(s, t, l - 1, (uint32_t)cx1, (uint32_t)cy0), ax);
+                const v4 bot = v4_lerp(fetchTexel(s, t, l - 1, (uint32_t)cx0, (uint32_t)cy1), fetchTexel(s, t, l - 1, (uint32_t)cx1, (uint32_t)cy1), ax);
+                const v4 c = v4_lerp(top, bot, ay);
+                const size_t idx = t->levelOffset[l] + (size_t)j * dw + i;
+                if (t->format == PTX_TEXTURE_RGBA32F)
+                {
+                    s->texelsF[idx * 4] = c.x; s->texelsF[idx * 4 + 1] = c.y; s->texelsF[idx * 4 + 2] = c.z; s->texelsF[idx * 4 + 3] = c.w;
+                }
+                else if (t->format == PTX_TEXTURE_RGBA8_SRGB)
+                    s->texels8[idx] = quantize8(linearToSrgb(c.x)) | quantize8(linearToSrgb(c.y)) << 8 | quantize8(linearToSrgb(c.z)) << 16 | quantize8(c.w) << 24;
+                else
+                    s->texels8[idx] = quantize8(c.x) | quantize8(c.y) << 8 | quantize8(c.z) << 16 | quantize8(c.w) << 24;
+            }
+    }
+}
+
+static void uploadTextures(PtoScene *s, const PtxSceneDesc *desc)
+{
+    for (int c = 0; c < 256; c++)
+        s->srgbLut[c] = srgbToLinear((float)c / 255.0f);
+    s->textureCount = desc->textures ? desc->textureCount : 0;
+    if (!s->textureCount)
+        return;
+    s->textures = (OTexture *)calloc(s->textureCount, sizeof(OTexture));
+    size_t n8 = 0, nf = 0;
+    for (uint32_t i = 0; i < s->textureCount; i++)
+    {
+        const PtxTextureDesc *d = &desc->textures[i];
+        OTexture *t = &s->textures[i];
+        t->width = d->width ? d->width : 1;
+        t->height = d->height ? d->height : 1;
+        t->format = d->format;
+        uint32_t m = t->width > t->height ? t->width : t->height, levels = 1;
+        while (m > 1) { m >>= 1; levels++; } /* floor(log2(max)) + 1, Image.cpp:14-17 */
+        t->levels = levels > 16 ? 16 : levels;
+        size_t *cursor = t->format == PTX_TEXTURE_RGBA32F ? &nf : &n8;
+        for (uint32_t l = 0; l < t->levels; l++)
+        {
+            t->levelOffset[l] = *cursor;
+            *cursor += (size_t)levelDim(t->width, l) * levelDim(t->height, l);
+        }
+    }
+    s->texels8 = (uint32_t *)calloc(n8 ? n8 : 1, 4);
+    s->texelsF = (float *)calloc(nf ? nf : 1, 16);
+    for (uint32_t i = 0; i < s->textureCount; i++)
+    {
+        const PtxTextureDesc *d = &desc->textures[i];
+        OTexture *t = &s->textures[i];
+        const size_t n0 = (size_t)t->width * t->height;
+        if (d->data)
+        {
+            if (t->format == PTX_TEXTURE_RGBA32F)
+                memcpy(&s->texelsF[t->levelOffset[0] * 4], d->data, n0 * 16);
+            else
+                memcpy(&s->texels8[t->levelOffset[0]], d->data, n0 * 4);
+        }
+        generateMips(s, t);
+    }
+}
+
+int pto_test_texture(const PtoScene *s, const float *in, float *out, uint32_t n, int implicitLod)
+{
+    for (uint32_t i = 0; i < n; i++)
+    {
+        const float *a = &in[(size_t)i * 7];
+        const uint32_t idx = f2u(a[0]);
+        v4 r = { 1.0f, 1.0f, 1.0f, 1.0f };
+        if (idx >= PTX_SCENE_TEXTURE_OFFSET && idx - PTX_SCENE_TEXTURE_OFFSET < s->textureCount)
+        {
+            const OTexture *t = &s->textures[idx - PTX_SCENE_TEXTURE_OFFSET];
+            r = implicitLod ? sampleLevel(s, t, 0, a[1], a[2]) : textureGradSample(s, t, a[1], a[2], a[3], a[4], a[5], a[6]);
+        }
+        out[i * 4] = r.x; out[i * 4 + 1] = r.y; out[i * 4 + 2] = r.z; out[i * 4 + 3] = r.w;
+    }
+    return 0;
 }
 
 /* ======================================================================== */

@@ -74,6 +74,9 @@ PTX_API int pto_render(const PtoScene *s, const PtxRaygenUniformData *u, const P
 PTX_API void pto_trace_closest(const PtoScene *s, const float *rays, uint32_t n, PtoHit *hits, int bruteForce);
 PTX_API void pto_trace_any(const PtoScene *s, const float *rays, uint32_t n, uint32_t *occluded, int bruteForce);
 
+/* Sampler entry, same packing as ptx_test_texture (include/ptx.h). */
+PTX_API int pto_test_texture(const PtoScene *s, const float *in, float *out, uint32_t n, int implicitLod);
+
 /* Function-level entry, same packing as ptx_test_eval (include/ptx.h). */
 PTX_API int pto_test_eval(uint32_t fn, const float *in, float *out, uint32_t n);
 

@@ -42,7 +42,7 @@ PTX_SYMBOLS = [
     "ptx_resize", "ptx_set_tile_shard", "ptx_set_backend", "ptx_reset_accumulation", "ptx_render",
     "ptx_render_frames", "ptx_synchronize", "ptx_readback", "ptx_device_accum_ptr", "ptx_accum_bytes",
     "ptx_shard_bytes", "ptx_pack_shard", "ptx_unpack_shard", "ptx_get_stats", "ptx_bind_accumulation",
-    "ptx_trace_rays", "ptx_test_input_stride", "ptx_test_output_stride", "ptx_test_eval",
+    "ptx_trace_rays", "ptx_test_input_stride", "ptx_test_output_stride", "ptx_test_eval", "ptx_test_texture",
 ]
 PTH_SYMBOLS = [
     "pth_scene_names", "pth_scene_create", "pth_scene_destroy", "pth_last_error", "pth_scene_desc",
@@ -70,6 +70,7 @@ class SceneDesc(C.Structure):
         ("models", C.c_void_p), ("modelCount", C.c_uint32),
         ("instances", C.c_void_p), ("instanceCount", C.c_uint32),
         ("skyboxKind", C.c_uint32), ("dxNormalTextures", C.c_uint32),
+        ("textures", C.c_void_p), ("textureCount", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
 
@@ -227,6 +228,7 @@ def load_hip() -> C.CDLL:
         lib.ptx_test_input_stride.argtypes = [C.c_uint32]
         lib.ptx_test_output_stride.argtypes = [C.c_uint32]
         lib.ptx_test_eval.argtypes = [P, C.c_uint32, P, P, C.c_uint32]
+        lib.ptx_test_texture.argtypes = [P, P, P, C.c_uint32, C.c_int]
         _hip = lib
     return _hip
 
@@ -376,6 +378,12 @@ class Renderer:
         self._check(self.lib.ptx_trace_rays(self.handle, rays.ctypes.data, n, int(any_hit), hits.ctypes.data,
                                             ids.ctypes.data))
         return hits, ids
+
+    def test_texture(self, inputs: np.ndarray, implicit_lod: bool = False) -> np.ndarray:
+        inputs = np.ascontiguousarray(inputs).view(np.uint32).reshape(-1, 7)
+        out = np.zeros((inputs.shape[0], 4), np.uint32)
+        self._check(self.lib.ptx_test_texture(self.handle, inputs.ctypes.data, out.ctypes.data, inputs.shape[0], int(implicit_lod)))
+        return out
 
     def test_eval(self, fn: int, inputs: np.ndarray) -> np.ndarray:
         nin, nout = self.lib.ptx_test_input_stride(fn), self.lib.ptx_test_output_stride(fn)

@@ -586,6 +586,115 @@ PT_DEV LightSample sampleLight(const PtxLightsUbo *ubo, f3 u, f3 position, float
     return ret;
 }
 
+// ---- software sampler (row N1) ---------------------------------------------------------------------
+// What the Vulkan sampler of Renderer.cpp:103-112 does (linear min/mag/mip, repeat addressing),
+// with fixed arithmetic shared with the oracle.  Anisotropic filtering is implementation-defined
+// in Vulkan and is NOT modelled: textureGrad is isotropic trilinear.
+
+struct DevTexture
+{
+    uint32_t width, height, levels, format;
+    uint32_t levelOffset[16]; // texels, into the pool of its format
+};
+
+struct TextureView
+{
+    const DevTexture *textures;
+    uint32_t textureCount;
+    const uint32_t *texels8; // RGBA8 pool
+    const float4 *texelsF;   // RGBA32F pool
+    const float *srgbLut;    // 256 entries, sRGB byte -> linear
+};
+
+PT_DEV uint32_t levelDim(uint32_t d, uint32_t level) { const uint32_t v = d >> level; return v ? v : 1u; }
+
+PT_DEV float srgbToLinear(float c) { return c <= 0.04045f ? c / 12.92f : pow_((c + 0.055f) / 1.055f, 2.4f); }
+PT_DEV float linearToSrgb(float c) { return c <= 0.0031308f ? 12.92f * c : 1.055f * pow_(c, 1.0f / 2.4f) - 0.055f; }
+PT_DEV uint32_t quantize8(float x)
+{
+    if (!(x > 0.0f))
+        return 0u;
+    if (x > 1.0f)
+        x = 1.0f;
+    return (uint32_t)__builtin_floorf(x * 255.0f + 0.5f);
+}
+
+PT_DEV f4 fetchTexel(const TextureView &tv, const DevTexture &t, uint32_t level, uint32_t x, uint32_t y)
+{
+    const size_t idx = (size_t)t.levelOffset[level] + (size_t)y * levelDim(t.width, level) + x;
+    f4 r;
+    if (t.format == PTX_TEXTURE_RGBA32F)
+    {
+        const float4 v = tv.texelsF[idx];
+        r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+        return r;
+    }
+    const uint32_t p = tv.texels8[idx];
+    if (t.format == PTX_TEXTURE_RGBA8_SRGB)
+    {
+        r.x = tv.srgbLut[p & 255u]; r.y = tv.srgbLut[(p >> 8) & 255u]; r.z = tv.srgbLut[(p >> 16) & 255u];
+    }
+    else
+    {
+        r.x = (float)(p & 255u) / 255.0f; r.y = (float)((p >> 8) & 255u) / 255.0f; r.z = (float)((p >> 16) & 255u) / 255.0f;
+    }
+    r.w = (float)(p >> 24) / 255.0f;
+    return r;
+}
+
+PT_DEV f4 lerp4(f4 a, f4 b, float t)
+{
+    f4 r;
+    r.x = a.x * (1.0f - t) + b.x * t; r.y = a.y * (1.0f - t) + b.y * t; r.z = a.z * (1.0f - t) + b.z * t; r.w = a.w * (1.0f - t) + b.w * t;
+    return r;
+}
+
+PT_DEV uint32_t wrapRepeat(float x0, uint32_t n) // floor(x) mod n, in float: CPU and GPU agree for any finite x
+{
+    const float fn = (float)n;
+    float m = x0 - __builtin_floorf(x0 / fn) * fn;
+    if (!(m >= 0.0f)) m = 0.0f;
+    const uint32_t i = (uint32_t)m;
+    return i >= n ? n - 1 : i;
+}
+
+PT_DEV f4 sampleLevel(const TextureView &tv, const DevTexture &t, uint32_t level, float u, float v)
+{
+    const uint32_t w = levelDim(t.width, level), h = levelDim(t.height, level);
+    if (w == 1 && h == 1) // exact for 1x1 (hardware weights are fixed point and sum to 1)
+        return fetchTexel(tv, t, level, 0, 0);
+    if (!(abs_(u) < 1e9f)) u = 0.0f;
+    if (!(abs_(v) < 1e9f)) v = 0.0f;
+    const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    const float x0 = __builtin_floorf(x), y0 = __builtin_floorf(y);
+    const float ax = x - x0, ay = y - y0;
+    const uint32_t ix0 = wrapRepeat(x0, w), ix1 = wrapRepeat(x0 + 1.0f, w), iy0 = wrapRepeat(y0, h), iy1 = wrapRepeat(y0 + 1.0f, h);
+    const f4 top = lerp4(fetchTexel(tv, t, level, ix0, iy0), fetchTexel(tv, t, level, ix1, iy0), ax);
+    const f4 bot = lerp4(fetchTexel(tv, t, level, ix0, iy1), fetchTexel(tv, t, level, ix1, iy1), ax);
+    return lerp4(top, bot, ay);
+}
+
+// textureGrad: LOD from the gradients (Vulkan 1.3 spec 16.5.7, isotropic), trilinear
+PT_DEV f4 textureGradSample(const TextureView &tv, const DevTexture &t, float u, float v, float dudx, float dvdx, float dudy, float dvdy)
+{
+    if (t.levels <= 1)
+        return sampleLevel(tv, t, 0, u, v);
+    const float mux = dudx * (float)t.width, mvx = dvdx * (float)t.height;
+    const float muy = dudy * (float)t.width, mvy = dvdy * (float)t.height;
+    const float rx = sqrt_(mux * mux + mvx * mvx), ry = sqrt_(muy * muy + mvy * mvy);
+    const float rho = fmax_(rx, ry);
+    float lod = rho > 0.0f ? (float)log2_((double)rho) : 0.0f;
+    const float q = (float)(t.levels - 1);
+    if (!(lod >= 0.0f)) lod = 0.0f;
+    if (lod > q) lod = q;
+    const float d0 = __builtin_floorf(lod), f = lod - d0;
+    const uint32_t l0 = (uint32_t)d0, l1 = l0 + 1 < t.levels ? l0 + 1 : t.levels - 1;
+    const f4 c0 = sampleLevel(tv, t, l0, u, v);
+    if (f == 0.0f || l1 == l0)
+        return c0;
+    return lerp4(c0, sampleLevel(tv, t, l1, u, v), f);
+}
+
 // ---- material.glsl with the fixed 1x1 default textures ------------------------------------------
 
 // Texels of slots 0..8 after format decode (ShaderRendererTypes.incl:49-56; sRGB for

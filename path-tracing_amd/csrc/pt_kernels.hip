@@ -655,6 +655,58 @@ __global__ void k_unpack_shard(LaunchParams p, const float4 *__restrict__ src, f
     }
 }
 
+// ---- textures (row N1): sRGB table and the mip chain are produced on the device ------------------
+__global__ void k_build_srgb_lut(float *lut)
+{
+    const uint32_t c = threadIdx.x;
+    if (c < 256)
+        lut[c] = srgbToLinear((float)c / 255.0f);
+}
+
+// one level of the chain = linear blit of the previous one (Image.cpp:264-300): decode, bilinear at
+// the destination texel centre with clamp-to-edge, re-encode in the image format
+__global__ void k_generate_mip(TextureView tv, uint32_t textureIndex, uint32_t level, uint32_t *texels8, float4 *texelsF)
+{
+    const DevTexture t = tv.textures[textureIndex];
+    const uint32_t sw = levelDim(t.width, level - 1), sh = levelDim(t.height, level - 1);
+    const uint32_t dw = levelDim(t.width, level), dh = levelDim(t.height, level);
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= dw * dh)
+        return;
+    const uint32_t i = k % dw, j = k / dw;
+    const float x = ((float)i + 0.5f) * ((float)sw / (float)dw) - 0.5f, y = ((float)j + 0.5f) * ((float)sh / (float)dh) - 0.5f;
+    const float x0 = __builtin_floorf(x), y0 = __builtin_floorf(y), ax = x - x0, ay = y - y0;
+    const float cx0 = clamp_(x0, 0.0f, (float)(sw - 1)), cx1 = clamp_(x0 + 1.0f, 0.0f, (float)(sw - 1));
+    const float cy0 = clamp_(y0, 0.0f, (float)(sh - 1)), cy1 = clamp_(y0 + 1.0f, 0.0f, (float)(sh - 1));
+    const f4 top = lerp4(fetchTexel(tv, t, level - 1, (uint32_t)cx0, (uint32_t)cy0), fetchTexel(tv, t, level - 1, (uint32_t)cx1, (uint32_t)cy0), ax);
+    const f4 bot = lerp4(fetchTexel(tv, t, level - 1, (uint32_t)cx0, (uint32_t)cy1), fetchTexel(tv, t, level - 1, (uint32_t)cx1, (uint32_t)cy1), ax);
+    const f4 c = lerp4(top, bot, ay);
+    const size_t idx = (size_t)t.levelOffset[level] + (size_t)j * dw + i;
+    if (t.format == PTX_TEXTURE_RGBA32F)
+        texelsF[idx] = make_float4(c.x, c.y, c.z, c.w);
+    else if (t.format == PTX_TEXTURE_RGBA8_SRGB)
+        texels8[idx] = quantize8(linearToSrgb(c.x)) | quantize8(linearToSrgb(c.y)) << 8 | quantize8(linearToSrgb(c.z)) << 16 | quantize8(c.w) << 24;
+    else
+        texels8[idx] = quantize8(c.x) | quantize8(c.y) << 8 | quantize8(c.z) << 16 | quantize8(c.w) << 24;
+}
+
+__global__ void k_test_texture(TextureView tv, const float *__restrict__ in, float *__restrict__ out, uint32_t n, int implicitLod)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const float *a = in + (size_t)i * 7;
+    const uint32_t idx = __float_as_uint(a[0]);
+    f4 r;
+    r.x = r.y = r.z = r.w = 1.0f;
+    if (idx >= PTX_SCENE_TEXTURE_OFFSET && idx - PTX_SCENE_TEXTURE_OFFSET < tv.textureCount)
+    {
+        const DevTexture t = tv.textures[idx - PTX_SCENE_TEXTURE_OFFSET];
+        r = implicitLod ? sampleLevel(tv, t, 0, a[1], a[2]) : textureGradSample(tv, t, a[1], a[2], a[3], a[4], a[5], a[6]);
+    }
+    out[i * 4] = r.x; out[i * 4 + 1] = r.y; out[i * 4 + 2] = r.z; out[i * 4 + 3] = r.w;
+}
+
 // function-level entry (Path-Tracing-Tests/TestRenderer.cpp:79-105 dispatches a compute
 // shader that calls the production functions; packing documented in include/ptx.h)
 __constant__ int c_inStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4 };
@@ -910,6 +962,11 @@ struct PtxRenderer
     DevBuf<DevPair> pairs;
     DevBuf<uint32_t> pairFirst;
     DevBuf<PtxLightsUbo> lights;
+    DevBuf<DevTexture> textures;
+    DevBuf<uint32_t> texels8;
+    DevBuf<float4> texelsF;
+    DevBuf<float> srgbLut;
+    uint32_t textureCount = 0;
     uint32_t pairCount = 0, triCount = 0, dxNormalTextures = 0;
     bool sceneReady = false, accelReady = false;
 
@@ -1087,6 +1144,7 @@ void ptx_destroy(PtxRenderer *r)
     (void)hipSetDevice(r->device);
     if (r->stream)
         (void)hipStreamSynchronize(r->stream);
+    r->textures.release(); r->texels8.release(); r->texelsF.release(); r->srgbLut.release();
     r->vertices.release(); r->indices.release(); r->mr.release(); r->sg.release(); r->phong.release();
     r->pairs.release(); r->pairFirst.release(); r->lights.release(); r->nodes.release(); r->tris.release();
     r->image.release(); r->rayO.release(); r->rayD.release(); r->thr.release(); r->rad.release(); r->hit.release();
@@ -1263,6 +1321,64 @@ int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *s)
     if ((rc = upload(r, r->phong, s->phongMaterials, s->phongMaterialCount)) != PTX_OK) return rc;
     if ((rc = upload(r, r->pairs, pairs.data(), pairs.size())) != PTX_OK) return rc;
     if ((rc = upload(r, r->pairFirst, pairFirst.data(), pairFirst.size())) != PTX_OK) return rc;
+    // textures (row N1): level 0 to the pools, then the mip chain level by level on the device
+    {
+        HIP_TRY(r, r->srgbLut.alloc(256));
+        k_build_srgb_lut<<<1, 256, 0, r->stream>>>(r->srgbLut.p);
+        r->textureCount = s->textures ? s->textureCount : 0;
+        std::vector<DevTexture> table(r->textureCount);
+        size_t n8 = 0, nf = 0;
+        for (uint32_t i = 0; i < r->textureCount; i++)
+        {
+            const PtxTextureDesc &d = s->textures[i];
+            DevTexture &t = table[i];
+            if (d.format > PTX_TEXTURE_RGBA32F)
+                return fail(r, PTX_ERROR_INVALID_ARGUMENT, "texture %u: unknown format %u", i, d.format);
+            t.width = d.width ? d.width : 1;
+            t.height = d.height ? d.height : 1;
+            t.format = d.format;
+            uint32_t m = t.width > t.height ? t.width : t.height, levels = 1;
+            while (m > 1) { m >>= 1; levels++; } // floor(log2(max)) + 1, Image.cpp:14-17
+            t.levels = levels > 16 ? 16 : levels;
+            size_t &cursor = t.format == PTX_TEXTURE_RGBA32F ? nf : n8;
+            for (uint32_t l = 0; l < t.levels; l++)
+            {
+                if (cursor > 0xffffffffull)
+                    return fail(r, PTX_ERROR_INVALID_ARGUMENT, "texture pool exceeds 2^32 texels");
+                t.levelOffset[l] = (uint32_t)cursor;
+                const uint32_t lw = t.width >> l ? t.width >> l : 1, lh = t.height >> l ? t.height >> l : 1;
+                cursor += (size_t)lw * lh;
+            }
+        }
+        HIP_TRY(r, r->textures.alloc(r->textureCount));
+        HIP_TRY(r, r->texels8.alloc(n8));
+        HIP_TRY(r, r->texelsF.alloc(nf));
+        if (r->textureCount)
+            HIP_TRY(r, hipMemcpyAsync(r->textures.p, table.data(), table.size() * sizeof(DevTexture), hipMemcpyHostToDevice, r->stream));
+        TextureView tv;
+        tv.textures = r->textures.p; tv.textureCount = r->textureCount; tv.texels8 = r->texels8.p; tv.texelsF = r->texelsF.p;
+        tv.srgbLut = r->srgbLut.p;
+        for (uint32_t i = 0; i < r->textureCount; i++)
+        {
+            const PtxTextureDesc &d = s->textures[i];
+            const DevTexture &t = table[i];
+            const size_t n0 = (size_t)t.width * t.height;
+            if (d.data)
+            {
+                if (t.format == PTX_TEXTURE_RGBA32F)
+                    HIP_TRY(r, hipMemcpyAsync(r->texelsF.p + t.levelOffset[0], d.data, n0 * 16, hipMemcpyHostToDevice, r->stream));
+                else
+                    HIP_TRY(r, hipMemcpyAsync(r->texels8.p + t.levelOffset[0], d.data, n0 * 4, hipMemcpyHostToDevice, r->stream));
+            }
+            for (uint32_t l = 1; l < t.levels; l++)
+            {
+                const uint32_t lw = t.width >> l ? t.width >> l : 1, lh = t.height >> l ? t.height >> l : 1;
+                k_generate_mip<<<(lw * lh + 255) / 256, 256, 0, r->stream>>>(tv, i, l, r->texels8.p, r->texelsF.p);
+            }
+        }
+        HIP_TRY(r, hipStreamSynchronize(r->stream)); // `table` and the caller's texel arrays may go away
+        HIP_TRY(r, hipGetLastError());
+    }
     HIP_TRY(r, hipStreamSynchronize(r->stream)); // the host vectors above go out of scope
     r->sceneReady = true;
     r->stats.triangles = tri;
@@ -1870,6 +1986,28 @@ int ptx_test_eval(PtxRenderer *r, uint32_t fn, const float *in, float *out, uint
     HIP_TRY(r, hipMemsetAsync(r->testOut.p, 0, no * 4, r->stream));
     k_test_eval<<<(n + 63) / 64, 64, 0, r->stream>>>(fn, r->testIn.p, r->testOut.p, n, r->testUbo.p);
     HIP_TRY(r, hipMemcpyAsync(out, r->testOut.p, no * 4, hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(r, hipStreamSynchronize(r->stream));
+    HIP_TRY(r, hipGetLastError());
+    return PTX_OK;
+}
+
+int ptx_test_texture(PtxRenderer *r, const float *in, float *out, uint32_t n, int implicitLod)
+{
+    if (!r || !in || !out)
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_test_texture: null argument");
+    if (!r->sceneReady)
+        return fail(r, PTX_ERROR_NOT_READY, "ptx_test_texture: no scene uploaded");
+    if (!n)
+        return PTX_OK;
+    HIP_TRY(r, hipSetDevice(r->device));
+    HIP_TRY(r, r->testIn.alloc((size_t)n * 7));
+    HIP_TRY(r, r->testOut.alloc((size_t)n * 4));
+    HIP_TRY(r, hipMemcpyAsync(r->testIn.p, in, (size_t)n * 28, hipMemcpyHostToDevice, r->stream));
+    TextureView tv;
+    tv.textures = r->textures.p; tv.textureCount = r->textureCount; tv.texels8 = r->texels8.p; tv.texelsF = r->texelsF.p;
+    tv.srgbLut = r->srgbLut.p;
+    k_test_texture<<<(n + 63) / 64, 64, 0, r->stream>>>(tv, r->testIn.p, r->testOut.p, n, implicitLod);
+    HIP_TRY(r, hipMemcpyAsync(out, r->testOut.p, (size_t)n * 16, hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(r, hipStreamSynchronize(r->stream));
     HIP_TRY(r, hipGetLastError());
     return PTX_OK;

@@ -335,10 +335,10 @@ void CreateDefaultScene(SceneBuilder &sceneBuilder)
 {
     const Shaders::MetallicRoughnessMaterial defaultMaterialInfo = DefaultMaterialInfo();
 
-    const uint32_t logoColorTexture = sceneBuilder.AddTexture({ TextureType::Color, 1, 1, "Logo Color Texture" });
-    const uint32_t vulkanPathTracingTexture = sceneBuilder.AddTexture({ TextureType::Color, 1, 1, "Vulkan Path-Tracing Texture" });
-    const uint32_t authorsTexture = sceneBuilder.AddTexture({ TextureType::Color, 1, 1, "Authors Texture" });
-    const uint32_t pressSpaceTexture = sceneBuilder.AddTexture({ TextureType::Color, 1, 1, "Press Space Texture" });
+    const uint32_t logoColorTexture = sceneBuilder.AddTexture({ TextureType::Color, 1, 1, "Logo Color Texture", TextureFormat::RGBAU8, {} });
+    const uint32_t vulkanPathTracingTexture = sceneBuilder.AddTexture({ TextureType::Color, 1, 1, "Vulkan Path-Tracing Texture", TextureFormat::RGBAU8, {} });
+    const uint32_t authorsTexture = sceneBuilder.AddTexture({ TextureType::Color, 1, 1, "Authors Texture", TextureFormat::RGBAU8, {} });
+    const uint32_t pressSpaceTexture = sceneBuilder.AddTexture({ TextureType::Color, 1, 1, "Press Space Texture", TextureFormat::RGBAU8, {} });
 
     auto whiteMaterialInfo = defaultMaterialInfo;
     auto greenMaterialInfo = defaultMaterialInfo;
@@ -896,8 +896,129 @@ void CreateStreetLikeScene(SceneBuilder &sb, float detail, uint32_t seed)
 }
 
 // ---------------------------------------------------------------------------
+// Procedural textures (row N1): there is no image decoder in this tree yet (N2), so textured
+// test content is generated.  TextureImporter.cpp:24-51: texels with alpha 0 get rgb 0.
+// ---------------------------------------------------------------------------
 
-const char *const kSceneNames = "default,roughness_cubes,attenuation_blob,chess_like,temple_like,atrium_like,street_like";
+TextureInfo MakeTexture(TextureType type, const std::string &name, uint32_t w, uint32_t h,
+                        const std::function<void(uint32_t, uint32_t, uint8_t *)> &texel)
+{
+    TextureInfo t;
+    t.Type = type;
+    t.Width = w;
+    t.Height = h;
+    t.Name = name;
+    t.Format = TextureFormat::RGBAU8;
+    t.Pixels.resize(static_cast<size_t>(w) * h * 4);
+    for (uint32_t y = 0; y < h; y++)
+        for (uint32_t x = 0; x < w; x++)
+        {
+            uint8_t *p = &t.Pixels[(static_cast<size_t>(y) * w + x) * 4];
+            texel(x, y, p);
+            if (p[3] == 0)
+                p[0] = p[1] = p[2] = 0;
+        }
+    return t;
+}
+
+uint32_t HashU(uint32_t x, uint32_t y, uint32_t seed)
+{
+    uint32_t h = x * 374761393u + y * 668265263u + seed * 2246822519u;
+    h = (h ^ (h >> 13)) * 1274126177u;
+    return h ^ (h >> 16);
+}
+
+// small scene that exercises the sampler: square / non-square / non-power-of-two sizes, sRGB and
+// UNORM types, a float texture, tiled and magnified uv ranges
+void CreateTextureTestScene(SceneBuilder &sb, uint32_t seed)
+{
+    const uint32_t checker = sb.AddTexture(MakeTexture(TextureType::Color, "Checker", 64, 64, [](uint32_t x, uint32_t y, uint8_t *p) {
+        const bool on = ((x / 8) + (y / 8)) & 1;
+        p[0] = on ? 230 : 30; p[1] = on ? 200 : 40; p[2] = on ? 60 : 150; p[3] = 255;
+    }));
+    const uint32_t noise = sb.AddTexture(MakeTexture(TextureType::Color, "Noise", 37, 21, [seed](uint32_t x, uint32_t y, uint8_t *p) {
+        const uint32_t h = HashU(x, y, seed);
+        p[0] = h & 255; p[1] = (h >> 8) & 255; p[2] = (h >> 16) & 255; p[3] = 255;
+    }));
+    const uint32_t rough = sb.AddTexture(MakeTexture(TextureType::Roughness, "Roughness Stripes", 128, 8, [](uint32_t x, uint32_t, uint8_t *p) {
+        p[0] = 0; p[1] = static_cast<uint8_t>(40 + (x * 200) / 127); p[2] = 0; p[3] = 255;
+    }));
+    const uint32_t metal = sb.AddTexture(MakeTexture(TextureType::Metallic, "Metal Dots", 32, 32, [](uint32_t x, uint32_t y, uint8_t *p) {
+        const int dx = static_cast<int>(x % 16) - 8, dy = static_cast<int>(y % 16) - 8;
+        p[0] = p[1] = 0; p[2] = (dx * dx + dy * dy < 30) ? 255 : 0; p[3] = 255;
+    }));
+    const uint32_t bump = sb.AddTexture(MakeTexture(TextureType::Normal, "Bumps", 64, 64, [](uint32_t x, uint32_t y, uint8_t *p) {
+        const float fx = std::sin(static_cast<float>(x) * 0.3927f), fy = std::sin(static_cast<float>(y) * 0.3927f);
+        p[0] = static_cast<uint8_t>(128.0f + 90.0f * fx); p[1] = static_cast<uint8_t>(128.0f + 90.0f * fy); p[2] = 255; p[3] = 255;
+    }));
+    const uint32_t glow = sb.AddTexture(MakeTexture(TextureType::Emisive, "Glow Grid", 16, 16, [](uint32_t x, uint32_t y, uint8_t *p) {
+        const bool on = (x % 4 == 0) || (y % 4 == 0);
+        p[0] = on ? 255 : 0; p[1] = on ? 120 : 0; p[2] = on ? 30 : 0; p[3] = 255;
+    }));
+    TextureInfo hdr; // RGBA32F
+    hdr.Type = TextureType::Color;
+    hdr.Name = "Float Ramp";
+    hdr.Width = 16;
+    hdr.Height = 4;
+    hdr.Format = TextureFormat::RGBAF32;
+    hdr.Pixels.resize(16 * 4 * 16);
+    for (uint32_t y = 0; y < 4; y++)
+        for (uint32_t x = 0; x < 16; x++)
+        {
+            const float v[4] = { 0.05f + 0.06f * static_cast<float>(x), 0.2f + 0.2f * static_cast<float>(y), 0.9f - 0.05f * static_cast<float>(x), 1.0f };
+            std::memcpy(&hdr.Pixels[(static_cast<size_t>(y) * 16 + x) * 16], v, 16);
+        }
+    const uint32_t ramp = sb.AddTexture(std::move(hdr));
+
+    auto textured = [&](const char *name, uint32_t colorIdx, float roughness, float metalness) {
+        auto m = MakeMaterial(Vec3(1.0f), roughness, metalness);
+        m.ColorIdx = colorIdx;
+        return sb.AddMaterial(name, m);
+    };
+    const auto floorMat = textured("Checker Floor", checker, 0.9f, 0.0f);
+    const auto noiseMat = textured("Noise", noise, 0.6f, 0.0f);
+    const auto rampMat = textured("Ramp", ramp, 0.4f, 0.0f);
+    auto pbr = MakeMaterial(Vec3(0.9f, 0.85f, 0.8f), 1.0f, 1.0f);
+    pbr.RoughnessIdx = rough;
+    pbr.MetallicIdx = metal;
+    pbr.NormalIdx = bump;
+    const auto pbrMat = sb.AddMaterial("PBR Maps", pbr);
+    auto lamp = MakeMaterial(Vec3(0.2f), 0.8f, 0.0f);
+    lamp.EmissiveIdx = glow;
+    lamp.EmissiveIntensity = 4.0f;
+    const auto lampMat = sb.AddMaterial("Lamp", lamp);
+
+    // floor: uv tiled 6x (minification at the far end), built as a grid so uv varies per vertex
+    const uint32_t floor = AddGridSurface(sb, 8, 8, false, [](float u, float v) { return Vec3(-6.0f + 12.0f * u, 0.0f, -6.0f + 12.0f * v); }, true);
+    {
+        auto &vertices = sb.GetVertices();
+        for (size_t k = vertices.size() - 81; k < vertices.size(); k++)
+        {
+            vertices[k].TexCoords[0] *= 6.0f;
+            vertices[k].TexCoords[1] *= 6.0f;
+        }
+    }
+    const std::array<uint32_t, 6> cube = AddCube(sb);
+    const uint32_t root = sb.AddSceneNode({ 0u, Mat4::Identity(), Mat4::Identity() });
+    const std::array<MeshInfo, 1> floorMesh = { MI(floor, floorMat) };
+    sb.AddModelInstance(sb.AddModel(floorMesh), root);
+    const Shaders::MaterialId mats[4] = { noiseMat, rampMat, pbrMat, lampMat };
+    for (int i = 0; i < 4; i++)
+    {
+        std::array<MeshInfo, 6> meshes;
+        for (int k = 0; k < 6; k++)
+            meshes[k] = MI(cube[k], mats[i]);
+        const uint32_t model = sb.AddModel(meshes);
+        const Mat4 t = Scale(Rotate(Translate(Mat4::Identity(), Vec3(-3.0f + 2.0f * static_cast<float>(i), 0.6f, 0.5f * static_cast<float>(i & 1))), 0.4f * static_cast<float>(i), Vec3(0, 1, 0)), Vec3(0.6f));
+        sb.AddModelInstance(model, sb.AddSceneNode({ root, t, Mat4::Identity() }));
+    }
+    sb.AddLight(MakePointLight(Vec3(6.0f, 6.0f, 6.0f), Vec3(0.0f, 4.0f, -2.0f)), root);
+    AddViewCamera(sb, Vec3(0.0f, 2.2f, -6.5f), Vec3(0.0f, 0.4f, 0.0f));
+}
+
+// ---------------------------------------------------------------------------
+
+const char *const kSceneNames = "default,roughness_cubes,attenuation_blob,chess_like,temple_like,atrium_like,street_like,texture_test";
 
 const char *GetSceneNames()
 {
@@ -928,6 +1049,8 @@ std::shared_ptr<Scene> CreateScene(const std::string &name, float detail, uint32
         CreateAtriumLikeScene(sb, detail, seed ? seed : 4);
     else if (name == "street_like")
         CreateStreetLikeScene(sb, detail, seed ? seed : 5);
+    else if (name == "texture_test")
+        CreateTextureTestScene(sb, seed ? seed : 6);
     else
         throw error("Unknown scene: " + name);
     auto scene = sb.CreateSceneShared(name);

@@ -19,6 +19,7 @@ void CreateChessLikeScene(SceneBuilder &sceneBuilder, float detail, uint32_t see
 void CreateTempleLikeScene(SceneBuilder &sceneBuilder, float detail, uint32_t seed);
 void CreateAtriumLikeScene(SceneBuilder &sceneBuilder, float detail, uint32_t seed);
 void CreateStreetLikeScene(SceneBuilder &sceneBuilder, float detail, uint32_t seed);
+void CreateTextureTestScene(SceneBuilder &sceneBuilder, uint32_t seed); // sampler test content (row N1)
 
 const char *GetSceneNames();
 std::shared_ptr<Scene> CreateScene(const std::string &name, float detail, uint32_t seed);

@@ -146,6 +146,29 @@ PtxSceneDesc Scene::GetDesc() const
     d.modelCount = static_cast<uint32_t>(m_ModelRanges.size());
     d.instances = m_InstanceRecords.data();
     d.instanceCount = static_cast<uint32_t>(m_InstanceRecords.size());
+    // TextureUploader::GetImageFormat (TextureUploader.cpp:571-594): colour-like types are sRGB
+    m_TextureRecords.resize(m_Textures.size());
+    for (size_t i = 0; i < m_Textures.size(); i++)
+    {
+        const TextureInfo &t = m_Textures[i];
+        const bool isColor = t.Type == TextureType::Color || t.Type == TextureType::Specular || t.Type == TextureType::Emisive ||
+                             t.Type == TextureType::Skybox;
+        PtxTextureDesc &rec = m_TextureRecords[i];
+        rec.width = t.Width;
+        rec.height = t.Height;
+        rec.format = t.Format == TextureFormat::RGBAF32 ? PTX_TEXTURE_RGBA32F : (isColor ? PTX_TEXTURE_RGBA8_SRGB : PTX_TEXTURE_RGBA8_UNORM);
+        rec.reserved = 0;
+        rec.data = t.Pixels.empty() ? nullptr : t.Pixels.data();
+        if (t.Pixels.empty()) // no data: a 1x1 white placeholder
+        {
+            rec.width = rec.height = 1;
+            static const uint32_t white = 0xffffffffu;
+            rec.format = PTX_TEXTURE_RGBA8_UNORM;
+            rec.data = &white;
+        }
+    }
+    d.textures = m_TextureRecords.data();
+    d.textureCount = static_cast<uint32_t>(m_TextureRecords.size());
     d.skyboxKind = PTX_SKYBOX_CLEAR_COLOR;
     d.dxNormalTextures = m_HasDxNormalTextures ? 1u : 0u;
     return d;

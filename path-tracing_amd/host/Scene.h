@@ -65,12 +65,24 @@ enum class TextureType : uint8_t
     Skybox,
 };
 
-// Scene.h:48-59, descriptor only
+// Scene.h:35-42 (the block-compressed formats arrive with the importer, row N2)
+enum class TextureFormat : uint8_t
+{
+    RGBAU8,
+    RGBAF32,
+};
+
+// Scene.h:48-59.  The reference keeps a file / memory source and decodes on a loader thread
+// (TextureImporter.cpp); here the decoded level-0 texels ride along.  An empty Pixels vector is a
+// texture whose data is not available: it samples as the white placeholder, which is what the
+// reference shows until a texture has finished loading (Renderer.cpp:421-429).
 struct TextureInfo
 {
     TextureType Type;
     uint32_t Width = 1, Height = 1;
     std::string Name;
+    TextureFormat Format = TextureFormat::RGBAU8;
+    std::vector<uint8_t> Pixels; // RGBAU8: 4 bytes per texel; RGBAF32: 16 bytes per texel
 };
 
 using Geometry = PtxGeometry; // Scene.h:63-71
@@ -219,6 +231,7 @@ private:
     std::vector<PtxMeshRecord> m_MeshRecords;
     std::vector<PtxModel> m_ModelRanges;
     mutable std::vector<PtxModelInstance> m_InstanceRecords;
+    mutable std::vector<PtxTextureDesc> m_TextureRecords;
 
     // Scene.h:259-260
     InputCamera m_InputCamera = InputCamera(45.0f, 100.0f, 0.1f, Vec3(3.0f, 1.0f, 0.0f), Vec3(-1.0f, 0.0f, 0.0f));

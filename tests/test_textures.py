@@ -1,0 +1,102 @@
+"""Row N1, stage 1: the software sampler (textureGrad / texture()), mip generation and texture
+formats.  The Vulkan sampler's filtering is implementation-defined, so parity here is HIP vs the
+oracle (bit-exact, same fixed arithmetic) plus analytic properties of the oracle itself."""
+import numpy as np
+import pytest
+
+CHECKER, NOISE, ROUGH, METAL, BUMP, GLOW, RAMP = range(9, 16)
+
+
+def _inputs(idx, u, v, dudx=0.0, dvdx=0.0, dudy=0.0, dvdy=0.0):
+    a = np.zeros((len(u), 7), np.float32)
+    a.view(np.uint32)[:, 0] = idx
+    a[:, 1], a[:, 2], a[:, 3], a[:, 4], a[:, 5], a[:, 6] = u, v, dudx, dvdx, dudy, dvdy
+    return a
+
+
+def _srgb_to_linear(c8):
+    c = np.asarray(c8, np.float64) / 255.0
+    return np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+
+
+def test_texture_descs_follow_reference_format_rule(pkg):
+    import ctypes as C
+
+    class TextureDesc(C.Structure):
+        _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("format", C.c_uint32), ("reserved", C.c_uint32), ("data", C.c_void_p)]
+
+    s = pkg.Scene("texture_test")
+    d = s.desc
+    assert d.textureCount == 7
+    t = (TextureDesc * d.textureCount).from_address(d.textures)
+    # TextureUploader.cpp:571-594: Color / Emissive -> sRGB, Roughness / Metallic / Normal -> UNORM, RGBAF32 as is
+    assert [x.format for x in t] == [1, 1, 0, 0, 0, 1, 2]
+    assert (t[1].width, t[1].height) == (37, 21) and (t[2].width, t[2].height) == (128, 8)
+    # a scene whose texel data is unavailable still presents 1x1 placeholders (default scene's embedded PNGs)
+    s0 = pkg.Scene("default")  # keep alive: the desc points into it
+    d0 = s0.desc
+    t0 = (TextureDesc * d0.textureCount).from_address(d0.textures)
+    assert d0.textureCount == 4 and all((x.width, x.height) == (1, 1) for x in t0)
+
+
+def test_oracle_sampler_properties(pkg, orc):
+    s = pkg.Scene("texture_test")
+    osc = orc.OracleScene(s.desc, build_bvh=False)
+    # texel centres of the checker at LOD 0: exactly the decoded sRGB texel
+    xs = np.array([0, 7, 8, 15, 63], np.float32)
+    u = (xs + 0.5) / 64
+    out = osc.test_texture(_inputs(CHECKER, u, np.full_like(u, 0.5 / 64))).view(np.float32)
+    on = ((xs // 8).astype(int) + 0) & 1
+    expect = np.where(on[:, None] == 1, _srgb_to_linear([230, 200, 60]), _srgb_to_linear([30, 40, 150]))
+    assert np.abs(out[:, :3] - expect).max() < 2e-7 and (out[:, 3] == 1).all()
+    # repeat addressing: whole-number shifts of uv hit the same texel
+    a = osc.test_texture(_inputs(CHECKER, u, u))
+    b = osc.test_texture(_inputs(CHECKER, u + 1, u - 3))
+    assert (a == b).all()
+    # texture() at implicit LOD 0 == textureGrad with zero gradients
+    rng = np.random.default_rng(2)
+    uv = rng.uniform(-2, 3, (500, 2)).astype(np.float32)
+    for idx in (CHECKER, NOISE, ROUGH, RAMP):
+        g = osc.test_texture(_inputs(idx, uv[:, 0], uv[:, 1]))
+        t = osc.test_texture(_inputs(idx, uv[:, 0], uv[:, 1]), implicit_lod=True)
+        assert (g == t).all()
+    # bilinear results stay inside the range of the texture and the filter is continuous
+    n = osc.test_texture(_inputs(NOISE, uv[:, 0], uv[:, 1])).view(np.float32)
+    assert (n >= 0).all() and (n <= 1).all()
+    # huge footprint -> the 1x1 top level = (approximately) the average colour of the checker
+    top = osc.test_texture(_inputs(CHECKER, u, u, dudx=8.0, dvdy=8.0)).view(np.float32)
+    mean = 0.5 * (_srgb_to_linear([230, 200, 60]) + _srgb_to_linear([30, 40, 150]))
+    assert np.abs(top[:, :3] - mean).max() < 0.02
+    # trilinear: the LOD grows monotonically with the footprint (less contrast), NaN / inf gradients are safe
+    c = [osc.test_texture(_inputs(CHECKER, u[:1], u[:1], dudx=g, dvdy=g)).view(np.float32)[0, 0] for g in (1e-4, 0.05, 0.2, 1.0)]
+    assert c[0] <= c[1] <= c[2] <= c[3] + 1e-6  # texel (0,0) is the dark colour: blends towards the mean
+    bad = osc.test_texture(_inputs(CHECKER, u, u, dudx=np.nan, dvdy=np.inf)).view(np.float32)
+    assert np.isfinite(bad).all()
+    # the float texture passes through untouched at texel centres
+    r = osc.test_texture(_inputs(RAMP, np.float32([(3 + 0.5) / 16]), np.float32([(2 + 0.5) / 4]))).view(np.float32)[0]
+    assert np.allclose(r, [0.05 + 0.06 * 3, 0.2 + 0.2 * 2, 0.9 - 0.05 * 3, 1.0], atol=1e-6)
+    # indices outside the table (and the fixed slots) are the white placeholder here
+    w = osc.test_texture(_inputs(200, u, u)).view(np.float32)
+    assert (w == 1).all()
+
+
+@pytest.mark.gpu
+def test_sampler_matches_oracle_bitexact(pkg, orc, gpu_renderer):
+    s = pkg.Scene("texture_test")
+    gpu_renderer.upload(s)
+    osc = orc.OracleScene(s.desc, build_bvh=False)
+    rng = np.random.default_rng(5)
+    n = 20000
+    idx = rng.integers(9, 17, n).astype(np.uint32)  # includes one index past the table
+    uv = rng.uniform(-2.5, 3.5, (n, 2)).astype(np.float32)
+    g = (10.0 ** rng.uniform(-5, 0.5, (n, 4)) * rng.choice([-1, 1], (n, 4))).astype(np.float32)
+    g[:50] = 0
+    g[50:60, 0] = np.nan
+    g[60:70, 3] = np.inf
+    uv[70:80, 0] = np.nan
+    uv[80:90, 1] = 1e30
+    inp = _inputs(idx, uv[:, 0], uv[:, 1], g[:, 0], g[:, 1], g[:, 2], g[:, 3])
+    for implicit in (False, True):
+        a = gpu_renderer.test_texture(inp, implicit)
+        b = osc.test_texture(inp, implicit)
+        assert (a == b).all(), f"{int((a != b).any(axis=1).sum())} samples differ (implicit={implicit})"
