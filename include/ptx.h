@@ -407,13 +407,13 @@ typedef enum PtxTestFunction {
     PTX_FN_COS_HEMISPHERE = 13,     /* in: u.xy                    out: d.xyz                   */
     PTX_FN_TANGENT_SPACE = 14,      /* in: n.xyz                   out: 9 (columns T,B,N)       */
     PTX_FN_OFFSET_SELF_INTERSECTION = 15, /* in: origin.xyz normal.xyz  out: p.xyz              */
-    PTX_FN_PRIMARY_RAY = 16,        /* in: px py w h u.xy + 32 matrix floats (38)  out: o.xyz d.xyz */
+    PTX_FN_PRIMARY_RAY = 16,        /* in: px py w h u.xy + 32 matrix floats (38)  out: o d rx.o rx.d ry.o ry.d (18) */
     PTX_FN_SINCOS = 17,             /* in: x                       out: sin, cos                */
     PTX_FN_POW = 18,                /* in: x, y                    out: pow(x, y)               */
     PTX_FN_SAMPLE_LIGHT = 19,       /* in: u.xyz pos.xyz count(u32) dirColor dirDir 2x(color pos att) (31)
                                        out: dir.xyz dist color.xyz atten pdf (9)                 */
     PTX_FN_SHADOW_TERMINATOR = 20,  /* in: P, (P,N)x3, bary.xyz, isRefracted (25)  out: origin.xyz */
-    PTX_FN_PRIMARY_RAY_LENS = 21,   /* in: px py w h u.xy u2.xy lensRadius focalDistance + 32 (42) out: o d */
+    PTX_FN_PRIMARY_RAY_LENS = 21,   /* in: px py w h u.xy u2.xy lensRadius focalDistance + 32 (42) out: as 16 (18) */
     /* tracing.glsl (ray differentials -> texture footprint) */
     PTX_FN_DPN_DUV = 22,            /* in: (P,N,uv)x3 (24), vertex T,B (6) = 30   out: dpdu dpdv dndu dndv (12)  */
     PTX_FN_DP_DXY = 23,             /* in: p o d rxO rxD ryO ryD n (24)           out: dpdx dpdy (6)             */

@@ -361,59 +361,91 @@ typedef struct Ray
     float tmax;
 } Ray;
 
-/* ray.glsl:58-85 (pinhole).  rx/ry offset rays feed only textureGrad and are not
- * produced here. */
-static inline Ray constructPrimaryRay(uint32_t px, uint32_t py, uint32_t resX, uint32_t resY, const float *ViewInverse,
-                                      const float *ProjInverse, v2 u)
+/* direction through pixel-centre coordinates (pcx, pcy): ray.glsl:64-65,72-73 */
+static inline v3 pinholeDirection(float pcx, float pcy, uint32_t resX, uint32_t resY, const float *ViewInverse, const float *ProjInverse)
 {
-    const float pcx = (float)px + u.x;
-    const float pcy = (float)py + u.y;
     const float inUVx = pcx / (float)resX;
     const float inUVy = pcy / (float)resY;
     const float dx = inUVx * 2.0f - 1.0f;
     const float dy = inUVy * 2.0f - 1.0f;
-
-    const v4 origin = m4_mul(ViewInverse, 0, 0, 0, 1);
     const v4 target = m4_mul(ProjInverse, dx, dy, 1, 1);
     const v3 nt = v_normalize(V3(target.x, target.y, target.z));
     const v4 direction = m4_mul(ViewInverse, nt.x, nt.y, nt.z, 0);
-
-    Ray r;
-    r.Origin = V3(origin.x, origin.y, origin.z);
-    r.tmin = 0.00001f;
-    r.Direction = V3(direction.x, direction.y, direction.z);
-    r.tmax = 10000.0f;
-    return r;
+    return V3(direction.x, direction.y, direction.z);
 }
 
-/* ray.glsl:16-56 (thin lens) */
-static inline Ray constructPrimaryRayLens(uint32_t px, uint32_t py, uint32_t resX, uint32_t resY,
-                                          const float *ViewInverse, const float *ProjInverse, v2 u, v2 u2,
-                                          float lensRadius, float focalDistance)
+/* ray.glsl:58-85 (pinhole); rx / ry are the rays through the pixels one to the right / below */
+static inline Ray constructPrimaryRayD(uint32_t px, uint32_t py, uint32_t resX, uint32_t resY, const float *ViewInverse,
+                                       const float *ProjInverse, v2 u, Ray *rx, Ray *ry)
 {
     const float pcx = (float)px + u.x;
     const float pcy = (float)py + u.y;
-    const v2 disk = sampleUniformDiskConcentric(u2);
-    const v2 pLens = { lensRadius * disk.x, lensRadius * disk.y };
+    const v4 origin = m4_mul(ViewInverse, 0, 0, 0, 1);
+    Ray r;
+    r.Origin = V3(origin.x, origin.y, origin.z);
+    r.tmin = 0.00001f;
+    r.Direction = pinholeDirection(pcx, pcy, resX, resY, ViewInverse, ProjInverse);
+    r.tmax = 10000.0f;
+    if (rx)
+    {
+        *rx = r;
+        rx->Direction = pinholeDirection(pcx + 1.0f, pcy + 0.0f, resX, resY, ViewInverse, ProjInverse);
+        *ry = r;
+        ry->Direction = pinholeDirection(pcx + 0.0f, pcy + 1.0f, resX, resY, ViewInverse, ProjInverse);
+    }
+    return r;
+}
+static inline Ray constructPrimaryRay(uint32_t px, uint32_t py, uint32_t resX, uint32_t resY, const float *ViewInverse,
+                                      const float *ProjInverse, v2 u)
+{
+    return constructPrimaryRayD(px, py, resX, resY, ViewInverse, ProjInverse, u, NULL, NULL);
+}
+
+/* thin-lens direction through (pcx, pcy): ray.glsl:24-25,35-38 */
+static inline v3 lensDirection(float pcx, float pcy, uint32_t resX, uint32_t resY, const float *ViewInverse, const float *ProjInverse,
+                               v3 originCameraSpace, float focalDistance)
+{
     const float inUVx = pcx / (float)resX;
     const float inUVy = pcy / (float)resY;
     const float dx = inUVx * 2.0f - 1.0f;
     const float dy = inUVy * 2.0f - 1.0f;
-
-    const v3 originCameraSpace = V3(pLens.x, pLens.y, 0);
-    const v4 origin = m4_mul(ViewInverse, originCameraSpace.x, originCameraSpace.y, originCameraSpace.z, 1);
     const v4 target = m4_mul(ProjInverse, dx, dy, 1, 1);
     const float ft = focalDistance / target.z;
     const v3 pFocus = v_scale(V3(target.x, target.y, target.z), ft);
     const v3 nd = v_normalize(v_sub(pFocus, originCameraSpace));
     const v4 direction = m4_mul(ViewInverse, nd.x, nd.y, nd.z, 0);
+    return V3(direction.x, direction.y, direction.z);
+}
 
+/* ray.glsl:16-56 (thin lens) */
+static inline Ray constructPrimaryRayLensD(uint32_t px, uint32_t py, uint32_t resX, uint32_t resY, const float *ViewInverse,
+                                           const float *ProjInverse, v2 u, v2 u2, float lensRadius, float focalDistance, Ray *rx,
+                                           Ray *ry)
+{
+    const float pcx = (float)px + u.x;
+    const float pcy = (float)py + u.y;
+    const v2 disk = sampleUniformDiskConcentric(u2);
+    const v2 pLens = { lensRadius * disk.x, lensRadius * disk.y };
+    const v3 originCameraSpace = V3(pLens.x, pLens.y, 0);
+    const v4 origin = m4_mul(ViewInverse, originCameraSpace.x, originCameraSpace.y, originCameraSpace.z, 1);
     Ray r;
     r.Origin = V3(origin.x, origin.y, origin.z);
     r.tmin = 0.00001f;
-    r.Direction = V3(direction.x, direction.y, direction.z);
+    r.Direction = lensDirection(pcx, pcy, resX, resY, ViewInverse, ProjInverse, originCameraSpace, focalDistance);
     r.tmax = 10000.0f;
+    if (rx)
+    {
+        *rx = r;
+        rx->Direction = lensDirection(pcx + 1.0f, pcy + 0.0f, resX, resY, ViewInverse, ProjInverse, originCameraSpace, focalDistance);
+        *ry = r;
+        ry->Direction = lensDirection(pcx + 0.0f, pcy + 1.0f, resX, resY, ViewInverse, ProjInverse, originCameraSpace, focalDistance);
+    }
     return r;
+}
+static inline Ray constructPrimaryRayLens(uint32_t px, uint32_t py, uint32_t resX, uint32_t resY, const float *ViewInverse,
+                                          const float *ProjInverse, v2 u, v2 u2, float lensRadius, float focalDistance)
+{
+    return constructPrimaryRayLensD(px, py, resX, resY, ViewInverse, ProjInverse, u, u2, lensRadius, focalDistance, NULL, NULL);
 }
 
 /* ray.glsl:93-106 (Waechter-Binder) */
@@ -590,6 +622,7 @@ static inline v4 computeDerivatives(v3 dpdx, v3 dpdy, v3 dpdu, v3 dpdv)
     return r;
 }
 
+typedef v2 texcoord2; /* closestHit names its vertices v0..v2, which hides the type there */
 typedef struct DiffRays
 {
     v3 rxOrigin, rxDirection, ryOrigin, ryDirection;
@@ -1385,11 +1418,14 @@ int pto_test_texture(const PtoScene *s, const float *in, float *out, uint32_t n,
 
 /* Texels of the fixed slots 0..8 after format decode (ShaderRendererTypes.incl:49-56,
  * formats TextureUploader.cpp:571-594: Color/Specular/Emissive sRGB, others UNORM).
- * Scene textures (index >= 9) are the next row N1; until then they sample as the white
- * placeholder, like a texture that has not finished loading (Renderer.cpp:421-429). */
-static inline v4 sampleTexture(uint32_t idx)
+ * Scene textures (index >= 9) go through the software sampler; an index past the uploaded table
+ * samples as the white placeholder, like a texture that has not finished loading
+ * (Renderer.cpp:421-429). */
+static inline v4 sampleTexture(const PtoScene *s, uint32_t idx, v2 uv, v4 dv)
 {
     v4 w = { 1.0f, 1.0f, 1.0f, 1.0f };
+    if (idx >= PTX_SCENE_TEXTURE_OFFSET && idx - PTX_SCENE_TEXTURE_OFFSET < s->textureCount) /* textureGrad(textures[idx], uv, dv.xy, dv.zw) */
+        return textureGradSample(s, &s->textures[idx - PTX_SCENE_TEXTURE_OFFSET], uv.x, uv.y, dv.x, dv.y, dv.z, dv.w);
     switch (idx)
     {
     case PTX_DEFAULT_NORMAL_TEXTURE_INDEX: /* 0xffff8080 UNORM */
@@ -1416,8 +1452,10 @@ static inline v3 ReconstructNormalFromXY(v3 n)
 static inline v3 rgb(v4 t) { return V3(t.x, t.y, t.z); }
 
 /* material.glsl:144-171 dispatching to :62-142 */
-static MaterialSample sampleMaterial(const PtoScene *s, uint32_t materialId, int isHitFromInside, int flipNormalY)
+static MaterialSample sampleMaterial(const PtoScene *s, uint32_t materialId, v2 texCoords, v4 derivatives, int isHitFromInside,
+                                     int flipNormalY)
 {
+#define sampleTexture(idx) sampleTexture(s, (idx), texCoords, derivatives)
     const uint32_t materialType = materialId & 0xffu; /* ShaderTypes.incl:164-168 */
     const uint32_t materialIndex = materialId >> 8;
     MaterialSample ret;
@@ -1481,15 +1519,17 @@ static MaterialSample sampleMaterial(const PtoScene *s, uint32_t materialId, int
     if (flipNormalY)
         ret.Normal.y *= -1;
     return ret;
+#undef sampleTexture
 }
 
 /* ======================================================================== */
 /* closestHit.rchit / miss.rmiss                                            */
 /* ======================================================================== */
 
-/* ShaderRendererTypes.incl:101-118 (ray differentials omitted, quirk 10) */
+/* ShaderRendererTypes.incl:101-118 */
 typedef struct Payload
 {
+    DiffRays diff; /* RayDifferentials0..2 */
     v3 Position;
     v3 Direction;
     float MaxRoughness;
@@ -1538,7 +1578,6 @@ static inline Vtx transformVertex(const Pair *pr, Vtx v)
 static void closestHit(const PtoScene *s, const PtxLightsUbo *lights, v3 rayOriginW, v3 rayDirW, const PtoHit *hit,
                        Payload *payload)
 {
-    (void)rayOriginW;
     const v3 bary = V3(1.0f - hit->u - hit->v, hit->u, hit->v); /* common.glsl:22-25 */
     const Pair *pr = &s->pairs[s->triPair[hit->tri]];
     const uint32_t prim = s->triPrim[hit->tri];
@@ -1568,7 +1607,19 @@ static void closestHit(const PtoScene *s, const PtxLightsUbo *lights, v3 rayOrig
         vertex.Bitangent = v_neg(vertex.Bitangent);
     }
 
-    MaterialSample material = sampleMaterial(s, pr->materialId, isHitFromInside, s->d.dxNormalTextures != 0);
+    /* :88-99 texture footprint from the ray differentials */
+    v3 dpdu, dpdv, dndu, dndv;
+    {
+        const v3 P3[3] = { v0.Position, v1.Position, v2.Position }, N3[3] = { v0.Normal, v1.Normal, v2.Normal };
+        const texcoord2 UV3[3] = { o0.TexCoords, o1.TexCoords, o2.TexCoords };
+        computeDpnDuv(P3, N3, UV3, vertex.Tangent, vertex.Bitangent, &dpdu, &dpdv, &dndu, &dndv);
+    }
+    v3 dpdx, dpdy;
+    computeDpDxy(vertex.Position, rayOriginW, v_normalize(rayDirW), payload->diff.rxOrigin, payload->diff.rxDirection,
+                 payload->diff.ryOrigin, payload->diff.ryDirection, vertex.Normal, &dpdx, &dpdy);
+    const v4 derivatives = computeDerivatives(dpdx, dpdy, dpdu, dpdv);
+
+    MaterialSample material = sampleMaterial(s, pr->materialId, ov.TexCoords, derivatives, isHitFromInside, s->d.dxNormalTextures != 0);
 
     /* :105-106 decals: never taken for opaque geometry (DirectLightPdf == -1 on entry) */
 
@@ -1620,6 +1671,13 @@ static void closestHit(const PtoScene *s, const PtxLightsUbo *lights, v3 rayOrig
     payload->DirectLightPdf = lightPdf;
     payload->LightDirection = light.Direction;
     payload->LightDistance = light.Distance;
+
+    /* :150-160 differentials of the continuation ray */
+    if (isRefracted)
+        computeRefractedDifferentialRays(derivatives, vertex.Normal, rayOrigin, v_neg(rayDirW), payload->Direction, dndu, dndv, material.Eta,
+                                         &payload->diff);
+    else
+        computeReflectedDifferentialRays(derivatives, vertex.Normal, rayOrigin, v_neg(rayDirW), payload->Direction, dndu, dndv, &payload->diff);
 }
 
 /* miss.rmiss:16-39, MissFlagsNone branch (skybox textures are next row N1) */
@@ -1656,17 +1714,20 @@ static void raygenPixel(const PtoScene *s, const PtxRaygenUniformData *U, const 
         v2 u;
         u.x = rnd(&rngState);
         u.y = rnd(&rngState);
-        Ray ray;
+        Ray ray, rx, ry;
         if (U->LensRadius > 0)
         {
             v2 u2;
             u2.x = rnd(&rngState);
             u2.y = rnd(&rngState);
-            ray = constructPrimaryRayLens(px, py, W, H, U->ViewInverse, U->ProjInverse, u, u2, U->LensRadius,
-                                          U->FocalDistance);
+            ray = constructPrimaryRayLensD(px, py, W, H, U->ViewInverse, U->ProjInverse, u, u2, U->LensRadius, U->FocalDistance, &rx, &ry);
         }
         else
-            ray = constructPrimaryRay(px, py, W, H, U->ViewInverse, U->ProjInverse, u);
+            ray = constructPrimaryRayD(px, py, W, H, U->ViewInverse, U->ProjInverse, u, &rx, &ry);
+        payload.diff.rxOrigin = rx.Origin; /* raygen.rgen:56-58 */
+        payload.diff.rxDirection = rx.Direction;
+        payload.diff.ryOrigin = ry.Origin;
+        payload.diff.ryDirection = ry.Direction;
 
         payload.MaxRoughness = 0.0f;
 
@@ -1782,7 +1843,7 @@ int pto_render(const PtoScene *s, const PtxRaygenUniformData *U, const PtxLights
 /* ======================================================================== */
 
 static const int kInStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4 };
-static const int kOutStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 6, 2, 1, 9, 3, 6, 12, 6, 4, 12, 12, 1 };
+static const int kOutStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1 };
 
 static MaterialSample unpackMaterial(const float *p)
 {
@@ -1886,9 +1947,14 @@ int pto_test_eval(uint32_t fn, const float *in, float *out, uint32_t n)
         }
         case PTX_FN_PRIMARY_RAY: {
             v2 u = { a[4], a[5] };
-            const Ray r = constructPrimaryRay(f2u(a[0]), f2u(a[1]), f2u(a[2]), f2u(a[3]), &a[6], &a[22], u);
-            o[0] = r.Origin.x; o[1] = r.Origin.y; o[2] = r.Origin.z;
-            o[3] = r.Direction.x; o[4] = r.Direction.y; o[5] = r.Direction.z;
+            Ray rx, ry;
+            const Ray r = constructPrimaryRayD(f2u(a[0]), f2u(a[1]), f2u(a[2]), f2u(a[3]), &a[6], &a[22], u, &rx, &ry);
+            const Ray *rs[3] = { &r, &rx, &ry };
+            for (int k = 0; k < 3; k++)
+            {
+                o[6 * k] = rs[k]->Origin.x; o[6 * k + 1] = rs[k]->Origin.y; o[6 * k + 2] = rs[k]->Origin.z;
+                o[6 * k + 3] = rs[k]->Direction.x; o[6 * k + 4] = rs[k]->Direction.y; o[6 * k + 5] = rs[k]->Direction.z;
+            }
             break;
         }
         case PTX_FN_SINCOS: pto_sincosf(a[0], &o[0], &o[1]); break;
@@ -1926,9 +1992,14 @@ int pto_test_eval(uint32_t fn, const float *in, float *out, uint32_t n)
         }
         case PTX_FN_PRIMARY_RAY_LENS: {
             v2 u = { a[4], a[5] }, u2 = { a[6], a[7] };
-            const Ray r = constructPrimaryRayLens(f2u(a[0]), f2u(a[1]), f2u(a[2]), f2u(a[3]), &a[10], &a[26], u, u2, a[8], a[9]);
-            o[0] = r.Origin.x; o[1] = r.Origin.y; o[2] = r.Origin.z;
-            o[3] = r.Direction.x; o[4] = r.Direction.y; o[5] = r.Direction.z;
+            Ray rx, ry;
+            const Ray r = constructPrimaryRayLensD(f2u(a[0]), f2u(a[1]), f2u(a[2]), f2u(a[3]), &a[10], &a[26], u, u2, a[8], a[9], &rx, &ry);
+            const Ray *rs[3] = { &r, &rx, &ry };
+            for (int k = 0; k < 3; k++)
+            {
+                o[6 * k] = rs[k]->Origin.x; o[6 * k + 1] = rs[k]->Origin.y; o[6 * k + 2] = rs[k]->Origin.z;
+                o[6 * k + 3] = rs[k]->Direction.x; o[6 * k + 4] = rs[k]->Direction.y; o[6 * k + 5] = rs[k]->Direction.z;
+            }
             break;
         }
         case PTX_FN_DPN_DUV: {

@@ -31,6 +31,7 @@ struct f3 { float x, y, z; };
 struct f4 { float x, y, z, w; };
 struct mat3 { f3 c0, c1, c2; }; // columns
 
+PT_DEV f2 F2(float x, float y) { f2 r; r.x = x; r.y = y; return r; }
 PT_DEV f3 F3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 PT_DEV f3 F3s(float s) { return F3(s, s, s); }
 PT_DEV f3 operator+(f3 a, f3 b) { return F3(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -466,44 +467,81 @@ PT_DEV BSDFSample sampleBSDF(const MaterialSample &m, f3 V, uint32_t &rngState) 
 
 // ---- ray.glsl ------------------------------------------------------------------------------
 
-PT_DEV void constructPrimaryRay(uint32_t px, uint32_t py, uint32_t resX, uint32_t resY, const float *ViewInverse,
-                                const float *ProjInverse, f2 u, f3 &origin, f3 &direction) // :58-85
+PT_DEV f3 pinholeDirection(float pcx, float pcy, uint32_t resX, uint32_t resY, const float *ViewInverse, const float *ProjInverse) // :64-65,72-73
 {
-    const float pcx = (float)px + u.x;
-    const float pcy = (float)py + u.y;
     const float inUVx = pcx / (float)resX;
     const float inUVy = pcy / (float)resY;
     const float dx = inUVx * 2.0f - 1.0f;
     const float dy = inUVy * 2.0f - 1.0f;
-    const f4 o = mul4(ViewInverse, 0, 0, 0, 1);
     const f4 target = mul4(ProjInverse, dx, dy, 1, 1);
     const f3 nt = normalize(F3(target.x, target.y, target.z));
     const f4 d = mul4(ViewInverse, nt.x, nt.y, nt.z, 0);
-    origin = F3(o.x, o.y, o.z);
-    direction = F3(d.x, d.y, d.z);
+    return F3(d.x, d.y, d.z);
 }
 
-PT_DEV void constructPrimaryRayLens(uint32_t px, uint32_t py, uint32_t resX, uint32_t resY, const float *ViewInverse,
-                                    const float *ProjInverse, f2 u, f2 u2, float lensRadius, float focalDistance,
-                                    f3 &origin, f3 &direction) // :16-56
+// :58-85; with DIFF also the directions through the pixels one to the right (rxDir) / below (ryDir)
+template <bool DIFF>
+PT_DEV void constructPrimaryRay(uint32_t px, uint32_t py, uint32_t resX, uint32_t resY, const float *ViewInverse,
+                                const float *ProjInverse, f2 u, f3 &origin, f3 &direction, f3 &rxDir, f3 &ryDir)
 {
     const float pcx = (float)px + u.x;
     const float pcy = (float)py + u.y;
-    const f2 disk = sampleUniformDiskConcentric(u2);
-    const float plx = lensRadius * disk.x, ply = lensRadius * disk.y;
+    const f4 o = mul4(ViewInverse, 0, 0, 0, 1);
+    origin = F3(o.x, o.y, o.z);
+    direction = pinholeDirection(pcx, pcy, resX, resY, ViewInverse, ProjInverse);
+    if (DIFF)
+    {
+        rxDir = pinholeDirection(pcx + 1.0f, pcy + 0.0f, resX, resY, ViewInverse, ProjInverse);
+        ryDir = pinholeDirection(pcx + 0.0f, pcy + 1.0f, resX, resY, ViewInverse, ProjInverse);
+    }
+}
+PT_DEV void constructPrimaryRay(uint32_t px, uint32_t py, uint32_t resX, uint32_t resY, const float *ViewInverse,
+                                const float *ProjInverse, f2 u, f3 &origin, f3 &direction)
+{
+    f3 rx, ry;
+    constructPrimaryRay<false>(px, py, resX, resY, ViewInverse, ProjInverse, u, origin, direction, rx, ry);
+}
+
+PT_DEV f3 lensDirection(float pcx, float pcy, uint32_t resX, uint32_t resY, const float *ViewInverse, const float *ProjInverse,
+                        f3 originCameraSpace, float focalDistance) // :24-25,35-38
+{
     const float inUVx = pcx / (float)resX;
     const float inUVy = pcy / (float)resY;
     const float dx = inUVx * 2.0f - 1.0f;
     const float dy = inUVy * 2.0f - 1.0f;
-    const f3 originCameraSpace = F3(plx, ply, 0);
-    const f4 o = mul4(ViewInverse, originCameraSpace.x, originCameraSpace.y, originCameraSpace.z, 1);
     const f4 target = mul4(ProjInverse, dx, dy, 1, 1);
     const float ft = focalDistance / target.z;
     const f3 pFocus = F3(target.x, target.y, target.z) * ft;
     const f3 nd = normalize(pFocus - originCameraSpace);
     const f4 d = mul4(ViewInverse, nd.x, nd.y, nd.z, 0);
+    return F3(d.x, d.y, d.z);
+}
+
+template <bool DIFF>
+PT_DEV void constructPrimaryRayLens(uint32_t px, uint32_t py, uint32_t resX, uint32_t resY, const float *ViewInverse,
+                                    const float *ProjInverse, f2 u, f2 u2, float lensRadius, float focalDistance,
+                                    f3 &origin, f3 &direction, f3 &rxDir, f3 &ryDir) // :16-56
+{
+    const float pcx = (float)px + u.x;
+    const float pcy = (float)py + u.y;
+    const f2 disk = sampleUniformDiskConcentric(u2);
+    const float plx = lensRadius * disk.x, ply = lensRadius * disk.y;
+    const f3 originCameraSpace = F3(plx, ply, 0);
+    const f4 o = mul4(ViewInverse, originCameraSpace.x, originCameraSpace.y, originCameraSpace.z, 1);
     origin = F3(o.x, o.y, o.z);
-    direction = F3(d.x, d.y, d.z);
+    direction = lensDirection(pcx, pcy, resX, resY, ViewInverse, ProjInverse, originCameraSpace, focalDistance);
+    if (DIFF)
+    {
+        rxDir = lensDirection(pcx + 1.0f, pcy + 0.0f, resX, resY, ViewInverse, ProjInverse, originCameraSpace, focalDistance);
+        ryDir = lensDirection(pcx + 0.0f, pcy + 1.0f, resX, resY, ViewInverse, ProjInverse, originCameraSpace, focalDistance);
+    }
+}
+PT_DEV void constructPrimaryRayLens(uint32_t px, uint32_t py, uint32_t resX, uint32_t resY, const float *ViewInverse,
+                                    const float *ProjInverse, f2 u, f2 u2, float lensRadius, float focalDistance,
+                                    f3 &origin, f3 &direction)
+{
+    f3 rx, ry;
+    constructPrimaryRayLens<false>(px, py, resX, resY, ViewInverse, ProjInverse, u, u2, lensRadius, focalDistance, origin, direction, rx, ry);
 }
 
 PT_DEV float offsetComponent(float o, float n) // :93-106 (Waechter-Binder)
@@ -586,380 +624,10 @@ PT_DEV LightSample sampleLight(const PtxLightsUbo *ubo, f3 u, f3 position, float
     return ret;
 }
 
-// ---- software sampler (row N1) ---------------------------------------------------------------------
-// What the Vulkan sampler of Renderer.cpp:103-112 does (linear min/mag/mip, repeat addressing),
-// with fixed arithmetic shared with the oracle.  Anisotropic filtering is implementation-defined
-// in Vulkan and is NOT modelled: textureGrad is isotropic trilinear.
-
-struct DevTexture
-{
-    uint32_t width, height, levels, format;
-    uint32_t levelOffset[16]; // texels, into the pool of its format
-};
-
-struct TextureView
-{
-    const DevTexture *textures;
-    uint32_t textureCount;
-    const uint32_t *texels8; // RGBA8 pool
-    const float4 *texelsF;   // RGBA32F pool
-    const float *srgbLut;    // 256 entries, sRGB byte -> linear
-};
-
-PT_DEV uint32_t levelDim(uint32_t d, uint32_t level) { const uint32_t v = d >> level; return v ? v : 1u; }
-
-PT_DEV float srgbToLinear(float c) { return c <= 0.04045f ? c / 12.92f : pow_((c + 0.055f) / 1.055f, 2.4f); }
-PT_DEV float linearToSrgb(float c) { return c <= 0.0031308f ? 12.92f * c : 1.055f * pow_(c, 1.0f / 2.4f) - 0.055f; }
-PT_DEV uint32_t quantize8(float x)
-{
-    if (!(x > 0.0f))
-        return 0u;
-    if (x > 1.0f)
-        x = 1.0f;
-    return (uint32_t)__builtin_floorf(x * 255.0f + 0.5f);
-}
-
-PT_DEV f4 fetchTexel(const TextureView &tv, const DevTexture &t, uint32_t level, uint32_t x, uint32_t y)
-{
-    const size_t idx = (size_t)t.levelOffset[level] + (size_t)y * levelDim(t.width, level) + x;
-    f4 r;
-    if (t.format == PTX_TEXTURE_RGBA32F)
-    {
-        const float4 v = tv.texelsF[idx];
-        r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
-        return r;
-    }
-    const uint32_t p = tv.texels8[idx];
-    if (t.format == PTX_TEXTURE_RGBA8_SRGB)
-    {
-        r.x = tv.srgbLut[p & 255u]; r.y = tv.srgbLut[(p >> 8) & 255u]; r.z = tv.srgbLut[(p >> 16) & 255u];
-    }
-    else
-    {
-        r.x = (float)(p & 255u) / 255.0f; r.y = (float)((p >> 8) & 255u) / 255.0f; r.z = (float)((p >> 16) & 255u) / 255.0f;
-    }
-    r.w = (float)(p >> 24) / 255.0f;
-    return r;
-}
-
-PT_DEV f4 lerp4(f4 a, f4 b, float t)
-{
-    f4 r;
-    r.x = a.x * (1.0f - t) + b.x * t; r.y = a.y * (1.0f - t) + b.y * t; r.z = a.z * (1.0f - t) + b.z * t; r.w = a.w * (1.0f - t) + b.w * t;
-    return r;
-}
-
-PT_DEV uint32_t wrapRepeat(float x0, uint32_t n) // floor(x) mod n, in float: CPU and GPU agree for any finite x
-{
-    const float fn = (float)n;
-    float m = x0 - __builtin_floorf(x0 / fn) * fn;
-    if (!(m >= 0.0f)) m = 0.0f;
-    const uint32_t i = (uint32_t)m;
-    return i >= n ? n - 1 : i;
-}
-
-PT_DEV f4 sampleLevel(const TextureView &tv, const DevTexture &t, uint32_t level, float u, float v)
-{
-    const uint32_t w = levelDim(t.width, level), h = levelDim(t.height, level);
-    if (w == 1 && h == 1) // exact for 1x1 (hardware weights are fixed point and sum to 1)
-        return fetchTexel(tv, t, level, 0, 0);
-    if (!(abs_(u) < 1e9f)) u = 0.0f;
-    if (!(abs_(v) < 1e9f)) v = 0.0f;
-    const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
-    const float x0 = __builtin_floorf(x), y0 = __builtin_floorf(y);
-    const float ax = x - x0, ay = y - y0;
-    const uint32_t ix0 = wrapRepeat(x0, w), ix1 = wrapRepeat(x0 + 1.0f, w), iy0 = wrapRepeat(y0, h), iy1 = wrapRepeat(y0 + 1.0f, h);
-    const f4 top = lerp4(fetchTexel(tv, t, level, ix0, iy0), fetchTexel(tv, t, level, ix1, iy0), ax);
-    const f4 bot = lerp4(fetchTexel(tv, t, level, ix0, iy1), fetchTexel(tv, t, level, ix1, iy1), ax);
-    return lerp4(top, bot, ay);
-}
-
-// textureGrad: LOD from the gradients (Vulkan 1.3 spec 16.5.7, isotropic), trilinear
-PT_DEV f4 textureGradSample(const TextureView &tv, const DevTexture &t, float u, float v, float dudx, float dvdx, float dudy, float dvdy)
-{
-    if (t.levels <= 1)
-        return sampleLevel(tv, t, 0, u, v);
-    const float mux = dudx * (float)t.width, mvx = dvdx * (float)t.height;
-    const float muy = dudy * (float)t.width, mvy = dvdy * (float)t.height;
-    const float rx = sqrt_(mux * mux + mvx * mvx), ry = sqrt_(muy * muy + mvy * mvy);
-    const float rho = fmax_(rx, ry);
-    float lod = rho > 0.0f ? (float)log2_((double)rho) : 0.0f;
-    const float q = (float)(t.levels - 1);
-    if (!(lod >= 0.0f)) lod = 0.0f;
-    if (lod > q) lod = q;
-    const float d0 = __builtin_floorf(lod), f = lod - d0;
-    const uint32_t l0 = (uint32_t)d0, l1 = l0 + 1 < t.levels ? l0 + 1 : t.levels - 1;
-    const f4 c0 = sampleLevel(tv, t, l0, u, v);
-    if (f == 0.0f || l1 == l0)
-        return c0;
-    return lerp4(c0, sampleLevel(tv, t, l1, u, v), f);
-}
-
-// ---- material.glsl with the fixed 1x1 default textures ------------------------------------------
-
-// Texels of slots 0..8 after format decode (ShaderRendererTypes.incl:49-56; sRGB for
-// Color/Specular/Emissive, UNORM otherwise: TextureUploader.cpp:571-594).  Scene
-// textures (index >= 9) are the next row N1 and sample as the white placeholder.
-PT_DEV f4 sampleTexture(uint32_t idx)
-{
-    f4 w;
-    w.x = w.y = w.z = w.w = 1.0f;
-    if (idx == PTX_DEFAULT_NORMAL_TEXTURE_INDEX)
-    {
-        w.x = 128.0f / 255.0f;
-        w.y = 128.0f / 255.0f;
-    }
-    else if (idx == PTX_DEFAULT_EMISSIVE_TEXTURE_INDEX || idx == PTX_DEFAULT_GLOSSINESS_TEXTURE_INDEX ||
-             idx == PTX_DEFAULT_SHININESS_TEXTURE_INDEX)
-        w.x = w.y = w.z = w.w = 0.0f;
-    return w;
-}
-
-PT_DEV f3 ReconstructNormalFromXY(f3 n) // :55-60
-{
-    n = F3(2.0f * n.x - 1.0f, 2.0f * n.y - 1.0f, 2.0f * n.z - 1.0f);
-    return F3(n.x, n.y, sqrt_(fmax_(1 - n.x * n.x - n.y * n.y, 0.0f)));
-}
-
-PT_DEV f3 rgb(f4 t) { return F3(t.x, t.y, t.z); }
-PT_DEV f3 ld3(const float *p) { return F3(p[0], p[1], p[2]); }
-
-struct SceneView // read-only device views of the uploaded scene
-{
-    const PtxVertex *vertices;
-    const uint32_t *indices;
-    const PtxMetallicRoughnessMaterial *mr;
-    const PtxSpecularGlossinessMaterial *sg;
-    const PtxPhongMaterial *phong;
-    const struct DevPair *pairs;
-    const PtxLightsUbo *lights;
-    uint32_t dxNormalTextures;
-};
-
-// one (instance, mesh): world = A_instance * A_mesh * x (sampling.glsl:5-15); Rinv is
-// the inverse of the linear part, for the inverse-transpose normal transform
-struct DevPair
-{
-    float M[12];
-    float Rinv[9]; // columns c0, c1, c2
-    uint32_t vertexOffset, indexOffset, materialId;
-};
-
-PT_DEV f3 specGlossMetalness(f3 specular, f3 color) // material.glsl:109-110, :138-139
-{
-    return F3(fmax_(specular.x - 0.04f, 0.0f) / ((color.x - 0.04f) + 0.00001f),
-              fmax_(specular.y - 0.04f, 0.0f) / ((color.y - 0.04f) + 0.00001f),
-              fmax_(specular.z - 0.04f, 0.0f) / ((color.z - 0.04f) + 0.00001f));
-}
-
-PT_DEV MaterialSample sampleMaterial(const SceneView &sv, uint32_t materialId, bool isHitFromInside) // :144-171
-{
-    const uint32_t materialType = materialId & 0xffu;
-    const uint32_t materialIndex = materialId >> 8;
-    MaterialSample ret;
-    ret.EmissiveColor = ret.Color = ret.Normal = ret.AttenuationColor = F3s(0.0f);
-    ret.Roughness = ret.Metalness = ret.Transmission = ret.Eta = ret.AttenuationDistance = 0.0f;
-    if (materialType == PTX_MATERIAL_TYPE_METALLIC_ROUGHNESS) // :62-84
-    {
-        const PtxMetallicRoughnessMaterial *m = &sv.mr[materialIndex];
-        ret.EmissiveColor = (rgb(sampleTexture(m->EmissiveIdx)) + ld3(m->EmissiveColor)) * m->EmissiveIntensity;
-        ret.Color = rgb(sampleTexture(m->ColorIdx)) * ld3(m->Color);
-        ret.Normal = ReconstructNormalFromXY(rgb(sampleTexture(m->NormalIdx)));
-        ret.Roughness = sampleTexture(m->RoughnessIdx).y * m->Roughness;
-        ret.Metalness = sampleTexture(m->MetallicIdx).z * m->Metalness;
-        ret.Transmission = m->Transmission;
-        ret.AttenuationColor = ld3(m->AttenuationColor);
-        ret.AttenuationDistance = m->AttenuationDistance;
-        ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
-    }
-    else if (materialType == PTX_MATERIAL_TYPE_SPECULAR_GLOSSINESS) // :86-113
-    {
-        const PtxSpecularGlossinessMaterial *m = &sv.sg[materialIndex];
-        ret.EmissiveColor = (rgb(sampleTexture(m->EmissiveIdx)) + ld3(m->EmissiveColor)) * m->EmissiveIntensity;
-        ret.Color = rgb(sampleTexture(m->ColorIdx)) * ld3(m->Color);
-        ret.Normal = ReconstructNormalFromXY(rgb(sampleTexture(m->NormalIdx)));
-        ret.Transmission = m->Transmission;
-        ret.AttenuationColor = ld3(m->AttenuationColor);
-        ret.AttenuationDistance = m->AttenuationDistance;
-        ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
-        const f3 specular = rgb(sampleTexture(m->SpecularIdx)) * ld3(m->Specular);
-        const float glossiness = sampleTexture(m->GlossinessIdx).w * m->Glossiness;
-        ret.Roughness = 1.0f - glossiness;
-        const f3 diff = specGlossMetalness(specular, ret.Color);
-        ret.Metalness = (diff.x + diff.y + diff.z) / 3.0f;
-    }
-    else if (materialType == PTX_MATERIAL_TYPE_PHONG) // :115-142
-    {
-        const PtxPhongMaterial *m = &sv.phong[materialIndex];
-        ret.EmissiveColor = (rgb(sampleTexture(m->EmissiveIdx)) + ld3(m->EmissiveColor)) * m->EmissiveIntensity;
-        ret.Color = rgb(sampleTexture(m->ColorIdx)) * ld3(m->Color);
-        ret.Normal = ReconstructNormalFromXY(rgb(sampleTexture(m->NormalIdx)));
-        ret.Transmission = m->Transmission;
-        ret.AttenuationColor = ld3(m->AttenuationColor);
-        ret.AttenuationDistance = m->AttenuationDistance;
-        ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
-        const f3 specular = rgb(sampleTexture(m->SpecularIdx)) * ld3(m->Specular);
-        const float shininess = sampleTexture(m->ShininessIdx).w * m->Shininess;
-        ret.Roughness = 1.0f - shininess;
-        const f3 diff = specGlossMetalness(specular, ret.Color);
-        ret.Metalness = (diff.x + diff.y + diff.z) / 3.0f;
-    }
-    else // :163-166
-    {
-        ret.Color = F3(1.0f, 0.0f, 0.0f);
-        ret.EmissiveColor = F3(1.0f, 0.0f, 0.0f);
-    }
-    if (sv.dxNormalTextures)
-        ret.Normal.y *= -1;
-    return ret;
-}
-
-// ---- closestHit.rchit ---------------------------------------------------------------------------
-
-struct Vtx
-{
-    f3 Position;
-    f3 Normal, Tangent, Bitangent;
-};
-
-PT_DEV f3 xformPoint(const float *M, f3 p)
-{
-    return F3(((p.x * M[0] + p.y * M[1]) + p.z * M[2]) + M[3], ((p.x * M[4] + p.y * M[5]) + p.z * M[6]) + M[7],
-              ((p.x * M[8] + p.y * M[9]) + p.z * M[10]) + M[11]);
-}
-PT_DEV f3 xformVector(const float *M, f3 p)
-{
-    return F3((p.x * M[0] + p.y * M[1]) + p.z * M[2], (p.x * M[4] + p.y * M[5]) + p.z * M[6],
-              (p.x * M[8] + p.y * M[9]) + p.z * M[10]);
-}
-
-PT_DEV Vtx transformVertex(const DevPair &pr, Vtx v) // sampling.glsl:5-15
-{
-    v.Position = xformPoint(pr.M, v.Position);
-    v.Tangent = normalize(xformVector(pr.M, v.Tangent));
-    v.Bitangent = normalize(xformVector(pr.M, v.Bitangent));
-    v.Normal = normalize(F3(dot(v.Normal, F3(pr.Rinv[0], pr.Rinv[1], pr.Rinv[2])), dot(v.Normal, F3(pr.Rinv[3], pr.Rinv[4], pr.Rinv[5])),
-                            dot(v.Normal, F3(pr.Rinv[6], pr.Rinv[7], pr.Rinv[8]))));
-    return v;
-}
-
-PT_DEV Vtx loadVertex(const PtxVertex *p) // common.glsl:27-46
-{
-    Vtx v;
-    v.Position = ld3(p->Position);
-    v.Normal = ld3(p->Normal);
-    v.Tangent = ld3(p->Tangent);
-    v.Bitangent = ld3(p->Bitangent);
-    return v;
-}
-
-PT_DEV f3 interp3(f3 a, f3 b, f3 c, f3 bc) { return (a * bc.x + b * bc.y) + c * bc.z; } // common.glsl:107-110
-
-// What closestHit.rchit writes into the payload (ShaderRendererTypes.incl:101-118; ray
-// differentials feed only textureGrad and are not carried while textures are 1x1).
-struct HitOut
-{
-    f3 Position;
-    f3 Direction;
-    float MaxRoughness;
-    f3 Bsdf;
-    float Pdf;
-    f3 Emissive;
-    f3 DirectLight;
-    float DirectLightPdf;
-    f3 LightDirection;
-    float LightDistance;
-};
-
-// closestHit.rchit:52-161.  (u, v) = hitAttributeEXT barycentrics, t = gl_RayTmaxEXT.
-PT_DEV void closestHit(const SceneView &sv, f3 rayDirW, float t, float hu, float hv, uint32_t pairIdx, uint32_t prim,
-                       float maxRoughnessIn, uint32_t &rngState, HitOut &out)
-{
-    const f3 bary = F3(1.0f - hu - hv, hu, hv);
-    const DevPair pr = sv.pairs[pairIdx];
-    const uint32_t *ix = sv.indices + pr.indexOffset + prim * 3;
-    const PtxVertex *vb = sv.vertices + pr.vertexOffset;
-    const Vtx o0 = loadVertex(vb + ix[0]), o1 = loadVertex(vb + ix[1]), o2 = loadVertex(vb + ix[2]);
-
-    Vtx ov; // getInterpolatedVertex, common.glsl:112-130 (TexCoords unused with 1x1 textures)
-    ov.Position = interp3(o0.Position, o1.Position, o2.Position, bary);
-    ov.Normal = interp3(o0.Normal, o1.Normal, o2.Normal, bary);
-    ov.Tangent = interp3(o0.Tangent, o1.Tangent, o2.Tangent, bary);
-    ov.Bitangent = interp3(o0.Bitangent, o1.Bitangent, o2.Bitangent, bary);
-    Vtx vertex = transformVertex(pr, ov);
-
-    const Vtx v0 = transformVertex(pr, o0), v1 = transformVertex(pr, o1), v2 = transformVertex(pr, o2);
-
-    const f3 edge1 = v1.Position - v0.Position;
-    const f3 edge2 = v2.Position - v0.Position;
-    f3 geometricNormal = normalize(cross(edge1, edge2));
-
-    const bool isHitFromInside = dot(geometricNormal, rayDirW) > 0.0f;
-    if (isHitFromInside)
-    {
-        geometricNormal = -geometricNormal;
-        vertex.Normal = -vertex.Normal;
-        vertex.Tangent = -vertex.Tangent;
-        vertex.Bitangent = -vertex.Bitangent;
-    }
-
-    MaterialSample material = sampleMaterial(sv, pr.materialId, isHitFromInside);
-
-    // :105-106 decal mix: never taken for opaque geometry
-
-    out.MaxRoughness = fmax_(material.Roughness, maxRoughnessIn); // :109
-    material.Roughness = fmax_(out.MaxRoughness, 0.01f);          // :112
-
-    mat3 geometryTBN;
-    geometryTBN.c0 = vertex.Tangent;
-    geometryTBN.c1 = vertex.Bitangent;
-    geometryTBN.c2 = vertex.Normal;
-    const f3 N = normalize(vertex.Normal + mul(geometryTBN, material.Normal));
-    const mat3 TBN = computeTangentSpace(N);
-    const mat3 invTBN = inverse(TBN);
-    const f3 V = normalize(mul(invTBN, normalize(-rayDirW)));
-
-    BSDFSample bsdf = sampleBSDF(material, V, rngState);
-
-    if (isHitFromInside) // :123-128
-    {
-        const float e = t / material.AttenuationDistance;
-        bsdf.Color.x *= pow_(material.AttenuationColor.x, e);
-        bsdf.Color.y *= pow_(material.AttenuationColor.y, e);
-        bsdf.Color.z *= pow_(material.AttenuationColor.z, e);
-    }
-
-    const bool isRefracted = bsdf.Direction.z < 0.0f;
-    const f3 rayOrigin = offsetRayOriginShadowTerminator(vertex.Position, v0.Position, v0.Normal, v1.Position, v1.Normal,
-                                                         v2.Position, v2.Normal, bary, isRefracted);
-
-    float lightPdf, lightSmplPdf;
-    f3 u3;
-    u3.x = rnd(rngState);
-    u3.y = rnd(rngState);
-    u3.z = rnd(rngState);
-    const LightSample light = sampleLight(sv.lights, u3, rayOrigin, lightPdf);
-    const f3 L = normalize(mul(invTBN, -light.Direction));
-    const f3 lightBsdf = evaluateBSDF(material, V, L, lightSmplPdf);
-
-    out.Direction = normalize(mul(TBN, bsdf.Direction));
-    if (isRefracted)
-        out.Position = offsetRayOriginSelfIntersection(vertex.Position, -geometricNormal);
-    else
-        out.Position = rayOrigin;
-    out.Bsdf = bsdf.Color;
-    out.Pdf = bsdf.Pdf;
-    out.Emissive = material.EmissiveColor;
-    out.DirectLight = (light.Color * light.Attenuation) * lightBsdf;
-    out.DirectLightPdf = lightPdf;
-    out.LightDirection = light.Direction;
-    out.LightDistance = light.Distance;
-}
-
 // ---- tracing.glsl: ray differentials and texture footprint ------------------------------------------
-// These feed only textureGrad.  While every texture is 1x1 they cannot change radiance and the
-// wavefront does not carry them; they are restated, and tested against the
-// reference's GLSL vectors, for the texture row N1.
+// These feed only textureGrad: a scene whose textures are all the fixed 1x1 defaults cannot see
+// them, and its kernels (TEX = false) do not carry them.  A scene with
+// uploaded textures runs the TEX = true variants, which do.
 
 PT_DEV void computeDpnDuv(const f3 *p, const f3 *n, const f2 *uv, f3 vtxTangent, f3 vtxBitangent, f3 &dpdu, f3 &dpdv, f3 &dndu,
                           f3 &dndv) // :2-28
@@ -1087,6 +755,417 @@ PT_DEV float computeLod(f4 derivatives) // :151-161, log2 through the fixed kern
     const float sy = sqrt_(derivatives.z * derivatives.z + derivatives.w * derivatives.w);
     const float smax = fmax_(sx, sy);
     return smax == 0.0f ? 0.0f : (float)log2_((double)smax);
+}
+
+// ---- software sampler (row N1) ---------------------------------------------------------------------
+// What the Vulkan sampler of Renderer.cpp:103-112 does (linear min/mag/mip, repeat addressing),
+// with fixed arithmetic shared with the oracle.  Anisotropic filtering is implementation-defined
+// in Vulkan and is NOT modelled: textureGrad is isotropic trilinear.
+
+struct DevTexture
+{
+    uint32_t width, height, levels, format;
+    uint32_t levelOffset[16]; // texels, into the pool of its format
+};
+
+struct TextureView
+{
+    const DevTexture *textures;
+    uint32_t textureCount;
+    const uint32_t *texels8; // RGBA8 pool
+    const float4 *texelsF;   // RGBA32F pool
+    const float *srgbLut;    // 256 entries, sRGB byte -> linear
+};
+
+PT_DEV uint32_t levelDim(uint32_t d, uint32_t level) { const uint32_t v = d >> level; return v ? v : 1u; }
+
+PT_DEV float srgbToLinear(float c) { return c <= 0.04045f ? c / 12.92f : pow_((c + 0.055f) / 1.055f, 2.4f); }
+PT_DEV float linearToSrgb(float c) { return c <= 0.0031308f ? 12.92f * c : 1.055f * pow_(c, 1.0f / 2.4f) - 0.055f; }
+PT_DEV uint32_t quantize8(float x)
+{
+    if (!(x > 0.0f))
+        return 0u;
+    if (x > 1.0f)
+        x = 1.0f;
+    return (uint32_t)__builtin_floorf(x * 255.0f + 0.5f);
+}
+
+PT_DEV f4 fetchTexel(const TextureView &tv, const DevTexture &t, uint32_t level, uint32_t x, uint32_t y)
+{
+    const size_t idx = (size_t)t.levelOffset[level] + (size_t)y * levelDim(t.width, level) + x;
+    f4 r;
+    if (t.format == PTX_TEXTURE_RGBA32F)
+    {
+        const float4 v = tv.texelsF[idx];
+        r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+        return r;
+    }
+    const uint32_t p = tv.texels8[idx];
+    if (t.format == PTX_TEXTURE_RGBA8_SRGB)
+    {
+        r.x = tv.srgbLut[p & 255u]; r.y = tv.srgbLut[(p >> 8) & 255u]; r.z = tv.srgbLut[(p >> 16) & 255u];
+    }
+    else
+    {
+        r.x = (float)(p & 255u) / 255.0f; r.y = (float)((p >> 8) & 255u) / 255.0f; r.z = (float)((p >> 16) & 255u) / 255.0f;
+    }
+    r.w = (float)(p >> 24) / 255.0f;
+    return r;
+}
+
+PT_DEV f4 lerp4(f4 a, f4 b, float t)
+{
+    f4 r;
+    r.x = a.x * (1.0f - t) + b.x * t; r.y = a.y * (1.0f - t) + b.y * t; r.z = a.z * (1.0f - t) + b.z * t; r.w = a.w * (1.0f - t) + b.w * t;
+    return r;
+}
+
+PT_DEV uint32_t wrapRepeat(float x0, uint32_t n) // floor(x) mod n, in float: CPU and GPU agree for any finite x
+{
+    const float fn = (float)n;
+    float m = x0 - __builtin_floorf(x0 / fn) * fn;
+    if (!(m >= 0.0f)) m = 0.0f;
+    const uint32_t i = (uint32_t)m;
+    return i >= n ? n - 1 : i;
+}
+
+PT_DEV f4 sampleLevel(const TextureView &tv, const DevTexture &t, uint32_t level, float u, float v)
+{
+    const uint32_t w = levelDim(t.width, level), h = levelDim(t.height, level);
+    if (w == 1 && h == 1) // exact for 1x1 (hardware weights are fixed point and sum to 1)
+        return fetchTexel(tv, t, level, 0, 0);
+    if (!(abs_(u) < 1e9f)) u = 0.0f;
+    if (!(abs_(v) < 1e9f)) v = 0.0f;
+    const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    const float x0 = __builtin_floorf(x), y0 = __builtin_floorf(y);
+    const float ax = x - x0, ay = y - y0;
+    const uint32_t ix0 = wrapRepeat(x0, w), ix1 = wrapRepeat(x0 + 1.0f, w), iy0 = wrapRepeat(y0, h), iy1 = wrapRepeat(y0 + 1.0f, h);
+    const f4 top = lerp4(fetchTexel(tv, t, level, ix0, iy0), fetchTexel(tv, t, level, ix1, iy0), ax);
+    const f4 bot = lerp4(fetchTexel(tv, t, level, ix0, iy1), fetchTexel(tv, t, level, ix1, iy1), ax);
+    return lerp4(top, bot, ay);
+}
+
+// textureGrad: LOD from the gradients (Vulkan 1.3 spec 16.5.7, isotropic), trilinear
+PT_DEV f4 textureGradSample(const TextureView &tv, const DevTexture &t, float u, float v, float dudx, float dvdx, float dudy, float dvdy)
+{
+    if (t.levels <= 1)
+        return sampleLevel(tv, t, 0, u, v);
+    const float mux = dudx * (float)t.width, mvx = dvdx * (float)t.height;
+    const float muy = dudy * (float)t.width, mvy = dvdy * (float)t.height;
+    const float rx = sqrt_(mux * mux + mvx * mvx), ry = sqrt_(muy * muy + mvy * mvy);
+    const float rho = fmax_(rx, ry);
+    float lod = rho > 0.0f ? (float)log2_((double)rho) : 0.0f;
+    const float q = (float)(t.levels - 1);
+    if (!(lod >= 0.0f)) lod = 0.0f;
+    if (lod > q) lod = q;
+    const float d0 = __builtin_floorf(lod), f = lod - d0;
+    const uint32_t l0 = (uint32_t)d0, l1 = l0 + 1 < t.levels ? l0 + 1 : t.levels - 1;
+    const f4 c0 = sampleLevel(tv, t, l0, u, v);
+    if (f == 0.0f || l1 == l0)
+        return c0;
+    return lerp4(c0, sampleLevel(tv, t, l1, u, v), f);
+}
+
+// ---- material.glsl with the fixed 1x1 default textures ------------------------------------------
+
+// Texels of slots 0..8 after format decode (ShaderRendererTypes.incl:49-56; sRGB for
+// Color/Specular/Emissive, UNORM otherwise: TextureUploader.cpp:571-594).  Scene
+// textures (index >= 9) go through the software sampler (TEX variants); an index past the
+// uploaded table samples as the white placeholder (Renderer.cpp:421-429).
+PT_DEV f4 sampleTexture(uint32_t idx)
+{
+    f4 w;
+    w.x = w.y = w.z = w.w = 1.0f;
+    if (idx == PTX_DEFAULT_NORMAL_TEXTURE_INDEX)
+    {
+        w.x = 128.0f / 255.0f;
+        w.y = 128.0f / 255.0f;
+    }
+    else if (idx == PTX_DEFAULT_EMISSIVE_TEXTURE_INDEX || idx == PTX_DEFAULT_GLOSSINESS_TEXTURE_INDEX ||
+             idx == PTX_DEFAULT_SHININESS_TEXTURE_INDEX)
+        w.x = w.y = w.z = w.w = 0.0f;
+    return w;
+}
+
+PT_DEV f3 ReconstructNormalFromXY(f3 n) // :55-60
+{
+    n = F3(2.0f * n.x - 1.0f, 2.0f * n.y - 1.0f, 2.0f * n.z - 1.0f);
+    return F3(n.x, n.y, sqrt_(fmax_(1 - n.x * n.x - n.y * n.y, 0.0f)));
+}
+
+// textureGrad(textures[idx], uv, dv.xy, dv.zw)
+template <bool TEX>
+PT_DEV f4 sampleTexture(const TextureView &tv, uint32_t idx, f2 uv, f4 dv)
+{
+    if (TEX && idx >= PTX_SCENE_TEXTURE_OFFSET && idx - PTX_SCENE_TEXTURE_OFFSET < tv.textureCount)
+        return textureGradSample(tv, tv.textures[idx - PTX_SCENE_TEXTURE_OFFSET], uv.x, uv.y, dv.x, dv.y, dv.z, dv.w);
+    return sampleTexture(idx);
+}
+
+PT_DEV f3 rgb(f4 t) { return F3(t.x, t.y, t.z); }
+PT_DEV f3 ld3(const float *p) { return F3(p[0], p[1], p[2]); }
+
+struct SceneView // read-only device views of the uploaded scene
+{
+    const PtxVertex *vertices;
+    const uint32_t *indices;
+    const PtxMetallicRoughnessMaterial *mr;
+    const PtxSpecularGlossinessMaterial *sg;
+    const PtxPhongMaterial *phong;
+    const struct DevPair *pairs;
+    const PtxLightsUbo *lights;
+    uint32_t dxNormalTextures;
+    TextureView tex;
+};
+
+// one (instance, mesh): world = A_instance * A_mesh * x (sampling.glsl:5-15); Rinv is
+// the inverse of the linear part, for the inverse-transpose normal transform
+struct DevPair
+{
+    float M[12];
+    float Rinv[9]; // columns c0, c1, c2
+    uint32_t vertexOffset, indexOffset, materialId;
+};
+
+PT_DEV f3 specGlossMetalness(f3 specular, f3 color) // material.glsl:109-110, :138-139
+{
+    return F3(fmax_(specular.x - 0.04f, 0.0f) / ((color.x - 0.04f) + 0.00001f),
+              fmax_(specular.y - 0.04f, 0.0f) / ((color.y - 0.04f) + 0.00001f),
+              fmax_(specular.z - 0.04f, 0.0f) / ((color.z - 0.04f) + 0.00001f));
+}
+
+template <bool TEX>
+PT_DEV MaterialSample sampleMaterial(const SceneView &sv, uint32_t materialId, f2 texCoords, f4 derivatives, bool isHitFromInside) // :144-171
+{
+#define sampleTexture(idx) sampleTexture<TEX>(sv.tex, (idx), texCoords, derivatives)
+    const uint32_t materialType = materialId & 0xffu;
+    const uint32_t materialIndex = materialId >> 8;
+    MaterialSample ret;
+    ret.EmissiveColor = ret.Color = ret.Normal = ret.AttenuationColor = F3s(0.0f);
+    ret.Roughness = ret.Metalness = ret.Transmission = ret.Eta = ret.AttenuationDistance = 0.0f;
+    if (materialType == PTX_MATERIAL_TYPE_METALLIC_ROUGHNESS) // :62-84
+    {
+        const PtxMetallicRoughnessMaterial *m = &sv.mr[materialIndex];
+        ret.EmissiveColor = (rgb(sampleTexture(m->EmissiveIdx)) + ld3(m->EmissiveColor)) * m->EmissiveIntensity;
+        ret.Color = rgb(sampleTexture(m->ColorIdx)) * ld3(m->Color);
+        ret.Normal = ReconstructNormalFromXY(rgb(sampleTexture(m->NormalIdx)));
+        ret.Roughness = sampleTexture(m->RoughnessIdx).y * m->Roughness;
+        ret.Metalness = sampleTexture(m->MetallicIdx).z * m->Metalness;
+        ret.Transmission = m->Transmission;
+        ret.AttenuationColor = ld3(m->AttenuationColor);
+        ret.AttenuationDistance = m->AttenuationDistance;
+        ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
+    }
+    else if (materialType == PTX_MATERIAL_TYPE_SPECULAR_GLOSSINESS) // :86-113
+    {
+        const PtxSpecularGlossinessMaterial *m = &sv.sg[materialIndex];
+        ret.EmissiveColor = (rgb(sampleTexture(m->EmissiveIdx)) + ld3(m->EmissiveColor)) * m->EmissiveIntensity;
+        ret.Color = rgb(sampleTexture(m->ColorIdx)) * ld3(m->Color);
+        ret.Normal = ReconstructNormalFromXY(rgb(sampleTexture(m->NormalIdx)));
+        ret.Transmission = m->Transmission;
+        ret.AttenuationColor = ld3(m->AttenuationColor);
+        ret.AttenuationDistance = m->AttenuationDistance;
+        ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
+        const f3 specular = rgb(sampleTexture(m->SpecularIdx)) * ld3(m->Specular);
+        const float glossiness = sampleTexture(m->GlossinessIdx).w * m->Glossiness;
+        ret.Roughness = 1.0f - glossiness;
+        const f3 diff = specGlossMetalness(specular, ret.Color);
+        ret.Metalness = (diff.x + diff.y + diff.z) / 3.0f;
+    }
+    else if (materialType == PTX_MATERIAL_TYPE_PHONG) // :115-142
+    {
+        const PtxPhongMaterial *m = &sv.phong[materialIndex];
+        ret.EmissiveColor = (rgb(sampleTexture(m->EmissiveIdx)) + ld3(m->EmissiveColor)) * m->EmissiveIntensity;
+        ret.Color = rgb(sampleTexture(m->ColorIdx)) * ld3(m->Color);
+        ret.Normal = ReconstructNormalFromXY(rgb(sampleTexture(m->NormalIdx)));
+        ret.Transmission = m->Transmission;
+        ret.AttenuationColor = ld3(m->AttenuationColor);
+        ret.AttenuationDistance = m->AttenuationDistance;
+        ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
+        const f3 specular = rgb(sampleTexture(m->SpecularIdx)) * ld3(m->Specular);
+        const float shininess = sampleTexture(m->ShininessIdx).w * m->Shininess;
+        ret.Roughness = 1.0f - shininess;
+        const f3 diff = specGlossMetalness(specular, ret.Color);
+        ret.Metalness = (diff.x + diff.y + diff.z) / 3.0f;
+    }
+    else // :163-166
+    {
+        ret.Color = F3(1.0f, 0.0f, 0.0f);
+        ret.EmissiveColor = F3(1.0f, 0.0f, 0.0f);
+    }
+    if (sv.dxNormalTextures)
+        ret.Normal.y *= -1;
+    return ret;
+#undef sampleTexture
+}
+
+// ---- closestHit.rchit ---------------------------------------------------------------------------
+
+struct Vtx
+{
+    f3 Position;
+    f3 Normal, Tangent, Bitangent;
+};
+
+PT_DEV f3 xformPoint(const float *M, f3 p)
+{
+    return F3(((p.x * M[0] + p.y * M[1]) + p.z * M[2]) + M[3], ((p.x * M[4] + p.y * M[5]) + p.z * M[6]) + M[7],
+              ((p.x * M[8] + p.y * M[9]) + p.z * M[10]) + M[11]);
+}
+PT_DEV f3 xformVector(const float *M, f3 p)
+{
+    return F3((p.x * M[0] + p.y * M[1]) + p.z * M[2], (p.x * M[4] + p.y * M[5]) + p.z * M[6],
+              (p.x * M[8] + p.y * M[9]) + p.z * M[10]);
+}
+
+PT_DEV Vtx transformVertex(const DevPair &pr, Vtx v) // sampling.glsl:5-15
+{
+    v.Position = xformPoint(pr.M, v.Position);
+    v.Tangent = normalize(xformVector(pr.M, v.Tangent));
+    v.Bitangent = normalize(xformVector(pr.M, v.Bitangent));
+    v.Normal = normalize(F3(dot(v.Normal, F3(pr.Rinv[0], pr.Rinv[1], pr.Rinv[2])), dot(v.Normal, F3(pr.Rinv[3], pr.Rinv[4], pr.Rinv[5])),
+                            dot(v.Normal, F3(pr.Rinv[6], pr.Rinv[7], pr.Rinv[8]))));
+    return v;
+}
+
+PT_DEV Vtx loadVertex(const PtxVertex *p) // common.glsl:27-46
+{
+    Vtx v;
+    v.Position = ld3(p->Position);
+    v.Normal = ld3(p->Normal);
+    v.Tangent = ld3(p->Tangent);
+    v.Bitangent = ld3(p->Bitangent);
+    return v;
+}
+
+PT_DEV f3 interp3(f3 a, f3 b, f3 c, f3 bc) { return (a * bc.x + b * bc.y) + c * bc.z; } // common.glsl:107-110
+
+// What closestHit.rchit writes into the payload (ShaderRendererTypes.incl:101-118); the ray
+// differentials (RayDifferentials0..2) travel separately as DiffRays, in the TEX variants only.
+struct HitOut
+{
+    f3 Position;
+    f3 Direction;
+    float MaxRoughness;
+    f3 Bsdf;
+    float Pdf;
+    f3 Emissive;
+    f3 DirectLight;
+    float DirectLightPdf;
+    f3 LightDirection;
+    float LightDistance;
+};
+
+// closestHit.rchit:52-161.  (u, v) = hitAttributeEXT barycentrics, t = gl_RayTmaxEXT.
+template <bool TEX>
+PT_DEV void closestHit(const SceneView &sv, f3 rayDirW, float t, float hu, float hv, uint32_t pairIdx, uint32_t prim,
+                       float maxRoughnessIn, uint32_t &rngState, HitOut &out, DiffRays &diff)
+{
+    const f3 bary = F3(1.0f - hu - hv, hu, hv);
+    const DevPair pr = sv.pairs[pairIdx];
+    const uint32_t *ix = sv.indices + pr.indexOffset + prim * 3;
+    const PtxVertex *vb = sv.vertices + pr.vertexOffset;
+    const Vtx o0 = loadVertex(vb + ix[0]), o1 = loadVertex(vb + ix[1]), o2 = loadVertex(vb + ix[2]);
+
+    Vtx ov; // getInterpolatedVertex, common.glsl:112-130
+    ov.Position = interp3(o0.Position, o1.Position, o2.Position, bary);
+    ov.Normal = interp3(o0.Normal, o1.Normal, o2.Normal, bary);
+    ov.Tangent = interp3(o0.Tangent, o1.Tangent, o2.Tangent, bary);
+    ov.Bitangent = interp3(o0.Bitangent, o1.Bitangent, o2.Bitangent, bary);
+    Vtx vertex = transformVertex(pr, ov);
+
+    const Vtx v0 = transformVertex(pr, o0), v1 = transformVertex(pr, o1), v2 = transformVertex(pr, o2);
+
+    const f3 edge1 = v1.Position - v0.Position;
+    const f3 edge2 = v2.Position - v0.Position;
+    f3 geometricNormal = normalize(cross(edge1, edge2));
+
+    const bool isHitFromInside = dot(geometricNormal, rayDirW) > 0.0f;
+    if (isHitFromInside)
+    {
+        geometricNormal = -geometricNormal;
+        vertex.Normal = -vertex.Normal;
+        vertex.Tangent = -vertex.Tangent;
+        vertex.Bitangent = -vertex.Bitangent;
+    }
+
+    // :88-99 texture footprint from the ray differentials
+    f2 texCoords = F2(0.0f, 0.0f);
+    f4 derivatives;
+    derivatives.x = derivatives.y = derivatives.z = derivatives.w = 0.0f;
+    f3 dndu = F3s(0.0f), dndv = F3s(0.0f);
+    if (TEX)
+    {
+        const f2 uv0 = F2(vb[ix[0]].TexCoords[0], vb[ix[0]].TexCoords[1]), uv1 = F2(vb[ix[1]].TexCoords[0], vb[ix[1]].TexCoords[1]),
+                 uv2 = F2(vb[ix[2]].TexCoords[0], vb[ix[2]].TexCoords[1]);
+        texCoords = F2((uv0.x * bary.x + uv1.x * bary.y) + uv2.x * bary.z, (uv0.y * bary.x + uv1.y * bary.y) + uv2.y * bary.z);
+        const f3 P3[3] = { v0.Position, v1.Position, v2.Position }, N3[3] = { v0.Normal, v1.Normal, v2.Normal };
+        const f2 UV3[3] = { uv0, uv1, uv2 };
+        f3 dpdu, dpdv, dpdx, dpdy;
+        computeDpnDuv(P3, N3, UV3, vertex.Tangent, vertex.Bitangent, dpdu, dpdv, dndu, dndv);
+        computeDpDxy(vertex.Position, diff.rxOrigin, diff.rxDirection, diff.ryOrigin, diff.ryDirection, vertex.Normal, dpdx, dpdy);
+        derivatives = computeDerivatives(dpdx, dpdy, dpdu, dpdv);
+    }
+
+    MaterialSample material = sampleMaterial<TEX>(sv, pr.materialId, texCoords, derivatives, isHitFromInside);
+
+    // :105-106 decal mix: never taken for opaque geometry
+
+    out.MaxRoughness = fmax_(material.Roughness, maxRoughnessIn); // :109
+    material.Roughness = fmax_(out.MaxRoughness, 0.01f);          // :112
+
+    mat3 geometryTBN;
+    geometryTBN.c0 = vertex.Tangent;
+    geometryTBN.c1 = vertex.Bitangent;
+    geometryTBN.c2 = vertex.Normal;
+    const f3 N = normalize(vertex.Normal + mul(geometryTBN, material.Normal));
+    const mat3 TBN = computeTangentSpace(N);
+    const mat3 invTBN = inverse(TBN);
+    const f3 V = normalize(mul(invTBN, normalize(-rayDirW)));
+
+    BSDFSample bsdf = sampleBSDF(material, V, rngState);
+
+    if (isHitFromInside) // :123-128
+    {
+        const float e = t / material.AttenuationDistance;
+        bsdf.Color.x *= pow_(material.AttenuationColor.x, e);
+        bsdf.Color.y *= pow_(material.AttenuationColor.y, e);
+        bsdf.Color.z *= pow_(material.AttenuationColor.z, e);
+    }
+
+    const bool isRefracted = bsdf.Direction.z < 0.0f;
+    const f3 rayOrigin = offsetRayOriginShadowTerminator(vertex.Position, v0.Position, v0.Normal, v1.Position, v1.Normal,
+                                                         v2.Position, v2.Normal, bary, isRefracted);
+
+    float lightPdf, lightSmplPdf;
+    f3 u3;
+    u3.x = rnd(rngState);
+    u3.y = rnd(rngState);
+    u3.z = rnd(rngState);
+    const LightSample light = sampleLight(sv.lights, u3, rayOrigin, lightPdf);
+    const f3 L = normalize(mul(invTBN, -light.Direction));
+    const f3 lightBsdf = evaluateBSDF(material, V, L, lightSmplPdf);
+
+    out.Direction = normalize(mul(TBN, bsdf.Direction));
+    if (isRefracted)
+        out.Position = offsetRayOriginSelfIntersection(vertex.Position, -geometricNormal);
+    else
+        out.Position = rayOrigin;
+    out.Bsdf = bsdf.Color;
+    out.Pdf = bsdf.Pdf;
+    out.Emissive = material.EmissiveColor;
+    out.DirectLight = (light.Color * light.Attenuation) * lightBsdf;
+    out.DirectLightPdf = lightPdf;
+    out.LightDirection = light.Direction;
+    out.LightDistance = light.Distance;
+
+    if (TEX) // :150-160 differentials of the continuation ray
+    {
+        if (isRefracted)
+            computeRefractedDifferentialRays(derivatives, vertex.Normal, rayOrigin, -rayDirW, out.Direction, dndu, dndv, material.Eta, diff);
+        else
+            computeReflectedDifferentialRays(derivatives, vertex.Normal, rayOrigin, -rayDirW, out.Direction, dndu, dndv, diff);
+    }
 }
 
 // ---- ray / triangle --------------------------------------------------------------------------------

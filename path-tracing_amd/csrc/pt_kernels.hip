@@ -50,6 +50,7 @@ struct Wavefront // device pointers of the per-slot state (SoA)
     float4 *shD;    // shadow direction.xyz, w = 1 if the path ends after this bounce
     float4 *shC;    // NEE contribution throughput * DirectLight / DirectLightPdf
     float4 *slotRad; // final radiance of the slot (consumed by k_accumulate)
+    float4 *diff[3]; // payload.RayDifferentials0..2 (rx origin, rx dir, ry origin, ry dir); null unless the scene has textures
     uint32_t *queue[2];
     uint32_t *shadowQueue;
     uint32_t *restartQueue;
@@ -98,23 +99,64 @@ PT_DEV uint32_t slotPixel(const LaunchParams &p, uint32_t slotInFrame)
     return y * p.width + x;
 }
 
-// raygen.rgen:44-60: start one sample of a slot (jitter draws, primary ray)
-PT_DEV void startSample(const LaunchParams &p, uint32_t pixel, uint32_t &rng, f3 &origin, f3 &direction)
+// raygen.rgen:44-60: start one sample of a slot (jitter draws, primary ray; with DIFF also the
+// offset rays of raygen.rgen:56-58)
+template <bool DIFF>
+PT_DEV void startSample(const LaunchParams &p, uint32_t pixel, uint32_t &rng, f3 &origin, f3 &direction, DiffRays &diff)
 {
     f2 u;
     u.x = rnd(rng);
     u.y = rnd(rng);
     const uint32_t px = pixel % p.width, py = pixel / p.width;
+    f3 rx = F3s(0.0f), ry = F3s(0.0f);
     if (p.u.LensRadius > 0)
     {
         f2 u2;
         u2.x = rnd(rng);
         u2.y = rnd(rng);
-        constructPrimaryRayLens(px, py, p.width, p.height, p.u.ViewInverse, p.u.ProjInverse, u, u2, p.u.LensRadius,
-                                p.u.FocalDistance, origin, direction);
+        constructPrimaryRayLens<DIFF>(px, py, p.width, p.height, p.u.ViewInverse, p.u.ProjInverse, u, u2, p.u.LensRadius, p.u.FocalDistance,
+                                      origin, direction, rx, ry);
     }
     else
-        constructPrimaryRay(px, py, p.width, p.height, p.u.ViewInverse, p.u.ProjInverse, u, origin, direction);
+        constructPrimaryRay<DIFF>(px, py, p.width, p.height, p.u.ViewInverse, p.u.ProjInverse, u, origin, direction, rx, ry);
+    if (DIFF)
+    {
+        diff.rxOrigin = origin;
+        diff.rxDirection = rx;
+        diff.ryOrigin = origin;
+        diff.ryDirection = ry;
+    }
+}
+
+// the payload packing of raygen.rgen:56-58 / closestHit.rchit:157-159
+PT_DEV void storeDiff(const Wavefront &wf, uint32_t slot, const DiffRays &d)
+{
+    wf.diff[0][slot] = make_float4(d.rxOrigin.x, d.rxOrigin.y, d.rxOrigin.z, d.rxDirection.x);
+    wf.diff[1][slot] = make_float4(d.rxDirection.y, d.rxDirection.z, d.ryOrigin.x, d.ryOrigin.y);
+    wf.diff[2][slot] = make_float4(d.ryOrigin.z, d.ryDirection.x, d.ryDirection.y, d.ryDirection.z);
+}
+PT_DEV DiffRays loadDiff(const Wavefront &wf, uint32_t slot)
+{
+    const float4 a = wf.diff[0][slot], b = wf.diff[1][slot], c = wf.diff[2][slot];
+    DiffRays d;
+    d.rxOrigin = F3(a.x, a.y, a.z);
+    d.rxDirection = F3(a.w, b.x, b.y);
+    d.ryOrigin = F3(b.z, b.w, c.x);
+    d.ryDirection = F3(c.y, c.z, c.w);
+    return d;
+}
+
+// new primary ray of a slot; the differentials go straight to the slot state when the scene carries them
+PT_DEV void startSlotSample(const LaunchParams &p, const Wavefront &wf, uint32_t slot, uint32_t pixel, uint32_t &rng, f3 &o, f3 &d)
+{
+    DiffRays diff;
+    if (wf.diff[0])
+    {
+        startSample<true>(p, pixel, rng, o, d, diff);
+        storeDiff(wf, slot, diff);
+    }
+    else
+        startSample<false>(p, pixel, rng, o, d, diff);
 }
 
 PT_DEV bool badRadiance(f3 r) // raygen.rgen:101,107
@@ -173,7 +215,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(LaunchParams p, Wavefront w
         {
             uint32_t rng = initRng(pixel % p.width, pixel / p.width, p.width, frame); // raygen.rgen:38
             f3 o, d;
-            startSample(p, pixel, rng, o, d);
+            startSlotSample(p, wf, slot, pixel, rng, o, d);
             meta.x = rng;
             wf.rayO[slot] = make_float4(o.x, o.y, o.z, 0.0f); // MaxRoughness = 0, raygen.rgen:60
             wf.rayD[slot] = make_float4(d.x, d.y, d.z, 0.0f);
@@ -244,7 +286,7 @@ PT_DEV bool finishSample(const LaunchParams &p, const Wavefront &wf, uint32_t sl
     if (smpl < p.u.SampleCount)
     {
         f3 o, d;
-        startSample(p, meta.y, meta.x, o, d);
+        startSlotSample(p, wf, slot, meta.y, meta.x, o, d);
         meta.z = smpl << 16; // bounce = 0
         wf.rayO[slot] = make_float4(o.x, o.y, o.z, 0.0f);
         wf.rayD[slot] = make_float4(d.x, d.y, d.z, 0.0f);
@@ -256,6 +298,7 @@ PT_DEV bool finishSample(const LaunchParams &p, const Wavefront &wf, uint32_t sl
     return false;
 }
 
+template <bool TEX>
 __global__ void __launch_bounds__(kBlock) k_shade(LaunchParams p, SceneView sv, Wavefront wf, int qin)
 {
     __shared__ uint32_t s_cnt[2], s_base[2];
@@ -289,7 +332,10 @@ __global__ void __launch_bounds__(kBlock) k_shade(LaunchParams p, SceneView sv, 
             {
                 const float4 o4 = wf.rayO[slot], d4 = wf.rayD[slot];
                 HitOut out;
-                closestHit(sv, F3(d4.x, d4.y, d4.z), hit.x, hit.y, hit.z, pair, __float_as_uint(hit.w), o4.w, meta.x, out);
+                DiffRays diff;
+                if (TEX)
+                    diff = loadDiff(wf, slot);
+                closestHit<TEX>(sv, F3(d4.x, d4.y, d4.z), hit.x, hit.y, hit.z, pair, __float_as_uint(hit.w), o4.w, meta.x, out, diff);
                 nHits++;
 
                 radiance = radiance + throughput * out.Emissive; // raygen.rgen:77
@@ -339,6 +385,8 @@ __global__ void __launch_bounds__(kBlock) k_shade(LaunchParams p, SceneView sv, 
                         wf.rayO[slot] = make_float4(out.Position.x, out.Position.y, out.Position.z, out.MaxRoughness);
                         wf.rayD[slot] = make_float4(out.Direction.x, out.Direction.y, out.Direction.z, 0.0f);
                         wf.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, 0.0f);
+                        if (TEX)
+                            storeDiff(wf, slot, diff);
                         pushNext = true; // a pending shadow query only adds to rad[slot] before the next bounce
                     }
                 }
@@ -469,8 +517,9 @@ struct PathCounters
 
 // Runs a slot to the end of its launch.  `fresh` = start with a new sample (primary ray);
 // otherwise continue the current sample at `bounce` with the given ray / throughput.
+template <bool TEX>
 PT_DEV f3 runPath(const LaunchParams &p, const SceneView &sv, const TraceScene &sc, Stack &st, uint32_t pixel, uint32_t &rng,
-                  f3 radiance, f3 throughput, f3 ro, f3 rd, float maxRoughness, uint32_t bounce, int smpl, bool fresh,
+                  f3 radiance, f3 throughput, f3 ro, f3 rd, DiffRays diff, float maxRoughness, uint32_t bounce, int smpl, bool fresh,
                   PathCounters &pc)
 {
     for (;;)
@@ -480,7 +529,7 @@ PT_DEV f3 runPath(const LaunchParams &p, const SceneView &sv, const TraceScene &
             if (smpl >= (int)p.u.SampleCount)
                 break;
             throughput = F3s(1.0f);
-            startSample(p, pixel, rng, ro, rd);
+            startSample<TEX>(p, pixel, rng, ro, rd, diff);
             maxRoughness = 0.0f;
             bounce = 0;
             fresh = false;
@@ -495,7 +544,7 @@ PT_DEV f3 runPath(const LaunchParams &p, const SceneView &sv, const TraceScene &
                 break;
             }
             HitOut out;
-            closestHit(sv, rd, h.t, h.u, h.v, h.pair, h.prim, maxRoughness, rng, out);
+            closestHit<TEX>(sv, rd, h.t, h.u, h.v, h.pair, h.prim, maxRoughness, rng, out, diff);
             pc.nHit++;
             maxRoughness = out.MaxRoughness;
             radiance = radiance + throughput * out.Emissive;
@@ -534,6 +583,7 @@ PT_DEV f3 runPath(const LaunchParams &p, const SceneView &sv, const TraceScene &
     return radiance;
 }
 
+template <bool TEX>
 __global__ void __launch_bounds__(kBlock) k_megakernel(LaunchParams p, SceneView sv, TraceScene sc, float4 *__restrict__ slotRad,
                                                         uint32_t *__restrict__ counters)
 {
@@ -546,7 +596,9 @@ __global__ void __launch_bounds__(kBlock) k_megakernel(LaunchParams p, SceneView
     if (pixel != 0xffffffffu)
     {
         uint32_t rng = initRng(pixel % p.width, pixel / p.width, p.width, p.firstFrame + f);
-        radiance = runPath(p, sv, sc, st, pixel, rng, F3s(0.0f), F3s(1.0f), F3s(0.0f), F3s(0.0f), 0.0f, 0u, 0, true, pc);
+        DiffRays diff;
+        diff.rxOrigin = diff.rxDirection = diff.ryOrigin = diff.ryDirection = F3s(0.0f);
+        radiance = runPath<TEX>(p, sv, sc, st, pixel, rng, F3s(0.0f), F3s(1.0f), F3s(0.0f), F3s(0.0f), diff, 0.0f, 0u, 0, true, pc);
     }
     if (slot < p.numSlots)
         slotRad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
@@ -560,6 +612,7 @@ __global__ void __launch_bounds__(kBlock) k_megakernel(LaunchParams p, SceneView
 
 // The slots of queue `qin` sit at a bounce boundary (ray, throughput, radiance, RNG and
 // bounce/sample counters in the SoA state, no shadow query pending): run each to the end.
+template <bool TEX>
 __global__ void __launch_bounds__(kBlock) k_tail(LaunchParams p, SceneView sv, TraceScene sc, Wavefront wf, int qin, uint32_t count)
 {
     PT_DECLARE_STACK(st, kLdsStackMega, (uint32_t *)nullptr)
@@ -573,8 +626,13 @@ __global__ void __launch_bounds__(kBlock) k_tail(LaunchParams p, SceneView sv, T
             const uint4 meta = wf.meta[slot];
             const float4 o4 = wf.rayO[slot], d4 = wf.rayD[slot], t4 = wf.thr[slot], r4 = wf.rad[slot];
             uint32_t rng = meta.x;
-            const f3 radiance = runPath(p, sv, sc, st, meta.y, rng, F3(r4.x, r4.y, r4.z), F3(t4.x, t4.y, t4.z), F3(o4.x, o4.y, o4.z),
-                                        F3(d4.x, d4.y, d4.z), o4.w, meta.z & 0xffffu, (int)(meta.z >> 16), false, pc);
+            DiffRays diff;
+            if (TEX)
+                diff = loadDiff(wf, slot);
+            else
+                diff.rxOrigin = diff.rxDirection = diff.ryOrigin = diff.ryDirection = F3s(0.0f);
+            const f3 radiance = runPath<TEX>(p, sv, sc, st, meta.y, rng, F3(r4.x, r4.y, r4.z), F3(t4.x, t4.y, t4.z), F3(o4.x, o4.y, o4.z),
+                                             F3(d4.x, d4.y, d4.z), diff, o4.w, meta.z & 0xffffu, (int)(meta.z >> 16), false, pc);
             wf.slotRad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
         }
     }
@@ -710,9 +768,9 @@ __global__ void k_test_texture(TextureView tv, const float *__restrict__ in, flo
 // function-level entry (Path-Tracing-Tests/TestRenderer.cpp:79-105 dispatches a compute
 // shader that calls the production functions; packing documented in include/ptx.h)
 __constant__ int c_inStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4 };
-__constant__ int c_outStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 6, 2, 1, 9, 3, 6, 12, 6, 4, 12, 12, 1 };
+__constant__ int c_outStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1 };
 static const int h_inStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4 };
-static const int h_outStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 6, 2, 1, 9, 3, 6, 12, 6, 4, 12, 12, 1 };
+static const int h_outStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1 };
 
 PT_DEV MaterialSample unpackMaterial(const float *p)
 {
@@ -815,9 +873,11 @@ __global__ void k_test_eval(uint32_t fn, const float *__restrict__ in, float *__
     }
     case PTX_FN_PRIMARY_RAY: {
         f2 u; u.x = a[4]; u.y = a[5];
-        f3 ro, rd;
-        constructPrimaryRay(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3]), &a[6], &a[22], u, ro, rd);
-        o[0] = ro.x; o[1] = ro.y; o[2] = ro.z; o[3] = rd.x; o[4] = rd.y; o[5] = rd.z;
+        f3 ro, rd, rx, ry;
+        constructPrimaryRay<true>(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3]), &a[6], &a[22], u, ro, rd,
+                                  rx, ry);
+        const f3 v[6] = { ro, rd, ro, rx, ro, ry };
+        for (int k = 0; k < 6; k++) { o[3 * k] = v[k].x; o[3 * k + 1] = v[k].y; o[3 * k + 2] = v[k].z; }
         break;
     }
     case PTX_FN_SINCOS: sincos_(a[0], o[0], o[1]); break;
@@ -856,10 +916,11 @@ __global__ void k_test_eval(uint32_t fn, const float *__restrict__ in, float *__
     }
     case PTX_FN_PRIMARY_RAY_LENS: {
         f2 u, u2; u.x = a[4]; u.y = a[5]; u2.x = a[6]; u2.y = a[7];
-        f3 ro, rd;
-        constructPrimaryRayLens(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3]), &a[10], &a[26],
-                                u, u2, a[8], a[9], ro, rd);
-        o[0] = ro.x; o[1] = ro.y; o[2] = ro.z; o[3] = rd.x; o[4] = rd.y; o[5] = rd.z;
+        f3 ro, rd, rx, ry;
+        constructPrimaryRayLens<true>(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3]), &a[10], &a[26],
+                                      u, u2, a[8], a[9], ro, rd, rx, ry);
+        const f3 v[6] = { ro, rd, ro, rx, ro, ry };
+        for (int k = 0; k < 6; k++) { o[3 * k] = v[k].x; o[3 * k + 1] = v[k].y; o[3 * k + 2] = v[k].z; }
         break;
     }
     case PTX_FN_DPN_DUV: {
@@ -967,6 +1028,7 @@ struct PtxRenderer
     DevBuf<float4> texelsF;
     DevBuf<float> srgbLut;
     uint32_t textureCount = 0;
+    bool samplerNeeded = false; // some uploaded texture is not a 1x1 white placeholder
     uint32_t pairCount = 0, triCount = 0, dxNormalTextures = 0;
     bool sceneReady = false, accelReady = false;
 
@@ -983,6 +1045,8 @@ struct PtxRenderer
     // wavefront state
     size_t slotCapacity = 0;
     DevBuf<float4> rayO, rayD, thr, rad, hit, shO, shD, shC, slotRad;
+    DevBuf<float4> diffs; // 3 x slotCapacity ray differentials, only for scenes with textures
+    size_t diffCapacity = 0;
     DevBuf<uint4> meta;
     DevBuf<uint32_t> hitPair, queue0, queue1, shadowQueue, restartQueue, counters, spill, spillAux;
     uint32_t *hostCounters = nullptr; // pinned
@@ -1148,7 +1212,7 @@ void ptx_destroy(PtxRenderer *r)
     r->vertices.release(); r->indices.release(); r->mr.release(); r->sg.release(); r->phong.release();
     r->pairs.release(); r->pairFirst.release(); r->lights.release(); r->nodes.release(); r->tris.release();
     r->image.release(); r->rayO.release(); r->rayD.release(); r->thr.release(); r->rad.release(); r->hit.release();
-    r->shO.release(); r->shD.release(); r->shC.release(); r->slotRad.release(); r->meta.release(); r->hitPair.release();
+    r->shO.release(); r->shD.release(); r->shC.release(); r->slotRad.release(); r->diffs.release(); r->diffCapacity = 0; r->meta.release(); r->hitPair.release();
     r->queue0.release(); r->queue1.release(); r->shadowQueue.release(); r->counters.release(); r->spill.release(); r->spillAux.release(); r->restartQueue.release();
     r->testIn.release(); r->testOut.release(); r->testUbo.release();
     for (int b = 0; b < r->batchesReady; b++)
@@ -1353,6 +1417,21 @@ int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *s)
         HIP_TRY(r, r->textures.alloc(r->textureCount));
         HIP_TRY(r, r->texels8.alloc(n8));
         HIP_TRY(r, r->texelsF.alloc(nf));
+        if (n8)
+            HIP_TRY(r, hipMemsetAsync(r->texels8.p, 0, n8 * 4, r->stream)); // a texture without data reads as zeros
+        if (nf)
+            HIP_TRY(r, hipMemsetAsync(r->texelsF.p, 0, nf * 16, r->stream));
+        // A 1x1 opaque-white 8-bit texture decodes to exactly (1,1,1,1) in both formats, which is what the
+        // kernels without the sampler return for any index >= 9: only other content needs the TEX variants.
+        r->samplerNeeded = false;
+        for (uint32_t i = 0; i < r->textureCount; i++)
+        {
+            const PtxTextureDesc &d = s->textures[i];
+            const bool whitePlaceholder = table[i].width == 1 && table[i].height == 1 && d.format != PTX_TEXTURE_RGBA32F && d.data &&
+                                          *static_cast<const uint32_t *>(d.data) == 0xffffffffu;
+            if (!whitePlaceholder)
+                r->samplerNeeded = true;
+        }
         if (r->textureCount)
             HIP_TRY(r, hipMemcpyAsync(r->textures.p, table.data(), table.size() * sizeof(DevTexture), hipMemcpyHostToDevice, r->stream));
         TextureView tv;
@@ -1502,6 +1581,11 @@ int ptx_reset_accumulation(PtxRenderer *r)
 
 static int ensureSlots(PtxRenderer *r, size_t slots)
 {
+    if (r->samplerNeeded && r->diffCapacity < std::max(slots, r->slotCapacity))
+    {
+        HIP_TRY(r, r->diffs.alloc(3 * std::max(slots, r->slotCapacity)));
+        r->diffCapacity = std::max(slots, r->slotCapacity);
+    }
     if (slots <= r->slotCapacity)
         return PTX_OK;
     HIP_TRY(r, r->slotRad.alloc(slots));
@@ -1568,6 +1652,9 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
     SceneView sv;
     sv.vertices = r->vertices.p; sv.indices = r->indices.p; sv.mr = r->mr.p; sv.sg = r->sg.p; sv.phong = r->phong.p;
     sv.pairs = r->pairs.p; sv.lights = r->lights.p; sv.dxNormalTextures = r->dxNormalTextures;
+    sv.tex.textures = r->textures.p; sv.tex.textureCount = r->textureCount; sv.tex.texels8 = r->texels8.p; sv.tex.texelsF = r->texelsF.p;
+    sv.tex.srgbLut = r->srgbLut.p;
+    const bool textured = r->samplerNeeded; // TEX kernel variants: ray differentials + textureGrad
     TraceScene sc;
     sc.nodes = r->nodes.p; sc.tris = r->tris.p; sc.triCount = r->triCount;
 
@@ -1585,7 +1672,10 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
 
     if (r->backend == PTX_BACKEND_MEGAKERNEL)
     {
-        k_megakernel<<<(p.numSlots + kBlock - 1) / kBlock, kBlock, 0, r->stream>>>(p, sv, sc, r->slotRad.p, r->counters.p);
+        if (textured)
+            k_megakernel<true><<<(p.numSlots + kBlock - 1) / kBlock, kBlock, 0, r->stream>>>(p, sv, sc, r->slotRad.p, r->counters.p);
+        else
+            k_megakernel<false><<<(p.numSlots + kBlock - 1) / kBlock, kBlock, 0, r->stream>>>(p, sv, sc, r->slotRad.p, r->counters.p);
         k_accumulate<<<gridFor(p.slotsPerFrame), kBlock, 0, r->stream>>>(p, r->slotRad.p, imagePtr(r));
         HIP_TRY(r, hipMemcpyAsync(r->hostCounters, r->counters.p, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
         HIP_TRY(r, hipEventRecord(r->evB, r->stream));
@@ -1658,6 +1748,8 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
         wf.shO = r->shO.p + off; wf.shD = r->shD.p + off; wf.shC = r->shC.p + off; wf.slotRad = r->slotRad.p + off;
         wf.queue[0] = r->queue0.p + off; wf.queue[1] = r->queue1.p + off; wf.shadowQueue = r->shadowQueue.p + off;
         wf.restartQueue = r->restartQueue.p + off;
+        for (int k = 0; k < 3; k++)
+            wf.diff[k] = textured ? r->diffs.p + (size_t)k * r->diffCapacity + off : nullptr;
         wf.counters = bt.res->dCounters;
         wf.spill = bt.res->spill;
         bt.wfAux = wf;
@@ -1690,7 +1782,10 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
         HIP_TRY(r, hipEventRecord(q.evT1, q.s));
         if (bt.shadowPending) // k_shade reads rad[slot]: the previous bounce's shadow adds must have landed
             HIP_TRY(r, hipStreamWaitEvent(q.s, q.evShadow[bt.shadowSlot], 0));
-        k_shade<<<gridFor(bt.active), kBlock, 0, q.s>>>(bt.p, sv, bt.wf, bt.qin);
+        if (textured)
+            k_shade<true><<<gridFor(bt.active), kBlock, 0, q.s>>>(bt.p, sv, bt.wf, bt.qin);
+        else
+            k_shade<false><<<gridFor(bt.active), kBlock, 0, q.s>>>(bt.p, sv, bt.wf, bt.qin);
         HIP_TRY(r, hipEventRecord(q.evT2, q.s));
         HIP_TRY(r, hipEventRecord(q.evShade, q.s));
         HIP_TRY(r, hipMemcpyAsync(q.hCounters, q.dCounters, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, q.s));
@@ -1716,7 +1811,10 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
             if (bt.shadowPending) // k_tail continues from rad[slot]
                 HIP_TRY(r, hipStreamWaitEvent(q.s, q.evShadow[bt.shadowSlot], 0));
             HIP_TRY(r, hipEventRecord(q.evT0, q.s));
-            k_tail<<<gridFor(bt.active, kBlock, 1u << 20), kBlock, 0, q.s>>>(bt.p, sv, sc, bt.wf, bt.qin, bt.active);
+            if (textured)
+                k_tail<true><<<gridFor(bt.active, kBlock, 1u << 20), kBlock, 0, q.s>>>(bt.p, sv, sc, bt.wf, bt.qin, bt.active);
+            else
+                k_tail<false><<<gridFor(bt.active, kBlock, 1u << 20), kBlock, 0, q.s>>>(bt.p, sv, sc, bt.wf, bt.qin, bt.active);
             HIP_TRY(r, hipEventRecord(q.evT1, q.s));
             HIP_TRY(r, hipMemcpyAsync(q.hCounters, q.dCounters, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, q.s));
             HIP_TRY(r, hipEventRecord(q.evReady, q.s));

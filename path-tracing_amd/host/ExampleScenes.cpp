@@ -989,7 +989,7 @@ void CreateTextureTestScene(SceneBuilder &sb, uint32_t seed)
     const auto lampMat = sb.AddMaterial("Lamp", lamp);
 
     // floor: uv tiled 6x (minification at the far end), built as a grid so uv varies per vertex
-    const uint32_t floor = AddGridSurface(sb, 8, 8, false, [](float u, float v) { return Vec3(-6.0f + 12.0f * u, 0.0f, -6.0f + 12.0f * v); }, true);
+    const uint32_t floor = AddGridSurface(sb, 8, 8, false, [](float u, float v) { return Vec3(-6.0f + 12.0f * u, 0.0f, -6.0f + 12.0f * v); });
     {
         auto &vertices = sb.GetVertices();
         for (size_t k = vertices.size() - 81; k < vertices.size(); k++)

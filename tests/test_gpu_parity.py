@@ -149,27 +149,7 @@ def test_empty_scene_renders_sky(pkg):
 # ---------------------------------------------------------------------------------------
 # image level
 # ---------------------------------------------------------------------------------------
-def _render_pair(pkg, orc, name, detail, W, H, frames, depth, backend=0, brute=False, lens=0.0):
-    scene = pkg.Scene(name, detail)
-    lights = scene.lights
-    r = pkg.Renderer(backend=backend)
-    r.upload(scene)
-    r.resize(W, H)
-    osc = orc.OracleScene(scene.desc, build_bvh=not brute)
-    ref = np.zeros((H, W, 4), np.float32)
-    seg = shadow = 0
-    for f in range(frames):
-        u = scene.uniform(W, H, bounces=depth, sample_count=1, total_samples=f, lens_radius=lens, focal_distance=6.0)
-        r.render(u, lights)
-        st = r.stats()
-        _, ost = osc.render(u, lights, W, H, accum=ref, brute_force=brute)
-        assert st.segments == ost.segments and st.shadowRays == ost.shadowRays, "segment counts differ"
-        assert st.pathSamples == ost.pathSamples and st.retries == ost.retries
-        seg += st.segments
-        shadow += st.shadowRays
-    img = r.readback()
-    r.close()
-    return img, ref
+_render_pair = util.render_pair
 
 
 @pytest.mark.parametrize("backend", [0, 1])

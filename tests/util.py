@@ -79,3 +79,28 @@ def random_rays(rng, n, lo, hi, tmax=1e4):
     rays[:, 4:7] = d
     rays[:, 7] = tmax
     return rays
+
+
+def render_pair(pkg, orc, name, detail, W, H, frames, depth, backend=0, brute=False, lens=0.0, sample_count=1):
+    """Render `frames` launches with the HIP path and with the oracle; returns both accumulation images
+    after checking that segment / shadow-ray / sample / retry counts agree launch by launch."""
+    scene = pkg.Scene(name, detail)
+    lights = scene.lights
+    r = pkg.Renderer(backend=backend)
+    r.upload(scene)
+    r.resize(W, H)
+    osc = orc.OracleScene(scene.desc, build_bvh=not brute)
+    ref = np.zeros((H, W, 4), np.float32)
+    seg = shadow = 0
+    for f in range(frames):
+        u = scene.uniform(W, H, bounces=depth, sample_count=sample_count, total_samples=f * sample_count, lens_radius=lens, focal_distance=6.0)
+        r.render(u, lights)
+        st = r.stats()
+        _, ost = osc.render(u, lights, W, H, accum=ref, brute_force=brute)
+        assert st.segments == ost.segments and st.shadowRays == ost.shadowRays, "segment counts differ"
+        assert st.pathSamples == ost.pathSamples and st.retries == ost.retries
+        seg += st.segments
+        shadow += st.shadowRays
+    img = r.readback()
+    r.close()
+    return img, ref
