@@ -700,6 +700,7 @@ typedef struct Pair /* one (instance, mesh) */
     float M[12];   /* A_instance * A_mesh, 3 rows x 4 (sampling.glsl:5-15 derivation) */
     m3 Rinv;       /* inverse of the linear part, for the normal transform             */
     uint32_t vertexOffset, indexOffset, materialId, firstTri;
+    uint32_t nonOpaque; /* geometry without VK_GEOMETRY_OPAQUE_BIT: any-hit shaders run (AccelerationStructure.cpp:94-97) */
 } Pair;
 
 typedef struct BvhNode
@@ -827,6 +828,7 @@ PtoScene *pto_scene_create(const PtxSceneDesc *desc, int wantBvh)
             pr->indexOffset = g->IndexOffset;
             pr->materialId = rec->MaterialId;
             pr->firstTri = (uint32_t)t;
+            pr->nonOpaque = g->IsOpaque ? 0u : 1u;
             const uint32_t nprim = g->IndexLength / 3;
             for (uint32_t q = 0; q < nprim; q++, t++)
             {
@@ -902,14 +904,42 @@ static inline int intersectTri(const float *v0, const float *e1, const float *e2
     return 1;
 }
 
+/* What anyhit.rahit leaves in the payload: the nearest ignored (alpha < 0.5) hit.  The any-hit
+ * invocation order is the driver's; the nearest one (ties: smaller triangle id) is the only
+ * order-independent reading of anyhit.rahit:54-61 that closestHit.rchit:105-106 can observe. */
+typedef struct Decal
+{
+    float dist; /* -1 = none (payload.DirectLightPdf) */
+    v3 color;   /* payload.LightDirection             */
+    float alpha; /* payload.LightDistance             */
+    uint32_t tri;
+} Decal;
+
+static v4 hitBaseColor(const PtoScene *s, uint32_t tri, float u, float v);
+
 /* closest hit: min t, ties broken by the smaller global triangle id */
-static inline void considerTri(const PtoScene *s, uint32_t tri, v3 o, v3 d, float tmin, float tmax, PtoHit *best)
+static inline void considerTri(const PtoScene *s, uint32_t tri, v3 o, v3 d, float tmin, float tmax, PtoHit *best, Decal *decal)
 {
     float t, u, v;
     const float lim = best->tri == 0xffffffffu ? tmax : best->t;
     /* accept t == best.t only for a smaller id: test against nextafter(lim) via <= below */
     if (!intersectTri(&s->v0[tri * 3], &s->e1[tri * 3], &s->e2[tri * 3], o, d, tmin, tmax, &t, &u, &v))
         return;
+    if (s->pairs[s->triPair[tri]].nonOpaque) /* anyhit.rahit:36-64 */
+    {
+        const v4 color = hitBaseColor(s, tri, u, v);
+        if (color.w < 0.5f)
+        {
+            if (decal && (decal->dist == -1.0f || t < decal->dist || (t == decal->dist && tri < decal->tri)))
+            {
+                decal->dist = t;
+                decal->color = V3(color.x, color.y, color.z);
+                decal->alpha = color.w;
+                decal->tri = tri;
+            }
+            return; /* ignoreIntersectionEXT */
+        }
+    }
     if (best->tri == 0xffffffffu || t < lim || (t == lim && tri < best->tri))
     {
         best->t = t;
@@ -1120,16 +1150,18 @@ static inline int slab(const BvhNode *n, v3 o, v3 id, float tmin, float tmax, fl
     return lo <= hi * 1.0000004f;
 }
 
-static PtoHit traceClosest(const PtoScene *s, v3 o, v3 d, float tmin, float tmax, int brute, PtoStats *st)
+static PtoHit traceClosest(const PtoScene *s, v3 o, v3 d, float tmin, float tmax, int brute, PtoStats *st, Decal *decal)
 {
     PtoHit best;
+    if (decal)
+        decal->dist = -1.0f;
     best.t = tmax;
     best.u = best.v = 0.0f;
     best.tri = 0xffffffffu;
     if (brute || !s->nodes)
     {
         for (uint32_t t = 0; t < s->triCount; t++)
-            considerTri(s, t, o, d, tmin, tmax, &best);
+            considerTri(s, t, o, d, tmin, tmax, &best, decal);
         if (st)
             st->trisTested += s->triCount;
         return best;
@@ -1150,7 +1182,7 @@ static PtoHit traceClosest(const PtoScene *s, v3 o, v3 d, float tmin, float tmax
         if (n->count)
         {
             for (uint32_t i = 0; i < n->count; i++)
-                considerTri(s, s->bvhTris[n->left + i], o, d, tmin, tmax, &best);
+                considerTri(s, s->bvhTris[n->left + i], o, d, tmin, tmax, &best, decal);
             if (st)
                 st->trisTested += n->count;
         }
@@ -1163,13 +1195,21 @@ static PtoHit traceClosest(const PtoScene *s, v3 o, v3 d, float tmin, float tmax
     return best;
 }
 
+/* occlusionAnyhit.rahit:35-53: a shadow ray passes through any hit whose alpha is below 1 */
+static inline int occlusionIgnores(const PtoScene *s, uint32_t tri, float u, float v)
+{
+    if (!s->pairs[s->triPair[tri]].nonOpaque)
+        return 0;
+    return hitBaseColor(s, tri, u, v).w < 1.0f;
+}
+
 static int traceAny(const PtoScene *s, v3 o, v3 d, float tmin, float tmax, int brute, PtoStats *st)
 {
     float t, u, v;
     if (brute || !s->nodes)
     {
         for (uint32_t i = 0; i < s->triCount; i++)
-            if (intersectTri(&s->v0[i * 3], &s->e1[i * 3], &s->e2[i * 3], o, d, tmin, tmax, &t, &u, &v))
+            if (intersectTri(&s->v0[i * 3], &s->e1[i * 3], &s->e2[i * 3], o, d, tmin, tmax, &t, &u, &v) && !occlusionIgnores(s, i, u, v))
                 return 1;
         return 0;
     }
@@ -1190,7 +1230,7 @@ static int traceAny(const PtoScene *s, v3 o, v3 d, float tmin, float tmax, int b
             for (uint32_t i = 0; i < n->count; i++)
             {
                 const uint32_t tr = s->bvhTris[n->left + i];
-                if (intersectTri(&s->v0[tr * 3], &s->e1[tr * 3], &s->e2[tr * 3], o, d, tmin, tmax, &t, &u, &v))
+                if (intersectTri(&s->v0[tr * 3], &s->e1[tr * 3], &s->e2[tr * 3], o, d, tmin, tmax, &t, &u, &v) && !occlusionIgnores(s, tr, u, v))
                     return 1;
             }
         }
@@ -1209,7 +1249,7 @@ void pto_trace_closest(const PtoScene *s, const float *rays, uint32_t n, PtoHit 
     for (int64_t i = 0; i < (int64_t)n; i++)
     {
         const float *r = &rays[i * 8];
-        hits[i] = traceClosest(s, V3(r[0], r[1], r[2]), V3(r[4], r[5], r[6]), r[3], r[7], brute, NULL);
+        hits[i] = traceClosest(s, V3(r[0], r[1], r[2]), V3(r[4], r[5], r[6]), r[3], r[7], brute, NULL, NULL);
     }
 }
 
@@ -1442,6 +1482,56 @@ static inline v4 sampleTexture(const PtoScene *s, uint32_t idx, v2 uv, v4 dv)
     }
 }
 
+/* anyhit.rahit:38-52 / occlusionAnyhit.rahit:37-50: texture(textures[colorIdx], uv) * colorFactor at
+ * the candidate hit, with getColorTextureIdx / getColorFactor of material.glsl:25-54.  texture() in a
+ * ray-tracing stage has no implicit derivatives: base level. */
+static v4 hitBaseColor(const PtoScene *s, uint32_t tri, float u, float v)
+{
+    const Pair *pr = &s->pairs[s->triPair[tri]];
+    const uint32_t prim = s->triPrim[tri];
+    const v3 bary = V3(1.0f - u - v, u, v);
+    const uint32_t *ix = &s->d.indices[pr->indexOffset + prim * 3];
+    const PtxVertex *vb = &s->d.vertices[pr->vertexOffset];
+    v2 uv;
+    uv.x = vb[ix[0]].TexCoords[0] * bary.x + vb[ix[1]].TexCoords[0] * bary.y + vb[ix[2]].TexCoords[0] * bary.z;
+    uv.y = vb[ix[0]].TexCoords[1] * bary.x + vb[ix[1]].TexCoords[1] * bary.y + vb[ix[2]].TexCoords[1] * bary.z;
+    const uint32_t materialType = pr->materialId & 0xffu, materialIndex = pr->materialId >> 8;
+    uint32_t idx = 0;
+    v4 factor = { 1.0f, 0.0f, 0.0f, 1.0f };
+    const float *c = NULL;
+    switch (materialType)
+    {
+    case PTX_MATERIAL_TYPE_METALLIC_ROUGHNESS:
+        idx = s->d.metallicRoughnessMaterials[materialIndex].ColorIdx;
+        c = s->d.metallicRoughnessMaterials[materialIndex].Color;
+        break;
+    case PTX_MATERIAL_TYPE_SPECULAR_GLOSSINESS:
+        idx = s->d.specularGlossinessMaterials[materialIndex].ColorIdx;
+        c = s->d.specularGlossinessMaterials[materialIndex].Color;
+        break;
+    case PTX_MATERIAL_TYPE_PHONG:
+        idx = s->d.phongMaterials[materialIndex].ColorIdx;
+        c = s->d.phongMaterials[materialIndex].Color;
+        break;
+    default:
+        break;
+    }
+    if (c)
+    {
+        factor.x = c[0]; factor.y = c[1]; factor.z = c[2]; factor.w = c[3];
+    }
+    v4 t;
+    if (idx >= PTX_SCENE_TEXTURE_OFFSET && idx - PTX_SCENE_TEXTURE_OFFSET < s->textureCount)
+        t = sampleLevel(s, &s->textures[idx - PTX_SCENE_TEXTURE_OFFSET], 0, uv.x, uv.y);
+    else
+    {
+        const v4 zero = { 0.0f, 0.0f, 0.0f, 0.0f };
+        t = sampleTexture(s, idx, uv, zero);
+    }
+    t.x *= factor.x; t.y *= factor.y; t.z *= factor.z; t.w *= factor.w;
+    return t;
+}
+
 /* material.glsl:55-60 */
 static inline v3 ReconstructNormalFromXY(v3 n)
 {
@@ -1621,7 +1711,9 @@ static void closestHit(const PtoScene *s, const PtxLightsUbo *lights, v3 rayOrig
 
     MaterialSample material = sampleMaterial(s, pr->materialId, ov.TexCoords, derivatives, isHitFromInside, s->d.dxNormalTextures != 0);
 
-    /* :105-106 decals: never taken for opaque geometry (DirectLightPdf == -1 on entry) */
+    /* :105-106 decals: an ignored alpha < 0.5 hit in front of this one tints the base colour */
+    if (payload->DirectLightPdf != -1.0f && hit->t > payload->DirectLightPdf)
+        material.Color = v_mix(material.Color, payload->LightDirection, payload->LightDistance);
 
     payload->MaxRoughness = f_max(material.Roughness, payload->MaxRoughness); /* :109 */
     material.Roughness = f_max(payload->MaxRoughness, 0.01f);                 /* :112 */
@@ -1738,7 +1830,14 @@ static void raygenPixel(const PtoScene *s, const PtxRaygenUniformData *U, const 
             payload.LightDirection = v3s(0.0f);
             payload.LightDistance = 0.0f;
             st->segments++;
-            const PtoHit hit = traceClosest(s, ray.Origin, ray.Direction, ray.tmin, ray.tmax, brute, st);
+            Decal decal;
+            const PtoHit hit = traceClosest(s, ray.Origin, ray.Direction, ray.tmin, ray.tmax, brute, st, &decal);
+            if (decal.dist != -1.0f) /* anyhit.rahit:57-59 */
+            {
+                payload.LightDirection = decal.color;
+                payload.LightDistance = decal.alpha;
+                payload.DirectLightPdf = decal.dist;
+            }
             if (hit.tri == 0xffffffffu)
                 missShader(&payload);
             else

@@ -41,7 +41,7 @@ struct Tri
 {
     float4 a; // v0.xyz, e1.x
     float4 b; // e1.yz, e2.xy
-    float4 c; // e2.z, pair (bits), prim (bits), unused
+    float4 c; // e2.z, pair (bits), prim (bits), flags (bits): 1 = non-opaque geometry (any-hit stages run)
 };
 static_assert(sizeof(Tri) == 48, "Tri is 48 B");
 
@@ -96,7 +96,7 @@ __global__ void k_tri_setup(uint32_t n, uint32_t pairCount, const uint32_t *__re
     Tri t;
     t.a = make_float4(w[0].x, w[0].y, w[0].z, e1.x);
     t.b = make_float4(e1.y, e1.z, e2.x, e2.y);
-    t.c = make_float4(e2.z, __uint_as_float(p), __uint_as_float(prim), 0.0f);
+    t.c = make_float4(e2.z, __uint_as_float(p), __uint_as_float(prim), __uint_as_float(pr->nonOpaque ? 1u : 0u));
     triTmp[g] = t;
 
     // bounds from the same p0, p0+e1, p0+e2 the intersection test sees, padded so the slab
@@ -515,7 +515,32 @@ struct TraceScene
     const BvhNode *nodes;
     const Tri *tris;
     uint32_t triCount;
+    SceneView sv; // read by the ALPHA variants only (base colour of non-opaque candidates)
 };
+
+// The any-hit stage for one candidate of a non-opaque geometry; true = the candidate stays.
+//   closest rays  anyhit.rahit:36-64: alpha < 0.5 -> remembered as the decal if it is the nearest so far, ignored
+//   shadow rays   occlusionAnyhit.rahit:35-53: alpha < 1 -> ignored
+template <bool ANY_HIT>
+PT_DEV bool anyHitKeeps(const TraceScene &sc, uint32_t pair, uint32_t prim, float t, float u, float v, Decal &decal)
+{
+    const f4 color = hitBaseColor(sc.sv, pair, prim, u, v);
+    if (ANY_HIT)
+        return !(color.w < 1.0f);
+    if (color.w < 0.5f)
+    {
+        if (decal.dist == -1.0f || t < decal.dist || (t == decal.dist && (pair < decal.pair || (pair == decal.pair && prim < decal.prim))))
+        {
+            decal.dist = t;
+            decal.color = F3(color.x, color.y, color.z);
+            decal.alpha = color.w;
+            decal.pair = pair;
+            decal.prim = prim;
+        }
+        return false;
+    }
+    return true;
+}
 
 // explicit LDS address space: through a generic pointer hipcc emits flat_load/flat_store
 // (checked in the ISA), which go down the vector-memory path instead of ds_read/ds_write
@@ -667,10 +692,13 @@ PT_DEV f3 fastInverse(f3 d) { return F3(__builtin_amdgcn_rcpf(d.x), __builtin_am
 
 // Closest hit = min t over all triangles the ray hits in (tmin, tmax); ties go to the
 // smaller (pair, prim), i.e. the smaller global triangle id -- independent of tree shape.
-template <bool ANY_HIT, bool STATS = false>
+template <bool ANY_HIT, bool STATS = false, bool ALPHA = false>
 PT_DEV bool traceRay(const TraceScene &sc, f3 o, f3 d, float tmin, float tmax, Stack &st, Hit &best, uint32_t *nodeVisits = nullptr,
-                     uint32_t *triTests = nullptr)
+                     uint32_t *triTests = nullptr, Decal *decalOut = nullptr)
 {
+    Decal decal = noDecal();
+    if (ALPHA && decalOut)
+        *decalOut = decal;
     best.t = tmax;
     best.u = best.v = 0.0f;
     best.pair = 0xffffffffu;
@@ -709,7 +737,9 @@ PT_DEV bool traceRay(const TraceScene &sc, f3 o, f3 d, float tmin, float tmax, S
             const Tri *tp = &sc.tris[~ref];
             const float4 ta = tp->a, tb = tp->b, tc = tp->c;
             float t, u, v;
-            if (intersectTri(F3(ta.x, ta.y, ta.z), F3(ta.w, tb.x, tb.y), F3(tb.z, tb.w, tc.x), o, d, tmin, tmax, t, u, v))
+            if (intersectTri(F3(ta.x, ta.y, ta.z), F3(ta.w, tb.x, tb.y), F3(tb.z, tb.w, tc.x), o, d, tmin, tmax, t, u, v) &&
+                (!ALPHA || __float_as_uint(tc.w) == 0u ||
+                 anyHitKeeps<ANY_HIT>(sc, __float_as_uint(tc.y), __float_as_uint(tc.z), t, u, v, decal)))
             {
                 const uint32_t pair = __float_as_uint(tc.y), prim = __float_as_uint(tc.z);
                 if (ANY_HIT)
@@ -732,6 +762,8 @@ PT_DEV bool traceRay(const TraceScene &sc, f3 o, f3 d, float tmin, float tmax, S
             ref = (int)st.pop();
         }
     }
+    if (ALPHA && decalOut)
+        *decalOut = decal;
     return best.pair != 0xffffffffu;
 }
 
@@ -747,7 +779,7 @@ PT_DEV bool traceRay(const TraceScene &sc, f3 o, f3 d, float tmin, float tmax, S
 // refill -- so the triangle code is issued once per round, not once per node visit.
 //
 // IO supplies the queue: bool load(item, o, d, tmin, tmax) (false = nothing to trace,
-// e.g. a dead slot) and void store(item, hit, anyHit).
+// e.g. a dead slot) and void store(item, hit, anyHit, decal).
 #ifndef PT_TRACE_CHUNK
 #define PT_TRACE_CHUNK 128
 #endif
@@ -758,9 +790,10 @@ constexpr uint32_t kTraceChunk = PT_TRACE_CHUNK;
 constexpr int kNodeStepsPerRound = PT_NODE_STEPS;
 constexpr int kRefDone = 0x7fffffff;
 
-template <bool ANY_HIT, typename IO>
+template <bool ANY_HIT, bool ALPHA, typename IO>
 PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32_t *__restrict__ chunkCounter, Stack &st)
 {
+    Decal decal = noDecal();
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t below = (1ull << lane) - 1ull;
     uint32_t cursor = 0, end = 0; // wave-uniform
@@ -810,6 +843,8 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
                         best.t = tmax;
                         best.u = best.v = 0.0f;
                         best.pair = best.prim = 0xffffffffu;
+                        if (ALPHA)
+                            decal = noDecal();
                         st.sp = 0;
                         ref = (sc.triCount && rayIsTraceable(o, d, tmin, tmax)) ? 0 : kRefDone;
                     }
@@ -841,7 +876,9 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
             const float4 ta = tp->a, tb = tp->b, tc = tp->c;
             float t, u, v;
             ref = st.sp ? (int)st.pop() : kRefDone;
-            if (intersectTri(F3(ta.x, ta.y, ta.z), F3(ta.w, tb.x, tb.y), F3(tb.z, tb.w, tc.x), o, d, tmin, tmax, t, u, v))
+            if (intersectTri(F3(ta.x, ta.y, ta.z), F3(ta.w, tb.x, tb.y), F3(tb.z, tb.w, tc.x), o, d, tmin, tmax, t, u, v) &&
+                (!ALPHA || __float_as_uint(tc.w) == 0u ||
+                 anyHitKeeps<ANY_HIT>(sc, __float_as_uint(tc.y), __float_as_uint(tc.z), t, u, v, decal)))
             {
                 const uint32_t pair = __float_as_uint(tc.y), prim = __float_as_uint(tc.z);
                 if (ANY_HIT)
@@ -864,7 +901,7 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
         // ---- retire finished rays
         if (have && ref == kRefDone)
         {
-            io.store(item, best, best.pair != 0xffffffffu);
+            io.store(item, best, best.pair != 0xffffffffu, decal);
             have = false;
         }
     }

@@ -925,7 +925,73 @@ struct DevPair
     float M[12];
     float Rinv[9]; // columns c0, c1, c2
     uint32_t vertexOffset, indexOffset, materialId;
+    uint32_t nonOpaque; // geometry without VK_GEOMETRY_OPAQUE_BIT: the any-hit stages run (AccelerationStructure.cpp:94-97)
 };
+
+// What anyhit.rahit leaves in the payload: the nearest ignored (alpha < 0.5) candidate.  The any-hit
+// invocation order is the driver's; nearest-with-id-tie-break is the order-independent reading of
+// anyhit.rahit:54-61 that closestHit.rchit:105-106 can observe.
+struct Decal
+{
+    float dist; // -1 = none (payload.DirectLightPdf)
+    f3 color;   // payload.LightDirection
+    float alpha; // payload.LightDistance
+    uint32_t pair, prim;
+};
+PT_DEV Decal noDecal()
+{
+    Decal d;
+    d.dist = -1.0f;
+    d.color = F3s(0.0f);
+    d.alpha = 0.0f;
+    d.pair = d.prim = 0xffffffffu;
+    return d;
+}
+
+// anyhit.rahit:38-52 / occlusionAnyhit.rahit:37-50: texture(textures[colorIdx], uv) * colorFactor at a
+// candidate hit (getColorTextureIdx / getColorFactor, material.glsl:25-54).  texture() in a ray-tracing
+// stage has no implicit derivatives: base level.
+PT_DEV f4 hitBaseColor(const SceneView &sv, uint32_t pairIdx, uint32_t prim, float u, float v)
+{
+    const DevPair *pr = &sv.pairs[pairIdx];
+    const f3 bary = F3(1.0f - u - v, u, v);
+    const uint32_t *ix = sv.indices + pr->indexOffset + prim * 3;
+    const PtxVertex *vb = sv.vertices + pr->vertexOffset;
+    const PtxVertex *a = vb + ix[0], *b = vb + ix[1], *c = vb + ix[2];
+    const float tu = (a->TexCoords[0] * bary.x + b->TexCoords[0] * bary.y) + c->TexCoords[0] * bary.z;
+    const float tv = (a->TexCoords[1] * bary.x + b->TexCoords[1] * bary.y) + c->TexCoords[1] * bary.z;
+    const uint32_t materialType = pr->materialId & 0xffu, materialIndex = pr->materialId >> 8;
+    uint32_t idx = 0;
+    f4 factor;
+    factor.x = 1.0f; factor.y = 0.0f; factor.z = 0.0f; factor.w = 1.0f;
+    const float *col = nullptr;
+    if (materialType == PTX_MATERIAL_TYPE_METALLIC_ROUGHNESS)
+    {
+        idx = sv.mr[materialIndex].ColorIdx;
+        col = sv.mr[materialIndex].Color;
+    }
+    else if (materialType == PTX_MATERIAL_TYPE_SPECULAR_GLOSSINESS)
+    {
+        idx = sv.sg[materialIndex].ColorIdx;
+        col = sv.sg[materialIndex].Color;
+    }
+    else if (materialType == PTX_MATERIAL_TYPE_PHONG)
+    {
+        idx = sv.phong[materialIndex].ColorIdx;
+        col = sv.phong[materialIndex].Color;
+    }
+    if (col)
+    {
+        factor.x = col[0]; factor.y = col[1]; factor.z = col[2]; factor.w = col[3];
+    }
+    f4 t;
+    if (idx >= PTX_SCENE_TEXTURE_OFFSET && idx - PTX_SCENE_TEXTURE_OFFSET < sv.tex.textureCount)
+        t = sampleLevel(sv.tex, sv.tex.textures[idx - PTX_SCENE_TEXTURE_OFFSET], 0, tu, tv);
+    else
+        t = sampleTexture(idx);
+    t.x *= factor.x; t.y *= factor.y; t.z *= factor.z; t.w *= factor.w;
+    return t;
+}
 
 PT_DEV f3 specGlossMetalness(f3 specular, f3 color) // material.glsl:109-110, :138-139
 {
@@ -1059,7 +1125,8 @@ struct HitOut
 // closestHit.rchit:52-161.  (u, v) = hitAttributeEXT barycentrics, t = gl_RayTmaxEXT.
 template <bool TEX>
 PT_DEV void closestHit(const SceneView &sv, f3 rayDirW, float t, float hu, float hv, uint32_t pairIdx, uint32_t prim,
-                       float maxRoughnessIn, uint32_t &rngState, HitOut &out, DiffRays &diff)
+                       float maxRoughnessIn, uint32_t &rngState, HitOut &out, DiffRays &diff, float decalDist = -1.0f,
+                       f3 decalColor = F3s(0.0f), float decalAlpha = 0.0f)
 {
     const f3 bary = F3(1.0f - hu - hv, hu, hv);
     const DevPair pr = sv.pairs[pairIdx];
@@ -1109,7 +1176,9 @@ PT_DEV void closestHit(const SceneView &sv, f3 rayDirW, float t, float hu, float
 
     MaterialSample material = sampleMaterial<TEX>(sv, pr.materialId, texCoords, derivatives, isHitFromInside);
 
-    // :105-106 decal mix: never taken for opaque geometry
+    // :105-106 decals: an ignored alpha < 0.5 candidate in front of this hit tints the base colour
+    if (decalDist != -1.0f && t > decalDist)
+        material.Color = mix(material.Color, decalColor, decalAlpha);
 
     out.MaxRoughness = fmax_(material.Roughness, maxRoughnessIn); // :109
     material.Roughness = fmax_(out.MaxRoughness, 0.01f);          // :112

@@ -50,6 +50,8 @@ struct Wavefront // device pointers of the per-slot state (SoA)
     float4 *shD;    // shadow direction.xyz, w = 1 if the path ends after this bounce
     float4 *shC;    // NEE contribution throughput * DirectLight / DirectLightPdf
     float4 *slotRad; // final radiance of the slot (consumed by k_accumulate)
+    float4 *decal;   // nearest ignored any-hit candidate: rgb, alpha (payload.LightDirection / LightDistance); null unless the
+    float *decalT;   // scene has non-opaque geometry.  decalT = its distance or -1 (payload.DirectLightPdf)
     float4 *diff[3]; // payload.RayDifferentials0..2 (rx origin, rx dir, ry origin, ry dir); null unless the scene has textures
     uint32_t *queue[2];
     uint32_t *shadowQueue;
@@ -252,18 +254,25 @@ struct ClosestIO
         tmax = 10000.0f;
         return true;
     }
-    PT_DEV void store(uint32_t, const Hit &h, bool)
+    PT_DEV void store(uint32_t, const Hit &h, bool, const Decal &dc)
     {
         wf.hit[slot] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
         wf.hitPair[slot] = h.pair;
+        if (wf.decalT)
+        {
+            wf.decalT[slot] = dc.dist;
+            if (dc.dist != -1.0f)
+                wf.decal[slot] = make_float4(dc.color.x, dc.color.y, dc.color.z, dc.alpha);
+        }
     }
 };
 
+template <bool ALPHA>
 __global__ void __launch_bounds__(kBlock) k_trace_closest(TraceScene sc, Wavefront wf, int qin, uint32_t count)
 {
     PT_DECLARE_STACK(st, kLdsStack, wf.spill)
     ClosestIO io = { wf, wf.queue[qin], 0u };
-    persistentTrace<false>(sc, io, count, &wf.counters[C_CHUNK], st);
+    persistentTrace<false, ALPHA>(sc, io, count, &wf.counters[C_CHUNK], st);
     if (st.overflow)
         atomicAdd(&wf.counters[C_OVERFLOW], 1u);
 }
@@ -335,7 +344,16 @@ __global__ void __launch_bounds__(kBlock) k_shade(LaunchParams p, SceneView sv, 
                 DiffRays diff;
                 if (TEX)
                     diff = loadDiff(wf, slot);
-                closestHit<TEX>(sv, F3(d4.x, d4.y, d4.z), hit.x, hit.y, hit.z, pair, __float_as_uint(hit.w), o4.w, meta.x, out, diff);
+                float decalT = -1.0f;
+                float4 decal = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (wf.decalT)
+                {
+                    decalT = wf.decalT[slot];
+                    if (decalT != -1.0f)
+                        decal = wf.decal[slot];
+                }
+                closestHit<TEX>(sv, F3(d4.x, d4.y, d4.z), hit.x, hit.y, hit.z, pair, __float_as_uint(hit.w), o4.w, meta.x, out, diff, decalT,
+                                F3(decal.x, decal.y, decal.z), decal.w);
                 nHits++;
 
                 radiance = radiance + throughput * out.Emissive; // raygen.rgen:77
@@ -444,7 +462,7 @@ struct ShadowIO
         finished = d4.w;
         return true;
     }
-    PT_DEV void store(uint32_t, const Hit &, bool occluded)
+    PT_DEV void store(uint32_t, const Hit &, bool occluded, const Decal &)
     {
         float4 r4 = wf.rad[slot];
         if (!occluded)
@@ -469,11 +487,12 @@ struct ShadowIO
     }
 };
 
+template <bool ALPHA>
 __global__ void __launch_bounds__(kBlock) k_trace_shadow(LaunchParams p, TraceScene sc, Wavefront wf, int qout, uint32_t count)
 {
     PT_DECLARE_STACK(st, kLdsStack, wf.spill)
     ShadowIO io = { p, wf, qout, 0u, 0.0f, 0u, 0u };
-    persistentTrace<true>(sc, io, count, &wf.counters[C_CHUNK + 1], st);
+    persistentTrace<true, ALPHA>(sc, io, count, &wf.counters[C_CHUNK + 1], st);
     if (st.overflow)
         atomicAdd(&wf.counters[C_OVERFLOW], 1u);
     waveAddCounter(&wf.counters[C_SAMPLES], io.nSamples);
@@ -517,11 +536,13 @@ struct PathCounters
 
 // Runs a slot to the end of its launch.  `fresh` = start with a new sample (primary ray);
 // otherwise continue the current sample at `bounce` with the given ray / throughput.
-template <bool TEX>
+// MODE 0: opaque geometry, fixed 1x1 textures; 1: + ray differentials and the sampler (TEX); 2: + any-hit stages (ALPHA)
+template <int MODE>
 PT_DEV f3 runPath(const LaunchParams &p, const SceneView &sv, const TraceScene &sc, Stack &st, uint32_t pixel, uint32_t &rng,
                   f3 radiance, f3 throughput, f3 ro, f3 rd, DiffRays diff, float maxRoughness, uint32_t bounce, int smpl, bool fresh,
                   PathCounters &pc)
 {
+    constexpr bool TEX = MODE >= 1, ALPHA = MODE == 2;
     for (;;)
     {
         if (fresh)
@@ -538,13 +559,14 @@ PT_DEV f3 runPath(const LaunchParams &p, const SceneView &sv, const TraceScene &
         {
             Hit h;
             pc.nSeg++;
-            if (!traceRay<false>(sc, ro, rd, 0.00001f, 10000.0f, st, h))
+            Decal decal = noDecal();
+            if (!traceRay<false, false, ALPHA>(sc, ro, rd, 0.00001f, 10000.0f, st, h, nullptr, nullptr, &decal))
             {
                 radiance = radiance + throughput * F3(0.08f, 0.09f, 0.1f);
                 break;
             }
             HitOut out;
-            closestHit<TEX>(sv, rd, h.t, h.u, h.v, h.pair, h.prim, maxRoughness, rng, out, diff);
+            closestHit<TEX>(sv, rd, h.t, h.u, h.v, h.pair, h.prim, maxRoughness, rng, out, diff, decal.dist, decal.color, decal.alpha);
             pc.nHit++;
             maxRoughness = out.MaxRoughness;
             radiance = radiance + throughput * out.Emissive;
@@ -554,7 +576,7 @@ PT_DEV f3 runPath(const LaunchParams &p, const SceneView &sv, const TraceScene &
                 if (!(c.x == 0.0f && c.y == 0.0f && c.z == 0.0f))
                 {
                     Hit sh;
-                    if (!traceRay<true>(sc, out.Position, -normalize(out.LightDirection), 0.00001f, out.LightDistance, st, sh))
+                    if (!traceRay<true, false, ALPHA>(sc, out.Position, -normalize(out.LightDirection), 0.00001f, out.LightDistance, st, sh))
                         radiance = radiance + c;
                 }
             }
@@ -583,7 +605,7 @@ PT_DEV f3 runPath(const LaunchParams &p, const SceneView &sv, const TraceScene &
     return radiance;
 }
 
-template <bool TEX>
+template <int MODE>
 __global__ void __launch_bounds__(kBlock) k_megakernel(LaunchParams p, SceneView sv, TraceScene sc, float4 *__restrict__ slotRad,
                                                         uint32_t *__restrict__ counters)
 {
@@ -598,7 +620,7 @@ __global__ void __launch_bounds__(kBlock) k_megakernel(LaunchParams p, SceneView
         uint32_t rng = initRng(pixel % p.width, pixel / p.width, p.width, p.firstFrame + f);
         DiffRays diff;
         diff.rxOrigin = diff.rxDirection = diff.ryOrigin = diff.ryDirection = F3s(0.0f);
-        radiance = runPath<TEX>(p, sv, sc, st, pixel, rng, F3s(0.0f), F3s(1.0f), F3s(0.0f), F3s(0.0f), diff, 0.0f, 0u, 0, true, pc);
+        radiance = runPath<MODE>(p, sv, sc, st, pixel, rng, F3s(0.0f), F3s(1.0f), F3s(0.0f), F3s(0.0f), diff, 0.0f, 0u, 0, true, pc);
     }
     if (slot < p.numSlots)
         slotRad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
@@ -612,7 +634,7 @@ __global__ void __launch_bounds__(kBlock) k_megakernel(LaunchParams p, SceneView
 
 // The slots of queue `qin` sit at a bounce boundary (ray, throughput, radiance, RNG and
 // bounce/sample counters in the SoA state, no shadow query pending): run each to the end.
-template <bool TEX>
+template <int MODE>
 __global__ void __launch_bounds__(kBlock) k_tail(LaunchParams p, SceneView sv, TraceScene sc, Wavefront wf, int qin, uint32_t count)
 {
     PT_DECLARE_STACK(st, kLdsStackMega, (uint32_t *)nullptr)
@@ -627,11 +649,11 @@ __global__ void __launch_bounds__(kBlock) k_tail(LaunchParams p, SceneView sv, T
             const float4 o4 = wf.rayO[slot], d4 = wf.rayD[slot], t4 = wf.thr[slot], r4 = wf.rad[slot];
             uint32_t rng = meta.x;
             DiffRays diff;
-            if (TEX)
+            if (MODE >= 1)
                 diff = loadDiff(wf, slot);
             else
                 diff.rxOrigin = diff.rxDirection = diff.ryOrigin = diff.ryDirection = F3s(0.0f);
-            const f3 radiance = runPath<TEX>(p, sv, sc, st, meta.y, rng, F3(r4.x, r4.y, r4.z), F3(t4.x, t4.y, t4.z), F3(o4.x, o4.y, o4.z),
+            const f3 radiance = runPath<MODE>(p, sv, sc, st, meta.y, rng, F3(r4.x, r4.y, r4.z), F3(t4.x, t4.y, t4.z), F3(o4.x, o4.y, o4.z),
                                              F3(d4.x, d4.y, d4.z), diff, o4.w, meta.z & 0xffffu, (int)(meta.z >> 16), false, pc);
             wf.slotRad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
         }
@@ -663,13 +685,14 @@ struct RaysIO
         tmax = d4.w;
         return true;
     }
-    PT_DEV void store(uint32_t item, const Hit &h, bool hitAny)
+    PT_DEV void store(uint32_t item, const Hit &h, bool hitAny, const Decal &)
     {
         outHit[item] = make_float4(h.t, h.u, h.v, hitAny ? 1.0f : 0.0f);
         outIds[item] = make_uint2(h.pair, h.prim);
     }
 };
 
+template <bool ALPHA>
 __global__ void __launch_bounds__(kBlock) k_trace_rays(TraceScene sc, const float4 *__restrict__ rays, uint32_t n, int anyHit,
                                                         float4 *__restrict__ outHit, uint2 *__restrict__ outIds, uint32_t *chunkCounter, uint32_t *spill)
 {
@@ -681,7 +704,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_rays(TraceScene sc, const floa
             const float4 o = rays[2 * i], d = rays[2 * i + 1];
             Hit h;
             uint32_t nv = 0, nt = 0;
-            const bool hitAny = traceRay<false, true>(sc, F3(o.x, o.y, o.z), F3(d.x, d.y, d.z), o.w, d.w, st, h, &nv, &nt);
+            const bool hitAny = traceRay<false, true, ALPHA>(sc, F3(o.x, o.y, o.z), F3(d.x, d.y, d.z), o.w, d.w, st, h, &nv, &nt);
             outHit[i] = make_float4(h.t, h.u, h.v, hitAny ? 1.0f : 0.0f);
             outIds[i] = make_uint2(nv, nt);
         }
@@ -689,9 +712,9 @@ __global__ void __launch_bounds__(kBlock) k_trace_rays(TraceScene sc, const floa
     }
     RaysIO io = { rays, outHit, outIds };
     if (anyHit)
-        persistentTrace<true>(sc, io, n, chunkCounter, st);
+        persistentTrace<true, ALPHA>(sc, io, n, chunkCounter, st);
     else
-        persistentTrace<false>(sc, io, n, chunkCounter, st);
+        persistentTrace<false, ALPHA>(sc, io, n, chunkCounter, st);
 }
 
 // shard pack / unpack: tile-major dense buffer [ownedTile][tileSize^2] of RGBA32F
@@ -1029,6 +1052,10 @@ struct PtxRenderer
     DevBuf<float> srgbLut;
     uint32_t textureCount = 0;
     bool samplerNeeded = false; // some uploaded texture is not a 1x1 white placeholder
+    bool anyNonOpaque = false;  // some instanced geometry lacks the opaque flag: any-hit stages run
+    DevBuf<float4> decal;
+    DevBuf<float> decalT;
+    size_t decalCapacity = 0;
     uint32_t pairCount = 0, triCount = 0, dxNormalTextures = 0;
     bool sceneReady = false, accelReady = false;
 
@@ -1212,7 +1239,7 @@ void ptx_destroy(PtxRenderer *r)
     r->vertices.release(); r->indices.release(); r->mr.release(); r->sg.release(); r->phong.release();
     r->pairs.release(); r->pairFirst.release(); r->lights.release(); r->nodes.release(); r->tris.release();
     r->image.release(); r->rayO.release(); r->rayD.release(); r->thr.release(); r->rad.release(); r->hit.release();
-    r->shO.release(); r->shD.release(); r->shC.release(); r->slotRad.release(); r->diffs.release(); r->diffCapacity = 0; r->meta.release(); r->hitPair.release();
+    r->shO.release(); r->shD.release(); r->shC.release(); r->slotRad.release(); r->diffs.release(); r->diffCapacity = 0; r->decal.release(); r->decalT.release(); r->decalCapacity = 0; r->meta.release(); r->hitPair.release();
     r->queue0.release(); r->queue1.release(); r->shadowQueue.release(); r->counters.release(); r->spill.release(); r->spillAux.release(); r->restartQueue.release();
     r->testIn.release(); r->testOut.release(); r->testUbo.release();
     for (int b = 0; b < r->batchesReady; b++)
@@ -1351,6 +1378,7 @@ int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *s)
     std::vector<DevPair> pairs;
     std::vector<uint32_t> pairFirst;
     uint64_t tri = 0;
+    bool anyNonOpaque = false;
     for (uint32_t i = 0; i < s->instanceCount; i++)
     {
         const PtxModelInstance &inst = s->instances[i];
@@ -1365,6 +1393,9 @@ int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *s)
             pr.vertexOffset = geo.VertexOffset;
             pr.indexOffset = geo.IndexOffset;
             pr.materialId = rec.MaterialId;
+            pr.nonOpaque = geo.IsOpaque ? 0u : 1u;
+            if (pr.nonOpaque)
+                anyNonOpaque = true;
             pairs.push_back(pr);
             pairFirst.push_back(static_cast<uint32_t>(tri));
             tri += geo.IndexLength / 3;
@@ -1424,6 +1455,7 @@ int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *s)
         // A 1x1 opaque-white 8-bit texture decodes to exactly (1,1,1,1) in both formats, which is what the
         // kernels without the sampler return for any index >= 9: only other content needs the TEX variants.
         r->samplerNeeded = false;
+        r->anyNonOpaque = anyNonOpaque;
         for (uint32_t i = 0; i < r->textureCount; i++)
         {
             const PtxTextureDesc &d = s->textures[i];
@@ -1579,12 +1611,35 @@ int ptx_reset_accumulation(PtxRenderer *r)
 
 } // extern "C"
 
+// Kernel variant of the uploaded scene: 0 = opaque geometry with the fixed 1x1 textures only, 1 = ray
+// differentials + software sampler, 2 = 1 + the any-hit stages (alpha test, decals).
+static int kernelMode(const PtxRenderer *r)
+{
+    return r->anyNonOpaque ? 2 : (r->samplerNeeded ? 1 : 0);
+}
+
+static SceneView makeSceneView(const PtxRenderer *r)
+{
+    SceneView sv;
+    sv.vertices = r->vertices.p; sv.indices = r->indices.p; sv.mr = r->mr.p; sv.sg = r->sg.p; sv.phong = r->phong.p;
+    sv.pairs = r->pairs.p; sv.lights = r->lights.p; sv.dxNormalTextures = r->dxNormalTextures;
+    sv.tex.textures = r->textures.p; sv.tex.textureCount = r->textureCount; sv.tex.texels8 = r->texels8.p; sv.tex.texelsF = r->texelsF.p;
+    sv.tex.srgbLut = r->srgbLut.p;
+    return sv;
+}
+
 static int ensureSlots(PtxRenderer *r, size_t slots)
 {
-    if (r->samplerNeeded && r->diffCapacity < std::max(slots, r->slotCapacity))
+    if (kernelMode(r) >= 1 && r->diffCapacity < std::max(slots, r->slotCapacity))
     {
         HIP_TRY(r, r->diffs.alloc(3 * std::max(slots, r->slotCapacity)));
         r->diffCapacity = std::max(slots, r->slotCapacity);
+    }
+    if (kernelMode(r) == 2 && r->decalCapacity < std::max(slots, r->slotCapacity))
+    {
+        HIP_TRY(r, r->decal.alloc(std::max(slots, r->slotCapacity)));
+        HIP_TRY(r, r->decalT.alloc(std::max(slots, r->slotCapacity)));
+        r->decalCapacity = std::max(slots, r->slotCapacity);
     }
     if (slots <= r->slotCapacity)
         return PTX_OK;
@@ -1649,14 +1704,11 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
     HIP_TRY(r, hipMemcpyAsync(r->lights.p, lights, sizeof(PtxLightsUbo), hipMemcpyHostToDevice, r->stream));
     HIP_TRY(r, hipMemsetAsync(r->counters.p, 0, C_COUNT * sizeof(uint32_t), r->stream));
 
-    SceneView sv;
-    sv.vertices = r->vertices.p; sv.indices = r->indices.p; sv.mr = r->mr.p; sv.sg = r->sg.p; sv.phong = r->phong.p;
-    sv.pairs = r->pairs.p; sv.lights = r->lights.p; sv.dxNormalTextures = r->dxNormalTextures;
-    sv.tex.textures = r->textures.p; sv.tex.textureCount = r->textureCount; sv.tex.texels8 = r->texels8.p; sv.tex.texelsF = r->texelsF.p;
-    sv.tex.srgbLut = r->srgbLut.p;
-    const bool textured = r->samplerNeeded; // TEX kernel variants: ray differentials + textureGrad
+    const SceneView sv = makeSceneView(r);
+    const int mode = kernelMode(r);
+    const bool textured = mode >= 1, alpha = mode == 2;
     TraceScene sc;
-    sc.nodes = r->nodes.p; sc.tris = r->tris.p; sc.triCount = r->triCount;
+    sc.nodes = r->nodes.p; sc.tris = r->tris.p; sc.triCount = r->triCount; sc.sv = sv;
 
     r->stats.pathSamples = r->stats.segments = r->stats.shadowRays = r->stats.retries = 0;
     r->stats.traceLaunches = 0;
@@ -1672,10 +1724,13 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
 
     if (r->backend == PTX_BACKEND_MEGAKERNEL)
     {
-        if (textured)
-            k_megakernel<true><<<(p.numSlots + kBlock - 1) / kBlock, kBlock, 0, r->stream>>>(p, sv, sc, r->slotRad.p, r->counters.p);
+        const dim3 grid((p.numSlots + kBlock - 1) / kBlock);
+        if (mode == 2)
+            k_megakernel<2><<<grid, kBlock, 0, r->stream>>>(p, sv, sc, r->slotRad.p, r->counters.p);
+        else if (mode == 1)
+            k_megakernel<1><<<grid, kBlock, 0, r->stream>>>(p, sv, sc, r->slotRad.p, r->counters.p);
         else
-            k_megakernel<false><<<(p.numSlots + kBlock - 1) / kBlock, kBlock, 0, r->stream>>>(p, sv, sc, r->slotRad.p, r->counters.p);
+            k_megakernel<0><<<grid, kBlock, 0, r->stream>>>(p, sv, sc, r->slotRad.p, r->counters.p);
         k_accumulate<<<gridFor(p.slotsPerFrame), kBlock, 0, r->stream>>>(p, r->slotRad.p, imagePtr(r));
         HIP_TRY(r, hipMemcpyAsync(r->hostCounters, r->counters.p, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
         HIP_TRY(r, hipEventRecord(r->evB, r->stream));
@@ -1750,6 +1805,8 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
         wf.restartQueue = r->restartQueue.p + off;
         for (int k = 0; k < 3; k++)
             wf.diff[k] = textured ? r->diffs.p + (size_t)k * r->diffCapacity + off : nullptr;
+        wf.decal = alpha ? r->decal.p + off : nullptr;
+        wf.decalT = alpha ? r->decalT.p + off : nullptr;
         wf.counters = bt.res->dCounters;
         wf.spill = bt.res->spill;
         bt.wfAux = wf;
@@ -1778,7 +1835,10 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
         HIP_TRY(r, hipMemsetAsync(&q.dCounters[C_SHADOW], 0, sizeof(uint32_t), q.s));
         HIP_TRY(r, hipMemsetAsync(&q.dCounters[C_CHUNK], 0, sizeof(uint32_t), q.s));
         HIP_TRY(r, hipEventRecord(q.evT0, q.s));
-        k_trace_closest<<<gridFor(bt.active), kBlock, 0, q.s>>>(sc, bt.wf, bt.qin, bt.active);
+        if (alpha)
+            k_trace_closest<true><<<gridFor(bt.active), kBlock, 0, q.s>>>(sc, bt.wf, bt.qin, bt.active);
+        else
+            k_trace_closest<false><<<gridFor(bt.active), kBlock, 0, q.s>>>(sc, bt.wf, bt.qin, bt.active);
         HIP_TRY(r, hipEventRecord(q.evT1, q.s));
         if (bt.shadowPending) // k_shade reads rad[slot]: the previous bounce's shadow adds must have landed
             HIP_TRY(r, hipStreamWaitEvent(q.s, q.evShadow[bt.shadowSlot], 0));
@@ -1811,10 +1871,13 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
             if (bt.shadowPending) // k_tail continues from rad[slot]
                 HIP_TRY(r, hipStreamWaitEvent(q.s, q.evShadow[bt.shadowSlot], 0));
             HIP_TRY(r, hipEventRecord(q.evT0, q.s));
-            if (textured)
-                k_tail<true><<<gridFor(bt.active, kBlock, 1u << 20), kBlock, 0, q.s>>>(bt.p, sv, sc, bt.wf, bt.qin, bt.active);
+            const dim3 grid(gridFor(bt.active, kBlock, 1u << 20));
+            if (mode == 2)
+                k_tail<2><<<grid, kBlock, 0, q.s>>>(bt.p, sv, sc, bt.wf, bt.qin, bt.active);
+            else if (mode == 1)
+                k_tail<1><<<grid, kBlock, 0, q.s>>>(bt.p, sv, sc, bt.wf, bt.qin, bt.active);
             else
-                k_tail<false><<<gridFor(bt.active, kBlock, 1u << 20), kBlock, 0, q.s>>>(bt.p, sv, sc, bt.wf, bt.qin, bt.active);
+                k_tail<0><<<grid, kBlock, 0, q.s>>>(bt.p, sv, sc, bt.wf, bt.qin, bt.active);
             HIP_TRY(r, hipEventRecord(q.evT1, q.s));
             HIP_TRY(r, hipMemcpyAsync(q.hCounters, q.dCounters, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, q.s));
             HIP_TRY(r, hipEventRecord(q.evReady, q.s));
@@ -1851,7 +1914,10 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
                 HIP_TRY(r, hipStreamWaitEvent(q.x, q.evShade, 0));
                 HIP_TRY(r, hipMemsetAsync(&q.dCounters[C_CHUNK + 1], 0, sizeof(uint32_t), q.x));
                 HIP_TRY(r, hipEventRecord(q.evX0[bt.shadowSlot], q.x));
-                k_trace_shadow<<<gridFor(shadowCount), kBlock, 0, q.x>>>(bt.p, sc, bt.wfAux, qout, shadowCount);
+                if (alpha)
+                    k_trace_shadow<true><<<gridFor(shadowCount), kBlock, 0, q.x>>>(bt.p, sc, bt.wfAux, qout, shadowCount);
+                else
+                    k_trace_shadow<false><<<gridFor(shadowCount), kBlock, 0, q.x>>>(bt.p, sc, bt.wfAux, qout, shadowCount);
                 HIP_TRY(r, hipEventRecord(q.evShadow[bt.shadowSlot], q.x));
                 bt.shadowPending = true;
             }
@@ -2126,13 +2192,16 @@ int ptx_trace_rays(PtxRenderer *r, const float *rays, uint32_t n, int anyHit, fl
     HIP_TRY(r, dHits.alloc(n));
     HIP_TRY(r, dIds.alloc(n));
     TraceScene sc;
-    sc.nodes = r->nodes.p; sc.tris = r->tris.p; sc.triCount = r->triCount;
+    sc.nodes = r->nodes.p; sc.tris = r->tris.p; sc.triCount = r->triCount; sc.sv = makeSceneView(r);
     hipError_t e = hipMemcpyAsync(dRays.p, rays, (size_t)n * 32, hipMemcpyHostToDevice, r->stream);
     if (e == hipSuccess)
     {
         (void)hipEventRecord(r->evT0, r->stream);
         (void)hipMemsetAsync(&r->counters.p[C_CHUNK], 0, sizeof(uint32_t), r->stream);
-        k_trace_rays<<<gridFor(n), kBlock, 0, r->stream>>>(sc, dRays.p, n, anyHit, dHits.p, dIds.p, &r->counters.p[C_CHUNK], r->spill.p);
+        if (r->anyNonOpaque)
+            k_trace_rays<true><<<gridFor(n), kBlock, 0, r->stream>>>(sc, dRays.p, n, anyHit, dHits.p, dIds.p, &r->counters.p[C_CHUNK], r->spill.p);
+        else
+            k_trace_rays<false><<<gridFor(n), kBlock, 0, r->stream>>>(sc, dRays.p, n, anyHit, dHits.p, dIds.p, &r->counters.p[C_CHUNK], r->spill.p);
         (void)hipEventRecord(r->evT1, r->stream);
         e = hipMemcpyAsync(hits, dHits.p, (size_t)n * 16, hipMemcpyDeviceToHost, r->stream);
     }

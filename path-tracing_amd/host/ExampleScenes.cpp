@@ -146,7 +146,7 @@ Vec3 SafeNormalize(Vec3 v, Vec3 fallback)
 // (a, d, c), (a, c, b) with a=(i,j) b=(i+1,j) c=(i+1,j+1) d=(i,j+1), i.e. the
 // geometric normal is cross(dP/dv, dP/du) (outward for a lathe with u = angle).
 uint32_t AddGridSurface(SceneBuilder &sb, uint32_t nu, uint32_t nv, bool closedU,
-                        const std::function<Vec3(float, float)> &f, bool flip = false)
+                        const std::function<Vec3(float, float)> &f, bool flip = false, bool opaque = true)
 {
     auto &vertices = sb.GetVertices();
     auto &indices = sb.GetIndices();
@@ -198,7 +198,7 @@ uint32_t AddGridSurface(SceneBuilder &sb, uint32_t nu, uint32_t nv, bool closedU
             v.Bitangent[0] = b.x; v.Bitangent[1] = b.y; v.Bitangent[2] = b.z;
             vertices.push_back(v);
         }
-    return sb.AddGeometry({ vertexOffset, cu * cv, indexOffset, nu * nv * 6, true, false, { 0, 0 } });
+    return sb.AddGeometry({ vertexOffset, cu * cv, indexOffset, nu * nv * 6, opaque, false, { 0, 0 } });
 }
 
 // Surface of revolution around +y through a piecewise-linear (radius, height) profile,
@@ -257,7 +257,7 @@ uint32_t AddBox(SceneBuilder &sb, Vec3 c, Vec3 h)
 }
 
 // `count` small randomly oriented quads ("leaf cards") inside a box
-uint32_t AddCards(SceneBuilder &sb, Rng &rng, uint32_t count, Vec3 lo, Vec3 hi, float size)
+uint32_t AddCards(SceneBuilder &sb, Rng &rng, uint32_t count, Vec3 lo, Vec3 hi, float size, bool opaque = true)
 {
     auto &vertices = sb.GetVertices();
     auto &indices = sb.GetIndices();
@@ -280,7 +280,7 @@ uint32_t AddCards(SceneBuilder &sb, Rng &rng, uint32_t count, Vec3 lo, Vec3 hi, 
         for (uint32_t k : { 0u, 1u, 2u, 2u, 3u, 0u })
             indices.push_back(q * 4 + k);
     }
-    return sb.AddGeometry({ vertexOffset, count * 4, indexOffset, count * 6, true, false, { 0, 0 } });
+    return sb.AddGeometry({ vertexOffset, count * 4, indexOffset, count * 6, opaque, false, { 0, 0 } });
 }
 
 Shaders::MetallicRoughnessMaterial MakeMaterial(Vec3 color, float roughness, float metalness)
@@ -1016,9 +1016,82 @@ void CreateTextureTestScene(SceneBuilder &sb, uint32_t seed)
     AddViewCamera(sb, Vec3(0.0f, 2.2f, -6.5f), Vec3(0.0f, 0.4f, 0.0f));
 }
 
+// Alpha-tested geometry and decals (anyhit.rahit / occlusionAnyhit.rahit): non-opaque geometries whose
+// base-colour alpha decides, per candidate hit, whether the ray sees the surface.
+//   leaves   alpha 1 inside, a soft 0.5..1 rim (visible to path rays, transparent to shadow rays), 0 outside
+//   decal    alpha 0.3 rings / 0 elsewhere on a panel in front of the wall: never hit, tints what is behind
+//   ghost    untextured material with colour alpha 0.4: an invisible tinting pane
+//   film     untextured material with colour alpha 0.8: solid to path rays, casts no shadow
+void CreateAlphaTestScene(SceneBuilder &sb, uint32_t seed)
+{
+    Rng rng(seed);
+    const uint32_t checker = sb.AddTexture(MakeTexture(TextureType::Color, "Tiles", 32, 32, [](uint32_t x, uint32_t y, uint8_t *p) {
+        const bool on = ((x / 4) + (y / 4)) & 1;
+        p[0] = on ? 200 : 120; p[1] = on ? 200 : 120; p[2] = on ? 210 : 130; p[3] = 255;
+    }));
+    const uint32_t leafTex = sb.AddTexture(MakeTexture(TextureType::Color, "Leaf", 48, 48, [](uint32_t x, uint32_t y, uint8_t *p) {
+        const float dx = (static_cast<float>(x) - 23.5f) / 23.5f, dy = (static_cast<float>(y) - 23.5f) / 16.0f;
+        const float r = dx * dx + dy * dy;
+        const bool vein = (x % 8 == 3) || std::abs(static_cast<int>(y) - 24) < 2;
+        p[0] = vein ? 90 : 40; p[1] = vein ? 170 : 130; p[2] = vein ? 60 : 35;
+        p[3] = r < 0.7f ? 255 : (r < 1.0f ? static_cast<uint8_t>(250.0f - 400.0f * (r - 0.7f)) : 0); // rim 250..130
+    }));
+    const uint32_t decalTex = sb.AddTexture(MakeTexture(TextureType::Color, "Rings", 64, 64, [](uint32_t x, uint32_t y, uint8_t *p) {
+        const float dx = static_cast<float>(x) - 31.5f, dy = static_cast<float>(y) - 31.5f;
+        const int ring = static_cast<int>(std::sqrt(dx * dx + dy * dy) / 5.0f);
+        const bool on = ring < 6 && (ring & 1) == 0;
+        p[0] = 220; p[1] = ring < 3 ? 30 : 120; p[2] = 40; p[3] = on ? 76 : 0;
+    }));
+
+    auto floorM = MakeMaterial(Vec3(1.0f), 0.8f, 0.0f);
+    floorM.ColorIdx = checker;
+    const auto floorMat = sb.AddMaterial("Tiles", floorM);
+    const auto wallMat = sb.AddMaterial("Wall", MakeMaterial(Vec3(0.85f, 0.85f, 0.8f), 0.9f, 0.0f));
+    auto leafM = MakeMaterial(Vec3(1.0f), 0.6f, 0.0f);
+    leafM.ColorIdx = leafTex;
+    const auto leafMat = sb.AddMaterial("Leaf", leafM);
+    auto decalM = MakeMaterial(Vec3(1.0f), 0.5f, 0.0f);
+    decalM.ColorIdx = decalTex;
+    const auto decalMat = sb.AddMaterial("Decal", decalM);
+    auto ghostM = MakeMaterial(Vec3(0.1f, 0.3f, 0.9f), 0.5f, 0.0f);
+    ghostM.Color[3] = 0.4f;
+    const auto ghostMat = sb.AddMaterial("Ghost", ghostM);
+    auto filmM = MakeMaterial(Vec3(0.9f, 0.8f, 0.2f), 0.3f, 0.0f);
+    filmM.Color[3] = 0.8f;
+    const auto filmMat = sb.AddMaterial("Film", filmM);
+
+    const uint32_t floor = AddGridSurface(sb, 4, 4, false, [](float u, float v) { return Vec3(-5.0f + 10.0f * u, 0.0f, -5.0f + 10.0f * v); });
+    {
+        auto &vertices = sb.GetVertices();
+        for (size_t k = vertices.size() - 25; k < vertices.size(); k++)
+        {
+            vertices[k].TexCoords[0] *= 3.0f;
+            vertices[k].TexCoords[1] *= 3.0f;
+        }
+    }
+    const uint32_t wall = AddGridSurface(sb, 2, 2, false, [](float u, float v) { return Vec3(-5.0f + 10.0f * u, 5.0f * v, 3.0f); }, true);
+    const uint32_t decal = AddGridSurface(sb, 1, 1, false, [](float u, float v) { return Vec3(0.8f + 2.4f * u, 2.6f + 2.4f * v, 2.9f); }, true, false);
+    const uint32_t ghost = AddGridSurface(sb, 1, 1, false, [](float u, float v) { return Vec3(0.5f + 2.0f * u, 0.2f + 2.5f * v, 1.5f); }, true, false);
+    const uint32_t film = AddGridSurface(sb, 1, 1, false, [](float u, float v) { return Vec3(2.8f + 1.6f * u, 0.0f + 2.0f * v, 0.5f - 0.8f * u); }, true, false);
+    const uint32_t leaves = AddCards(sb, rng, 300, Vec3(-3.5f, 0.3f, -1.5f), Vec3(0.5f, 3.2f, 1.5f), 0.35f, false);
+
+    const uint32_t root = sb.AddSceneNode({ 0u, Mat4::Identity(), Mat4::Identity() });
+    const std::array<MeshInfo, 6> meshes = { MI(floor, floorMat), MI(wall, wallMat), MI(decal, decalMat), MI(ghost, ghostMat), MI(film, filmMat),
+                                             MI(leaves, leafMat) };
+    sb.AddModelInstance(sb.AddModel(meshes), root);
+
+    sb.AddLight(MakePointLight(Vec3(9.0f, 8.5f, 8.0f), Vec3(-1.0f, 4.5f, -2.5f)), root);
+    Shaders::DirectionalLight dl;
+    std::memset(&dl, 0, sizeof(dl));
+    dl.Color[0] = 2.0f; dl.Color[1] = 1.9f; dl.Color[2] = 1.7f;
+    dl.Direction[0] = 0.3f; dl.Direction[1] = -1.0f; dl.Direction[2] = 0.5f;
+    sb.SetDirectionalLight(std::move(dl), root);
+    AddViewCamera(sb, Vec3(0.0f, 2.0f, -6.0f), Vec3(0.0f, 1.6f, 0.0f));
+}
+
 // ---------------------------------------------------------------------------
 
-const char *const kSceneNames = "default,roughness_cubes,attenuation_blob,chess_like,temple_like,atrium_like,street_like,texture_test";
+const char *const kSceneNames = "default,roughness_cubes,attenuation_blob,chess_like,temple_like,atrium_like,street_like,texture_test,alpha_test";
 
 const char *GetSceneNames()
 {
@@ -1051,6 +1124,8 @@ std::shared_ptr<Scene> CreateScene(const std::string &name, float detail, uint32
         CreateStreetLikeScene(sb, detail, seed ? seed : 5);
     else if (name == "texture_test")
         CreateTextureTestScene(sb, seed ? seed : 6);
+    else if (name == "alpha_test")
+        CreateAlphaTestScene(sb, seed ? seed : 7);
     else
         throw error("Unknown scene: " + name);
     auto scene = sb.CreateSceneShared(name);
