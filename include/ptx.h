@@ -242,8 +242,9 @@ typedef struct PtxTextureDesc {
 
 enum {
     PTX_SKYBOX_CLEAR_COLOR = 0, /* miss.rmiss:37: constant (0.08, 0.09, 0.10) */
-    PTX_SKYBOX_2D = 1,          /* MissFlagsSkybox2D  -- next row N1          */
-    PTX_SKYBOX_CUBE = 2         /* MissFlagsSkyboxCube -- next row N1         */
+    PTX_SKYBOX_2D = 1,          /* MissFlagsSkybox2D: miss.rmiss:18-30, skybox[0] is the equirectangular image */
+    PTX_SKYBOX_CUBE = 2         /* MissFlagsSkyboxCube: miss.rmiss:31-34, skybox[0..5] = +X -X +Y -Y +Z -Z
+                                 * (the layer order of TextureUploader.cpp:234-235: Front Back Up Down Left Right) */
 };
 
 /* What Renderer::UpdateSceneData pulls through the Scene getters
@@ -274,6 +275,8 @@ typedef struct PtxSceneDesc {
     const PtxTextureDesc *textures; /* Scene::GetTextures(); may be NULL: indices >= 9 then sample the white placeholder */
     uint32_t textureCount;
     uint32_t reserved;
+    const PtxTextureDesc *skybox; /* Scene::GetSkybox(): 1 (2D) or 6 (cube, equal square faces) images, one level each
+                                   * (TextureUploader.cpp:203-262); ignored for PTX_SKYBOX_CLEAR_COLOR */
 } PtxSceneDesc;
 
 /* ------------------------------------------------------------------------- */
@@ -421,7 +424,10 @@ typedef enum PtxTestFunction {
     PTX_FN_REFLECTED_DIFFERENTIALS = 25, /* in: deriv(4) n p wo wi dndu dndv rxO rxD ryO ryD (34)  out: rxO rxD ryO ryD (12) */
     PTX_FN_REFRACTED_DIFFERENTIALS = 26, /* in: same + eta (35)                   out: rxO rxD ryO ryD (12)      */
     PTX_FN_COMPUTE_LOD = 27,        /* in: derivatives (4)                        out: lod                       */
-    PTX_FN_COUNT = 28
+    PTX_FN_SKYBOX_TEXCOORDS = 28,   /* in: ray direction (3)                      out: uv (2)   miss.rmiss:20-25 */
+    PTX_FN_HDR_TO_LDR = 29,         /* in: rgb (3)                                out: rgb (3)  common.glsl:17-20 */
+    PTX_FN_ATAN_ASIN = 30,          /* in: y x (2)                                out: atan(y,x) asin(y) kernels */
+    PTX_FN_COUNT = 31
 } PtxTestFunction;
 
 /* Material block used by PTX_FN_EVALUATE_BSDF / PTX_FN_SAMPLE_BSDF:

@@ -724,6 +724,7 @@ struct PtoScene
     /* scene textures (row N1) */
     struct OTexture *textures;
     uint32_t textureCount;
+    uint32_t skyKind; /* PTX_SKYBOX_*; its 1 / 6 images sit at textures[textureCount ...] */
     uint32_t *texels8; /* RGBA8 pool, all levels of all 8-bit textures */
     float *texelsF;    /* RGBA32F pool */
     float srgbLut[256];
@@ -849,7 +850,8 @@ PtoScene *pto_scene_create(const PtxSceneDesc *desc, int wantBvh)
         }
     }
     uploadTextures(s, desc);
-    s->d.textures = NULL; /* the caller's array is not retained */
+    s->d.textures = NULL; /* the caller's arrays are not retained */
+    s->d.skybox = NULL;
     if (wantBvh && triCount)
         buildBvh(s);
     return s;
@@ -1396,19 +1398,25 @@ static void uploadTextures(PtoScene *s, const PtxSceneDesc *desc)
     for (int c = 0; c < 256; c++)
         s->srgbLut[c] = srgbToLinear((float)c / 255.0f);
     s->textureCount = desc->textures ? desc->textureCount : 0;
-    if (!s->textureCount)
+    /* the skybox images follow the scene textures in the table, one level each (TextureUploader.cpp:203-262) */
+    s->skyKind = desc->skybox ? desc->skyboxKind : PTX_SKYBOX_CLEAR_COLOR;
+    const uint32_t skyCount = s->skyKind == PTX_SKYBOX_2D ? 1u : s->skyKind == PTX_SKYBOX_CUBE ? 6u : 0u;
+    const uint32_t total = s->textureCount + skyCount;
+    if (!total)
         return;
-    s->textures = (OTexture *)calloc(s->textureCount, sizeof(OTexture));
+    s->textures = (OTexture *)calloc(total, sizeof(OTexture));
     size_t n8 = 0, nf = 0;
-    for (uint32_t i = 0; i < s->textureCount; i++)
+    for (uint32_t i = 0; i < total; i++)
     {
-        const PtxTextureDesc *d = &desc->textures[i];
+        const PtxTextureDesc *d = i < s->textureCount ? &desc->textures[i] : &desc->skybox[i - s->textureCount];
         OTexture *t = &s->textures[i];
         t->width = d->width ? d->width : 1;
         t->height = d->height ? d->height : 1;
         t->format = d->format;
         uint32_t m = t->width > t->height ? t->width : t->height, levels = 1;
         while (m > 1) { m >>= 1; levels++; } /* floor(log2(max)) + 1, Image.cpp:14-17 */
+        if (i >= s->textureCount)
+            levels = 1;
         t->levels = levels > 16 ? 16 : levels;
         size_t *cursor = t->format == PTX_TEXTURE_RGBA32F ? &nf : &n8;
         for (uint32_t l = 0; l < t->levels; l++)
@@ -1419,9 +1427,9 @@ static void uploadTextures(PtoScene *s, const PtxSceneDesc *desc)
     }
     s->texels8 = (uint32_t *)calloc(n8 ? n8 : 1, 4);
     s->texelsF = (float *)calloc(nf ? nf : 1, 16);
-    for (uint32_t i = 0; i < s->textureCount; i++)
+    for (uint32_t i = 0; i < total; i++)
     {
-        const PtxTextureDesc *d = &desc->textures[i];
+        const PtxTextureDesc *d = i < s->textureCount ? &desc->textures[i] : &desc->skybox[i - s->textureCount];
         OTexture *t = &s->textures[i];
         const size_t n0 = (size_t)t->width * t->height;
         if (d->data)
@@ -1772,10 +1780,87 @@ static void closestHit(const PtoScene *s, const PtxLightsUbo *lights, v3 rayOrig
         computeReflectedDifferentialRays(derivatives, vertex.Normal, rayOrigin, v_neg(rayDirW), payload->Direction, dndu, dndv, &payload->diff);
 }
 
-/* miss.rmiss:16-39, MissFlagsNone branch (skybox textures are next row N1) */
-static inline void missShader(Payload *payload)
+/* common.glsl:17-20 */
+static inline v3 hdrToLdr(v3 rgb) { return v_div(rgb, 1.0f + maxComponent(rgb)); }
+
+/* miss.rmiss:20-25: equirectangular coordinates of a direction */
+static inline v2 missSkyboxTexCoords(v3 dir)
 {
-    payload->Emissive = V3(0.08f, 0.09f, 0.1f);
+    const float PI = 3.14159265359f; /* common.glsl:3 */
+    const float longitude = pto_atan2f(dir.z, dir.x);
+    const float latitude = pto_asinf(-dir.y);
+    v2 uv;
+    uv.x = longitude / 2.0f / PI + 0.5f;
+    uv.y = latitude / PI + 0.5f;
+    return uv;
+}
+
+/* clamp-to-edge bilinear inside one cube face */
+static v4 sampleFace(const PtoScene *s, const OTexture *t, float u, float v)
+{
+    const uint32_t w = t->width, h = t->height;
+    if (!(fabsf(u) < 1e9f)) u = 0.0f;
+    if (!(fabsf(v) < 1e9f)) v = 0.0f;
+    const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    const float x0 = floorf(x), y0 = floorf(y);
+    const float ax = x - x0, ay = y - y0;
+    const float mx = (float)(w - 1), my = (float)(h - 1);
+    const uint32_t ix0 = (uint32_t)f_clamp(x0, 0.0f, mx), ix1 = (uint32_t)f_clamp(x0 + 1.0f, 0.0f, mx);
+    const uint32_t iy0 = (uint32_t)f_clamp(y0, 0.0f, my), iy1 = (uint32_t)f_clamp(y0 + 1.0f, 0.0f, my);
+    const v4 top = v4_lerp(fetchTexel(s, t, 0, ix0, iy0), fetchTexel(s, t, 0, ix1, iy0), ax);
+    const v4 bot = v4_lerp(fetchTexel(s, t, 0, ix0, iy1), fetchTexel(s, t, 0, ix1, iy1), ax);
+    return v4_lerp(top, bot, ay);
+}
+
+/* texture(samplerCube, dir): face selection and (s, t) of the Vulkan spec's cube map face selection
+ * tables (largest magnitude, z before y before x on ties); filtering stays inside the selected face
+ * (the seamless edge blend of the hardware sampler is not reproduced). */
+static v4 sampleCube(const PtoScene *s, const OTexture *faces, v3 r)
+{
+    const float ax = fabsf(r.x), ay = fabsf(r.y), az = fabsf(r.z);
+    uint32_t face;
+    float sc, tc, ma;
+    if (az >= ax && az >= ay)
+    {
+        face = r.z < 0.0f ? 5u : 4u;
+        sc = r.z < 0.0f ? -r.x : r.x;
+        tc = -r.y;
+        ma = az;
+    }
+    else if (ay >= ax)
+    {
+        face = r.y < 0.0f ? 3u : 2u;
+        sc = r.x;
+        tc = r.y < 0.0f ? -r.z : r.z;
+        ma = ay;
+    }
+    else
+    {
+        face = r.x < 0.0f ? 1u : 0u;
+        sc = r.x < 0.0f ? r.z : -r.z;
+        tc = -r.y;
+        ma = ax;
+    }
+    const float u = 0.5f * (sc / ma) + 0.5f, v = 0.5f * (tc / ma) + 0.5f;
+    return sampleFace(s, &faces[face], u, v);
+}
+
+/* miss.rmiss:16-39 */
+static inline void missShader(const PtoScene *s, v3 rayDir, Payload *payload)
+{
+    if (s->skyKind == PTX_SKYBOX_2D)
+    {
+        const v2 uv = missSkyboxTexCoords(rayDir);
+        const v4 c = sampleLevel(s, &s->textures[s->textureCount], 0, uv.x, uv.y);
+        payload->Emissive = hdrToLdr(V3(c.x, c.y, c.z));
+    }
+    else if (s->skyKind == PTX_SKYBOX_CUBE)
+    {
+        const v4 c = sampleCube(s, &s->textures[s->textureCount], rayDir);
+        payload->Emissive = V3(c.x, c.y, c.z);
+    }
+    else
+        payload->Emissive = V3(0.08f, 0.09f, 0.1f);
     payload->Pdf = -1.0f;
 }
 
@@ -1839,7 +1924,7 @@ static void raygenPixel(const PtoScene *s, const PtxRaygenUniformData *U, const 
                 payload.DirectLightPdf = decal.dist;
             }
             if (hit.tri == 0xffffffffu)
-                missShader(&payload);
+                missShader(s, ray.Direction, &payload);
             else
                 closestHit(s, lights, ray.Origin, ray.Direction, &hit, &payload);
             rngState = payload.RngState;
@@ -1941,8 +2026,8 @@ int pto_render(const PtoScene *s, const PtxRaygenUniformData *U, const PtxLights
 /* Function-level entry (packing documented in include/ptx.h)               */
 /* ======================================================================== */
 
-static const int kInStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4 };
-static const int kOutStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1 };
+static const int kInStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4, 3, 3, 2 };
+static const int kOutStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1, 2, 3, 2 };
 
 static MaterialSample unpackMaterial(const float *p)
 {
@@ -2144,6 +2229,20 @@ int pto_test_eval(uint32_t fn, const float *in, float *out, uint32_t n)
             o[6] = r.ryOrigin.x; o[7] = r.ryOrigin.y; o[8] = r.ryOrigin.z; o[9] = r.ryDirection.x; o[10] = r.ryDirection.y; o[11] = r.ryDirection.z;
             break;
         }
+        case PTX_FN_SKYBOX_TEXCOORDS: {
+            const v2 uv = missSkyboxTexCoords(V3(a[0], a[1], a[2]));
+            o[0] = uv.x; o[1] = uv.y;
+            break;
+        }
+        case PTX_FN_HDR_TO_LDR: {
+            const v3 r = hdrToLdr(V3(a[0], a[1], a[2]));
+            o[0] = r.x; o[1] = r.y; o[2] = r.z;
+            break;
+        }
+        case PTX_FN_ATAN_ASIN:
+            o[0] = pto_atan2f(a[0], a[1]);
+            o[1] = pto_asinf(a[0]);
+            break;
         case PTX_FN_COMPUTE_LOD: {
             v4 dv = { a[0], a[1], a[2], a[3] };
             o[0] = computeLod(dv);

@@ -191,4 +191,80 @@ static inline float pto_powf(float x, float y)
     return (float)pto_exp2(t);
 }
 
+/* atan(y, x) over the full circle and asin(x): fixed double-precision kernels (GLSL leaves the
+ * builtins' accuracy to the implementation).  |t| <= tan(pi/8) after the two reductions, where the
+ * odd Taylor series to t^23 is below double rounding of a float result. */
+static inline float pto_atan2f(float yf, float xf)
+{
+    const double y = (double)yf, x = (double)xf;
+    const double ax = x < 0.0 ? -x : x, ay = y < 0.0 ? -y : y;
+    const double hi = ax < ay ? ay : ax, lo = ax < ay ? ax : ay;
+    if (hi == 0.0)
+        return 0.0f;
+    const double a = lo / hi;
+    const int reduce = a > 0.4142135623730951;
+    const double t = reduce ? (a - 1.0) / (a + 1.0) : a;
+    const double z = t * t;
+    double p = -1.0 / 23.0;
+    p = p * z + 1.0 / 21.0;
+    p = p * z - 1.0 / 19.0;
+    p = p * z + 1.0 / 17.0;
+    p = p * z - 1.0 / 15.0;
+    p = p * z + 1.0 / 13.0;
+    p = p * z - 1.0 / 11.0;
+    p = p * z + 1.0 / 9.0;
+    p = p * z - 1.0 / 7.0;
+    p = p * z + 1.0 / 5.0;
+    p = p * z - 1.0 / 3.0;
+    p = p * z + 1.0;
+    double r = t * p;
+    if (reduce)
+        r = 0.7853981633974483 + r;
+    if (ay > ax)
+        r = 1.5707963267948966 - r;
+    if (x < 0.0)
+        r = 3.141592653589793 - r;
+    if (y < 0.0)
+        r = -r;
+    return (float)r;
+}
+
+static inline float pto_asinf(float xf)
+{
+    double x = (double)xf;
+    if (x > 1.0)
+        x = 1.0;
+    if (x < -1.0)
+        x = -1.0;
+    const double c = sqrt((1.0 - x) * (1.0 + x));
+    const double ax = c, ay = x < 0.0 ? -x : x; /* atan2(x, c) with c >= 0, in double throughout */
+    const double hi = ax < ay ? ay : ax, lo = ax < ay ? ax : ay;
+    if (!(hi > 0.0))
+        return xf != xf ? xf : 0.0f;
+    const double a = lo / hi;
+    const int reduce = a > 0.4142135623730951;
+    const double t = reduce ? (a - 1.0) / (a + 1.0) : a;
+    const double z = t * t;
+    double p = -1.0 / 23.0;
+    p = p * z + 1.0 / 21.0;
+    p = p * z - 1.0 / 19.0;
+    p = p * z + 1.0 / 17.0;
+    p = p * z - 1.0 / 15.0;
+    p = p * z + 1.0 / 13.0;
+    p = p * z - 1.0 / 11.0;
+    p = p * z + 1.0 / 9.0;
+    p = p * z - 1.0 / 7.0;
+    p = p * z + 1.0 / 5.0;
+    p = p * z - 1.0 / 3.0;
+    p = p * z + 1.0;
+    double r = t * p;
+    if (reduce)
+        r = 0.7853981633974483 + r;
+    if (ay > ax)
+        r = 1.5707963267948966 - r;
+    if (x < 0.0)
+        r = -r;
+    return (float)r;
+}
+
 #endif

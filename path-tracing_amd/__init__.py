@@ -71,6 +71,7 @@ class SceneDesc(C.Structure):
         ("instances", C.c_void_p), ("instanceCount", C.c_uint32),
         ("skyboxKind", C.c_uint32), ("dxNormalTextures", C.c_uint32),
         ("textures", C.c_void_p), ("textureCount", C.c_uint32), ("reserved", C.c_uint32),
+        ("skybox", C.c_void_p),
     ]
 
 
@@ -124,7 +125,7 @@ FN = {
     "computeTangentSpace": 14, "offsetRayOriginSelfIntersection": 15, "constructPrimaryRay": 16, "sincos": 17,
     "pow": 18, "sampleLight": 19, "offsetRayOriginShadowTerminator": 20, "constructPrimaryRayLens": 21,
     "computeDpnDuv": 22, "computeDpDxy": 23, "computeDerivatives": 24, "computeReflectedDifferentialRays": 25,
-    "computeRefractedDifferentialRays": 26, "computeLod": 27,
+    "computeRefractedDifferentialRays": 26, "computeLod": 27, "missSkyboxTexCoords": 28, "hdrToLdr": 29, "atanAsin": 30,
 }
 
 

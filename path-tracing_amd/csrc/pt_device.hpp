@@ -189,6 +189,81 @@ PT_DEV float pow_(float x, float y) // x >= 0
     return (float)exp2_(t);
 }
 
+// atan(y, x) over the full circle and asin(x): fixed double-precision kernels, the same operation
+// sequence as the CPU check library (|t| <= tan(pi/8) after the reductions, odd Taylor series to t^23).
+PT_DEV float atan2_(float yf, float xf)
+{
+    const double y = (double)yf, x = (double)xf;
+    const double ax = x < 0.0 ? -x : x, ay = y < 0.0 ? -y : y;
+    const double hi = ax < ay ? ay : ax, lo = ax < ay ? ax : ay;
+    if (hi == 0.0)
+        return 0.0f;
+    const double a = lo / hi;
+    const int reduce = a > 0.4142135623730951;
+    const double t = reduce ? (a - 1.0) / (a + 1.0) : a;
+    const double z = t * t;
+    double p = -1.0 / 23.0;
+    p = p * z + 1.0 / 21.0;
+    p = p * z - 1.0 / 19.0;
+    p = p * z + 1.0 / 17.0;
+    p = p * z - 1.0 / 15.0;
+    p = p * z + 1.0 / 13.0;
+    p = p * z - 1.0 / 11.0;
+    p = p * z + 1.0 / 9.0;
+    p = p * z - 1.0 / 7.0;
+    p = p * z + 1.0 / 5.0;
+    p = p * z - 1.0 / 3.0;
+    p = p * z + 1.0;
+    double r = t * p;
+    if (reduce)
+        r = 0.7853981633974483 + r;
+    if (ay > ax)
+        r = 1.5707963267948966 - r;
+    if (x < 0.0)
+        r = 3.141592653589793 - r;
+    if (y < 0.0)
+        r = -r;
+    return (float)r;
+}
+
+PT_DEV float asin_(float xf)
+{
+    double x = (double)xf;
+    if (x > 1.0)
+        x = 1.0;
+    if (x < -1.0)
+        x = -1.0;
+    const double c = __builtin_sqrt((1.0 - x) * (1.0 + x));
+    const double ax = c, ay = x < 0.0 ? -x : x; // atan2(x, c) with c >= 0, in double throughout
+    const double hi = ax < ay ? ay : ax, lo = ax < ay ? ax : ay;
+    if (!(hi > 0.0))
+        return xf != xf ? xf : 0.0f;
+    const double a = lo / hi;
+    const int reduce = a > 0.4142135623730951;
+    const double t = reduce ? (a - 1.0) / (a + 1.0) : a;
+    const double z = t * t;
+    double p = -1.0 / 23.0;
+    p = p * z + 1.0 / 21.0;
+    p = p * z - 1.0 / 19.0;
+    p = p * z + 1.0 / 17.0;
+    p = p * z - 1.0 / 15.0;
+    p = p * z + 1.0 / 13.0;
+    p = p * z - 1.0 / 11.0;
+    p = p * z + 1.0 / 9.0;
+    p = p * z - 1.0 / 7.0;
+    p = p * z + 1.0 / 5.0;
+    p = p * z - 1.0 / 3.0;
+    p = p * z + 1.0;
+    double r = t * p;
+    if (reduce)
+        r = 0.7853981633974483 + r;
+    if (ay > ax)
+        r = 1.5707963267948966 - r;
+    if (x < 0.0)
+        r = -r;
+    return (float)r;
+}
+
 // ---- common.glsl --------------------------------------------------------------------
 
 PT_DEV float maxComponent(f3 rgb) { return fmax_(rgb.x, fmax_(rgb.y, rgb.z)); } // :12-15
@@ -915,6 +990,7 @@ struct SceneView // read-only device views of the uploaded scene
     const struct DevPair *pairs;
     const PtxLightsUbo *lights;
     uint32_t dxNormalTextures;
+    uint32_t skyKind; // PTX_SKYBOX_*; its 1 / 6 single-level images sit at tex.textures[tex.textureCount ...]
     TextureView tex;
 };
 
@@ -991,6 +1067,79 @@ PT_DEV f4 hitBaseColor(const SceneView &sv, uint32_t pairIdx, uint32_t prim, flo
         t = sampleTexture(idx);
     t.x *= factor.x; t.y *= factor.y; t.z *= factor.z; t.w *= factor.w;
     return t;
+}
+
+// ---- miss.rmiss ------------------------------------------------------------------------------------
+
+PT_DEV f3 hdrToLdr(f3 rgb) { return rgb / (1.0f + maxComponent(rgb)); } // common.glsl:17-20
+
+PT_DEV f2 missSkyboxTexCoords(f3 dir) // miss.rmiss:20-25
+{
+    const float PI = 3.14159265359f; // common.glsl:3
+    const float longitude = atan2_(dir.z, dir.x);
+    const float latitude = asin_(-dir.y);
+    return F2(longitude / 2.0f / PI + 0.5f, latitude / PI + 0.5f);
+}
+
+PT_DEV f4 sampleFace(const TextureView &tv, const DevTexture &t, float u, float v) // clamp-to-edge bilinear inside one cube face
+{
+    const uint32_t w = t.width, h = t.height;
+    if (!(abs_(u) < 1e9f)) u = 0.0f;
+    if (!(abs_(v) < 1e9f)) v = 0.0f;
+    const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    const float x0 = __builtin_floorf(x), y0 = __builtin_floorf(y);
+    const float ax = x - x0, ay = y - y0;
+    const float mx = (float)(w - 1), my = (float)(h - 1);
+    const uint32_t ix0 = (uint32_t)clamp_(x0, 0.0f, mx), ix1 = (uint32_t)clamp_(x0 + 1.0f, 0.0f, mx);
+    const uint32_t iy0 = (uint32_t)clamp_(y0, 0.0f, my), iy1 = (uint32_t)clamp_(y0 + 1.0f, 0.0f, my);
+    const f4 top = lerp4(fetchTexel(tv, t, 0, ix0, iy0), fetchTexel(tv, t, 0, ix1, iy0), ax);
+    const f4 bot = lerp4(fetchTexel(tv, t, 0, ix0, iy1), fetchTexel(tv, t, 0, ix1, iy1), ax);
+    return lerp4(top, bot, ay);
+}
+
+// texture(samplerCube, dir): face and (s, t) by the Vulkan cube map face selection tables (largest
+// magnitude, z before y before x on ties); filtering stays inside the selected face.
+PT_DEV f4 sampleCube(const TextureView &tv, const DevTexture *faces, f3 r)
+{
+    const float ax = abs_(r.x), ay = abs_(r.y), az = abs_(r.z);
+    uint32_t face;
+    float sc, tc, ma;
+    if (az >= ax && az >= ay)
+    {
+        face = r.z < 0.0f ? 5u : 4u;
+        sc = r.z < 0.0f ? -r.x : r.x;
+        tc = -r.y;
+        ma = az;
+    }
+    else if (ay >= ax)
+    {
+        face = r.y < 0.0f ? 3u : 2u;
+        sc = r.x;
+        tc = r.y < 0.0f ? -r.z : r.z;
+        ma = ay;
+    }
+    else
+    {
+        face = r.x < 0.0f ? 1u : 0u;
+        sc = r.x < 0.0f ? r.z : -r.z;
+        tc = -r.y;
+        ma = ax;
+    }
+    const float u = 0.5f * (sc / ma) + 0.5f, v = 0.5f * (tc / ma) + 0.5f;
+    return sampleFace(tv, faces[face], u, v);
+}
+
+// payload.Emissive of miss.rmiss:16-39 (Pdf = -1 is the caller's path termination)
+PT_DEV f3 missEmissive(const SceneView &sv, f3 rayDir)
+{
+    if (sv.skyKind == PTX_SKYBOX_2D)
+    {
+        const f2 uv = missSkyboxTexCoords(rayDir);
+        return hdrToLdr(rgb(sampleLevel(sv.tex, sv.tex.textures[sv.tex.textureCount], 0, uv.x, uv.y)));
+    }
+    if (sv.skyKind == PTX_SKYBOX_CUBE)
+        return rgb(sampleCube(sv.tex, sv.tex.textures + sv.tex.textureCount, rayDir));
+    return F3(0.08f, 0.09f, 0.1f);
 }
 
 PT_DEV f3 specGlossMetalness(f3 specular, f3 color) // material.glsl:109-110, :138-139

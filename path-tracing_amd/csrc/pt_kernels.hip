@@ -333,8 +333,9 @@ __global__ void __launch_bounds__(kBlock) k_shade(LaunchParams p, SceneView sv, 
 
             if (pair == 0xffffffffu)
             {
-                // miss.rmiss:37-39 (MissFlagsNone): constant sky, Pdf = -1 -> raygen.rgen:71-75
-                radiance = radiance + throughput * F3(0.08f, 0.09f, 0.1f);
+                // miss.rmiss:16-39: sky colour / skybox lookup, Pdf = -1 -> raygen.rgen:71-75
+                const float4 d4 = wf.rayD[slot];
+                radiance = radiance + throughput * missEmissive(sv, F3(d4.x, d4.y, d4.z));
                 pushNext = finishSample(p, wf, slot, meta, radiance, nSamples, nRetries);
             }
             else
@@ -562,7 +563,7 @@ PT_DEV f3 runPath(const LaunchParams &p, const SceneView &sv, const TraceScene &
             Decal decal = noDecal();
             if (!traceRay<false, false, ALPHA>(sc, ro, rd, 0.00001f, 10000.0f, st, h, nullptr, nullptr, &decal))
             {
-                radiance = radiance + throughput * F3(0.08f, 0.09f, 0.1f);
+                radiance = radiance + throughput * missEmissive(sv, rd);
                 break;
             }
             HitOut out;
@@ -790,10 +791,10 @@ __global__ void k_test_texture(TextureView tv, const float *__restrict__ in, flo
 
 // function-level entry (Path-Tracing-Tests/TestRenderer.cpp:79-105 dispatches a compute
 // shader that calls the production functions; packing documented in include/ptx.h)
-__constant__ int c_inStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4 };
-__constant__ int c_outStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1 };
-static const int h_inStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4 };
-static const int h_outStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1 };
+__constant__ int c_inStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4, 3, 3, 2 };
+__constant__ int c_outStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1, 2, 3, 2 };
+static const int h_inStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4, 3, 3, 2 };
+static const int h_outStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1, 2, 3, 2 };
 
 PT_DEV MaterialSample unpackMaterial(const float *p)
 {
@@ -990,6 +991,20 @@ __global__ void k_test_eval(uint32_t fn, const float *__restrict__ in, float *__
         o[6] = r.ryOrigin.x; o[7] = r.ryOrigin.y; o[8] = r.ryOrigin.z; o[9] = r.ryDirection.x; o[10] = r.ryDirection.y; o[11] = r.ryDirection.z;
         break;
     }
+    case PTX_FN_SKYBOX_TEXCOORDS: {
+        const f2 uv = missSkyboxTexCoords(F3(a[0], a[1], a[2]));
+        o[0] = uv.x; o[1] = uv.y;
+        break;
+    }
+    case PTX_FN_HDR_TO_LDR: {
+        const f3 r = hdrToLdr(F3(a[0], a[1], a[2]));
+        o[0] = r.x; o[1] = r.y; o[2] = r.z;
+        break;
+    }
+    case PTX_FN_ATAN_ASIN:
+        o[0] = atan2_(a[0], a[1]);
+        o[1] = asin_(a[0]);
+        break;
     case PTX_FN_COMPUTE_LOD: {
         f4 dv; dv.x = a[0]; dv.y = a[1]; dv.z = a[2]; dv.w = a[3];
         o[0] = computeLod(dv);
@@ -1051,6 +1066,7 @@ struct PtxRenderer
     DevBuf<float4> texelsF;
     DevBuf<float> srgbLut;
     uint32_t textureCount = 0;
+    uint32_t skyKind = PTX_SKYBOX_CLEAR_COLOR; // its images follow the scene textures in `textures`
     bool samplerNeeded = false; // some uploaded texture is not a 1x1 white placeholder
     bool anyNonOpaque = false;  // some instanced geometry lacks the opaque flag: any-hit stages run
     DevBuf<float4> decal;
@@ -1421,11 +1437,22 @@ int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *s)
         HIP_TRY(r, r->srgbLut.alloc(256));
         k_build_srgb_lut<<<1, 256, 0, r->stream>>>(r->srgbLut.p);
         r->textureCount = s->textures ? s->textureCount : 0;
-        std::vector<DevTexture> table(r->textureCount);
+        // the skybox images follow the scene textures in the table, one level each (TextureUploader.cpp:203-262)
+        r->skyKind = s->skybox ? s->skyboxKind : (uint32_t)PTX_SKYBOX_CLEAR_COLOR;
+        if (r->skyKind > PTX_SKYBOX_CUBE)
+            return fail(r, PTX_ERROR_INVALID_ARGUMENT, "unknown skybox kind %u", r->skyKind);
+        const uint32_t skyCount = r->skyKind == PTX_SKYBOX_2D ? 1u : r->skyKind == PTX_SKYBOX_CUBE ? 6u : 0u;
+        const uint32_t total = r->textureCount + skyCount;
+        auto descOf = [&](uint32_t i) -> const PtxTextureDesc & { return i < r->textureCount ? s->textures[i] : s->skybox[i - r->textureCount]; };
+        if (r->skyKind == PTX_SKYBOX_CUBE)
+            for (uint32_t f = 0; f < 6; f++)
+                if (s->skybox[f].width != s->skybox[0].width || s->skybox[f].height != s->skybox[0].width || s->skybox[f].format != s->skybox[0].format)
+                    return fail(r, PTX_ERROR_INVALID_ARGUMENT, "cube skybox: the six faces must be equal squares of one format");
+        std::vector<DevTexture> table(total);
         size_t n8 = 0, nf = 0;
-        for (uint32_t i = 0; i < r->textureCount; i++)
+        for (uint32_t i = 0; i < total; i++)
         {
-            const PtxTextureDesc &d = s->textures[i];
+            const PtxTextureDesc &d = descOf(i);
             DevTexture &t = table[i];
             if (d.format > PTX_TEXTURE_RGBA32F)
                 return fail(r, PTX_ERROR_INVALID_ARGUMENT, "texture %u: unknown format %u", i, d.format);
@@ -1434,6 +1461,8 @@ int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *s)
             t.format = d.format;
             uint32_t m = t.width > t.height ? t.width : t.height, levels = 1;
             while (m > 1) { m >>= 1; levels++; } // floor(log2(max)) + 1, Image.cpp:14-17
+            if (i >= r->textureCount)
+                levels = 1;
             t.levels = levels > 16 ? 16 : levels;
             size_t &cursor = t.format == PTX_TEXTURE_RGBA32F ? nf : n8;
             for (uint32_t l = 0; l < t.levels; l++)
@@ -1445,7 +1474,7 @@ int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *s)
                 cursor += (size_t)lw * lh;
             }
         }
-        HIP_TRY(r, r->textures.alloc(r->textureCount));
+        HIP_TRY(r, r->textures.alloc(total));
         HIP_TRY(r, r->texels8.alloc(n8));
         HIP_TRY(r, r->texelsF.alloc(nf));
         if (n8)
@@ -1464,14 +1493,14 @@ int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *s)
             if (!whitePlaceholder)
                 r->samplerNeeded = true;
         }
-        if (r->textureCount)
+        if (total)
             HIP_TRY(r, hipMemcpyAsync(r->textures.p, table.data(), table.size() * sizeof(DevTexture), hipMemcpyHostToDevice, r->stream));
         TextureView tv;
         tv.textures = r->textures.p; tv.textureCount = r->textureCount; tv.texels8 = r->texels8.p; tv.texelsF = r->texelsF.p;
         tv.srgbLut = r->srgbLut.p;
-        for (uint32_t i = 0; i < r->textureCount; i++)
+        for (uint32_t i = 0; i < total; i++)
         {
-            const PtxTextureDesc &d = s->textures[i];
+            const PtxTextureDesc &d = descOf(i);
             const DevTexture &t = table[i];
             const size_t n0 = (size_t)t.width * t.height;
             if (d.data)
@@ -1625,6 +1654,7 @@ static SceneView makeSceneView(const PtxRenderer *r)
     sv.pairs = r->pairs.p; sv.lights = r->lights.p; sv.dxNormalTextures = r->dxNormalTextures;
     sv.tex.textures = r->textures.p; sv.tex.textureCount = r->textureCount; sv.tex.texels8 = r->texels8.p; sv.tex.texelsF = r->texelsF.p;
     sv.tex.srgbLut = r->srgbLut.p;
+    sv.skyKind = r->skyKind;
     return sv;
 }
 

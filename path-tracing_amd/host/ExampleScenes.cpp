@@ -473,7 +473,69 @@ void CreateDefaultScene(SceneBuilder &sceneBuilder)
     sceneBuilder.SetDirectionalLight(std::move(dl), rootNode);
 }
 
-// ExampleScenes.cpp:755-842 (the 2-D skybox texture is the next row N1: constant sky)
+TextureInfo MakeTexture(TextureType type, const std::string &name, uint32_t w, uint32_t h,
+                        const std::function<void(uint32_t, uint32_t, uint8_t *)> &texel);
+uint32_t HashU(uint32_t x, uint32_t y, uint32_t seed);
+
+// Procedural daylight sky, the stand-in for the reference's sky_42 skybox images (downloaded assets):
+// blue zenith, pale horizon, grey-brown ground, a sun disc, thin cloud streaks.  8-bit sRGB like the PNGs.
+void SkyTexel(Vec3 d, uint8_t *p)
+{
+    d = Normalize(d);
+    const Vec3 sun = Normalize(Vec3(0.45f, 0.55f, -0.7f));
+    float r, g, b;
+    if (d.y >= 0.0f)
+    {
+        const float h = std::pow(1.0f - d.y, 3.0f);
+        r = 0.25f + 0.6f * h; g = 0.45f + 0.45f * h; b = 0.85f + 0.1f * h;
+        const float streak = std::sin(9.0f * d.x + 4.0f * d.z) * std::sin(13.0f * d.z - 3.0f * d.x);
+        const float cloud = streak > 0.55f ? (streak - 0.55f) * 1.6f * d.y : 0.0f;
+        r += cloud * (1.0f - r); g += cloud * (1.0f - g); b += cloud * (1.0f - b);
+        const float c = Dot(d, sun);
+        if (c > 0.9985f)
+            r = g = b = 1.0f;
+        else if (c > 0.96f)
+        {
+            const float halo = (c - 0.96f) / 0.0385f;
+            r += halo * (1.0f - r); g += halo * 0.9f * (1.0f - g); b += halo * 0.6f * (1.0f - b);
+        }
+    }
+    else
+    {
+        const float h = std::pow(1.0f + d.y, 6.0f);
+        r = 0.22f + 0.5f * h; g = 0.2f + 0.5f * h; b = 0.18f + 0.55f * h;
+    }
+    auto q = [](float v) { return static_cast<uint8_t>(std::fmin(std::fmax(v, 0.0f), 1.0f) * 255.0f + 0.5f); };
+    p[0] = q(r); p[1] = q(g); p[2] = q(b); p[3] = 255;
+}
+
+// equirectangular image addressed as miss.rmiss:20-25 does: u = atan(z, x) / 2pi + 0.5, v = asin(-y) / pi + 0.5
+Skybox2D MakeSkybox2D(uint32_t width, uint32_t height)
+{
+    const float pi = 3.14159265358979f;
+    return Skybox2D { MakeTexture(TextureType::Skybox, "Skybox", width, height, [=](uint32_t x, uint32_t y, uint8_t *p) {
+        const float lon = ((static_cast<float>(x) + 0.5f) / static_cast<float>(width) - 0.5f) * 2.0f * pi;
+        const float lat = ((static_cast<float>(y) + 0.5f) / static_cast<float>(height) - 0.5f) * pi;
+        SkyTexel(Vec3(std::cos(lat) * std::cos(lon), -std::sin(lat), std::cos(lat) * std::sin(lon)), p);
+    }) };
+}
+
+// six faces in the layer order +X -X +Y -Y +Z -Z (px nx py ny pz nz of ExampleScenes.cpp:745-752)
+SkyboxCube MakeSkyboxCube(uint32_t size)
+{
+    const char *names[6] = { "Skybox px", "Skybox nx", "Skybox py", "Skybox ny", "Skybox pz", "Skybox nz" };
+    TextureInfo faces[6];
+    for (int f = 0; f < 6; f++)
+        faces[f] = MakeTexture(TextureType::Skybox, names[f], size, size, [=](uint32_t x, uint32_t y, uint8_t *p) {
+            const float sc = 2.0f * (static_cast<float>(x) + 0.5f) / static_cast<float>(size) - 1.0f;
+            const float tc = 2.0f * (static_cast<float>(y) + 0.5f) / static_cast<float>(size) - 1.0f;
+            const Vec3 dirs[6] = { Vec3(1, -tc, -sc), Vec3(-1, -tc, sc), Vec3(sc, 1, tc), Vec3(sc, -1, -tc), Vec3(sc, -tc, 1), Vec3(-sc, -tc, -1) };
+            SkyTexel(dirs[f], p);
+        });
+    return SkyboxCube { std::move(faces[0]), std::move(faces[1]), std::move(faces[2]), std::move(faces[3]), std::move(faces[4]), std::move(faces[5]) };
+}
+
+// ExampleScenes.cpp:755-842; the 2-D skybox is the procedural stand-in above
 void CreateRoughnessTestCubesScene(SceneBuilder &sceneBuilder)
 {
     std::array<std::array<Shaders::MaterialId, 6>, 6> whiteMaterials;
@@ -514,6 +576,104 @@ void CreateRoughnessTestCubesScene(SceneBuilder &sceneBuilder)
             const uint32_t cubeNode = sceneBuilder.AddSceneNode({ rootNode, t, Mat4::Identity() });
             sceneBuilder.AddModelInstance(cubeModels[i * 6 + j], cubeNode);
         }
+
+    sceneBuilder.SetSkybox(MakeSkybox2D(1024, 512)); // :839-841
+}
+
+// ExampleScenes.cpp:658-753 "Reuse Mesh Cubes": ONE cube model assembled from three quad geometries, each used
+// twice through a baked mesh transform (the half-turn about x / y / z), three PBR materials with colour, normal,
+// roughness and metallic maps, and a cube-map skybox.  The downloaded JPG material sets (Metal062C,
+// PavingStones142, Logs001) are replaced by procedural 256^2 maps of the same roles.
+void CreateReuseMeshCubesScene(SceneBuilder &sb, uint32_t seed)
+{
+    const char *names[3] = { "Metal", "PavingStones", "Logs" };
+    Shaders::MaterialId materialIds[3];
+    for (int i = 0; i < 3; i++)
+    {
+        const uint32_t salt = seed * 16u + static_cast<uint32_t>(i);
+        auto pattern = [i, salt](uint32_t x, uint32_t y) { // 0..1 height-like value per material
+            if (i == 0)
+                return 0.5f + 0.5f * std::sin(0.35f * static_cast<float>(x) + 0.02f * static_cast<float>(HashU(0, y / 3, salt) & 63));
+            if (i == 1)
+            {
+                const uint32_t bx = x % 64, by = (y + (x / 64 % 2) * 32) % 64;
+                const bool joint = bx < 4 || by < 4;
+                return joint ? 0.1f : 0.6f + 0.4f * static_cast<float>(HashU(x / 64, (y + (x / 64 % 2) * 32) / 64, salt) & 255) / 255.0f;
+            }
+            const float ring = std::sin(0.18f * std::sqrt(static_cast<float>((x % 128) * (x % 128) + ((y + 40) % 128) * ((y + 40) % 128))));
+            return 0.5f + 0.5f * ring;
+        };
+        const Vec3 tint = i == 0 ? Vec3(0.78f, 0.8f, 0.84f) : i == 1 ? Vec3(0.62f, 0.58f, 0.52f) : Vec3(0.5f, 0.33f, 0.18f);
+        const std::string base = names[i];
+        auto m = DefaultMaterialInfo();
+        m.Color[0] = m.Color[1] = m.Color[2] = m.Color[3] = 1.0f;
+        m.Roughness = 1.0f;
+        m.Metalness = 1.0f;
+        m.Ior = 1.5f;
+        m.ColorIdx = sb.AddTexture(MakeTexture(TextureType::Color, base + "_Color", 256, 256, [=](uint32_t x, uint32_t y, uint8_t *p) {
+            const float v = 0.55f + 0.45f * pattern(x, y);
+            p[0] = static_cast<uint8_t>(255.0f * tint.x * v); p[1] = static_cast<uint8_t>(255.0f * tint.y * v);
+            p[2] = static_cast<uint8_t>(255.0f * tint.z * v); p[3] = 255;
+        }));
+        m.NormalIdx = sb.AddTexture(MakeTexture(TextureType::Normal, base + "_NormalGL", 256, 256, [=](uint32_t x, uint32_t y, uint8_t *p) {
+            const float dx = pattern((x + 1) % 256, y) - pattern((x + 255) % 256, y), dy = pattern(x, (y + 1) % 256) - pattern(x, (y + 255) % 256);
+            p[0] = static_cast<uint8_t>(128.0f - 100.0f * std::fmax(-1.0f, std::fmin(1.0f, dx)));
+            p[1] = static_cast<uint8_t>(128.0f - 100.0f * std::fmax(-1.0f, std::fmin(1.0f, dy)));
+            p[2] = 255; p[3] = 255;
+        }));
+        // the reference binds the same *_Roughness image to both slots: roughness reads .g, metalness .b
+        const float metal = i == 0 ? 1.0f : 0.0f;
+        auto roughTexel = [=](uint32_t x, uint32_t y, uint8_t *p) {
+            const float rough = i == 0 ? 0.2f + 0.3f * pattern(x, y) : 0.55f + 0.4f * pattern(x, y);
+            p[0] = p[1] = static_cast<uint8_t>(255.0f * rough); p[2] = static_cast<uint8_t>(255.0f * metal); p[3] = 255;
+        };
+        m.RoughnessIdx = sb.AddTexture(MakeTexture(TextureType::Roughness, base + "_Roughness", 256, 256, roughTexel));
+        m.MetallicIdx = sb.AddTexture(MakeTexture(TextureType::Metallic, base + "_Roughness (metallic)", 256, 256, roughTexel));
+        materialIds[i] = sb.AddMaterial(names[i], m);
+    }
+
+    // three quads of the cube [-1,1]^3: +z, -x and +y faces
+    auto &vertices = sb.GetVertices();
+    auto &indices = sb.GetIndices();
+    const Vec3 origin[3] = { Vec3(-1, -1, 1), Vec3(-1, -1, -1), Vec3(-1, 1, 1) };
+    const Vec3 du[3] = { Vec3(2, 0, 0), Vec3(0, 0, 2), Vec3(2, 0, 0) }, dv[3] = { Vec3(0, 2, 0), Vec3(0, 2, 0), Vec3(0, 0, -2) };
+    const Vec3 nrm[3] = { Vec3(0, 0, 1), Vec3(-1, 0, 0), Vec3(0, 1, 0) };
+    uint32_t geometryIndices[3];
+    for (int f = 0; f < 3; f++)
+    {
+        const uint32_t vertexOffset = static_cast<uint32_t>(vertices.size()), indexOffset = static_cast<uint32_t>(indices.size());
+        const float cu[4] = { 0, 1, 1, 0 }, cv[4] = { 0, 0, 1, 1 };
+        const Vec3 t = Normalize(du[f]), b = Normalize(dv[f]);
+        for (int k = 0; k < 4; k++)
+        {
+            const Vec3 p = origin[f] + du[f] * cu[k] + dv[f] * cv[k];
+            vertices.push_back(V({ p.x, p.y, p.z }, { cu[k], 1.0f - cv[k] }, { nrm[f].x, nrm[f].y, nrm[f].z }, { t.x, t.y, t.z }, { b.x, b.y, b.z }));
+        }
+        for (uint32_t k : { 0u, 1u, 2u, 2u, 3u, 0u })
+            indices.push_back(k);
+        geometryIndices[f] = sb.AddGeometry({ vertexOffset, 4, indexOffset, 6, true, false, { 0, 0 } });
+    }
+
+    const float halfTurn = 3.14159265358979f;
+    const Vec3 axes[3] = { Vec3(1, 0, 0), Vec3(0, 1, 0), Vec3(0, 0, 1) };
+    const Shaders::MaterialId faceMaterials[6] = { materialIds[1], materialIds[1], materialIds[1], materialIds[2], materialIds[2], materialIds[2] };
+    std::array<MeshInfo, 6> meshes;
+    for (int f = 0; f < 3; f++)
+    {
+        meshes[2 * f] = MI(geometryIndices[f], faceMaterials[2 * f]);
+        meshes[2 * f + 1] = MI(geometryIndices[f], faceMaterials[2 * f + 1], ToTransform(Rotate(Mat4::Identity(), halfTurn, axes[f])));
+    }
+    const uint32_t cube = sb.AddModel(meshes);
+    const uint32_t root = sb.AddSceneNode({ 0u, Mat4::Identity(), Mat4::Identity() });
+    sb.AddModelInstance(cube, sb.AddSceneNode({ root, Mat4::Identity(), Mat4::Identity() }));
+    // a second, metal copy beside it so all three materials are on screen
+    const std::array<MeshInfo, 6> metalMeshes = { MI(geometryIndices[0], materialIds[0]), meshes[1], MI(geometryIndices[1], materialIds[0]), meshes[3],
+                                                  MI(geometryIndices[2], materialIds[0]), meshes[5] };
+    const Mat4 t2 = Rotate(Translate(Mat4::Identity(), Vec3(-3.0f, 0.0f, 0.5f)), 0.6f, Vec3(0, 1, 0));
+    sb.AddModelInstance(sb.AddModel(metalMeshes), sb.AddSceneNode({ root, t2, Mat4::Identity() }));
+
+    sb.SetSkybox(MakeSkyboxCube(256));
+    AddViewCamera(sb, Vec3(2.6f, 2.2f, -4.6f), Vec3(-1.2f, 0.0f, 0.0f));
 }
 
 // ---------------------------------------------------------------------------
@@ -1091,7 +1251,7 @@ void CreateAlphaTestScene(SceneBuilder &sb, uint32_t seed)
 
 // ---------------------------------------------------------------------------
 
-const char *const kSceneNames = "default,roughness_cubes,attenuation_blob,chess_like,temple_like,atrium_like,street_like,texture_test,alpha_test";
+const char *const kSceneNames = "default,roughness_cubes,attenuation_blob,chess_like,temple_like,atrium_like,street_like,texture_test,alpha_test,reuse_mesh_cubes";
 
 const char *GetSceneNames()
 {
@@ -1124,6 +1284,8 @@ std::shared_ptr<Scene> CreateScene(const std::string &name, float detail, uint32
         CreateStreetLikeScene(sb, detail, seed ? seed : 5);
     else if (name == "texture_test")
         CreateTextureTestScene(sb, seed ? seed : 6);
+    else if (name == "reuse_mesh_cubes")
+        CreateReuseMeshCubesScene(sb, seed ? seed : 8);
     else if (name == "alpha_test")
         CreateAlphaTestScene(sb, seed ? seed : 7);
     else

@@ -147,13 +147,9 @@ PtxSceneDesc Scene::GetDesc() const
     d.instances = m_InstanceRecords.data();
     d.instanceCount = static_cast<uint32_t>(m_InstanceRecords.size());
     // TextureUploader::GetImageFormat (TextureUploader.cpp:571-594): colour-like types are sRGB
-    m_TextureRecords.resize(m_Textures.size());
-    for (size_t i = 0; i < m_Textures.size(); i++)
-    {
-        const TextureInfo &t = m_Textures[i];
+    auto describe = [](const TextureInfo &t, PtxTextureDesc &rec) {
         const bool isColor = t.Type == TextureType::Color || t.Type == TextureType::Specular || t.Type == TextureType::Emisive ||
                              t.Type == TextureType::Skybox;
-        PtxTextureDesc &rec = m_TextureRecords[i];
         rec.width = t.Width;
         rec.height = t.Height;
         rec.format = t.Format == TextureFormat::RGBAF32 ? PTX_TEXTURE_RGBA32F : (isColor ? PTX_TEXTURE_RGBA8_SRGB : PTX_TEXTURE_RGBA8_UNORM);
@@ -166,10 +162,30 @@ PtxSceneDesc Scene::GetDesc() const
             rec.format = PTX_TEXTURE_RGBA8_UNORM;
             rec.data = &white;
         }
-    }
+    };
+    m_TextureRecords.resize(m_Textures.size());
+    for (size_t i = 0; i < m_Textures.size(); i++)
+        describe(m_Textures[i], m_TextureRecords[i]);
     d.textures = m_TextureRecords.data();
     d.textureCount = static_cast<uint32_t>(m_TextureRecords.size());
+    // Renderer.cpp:402-412, :679-690: the skybox variant picks the miss-shader flag and its images
     d.skyboxKind = PTX_SKYBOX_CLEAR_COLOR;
+    m_SkyboxRecords.clear();
+    if (const Skybox2D *sky = std::get_if<Skybox2D>(&m_Skybox))
+    {
+        m_SkyboxRecords.resize(1);
+        describe(sky->Content, m_SkyboxRecords[0]);
+        d.skyboxKind = PTX_SKYBOX_2D;
+    }
+    else if (const SkyboxCube *cube = std::get_if<SkyboxCube>(&m_Skybox))
+    {
+        const TextureInfo *faces[6] = { &cube->Front, &cube->Back, &cube->Up, &cube->Down, &cube->Left, &cube->Right };
+        m_SkyboxRecords.resize(6);
+        for (int i = 0; i < 6; i++)
+            describe(*faces[i], m_SkyboxRecords[i]);
+        d.skyboxKind = PTX_SKYBOX_CUBE;
+    }
+    d.skybox = m_SkyboxRecords.empty() ? nullptr : m_SkyboxRecords.data();
     d.dxNormalTextures = m_HasDxNormalTextures ? 1u : 0u;
     return d;
 }
@@ -219,6 +235,7 @@ void SceneBuilder::Reset()
     m_LightInfos.clear();
     m_PointLights.clear();
     m_DirectionalLight = g_DefaultLight;
+    m_Skybox = SkyboxClearColor {};
     m_DirectionalLightInfo = { RootNodeIndex, Vec3(-0.4f, -1.0f, -0.2f) };
     m_CameraInfos.clear();
     m_HasDxNormalTextures = false;
@@ -366,6 +383,7 @@ std::shared_ptr<Scene> SceneBuilder::CreateSceneShared(const std::string &name)
     scene->m_PointLights = std::move(m_PointLights);
     scene->m_DirectionalLightInfo = m_DirectionalLightInfo;
     scene->m_DirectionalLight = m_DirectionalLight;
+    scene->m_Skybox = std::move(m_Skybox);
 
     for (auto [modelIndex, sceneNodeIndex] : m_ModelInstanceInfos)
         scene->m_ModelInstances.push_back({ modelIndex, sceneNodeIndex, scene->m_SceneNodes[sceneNodeIndex].Transform });

@@ -11,6 +11,7 @@
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
+#include <variant>
 #include <vector>
 
 #include "../../include/ptx.h"
@@ -157,6 +158,27 @@ struct CameraInfo
     uint32_t SceneNodeIndex;
 };
 
+// Scene.h:127-157
+struct SkyboxClearColor
+{
+};
+
+struct Skybox2D
+{
+    TextureInfo Content;
+};
+
+struct SkyboxCube
+{
+    TextureInfo Front;
+    TextureInfo Back;
+    TextureInfo Up;
+    TextureInfo Down;
+    TextureInfo Left;
+    TextureInfo Right;
+};
+
+using SkyboxVariant = std::variant<SkyboxClearColor, Skybox2D, SkyboxCube>;
 using CameraId = int32_t;
 
 inline PtxTransform IdentityTransform()
@@ -189,6 +211,7 @@ public:
     [[nodiscard]] bool HasDxNormalTextures() const { return m_HasDxNormalTextures; }
     [[nodiscard]] std::span<const Shaders::PointLight> GetPointLights() const { return m_PointLights; }
     [[nodiscard]] const Shaders::DirectionalLight &GetDirectionalLight() const { return m_DirectionalLight; }
+    [[nodiscard]] const SkyboxVariant &GetSkybox() const { return m_Skybox; }
 
     [[nodiscard]] uint32_t GetSceneCamerasCount() const { return static_cast<uint32_t>(m_SceneCameras.size()); }
     [[nodiscard]] CameraId GetActiveCameraId() const { return m_ActiveCameraId; }
@@ -226,6 +249,8 @@ private:
     std::vector<Shaders::PointLight> m_PointLights;
     DirectionalLightInfo m_DirectionalLightInfo;
     Shaders::DirectionalLight m_DirectionalLight;
+    SkyboxVariant m_Skybox = SkyboxClearColor {};
+    mutable std::vector<PtxTextureDesc> m_SkyboxRecords;
 
     // flattened views handed to the C-ABI
     std::vector<PtxMeshRecord> m_MeshRecords;
@@ -263,6 +288,9 @@ public:
 
     void AddLight(Shaders::PointLight &&light, uint32_t sceneNodeIndex);
     void SetDirectionalLight(Shaders::DirectionalLight &&light, uint32_t sceneNodeIndex);
+
+    void SetSkybox(Skybox2D &&skybox) { m_Skybox = std::move(skybox); }
+    void SetSkybox(SkyboxCube &&skybox) { m_Skybox = std::move(skybox); }
 
     void AddCamera(CameraInfo &&camera);
 
@@ -302,6 +330,7 @@ private:
     std::vector<Shaders::PointLight> m_PointLights;
     DirectionalLightInfo m_DirectionalLightInfo;
     Shaders::DirectionalLight m_DirectionalLight;
+    SkyboxVariant m_Skybox = SkyboxClearColor {};
 
     std::vector<CameraInfo> m_CameraInfos;
 

@@ -6,7 +6,8 @@ built (Vulkan RT + absent submodules), but its pure-math shader headers compile 
 once the GLSL builtins are supplied by tools/glsl_shim.hpp.  This script
 
   1. reads the listed line ranges of Path-Tracing/Shaders/*.glsl / *.incl,
-  2. applies five mechanical rewrites (out/inout -> references, float-literal suffix,
+  2. applies five mechanical rewrites (plus one wrapper: the skybox texture-coordinate lines of
+     miss.rmiss:20-25 become a function of the ray direction) (out/inout -> references, float-literal suffix,
      swizzle -> method, drop #include/#version, braces around rand() argument lists so
      C++ keeps GLSL's left-to-right evaluation),
   3. writes the result into a TEMP directory (reference text is never copied into the
@@ -84,6 +85,10 @@ def main():
         for f, ranges in SOURCES:
             parts.append("// ---- %s" % f)
             parts.append(rewrite(lines(os.path.join(REF, f), ranges)))
+        # miss.rmiss:20-25 is straight-line code inside main(): wrapped as a function of the ray direction
+        parts.append("// ---- miss.rmiss")
+        parts.append("vec2 missSkyboxTexCoords(vec3 gl_WorldRayDirectionEXT)\n{\n" +
+                     rewrite(lines(os.path.join(REF, "miss.rmiss"), [(20, 25)])) + "\n    return texCoords;\n}")
         parts.append("} // namespace glsl")
         parts.append('#include "%s/golden_main.inc"' % HERE)
         cpp = os.path.join(tmp, "golden.cpp")

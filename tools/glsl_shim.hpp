@@ -88,6 +88,8 @@ inline vec2 operator+(uvec2 a, vec2 b) { return vec2((float)a.x + b.x, (float)a.
 inline vec2 operator-(vec2 a, vec2 b) { return vec2(a.x - b.x, a.y - b.y); }
 inline vec2 operator-(vec2 a, float s) { return vec2(a.x - s, a.y - s); }
 inline vec2 operator*(vec2 a, float s) { return vec2(a.x * s, a.y * s); }
+inline vec2 operator/(vec2 a, float s) { return vec2(a.x / s, a.y / s); }
+inline vec2 operator+(vec2 a, float s) { return vec2(a.x + s, a.y + s); }
 inline vec2 operator*(float s, vec2 a) { return vec2(s * a.x, s * a.y); }
 inline vec2 operator/(vec2 a, vec2 b) { return vec2(a.x / b.x, a.y / b.y); }
 inline vec2 operator/(vec2 a, uvec2 b) { return vec2(a.x / (float)b.x, a.y / (float)b.y); }
@@ -145,6 +147,13 @@ inline float sin(float x) { return sinf(x); }
 inline float pow(float x, float y) { return powf(x, y); }
 #endif
 inline float pow(float x, int y) { return pow(x, (float)y); }
+#ifdef SHIM_FIXED
+inline float atan(float y, float x) { return pto_atan2f(y, x); }
+inline float asin(float x) { return pto_asinf(x); }
+#else
+inline float atan(float y, float x) { return atan2f(y, x); }
+inline float asin(float x) { return asinf(x); }
+#endif
 #ifdef SHIM_FIXED
 inline float log2(float x) { return (float)pto_log2((double)x); }
 #else
