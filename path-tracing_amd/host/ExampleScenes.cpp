@@ -887,32 +887,72 @@ void CreateTempleLikeScene(SceneBuilder &sb, float detail, uint32_t seed)
 // C4 "Intel Sponza": two-storey arcade around an open atrium, curtain sheets and ivy
 // leaf cards (opaque until alpha testing lands with N1), ~4 M triangles, one
 // directional light through the open roof.
+// multiplies the texture coordinates of the vertices added since `firstVertex` (tiling of a procedural texture)
+void ScaleTexCoords(SceneBuilder &sb, size_t firstVertex, float su, float sv)
+{
+    auto &vertices = sb.GetVertices();
+    for (size_t k = firstVertex; k < vertices.size(); k++)
+    {
+        vertices[k].TexCoords[0] *= su;
+        vertices[k].TexCoords[1] *= sv;
+    }
+}
+
 void CreateAtriumLikeScene(SceneBuilder &sb, float detail, uint32_t seed)
 {
     Rng rng(seed);
     const uint32_t segs = Scaled(192, detail, 8), rings = Scaled(96, detail, 6); // 36,864 tris per column
     const std::vector<Vec2> columnProfile = { { 0.0f, 0.0f }, { 0.55f, 0.0f }, { 0.55f, 0.25f }, { 0.4f, 0.4f }, { 0.36f, 2.0f }, { 0.33f, 3.5f }, { 0.5f, 3.8f }, { 0.55f, 4.0f }, { 0.0f, 4.0f } };
     const uint32_t column = AddLathe(sb, columnProfile, segs, rings);
+    size_t mark = sb.GetVertices().size();
     const uint32_t floor = AddGridSurface(sb, Scaled(600, detail, 4), Scaled(300, detail, 4), false, [&](float u, float v) {
         return Vec3(-20.0f + 40.0f * u, 0.02f * std::sin(60 * u) * std::sin(45 * v), -10.0f + 20.0f * v);
-    }, true);
+    });
+    ScaleTexCoords(sb, mark, 10.0f, 5.0f); // 4 x 4 tiles per texture repeat, 1 m tiles
     const uint32_t gallery = AddBox(sb, Vec3(0, 4.2f, 0), Vec3(20, 0.2f, 2.5f));
     const uint32_t wall = AddBox(sb, Vec3(0, 5.0f, 0), Vec3(20.2f, 5.0f, 0.2f));
     const uint32_t endWall = AddBox(sb, Vec3(0, 5.0f, 0), Vec3(0.2f, 5.0f, 10.2f));
+    mark = sb.GetVertices().size();
     const uint32_t curtain = AddGridSurface(sb, Scaled(250, detail, 4), Scaled(200, detail, 4), false, [&](float u, float v) {
         return Vec3(3.0f * u, 3.6f * v, 0.18f * std::sin(25 * u + 3 * v) * (0.3f + v)); // 50k quads each
     });
-    const uint32_t ivy = AddCards(sb, rng, Scaled(250000, detail, 16), Vec3(-19.5f, 0.2f, 9.2f), Vec3(19.5f, 9.5f, 9.75f), 0.09f);
-    const uint32_t ivy2 = AddCards(sb, rng, Scaled(250000, detail, 16), Vec3(19.2f, 0.2f, -9.5f), Vec3(19.75f, 9.5f, 9.5f), 0.09f);
+    ScaleTexCoords(sb, mark, 30.0f, 36.0f); // 1 cm threads
+    // ivy: alpha-tested leaf cards (non-opaque geometry, anyhit.rahit), like the foliage of the Sponza / Bistro assets
+    const uint32_t ivy = AddCards(sb, rng, Scaled(250000, detail, 16), Vec3(-19.5f, 0.2f, 9.2f), Vec3(19.5f, 9.5f, 9.75f), 0.09f, false);
+    const uint32_t ivy2 = AddCards(sb, rng, Scaled(250000, detail, 16), Vec3(19.2f, 0.2f, -9.5f), Vec3(19.75f, 9.5f, 9.5f), 0.09f, false);
 
     const auto stone = sb.AddMaterial("Stone", MakeMaterial(Vec3(0.72f, 0.68f, 0.6f), 0.85f, 0.0f));
     const auto stone2 = sb.AddMaterial("Stone 2", MakeMaterial(Vec3(0.6f, 0.55f, 0.5f), 0.7f, 0.0f));
-    const auto floorMat = sb.AddMaterial("Atrium Floor", MakeMaterial(Vec3(0.5f, 0.45f, 0.4f), 0.4f, 0.0f));
-    const auto leaf = sb.AddMaterial("Leaf", MakeMaterial(Vec3(0.15f, 0.45f, 0.12f), 0.6f, 0.0f));
+    auto floorM = MakeMaterial(Vec3(1.0f), 0.4f, 0.0f);
+    floorM.ColorIdx = sb.AddTexture(MakeTexture(TextureType::Color, "Atrium Tiles", 256, 256, [seed](uint32_t x, uint32_t y, uint8_t *p) {
+        const bool joint = x % 64 < 2 || y % 64 < 2;
+        const uint32_t h = HashU(x / 64, y / 64, seed) & 31;
+        const uint8_t v = joint ? 60 : static_cast<uint8_t>(150 + h);
+        p[0] = v; p[1] = static_cast<uint8_t>(v * 9 / 10); p[2] = static_cast<uint8_t>(v * 8 / 10); p[3] = 255;
+    }));
+    const auto floorMat = sb.AddMaterial("Atrium Floor", floorM);
+    auto leafM = MakeMaterial(Vec3(1.0f), 0.6f, 0.0f);
+    leafM.ColorIdx = sb.AddTexture(MakeTexture(TextureType::Color, "Ivy Leaf", 64, 64, [](uint32_t x, uint32_t y, uint8_t *p) {
+        const float dx = (static_cast<float>(x) - 31.5f) / 31.5f, dy = (static_cast<float>(y) - 31.5f) / 22.0f;
+        const float r = dx * dx + dy * dy;
+        const bool vein = (x % 10 == 4) || std::abs(static_cast<int>(y) - 32) < 2;
+        p[0] = vein ? 70 : 38; p[1] = vein ? 150 : 115; p[2] = vein ? 50 : 30;
+        p[3] = r < 0.75f ? 255 : (r < 1.0f ? 200 : 0);
+    }));
+    const auto leaf = sb.AddMaterial("Leaf", leafM);
     const Vec3 curtainColours[4] = { { 0.7f, 0.1f, 0.1f }, { 0.1f, 0.2f, 0.65f }, { 0.1f, 0.5f, 0.2f }, { 0.75f, 0.6f, 0.2f } };
+    const uint32_t weave = sb.AddTexture(MakeTexture(TextureType::Color, "Weave", 32, 32, [](uint32_t x, uint32_t y, uint8_t *p) {
+        const bool over = ((x / 4) + (y / 4)) % 2 == 0;
+        const uint8_t v = static_cast<uint8_t>((over ? 235 : 170) - ((x % 4 == 0 || y % 4 == 0) ? 50 : 0));
+        p[0] = p[1] = p[2] = v; p[3] = 255;
+    }));
     Shaders::MaterialId curtainMats[4];
     for (int i = 0; i < 4; i++)
-        curtainMats[i] = sb.AddMaterial("Curtain " + std::to_string(i), MakeMaterial(curtainColours[i], 0.9f, 0.0f));
+    {
+        auto m = MakeMaterial(curtainColours[i], 0.9f, 0.0f);
+        m.ColorIdx = weave;
+        curtainMats[i] = sb.AddMaterial("Curtain " + std::to_string(i), m);
+    }
     const auto bronze = sb.AddMaterial("Bronze", MakeMaterial(Vec3(0.8f, 0.5f, 0.25f), 0.3f, 1.0f));
 
     const uint32_t root = sb.AddSceneNode({ 0u, Mat4::Identity(), Mat4::Identity() });
@@ -969,7 +1009,7 @@ void CreateStreetLikeScene(SceneBuilder &sb, float detail, uint32_t seed)
     Rng rng(seed);
     const uint32_t road = AddGridSurface(sb, Scaled(1400, detail, 8), Scaled(700, detail, 4), false, [&](float u, float v) {
         return Vec3(-40.0f + 80.0f * u, 0.03f * std::sin(220 * u) * std::sin(160 * v), -8.0f + 16.0f * v); // 1.96 M tris
-    }, true);
+    });
     const std::vector<Vec2> postProfile = { { 0.0f, 0.0f }, { 0.25f, 0.0f }, { 0.1f, 0.3f }, { 0.07f, 3.6f }, { 0.3f, 3.9f }, { 0.3f, 4.1f }, { 0.0f, 4.2f } };
     const uint32_t post = AddLathe(sb, postProfile, Scaled(96, detail, 8), Scaled(80, detail, 6)); // 15,360 tris
     const uint32_t awning = AddGridSurface(sb, Scaled(120, detail, 4), Scaled(60, detail, 4), false, [&](float u, float v) {
@@ -1229,10 +1269,10 @@ void CreateAlphaTestScene(SceneBuilder &sb, uint32_t seed)
             vertices[k].TexCoords[1] *= 3.0f;
         }
     }
-    const uint32_t wall = AddGridSurface(sb, 2, 2, false, [](float u, float v) { return Vec3(-5.0f + 10.0f * u, 5.0f * v, 3.0f); }, true);
-    const uint32_t decal = AddGridSurface(sb, 1, 1, false, [](float u, float v) { return Vec3(0.8f + 2.4f * u, 2.6f + 2.4f * v, 2.9f); }, true, false);
-    const uint32_t ghost = AddGridSurface(sb, 1, 1, false, [](float u, float v) { return Vec3(0.5f + 2.0f * u, 0.2f + 2.5f * v, 1.5f); }, true, false);
-    const uint32_t film = AddGridSurface(sb, 1, 1, false, [](float u, float v) { return Vec3(2.8f + 1.6f * u, 0.0f + 2.0f * v, 0.5f - 0.8f * u); }, true, false);
+    const uint32_t wall = AddGridSurface(sb, 2, 2, false, [](float u, float v) { return Vec3(-5.0f + 10.0f * u, 5.0f * v, 3.0f); });
+    const uint32_t decal = AddGridSurface(sb, 1, 1, false, [](float u, float v) { return Vec3(0.8f + 2.4f * u, 2.6f + 2.4f * v, 2.9f); }, false, false);
+    const uint32_t ghost = AddGridSurface(sb, 1, 1, false, [](float u, float v) { return Vec3(0.5f + 2.0f * u, 0.2f + 2.5f * v, 1.5f); }, false, false);
+    const uint32_t film = AddGridSurface(sb, 1, 1, false, [](float u, float v) { return Vec3(2.8f + 1.6f * u, 0.0f + 2.0f * v, 0.5f - 0.8f * u); }, false, false);
     const uint32_t leaves = AddCards(sb, rng, 300, Vec3(-3.5f, 0.3f, -1.5f), Vec3(0.5f, 3.2f, 1.5f), 0.35f, false);
 
     const uint32_t root = sb.AddSceneNode({ 0u, Mat4::Identity(), Mat4::Identity() });
