@@ -376,6 +376,41 @@ PTX_API int ptx_unpack_shard(PtxRenderer *r, uint32_t rank, const void *devSrc);
 
 PTX_API int ptx_get_stats(PtxRenderer *r, PtxStats *stats);
 
+/* ------------------------------------------------------------------------- */
+/* Output stage (row N4): what turns the running sum into a displayable image */
+/* ------------------------------------------------------------------------- */
+
+/* ShaderRendererTypes.incl:81-87 (uniform of postprocess.comp / composition.comp) */
+typedef struct PtxPostProcessingUniformData {
+    uint32_t TotalSamples;
+    float Exposure;
+    float BloomThreshold;
+    float BloomIntensity;
+} PtxPostProcessingUniformData;
+
+typedef enum PtxToneMappingMode {
+    PTX_TONE_MAPPING_SDR = 0, /* ToneMappingModeSDR: 1 - exp(-c), toneMapping.comp:22 */
+    PTX_TONE_MAPPING_HDR = 1  /* ToneMappingModeHDR: pass through                      */
+} PtxToneMappingMode;
+
+typedef enum PtxOutputFormat {
+    PTX_OUTPUT_RGBA8_SRGB = 0, /* OutputSaver::SelectImageFormat: Png / Jpg / Tga / Mp4 -> eR8G8B8A8Srgb */
+    PTX_OUTPUT_RGBA32F = 1     /* Hdr -> eR32G32B32A32Sfloat                                            */
+} PtxOutputFormat;
+
+/* Renderer::RecordPostProcessCommands (Renderer.cpp:928-1085) followed by RecordSaveOutputCommands
+ * (:1204-1246) on the accumulation image: postprocess.comp (sum / TotalSamples * Exposure, NaN / Inf
+ * markers, bloom prefilter) -> bloomDownsample.comp / bloomUpsample.comp over min(levels - 3, 12) mips
+ * -> composition.comp -> toneMapping.comp.  Every intermediate image of the reference is rgba16f and so
+ * is every intermediate value here.  Images whose larger side is below 16 pixels skip the bloom chain.
+ * The result stays on the device until ptx_read_output. */
+PTX_API int ptx_postprocess(PtxRenderer *r, const PtxPostProcessingUniformData *uniform, uint32_t toneMappingMode);
+/* OutputSaver's blit of the tone-mapped image into its sRGB8 / RGBA32F output image + readback
+ * (OutputSaver.cpp:64-86, :120-199): W*H*4 bytes or W*H*16 bytes, row-major, top row first. */
+PTX_API int ptx_read_output(PtxRenderer *r, uint32_t outputFormat, void *host, size_t bytes);
+/* Restores the accumulation image from a host copy of the running sum (checkpoint / resume). */
+PTX_API int ptx_write_accumulation(PtxRenderer *r, const float *rgba, size_t bytes);
+
 /* Use caller-owned device memory (width*height*16 bytes, e.g. a torch tensor that takes
  * part in the RCCL gather) as the accumulation image; NULL returns to the internal one. */
 PTX_API int ptx_bind_accumulation(PtxRenderer *r, void *devPtr, size_t bytes);
@@ -427,7 +462,10 @@ typedef enum PtxTestFunction {
     PTX_FN_SKYBOX_TEXCOORDS = 28,   /* in: ray direction (3)                      out: uv (2)   miss.rmiss:20-25 */
     PTX_FN_HDR_TO_LDR = 29,         /* in: rgb (3)                                out: rgb (3)  common.glsl:17-20 */
     PTX_FN_ATAN_ASIN = 30,          /* in: y x (2)                                out: atan(y,x) asin(y) kernels */
-    PTX_FN_COUNT = 31
+    PTX_FN_POSTPROCESS_PIXEL = 31,  /* in: acc.rgb TotalSamples(bits) Exposure BloomThreshold (6) out: color bloom (6) postprocess.comp:22-37 */
+    PTX_FN_COMPOSITION_PIXEL = 32,  /* in: post.rgb bloom.rgb BloomIntensity (7)    out: rgb (3)  composition.comp:23 */
+    PTX_FN_TONEMAP_PIXEL = 33,      /* in: rgb (3)                                  out: rgb (3)  toneMapping.comp:20-22, SDR */
+    PTX_FN_COUNT = 34
 } PtxTestFunction;
 
 /* Material block used by PTX_FN_EVALUATE_BSDF / PTX_FN_SAMPLE_BSDF:

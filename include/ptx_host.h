@@ -36,6 +36,13 @@ PTX_API int pth_scene_raygen_uniform(PthScene *s, uint32_t width, uint32_t heigh
 PTX_API int pth_scene_set_active_camera(PthScene *s, int32_t cameraId);
 PTX_API int pth_scene_set_camera_pose(PthScene *s, const float position[3], const float direction[3]);
 
+/* Output stage (row N4): OutputSaver::WriteImage (OutputSaver.cpp:227-257) for one image.  format: 0 Png, 1 Jpg
+ * (not implemented: returns 1), 2 Tga, 3 Hdr.  data: RGBA8 (Png / Tga) or RGBA32F (Hdr), top row first. */
+PTX_API int pth_write_image(const char *path, uint32_t format, uint32_t width, uint32_t height, const void *data, size_t bytes);
+/* checkpoint / resume of the running sum: { magic, width, height, totalSamples } + W*H*4 floats */
+PTX_API int pth_save_checkpoint(const char *path, uint32_t width, uint32_t height, uint32_t totalSamples, const float *rgba);
+PTX_API int pth_load_checkpoint(const char *path, uint32_t *width, uint32_t *height, uint32_t *totalSamples, float *rgba, size_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,7 +23,7 @@ class OracleHit(C.Structure):
 
 
 def build(force: bool = False) -> None:
-    src = [os.path.join(HERE, f) for f in ("pt_oracle.c", "pt_oracle.h", "pt_oracle_math.h")]
+    src = [os.path.join(HERE, f) for f in ("pt_oracle.c", "pt_oracle_post.c", "pt_oracle.h", "pt_oracle_math.h")]
     if force or not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in src):
         subprocess.check_call(["make", "-C", HERE, "-B" if force else "-s", "libpt_oracle.so"])
 
@@ -48,6 +48,8 @@ def load() -> C.CDLL:
         lib.pto_trace_any.argtypes = [P, P, C.c_uint32, P, C.c_int]
         lib.pto_test_eval.argtypes = [C.c_uint32, P, P, C.c_uint32]
         lib.pto_test_texture.argtypes = [P, P, P, C.c_uint32, C.c_int]
+        lib.pto_postprocess.argtypes = [P, C.c_uint32, C.c_uint32, P, C.c_uint32, P]
+        lib.pto_encode_output.argtypes = [P, C.c_uint32, C.c_uint32, C.c_uint32, P]
         _lib = lib
     return _lib
 
@@ -110,4 +112,29 @@ def test_eval(fn: int, inputs: np.ndarray, nout: int) -> np.ndarray:
     rc = lib.pto_test_eval(fn, inputs.ctypes.data, out.ctypes.data, n)
     if rc:
         raise RuntimeError("pto_test_eval failed")
+    return out
+
+
+def postprocess(accum: np.ndarray, total_samples: int, exposure: float = 1.0, bloom_threshold: float = 1.0,
+                bloom_intensity: float = 1.0, tone_mapping: int = 0) -> np.ndarray:
+    """ptx_postprocess on a host array: H x W x 4 running sum -> tone-mapped linear image (binary16-valued)."""
+    lib = load()
+    accum = np.ascontiguousarray(accum, dtype=np.float32)
+    h, w = accum.shape[:2]
+    u = (C.c_uint32 * 4)()
+    u[0] = total_samples
+    C.memmove(C.addressof(u) + 4, np.array([exposure, bloom_threshold, bloom_intensity], np.float32).ctypes.data, 12)
+    out = np.empty((h, w, 4), np.float32)
+    if lib.pto_postprocess(accum.ctypes.data, w, h, C.addressof(u), tone_mapping, out.ctypes.data):
+        raise RuntimeError("pto_postprocess failed")
+    return out
+
+
+def encode_output(linear: np.ndarray, fmt: int = 0) -> np.ndarray:
+    lib = load()
+    linear = np.ascontiguousarray(linear, dtype=np.float32)
+    h, w = linear.shape[:2]
+    out = np.empty((h, w, 4), np.float32 if fmt == 1 else np.uint8)
+    if lib.pto_encode_output(linear.ctypes.data, w, h, fmt, out.ctypes.data):
+        raise RuntimeError("pto_encode_output failed")
     return out

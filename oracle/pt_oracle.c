@@ -1275,16 +1275,6 @@ void pto_trace_any(const PtoScene *s, const float *rays, uint32_t n, uint32_t *o
 static inline uint32_t levelDim(uint32_t d, uint32_t level) { const uint32_t v = d >> level; return v ? v : 1u; }
 
 /* sRGB EOTF / inverse through the fixed pow kernel (shared definition with the HIP kernels) */
-static inline float srgbToLinear(float c) { return c <= 0.04045f ? c / 12.92f : pto_powf((c + 0.055f) / 1.055f, 2.4f); }
-static inline float linearToSrgb(float c) { return c <= 0.0031308f ? 12.92f * c : 1.055f * pto_powf(c, 1.0f / 2.4f) - 0.055f; }
-static inline uint32_t quantize8(float x)
-{
-    if (!(x > 0.0f))
-        return 0u;
-    if (x > 1.0f)
-        x = 1.0f;
-    return (uint32_t)floorf(x * 255.0f + 0.5f);
-}
 
 static inline v4 fetchTexel(const PtoScene *s, const OTexture *t, uint32_t level, uint32_t x, uint32_t y)
 {
@@ -2026,8 +2016,8 @@ int pto_render(const PtoScene *s, const PtxRaygenUniformData *U, const PtxLights
 /* Function-level entry (packing documented in include/ptx.h)               */
 /* ======================================================================== */
 
-static const int kInStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4, 3, 3, 2 };
-static const int kOutStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1, 2, 3, 2 };
+static const int kInStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4, 3, 3, 2, 6, 7, 3 };
+static const int kOutStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1, 2, 3, 2, 6, 3, 3 };
 
 static MaterialSample unpackMaterial(const float *p)
 {
@@ -2045,6 +2035,8 @@ int pto_test_eval(uint32_t fn, const float *in, float *out, uint32_t n)
 {
     if (fn >= PTX_FN_COUNT)
         return 1;
+    if (fn >= PTX_FN_POSTPROCESS_PIXEL && fn <= PTX_FN_TONEMAP_PIXEL) /* output stage: pt_oracle_post.c */
+        return pto_test_post(fn - PTX_FN_POSTPROCESS_PIXEL, in, out, n);
     for (uint32_t i = 0; i < n; i++)
     {
         const float *a = &in[(size_t)i * kInStride[fn]];

@@ -77,6 +77,12 @@ PTX_API void pto_trace_any(const PtoScene *s, const float *rays, uint32_t n, uin
 /* Sampler entry, same packing as ptx_test_texture (include/ptx.h). */
 PTX_API int pto_test_texture(const PtoScene *s, const float *in, float *out, uint32_t n, int implicitLod);
 
+/* Output stage (pt_oracle_post.c): ptx_postprocess / ptx_read_output on host arrays. */
+PTX_API int pto_postprocess(const float *accum, uint32_t W, uint32_t H, const PtxPostProcessingUniformData *u, uint32_t toneMode,
+                            float *outLinear);
+PTX_API int pto_encode_output(const float *linear, uint32_t W, uint32_t H, uint32_t format, void *out);
+PTX_API int pto_test_post(uint32_t which, const float *in, float *out, uint32_t n);
+
 /* Function-level entry, same packing as ptx_test_eval (include/ptx.h). */
 PTX_API int pto_test_eval(uint32_t fn, const float *in, float *out, uint32_t n);
 

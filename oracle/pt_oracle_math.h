@@ -267,4 +267,49 @@ static inline float pto_asinf(float xf)
     return (float)r;
 }
 
+/* sRGB transfer functions and 8-bit quantisation shared by the texture pipeline and the output stage */
+static inline float srgbToLinear(float c) { return c <= 0.04045f ? c / 12.92f : pto_powf((c + 0.055f) / 1.055f, 2.4f); }
+static inline float linearToSrgb(float c) { return c <= 0.0031308f ? 12.92f * c : 1.055f * pto_powf(c, 1.0f / 2.4f) - 0.055f; }
+static inline uint32_t quantize8(float x)
+{
+    if (!(x > 0.0f))
+        return 0u;
+    if (x > 1.0f)
+        x = 1.0f;
+    return (uint32_t)floorf(x * 255.0f + 0.5f);
+}
+
+/* exp(x) through the fixed exp2 kernel */
+static inline float pto_expf(float x)
+{
+    if (x != x)
+        return x;
+    double t = (double)x * 1.4426950408889634;
+    if (t > 300.0)
+        t = 300.0;
+    if (t < -300.0)
+        t = -300.0;
+    return (float)pto_exp2(t);
+}
+
+/* float -> IEEE binary16 (round to nearest even, overflow to infinity, subnormals kept) -> float:
+ * the value an rgba16f image holds after imageStore. */
+static inline float pto_f16_round(float f)
+{
+    const uint32_t x = f2u(f), sign = x & 0x80000000u, ax = x & 0x7fffffffu;
+    if (ax >= 0x7f800000u) /* inf / nan */
+        return ax > 0x7f800000u ? u2f(sign | 0x7fc00000u) : f;
+    if (ax >= 0x477ff000u) /* >= 65520: rounds to infinity */
+        return u2f(sign | 0x7f800000u);
+    if (ax < 0x38800000u) /* below 2^-14: half subnormal, quantum 2^-24 */
+    {
+        const float q = u2f(ax) * 16777216.0f; /* exact */
+        const float rq = (q + 12582912.0f) - 12582912.0f; /* round to nearest even integer (|q| < 2^10) */
+        return u2f(sign | f2u(rq * (1.0f / 16777216.0f)));
+    }
+    const uint32_t lsb = (ax >> 13) & 1u;
+    const uint32_t r = (ax + 0x0fffu + lsb) & 0xffffe000u;
+    return u2f(sign | r);
+}
+
 #endif

@@ -43,11 +43,12 @@ PTX_SYMBOLS = [
     "ptx_render_frames", "ptx_synchronize", "ptx_readback", "ptx_device_accum_ptr", "ptx_accum_bytes",
     "ptx_shard_bytes", "ptx_pack_shard", "ptx_unpack_shard", "ptx_get_stats", "ptx_bind_accumulation",
     "ptx_trace_rays", "ptx_test_input_stride", "ptx_test_output_stride", "ptx_test_eval", "ptx_test_texture",
+    "ptx_postprocess", "ptx_read_output", "ptx_write_accumulation",
 ]
 PTH_SYMBOLS = [
     "pth_scene_names", "pth_scene_create", "pth_scene_destroy", "pth_last_error", "pth_scene_desc",
     "pth_scene_lights", "pth_scene_triangle_count", "pth_scene_raygen_uniform", "pth_scene_set_active_camera",
-    "pth_scene_set_camera_pose",
+    "pth_scene_set_camera_pose", "pth_write_image", "pth_save_checkpoint", "pth_load_checkpoint",
 ]
 
 BACKEND_WAVEFRONT = 0
@@ -100,6 +101,14 @@ class LightsUbo(C.Structure):
                 ("Lights", PointLight * 64)]
 
 
+class PostProcessingUniformData(C.Structure):
+    _fields_ = [("TotalSamples", C.c_uint32), ("Exposure", C.c_float), ("BloomThreshold", C.c_float), ("BloomIntensity", C.c_float)]
+
+
+TONE_MAPPING_SDR, TONE_MAPPING_HDR = 0, 1
+OUTPUT_RGBA8_SRGB, OUTPUT_RGBA32F = 0, 1
+
+
 class DeviceDesc(C.Structure):
     _fields_ = [("deviceIndex", C.c_int32), ("backend", C.c_uint32), ("stream", C.c_void_p)]
 
@@ -126,6 +135,7 @@ FN = {
     "pow": 18, "sampleLight": 19, "offsetRayOriginShadowTerminator": 20, "constructPrimaryRayLens": 21,
     "computeDpnDuv": 22, "computeDpDxy": 23, "computeDerivatives": 24, "computeReflectedDifferentialRays": 25,
     "computeRefractedDifferentialRays": 26, "computeLod": 27, "missSkyboxTexCoords": 28, "hdrToLdr": 29, "atanAsin": 30,
+    "postprocessPixel": 31, "compositionPixel": 32, "toneMapPixel": 33,
 }
 
 
@@ -142,7 +152,7 @@ def _newer(target, sources):
 def build(force: bool = False, verbose: bool = True) -> None:
     """Compile the HIP extension for gfx950 and the C++ host mirror, in-tree."""
     csrc = os.path.join(PKG_DIR, "csrc")
-    hip_src = [os.path.join(csrc, f) for f in ("pt_kernels.hip", "pt_bvh.hpp", "pt_device.hpp")] + [
+    hip_src = [os.path.join(csrc, f) for f in ("pt_kernels.hip", "pt_bvh.hpp", "pt_device.hpp", "pt_post.hpp")] + [
         os.path.join(REPO_DIR, "include", "ptx.h")]
     if force or _newer(HIP_LIB, hip_src):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -151,8 +161,8 @@ def build(force: bool = False, verbose: bool = True) -> None:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
     host = os.path.join(PKG_DIR, "host")
-    host_src = [os.path.join(host, f) for f in ("Scene.cpp", "Camera.cpp", "ExampleScenes.cpp", "host_capi.cpp")]
-    host_dep = host_src + [os.path.join(host, f) for f in ("Scene.h", "Camera.h", "ExampleScenes.h", "Math.h")] + [
+    host_src = [os.path.join(host, f) for f in ("Scene.cpp", "Camera.cpp", "ExampleScenes.cpp", "OutputSaver.cpp", "host_capi.cpp")]
+    host_dep = host_src + [os.path.join(host, f) for f in ("Scene.h", "Camera.h", "ExampleScenes.h", "OutputSaver.h", "Math.h")] + [
         os.path.join(REPO_DIR, "include", "ptx_host.h"), os.path.join(REPO_DIR, "include", "ptx.h")]
     if force or _newer(HOST_LIB, host_dep):
         cmd = ["g++"] + HOST_FLAGS + ["-o", HOST_LIB] + host_src
@@ -187,6 +197,9 @@ def load_host() -> C.CDLL:
                                                  C.c_uint32, C.c_uint32, C.POINTER(RaygenUniformData)]
         lib.pth_scene_set_active_camera.argtypes = [C.c_void_p, C.c_int32]
         lib.pth_scene_set_camera_pose.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        lib.pth_write_image.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t]
+        lib.pth_save_checkpoint.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        lib.pth_load_checkpoint.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_size_t]
         _host = lib
     return _host
 
@@ -224,6 +237,9 @@ def load_hip() -> C.CDLL:
         lib.ptx_pack_shard.argtypes = [P, P]
         lib.ptx_unpack_shard.argtypes = [P, C.c_uint32, P]
         lib.ptx_get_stats.argtypes = [P, C.POINTER(Stats)]
+        lib.ptx_postprocess.argtypes = [P, C.POINTER(PostProcessingUniformData), C.c_uint32]
+        lib.ptx_read_output.argtypes = [P, C.c_uint32, P, C.c_size_t]
+        lib.ptx_write_accumulation.argtypes = [P, P, C.c_size_t]
         lib.ptx_bind_accumulation.argtypes = [P, P, C.c_size_t]
         lib.ptx_trace_rays.argtypes = [P, P, C.c_uint32, C.c_int, P, P]
         lib.ptx_test_input_stride.argtypes = [C.c_uint32]
@@ -351,6 +367,20 @@ class Renderer:
         self._check(self.lib.ptx_readback(self.handle, img.ctypes.data, img.nbytes))
         return img
 
+    def write_accumulation(self, img: np.ndarray):
+        img = np.ascontiguousarray(img, dtype=np.float32)
+        self._check(self.lib.ptx_write_accumulation(self.handle, img.ctypes.data, img.nbytes))
+
+    def postprocess(self, total_samples: int, exposure: float = 1.0, bloom_threshold: float = 1.0, bloom_intensity: float = 1.0,
+                    tone_mapping: int = TONE_MAPPING_SDR):
+        u = PostProcessingUniformData(total_samples, exposure, bloom_threshold, bloom_intensity)
+        self._check(self.lib.ptx_postprocess(self.handle, C.byref(u), tone_mapping))
+
+    def read_output(self, fmt: int = OUTPUT_RGBA8_SRGB) -> np.ndarray:
+        out = np.empty((self.height, self.width, 4), dtype=np.float32 if fmt == OUTPUT_RGBA32F else np.uint8)
+        self._check(self.lib.ptx_read_output(self.handle, fmt, out.ctypes.data, out.nbytes))
+        return out
+
     def stats(self) -> Stats:
         s = Stats()
         self._check(self.lib.ptx_get_stats(self.handle, C.byref(s)))
@@ -392,6 +422,33 @@ class Renderer:
         out = np.zeros((inputs.shape[0], nout), np.uint32)
         self._check(self.lib.ptx_test_eval(self.handle, fn, inputs.ctypes.data, out.ctypes.data, inputs.shape[0]))
         return out
+
+
+OUTPUT_PNG, OUTPUT_JPG, OUTPUT_TGA, OUTPUT_HDR = 0, 1, 2, 3
+
+
+def write_image(path: str, img: np.ndarray, fmt: int = OUTPUT_PNG):
+    """OutputSaver::WriteImage: H x W x 4 uint8 (Png / Tga) or float32 (Hdr)."""
+    img = np.ascontiguousarray(img)
+    if load_host().pth_write_image(str(path).encode(), fmt, img.shape[1], img.shape[0], img.ctypes.data, img.nbytes):
+        raise PtxError(f"pth_write_image({path}) failed")
+
+
+def save_checkpoint(path: str, accum: np.ndarray, total_samples: int):
+    accum = np.ascontiguousarray(accum, dtype=np.float32)
+    if load_host().pth_save_checkpoint(str(path).encode(), accum.shape[1], accum.shape[0], total_samples, accum.ctypes.data):
+        raise PtxError(f"pth_save_checkpoint({path}) failed")
+
+
+def load_checkpoint(path: str):
+    lib = load_host()
+    w, h, n = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    if lib.pth_load_checkpoint(str(path).encode(), C.byref(w), C.byref(h), C.byref(n), None, 0):
+        raise PtxError(f"pth_load_checkpoint({path}) failed")
+    img = np.empty((h.value, w.value, 4), np.float32)
+    if lib.pth_load_checkpoint(str(path).encode(), C.byref(w), C.byref(h), C.byref(n), img.ctypes.data, img.nbytes):
+        raise PtxError(f"pth_load_checkpoint({path}) failed")
+    return img, n.value
 
 
 def owned_tiles(width: int, height: int, rank: int, world: int, tile: int = 32):

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "pt_bvh.hpp"
+#include "pt_post.hpp"
 
 using namespace ptd;
 
@@ -791,10 +792,10 @@ __global__ void k_test_texture(TextureView tv, const float *__restrict__ in, flo
 
 // function-level entry (Path-Tracing-Tests/TestRenderer.cpp:79-105 dispatches a compute
 // shader that calls the production functions; packing documented in include/ptx.h)
-__constant__ int c_inStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4, 3, 3, 2 };
-__constant__ int c_outStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1, 2, 3, 2 };
-static const int h_inStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4, 3, 3, 2 };
-static const int h_outStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1, 2, 3, 2 };
+__constant__ int c_inStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4, 3, 3, 2, 6, 7, 3 };
+__constant__ int c_outStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1, 2, 3, 2, 6, 3, 3 };
+static const int h_inStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4, 3, 3, 2, 6, 7, 3 };
+static const int h_outStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1, 2, 3, 2, 6, 3, 3 };
 
 PT_DEV MaterialSample unpackMaterial(const float *p)
 {
@@ -1005,6 +1006,26 @@ __global__ void k_test_eval(uint32_t fn, const float *__restrict__ in, float *__
         o[0] = atan2_(a[0], a[1]);
         o[1] = asin_(a[0]);
         break;
+    case PTX_FN_POSTPROCESS_PIXEL: {
+        PtxPostProcessingUniformData u;
+        u.TotalSamples = __float_as_uint(a[3]); u.Exposure = a[4]; u.BloomThreshold = a[5]; u.BloomIntensity = 0.0f;
+        f3 c, b;
+        postprocessPixel(F3(a[0], a[1], a[2]), u, c, b);
+        o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = b.x; o[4] = b.y; o[5] = b.z;
+        break;
+    }
+    case PTX_FN_COMPOSITION_PIXEL: {
+        PtxPostProcessingUniformData u;
+        u.TotalSamples = 1u; u.Exposure = u.BloomThreshold = 0.0f; u.BloomIntensity = a[6];
+        const f3 c = compositionPixel(F3(a[0], a[1], a[2]), F3(a[3], a[4], a[5]), u);
+        o[0] = c.x; o[1] = c.y; o[2] = c.z;
+        break;
+    }
+    case PTX_FN_TONEMAP_PIXEL: {
+        const f3 c = toneMapPixel(F3(a[0], a[1], a[2]), PTX_TONE_MAPPING_SDR);
+        o[0] = c.x; o[1] = c.y; o[2] = c.z;
+        break;
+    }
     case PTX_FN_COMPUTE_LOD: {
         f4 dv; dv.x = a[0]; dv.y = a[1]; dv.z = a[2]; dv.w = a[3];
         o[0] = computeLod(dv);
@@ -1083,6 +1104,11 @@ struct PtxRenderer
     uint32_t width = 0, height = 0;
     PtxTileShard shard = { 0, 1, 32 };
     DevBuf<float4> image;
+    // output stage (row N4)
+    DevBuf<float> postRgb, bloomRgb; // rgba16f-valued post-process image and bloom mip chain (3 floats per texel)
+    DevBuf<float4> outLinear;        // tone-mapped image (OutputSaver's m_LinearImage)
+    DevBuf<uint32_t> outSrgb8;
+    bool outputReady = false;
     float4 *boundImage = nullptr; // external accumulation buffer, if bound
 
     // wavefront state
@@ -1617,6 +1643,7 @@ int ptx_resize(PtxRenderer *r, uint32_t width, uint32_t height)
     HIP_TRY(r, hipSetDevice(r->device));
     r->width = width;
     r->height = height;
+    r->outputReady = false;
     r->boundImage = nullptr;
     HIP_TRY(r, r->image.alloc((size_t)width * height));
     return ptx_reset_accumulation(r);
@@ -2139,6 +2166,82 @@ int ptx_unpack_shard(PtxRenderer *r, uint32_t rank, const void *devSrc)
     if (p.slotsPerFrame)
         k_unpack_shard<<<gridFor(p.slotsPerFrame), kBlock, 0, r->stream>>>(p, static_cast<const float4 *>(devSrc), imagePtr(r));
     HIP_TRY(r, hipGetLastError());
+    return PTX_OK;
+}
+
+// Renderer::RecordPostProcessCommands + RecordSaveOutputCommands (Renderer.cpp:928-1085, :1204-1246)
+int ptx_postprocess(PtxRenderer *r, const PtxPostProcessingUniformData *uniform, uint32_t toneMappingMode)
+{
+    if (!r || !uniform || toneMappingMode > PTX_TONE_MAPPING_HDR)
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_postprocess: bad argument");
+    if (!imagePtr(r))
+        return fail(r, PTX_ERROR_NOT_READY, "ptx_postprocess: no accumulation image (call ptx_resize)");
+    HIP_TRY(r, hipSetDevice(r->device));
+    const uint32_t W = r->width, H = r->height, n = W * H;
+    uint32_t levels = 1;
+    for (uint32_t m = W > H ? W : H; m > 1; m >>= 1)
+        levels++;
+    // mips 0 .. maxMipLevel-1 take part, maxMipLevel = min(levels - 3, MaxBloomMipmapLevel) (Renderer.cpp:955-956)
+    uint32_t used = levels >= 5 ? (levels - 3 < 12 ? levels - 3 : 12) : 1;
+    BloomLevel L[13];
+    size_t total = 0;
+    for (uint32_t l = 0; l < used; l++)
+    {
+        L[l].w = (W >> l) ? (W >> l) : 1;
+        L[l].h = (H >> l) ? (H >> l) : 1;
+        total += (size_t)L[l].w * L[l].h * 3;
+    }
+    HIP_TRY(r, r->postRgb.alloc((size_t)n * 3));
+    HIP_TRY(r, r->bloomRgb.alloc(total));
+    HIP_TRY(r, r->outLinear.alloc(n));
+    size_t off = 0;
+    for (uint32_t l = 0; l < used; l++)
+    {
+        L[l].rgb = r->bloomRgb.p + off;
+        off += (size_t)L[l].w * L[l].h * 3;
+    }
+    k_postprocess<<<gridFor(n), kBlock, 0, r->stream>>>(imagePtr(r), n, *uniform, r->postRgb.p, L[0].rgb);
+    for (uint32_t i = 0; i + 1 < used; i++)
+        k_bloom_downsample<<<gridFor((size_t)L[i + 1].w * L[i + 1].h), kBlock, 0, r->stream>>>(L[i], L[i + 1]);
+    for (uint32_t i = used - 1; i > 0; i--)
+        k_bloom_upsample<<<gridFor((size_t)L[i - 1].w * L[i - 1].h), kBlock, 0, r->stream>>>(L[i], L[i - 1]);
+    k_compose_tonemap<<<gridFor(n), kBlock, 0, r->stream>>>(r->postRgb.p, L[0].rgb, n, *uniform, toneMappingMode, r->outLinear.p);
+    HIP_TRY(r, hipGetLastError());
+    r->outputReady = true;
+    return PTX_OK;
+}
+
+// OutputSaver: blit of the tone-mapped image into its output image + readback (OutputSaver.cpp:64-86, :120-199)
+int ptx_read_output(PtxRenderer *r, uint32_t outputFormat, void *host, size_t bytes)
+{
+    if (!r || !host || outputFormat > PTX_OUTPUT_RGBA32F)
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_read_output: bad argument");
+    if (!r->outputReady)
+        return fail(r, PTX_ERROR_NOT_READY, "ptx_read_output: call ptx_postprocess first");
+    const uint32_t n = r->width * r->height;
+    const size_t want = (size_t)n * (outputFormat == PTX_OUTPUT_RGBA32F ? 16 : 4);
+    if (bytes != want)
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_read_output: buffer must be %zu bytes", want);
+    HIP_TRY(r, hipSetDevice(r->device));
+    if (outputFormat == PTX_OUTPUT_RGBA32F)
+        HIP_TRY(r, hipMemcpyAsync(host, r->outLinear.p, bytes, hipMemcpyDeviceToHost, r->stream));
+    else
+    {
+        HIP_TRY(r, r->outSrgb8.alloc(n));
+        k_encode_srgb8<<<gridFor(n), kBlock, 0, r->stream>>>(r->outLinear.p, n, r->outSrgb8.p);
+        HIP_TRY(r, hipMemcpyAsync(host, r->outSrgb8.p, bytes, hipMemcpyDeviceToHost, r->stream));
+    }
+    HIP_TRY(r, hipStreamSynchronize(r->stream));
+    HIP_TRY(r, hipGetLastError());
+    return PTX_OK;
+}
+
+int ptx_write_accumulation(PtxRenderer *r, const float *rgba, size_t bytes)
+{
+    if (!r || !rgba || !imagePtr(r) || bytes != (size_t)r->width * r->height * sizeof(float4))
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_write_accumulation: buffer must be width*height*16 bytes");
+    HIP_TRY(r, hipMemcpyAsync(imagePtr(r), rgba, bytes, hipMemcpyHostToDevice, r->stream));
+    HIP_TRY(r, hipStreamSynchronize(r->stream));
     return PTX_OK;
 }
 

@@ -105,6 +105,27 @@ uint32_t RendererHip::GetTotalSamples()
     return s_TotalSamples;
 }
 
+static RendererHip::PostProcessSettings s_PostProcessSettings;
+
+void RendererHip::SetPostProcessSettings(const PostProcessSettings &settings)
+{
+    s_PostProcessSettings = settings;
+}
+
+void RendererHip::SaveOutput(const OutputInfo &info)
+{
+    if (info.Extent.width != s_Width || info.Extent.height != s_Height)
+        throw error("SaveOutput: the output extent must equal the render extent");
+    const PtxPostProcessingUniformData u = { GetTotalSamples(), s_PostProcessSettings.Exposure, s_PostProcessSettings.BloomThreshold,
+                                             s_PostProcessSettings.BloomIntensity };
+    Check(ptx_postprocess(s_Renderer, &u, s_PostProcessSettings.Hdr ? PTX_TONE_MAPPING_HDR : PTX_TONE_MAPPING_SDR));
+    const uint32_t format = OutputSaver::SelectImageFormat(info.Format);
+    std::vector<std::byte> bytes(static_cast<size_t>(s_Width) * s_Height * (format == PTX_OUTPUT_RGBA32F ? 16 : 4));
+    Check(ptx_read_output(s_Renderer, format, bytes.data(), bytes.size()));
+    if (!OutputSaver::WriteImage(info, bytes))
+        throw error("SaveOutput: cannot write " + info.Path.string());
+}
+
 std::vector<float> RendererHip::ReadAccumulationImage()
 {
     std::vector<float> image(static_cast<size_t>(s_Width) * s_Height * 4);

@@ -2,13 +2,14 @@
 // (Path-Tracing/Renderer/Renderer.h:42-85) on top of the C-ABI in include/ptx.h, so
 // host code written against the static Renderer class keeps its call sequence:
 //   Init -> UpdateSceneData -> OnResize -> [SetSettings] -> Render ... -> Shutdown.
-// Only the path-tracing pass is implemented; post-processing, UI and output saving
-// stay with the reference's Vulkan renderer (out of scope).
+// The path-tracing pass and the output stage (post-processing chain + OutputSaver, row N4) are
+// implemented; UI and presentation stay with the reference's Vulkan renderer (out of scope).
 #pragma once
 
 #include <memory>
 #include <vector>
 
+#include "OutputSaver.h"
 #include "Scene.h"
 
 namespace PathTracing
@@ -37,6 +38,18 @@ public:
     // Renderer::Render (Renderer.cpp:1659-1809): uniform fill + one path-tracing launch.
     static void Render();
     static void ResetAccumulationImage();
+
+    // Renderer::PostProcessSettings (Renderer.h:68-75) / RenderSettings::Output
+    struct PostProcessSettings
+    {
+        float Exposure = 1.0f;
+        float BloomThreshold = 1.0f;
+        float BloomIntensity = 1.0f;
+        bool Hdr = false; // ToneMappingModeHDR
+    };
+    static void SetPostProcessSettings(const PostProcessSettings &settings);
+    // RecordPostProcessCommands + RecordSaveOutputCommands on the current running sum, then OutputSaver::WriteImage
+    static void SaveOutput(const OutputInfo &info);
 
     static uint32_t GetTotalSamples();
     static std::vector<float> ReadAccumulationImage(); // RGBA32F running sum

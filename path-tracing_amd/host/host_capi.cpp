@@ -4,6 +4,7 @@
 #include <string>
 
 #include "ExampleScenes.h"
+#include "OutputSaver.h"
 
 using namespace PathTracing;
 
@@ -109,6 +110,37 @@ int pth_scene_set_camera_pose(PthScene *s, const float position[3], const float 
         return PTX_ERROR_INVALID_ARGUMENT;
     s->scene->SetActiveCamera(Scene::g_InputCameraId);
     s->scene->GetActiveCamera().SetPose(Vec3(position[0], position[1], position[2]), Vec3(direction[0], direction[1], direction[2]));
+    return PTX_OK;
+}
+
+int pth_write_image(const char *path, uint32_t format, uint32_t width, uint32_t height, const void *data, size_t bytes)
+{
+    if (!path || !data || !width || !height || format > 3)
+        return PTX_ERROR_INVALID_ARGUMENT;
+    const OutputInfo info = { path, { width, height }, 0, static_cast<OutputFormat>(format) };
+    return OutputSaver::WriteImage(info, std::span<const std::byte>(static_cast<const std::byte *>(data), bytes)) ? PTX_OK : PTX_ERROR_INVALID_ARGUMENT;
+}
+
+int pth_save_checkpoint(const char *path, uint32_t width, uint32_t height, uint32_t totalSamples, const float *rgba)
+{
+    if (!path || !rgba || !width || !height)
+        return PTX_ERROR_INVALID_ARGUMENT;
+    return SaveCheckpoint(path, width, height, totalSamples, rgba) ? PTX_OK : PTX_ERROR_INVALID_ARGUMENT;
+}
+
+int pth_load_checkpoint(const char *path, uint32_t *width, uint32_t *height, uint32_t *totalSamples, float *rgba, size_t bytes)
+{
+    if (!path || !width || !height || !totalSamples)
+        return PTX_ERROR_INVALID_ARGUMENT;
+    std::vector<float> data;
+    if (!LoadCheckpoint(path, *width, *height, *totalSamples, data))
+        return PTX_ERROR_INVALID_ARGUMENT;
+    if (rgba) // rgba == NULL: header query only
+    {
+        if (bytes != data.size() * sizeof(float))
+            return PTX_ERROR_INVALID_ARGUMENT;
+        std::memcpy(rgba, data.data(), bytes);
+    }
     return PTX_OK;
 }
 }

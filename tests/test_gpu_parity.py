@@ -312,11 +312,11 @@ def test_cpp_host_adapter_end_to_end(pkg, tmp_path):
     host = pkg.PKG_DIR + "/host"
     exe = str(tmp_path / "render_scene")
     cmd = ["g++", "-std=c++20", "-O2", pkg.REPO_DIR + "/examples/render_scene.cpp"] + [f"{host}/{f}.cpp" for f in
-           ("Scene", "Camera", "ExampleScenes", "RendererHip")] + [f"-I{host}", f"-L{pkg.PKG_DIR}", "-lptx_hip",
+           ("Scene", "Camera", "ExampleScenes", "OutputSaver", "RendererHip")] + [f"-I{host}", f"-L{pkg.PKG_DIR}", "-lptx_hip",
            f"-Wl,-rpath,{pkg.PKG_DIR}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
     subprocess.check_call(cmd)
     W, H, spp, depth = 160, 90, 4, 4
-    out = subprocess.check_output([exe, "default", str(W), str(H), str(spp), str(depth), str(tmp_path / "o.ppm")], text=True)
+    out = subprocess.check_output([exe, "default", str(W), str(H), str(spp), str(depth), str(tmp_path / "o.png")], text=True)
     mean_cpp = float(out.split("mean radiance")[1].split()[0])
     scene = pkg.Scene("default")
     r = pkg.Renderer()
@@ -328,5 +328,16 @@ def test_cpp_host_adapter_end_to_end(pkg, tmp_path):
     r.close()
     mean_py = float((img[..., :3].astype(np.float32) * np.float32(1.0 / spp)).astype(np.float64).sum() / (3.0 * W * H))
     assert abs(mean_cpp - mean_py) <= 1e-6 * max(abs(mean_py), 1e-12)
-    data = open(tmp_path / "o.ppm", "rb").read()
-    assert data.startswith(b"P6") and len(data) > W * H * 3
+    # the PNG it wrote is the output stage applied to the same sum
+    import zlib
+    data = open(tmp_path / "o.png", "rb").read()
+    assert data.startswith(b"\x89PNG")
+    idat = data[data.index(b"IDAT") + 4:data.index(b"IEND") - 8]
+    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(H, W * 4 + 1)[:, 1:].reshape(H, W, 4).astype(np.uint32)
+    png = (np.cumsum(rows, axis=1) & 255).astype(np.uint8)
+    r = pkg.Renderer()
+    r.resize(W, H)
+    r.write_accumulation(img)
+    r.postprocess(spp)
+    assert (png == r.read_output()).all()
+    r.close()

@@ -5,12 +5,12 @@ import pytest
 
 import util
 
-# functions whose reference body calls sin / cos / pow / atan / asin: the libm-generated vectors differ from
+# functions whose reference body calls sin / cos / pow / atan / asin / exp: the libm-generated vectors differ from
 # the fixed polynomial kernels by a few ULP of the transcendental (amplified where the GLSL
 # subtracts nearly equal numbers, e.g. sqrt(1 - x^2 - y^2) at the rim of the disk)
 TRANSCENDENTAL = {"SchlickFresnel": 1e-6, "SampleGGX": 2e-6, "evaluateBSDF": 1e-6, "sampleBSDF": 5e-6,
                   "sampleUniformDiskConcentric": 1e-6, "sampleCosineHemisphere": 2e-4, "constructPrimaryRayLens": 1e-6,
-                  "sampleLight": 1e-6, "missSkyboxTexCoords": 2e-7}
+                  "sampleLight": 1e-6, "missSkyboxTexCoords": 2e-7, "toneMapPixel": 2e-7}
 
 
 def test_oracle_bitexact_against_reference_glsl(orc):

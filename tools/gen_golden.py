@@ -6,8 +6,9 @@ built (Vulkan RT + absent submodules), but its pure-math shader headers compile 
 once the GLSL builtins are supplied by tools/glsl_shim.hpp.  This script
 
   1. reads the listed line ranges of Path-Tracing/Shaders/*.glsl / *.incl,
-  2. applies five mechanical rewrites (plus one wrapper: the skybox texture-coordinate lines of
-     miss.rmiss:20-25 become a function of the ray direction) (out/inout -> references, float-literal suffix,
+  2. applies five mechanical rewrites (plus wrappers: the straight-line bodies of miss.rmiss:20-25,
+     postprocess.comp:22-36, composition.comp:22 and toneMapping.comp:19-21 become functions of the values
+     their main() reads) (out/inout -> references, float-literal suffix,
      swizzle -> method, drop #include/#version, braces around rand() argument lists so
      C++ keeps GLSL's left-to-right evaluation),
   3. writes the result into a TEMP directory (reference text is never copied into the
@@ -89,6 +90,17 @@ def main():
         parts.append("// ---- miss.rmiss")
         parts.append("vec2 missSkyboxTexCoords(vec3 gl_WorldRayDirectionEXT)\n{\n" +
                      rewrite(lines(os.path.join(REF, "miss.rmiss"), [(20, 25)])) + "\n    return texCoords;\n}")
+        # output stage: the straight-line bodies of postprocess.comp:22-36, composition.comp:22 and
+        # toneMapping.comp:19-21, each wrapped as a function of the values its imageLoads return
+        parts.append("// ---- postprocess.comp / composition.comp / toneMapping.comp")
+        parts.append(extract_struct(os.path.join(REF, "ShaderRendererTypes.incl"), "PostProcessingUniformData"))
+        parts.append("PostProcessingUniformData mainUniform; const uint ToneMappingModeSDR = 0u, ToneMappingModeHDR = 1u, s_ToneMappingMode = ToneMappingModeSDR;")
+        parts.append("void postprocessPixel(vec3 accColor, vec3& colorOut, vec3& bloomOut)\n{\n" +
+                     rewrite(lines(os.path.join(REF, "postprocess.comp"), [(22, 36)])) + "\n    colorOut = color; bloomOut = bloomColor;\n}")
+        parts.append("vec3 compositionPixel(vec3 postProcessColor, vec3 bloomColor)\n{\n" +
+                     rewrite(lines(os.path.join(REF, "composition.comp"), [(22, 22)])) + "\n    return color;\n}")
+        parts.append("vec3 toneMapPixel(vec3 color)\n{\n" +
+                     rewrite(lines(os.path.join(REF, "toneMapping.comp"), [(19, 21)])) + "\n    return outColor;\n}")
         parts.append("} // namespace glsl")
         parts.append('#include "%s/golden_main.inc"' % HERE)
         cpp = os.path.join(tmp, "golden.cpp")

@@ -104,6 +104,7 @@ inline vec3 operator*(vec3 a, vec3 b) { return vec3(a.x * b.x, a.y * b.y, a.z * 
 inline vec3 operator*(vec3 a, float s) { return vec3(a.x * s, a.y * s, a.z * s); }
 inline vec3 operator*(float s, vec3 a) { return vec3(s * a.x, s * a.y, s * a.z); }
 inline vec3 operator/(vec3 a, float s) { return vec3(a.x / s, a.y / s, a.z / s); }
+inline vec3 operator/(vec3 a, uint s) { return a / (float)s; } // implicit uint -> float conversion
 inline vec3 operator/(vec3 a, vec3 b) { return vec3(a.x / b.x, a.y / b.y, a.z / b.z); }
 
 inline vec3 operator*(const mat3 &m, vec3 v)
@@ -148,6 +149,11 @@ inline float pow(float x, float y) { return powf(x, y); }
 #endif
 inline float pow(float x, int y) { return pow(x, (float)y); }
 #ifdef SHIM_FIXED
+inline float exp(float x) { return pto_expf(x); }
+#else
+inline float exp(float x) { return expf(x); }
+#endif
+#ifdef SHIM_FIXED
 inline float atan(float y, float x) { return pto_atan2f(y, x); }
 inline float asin(float x) { return pto_asinf(x); }
 #else
@@ -175,6 +181,7 @@ inline vec3 refract(vec3 I, vec3 N, float eta)
         return vec3(0.0f);
     return I * eta - N * (eta * d + sqrtf(k));
 }
+inline vec3 exp(vec3 v) { return vec3(exp(v.x), exp(v.y), exp(v.z)); }
 inline vec3 mix(vec3 x, vec3 y, float a) { return x * (1.0f - a) + y * a; }
 inline mat3 inverse(const mat3 &m)
 {
