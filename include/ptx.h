@@ -233,6 +233,17 @@ typedef enum PtxTextureFormat {
     PTX_TEXTURE_RGBA32F = 2
 } PtxTextureFormat;
 
+/* ShaderTypes.incl:50-59 (scalar block layout), the input of skinning.comp */
+typedef struct PtxAnimatedVertex {
+    float Position[3];
+    float TexCoords[2];
+    float Normal[3];
+    float Tangent[3];
+    float Bitangent[3];
+    uint32_t BoneIndices[4]; /* MaxBonesPerVertex */
+    float BoneWeights[4];
+} PtxAnimatedVertex;
+
 typedef struct PtxTextureDesc {
     uint32_t width, height;
     uint32_t format;   /* PtxTextureFormat */
@@ -277,6 +288,13 @@ typedef struct PtxSceneDesc {
     uint32_t reserved;
     const PtxTextureDesc *skybox; /* Scene::GetSkybox(): 1 (2D) or 6 (cube, equal square faces) images, one level each
                                    * (TextureUploader.cpp:203-262); ignored for PTX_SKYBOX_CLEAR_COLOR */
+    /* Scene::GetAnimatedVertices() / GetAnimatedIndices(): geometries with IsAnimated index THESE arrays
+     * (Renderer.cpp:262-265, :280-312).  Every instanced animated mesh gets its own skinned copy, in bind pose
+     * until the first ptx_update_animation. */
+    const PtxAnimatedVertex *animatedVertices;
+    uint64_t animatedVertexCount;
+    const uint32_t *animatedIndices;
+    uint64_t animatedIndexCount;
 } PtxSceneDesc;
 
 /* ------------------------------------------------------------------------- */
@@ -375,6 +393,24 @@ PTX_API int ptx_pack_shard(PtxRenderer *r, void *devDst);
 PTX_API int ptx_unpack_shard(PtxRenderer *r, uint32_t rank, const void *devSrc);
 
 PTX_API int ptx_get_stats(PtxRenderer *r, PtxStats *stats);
+
+/* ------------------------------------------------------------------------- */
+/* Animation (row N3)                                                        */
+/* ------------------------------------------------------------------------- */
+
+typedef enum PtxAccelUpdate {
+    PTX_ACCEL_REFIT = 0,   /* keep the tree topology of the last full build: new triangle positions, boxes refitted bottom-up
+                            * (the reference's BLAS update + TLAS rebuild, AccelerationStructure.cpp:48-57) */
+    PTX_ACCEL_REBUILD = 1  /* full LBVH build */
+} PtxAccelUpdate;
+
+/* What Renderer::Render does when Scene::Update reported a change (Renderer.cpp:1750-1754, :854-890):
+ * new ModelInstance transforms (instanceCount must match the uploaded scene; NULL = unchanged), new bone
+ * matrices for skinning.comp (Scene::GetBoneTransforms(): boneCount x mat3x4; NULL = unchanged), the skinning
+ * pass over every animated mesh, then the acceleration-structure update.  Results never depend on the tree:
+ * a refit and a rebuild render identical images. */
+PTX_API int ptx_update_animation(PtxRenderer *r, const PtxTransform *instanceTransforms, uint32_t instanceCount,
+                                 const PtxTransform *boneTransforms, uint32_t boneCount, uint32_t accelUpdate);
 
 /* ------------------------------------------------------------------------- */
 /* Output stage (row N4): what turns the running sum into a displayable image */

@@ -36,6 +36,15 @@ PTX_API int pth_scene_raygen_uniform(PthScene *s, uint32_t width, uint32_t heigh
 PTX_API int pth_scene_set_active_camera(PthScene *s, int32_t cameraId);
 PTX_API int pth_scene_set_camera_pose(PthScene *s, const float position[3], const float direction[3]);
 
+/* Animation (row N3).  pth_scene_update = Scene::Update(timeStep) (Scene.cpp:52-83): advances the keyframe
+ * animations, the scene graph, instance transforms, bone matrices and light positions; returns 1 if the
+ * renderer has to refresh (Renderer.cpp:1750-1754), 0 if nothing moved, < 0 on error.  The state to hand to
+ * ptx_update_animation is read back with pth_scene_animation_state (either pointer may be NULL). */
+PTX_API int pth_scene_update(PthScene *s, float timeStep);
+PTX_API uint32_t pth_scene_bone_count(PthScene *s);
+PTX_API int pth_scene_animation_state(PthScene *s, PtxTransform *instanceTransforms, uint32_t instanceCount, PtxTransform *boneTransforms,
+                                      uint32_t boneCount);
+
 /* Output stage (row N4): OutputSaver::WriteImage (OutputSaver.cpp:227-257) for one image.  format: 0 Png, 1 Jpg
  * (not implemented: returns 1), 2 Tga, 3 Hdr.  data: RGBA8 (Png / Tga) or RGBA32F (Hdr), top row first. */
 PTX_API int pth_write_image(const char *path, uint32_t format, uint32_t width, uint32_t height, const void *data, size_t bytes);

@@ -40,6 +40,8 @@ def load() -> C.CDLL:
         P = C.c_void_p
         lib.pto_scene_create.restype = P
         lib.pto_scene_create.argtypes = [P, C.c_int]
+        lib.pto_scene_create_posed.restype = P
+        lib.pto_scene_create_posed.argtypes = [P, P, P, C.c_uint32, C.c_int]
         lib.pto_scene_destroy.argtypes = [P]
         lib.pto_scene_triangle_count.restype = C.c_uint64
         lib.pto_scene_triangle_count.argtypes = [P]
@@ -55,11 +57,16 @@ def load() -> C.CDLL:
 
 
 class OracleScene:
-    def __init__(self, desc, build_bvh: bool = True):
-        """desc: a ctypes image of PtxSceneDesc (anything with ctypes.byref support)."""
+    def __init__(self, desc, build_bvh: bool = True, instance_transforms=None, bones=None):
+        """desc: a ctypes image of PtxSceneDesc (anything with ctypes.byref support).  instance_transforms
+        (n x 12 float32) / bones (m x 12 float32): the state of one animated frame (Scene::Update)."""
         self.lib = load()
         self._desc = desc  # keep alive
-        self.handle = self.lib.pto_scene_create(C.addressof(desc), int(build_bvh))
+        it = None if instance_transforms is None else np.ascontiguousarray(instance_transforms, np.float32).reshape(-1, 12)
+        bn = None if bones is None else np.ascontiguousarray(bones, np.float32).reshape(-1, 12)
+        self.handle = self.lib.pto_scene_create_posed(C.addressof(desc), it.ctypes.data if it is not None else None,
+                                                      bn.ctypes.data if bn is not None else None, 0 if bn is None else bn.shape[0],
+                                                      int(build_bvh))
 
     def close(self):
         if getattr(self, "handle", None):

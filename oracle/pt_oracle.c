@@ -699,7 +699,9 @@ typedef struct Pair /* one (instance, mesh) */
 {
     float M[12];   /* A_instance * A_mesh, 3 rows x 4 (sampling.glsl:5-15 derivation) */
     m3 Rinv;       /* inverse of the linear part, for the normal transform             */
-    uint32_t vertexOffset, indexOffset, materialId, firstTri;
+    const PtxVertex *vb; /* first vertex of the mesh: the scene's vertices, or this pair's skinned copy */
+    const uint32_t *ib;  /* first index of the mesh */
+    uint32_t materialId, firstTri;
     uint32_t nonOpaque; /* geometry without VK_GEOMETRY_OPAQUE_BIT: any-hit shaders run (AccelerationStructure.cpp:94-97) */
 } Pair;
 
@@ -724,6 +726,7 @@ struct PtoScene
     /* scene textures (row N1) */
     struct OTexture *textures;
     uint32_t textureCount;
+    PtxVertex *skinned; /* skinning.comp output: one copy per instanced animated mesh, in pair order */
     uint32_t skyKind; /* PTX_SKYBOX_*; its 1 / 6 images sit at textures[textureCount ...] */
     uint32_t *texels8; /* RGBA8 pool, all levels of all 8-bit textures */
     float *texelsF;    /* RGBA32F pool */
@@ -771,12 +774,58 @@ static inline v3 xformVector(const float *M, v3 p)
 static void buildBvh(PtoScene *s);
 static void uploadTextures(PtoScene *s, const PtxSceneDesc *desc);
 
+/* skinning.comp:21-50 for one vertex.  bones = mat3x4[]: vec4 * mat3x4 takes the dot product with each of the three
+ * stored rows, i.e. bones[b] is the affine matrix of the bone in 3 rows x 4.  The normal goes through the inverse
+ * transpose of the linear part ("transpose(inverse(mat4(transform)))", fixed here as the cofactor inverse). */
+static PtxVertex skinVertex(const PtxAnimatedVertex *a, const PtxTransform *bones, uint32_t boneCount)
+{
+    v3 P = v3s(0.0f), N = v3s(0.0f), T = v3s(0.0f), B = v3s(0.0f);
+    float totalWeight = 0;
+    for (int i = 0; i < 4 && totalWeight < 1.0f; i++)
+    {
+        const uint32_t boneIndex = a->BoneIndices[i];
+        const float w = a->BoneWeights[i];
+        PtxTransform idt = { { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 } };
+        const float *M = (bones && boneIndex < boneCount) ? bones[boneIndex].m : idt.m;
+        const v3 p = xformPoint(M, V3(a->Position[0], a->Position[1], a->Position[2]));
+        P = v_add(P, v_scale(p, w));
+        T = v_add(T, v_scale(v_normalize(xformVector(M, V3(a->Tangent[0], a->Tangent[1], a->Tangent[2]))), w));
+        B = v_add(B, v_scale(v_normalize(xformVector(M, V3(a->Bitangent[0], a->Bitangent[1], a->Bitangent[2]))), w));
+        m3 R;
+        R.c0 = V3(M[0], M[4], M[8]);
+        R.c1 = V3(M[1], M[5], M[9]);
+        R.c2 = V3(M[2], M[6], M[10]);
+        const m3 Ri = m3_inverse(R);
+        const v3 n = V3(a->Normal[0], a->Normal[1], a->Normal[2]);
+        N = v_add(N, v_scale(v_normalize(V3(v_dot(n, Ri.c0), v_dot(n, Ri.c1), v_dot(n, Ri.c2))), w));
+        totalWeight += w;
+    }
+    PtxVertex o;
+    memset(&o, 0, sizeof(o));
+    o.Position[0] = P.x; o.Position[1] = P.y; o.Position[2] = P.z;
+    o.TexCoords[0] = a->TexCoords[0]; o.TexCoords[1] = a->TexCoords[1];
+    o.Normal[0] = N.x; o.Normal[1] = N.y; o.Normal[2] = N.z;
+    o.Tangent[0] = T.x; o.Tangent[1] = T.y; o.Tangent[2] = T.z;
+    o.Bitangent[0] = B.x; o.Bitangent[1] = B.y; o.Bitangent[2] = B.z;
+    return o;
+}
+
 PtoScene *pto_scene_create(const PtxSceneDesc *desc, int wantBvh)
+{
+    return pto_scene_create_posed(desc, NULL, NULL, 0, wantBvh);
+}
+
+/* The scene as Renderer::Render sees it after Scene::Update: instance transforms replaced (NULL = those of the
+ * desc), animated meshes skinned with `bones` (NULL = bind pose, Renderer.cpp:296-303). */
+PtoScene *pto_scene_create_posed(const PtxSceneDesc *desc, const PtxTransform *instanceTransforms, const PtxTransform *bones,
+                                 uint32_t boneCount, int wantBvh)
 {
     PtoScene *s = (PtoScene *)calloc(1, sizeof(PtoScene));
     s->d = *desc;
     s->d.vertices = (const PtxVertex *)dupmem(desc->vertices, desc->vertexCount * sizeof(PtxVertex));
     s->d.indices = (const uint32_t *)dupmem(desc->indices, desc->indexCount * 4);
+    s->d.animatedVertices = NULL;
+    s->d.animatedIndices = (const uint32_t *)dupmem(desc->animatedIndices, desc->animatedIndexCount * 4);
     s->d.transforms = (const PtxTransform *)dupmem(desc->transforms, desc->transformCount * sizeof(PtxTransform));
     s->d.geometries = (const PtxGeometry *)dupmem(desc->geometries, desc->geometryCount * sizeof(PtxGeometry));
     s->d.metallicRoughnessMaterials = (const PtxMetallicRoughnessMaterial *)dupmem(
@@ -802,6 +851,19 @@ PtoScene *pto_scene_create(const PtxSceneDesc *desc, int wantBvh)
     s->pairCount = pairCount;
     s->triCount = triCount;
     s->pairs = (Pair *)calloc(pairCount ? pairCount : 1, sizeof(Pair));
+    size_t skinnedCount = 0; /* one output range per instanced animated mesh, in pair order */
+    for (uint32_t i = 0; i < desc->instanceCount; i++)
+    {
+        const PtxModel *m = &desc->models[desc->instances[i].ModelIndex];
+        for (uint32_t k = 0; k < m->MeshCount; k++)
+        {
+            const PtxGeometry *g = &desc->geometries[desc->meshes[m->MeshOffset + k].GeometryIndex];
+            if (g->IsAnimated)
+                skinnedCount += g->VertexLength;
+        }
+    }
+    s->skinned = (PtxVertex *)calloc(skinnedCount ? skinnedCount : 1, sizeof(PtxVertex));
+    size_t skinnedCursor = 0;
     s->v0 = (float *)malloc((triCount ? triCount : 1) * 12);
     s->e1 = (float *)malloc((triCount ? triCount : 1) * 12);
     s->e2 = (float *)malloc((triCount ? triCount : 1) * 12);
@@ -819,14 +881,36 @@ PtoScene *pto_scene_create(const PtxSceneDesc *desc, int wantBvh)
             const PtxMeshRecord *rec = &desc->meshes[m->MeshOffset + k];
             const PtxGeometry *g = &desc->geometries[rec->GeometryIndex];
             Pair *pr = &s->pairs[p];
-            composeTransform(inst->Transform.m, desc->transforms[rec->TransformIndex].m, pr->M);
+            composeTransform(instanceTransforms ? instanceTransforms[i].m : inst->Transform.m, desc->transforms[rec->TransformIndex].m, pr->M);
             m3 R;
             R.c0 = V3(pr->M[0], pr->M[4], pr->M[8]);
             R.c1 = V3(pr->M[1], pr->M[5], pr->M[9]);
             R.c2 = V3(pr->M[2], pr->M[6], pr->M[10]);
             pr->Rinv = m3_inverse(R);
-            pr->vertexOffset = g->VertexOffset;
-            pr->indexOffset = g->IndexOffset;
+            if (g->IsAnimated)
+            {
+                PtxVertex *out = &s->skinned[skinnedCursor];
+                for (uint32_t v = 0; v < g->VertexLength; v++)
+                {
+                    const PtxAnimatedVertex *a = &desc->animatedVertices[g->VertexOffset + v];
+                    if (bones)
+                        out[v] = skinVertex(a, bones, boneCount);
+                    else /* bind pose: the attributes as authored (OutBindPoseAnimatedVertices, Renderer.cpp:296-303) */
+                    {
+                        memcpy(out[v].Position, a->Position, 12); memcpy(out[v].TexCoords, a->TexCoords, 8);
+                        memcpy(out[v].Normal, a->Normal, 12); memcpy(out[v].Tangent, a->Tangent, 12);
+                        memcpy(out[v].Bitangent, a->Bitangent, 12);
+                    }
+                }
+                skinnedCursor += g->VertexLength;
+                pr->vb = out;
+                pr->ib = &s->d.animatedIndices[g->IndexOffset];
+            }
+            else
+            {
+                pr->vb = &s->d.vertices[g->VertexOffset];
+                pr->ib = &s->d.indices[g->IndexOffset];
+            }
             pr->materialId = rec->MaterialId;
             pr->firstTri = (uint32_t)t;
             pr->nonOpaque = g->IsOpaque ? 0u : 1u;
@@ -836,8 +920,7 @@ PtoScene *pto_scene_create(const PtxSceneDesc *desc, int wantBvh)
                 v3 w[3];
                 for (int c = 0; c < 3; c++)
                 {
-                    const uint32_t idx = desc->indices[g->IndexOffset + q * 3 + c];
-                    const PtxVertex *vx = &desc->vertices[g->VertexOffset + idx];
+                    const PtxVertex *vx = &pr->vb[pr->ib[q * 3 + c]];
                     w[c] = xformPoint(pr->M, V3(vx->Position[0], vx->Position[1], vx->Position[2]));
                 }
                 const v3 a = v_sub(w[1], w[0]), b = v_sub(w[2], w[0]);
@@ -862,6 +945,7 @@ void pto_scene_destroy(PtoScene *s)
     if (!s)
         return;
     free((void *)s->d.vertices); free((void *)s->d.indices); free((void *)s->d.transforms);
+    free((void *)s->d.animatedIndices); free(s->skinned);
     free((void *)s->d.geometries); free((void *)s->d.metallicRoughnessMaterials);
     free((void *)s->d.specularGlossinessMaterials); free((void *)s->d.phongMaterials);
     free((void *)s->d.meshes); free((void *)s->d.models); free((void *)s->d.instances);
@@ -1488,8 +1572,8 @@ static v4 hitBaseColor(const PtoScene *s, uint32_t tri, float u, float v)
     const Pair *pr = &s->pairs[s->triPair[tri]];
     const uint32_t prim = s->triPrim[tri];
     const v3 bary = V3(1.0f - u - v, u, v);
-    const uint32_t *ix = &s->d.indices[pr->indexOffset + prim * 3];
-    const PtxVertex *vb = &s->d.vertices[pr->vertexOffset];
+    const uint32_t *ix = &pr->ib[prim * 3];
+    const PtxVertex *vb = pr->vb;
     v2 uv;
     uv.x = vb[ix[0]].TexCoords[0] * bary.x + vb[ix[1]].TexCoords[0] * bary.y + vb[ix[2]].TexCoords[0] * bary.z;
     uv.y = vb[ix[0]].TexCoords[1] * bary.x + vb[ix[1]].TexCoords[1] * bary.y + vb[ix[2]].TexCoords[1] * bary.z;
@@ -1634,8 +1718,8 @@ typedef struct Payload
 /* common.glsl:27-46 */
 static inline Vtx getVertex(const PtoScene *s, const Pair *pr, uint32_t offset)
 {
-    const uint32_t index = s->d.indices[pr->indexOffset + offset];
-    const PtxVertex *p = &s->d.vertices[pr->vertexOffset + index];
+    (void)s;
+    const PtxVertex *p = &pr->vb[pr->ib[offset]];
     Vtx v;
     v.Position = V3(p->Position[0], p->Position[1], p->Position[2]);
     v.TexCoords.x = p->TexCoords[0];

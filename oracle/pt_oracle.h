@@ -61,6 +61,10 @@ typedef struct PtoHit {
  * BLAS/TLAS build, AccelerationStructure.cpp:64-301); buildBvh != 0 adds a binned-SAH
  * BVH, otherwise queries are brute force. */
 PTX_API PtoScene *pto_scene_create(const PtxSceneDesc *desc, int buildBvh);
+/* The same with the state of one animated frame: instance transforms and bone matrices as Scene::Update left
+ * them (NULL = the desc's transforms / bind pose); animated meshes are skinned on the CPU (skinning.comp). */
+PTX_API PtoScene *pto_scene_create_posed(const PtxSceneDesc *desc, const PtxTransform *instanceTransforms, const PtxTransform *bones,
+                                         uint32_t boneCount, int buildBvh);
 PTX_API void pto_scene_destroy(PtoScene *s);
 PTX_API uint64_t pto_scene_triangle_count(const PtoScene *s);
 

@@ -43,12 +43,12 @@ PTX_SYMBOLS = [
     "ptx_render_frames", "ptx_synchronize", "ptx_readback", "ptx_device_accum_ptr", "ptx_accum_bytes",
     "ptx_shard_bytes", "ptx_pack_shard", "ptx_unpack_shard", "ptx_get_stats", "ptx_bind_accumulation",
     "ptx_trace_rays", "ptx_test_input_stride", "ptx_test_output_stride", "ptx_test_eval", "ptx_test_texture",
-    "ptx_postprocess", "ptx_read_output", "ptx_write_accumulation",
+    "ptx_postprocess", "ptx_read_output", "ptx_write_accumulation", "ptx_update_animation",
 ]
 PTH_SYMBOLS = [
     "pth_scene_names", "pth_scene_create", "pth_scene_destroy", "pth_last_error", "pth_scene_desc",
     "pth_scene_lights", "pth_scene_triangle_count", "pth_scene_raygen_uniform", "pth_scene_set_active_camera",
-    "pth_scene_set_camera_pose", "pth_write_image", "pth_save_checkpoint", "pth_load_checkpoint",
+    "pth_scene_set_camera_pose", "pth_scene_update", "pth_scene_bone_count", "pth_scene_animation_state", "pth_write_image", "pth_save_checkpoint", "pth_load_checkpoint",
 ]
 
 BACKEND_WAVEFRONT = 0
@@ -73,6 +73,8 @@ class SceneDesc(C.Structure):
         ("skyboxKind", C.c_uint32), ("dxNormalTextures", C.c_uint32),
         ("textures", C.c_void_p), ("textureCount", C.c_uint32), ("reserved", C.c_uint32),
         ("skybox", C.c_void_p),
+        ("animatedVertices", C.c_void_p), ("animatedVertexCount", C.c_uint64),
+        ("animatedIndices", C.c_void_p), ("animatedIndexCount", C.c_uint64),
     ]
 
 
@@ -106,6 +108,7 @@ class PostProcessingUniformData(C.Structure):
 
 
 TONE_MAPPING_SDR, TONE_MAPPING_HDR = 0, 1
+ACCEL_REFIT, ACCEL_REBUILD = 0, 1
 OUTPUT_RGBA8_SRGB, OUTPUT_RGBA32F = 0, 1
 
 
@@ -197,6 +200,10 @@ def load_host() -> C.CDLL:
                                                  C.c_uint32, C.c_uint32, C.POINTER(RaygenUniformData)]
         lib.pth_scene_set_active_camera.argtypes = [C.c_void_p, C.c_int32]
         lib.pth_scene_set_camera_pose.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        lib.pth_scene_update.argtypes = [C.c_void_p, C.c_float]
+        lib.pth_scene_bone_count.argtypes = [C.c_void_p]
+        lib.pth_scene_bone_count.restype = C.c_uint32
+        lib.pth_scene_animation_state.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
         lib.pth_write_image.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t]
         lib.pth_save_checkpoint.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         lib.pth_load_checkpoint.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_size_t]
@@ -240,6 +247,7 @@ def load_hip() -> C.CDLL:
         lib.ptx_postprocess.argtypes = [P, C.POINTER(PostProcessingUniformData), C.c_uint32]
         lib.ptx_read_output.argtypes = [P, C.c_uint32, P, C.c_size_t]
         lib.ptx_write_accumulation.argtypes = [P, P, C.c_size_t]
+        lib.ptx_update_animation.argtypes = [P, P, C.c_uint32, P, C.c_uint32, C.c_uint32]
         lib.ptx_bind_accumulation.argtypes = [P, P, C.c_size_t]
         lib.ptx_trace_rays.argtypes = [P, P, C.c_uint32, C.c_int, P, P]
         lib.ptx_test_input_stride.argtypes = [C.c_uint32]
@@ -299,6 +307,21 @@ class Scene:
         if rc:
             raise PtxError("pth_scene_raygen_uniform failed")
         return u
+
+    def update(self, time_step: float) -> bool:
+        """Scene::Update(timeStep): True if something the renderer consumes has moved."""
+        rc = self.lib.pth_scene_update(self.handle, float(time_step))
+        if rc < 0:
+            raise PtxError("pth_scene_update failed")
+        return bool(rc)
+
+    def animation_state(self):
+        """(instance transforms n x 12, bone matrices m x 12) as Scene::Update left them."""
+        n, m = self.desc.instanceCount, self.lib.pth_scene_bone_count(self.handle)
+        it, bn = np.zeros((n, 12), np.float32), np.zeros((m, 12), np.float32)
+        if self.lib.pth_scene_animation_state(self.handle, it.ctypes.data, n, bn.ctypes.data if m else None, m):
+            raise PtxError("pth_scene_animation_state failed")
+        return it, bn
 
     def set_active_camera(self, camera_id: int):
         if self.lib.pth_scene_set_active_camera(self.handle, camera_id):
@@ -366,6 +389,14 @@ class Renderer:
         img = np.empty((self.height, self.width, 4), dtype=np.float32)
         self._check(self.lib.ptx_readback(self.handle, img.ctypes.data, img.nbytes))
         return img
+
+    def update_animation(self, instance_transforms=None, bones=None, rebuild: bool = False):
+        """ptx_update_animation: n x 12 instance transforms and / or m x 12 bone matrices, then refit (or rebuild)."""
+        it = None if instance_transforms is None else np.ascontiguousarray(instance_transforms, np.float32).reshape(-1, 12)
+        bn = None if bones is None else np.ascontiguousarray(bones, np.float32).reshape(-1, 12)
+        self._check(self.lib.ptx_update_animation(self.handle, it.ctypes.data if it is not None else None, 0 if it is None else it.shape[0],
+                                                  bn.ctypes.data if bn is not None else None, 0 if bn is None else bn.shape[0],
+                                                  ACCEL_REBUILD if rebuild else ACCEL_REFIT))
 
     def write_accumulation(self, img: np.ndarray):
         img = np.ascontiguousarray(img, dtype=np.float32)

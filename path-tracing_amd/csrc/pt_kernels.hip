@@ -672,6 +672,47 @@ __global__ void __launch_bounds__(kBlock) k_tail(LaunchParams p, SceneView sv, T
 // Utility kernels
 // =====================================================================================
 
+// skinning.comp:21-50: 4-bone linear-blend skinning of one output vertex.  bones = mat3x4[]: "vec4 * mat3x4" is the
+// dot product with each stored row, i.e. a bone is the affine matrix in 3 rows x 4; the normal goes through the
+// inverse transpose of its linear part.
+__global__ void k_skin(const PtxAnimatedVertex *__restrict__ in, const uint32_t *__restrict__ source, uint32_t count,
+                       const PtxTransform *__restrict__ bones, uint32_t boneCount, PtxVertex *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count)
+        return;
+    const PtxAnimatedVertex a = in[source[i]];
+    f3 P = F3s(0.0f), N = F3s(0.0f), T = F3s(0.0f), B = F3s(0.0f);
+    float totalWeight = 0;
+    for (int k = 0; k < 4 && totalWeight < 1.0f; k++)
+    {
+        const uint32_t boneIndex = a.BoneIndices[k];
+        const float w = a.BoneWeights[k];
+        float M[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
+        if (boneIndex < boneCount)
+            for (int q = 0; q < 12; q++)
+                M[q] = bones[boneIndex].m[q];
+        P = P + xformPoint(M, ld3(a.Position)) * w;
+        T = T + normalize(xformVector(M, ld3(a.Tangent))) * w;
+        B = B + normalize(xformVector(M, ld3(a.Bitangent))) * w;
+        mat3 R;
+        R.c0 = F3(M[0], M[4], M[8]);
+        R.c1 = F3(M[1], M[5], M[9]);
+        R.c2 = F3(M[2], M[6], M[10]);
+        const mat3 Ri = inverse(R);
+        const f3 n = ld3(a.Normal);
+        N = N + normalize(F3(dot(n, Ri.c0), dot(n, Ri.c1), dot(n, Ri.c2))) * w;
+        totalWeight += w;
+    }
+    PtxVertex o;
+    o.Position[0] = P.x; o.Position[1] = P.y; o.Position[2] = P.z;
+    o.TexCoords[0] = a.TexCoords[0]; o.TexCoords[1] = a.TexCoords[1];
+    o.Normal[0] = N.x; o.Normal[1] = N.y; o.Normal[2] = N.z;
+    o.Tangent[0] = T.x; o.Tangent[1] = T.y; o.Tangent[2] = T.z;
+    o.Bitangent[0] = B.x; o.Bitangent[1] = B.y; o.Bitangent[2] = B.z;
+    out[i] = o;
+}
+
 // traceRayEXT stand-in over explicit rays (o.xyz, tmin, d.xyz, tmax): traversal parity tests
 struct RaysIO
 {
@@ -1089,6 +1130,32 @@ struct PtxRenderer
     uint32_t textureCount = 0;
     uint32_t skyKind = PTX_SKYBOX_CLEAR_COLOR; // its images follow the scene textures in `textures`
     bool samplerNeeded = false; // some uploaded texture is not a 1x1 white placeholder
+    // animation (row N3)
+    std::vector<DevPair> hostPairs;            // to recompose pair transforms when instances move
+    std::vector<uint32_t> pairInstance;        // pair -> instance
+    std::vector<PtxTransform> pairMeshTransform; // pair -> baked mesh transform
+    uint32_t instanceCount = 0, skinnedCount = 0, boneCount = 0;
+    uint64_t staticVertexCount = 0;
+    DevBuf<PtxAnimatedVertex> animatedVertices;
+    DevBuf<uint32_t> skinSource;
+    DevBuf<PtxTransform> bones;
+    struct BuildState // what a refit reuses from the last full build: sorted order and the binary topology
+    {
+        DevBuf<Tri> triTmp;
+        DevBuf<float4> boxLo, boxHi, nodeLo, nodeHi;
+        DevBuf<uint32_t> sceneBounds, vals0, vals1, hist, flags;
+        DevBuf<uint64_t> keys0, keys1;
+        DevBuf<int2> children;
+        DevBuf<int> parentOfNode, parentOfLeaf;
+        bool valid = false;
+        void release()
+        {
+            triTmp.release(); boxLo.release(); boxHi.release(); nodeLo.release(); nodeHi.release(); sceneBounds.release();
+            vals0.release(); vals1.release(); hist.release(); flags.release(); keys0.release(); keys1.release();
+            children.release(); parentOfNode.release(); parentOfLeaf.release();
+            valid = false;
+        }
+    } build;
     bool anyNonOpaque = false;  // some instanced geometry lacks the opaque flag: any-hit stages run
     DevBuf<float4> decal;
     DevBuf<float> decalT;
@@ -1409,16 +1476,25 @@ int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *s)
     for (uint32_t g = 0; g < s->geometryCount; g++)
     {
         const PtxGeometry &geo = s->geometries[g];
-        if ((uint64_t)geo.VertexOffset + geo.VertexLength > s->vertexCount || (uint64_t)geo.IndexOffset + geo.IndexLength > s->indexCount)
+        // an animated geometry addresses the animated vertex / index arrays (Renderer.cpp:280-312)
+        const uint64_t vLimit = geo.IsAnimated ? (s->animatedVertices ? s->animatedVertexCount : 0) : s->vertexCount;
+        const uint64_t iLimit = geo.IsAnimated ? (s->animatedIndices ? s->animatedIndexCount : 0) : s->indexCount;
+        const uint32_t *idx = geo.IsAnimated ? s->animatedIndices : s->indices;
+        if ((uint64_t)geo.VertexOffset + geo.VertexLength > vLimit || (uint64_t)geo.IndexOffset + geo.IndexLength > iLimit)
             return fail(r, PTX_ERROR_INVALID_ARGUMENT, "geometry %u: vertex/index range out of bounds", g);
         for (uint32_t k = 0; k < geo.IndexLength; k++)
-            if (s->indices[geo.IndexOffset + k] >= geo.VertexLength)
+            if (idx[geo.IndexOffset + k] >= geo.VertexLength)
                 return fail(r, PTX_ERROR_INVALID_ARGUMENT, "geometry %u: index %u beyond its vertex range", g, k);
     }
 
     // (instance, mesh) pairs in instance-then-mesh order; global triangle id = running prim count
+    // Device vertex buffer = scene vertices, then one skinned copy per instanced animated mesh in pair order
+    // (OutAnimatedVertexBuffer, Renderer.cpp:296-303); device index buffer = scene indices, then the animated indices.
     std::vector<DevPair> pairs;
     std::vector<uint32_t> pairFirst;
+    std::vector<uint32_t> skinSource; // output vertex -> animated vertex (AnimatedVertexMapBuffer)
+    r->pairInstance.clear();
+    r->pairMeshTransform.clear();
     uint64_t tri = 0;
     bool anyNonOpaque = false;
     for (uint32_t i = 0; i < s->instanceCount; i++)
@@ -1434,6 +1510,17 @@ int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *s)
             inverseLinear(pr.M, pr.Rinv);
             pr.vertexOffset = geo.VertexOffset;
             pr.indexOffset = geo.IndexOffset;
+            if (geo.IsAnimated)
+            {
+                if (s->vertexCount + skinSource.size() + geo.VertexLength > 0xffffffffull || s->indexCount + s->animatedIndexCount > 0xffffffffull)
+                    return fail(r, PTX_ERROR_INVALID_ARGUMENT, "animated meshes exceed the 32-bit vertex / index space");
+                pr.vertexOffset = static_cast<uint32_t>(s->vertexCount + skinSource.size());
+                pr.indexOffset = static_cast<uint32_t>(s->indexCount + geo.IndexOffset);
+                for (uint32_t v = 0; v < geo.VertexLength; v++)
+                    skinSource.push_back(geo.VertexOffset + v);
+            }
+            r->pairInstance.push_back(i);
+            r->pairMeshTransform.push_back(s->transforms[rec.TransformIndex]);
             pr.materialId = rec.MaterialId;
             pr.nonOpaque = geo.IsOpaque ? 0u : 1u;
             if (pr.nonOpaque)
@@ -1451,8 +1538,36 @@ int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *s)
     r->dxNormalTextures = s->dxNormalTextures;
 
     int rc;
-    if ((rc = upload(r, r->vertices, s->vertices, s->vertexCount)) != PTX_OK) return rc;
-    if ((rc = upload(r, r->indices, s->indices, s->indexCount)) != PTX_OK) return rc;
+    r->hostPairs = pairs;
+    r->instanceCount = s->instanceCount;
+    r->staticVertexCount = s->vertexCount;
+    r->skinnedCount = static_cast<uint32_t>(skinSource.size());
+    r->boneCount = 0;
+    r->build.release();
+    // bind pose of every skinned copy (OutBindPoseAnimatedVertices); the staging vectors live until the stream
+    // synchronisation at the end of this function
+    std::vector<PtxVertex> verts;
+    std::vector<uint32_t> inds;
+    {
+        verts.assign(s->vertices, s->vertices + s->vertexCount);
+        verts.reserve(verts.size() + skinSource.size());
+        for (uint32_t src : skinSource)
+        {
+            const PtxAnimatedVertex &a = s->animatedVertices[src];
+            PtxVertex v;
+            std::memset(&v, 0, sizeof(v));
+            std::memcpy(v.Position, a.Position, 12); std::memcpy(v.TexCoords, a.TexCoords, 8); std::memcpy(v.Normal, a.Normal, 12);
+            std::memcpy(v.Tangent, a.Tangent, 12); std::memcpy(v.Bitangent, a.Bitangent, 12);
+            verts.push_back(v);
+        }
+        inds.assign(s->indices, s->indices + s->indexCount);
+        if (s->animatedIndices)
+            inds.insert(inds.end(), s->animatedIndices, s->animatedIndices + s->animatedIndexCount);
+        if ((rc = upload(r, r->vertices, verts.data(), verts.size())) != PTX_OK) return rc;
+        if ((rc = upload(r, r->indices, inds.data(), inds.size())) != PTX_OK) return rc;
+        if ((rc = upload(r, r->animatedVertices, s->animatedVertices, skinSource.empty() ? 0 : s->animatedVertexCount)) != PTX_OK) return rc;
+        if ((rc = upload(r, r->skinSource, skinSource.data(), skinSource.size())) != PTX_OK) return rc;
+    }
     if ((rc = upload(r, r->mr, s->metallicRoughnessMaterials, s->metallicRoughnessMaterialCount)) != PTX_OK) return rc;
     if ((rc = upload(r, r->sg, s->specularGlossinessMaterials, s->specularGlossinessMaterialCount)) != PTX_OK) return rc;
     if ((rc = upload(r, r->phong, s->phongMaterials, s->phongMaterialCount)) != PTX_OK) return rc;
@@ -1551,78 +1666,80 @@ int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *s)
     return PTX_OK;
 }
 
-int ptx_build_accel(PtxRenderer *r)
+// Full build (refit = false) or refit: new triangle records and leaf boxes, then the bottom-up box pass and the
+// 4-wide emit over the KEPT Morton order and binary topology.  keepState leaves the temporaries allocated for
+// later refits; a static scene frees them.
+static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
 {
-    if (!r || !r->sceneReady)
-        return fail(r, PTX_ERROR_NOT_READY, "ptx_build_accel: no scene uploaded");
     HIP_TRY(r, hipSetDevice(r->device));
     const uint32_t n = r->triCount;
     r->stats.bvhNodes = n > 1 ? n - 1 : (n ? 1 : 0);
-    HIP_TRY(r, r->nodes.alloc(n > 1 ? n - 1 : 1));
-    HIP_TRY(r, r->tris.alloc(n ? n : 1));
+    if (!refit)
+    {
+        HIP_TRY(r, r->nodes.alloc(n > 1 ? n - 1 : 1));
+        HIP_TRY(r, r->tris.alloc(n ? n : 1));
+    }
     if (n == 0)
     {
         r->accelReady = true;
         r->stats.lastBuildMs = 0.0;
         return PTX_OK;
     }
-    // build temporaries (freed at the end: the build is outside the steady-state path)
-    DevBuf<Tri> triTmp;
-    DevBuf<float4> boxLo, boxHi, nodeLo, nodeHi;
-    DevBuf<uint32_t> sceneBounds, vals0, vals1, hist, flags;
-    DevBuf<uint64_t> keys0, keys1;
-    DevBuf<int2> children;
-    DevBuf<int> parentOfNode, parentOfLeaf;
+    PtxRenderer::BuildState &B = r->build;
     const uint32_t numTiles = (n + kSortTile - 1) / kSortTile;
-    auto freeAll = [&]() {
-        triTmp.release(); boxLo.release(); boxHi.release(); nodeLo.release(); nodeHi.release(); sceneBounds.release();
-        vals0.release(); vals1.release(); hist.release(); flags.release(); keys0.release(); keys1.release();
-        children.release(); parentOfNode.release(); parentOfLeaf.release();
-    };
 #define BUILD_TRY(expr)                                                                                                    \
     do                                                                                                                     \
     {                                                                                                                      \
         const hipError_t e_ = (expr);                                                                                      \
         if (e_ != hipSuccess)                                                                                              \
         {                                                                                                                  \
-            freeAll();                                                                                                     \
+            B.release();                                                                                                   \
             return fail(r, e_ == hipErrorOutOfMemory ? PTX_ERROR_OUT_OF_MEMORY : PTX_ERROR_DEVICE, "%s: %s", #expr,       \
                         hipGetErrorString(e_));                                                                            \
         }                                                                                                                  \
     } while (0)
-    BUILD_TRY(triTmp.alloc(n)); BUILD_TRY(boxLo.alloc(n)); BUILD_TRY(boxHi.alloc(n)); BUILD_TRY(nodeLo.alloc(n)); BUILD_TRY(nodeHi.alloc(n));
-    BUILD_TRY(sceneBounds.alloc(6)); BUILD_TRY(vals0.alloc(n)); BUILD_TRY(vals1.alloc(n)); BUILD_TRY(hist.alloc((size_t)256 * numTiles));
-    BUILD_TRY(flags.alloc(n)); BUILD_TRY(keys0.alloc(n)); BUILD_TRY(keys1.alloc(n)); BUILD_TRY(children.alloc(n));
-    BUILD_TRY(parentOfNode.alloc(n)); BUILD_TRY(parentOfLeaf.alloc(n));
+    if (!refit)
+    {
+        B.valid = false;
+        BUILD_TRY(B.triTmp.alloc(n)); BUILD_TRY(B.boxLo.alloc(n)); BUILD_TRY(B.boxHi.alloc(n)); BUILD_TRY(B.nodeLo.alloc(n));
+        BUILD_TRY(B.nodeHi.alloc(n)); BUILD_TRY(B.sceneBounds.alloc(6)); BUILD_TRY(B.vals0.alloc(n)); BUILD_TRY(B.vals1.alloc(n));
+        BUILD_TRY(B.hist.alloc((size_t)256 * numTiles)); BUILD_TRY(B.flags.alloc(n)); BUILD_TRY(B.keys0.alloc(n)); BUILD_TRY(B.keys1.alloc(n));
+        BUILD_TRY(B.children.alloc(n)); BUILD_TRY(B.parentOfNode.alloc(n)); BUILD_TRY(B.parentOfLeaf.alloc(n));
+    }
 
     const uint32_t initBounds[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
-    BUILD_TRY(hipMemcpyAsync(sceneBounds.p, initBounds, sizeof(initBounds), hipMemcpyHostToDevice, r->stream));
-    BUILD_TRY(hipMemsetAsync(flags.p, 0, (size_t)n * 4, r->stream));
+    BUILD_TRY(hipMemcpyAsync(B.sceneBounds.p, initBounds, sizeof(initBounds), hipMemcpyHostToDevice, r->stream));
+    BUILD_TRY(hipMemsetAsync(B.flags.p, 0, (size_t)n * 4, r->stream));
     BUILD_TRY(hipEventRecord(r->evA, r->stream));
 
     const uint32_t blocks = (n + 255) / 256;
-    k_tri_setup<<<blocks, 256, 0, r->stream>>>(n, r->pairCount, r->pairFirst.p, r->pairs.p, r->vertices.p, r->indices.p, triTmp.p,
-                                               boxLo.p, boxHi.p, sceneBounds.p);
-    k_morton<<<blocks, 256, 0, r->stream>>>(n, boxLo.p, boxHi.p, sceneBounds.p, keys0.p, vals0.p);
-    uint64_t *kin = keys0.p, *kout = keys1.p;
-    uint32_t *vin = vals0.p, *vout = vals1.p;
-    for (uint32_t shift = 0; shift < 64; shift += 8) // 63-bit keys: 8 passes
+    k_tri_setup<<<blocks, 256, 0, r->stream>>>(n, r->pairCount, r->pairFirst.p, r->pairs.p, r->vertices.p, r->indices.p, B.triTmp.p,
+                                               B.boxLo.p, B.boxHi.p, B.sceneBounds.p);
+    // 8 radix passes ping-pong the buffers an even number of times: the sorted order ends in keys0 / vals0
+    uint64_t *kin = B.keys0.p, *kout = B.keys1.p;
+    uint32_t *vin = B.vals0.p, *vout = B.vals1.p;
+    if (!refit)
     {
-        k_sort_hist<<<numTiles, 64, 0, r->stream>>>(n, kin, shift, numTiles, hist.p);
-        k_scan_exclusive<<<1, 1024, 0, r->stream>>>(256 * numTiles, hist.p);
-        k_sort_scatter<<<numTiles, 64, 0, r->stream>>>(n, kin, vin, kout, vout, shift, numTiles, hist.p);
-        std::swap(kin, kout);
-        std::swap(vin, vout);
+        k_morton<<<blocks, 256, 0, r->stream>>>(n, B.boxLo.p, B.boxHi.p, B.sceneBounds.p, B.keys0.p, B.vals0.p);
+        for (uint32_t shift = 0; shift < 64; shift += 8) // 63-bit keys: 8 passes
+        {
+            k_sort_hist<<<numTiles, 64, 0, r->stream>>>(n, kin, shift, numTiles, B.hist.p);
+            k_scan_exclusive<<<1, 1024, 0, r->stream>>>(256 * numTiles, B.hist.p);
+            k_sort_scatter<<<numTiles, 64, 0, r->stream>>>(n, kin, vin, kout, vout, shift, numTiles, B.hist.p);
+            std::swap(kin, kout);
+            std::swap(vin, vout);
+        }
     }
     if (n == 1)
-        k_single_leaf_root<<<1, 1, 0, r->stream>>>(boxLo.p, boxHi.p, triTmp.p, r->nodes.p, r->tris.p);
+        k_single_leaf_root<<<1, 1, 0, r->stream>>>(B.boxLo.p, B.boxHi.p, B.triTmp.p, r->nodes.p, r->tris.p);
     else
     {
-        k_karras<<<blocks, 256, 0, r->stream>>>((int)n, kin, children.p, parentOfNode.p, parentOfLeaf.p);
-        k_refit<<<blocks, 256, 0, r->stream>>>((int)n, vin, boxLo.p, boxHi.p, children.p, parentOfNode.p, parentOfLeaf.p, nodeLo.p,
-                                               nodeHi.p, flags.p);
-        k_emit<<<blocks, 256, 0, r->stream>>>((int)n, vin, boxLo.p, boxHi.p, children.p, nodeLo.p, nodeHi.p, triTmp.p, r->nodes.p,
-                                              r->tris.p);
+        if (!refit)
+            k_karras<<<blocks, 256, 0, r->stream>>>((int)n, kin, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p);
+        k_refit<<<blocks, 256, 0, r->stream>>>((int)n, vin, B.boxLo.p, B.boxHi.p, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p,
+                                               B.nodeLo.p, B.nodeHi.p, B.flags.p);
+        k_emit<<<blocks, 256, 0, r->stream>>>((int)n, vin, B.boxLo.p, B.boxHi.p, B.children.p, B.nodeLo.p, B.nodeHi.p, B.triTmp.p,
+                                              r->nodes.p, r->tris.p);
     }
     BUILD_TRY(hipEventRecord(r->evB, r->stream));
     BUILD_TRY(hipStreamSynchronize(r->stream));
@@ -1630,10 +1747,58 @@ int ptx_build_accel(PtxRenderer *r)
     float ms = 0.0f;
     (void)hipEventElapsedTime(&ms, r->evA, r->evB);
     r->stats.lastBuildMs = ms;
-    freeAll();
+    if (keepState)
+        B.valid = true;
+    else
+        B.release();
 #undef BUILD_TRY
     r->accelReady = true;
     return PTX_OK;
+}
+
+int ptx_build_accel(PtxRenderer *r)
+{
+    if (!r || !r->sceneReady)
+        return fail(r, PTX_ERROR_NOT_READY, "ptx_build_accel: no scene uploaded");
+    return buildAccel(r, false, false);
+}
+
+// Renderer.cpp:1750-1754 (+ RecordSkinningCommands :854-890, AccelerationStructure::Update :48-57)
+int ptx_update_animation(PtxRenderer *r, const PtxTransform *instanceTransforms, uint32_t instanceCount, const PtxTransform *boneTransforms,
+                         uint32_t boneCount, uint32_t accelUpdate)
+{
+    if (!r || accelUpdate > PTX_ACCEL_REBUILD)
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_update_animation: bad argument");
+    if (!r->sceneReady)
+        return fail(r, PTX_ERROR_NOT_READY, "ptx_update_animation: no scene uploaded");
+    if (instanceTransforms && instanceCount != r->instanceCount)
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_update_animation: %u instance transforms for a scene of %u instances", instanceCount,
+                    r->instanceCount);
+    HIP_TRY(r, hipSetDevice(r->device));
+    if (instanceTransforms)
+    {
+        for (size_t p = 0; p < r->hostPairs.size(); p++)
+        {
+            DevPair &pr = r->hostPairs[p];
+            composeTransform(instanceTransforms[r->pairInstance[p]].m, r->pairMeshTransform[p].m, pr.M);
+            inverseLinear(pr.M, pr.Rinv);
+        }
+        if (!r->hostPairs.empty())
+            HIP_TRY(r, hipMemcpyAsync(r->pairs.p, r->hostPairs.data(), r->hostPairs.size() * sizeof(DevPair), hipMemcpyHostToDevice, r->stream));
+    }
+    if (boneTransforms && r->skinnedCount)
+    {
+        if (boneCount > r->bones.n)
+            HIP_TRY(r, r->bones.alloc(boneCount));
+        r->boneCount = boneCount;
+        if (boneCount)
+            HIP_TRY(r, hipMemcpyAsync(r->bones.p, boneTransforms, (size_t)boneCount * sizeof(PtxTransform), hipMemcpyHostToDevice, r->stream));
+        k_skin<<<(r->skinnedCount + 255) / 256, 256, 0, r->stream>>>(r->animatedVertices.p, r->skinSource.p, r->skinnedCount, r->bones.p, boneCount,
+                                                                  r->vertices.p + r->staticVertexCount);
+    }
+    HIP_TRY(r, hipStreamSynchronize(r->stream)); // the caller's arrays may go away
+    const bool refit = accelUpdate == PTX_ACCEL_REFIT && r->build.valid && r->accelReady;
+    return buildAccel(r, refit, true);
 }
 
 int ptx_resize(PtxRenderer *r, uint32_t width, uint32_t height)

@@ -1289,9 +1289,147 @@ void CreateAlphaTestScene(SceneBuilder &sb, uint32_t seed)
     AddViewCamera(sb, Vec3(0.0f, 2.0f, -6.0f), Vec3(0.0f, 1.6f, 0.0f));
 }
 
+// Node animation, hierarchy and skinning in one small scene (row N3):
+//   * a platform spinning about y with a cube riding on it (child node of an animated node) that also bobs,
+//   * a skinned "tentacle": a 12-sided tube whose rings blend between consecutive bones of a 4-bone chain
+//     (AnimatedVertex / Bone / skinning.comp), each joint swinging with a phase offset,
+//   * a point light sliding along x (the animated light of the reference's textured-cubes scene,
+//     ExampleScenes.cpp:636-651).
+// TickPerSecond 30, duration 120 ticks (4 s loop).
+void CreateAnimatedTestScene(SceneBuilder &sb, float detail, uint32_t seed)
+{
+    (void)seed;
+    const auto floorMat = sb.AddMaterial("Anim Floor", MakeMaterial(Vec3(0.6f, 0.6f, 0.62f), 0.8f, 0.0f));
+    const auto platformMat = sb.AddMaterial("Platform", MakeMaterial(Vec3(0.75f, 0.3f, 0.2f), 0.5f, 0.0f));
+    const auto riderMat = sb.AddMaterial("Rider", MakeMaterial(Vec3(0.9f, 0.8f, 0.3f), 0.3f, 1.0f));
+    const auto skinMat = sb.AddMaterial("Tentacle", MakeMaterial(Vec3(0.25f, 0.55f, 0.35f), 0.45f, 0.0f));
+
+    const uint32_t floor = AddBox(sb, Vec3(0, -0.1f, 0), Vec3(8, 0.1f, 8));
+    const uint32_t platform = AddBox(sb, Vec3(0, 0.15f, 0), Vec3(1.4f, 0.15f, 1.4f));
+    const uint32_t rider = AddBox(sb, Vec3(0, 0, 0), Vec3(0.3f, 0.3f, 0.3f));
+
+    const uint32_t root = sb.AddSceneNode({ 0u, Mat4::Identity(), Mat4::Identity() });
+    const std::array<MeshInfo, 1> floorMesh = { MI(floor, floorMat) };
+    sb.AddModelInstance(sb.AddModel(floorMesh), root);
+
+    const uint32_t platformNode = sb.AddSceneNode({ root, Translate(Mat4::Identity(), Vec3(-2.0f, 0.0f, 0.5f)), Mat4::Identity() });
+    const std::array<MeshInfo, 1> platformMesh = { MI(platform, platformMat) };
+    sb.AddModelInstance(sb.AddModel(platformMesh), platformNode);
+    const uint32_t riderNode = sb.AddSceneNode({ platformNode, Translate(Mat4::Identity(), Vec3(0.9f, 0.6f, 0.0f)), Mat4::Identity() });
+    const std::array<MeshInfo, 1> riderMesh = { MI(rider, riderMat) };
+    sb.AddModelInstance(sb.AddModel(riderMesh), riderNode);
+
+    const float duration = 120.0f;
+    std::vector<AnimationNode> nodes;
+    {
+        AnimationNode spin;
+        spin.SceneNodeIndex = platformNode;
+        spin.Positions.Keys = { { Vec3(-2.0f, 0.0f, 0.5f), 0.0f } };
+        for (int k = 0; k <= 4; k++)
+            spin.Rotations.Keys.push_back({ AngleAxis(1.5707963f * static_cast<float>(k), Vec3(0, 1, 0)), 30.0f * static_cast<float>(k) });
+        spin.Scales.Keys = { { Vec3(1.0f), 0.0f } };
+        nodes.push_back(std::move(spin));
+        AnimationNode bob;
+        bob.SceneNodeIndex = riderNode;
+        bob.Positions.Keys = { { Vec3(0.9f, 0.6f, 0.0f), 0.0f }, { Vec3(0.9f, 1.3f, 0.0f), 60.0f }, { Vec3(0.9f, 0.6f, 0.0f), 120.0f } };
+        bob.Rotations.Keys = { { Quat(), 0.0f }, { AngleAxis(3.0f, Vec3(1, 0, 0)), 120.0f } };
+        bob.Scales.Keys = { { Vec3(1.0f), 0.0f }, { Vec3(1.4f, 0.7f, 1.4f), 60.0f }, { Vec3(1.0f), 120.0f } };
+        nodes.push_back(std::move(bob));
+    }
+
+    // skinned tube along +y: 4 bones of length 0.8, ring weights blend linearly between neighbouring bones
+    const uint32_t sides = Scaled(48, detail, 12), ringsPerBone = Scaled(24, detail, 4), boneCountLocal = 4;
+    const float boneLength = 0.8f, radius = 0.22f, twoPi = 6.283185307179586f;
+    const Vec3 base(2.0f, 0.0f, 0.0f);
+    uint32_t boneNodes[4];
+    uint32_t parent = root;
+    for (uint32_t b = 0; b < boneCountLocal; b++)
+    {
+        const Vec3 local = b == 0 ? base : Vec3(0.0f, boneLength, 0.0f);
+        boneNodes[b] = sb.AddSceneNode({ parent, Translate(Mat4::Identity(), local), Mat4::Identity() });
+        parent = boneNodes[b];
+        // inverse bind matrix: the joint sits at base + (0, b * boneLength, 0) in bind pose
+        const Mat4 bind = Translate(Mat4::Identity(), base + Vec3(0.0f, boneLength * static_cast<float>(b), 0.0f));
+        sb.AddBone({ boneNodes[b], Inverse(bind) });
+        AnimationNode swing;
+        swing.SceneNodeIndex = boneNodes[b];
+        swing.Positions.Keys = { { local, 0.0f } };
+        const float amp = 0.35f;
+        for (int k = 0; k <= 8; k++)
+        {
+            const float phase = twoPi * static_cast<float>(k) / 8.0f - 0.9f * static_cast<float>(b);
+            swing.Rotations.Keys.push_back({ AngleAxis(amp * std::sin(phase), Vec3(0, 0, 1)), duration * static_cast<float>(k) / 8.0f });
+        }
+        swing.Scales.Keys = { { Vec3(1.0f), 0.0f } };
+        nodes.push_back(std::move(swing));
+    }
+    {
+        auto &av = sb.GetAnimatedVertices();
+        auto &ai = sb.GetAnimatedIndices();
+        const uint32_t vertexOffset = static_cast<uint32_t>(av.size()), indexOffset = static_cast<uint32_t>(ai.size());
+        const uint32_t rings = ringsPerBone * boneCountLocal;
+        for (uint32_t j = 0; j <= rings; j++)
+        {
+            const float t = static_cast<float>(j) / static_cast<float>(ringsPerBone); // position along the chain in bones
+            uint32_t b0 = static_cast<uint32_t>(t);
+            if (b0 > boneCountLocal - 1)
+                b0 = boneCountLocal - 1;
+            const uint32_t b1 = b0 + 1 < boneCountLocal ? b0 + 1 : b0;
+            const float frac = t - static_cast<float>(b0);
+            const float w1 = b1 == b0 ? 0.0f : frac * frac * (3.0f - 2.0f * frac) * 0.5f; // the next joint takes over gradually
+            const float taper = 1.0f - 0.55f * static_cast<float>(j) / static_cast<float>(rings);
+            for (uint32_t i = 0; i < sides; i++)
+            {
+                const float a = twoPi * static_cast<float>(i) / static_cast<float>(sides);
+                const Vec3 n(std::cos(a), 0.0f, std::sin(a));
+                const Vec3 p = base + Vec3(0.0f, boneLength * t, 0.0f) + n * (radius * taper);
+                Shaders::AnimatedVertex v;
+                std::memset(&v, 0, sizeof(v));
+                v.Position[0] = p.x; v.Position[1] = p.y; v.Position[2] = p.z;
+                v.TexCoords[0] = static_cast<float>(i) / static_cast<float>(sides); v.TexCoords[1] = t;
+                v.Normal[0] = n.x; v.Normal[1] = n.y; v.Normal[2] = n.z;
+                v.Tangent[0] = -n.z; v.Tangent[1] = 0.0f; v.Tangent[2] = n.x;
+                v.Bitangent[0] = 0.0f; v.Bitangent[1] = 1.0f; v.Bitangent[2] = 0.0f;
+                v.BoneIndices[0] = b0; v.BoneIndices[1] = b1;
+                v.BoneWeights[0] = 1.0f - w1; v.BoneWeights[1] = w1;
+                av.push_back(v);
+            }
+        }
+        for (uint32_t j = 0; j < rings; j++)
+            for (uint32_t i = 0; i < sides; i++)
+            {
+                const uint32_t a = j * sides + i, b = j * sides + (i + 1) % sides, c = (j + 1) * sides + (i + 1) % sides, d = (j + 1) * sides + i;
+                for (uint32_t k : { a, d, c, a, c, b }) // outward-facing
+                    ai.push_back(k);
+            }
+        const uint32_t tube = sb.AddGeometry({ vertexOffset, (rings + 1) * sides, indexOffset, rings * sides * 6, true, true, { 0, 0 } });
+        const std::array<MeshInfo, 1> tubeMesh = { MI(tube, skinMat) };
+        sb.AddModelInstance(sb.AddModel(tubeMesh), root); // skinned meshes live in world space: the bones move them
+    }
+
+    const uint32_t lightNode = sb.AddSceneNode({ root, Translate(Mat4::Identity(), Vec3(-1.0f, 3.0f, -1.0f)), Mat4::Identity() });
+    sb.AddLight(MakePointLight(Vec3(14.0f, 13.0f, 12.0f), Vec3(0.0f)), lightNode);
+    {
+        AnimationNode slide;
+        slide.SceneNodeIndex = lightNode;
+        slide.Positions.Keys = { { Vec3(-1.0f, 3.0f, -1.0f), 0.0f }, { Vec3(2.5f, 3.0f, -1.0f), 60.0f }, { Vec3(-1.0f, 3.0f, -1.0f), 120.0f } };
+        slide.Rotations.Keys = { { Quat(), 0.0f } };
+        slide.Scales.Keys = { { Vec3(1.0f), 0.0f } };
+        nodes.push_back(std::move(slide));
+    }
+    sb.AddAnimation(Animation { std::move(nodes), 30.0f, duration });
+
+    Shaders::DirectionalLight dl;
+    std::memset(&dl, 0, sizeof(dl));
+    dl.Color[0] = dl.Color[1] = dl.Color[2] = 1.5f;
+    dl.Direction[0] = -0.3f; dl.Direction[1] = -1.0f; dl.Direction[2] = 0.4f;
+    sb.SetDirectionalLight(std::move(dl), root);
+    AddViewCamera(sb, Vec3(0.3f, 3.0f, -6.5f), Vec3(0.0f, 1.2f, 0.0f));
+}
+
 // ---------------------------------------------------------------------------
 
-const char *const kSceneNames = "default,roughness_cubes,attenuation_blob,chess_like,temple_like,atrium_like,street_like,texture_test,alpha_test,reuse_mesh_cubes";
+const char *const kSceneNames = "default,roughness_cubes,attenuation_blob,chess_like,temple_like,atrium_like,street_like,texture_test,alpha_test,reuse_mesh_cubes,animated_test";
 
 const char *GetSceneNames()
 {
@@ -1326,6 +1464,8 @@ std::shared_ptr<Scene> CreateScene(const std::string &name, float detail, uint32
         CreateTextureTestScene(sb, seed ? seed : 6);
     else if (name == "reuse_mesh_cubes")
         CreateReuseMeshCubesScene(sb, seed ? seed : 8);
+    else if (name == "animated_test")
+        CreateAnimatedTestScene(sb, detail, seed ? seed : 9);
     else if (name == "alpha_test")
         CreateAlphaTestScene(sb, seed ? seed : 7);
     else

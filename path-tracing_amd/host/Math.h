@@ -99,6 +99,55 @@ inline Mat4 Rotate(const Mat4 &M, float angle, Vec3 v)
     return M * r;
 }
 
+// glm::quat (w, x, y, z) with the three operations the animation system uses
+struct Quat
+{
+    float w = 1.0f, x = 0.0f, y = 0.0f, z = 0.0f;
+};
+
+// glm::mix for vec3
+inline Vec3 Mix(Vec3 a, Vec3 b, float t)
+{
+    return a * (1.0f - t) + b * t;
+}
+
+// glm::slerp: shortest arc, linear blend when the quaternions are nearly parallel
+inline Quat Slerp(const Quat &x, const Quat &y, float a)
+{
+    Quat z = y;
+    float cosTheta = x.w * y.w + x.x * y.x + x.y * y.y + x.z * y.z;
+    if (cosTheta < 0.0f)
+    {
+        z = { -y.w, -y.x, -y.y, -y.z };
+        cosTheta = -cosTheta;
+    }
+    if (cosTheta > 1.0f - 1.1920929e-7f)
+        return { x.w * (1.0f - a) + z.w * a, x.x * (1.0f - a) + z.x * a, x.y * (1.0f - a) + z.y * a, x.z * (1.0f - a) + z.z * a };
+    const float angle = std::acos(cosTheta);
+    const float s0 = std::sin((1.0f - a) * angle), s1 = std::sin(a * angle), d = std::sin(angle);
+    return { (s0 * x.w + s1 * z.w) / d, (s0 * x.x + s1 * z.x) / d, (s0 * x.y + s1 * z.y) / d, (s0 * x.z + s1 * z.z) / d };
+}
+
+// glm::mat4_cast
+inline Mat4 ToMat4(const Quat &q)
+{
+    const float qxx = q.x * q.x, qyy = q.y * q.y, qzz = q.z * q.z, qxz = q.x * q.z, qxy = q.x * q.y, qyz = q.y * q.z, qwx = q.w * q.x,
+                qwy = q.w * q.y, qwz = q.w * q.z;
+    Mat4 r = Mat4::Identity();
+    r.m[0][0] = 1.0f - 2.0f * (qyy + qzz); r.m[1][0] = 2.0f * (qxy + qwz); r.m[2][0] = 2.0f * (qxz - qwy);
+    r.m[0][1] = 2.0f * (qxy - qwz); r.m[1][1] = 1.0f - 2.0f * (qxx + qzz); r.m[2][1] = 2.0f * (qyz + qwx);
+    r.m[0][2] = 2.0f * (qxz + qwy); r.m[1][2] = 2.0f * (qyz - qwx); r.m[2][2] = 1.0f - 2.0f * (qxx + qyy);
+    return r;
+}
+
+// glm::angleAxis
+inline Quat AngleAxis(float angle, Vec3 axis)
+{
+    const float s = std::sin(angle * 0.5f);
+    const Vec3 a = Normalize(axis);
+    return { std::cos(angle * 0.5f), a.x * s, a.y * s, a.z * s };
+}
+
 // general 4x4 inverse by cofactors (glm::inverse)
 inline Mat4 Inverse(const Mat4 &a)
 {

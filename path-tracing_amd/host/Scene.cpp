@@ -56,13 +56,52 @@ void Scene::UpdateTransforms()
     }
 }
 
-// Scene.cpp:52-83
+// SceneGraph.cpp:8-34.  glm::transpose(scale(translate(I, p) * mat4(r), s)) in the reference's transposed
+// storage is the math matrix T * R * S here.
+void Animation::Update(float timeStep, std::span<SceneNode> nodes)
+{
+    CurrentTick += timeStep * TickPerSecond;
+    if (CurrentTick >= Duration)
+    {
+        for (AnimationNode &node : Nodes)
+        {
+            node.Positions.Index = 0;
+            node.Rotations.Index = 0;
+            node.Scales.Index = 0;
+        }
+    }
+
+    while (CurrentTick >= Duration)
+        CurrentTick -= Duration;
+
+    for (AnimationNode &node : Nodes)
+    {
+        const Vec3 position = node.Positions.Update(CurrentTick);
+        const Quat rotation = node.Rotations.Update(CurrentTick);
+        const Vec3 scale = node.Scales.Update(CurrentTick);
+
+        nodes[node.SceneNodeIndex].Transform = Scale(Translate(Mat4::Identity(), position) * ToMat4(rotation), scale);
+    }
+}
+
+// Scene.cpp:52-83 with SceneGraph::Update (SceneGraph.cpp:86-92) inlined
 bool Scene::Update(float timeStep)
 {
     bool updated = GetActiveCamera().OnUpdate(timeStep);
+    if (m_IsAnimationPaused)
+        return updated;
+    updated |= m_HasAnimatedInstances;
+
+    for (Animation &animation : m_Animations)
+        animation.Update(timeStep, m_SceneNodes);
     UpdateTransforms();
     for (auto &instance : m_ModelInstances)
         instance.Transform = m_SceneNodes[instance.SceneNodeIndex].CurrentTransform;
+    for (size_t i = 0; i < m_Bones.size(); i++) // "Offset * node" of the transposed glm form = node * Offset
+    {
+        const Mat4 t = m_SceneNodes[m_Bones[i].SceneNodeIndex].CurrentTransform * m_Bones[i].Offset;
+        std::memcpy(m_BoneTransforms[i].m, &t.m[0][0], sizeof(float) * 12);
+    }
     for (size_t i = 0; i < m_LightInfos.size(); i++)
     {
         const Vec3 p = TransformPoint(m_SceneNodes[m_LightInfos[i].SceneNodeIndex].CurrentTransform, m_LightInfos[i].Position);
@@ -186,6 +225,10 @@ PtxSceneDesc Scene::GetDesc() const
         d.skyboxKind = PTX_SKYBOX_CUBE;
     }
     d.skybox = m_SkyboxRecords.empty() ? nullptr : m_SkyboxRecords.data();
+    d.animatedVertices = m_AnimatedVertices.empty() ? nullptr : m_AnimatedVertices.data();
+    d.animatedVertexCount = m_AnimatedVertices.size();
+    d.animatedIndices = m_AnimatedIndices.empty() ? nullptr : m_AnimatedIndices.data();
+    d.animatedIndexCount = m_AnimatedIndices.size();
     d.dxNormalTextures = m_HasDxNormalTextures ? 1u : 0u;
     return d;
 }
@@ -232,6 +275,10 @@ void SceneBuilder::Reset()
     m_SceneNodes.push_back(SceneNode { RootNodeIndex, Mat4::Identity(), Mat4::Identity() }); // Scene.h:336
     m_IsRelativeTransform.clear();
     m_IsRelativeTransform.push_back(true);
+    m_Animations.clear();
+    m_AnimatedVertices.clear();
+    m_AnimatedIndices.clear();
+    m_Bones.clear();
     m_LightInfos.clear();
     m_PointLights.clear();
     m_DirectionalLight = g_DefaultLight;
@@ -365,8 +412,23 @@ Model SceneBuilder::CreateModel(std::span<const MeshInfo> meshInfos)
 // Scene.cpp:267-335
 std::shared_ptr<Scene> SceneBuilder::CreateSceneShared(const std::string &name)
 {
+    // Scene.cpp:269-288: anything below an animated node moves
+    std::vector<bool> isAnimated(m_SceneNodes.size(), false);
+    for (const Animation &animation : m_Animations)
+        for (const AnimationNode &node : animation.Nodes)
+            isAnimated[node.SceneNodeIndex] = true;
+    for (size_t i = 0; i < m_SceneNodes.size(); i++)
+        if (isAnimated[m_SceneNodes[i].Parent])
+            isAnimated[i] = true;
+    bool hasAnimatedInstances = !m_Bones.empty();
+    for (const LightInfo &light : m_LightInfos)
+        hasAnimatedInstances |= isAnimated[light.SceneNodeIndex];
+    for (auto [modelIndex, sceneNodeIndex] : m_ModelInstanceInfos)
+        hasAnimatedInstances |= isAnimated[sceneNodeIndex];
+
     auto scene = std::make_shared<Scene>();
     scene->m_Name = name;
+    scene->m_HasAnimatedInstances = hasAnimatedInstances;
     scene->m_Vertices = std::move(m_Vertices);
     scene->m_Indices = std::move(m_Indices);
     scene->m_Transforms = std::move(m_Transforms);
@@ -379,6 +441,14 @@ std::shared_ptr<Scene> SceneBuilder::CreateSceneShared(const std::string &name)
     scene->m_Models = std::move(m_Models);
     scene->m_SceneNodes = std::move(m_SceneNodes);
     scene->m_IsRelativeTransform = std::move(m_IsRelativeTransform);
+    scene->m_Animations = std::move(m_Animations);
+    scene->m_AnimatedVertices = std::move(m_AnimatedVertices);
+    scene->m_AnimatedIndices = std::move(m_AnimatedIndices);
+    scene->m_Bones = std::move(m_Bones);
+    scene->m_BoneTransforms.assign(scene->m_Bones.size(), IdentityTransform());
+    scene->m_HasSkeletalAnimations = false;
+    for (const Geometry &g : scene->m_Geometries)
+        scene->m_HasSkeletalAnimations |= g.IsAnimated != 0; // Scene.cpp:47-48
     scene->m_LightInfos = std::move(m_LightInfos);
     scene->m_PointLights = std::move(m_PointLights);
     scene->m_DirectionalLightInfo = m_DirectionalLightInfo;

@@ -2,8 +2,8 @@
 // (Path-Tracing/Scene.h:63-361, Scene.cpp) for the part the path-tracing pass consumes.
 // Same class and method names, same argument meaning, so scene-construction code
 // written against the reference (ExampleScenes.cpp) reads the same here.  Differences:
-// no glm (Math.h), textures are carried as descriptors only (software texturing is the
-// next row N1), skeletal animation is out of scope (N3).
+// no glm (Math.h), textures carry their decoded level-0 texels, and the SceneGraph with its
+// keyframe animations (SceneGraph.h / SceneGraph.cpp) lives inside Scene instead of a separate class.
 #pragma once
 
 #include <memory>
@@ -37,6 +37,7 @@ using SpecularGlossinessMaterial = PtxSpecularGlossinessMaterial;
 using PhongMaterial = PtxPhongMaterial;
 using DirectionalLight = PtxDirectionalLight;
 using PointLight = PtxPointLight;
+using AnimatedVertex = PtxAnimatedVertex;
 using MaterialId = uint32_t;
 
 inline constexpr uint32_t SceneTextureOffset = PTX_SCENE_TEXTURE_OFFSET;
@@ -135,6 +136,78 @@ struct SceneNode
     Mat4 CurrentTransform;
 };
 
+// SceneGraph.h:20-49: per-node TRS keyframe tracks
+struct AnimationNode
+{
+    template<typename T> struct Sequence
+    {
+        struct Key
+        {
+            T Value;
+            float Tick;
+        };
+
+        std::vector<Key> Keys;
+        uint32_t Index = 0;
+
+        T Update(float currentTick);
+        T Interpolate(float ratio);
+    };
+
+    uint32_t SceneNodeIndex;
+
+    Sequence<Vec3> Positions;
+    Sequence<Quat> Rotations;
+    Sequence<Vec3> Scales;
+};
+
+// SceneGraph.h:51-66
+template<typename T> inline T AnimationNode::Sequence<T>::Update(float currentTick)
+{
+    if (currentTick < Keys[0].Tick)
+        return Keys[0].Value;
+
+    while (Index + 1 < Keys.size() && currentTick > Keys[Index + 1].Tick)
+        Index++;
+
+    if (Index + 1 == Keys.size())
+        return Keys.back().Value;
+
+    const float total = Keys[Index + 1].Tick - Keys[Index].Tick;
+    const float current = currentTick - Keys[Index].Tick;
+
+    return Interpolate(current / total);
+}
+
+// SceneGraph.h:68-76
+template<typename T> inline T AnimationNode::Sequence<T>::Interpolate(float ratio)
+{
+    return Mix(Keys[Index].Value, Keys[Index + 1].Value, ratio);
+}
+
+template<> inline Quat AnimationNode::Sequence<Quat>::Interpolate(float ratio)
+{
+    return Slerp(Keys[Index].Value, Keys[Index + 1].Value, ratio);
+}
+
+// SceneGraph.h:78-86
+struct Animation
+{
+    std::vector<AnimationNode> Nodes;
+    float TickPerSecond;
+    float Duration;
+    float CurrentTick = 0;
+
+    void Update(float timeStep, std::span<SceneNode> nodes);
+};
+
+// Scene.h:109-113
+struct Bone
+{
+    uint32_t SceneNodeIndex;
+    Mat4 Offset;
+};
+
 struct LightInfo
 {
     uint32_t SceneNodeIndex;
@@ -200,6 +273,12 @@ public:
 
     [[nodiscard]] std::span<const Shaders::Vertex> GetVertices() const { return m_Vertices; }
     [[nodiscard]] std::span<const uint32_t> GetIndices() const { return m_Indices; }
+    [[nodiscard]] std::span<const Shaders::AnimatedVertex> GetAnimatedVertices() const { return m_AnimatedVertices; }
+    [[nodiscard]] std::span<const uint32_t> GetAnimatedIndices() const { return m_AnimatedIndices; }
+    [[nodiscard]] std::span<const PtxTransform> GetBoneTransforms() const { return m_BoneTransforms; } // glm::mat3x4 each
+    [[nodiscard]] bool HasAnimations() const { return !m_Animations.empty(); }
+    [[nodiscard]] bool HasSkeletalAnimations() const { return m_HasSkeletalAnimations; }
+    void SetAnimationPaused(bool paused) { m_IsAnimationPaused = paused; }
     [[nodiscard]] std::span<const PtxTransform> GetTransforms() const { return m_Transforms; }
     [[nodiscard]] std::span<const Geometry> GetGeometries() const { return m_Geometries; }
     [[nodiscard]] std::span<const Shaders::MetallicRoughnessMaterial> GetMetallicRoughnessMaterials() const { return m_MetallicRoughnessMaterials; }
@@ -245,6 +324,14 @@ private:
     std::vector<ModelInstance> m_ModelInstances;
     std::vector<SceneNode> m_SceneNodes;
     std::vector<bool> m_IsRelativeTransform;
+    std::vector<Animation> m_Animations;
+    std::vector<Shaders::AnimatedVertex> m_AnimatedVertices;
+    std::vector<uint32_t> m_AnimatedIndices;
+    std::vector<Bone> m_Bones;
+    std::vector<PtxTransform> m_BoneTransforms;
+    bool m_HasAnimatedInstances = false;
+    bool m_HasSkeletalAnimations = false;
+    bool m_IsAnimationPaused = false;
     std::vector<LightInfo> m_LightInfos;
     std::vector<Shaders::PointLight> m_PointLights;
     DirectionalLightInfo m_DirectionalLightInfo;
@@ -283,6 +370,15 @@ public:
 
     std::vector<Shaders::Vertex> &GetVertices() { return m_Vertices; }
     std::vector<uint32_t> &GetIndices() { return m_Indices; }
+    std::vector<Shaders::AnimatedVertex> &GetAnimatedVertices() { return m_AnimatedVertices; }
+    std::vector<uint32_t> &GetAnimatedIndices() { return m_AnimatedIndices; }
+
+    void AddAnimation(Animation &&animation) { m_Animations.push_back(std::move(animation)); }
+    uint32_t AddBone(Bone &&bone)
+    {
+        m_Bones.push_back(std::move(bone));
+        return static_cast<uint32_t>(m_Bones.size() - 1);
+    }
 
     void SetAbsoluteTransform(uint32_t sceneNodeIndex);
 
@@ -325,6 +421,10 @@ private:
 
     std::vector<SceneNode> m_SceneNodes;
     std::vector<bool> m_IsRelativeTransform;
+    std::vector<Animation> m_Animations;
+    std::vector<Shaders::AnimatedVertex> m_AnimatedVertices;
+    std::vector<uint32_t> m_AnimatedIndices;
+    std::vector<Bone> m_Bones;
 
     std::vector<LightInfo> m_LightInfos;
     std::vector<Shaders::PointLight> m_PointLights;

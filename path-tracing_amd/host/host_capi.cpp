@@ -113,6 +113,34 @@ int pth_scene_set_camera_pose(PthScene *s, const float position[3], const float 
     return PTX_OK;
 }
 
+int pth_scene_update(PthScene *s, float timeStep)
+{
+    if (!s)
+        return -1;
+    return s->scene->Update(timeStep) ? 1 : 0;
+}
+
+uint32_t pth_scene_bone_count(PthScene *s)
+{
+    return s ? static_cast<uint32_t>(s->scene->GetBoneTransforms().size()) : 0;
+}
+
+int pth_scene_animation_state(PthScene *s, PtxTransform *instanceTransforms, uint32_t instanceCount, PtxTransform *boneTransforms, uint32_t boneCount)
+{
+    if (!s)
+        return PTX_ERROR_INVALID_ARGUMENT;
+    const auto instances = s->scene->GetModelInstances();
+    const auto bones = s->scene->GetBoneTransforms();
+    if ((instanceTransforms && instanceCount != instances.size()) || (boneTransforms && boneCount != bones.size()))
+        return PTX_ERROR_INVALID_ARGUMENT;
+    if (instanceTransforms)
+        for (size_t i = 0; i < instances.size(); i++)
+            std::memcpy(instanceTransforms[i].m, &instances[i].Transform.m[0][0], sizeof(float) * 12);
+    if (boneTransforms && !bones.empty())
+        std::memcpy(boneTransforms, bones.data(), bones.size() * sizeof(PtxTransform));
+    return PTX_OK;
+}
+
 int pth_write_image(const char *path, uint32_t format, uint32_t width, uint32_t height, const void *data, size_t bytes)
 {
     if (!path || !data || !width || !height || format > 3)
