@@ -45,6 +45,11 @@ PTX_API uint32_t pth_scene_bone_count(PthScene *s);
 PTX_API int pth_scene_animation_state(PthScene *s, PtxTransform *instanceTransforms, uint32_t instanceCount, PtxTransform *boneTransforms,
                                       uint32_t boneCount);
 
+/* TextureImporter (rows N1 / N2): decode an image file held in memory (PNG, baseline JPG, TGA, Radiance HDR, DDS
+ * BC1 / BC3 / BC5).  info = { width, height, channels in the file, isFloat }.  pixels may be NULL (query only);
+ * otherwise bytes must be width * height * (isFloat ? 16 : 4). */
+PTX_API int pth_decode_image(const void *file, size_t fileBytes, uint32_t info[4], void *pixels, size_t bytes);
+
 /* Output stage (row N4): OutputSaver::WriteImage (OutputSaver.cpp:227-257) for one image.  format: 0 Png, 1 Jpg
  * (not implemented: returns 1), 2 Tga, 3 Hdr.  data: RGBA8 (Png / Tga) or RGBA32F (Hdr), top row first. */
 PTX_API int pth_write_image(const char *path, uint32_t format, uint32_t width, uint32_t height, const void *data, size_t bytes);

@@ -48,7 +48,7 @@ PTX_SYMBOLS = [
 PTH_SYMBOLS = [
     "pth_scene_names", "pth_scene_create", "pth_scene_destroy", "pth_last_error", "pth_scene_desc",
     "pth_scene_lights", "pth_scene_triangle_count", "pth_scene_raygen_uniform", "pth_scene_set_active_camera",
-    "pth_scene_set_camera_pose", "pth_scene_update", "pth_scene_bone_count", "pth_scene_animation_state", "pth_write_image", "pth_save_checkpoint", "pth_load_checkpoint",
+    "pth_scene_set_camera_pose", "pth_scene_update", "pth_scene_bone_count", "pth_scene_animation_state", "pth_decode_image", "pth_write_image", "pth_save_checkpoint", "pth_load_checkpoint",
 ]
 
 BACKEND_WAVEFRONT = 0
@@ -164,8 +164,8 @@ def build(force: bool = False, verbose: bool = True) -> None:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
     host = os.path.join(PKG_DIR, "host")
-    host_src = [os.path.join(host, f) for f in ("Scene.cpp", "Camera.cpp", "ExampleScenes.cpp", "OutputSaver.cpp", "host_capi.cpp")]
-    host_dep = host_src + [os.path.join(host, f) for f in ("Scene.h", "Camera.h", "ExampleScenes.h", "OutputSaver.h", "Math.h")] + [
+    host_src = [os.path.join(host, f) for f in ("Scene.cpp", "Camera.cpp", "ExampleScenes.cpp", "OutputSaver.cpp", "TextureImporter.cpp", "JpegDecoder.cpp", "host_capi.cpp")]
+    host_dep = host_src + [os.path.join(host, f) for f in ("Scene.h", "Camera.h", "ExampleScenes.h", "OutputSaver.h", "TextureImporter.h", "Math.h")] + [
         os.path.join(REPO_DIR, "include", "ptx_host.h"), os.path.join(REPO_DIR, "include", "ptx.h")]
     if force or _newer(HOST_LIB, host_dep):
         cmd = ["g++"] + HOST_FLAGS + ["-o", HOST_LIB] + host_src
@@ -204,6 +204,7 @@ def load_host() -> C.CDLL:
         lib.pth_scene_bone_count.argtypes = [C.c_void_p]
         lib.pth_scene_bone_count.restype = C.c_uint32
         lib.pth_scene_animation_state.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+        lib.pth_decode_image.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.c_void_p, C.c_size_t]
         lib.pth_write_image.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t]
         lib.pth_save_checkpoint.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         lib.pth_load_checkpoint.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_size_t]
@@ -456,6 +457,18 @@ class Renderer:
 
 
 OUTPUT_PNG, OUTPUT_JPG, OUTPUT_TGA, OUTPUT_HDR = 0, 1, 2, 3
+
+
+def decode_image(data: bytes):
+    """TextureImporter::Decode: returns (H x W x 4 array, uint8 or float32; channels in the file)."""
+    lib = load_host()
+    info = (C.c_uint32 * 4)()
+    if lib.pth_decode_image(data, len(data), info, None, 0):
+        raise PtxError(lib.pth_last_error().decode())
+    img = np.empty((info[1], info[0], 4), np.float32 if info[3] else np.uint8)
+    if lib.pth_decode_image(data, len(data), info, img.ctypes.data, img.nbytes):
+        raise PtxError(lib.pth_last_error().decode())
+    return img, int(info[2])
 
 
 def write_image(path: str, img: np.ndarray, fmt: int = OUTPUT_PNG):

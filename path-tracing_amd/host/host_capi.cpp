@@ -5,6 +5,7 @@
 
 #include "ExampleScenes.h"
 #include "OutputSaver.h"
+#include "TextureImporter.h"
 
 using namespace PathTracing;
 
@@ -139,6 +140,29 @@ int pth_scene_animation_state(PthScene *s, PtxTransform *instanceTransforms, uin
     if (boneTransforms && !bones.empty())
         std::memcpy(boneTransforms, bones.data(), bones.size() * sizeof(PtxTransform));
     return PTX_OK;
+}
+
+int pth_decode_image(const void *file, size_t fileBytes, uint32_t info[4], void *pixels, size_t bytes)
+{
+    if (!file || !info)
+        return PTX_ERROR_INVALID_ARGUMENT;
+    try
+    {
+        const DecodedImage img = TextureImporter::Decode(std::span<const uint8_t>(static_cast<const uint8_t *>(file), fileBytes));
+        info[0] = img.Width; info[1] = img.Height; info[2] = img.Channels; info[3] = img.IsFloat ? 1u : 0u;
+        if (pixels)
+        {
+            if (bytes != img.Pixels.size())
+                return PTX_ERROR_INVALID_ARGUMENT;
+            std::memcpy(pixels, img.Pixels.data(), bytes);
+        }
+        return PTX_OK;
+    }
+    catch (const std::exception &e)
+    {
+        g_error = e.what();
+        return PTX_ERROR_INVALID_ARGUMENT;
+    }
 }
 
 int pth_write_image(const char *path, uint32_t format, uint32_t width, uint32_t height, const void *data, size_t bytes)

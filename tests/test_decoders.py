@@ -1,0 +1,250 @@
+"""TextureImporter mirror (rows N1 / N2): the image decoders the reference takes from stb_image / gli, written
+out here.  Files are synthesised in the test (zlib-compressed PNGs of every colour type and filter, a
+hand-assembled baseline JPEG, TGA, RGBE, BCn blocks) so that no asset is needed."""
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+
+def _png(w, h, ctype, depth, rows, palette=None, trns=None, filters=None, level=6, split=1):
+    """rows: list of raw (unfiltered) scanline bytes; filters: per-row PNG filter type to apply."""
+    samples = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    bpp = max(1, samples * depth // 8)
+
+    def chunk(t, b):
+        return struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b) & 0xFFFFFFFF)
+
+    raw = bytearray()
+    prev = bytes(len(rows[0]))
+    for y, row in enumerate(rows):
+        ft = filters[y % len(filters)] if filters else 0
+        out = bytearray(len(row))
+        for i in range(len(row)):
+            a = row[i - bpp] if i >= bpp else 0
+            b = prev[i]
+            c = prev[i - bpp] if i >= bpp else 0
+            if ft == 0:
+                p = 0
+            elif ft == 1:
+                p = a
+            elif ft == 2:
+                p = b
+            elif ft == 3:
+                p = (a + b) >> 1
+            else:
+                q = a + b - c
+                pa, pb, pc = abs(q - a), abs(q - b), abs(q - c)
+                p = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            out[i] = (row[i] - p) & 255
+        raw.append(ft)
+        raw += out
+        prev = row
+    z = zlib.compress(bytes(raw), level)
+    data = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0))
+    if palette is not None:
+        data += chunk(b"PLTE", bytes(palette))
+    if trns is not None:
+        data += chunk(b"tRNS", bytes(trns))
+    step = (len(z) + split - 1) // split
+    for k in range(0, len(z), step):
+        data += chunk(b"IDAT", z[k:k + step])
+    return data + chunk(b"IEND", b"")
+
+
+def test_inflate_and_png_variants(pkg):
+    rng = np.random.default_rng(0)
+    w, h = 37, 23
+    rgba = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    rgba[5:15, 3:30] = [9, 200, 77, 128]  # runs -> LZ77 matches, dynamic Huffman blocks
+    for level, split in ((0, 1), (1, 3), (9, 1)):  # stored blocks, fixed / dynamic Huffman, split IDAT
+        img, ch = pkg.decode_image(_png(w, h, 6, 8, [rgba[y].tobytes() for y in range(h)], filters=[0, 1, 2, 3, 4], level=level, split=split))
+        assert ch == 4 and (img == rgba).all()
+    rgb = rgba[..., :3].copy()
+    img, ch = pkg.decode_image(_png(w, h, 2, 8, [rgb[y].tobytes() for y in range(h)], filters=[4, 3]))
+    assert ch == 3 and (img[..., :3] == rgb).all() and (img[..., 3] == 255).all()
+    grey = rgba[..., 0].copy()
+    img, ch = pkg.decode_image(_png(w, h, 0, 8, [grey[y].tobytes() for y in range(h)], filters=[2]))
+    assert ch == 1 and (img[..., 0] == grey).all() and (img[..., 1] == grey).all()
+    ga = rgba[..., :2].copy()
+    img, ch = pkg.decode_image(_png(w, h, 4, 8, [ga[y].tobytes() for y in range(h)]))
+    assert ch == 2 and (img[..., 0] == ga[..., 0]).all() and (img[..., 3] == ga[..., 1]).all()
+    # 16 bit -> the high byte; colour key -> alpha 0
+    rgb16 = rng.integers(0, 65536, (h, w, 3)).astype(">u2")
+    rgb16[2, 2] = [0x1234, 0x5678, 0x9ABC]
+    img, ch = pkg.decode_image(_png(w, h, 2, 16, [rgb16[y].tobytes() for y in range(h)], trns=struct.pack(">HHH", 0x1234, 0x5678, 0x9ABC)))
+    assert ch == 4 and (img[..., :3] == (rgb16.astype(np.uint16) >> 8)).all() and img[2, 2, 3] == 0 and img[0, 0, 3] == 255
+    # palette with transparency, 4 bits per index
+    pal = rng.integers(0, 256, (16, 3), dtype=np.uint8)
+    idx = rng.integers(0, 16, (h, 38))
+    rows = [bytes((idx[y, 0::2] << 4 | idx[y, 1::2]).astype(np.uint8)) for y in range(h)]
+    img, ch = pkg.decode_image(_png(38, h, 3, 4, rows, palette=pal.reshape(-1), trns=[0, 128]))
+    assert ch == 4 and (img[..., :3] == pal[idx]).all() and (img[..., 3] == np.where(idx == 0, 0, np.where(idx == 1, 128, 255))).all()
+    # 1-bit greyscale
+    bits = rng.integers(0, 2, (h, 40))
+    rows = [bytes(np.packbits(bits[y].astype(np.uint8))) for y in range(h)]
+    img, _ = pkg.decode_image(_png(40, h, 0, 1, rows))
+    assert (img[..., 0] == bits * 255).all()
+    # our own encoder's files decode too (OutputSaver::EncodePng)
+    import tempfile, os
+    with tempfile.TemporaryDirectory() as d:
+        pkg.write_image(os.path.join(d, "x.png"), rgba, pkg.OUTPUT_PNG)
+        img, _ = pkg.decode_image(open(os.path.join(d, "x.png"), "rb").read())
+        assert (img == rgba).all()
+        pkg.write_image(os.path.join(d, "x.tga"), rgba, pkg.OUTPUT_TGA)
+        img, ch = pkg.decode_image(open(os.path.join(d, "x.tga"), "rb").read())
+        assert ch == 4 and (img == rgba).all()
+        f = rng.uniform(0, 50, (9, 12, 4)).astype(np.float32)
+        pkg.write_image(os.path.join(d, "x.hdr"), f, pkg.OUTPUT_HDR)
+        img, ch = pkg.decode_image(open(os.path.join(d, "x.hdr"), "rb").read())
+        assert img.dtype == np.float32 and ch == 3 and np.abs(img[..., :3] - f[..., :3]).max() <= f[..., :3].max() / 100 and (img[..., 3] == 1).all()
+    # errors: truncated stream, interlaced file, garbage
+    good = _png(w, h, 6, 8, [rgba[y].tobytes() for y in range(h)])
+    for bad in (good[:100], good.replace(b"IHDR" + good[16:28] + b"\x00", b"IHDR" + good[16:28] + b"\x01"), b"not an image at all" * 4):
+        with pytest.raises(pkg.PtxError):
+            pkg.decode_image(bad)
+
+
+def test_hdr_rle_and_tga_rle(pkg):
+    w, h = 40, 3
+    rgbe = np.zeros((h, w, 4), np.uint8)
+    rgbe[..., 0] = 128
+    rgbe[..., 1] = np.arange(w)[None, :] * 3
+    rgbe[..., 2] = 7
+    rgbe[..., 3] = 130
+    body = bytearray()
+    for y in range(h):
+        body += bytes([2, 2, w >> 8, w & 255])
+        for c in range(4):
+            line = rgbe[y, :, c]
+            x = 0
+            while x < w:
+                run = 1
+                while x + run < w and run < 127 and line[x + run] == line[x]:
+                    run += 1
+                if run > 2:
+                    body += bytes([128 + run, int(line[x])])
+                    x += run
+                else:
+                    n = min(w - x, 5)
+                    body += bytes([n]) + bytes(line[x:x + n])
+                    x += n
+    data = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w) + bytes(body)
+    img, ch = pkg.decode_image(data)
+    want = rgbe[..., :3].astype(np.float32) * np.float32(2.0 ** (130 - 136))
+    assert img.shape == (h, w, 4) and (img[..., :3] == want).all()
+    # TGA: RLE, bottom-up, 24 bit
+    px = np.zeros((4, 6, 3), np.uint8)
+    px[..., 0] = 10
+    px[..., 1] = np.arange(6)[None, :] * 20
+    px[1] = [1, 2, 3]
+    tga = bytearray(18)
+    tga[2] = 10
+    tga[12:14] = struct.pack("<H", 6)
+    tga[14:16] = struct.pack("<H", 4)
+    tga[16] = 24
+    for y in (3, 2, 1, 0):  # bottom-up
+        if y == 1:
+            tga += bytes([0x80 + 5, 3, 2, 1])
+        else:
+            tga += bytes([5]) + b"".join(bytes([int(p[2]), int(p[1]), int(p[0])]) for p in px[y])
+    img, ch = pkg.decode_image(bytes(tga))
+    assert ch == 3 and (img[..., :3] == px).all() and (img[..., 3] == 255).all()
+
+
+def test_block_compressed_dds(pkg):
+    def header(w, h, fourcc):
+        hd = bytearray(128)
+        hd[0:4] = b"DDS "
+        struct.pack_into("<IIII", hd, 4, 124, 0x1007, h, w)
+        struct.pack_into("<II", hd, 76, 32, 4)
+        hd[84:88] = fourcc
+        return bytes(hd)
+
+    # BC1: c0 > c1 -> 4-colour mode; indices pick the two end points and the two interpolants
+    c0, c1 = 0xF800, 0x001F  # red, blue
+    block = struct.pack("<HHI", c0, c1, 0b11100100_11100100_11100100_11100100)
+    img, ch = pkg.decode_image(header(4, 4, b"DXT1") + block)
+    assert (img[0, 0] == [255, 0, 0, 255]).all() and (img[0, 1] == [0, 0, 255, 255]).all()
+    assert (img[0, 2] == [170, 0, 85, 255]).all() and (img[0, 3] == [85, 0, 170, 255]).all()
+    # c0 <= c1 -> 3 colours + transparent black
+    block = struct.pack("<HHI", c1, c0, 0xFFFFFFFF)
+    img, _ = pkg.decode_image(header(4, 4, b"DXT1") + block)
+    assert (img == 0).all()
+    # BC3: interpolated alpha block + colour block (no punch-through); 5x3 image = partial blocks
+    alpha = bytes([200, 100]) + (0b001_000_001_000_001_000_001_000_001_000_001_000_001_000_001_000).to_bytes(6, "little")
+    color = struct.pack("<HHI", 0x07E0, 0x07E0, 0)
+    img, ch = pkg.decode_image(header(5, 3, b"DXT5") + (alpha + color) * 2)
+    assert img.shape == (3, 5, 4) and ch == 4 and (img[..., 1] == 255).all() and set(np.unique(img[..., 3])) == {100, 200}
+    # BC5: two BC4 channels -> R, G
+    r = bytes([10, 250]) + (0).to_bytes(6, "little")       # a0 <= a1: 6-value mode, index 0 = a0
+    g = bytes([250, 10]) + (0o77777777_77777777 & ((1 << 48) - 1)).to_bytes(6, "little")  # index 7 = last interpolant
+    img, ch = pkg.decode_image(header(4, 4, b"ATI2") + r + g)
+    assert ch == 2 and (img[..., 0] == 10).all() and (img[..., 1] == (1 * 250 + 6 * 10) // 7).all() and (img[..., 2] == 0).all()
+
+
+def _bits(v, n):
+    return [(v >> (n - 1 - i)) & 1 for i in range(n)]
+
+
+def test_baseline_jpeg_dc_only(pkg):
+    """A hand-assembled 4:2:0 baseline JPEG whose blocks carry only DC terms: every 8x8 block decodes to a flat
+    value, chroma is shared by 16x16 pixels, and the JFIF matrix maps it to RGB."""
+    W, H = 32, 16  # 2 MCUs of 16x16
+    # Huffman tables: DC categories 0..8 as 4-bit codes 0000..1000 (code = category); AC: EOB only ('0')
+    dc_bits = [0] * 16
+    dc_bits[3] = 9
+    dc_vals = list(range(9))
+    ac_bits = [0] * 16
+    ac_bits[0] = 1
+    ac_vals = [0x00]
+
+    def seg(marker, body):
+        return bytes([0xFF, marker]) + struct.pack(">H", len(body) + 2) + bytes(body)
+
+    dqt = bytes([0]) + bytes([8] * 64)  # one table, every step 8 -> DC value 8 * coeff, pixel = coeff + 128
+    sof = bytes([8]) + struct.pack(">HH", H, W) + bytes([3, 1, 0x22, 0, 2, 0x11, 0, 3, 0x11, 0])
+    dht = bytes([0x00] + dc_bits + dc_vals + [0x10] + ac_bits + ac_vals)
+    sos = bytes([3, 1, 0x00, 2, 0x00, 3, 0x00, 0, 63, 0])
+    # per MCU: 4 luma blocks, Cb, Cr.  Luma levels (pixel - 128) and chroma offsets:
+    luma = [[-100, -50, 0, 50], [60, 70, 80, 90]]
+    cb, cr = [40, -30], [-20, 64]
+    bits = []
+    pred = [0, 0, 0]
+
+    def put_dc(comp, value):
+        diff = value - pred[comp]
+        pred[comp] = value
+        cat = 0 if diff == 0 else int(abs(diff)).bit_length()
+        bits.extend(_bits(cat, 4))
+        if cat:
+            bits.extend(_bits(diff if diff > 0 else diff + (1 << cat) - 1, cat))
+        bits.append(0)  # EOB
+
+    for m in range(2):
+        for k in range(4):
+            put_dc(0, luma[m][k])
+        put_dc(1, cb[m])
+        put_dc(2, cr[m])
+    while len(bits) % 8:
+        bits.append(1)
+    scan = bytearray()
+    for i in range(0, len(bits), 8):
+        b = int("".join(map(str, bits[i:i + 8])), 2)
+        scan.append(b)
+        if b == 0xFF:
+            scan.append(0)
+    jpg = b"\xff\xd8" + seg(0xE0, b"JFIF\0\1\1\0\0\1\0\1\0\0") + seg(0xDB, dqt) + seg(0xC0, sof) + seg(0xC4, dht) + seg(0xDA, sos) + bytes(scan) + b"\xff\xd9"
+    img, ch = pkg.decode_image(jpg)
+    assert img.shape == (H, W, 4) and ch == 3 and (img[..., 3] == 255).all()
+    for m in range(2):
+        for k in range(4):
+            y0, x0 = (k // 2) * 8, m * 16 + (k % 2) * 8
+            Y, b, r = luma[m][k] + 128, cb[m], cr[m]
+            want = np.clip(np.floor(np.array([Y + 1.402 * r, Y - 0.344136 * b - 0.714136 * r, Y + 1.772 * b]) + 0.5), 0, 255)
+            blk = img[y0:y0 + 8, x0:x0 + 8, :3]
+            assert (blk == blk[0, 0]).all() and np.abs(blk[0, 0].astype(int) - want).max() <= 1, (m, k)
+    # progressive files are refused
+    with pytest.raises(pkg.PtxError):
+        pkg.decode_image(jpg.replace(b"\xff\xc0", b"\xff\xc2"))
