@@ -4,7 +4,7 @@
 // samples, run the post-process chain (postprocess.comp -> bloom -> composition.comp -> toneMapping.comp) and
 // hand the output image to the OutputSaver (PNG / TGA / HDR by file extension).
 //
-//   g++ -std=c++20 -O2 examples/render_scene.cpp path-tracing_amd/host/{Scene,Camera,ExampleScenes,OutputSaver,RendererHip}.cpp \
+//   g++ -std=c++20 -O2 examples/render_scene.cpp path-tracing_amd/host/{Scene,Camera,ExampleScenes,OutputSaver,TextureImporter,JpegDecoder,SceneImporter,RendererHip}.cpp \
 //       -Ipath-tracing_amd/host -Lpath-tracing_amd -lptx_hip -Wl,-rpath,'$ORIGIN/../path-tracing_amd' -o examples/render_scene
 //   examples/render_scene default 640 360 16 4 out.png
 #include <cmath>

@@ -164,8 +164,8 @@ def build(force: bool = False, verbose: bool = True) -> None:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
     host = os.path.join(PKG_DIR, "host")
-    host_src = [os.path.join(host, f) for f in ("Scene.cpp", "Camera.cpp", "ExampleScenes.cpp", "OutputSaver.cpp", "TextureImporter.cpp", "JpegDecoder.cpp", "host_capi.cpp")]
-    host_dep = host_src + [os.path.join(host, f) for f in ("Scene.h", "Camera.h", "ExampleScenes.h", "OutputSaver.h", "TextureImporter.h", "Math.h")] + [
+    host_src = [os.path.join(host, f) for f in ("Scene.cpp", "Camera.cpp", "ExampleScenes.cpp", "OutputSaver.cpp", "TextureImporter.cpp", "JpegDecoder.cpp", "SceneImporter.cpp", "host_capi.cpp")]
+    host_dep = host_src + [os.path.join(host, f) for f in ("Scene.h", "Camera.h", "ExampleScenes.h", "OutputSaver.h", "TextureImporter.h", "SceneImporter.h", "Json.h", "Math.h")] + [
         os.path.join(REPO_DIR, "include", "ptx_host.h"), os.path.join(REPO_DIR, "include", "ptx.h")]
     if force or _newer(HOST_LIB, host_dep):
         cmd = ["g++"] + HOST_FLAGS + ["-o", HOST_LIB] + host_src

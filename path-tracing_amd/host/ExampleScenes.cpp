@@ -10,6 +10,7 @@
 //    assets are downloaded at CMake time by the reference (cmake/DownloadAssets.cmake)
 //    and do not exist offline.
 #include "ExampleScenes.h"
+#include "SceneImporter.h"
 
 #include <array>
 #include <cmath>
@@ -1440,7 +1441,9 @@ std::shared_ptr<Scene> CreateScene(const std::string &name, float detail, uint32
 {
     SceneBuilder sb;
     bool useSceneCamera = true;
-    if (name == "default")
+    if (name.rfind("file:", 0) == 0) // a glTF 2.0 asset through the importer (SceneManager's file scenes, ExampleScenes.cpp:87-236)
+        SceneImporter::AddFile(sb, name.substr(5));
+    else if (name == "default")
     {
         CreateDefaultScene(sb);
         useSceneCamera = false;
