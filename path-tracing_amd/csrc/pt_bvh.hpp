@@ -49,6 +49,7 @@ struct Hit
 {
     float t, u, v;
     uint32_t pair, prim; // pair == 0xffffffff: miss
+    uint32_t slot;       // triangle slot in leaf order (index into tris / shadeTris)
 };
 
 // ---------------------------------------------------------------------------------
@@ -302,6 +303,187 @@ __global__ void k_karras(int n, const uint64_t *__restrict__ keys, int2 *__restr
         parentOfNode[0] = -1;
 }
 
+// ---- PLOC: parallel locally-ordered clustering (Meister & Bittner 2017) ------------------------
+// Alternative to the Karras topology over the same Morton order: clusters (initially the sorted leaves)
+// repeatedly look for the neighbour within +-kPlocRadius positions whose union box has the smallest
+// surface area; mutual nearest neighbours merge into a new internal node, the sequence is compacted, and
+// the loop runs until one cluster is left.  The result is a bottom-up agglomerative tree guided by the
+// surface-area metric instead of by Morton prefixes -- lower SAH cost, i.e. fewer node visits per ray --
+// in the SAME arrays (children / parentOfNode / parentOfLeaf, root = node 0, leaf ref = ~sorted position),
+// so k_refit / k_emit and the refit path are unchanged.  Node ids are handed out downwards from n - 2 by
+// the prefix scan of the merge flags: deterministic, and the last merge (the root) gets id 0.
+constexpr int kPlocRadius = 32; // measured on chess_like: 4 -> 1265, 8 -> 1277, 16 -> 1270, 32 -> 1285, 64 -> 1297, 128 -> 1298 Msamples/s (build 11.7 .. 21 ms)
+
+__global__ void k_ploc_init(uint32_t n, const uint32_t *__restrict__ vals, const float4 *__restrict__ boxLo, const float4 *__restrict__ boxHi,
+                            int *__restrict__ cluster, float4 *__restrict__ cLo, float4 *__restrict__ cHi)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const uint32_t g = vals[i];
+    cluster[i] = ~(int)i;
+    cLo[i] = boxLo[g];
+    cHi[i] = boxHi[g];
+}
+
+// pairs are ordered by (union area, lower position, higher position): a strict total order, so the globally
+// smallest pair is always mutual and every iteration merges at least once
+__global__ void k_ploc_nearest(uint32_t count, uint32_t radius, const float4 *__restrict__ cLo, const float4 *__restrict__ cHi, uint32_t *__restrict__ nn)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count)
+        return;
+    const float4 lo = cLo[i], hi = cHi[i];
+    const uint32_t first = i > radius ? i - radius : 0u;
+    const uint32_t last = i + radius < count ? i + radius : count - 1u;
+    float best = 3.0e38f;
+    uint32_t bestJ = i == first ? last : first, bestA = 0xffffffffu, bestB = 0xffffffffu;
+    for (uint32_t j = first; j <= last; j++)
+    {
+        if (j == i)
+            continue;
+        const float4 l = cLo[j], h = cHi[j];
+        const float dx = fmaxf(hi.x, h.x) - fminf(lo.x, l.x), dy = fmaxf(hi.y, h.y) - fminf(lo.y, l.y), dz = fmaxf(hi.z, h.z) - fminf(lo.z, l.z);
+        const float area = dx * dy + dy * dz + dz * dx;
+        const uint32_t a = i < j ? i : j, b = i < j ? j : i;
+        if (area < best || (area == best && (a < bestA || (a == bestA && b < bestB))) || bestA == 0xffffffffu)
+        {
+            best = area;
+            bestJ = j;
+            bestA = a;
+            bestB = b;
+        }
+    }
+    nn[i] = bestJ;
+}
+
+// flags for the scan: low word = the position survives, high word = it leads a merge
+__global__ void k_ploc_flags(uint32_t count, const uint32_t *__restrict__ nn, unsigned long long *__restrict__ flags)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count)
+        return;
+    const uint32_t j = nn[i];
+    const bool mutual = nn[j] == i;
+    const unsigned long long keep = (mutual && i > j) ? 0ull : 1ull, lead = (mutual && i < j) ? 1ull : 0ull;
+    flags[i] = keep | (lead << 32);
+}
+
+// three-pass exclusive scan of packed (32 + 32 bit) counters: block sums, scan of the sums, apply
+constexpr uint32_t kScanBlock = 1024;
+__global__ void __launch_bounds__(256) k_scan64_sums(uint32_t count, const unsigned long long *__restrict__ data, unsigned long long *__restrict__ sums)
+{
+    __shared__ unsigned long long part[256];
+    const uint32_t base = blockIdx.x * kScanBlock;
+    unsigned long long s = 0;
+    for (uint32_t k = threadIdx.x; k < kScanBlock; k += 256)
+        if (base + k < count)
+            s += data[base + k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t off = 128; off > 0; off >>= 1)
+    {
+        if (threadIdx.x < off)
+            part[threadIdx.x] += part[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        sums[blockIdx.x] = part[0];
+}
+__global__ void __launch_bounds__(1024) k_scan64_top(uint32_t blocks, unsigned long long *__restrict__ sums, unsigned long long *__restrict__ total)
+{
+    __shared__ unsigned long long part[1024];
+    const uint32_t tid = threadIdx.x, per = (blocks + 1023u) / 1024u;
+    const uint32_t begin = tid * per, end = begin + per < blocks ? begin + per : blocks;
+    unsigned long long s = 0;
+    for (uint32_t i = begin; i < end; i++)
+        s += sums[i];
+    part[tid] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1)
+    {
+        const unsigned long long v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    unsigned long long run = tid ? part[tid - 1] : 0;
+    for (uint32_t i = begin; i < end; i++)
+    {
+        const unsigned long long v = sums[i];
+        sums[i] = run;
+        run += v;
+    }
+    if (tid == 1023)
+        *total = part[1023];
+}
+__global__ void __launch_bounds__(256) k_scan64_apply(uint32_t count, unsigned long long *__restrict__ data, const unsigned long long *__restrict__ sums)
+{
+    // one block scans its kScanBlock elements serially per thread-chunk of 4, then adds the block offset
+    __shared__ unsigned long long part[256];
+    const uint32_t base = blockIdx.x * kScanBlock + threadIdx.x * 4;
+    unsigned long long v[4], s = 0;
+    for (int k = 0; k < 4; k++)
+    {
+        v[k] = base + k < count ? data[base + k] : 0ull;
+        s += v[k];
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1)
+    {
+        const unsigned long long t = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    unsigned long long run = sums[blockIdx.x] + (threadIdx.x ? part[threadIdx.x - 1] : 0ull);
+    for (int k = 0; k < 4; k++)
+        if (base + k < count)
+        {
+            data[base + k] = run;
+            run += v[k];
+        }
+}
+
+__global__ void k_ploc_merge(uint32_t count, const int *__restrict__ cluster, const float4 *__restrict__ cLo, const float4 *__restrict__ cHi,
+                             const uint32_t *__restrict__ nn, const unsigned long long *__restrict__ prefix, int firstId,
+                             int *__restrict__ outCluster, float4 *__restrict__ outLo, float4 *__restrict__ outHi, int2 *__restrict__ children,
+                             int *__restrict__ parentOfNode, int *__restrict__ parentOfLeaf, float4 *__restrict__ nodeLo, float4 *__restrict__ nodeHi)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count)
+        return;
+    const uint32_t j = nn[i];
+    const bool mutual = nn[j] == i;
+    if (mutual && i > j)
+        return; // absorbed by its partner
+    const unsigned long long p = prefix[i];
+    const uint32_t dst = (uint32_t)p;
+    if (!mutual)
+    {
+        outCluster[dst] = cluster[i];
+        outLo[dst] = cLo[i];
+        outHi[dst] = cHi[i];
+        return;
+    }
+    const int id = firstId - (int)(p >> 32);
+    const int a = cluster[i], b = cluster[j];
+    children[id] = make_int2(a, b);
+    if (a < 0) parentOfLeaf[~a] = id; else parentOfNode[a] = id;
+    if (b < 0) parentOfLeaf[~b] = id; else parentOfNode[b] = id;
+    const float4 l0 = cLo[i], h0 = cHi[i], l1 = cLo[j], h1 = cHi[j];
+    const float4 lo = make_float4(fminf(l0.x, l1.x), fminf(l0.y, l1.y), fminf(l0.z, l1.z), 0.0f);
+    const float4 hi = make_float4(fmaxf(h0.x, h1.x), fmaxf(h0.y, h1.y), fmaxf(h0.z, h1.z), 0.0f);
+    nodeLo[id] = lo;
+    nodeHi[id] = hi;
+    if (id == 0)
+        parentOfNode[0] = -1;
+    outCluster[dst] = id;
+    outLo[dst] = lo;
+    outHi[dst] = hi;
+}
+
 typedef float v4f_native __attribute__((ext_vector_type(4)));
 PT_DEV float4 loadUncached(const float4 *p) // bypasses the (incoherent) L1 for cross-CU data
 {
@@ -373,14 +555,40 @@ PT_DEV float childArea(const ChildBox &c)
 // contain the child box in REAL arithmetic, whatever rounding the traversal's slab test applies
 PT_DEV double decodeQ(float o, uint32_t q, float scale) { return (double)o + (double)q * (double)scale; }
 
+// the deindexed vertices of one triangle, next to its Tri record (see ShadeTri)
+PT_DEV void writeShadeTri(const Tri &t, const DevPair *pairs, const PtxVertex *vertices, const uint32_t *indices, ShadeTri *out)
+{
+    const DevPair *pr = &pairs[__float_as_uint(t.c.y)];
+    const uint32_t prim = __float_as_uint(t.c.z);
+    float f[44];
+    for (int k = 0; k < 3; k++)
+    {
+        const PtxVertex *v = &vertices[pr->vertexOffset + indices[pr->indexOffset + prim * 3 + k]];
+        float *d = &f[14 * k];
+        d[0] = v->Position[0]; d[1] = v->Position[1]; d[2] = v->Position[2];
+        d[3] = v->TexCoords[0]; d[4] = v->TexCoords[1];
+        d[5] = v->Normal[0]; d[6] = v->Normal[1]; d[7] = v->Normal[2];
+        d[8] = v->Tangent[0]; d[9] = v->Tangent[1]; d[10] = v->Tangent[2];
+        d[11] = v->Bitangent[0]; d[12] = v->Bitangent[1]; d[13] = v->Bitangent[2];
+    }
+    f[42] = f[43] = 0.0f;
+    for (int k = 0; k < 11; k++)
+        out->v[k] = make_float4(f[4 * k], f[4 * k + 1], f[4 * k + 2], f[4 * k + 3]);
+}
+
 __global__ void k_emit(int n, const uint32_t *__restrict__ vals, const float4 *__restrict__ boxLo,
                        const float4 *__restrict__ boxHi, const int2 *__restrict__ children, const float4 *__restrict__ nodeLo,
                        const float4 *__restrict__ nodeHi, const Tri *__restrict__ triTmp, BvhNode *__restrict__ nodes,
-                       Tri *__restrict__ tris)
+                       Tri *__restrict__ tris, const DevPair *__restrict__ pairs, const PtxVertex *__restrict__ vertices,
+                       const uint32_t *__restrict__ indices, ShadeTri *__restrict__ shadeTris)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n)
-        tris[i] = triTmp[vals[i]];
+    {
+        const Tri t = triTmp[vals[i]];
+        tris[i] = t;
+        writeShadeTri(t, pairs, vertices, indices, &shadeTris[i]);
+    }
     if (i >= n - 1)
         return;
     ChildBox c[4];
@@ -476,8 +684,10 @@ __global__ void k_emit(int n, const uint32_t *__restrict__ vals, const float4 *_
 }
 
 // a one-triangle scene has no internal node: give it a root with one leaf child
-__global__ void k_single_leaf_root(const float4 *boxLo, const float4 *boxHi, const Tri *triTmp, BvhNode *nodes, Tri *tris)
+__global__ void k_single_leaf_root(const float4 *boxLo, const float4 *boxHi, const Tri *triTmp, BvhNode *nodes, Tri *tris, const DevPair *pairs,
+                                   const PtxVertex *vertices, const uint32_t *indices, ShadeTri *shadeTris)
 {
+    writeShadeTri(triTmp[0], pairs, vertices, indices, &shadeTris[0]);
     tris[0] = triTmp[0];
     BvhNode nd;
     // origin below the box, scale covering it: child 0 spans the whole quantised range
@@ -522,9 +732,9 @@ struct TraceScene
 //   closest rays  anyhit.rahit:36-64: alpha < 0.5 -> remembered as the decal if it is the nearest so far, ignored
 //   shadow rays   occlusionAnyhit.rahit:35-53: alpha < 1 -> ignored
 template <bool ANY_HIT>
-PT_DEV bool anyHitKeeps(const TraceScene &sc, uint32_t pair, uint32_t prim, float t, float u, float v, Decal &decal)
+PT_DEV bool anyHitKeeps(const TraceScene &sc, uint32_t pair, uint32_t prim, uint32_t slot, float t, float u, float v, Decal &decal)
 {
-    const f4 color = hitBaseColor(sc.sv, pair, prim, u, v);
+    const f4 color = hitBaseColor(sc.sv, pair, slot, u, v);
     if (ANY_HIT)
         return !(color.w < 1.0f);
     if (color.w < 0.5f)
@@ -703,6 +913,7 @@ PT_DEV bool traceRay(const TraceScene &sc, f3 o, f3 d, float tmin, float tmax, S
     best.u = best.v = 0.0f;
     best.pair = 0xffffffffu;
     best.prim = 0xffffffffu;
+    best.slot = 0u;
     if (sc.triCount == 0 || !rayIsTraceable(o, d, tmin, tmax))
         return false;
     const f3 id = fastInverse(d);
@@ -734,18 +945,20 @@ PT_DEV bool traceRay(const TraceScene &sc, f3 o, f3 d, float tmin, float tmax, S
         {
             if (STATS)
                 (*triTests)++;
+            const int leafRef = ref;
             const Tri *tp = &sc.tris[~ref];
             const float4 ta = tp->a, tb = tp->b, tc = tp->c;
             float t, u, v;
             if (intersectTri(F3(ta.x, ta.y, ta.z), F3(ta.w, tb.x, tb.y), F3(tb.z, tb.w, tc.x), o, d, tmin, tmax, t, u, v) &&
                 (!ALPHA || __float_as_uint(tc.w) == 0u ||
-                 anyHitKeeps<ANY_HIT>(sc, __float_as_uint(tc.y), __float_as_uint(tc.z), t, u, v, decal)))
+                 anyHitKeeps<ANY_HIT>(sc, __float_as_uint(tc.y), __float_as_uint(tc.z), (uint32_t)~leafRef, t, u, v, decal)))
             {
                 const uint32_t pair = __float_as_uint(tc.y), prim = __float_as_uint(tc.z);
                 if (ANY_HIT)
                 {
                     best.pair = pair;
                     best.prim = prim;
+                    best.slot = (uint32_t)~leafRef;
                     return true;
                 }
                 if (t < best.t || (t == best.t && (pair < best.pair || (pair == best.pair && prim < best.prim))))
@@ -755,6 +968,7 @@ PT_DEV bool traceRay(const TraceScene &sc, f3 o, f3 d, float tmin, float tmax, S
                     best.v = v;
                     best.pair = pair;
                     best.prim = prim;
+                    best.slot = (uint32_t)~leafRef;
                 }
             }
             if (st.sp == 0)
@@ -803,7 +1017,7 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
     f3 o = F3s(0.0f), d = F3s(0.0f), id = F3s(0.0f);
     float tmin = 0.0f, tmax = 0.0f;
     Hit best;
-    best.t = 0.0f; best.u = best.v = 0.0f; best.pair = best.prim = 0xffffffffu;
+    best.t = 0.0f; best.u = best.v = 0.0f; best.pair = best.prim = 0xffffffffu; best.slot = 0u;
     int ref = kRefDone;
     st.sp = 0;
     st.overflow = false;
@@ -872,19 +1086,21 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
         // ---- leaf phase (single-triangle leaves: ref = ~slot)
         if (have && ref < 0)
         {
+            const int leafRef = ref;
             const Tri *tp = &sc.tris[~ref];
             const float4 ta = tp->a, tb = tp->b, tc = tp->c;
             float t, u, v;
             ref = st.sp ? (int)st.pop() : kRefDone;
             if (intersectTri(F3(ta.x, ta.y, ta.z), F3(ta.w, tb.x, tb.y), F3(tb.z, tb.w, tc.x), o, d, tmin, tmax, t, u, v) &&
                 (!ALPHA || __float_as_uint(tc.w) == 0u ||
-                 anyHitKeeps<ANY_HIT>(sc, __float_as_uint(tc.y), __float_as_uint(tc.z), t, u, v, decal)))
+                 anyHitKeeps<ANY_HIT>(sc, __float_as_uint(tc.y), __float_as_uint(tc.z), (uint32_t)~leafRef, t, u, v, decal)))
             {
                 const uint32_t pair = __float_as_uint(tc.y), prim = __float_as_uint(tc.z);
                 if (ANY_HIT)
                 {
                     best.pair = pair;
                     best.prim = prim;
+                    best.slot = (uint32_t)~leafRef;
                     ref = kRefDone;
                 }
                 else if (t < best.t || (t == best.t && (pair < best.pair || (pair == best.pair && prim < best.prim))))
@@ -894,6 +1110,7 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
                     best.v = v;
                     best.pair = pair;
                     best.prim = prim;
+                    best.slot = (uint32_t)~leafRef;
                 }
             }
         }

@@ -980,8 +980,19 @@ PT_DEV f4 sampleTexture(const TextureView &tv, uint32_t idx, f2 uv, f4 dv)
 PT_DEV f3 rgb(f4 t) { return F3(t.x, t.y, t.z); }
 PT_DEV f3 ld3(const float *p) { return F3(p[0], p[1], p[2]); }
 
+// The three vertices of one triangle, deindexed and stored in BVH leaf order beside the traversal's Tri record:
+// the closest-hit stage reads ONE contiguous, 16-byte aligned 176-byte record per hit instead of chasing
+// hit -> pair -> 3 indices -> 3 scattered 56-byte vertices (three dependent gathers at 2 waves / SIMD).
+// Vertex k occupies floats [14 k, 14 k + 14) in PtxVertex order; the last two floats are padding.
+struct ShadeTri
+{
+    float4 v[11];
+};
+static_assert(sizeof(ShadeTri) == 176, "ShadeTri is 176 B");
+
 struct SceneView // read-only device views of the uploaded scene
 {
+    const ShadeTri *shadeTris; // [triangle slot in leaf order]
     const PtxVertex *vertices;
     const uint32_t *indices;
     const PtxMetallicRoughnessMaterial *mr;
@@ -1027,15 +1038,16 @@ PT_DEV Decal noDecal()
 // anyhit.rahit:38-52 / occlusionAnyhit.rahit:37-50: texture(textures[colorIdx], uv) * colorFactor at a
 // candidate hit (getColorTextureIdx / getColorFactor, material.glsl:25-54).  texture() in a ray-tracing
 // stage has no implicit derivatives: base level.
-PT_DEV f4 hitBaseColor(const SceneView &sv, uint32_t pairIdx, uint32_t prim, float u, float v)
+PT_DEV f4 hitBaseColor(const SceneView &sv, uint32_t pairIdx, uint32_t slot, float u, float v)
 {
     const DevPair *pr = &sv.pairs[pairIdx];
     const f3 bary = F3(1.0f - u - v, u, v);
-    const uint32_t *ix = sv.indices + pr->indexOffset + prim * 3;
-    const PtxVertex *vb = sv.vertices + pr->vertexOffset;
-    const PtxVertex *a = vb + ix[0], *b = vb + ix[1], *c = vb + ix[2];
-    const float tu = (a->TexCoords[0] * bary.x + b->TexCoords[0] * bary.y) + c->TexCoords[0] * bary.z;
-    const float tv = (a->TexCoords[1] * bary.x + b->TexCoords[1] * bary.y) + c->TexCoords[1] * bary.z;
+    // texture coordinates of the three vertices: floats 3..4, 17..18, 31..32 of the record
+    const ShadeTri *st = &sv.shadeTris[slot];
+    const float4 q0 = st->v[0], q1 = st->v[1], q4 = st->v[4], q7 = st->v[7], q8 = st->v[8];
+    const float u0 = q0.w, v0 = q1.x, u1 = q4.y, v1 = q4.z, u2 = q7.w, v2 = q8.x;
+    const float tu = (u0 * bary.x + u1 * bary.y) + u2 * bary.z;
+    const float tv = (v0 * bary.x + v1 * bary.y) + v2 * bary.z;
     const uint32_t materialType = pr->materialId & 0xffu, materialIndex = pr->materialId >> 8;
     uint32_t idx = 0;
     f4 factor;
@@ -1253,6 +1265,33 @@ PT_DEV Vtx loadVertex(const PtxVertex *p) // common.glsl:27-46
     return v;
 }
 
+struct TriVertices // the vertices of the hit triangle as common.glsl:27-46 would fetch them
+{
+    Vtx o[3];
+    f2 uv[3];
+};
+
+PT_DEV TriVertices loadTriangle(const ShadeTri *st)
+{
+    float f[44];
+    for (int k = 0; k < 11; k++)
+    {
+        const float4 q = st->v[k];
+        f[4 * k] = q.x; f[4 * k + 1] = q.y; f[4 * k + 2] = q.z; f[4 * k + 3] = q.w;
+    }
+    TriVertices t;
+    for (int k = 0; k < 3; k++)
+    {
+        const float *p = &f[14 * k];
+        t.o[k].Position = F3(p[0], p[1], p[2]);
+        t.uv[k] = F2(p[3], p[4]);
+        t.o[k].Normal = F3(p[5], p[6], p[7]);
+        t.o[k].Tangent = F3(p[8], p[9], p[10]);
+        t.o[k].Bitangent = F3(p[11], p[12], p[13]);
+    }
+    return t;
+}
+
 PT_DEV f3 interp3(f3 a, f3 b, f3 c, f3 bc) { return (a * bc.x + b * bc.y) + c * bc.z; } // common.glsl:107-110
 
 // What closestHit.rchit writes into the payload (ShaderRendererTypes.incl:101-118); the ray
@@ -1273,15 +1312,14 @@ struct HitOut
 
 // closestHit.rchit:52-161.  (u, v) = hitAttributeEXT barycentrics, t = gl_RayTmaxEXT.
 template <bool TEX>
-PT_DEV void closestHit(const SceneView &sv, f3 rayDirW, float t, float hu, float hv, uint32_t pairIdx, uint32_t prim,
+PT_DEV void closestHit(const SceneView &sv, f3 rayDirW, float t, float hu, float hv, uint32_t pairIdx, uint32_t slot,
                        float maxRoughnessIn, uint32_t &rngState, HitOut &out, DiffRays &diff, float decalDist = -1.0f,
                        f3 decalColor = F3s(0.0f), float decalAlpha = 0.0f)
 {
     const f3 bary = F3(1.0f - hu - hv, hu, hv);
     const DevPair pr = sv.pairs[pairIdx];
-    const uint32_t *ix = sv.indices + pr.indexOffset + prim * 3;
-    const PtxVertex *vb = sv.vertices + pr.vertexOffset;
-    const Vtx o0 = loadVertex(vb + ix[0]), o1 = loadVertex(vb + ix[1]), o2 = loadVertex(vb + ix[2]);
+    const TriVertices tv3 = loadTriangle(&sv.shadeTris[slot]);
+    const Vtx o0 = tv3.o[0], o1 = tv3.o[1], o2 = tv3.o[2];
 
     Vtx ov; // getInterpolatedVertex, common.glsl:112-130
     ov.Position = interp3(o0.Position, o1.Position, o2.Position, bary);
@@ -1312,8 +1350,7 @@ PT_DEV void closestHit(const SceneView &sv, f3 rayDirW, float t, float hu, float
     f3 dndu = F3s(0.0f), dndv = F3s(0.0f);
     if (TEX)
     {
-        const f2 uv0 = F2(vb[ix[0]].TexCoords[0], vb[ix[0]].TexCoords[1]), uv1 = F2(vb[ix[1]].TexCoords[0], vb[ix[1]].TexCoords[1]),
-                 uv2 = F2(vb[ix[2]].TexCoords[0], vb[ix[2]].TexCoords[1]);
+        const f2 uv0 = tv3.uv[0], uv1 = tv3.uv[1], uv2 = tv3.uv[2];
         texCoords = F2((uv0.x * bary.x + uv1.x * bary.y) + uv2.x * bary.z, (uv0.y * bary.x + uv1.y * bary.y) + uv2.y * bary.z);
         const f3 P3[3] = { v0.Position, v1.Position, v2.Position }, N3[3] = { v0.Normal, v1.Normal, v2.Normal };
         const f2 UV3[3] = { uv0, uv1, uv2 };

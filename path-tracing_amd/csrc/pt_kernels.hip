@@ -45,7 +45,7 @@ struct Wavefront // device pointers of the per-slot state (SoA)
     float4 *thr;    // throughput.rgb
     float4 *rad;    // radiance.rgb accumulated over the samples of this launch
     uint4 *meta;    // x = rngState, y = pixel (y*W+x) or 0xffffffff, z = bounce | smpl<<16, w = frame
-    float4 *hit;    // t, u, v, prim (bits)
+    float4 *hit;    // t, u, v, triangle slot in leaf order (bits)
     uint32_t *hitPair;
     float4 *shO;    // shadow origin.xyz, w = tmax (LightDistance)
     float4 *shD;    // shadow direction.xyz, w = 1 if the path ends after this bounce
@@ -257,7 +257,7 @@ struct ClosestIO
     }
     PT_DEV void store(uint32_t, const Hit &h, bool, const Decal &dc)
     {
-        wf.hit[slot] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
+        wf.hit[slot] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot)); // w = triangle slot in leaf order
         wf.hitPair[slot] = h.pair;
         if (wf.decalT)
         {
@@ -568,7 +568,7 @@ PT_DEV f3 runPath(const LaunchParams &p, const SceneView &sv, const TraceScene &
                 break;
             }
             HitOut out;
-            closestHit<TEX>(sv, rd, h.t, h.u, h.v, h.pair, h.prim, maxRoughness, rng, out, diff, decal.dist, decal.color, decal.alpha);
+            closestHit<TEX>(sv, rd, h.t, h.u, h.v, h.pair, h.slot, maxRoughness, rng, out, diff, decal.dist, decal.color, decal.alpha);
             pc.nHit++;
             maxRoughness = out.MaxRoughness;
             radiance = radiance + throughput * out.Emissive;
@@ -1157,6 +1157,8 @@ struct PtxRenderer
         }
     } build;
     bool anyNonOpaque = false;  // some instanced geometry lacks the opaque flag: any-hit stages run
+    bool usePloc = true;        // PLOC topology instead of Karras (PTX_BUILDER=lbvh switches back)
+    uint32_t plocRadius = kPlocRadius;
     DevBuf<float4> decal;
     DevBuf<float> decalT;
     size_t decalCapacity = 0;
@@ -1166,6 +1168,7 @@ struct PtxRenderer
     // accel
     DevBuf<BvhNode> nodes;
     DevBuf<Tri> tris;
+    DevBuf<ShadeTri> shadeTris; // deindexed vertices per triangle slot (leaf order), written by k_emit
 
     // frame
     uint32_t width = 0, height = 0;
@@ -1311,6 +1314,10 @@ int ptx_create(const PtxDeviceDesc *desc, PtxRenderer **out)
         }
         r->ownStream = true;
     }
+    if (const char *e = getenv("PTX_BUILDER"))
+        r->usePloc = std::strcmp(e, "lbvh") != 0;
+    if (const char *e = getenv("PTX_PLOC_RADIUS"))
+        r->plocRadius = std::max(1u, (uint32_t)strtoul(e, nullptr, 10));
     (void)hipEventCreate(&r->evA);
     (void)hipEventCreate(&r->evB);
     (void)hipEventCreate(&r->evT0);
@@ -1346,7 +1353,7 @@ void ptx_destroy(PtxRenderer *r)
         (void)hipStreamSynchronize(r->stream);
     r->textures.release(); r->texels8.release(); r->texelsF.release(); r->srgbLut.release();
     r->vertices.release(); r->indices.release(); r->mr.release(); r->sg.release(); r->phong.release();
-    r->pairs.release(); r->pairFirst.release(); r->lights.release(); r->nodes.release(); r->tris.release();
+    r->pairs.release(); r->pairFirst.release(); r->lights.release(); r->nodes.release(); r->tris.release(); r->shadeTris.release();
     r->image.release(); r->rayO.release(); r->rayD.release(); r->thr.release(); r->rad.release(); r->hit.release();
     r->shO.release(); r->shD.release(); r->shC.release(); r->slotRad.release(); r->diffs.release(); r->diffCapacity = 0; r->decal.release(); r->decalT.release(); r->decalCapacity = 0; r->meta.release(); r->hitPair.release();
     r->queue0.release(); r->queue1.release(); r->shadowQueue.release(); r->counters.release(); r->spill.release(); r->spillAux.release(); r->restartQueue.release();
@@ -1678,6 +1685,7 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
     {
         HIP_TRY(r, r->nodes.alloc(n > 1 ? n - 1 : 1));
         HIP_TRY(r, r->tris.alloc(n ? n : 1));
+        HIP_TRY(r, r->shadeTris.alloc(n ? n : 1));
     }
     if (n == 0)
     {
@@ -1731,15 +1739,66 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
         }
     }
     if (n == 1)
-        k_single_leaf_root<<<1, 1, 0, r->stream>>>(B.boxLo.p, B.boxHi.p, B.triTmp.p, r->nodes.p, r->tris.p);
+        k_single_leaf_root<<<1, 1, 0, r->stream>>>(B.boxLo.p, B.boxHi.p, B.triTmp.p, r->nodes.p, r->tris.p, r->pairs.p, r->vertices.p, r->indices.p,
+                                                   r->shadeTris.p);
     else
     {
-        if (!refit)
+        bool boxesDone = false;
+        if (!refit && r->usePloc)
+        {
+            // PLOC over the sorted leaves; temporaries: two cluster sequences, neighbour indices, scan flags
+            DevBuf<int> cl0, cl1;
+            DevBuf<float4> lo0, hi0, lo1, hi1;
+            DevBuf<uint32_t> nn;
+            DevBuf<unsigned long long> flags, sums, total;
+            const uint32_t scanBlocks = (n + kScanBlock - 1) / kScanBlock;
+            BUILD_TRY(cl0.alloc(n)); BUILD_TRY(cl1.alloc(n)); BUILD_TRY(lo0.alloc(n)); BUILD_TRY(hi0.alloc(n)); BUILD_TRY(lo1.alloc(n));
+            BUILD_TRY(hi1.alloc(n)); BUILD_TRY(nn.alloc(n)); BUILD_TRY(flags.alloc(n)); BUILD_TRY(sums.alloc(scanBlocks)); BUILD_TRY(total.alloc(1));
+            k_ploc_init<<<blocks, 256, 0, r->stream>>>(n, vin, B.boxLo.p, B.boxHi.p, cl0.p, lo0.p, hi0.p);
+            int *cIn = cl0.p, *cOut = cl1.p;
+            float4 *lIn = lo0.p, *hIn = hi0.p, *lOut = lo1.p, *hOut = hi1.p;
+            uint32_t count = n;
+            int nextId = (int)n - 2;
+            uint32_t iterations = 0;
+            while (count > 1)
+            {
+                const uint32_t cb = (count + 255) / 256, sb = (count + kScanBlock - 1) / kScanBlock;
+                k_ploc_nearest<<<cb, 256, 0, r->stream>>>(count, r->plocRadius, lIn, hIn, nn.p);
+                k_ploc_flags<<<cb, 256, 0, r->stream>>>(count, nn.p, flags.p);
+                k_scan64_sums<<<sb, 256, 0, r->stream>>>(count, flags.p, sums.p);
+                k_scan64_top<<<1, 1024, 0, r->stream>>>(sb, sums.p, total.p);
+                k_scan64_apply<<<sb, 256, 0, r->stream>>>(count, flags.p, sums.p);
+                k_ploc_merge<<<cb, 256, 0, r->stream>>>(count, cIn, lIn, hIn, nn.p, flags.p, nextId, cOut, lOut, hOut, B.children.p, B.parentOfNode.p,
+                                                        B.parentOfLeaf.p, B.nodeLo.p, B.nodeHi.p);
+                unsigned long long t = 0;
+                BUILD_TRY(hipMemcpyAsync(&t, total.p, sizeof(t), hipMemcpyDeviceToHost, r->stream));
+                BUILD_TRY(hipStreamSynchronize(r->stream));
+                const uint32_t kept = (uint32_t)t, merged = (uint32_t)(t >> 32);
+                if (merged == 0 || kept + merged != count)
+                {
+                    B.release();
+                    return fail(r, PTX_ERROR_DEVICE, "ptx_build_accel: PLOC made no progress (%u clusters, %u kept, %u merged)", count, kept, merged);
+                }
+                nextId -= (int)merged;
+                count = kept;
+                std::swap(cIn, cOut);
+                std::swap(lIn, lOut);
+                std::swap(hIn, hOut);
+                iterations++;
+            }
+            if (getenv("PTX_VERBOSE"))
+                std::fprintf(stderr, "[ptx] PLOC: %u triangles, %u iterations\n", n, iterations);
+            boxesDone = true;
+            cl0.release(); cl1.release(); lo0.release(); hi0.release(); lo1.release(); hi1.release(); nn.release(); flags.release(); sums.release();
+            total.release();
+        }
+        else if (!refit)
             k_karras<<<blocks, 256, 0, r->stream>>>((int)n, kin, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p);
-        k_refit<<<blocks, 256, 0, r->stream>>>((int)n, vin, B.boxLo.p, B.boxHi.p, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p,
+        if (!boxesDone)
+            k_refit<<<blocks, 256, 0, r->stream>>>((int)n, vin, B.boxLo.p, B.boxHi.p, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p,
                                                B.nodeLo.p, B.nodeHi.p, B.flags.p);
         k_emit<<<blocks, 256, 0, r->stream>>>((int)n, vin, B.boxLo.p, B.boxHi.p, B.children.p, B.nodeLo.p, B.nodeHi.p, B.triTmp.p,
-                                              r->nodes.p, r->tris.p);
+                                              r->nodes.p, r->tris.p, r->pairs.p, r->vertices.p, r->indices.p, r->shadeTris.p);
     }
     BUILD_TRY(hipEventRecord(r->evB, r->stream));
     BUILD_TRY(hipStreamSynchronize(r->stream));
@@ -1842,6 +1901,7 @@ static int kernelMode(const PtxRenderer *r)
 static SceneView makeSceneView(const PtxRenderer *r)
 {
     SceneView sv;
+    sv.shadeTris = r->shadeTris.p;
     sv.vertices = r->vertices.p; sv.indices = r->indices.p; sv.mr = r->mr.p; sv.sg = r->sg.p; sv.phong = r->phong.p;
     sv.pairs = r->pairs.p; sv.lights = r->lights.p; sv.dxNormalTextures = r->dxNormalTextures;
     sv.tex.textures = r->textures.p; sv.tex.textureCount = r->textureCount; sv.tex.texels8 = r->texels8.p; sv.tex.texelsF = r->texelsF.p;
