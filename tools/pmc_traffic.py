@@ -25,7 +25,7 @@ def load(d):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for f in files:
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0]
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]  # template variants of one kernel merge
             agg[k][0] += 1
             agg[k][1] += float(r["Counter_Value"])
     return agg
