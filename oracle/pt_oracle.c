@@ -1415,16 +1415,14 @@ static v4 sampleLevel(const PtoScene *s, const OTexture *t, uint32_t level, floa
     return v4_lerp(top, bot, ay);
 }
 
-/* textureGrad: LOD from the gradients (Vulkan 1.3 spec 16.5.7, isotropic), trilinear */
-static v4 textureGradSample(const PtoScene *s, const OTexture *t, float u, float v, float dudx, float dvdx, float dudy, float dvdy)
+/* textureGrad with the reference's sampler (trilinear, anisotropy enabled at the device maximum, Renderer.cpp:103-110).
+ * Anisotropic filtering is implementation-defined; this follows the scheme of the Vulkan / EXT_texture_filter_anisotropic
+ * specifications: rho_x, rho_y = lengths of the two gradients in texels, eta = min(rho_max / rho_min, 16), N = ceil(eta)
+ * trilinear taps at LOD log2(rho_max / eta), spaced along the longer gradient at (i / (N + 1) - 1/2), averaged.  With N = 1
+ * this is the isotropic lookup. */
+#define PTO_MAX_ANISOTROPY 16.0f
+static v4 trilinearSample(const PtoScene *s, const OTexture *t, float lod, float u, float v)
 {
-    if (t->levels <= 1)
-        return sampleLevel(s, t, 0, u, v);
-    const float mux = dudx * (float)t->width, mvx = dvdx * (float)t->height;
-    const float muy = dudy * (float)t->width, mvy = dvdy * (float)t->height;
-    const float rx = sqrtf(mux * mux + mvx * mvx), ry = sqrtf(muy * muy + mvy * mvy);
-    const float rho = f_max(rx, ry);
-    float lod = rho > 0.0f ? (float)pto_log2((double)rho) : 0.0f;
     const float q = (float)(t->levels - 1);
     if (!(lod >= 0.0f)) lod = 0.0f;
     if (lod > q) lod = q;
@@ -1434,6 +1432,36 @@ static v4 textureGradSample(const PtoScene *s, const OTexture *t, float u, float
     if (f == 0.0f || l1 == l0)
         return c0;
     return v4_lerp(c0, sampleLevel(s, t, l1, u, v), f);
+}
+
+static v4 textureGradSample(const PtoScene *s, const OTexture *t, float u, float v, float dudx, float dvdx, float dudy, float dvdy)
+{
+    if (t->levels <= 1)
+        return sampleLevel(s, t, 0, u, v);
+    const float mux = dudx * (float)t->width, mvx = dvdx * (float)t->height;
+    const float muy = dudy * (float)t->width, mvy = dvdy * (float)t->height;
+    const float rx = sqrtf(mux * mux + mvx * mvx), ry = sqrtf(muy * muy + mvy * mvy);
+    const float rmax = f_max(rx, ry), rmin = f_min(rx, ry);
+    float eta = 1.0f;
+    if (rmax > 0.0f && rmax < 3.0e38f) /* finite footprint: otherwise a single tap */
+        eta = rmin > 0.0f ? f_min(rmax / rmin, PTO_MAX_ANISOTROPY) : PTO_MAX_ANISOTROPY;
+    if (!(eta >= 1.0f)) eta = 1.0f;
+    const float n = ceilf(eta);
+    const float rho = rmax / eta;
+    const float lod = rho > 0.0f ? (float)pto_log2((double)rho) : 0.0f;
+    if (n <= 1.0f || lod >= (float)(t->levels - 1)) /* every tap would read the 1x1 top level: one tap */
+        return trilinearSample(s, t, lod, u, v);
+    const float du = rx >= ry ? dudx : dudy, dv = rx >= ry ? dvdx : dvdy;
+    v4 sum = { 0.0f, 0.0f, 0.0f, 0.0f };
+    const int taps = (int)n;
+    for (int i = 1; i <= taps; i++)
+    {
+        const float w = (float)i / (n + 1.0f) - 0.5f;
+        const v4 c = trilinearSample(s, t, lod, u + du * w, v + dv * w);
+        sum.x += c.x; sum.y += c.y; sum.z += c.z; sum.w += c.w;
+    }
+    sum.x /= n; sum.y /= n; sum.z /= n; sum.w /= n;
+    return sum;
 }
 
 /* mip chain: each level is a linear blit of the previous one (Image.cpp:264-300): decode,

@@ -920,16 +920,14 @@ PT_DEV f4 sampleLevel(const TextureView &tv, const DevTexture &t, uint32_t level
     return lerp4(top, bot, ay);
 }
 
-// textureGrad: LOD from the gradients (Vulkan 1.3 spec 16.5.7, isotropic), trilinear
-PT_DEV f4 textureGradSample(const TextureView &tv, const DevTexture &t, float u, float v, float dudx, float dvdx, float dudy, float dvdy)
+// textureGrad with the reference's sampler (trilinear, anisotropy at the device maximum, Renderer.cpp:103-110), by the
+// scheme of the Vulkan / EXT_texture_filter_anisotropic specifications: eta = min(rho_max / rho_min, 16), N = ceil(eta)
+// trilinear taps at LOD log2(rho_max / eta) along the longer gradient at (i / (N + 1) - 1/2), averaged; N = 1 is the
+// isotropic lookup.
+constexpr float kMaxAnisotropy = 16.0f;
+
+PT_DEV f4 trilinearSample(const TextureView &tv, const DevTexture &t, float lod, float u, float v)
 {
-    if (t.levels <= 1)
-        return sampleLevel(tv, t, 0, u, v);
-    const float mux = dudx * (float)t.width, mvx = dvdx * (float)t.height;
-    const float muy = dudy * (float)t.width, mvy = dvdy * (float)t.height;
-    const float rx = sqrt_(mux * mux + mvx * mvx), ry = sqrt_(muy * muy + mvy * mvy);
-    const float rho = fmax_(rx, ry);
-    float lod = rho > 0.0f ? (float)log2_((double)rho) : 0.0f;
     const float q = (float)(t.levels - 1);
     if (!(lod >= 0.0f)) lod = 0.0f;
     if (lod > q) lod = q;
@@ -939,6 +937,37 @@ PT_DEV f4 textureGradSample(const TextureView &tv, const DevTexture &t, float u,
     if (f == 0.0f || l1 == l0)
         return c0;
     return lerp4(c0, sampleLevel(tv, t, l1, u, v), f);
+}
+
+PT_DEV f4 textureGradSample(const TextureView &tv, const DevTexture &t, float u, float v, float dudx, float dvdx, float dudy, float dvdy)
+{
+    if (t.levels <= 1)
+        return sampleLevel(tv, t, 0, u, v);
+    const float mux = dudx * (float)t.width, mvx = dvdx * (float)t.height;
+    const float muy = dudy * (float)t.width, mvy = dvdy * (float)t.height;
+    const float rx = sqrt_(mux * mux + mvx * mvx), ry = sqrt_(muy * muy + mvy * mvy);
+    const float rmax = fmax_(rx, ry), rmin = fmin_(rx, ry);
+    float eta = 1.0f;
+    if (rmax > 0.0f && rmax < 3.0e38f) // finite footprint: otherwise a single tap
+        eta = rmin > 0.0f ? fmin_(rmax / rmin, kMaxAnisotropy) : kMaxAnisotropy;
+    if (!(eta >= 1.0f)) eta = 1.0f;
+    const float n = __builtin_ceilf(eta);
+    const float rho = rmax / eta;
+    const float lod = rho > 0.0f ? (float)log2_((double)rho) : 0.0f;
+    if (n <= 1.0f || lod >= (float)(t.levels - 1)) // every tap would read the 1x1 top level: one tap
+        return trilinearSample(tv, t, lod, u, v);
+    const float du = rx >= ry ? dudx : dudy, dv = rx >= ry ? dvdx : dvdy;
+    f4 sum;
+    sum.x = sum.y = sum.z = sum.w = 0.0f;
+    const int taps = (int)n;
+    for (int i = 1; i <= taps; i++)
+    {
+        const float w = (float)i / (n + 1.0f) - 0.5f;
+        const f4 c = trilinearSample(tv, t, lod, u + du * w, v + dv * w);
+        sum.x += c.x; sum.y += c.y; sum.z += c.z; sum.w += c.w;
+    }
+    sum.x /= n; sum.y /= n; sum.z /= n; sum.w /= n;
+    return sum;
 }
 
 // ---- material.glsl with the fixed 1x1 default textures ------------------------------------------

@@ -74,6 +74,18 @@ def test_oracle_sampler_properties(pkg, orc):
     assert c[0] <= c[1] <= c[2] <= c[3] + 1e-6  # texel (0,0) is the dark colour: blends towards the mean
     bad = osc.test_texture(_inputs(CHECKER, u, u, dudx=np.nan, dvdy=np.inf)).view(np.float32)
     assert np.isfinite(bad).all()
+    # anisotropy (the reference's sampler enables it at the device maximum): a footprint 1 texel wide and 8 long is the
+    # average of N = 8 trilinear taps at LOD log2(8 / 8) = 0, spaced along the long gradient at i / (N + 1) - 1/2
+    uu, vv = np.float32([0.3, 0.61, 0.87]), np.float32([0.2, 0.45, 0.7])
+    for idx, (tw, th) in ((CHECKER, (64, 64)), (NOISE, (37, 21))):
+        thin = osc.test_texture(_inputs(idx, uu, vv, dudx=1.0 / tw, dvdy=8.0 / th)).view(np.float32)
+        taps = [osc.test_texture(_inputs(idx, uu, vv + np.float32(8.0 / th) * np.float32(i / 9.0 - 0.5))).view(np.float32) for i in range(1, 9)]
+        assert np.abs(thin - np.mean(taps, axis=0)).max() < 2e-6
+    # ... which keeps the resolution across the short side where an isotropic 8 x 8 footprint does not
+    u2 = np.float32(np.arange(40) / 40.0)
+    thin = osc.test_texture(_inputs(NOISE, u2, np.full_like(u2, 0.5), dudx=1.0 / 37, dvdy=8.0 / 21)).view(np.float32)
+    wide = osc.test_texture(_inputs(NOISE, u2, np.full_like(u2, 0.5), dudx=8.0 / 37, dvdy=8.0 / 21)).view(np.float32)
+    assert thin[:, 0].std() > 1.5 * wide[:, 0].std()
     # the float texture passes through untouched at texel centres
     r = osc.test_texture(_inputs(RAMP, np.float32([(3 + 0.5) / 16]), np.float32([(2 + 0.5) / 4]))).view(np.float32)[0]
     assert np.allclose(r, [0.05 + 0.06 * 3, 0.2 + 0.2 * 2, 0.9 - 0.05 * 3, 1.0], atol=1e-6)
