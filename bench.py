@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --single-device lets the N > 1 code path be exercised on a 1-GPU box (testing only)")
     ap.add_argument("--single-device", action="store_true", help="testing only: every rank uses cuda:0")
+    ap.add_argument("--emulate-shard", default=None, metavar="R/N",
+                    help="experiments only: one process renders the tile shard of rank R of N (no gather) to see what a rank of an "
+                         "N-GPU run costs; the printed line is marked and is not a benchmark result")
     ap.add_argument("--traffic-json", default=None,
                     help="per-kernel HBM bytes per launch from tools/pmc_traffic.py (default: newest profiles/r*_traffic.json)")
     args = ap.parse_args()
@@ -137,7 +140,8 @@ def main():
     r.synchronize()
     upload_build_s = time.time() - t0
     r.resize(W, H)
-    r.set_tile_shard(rank, world, args.tile)
+    emu_rank, emu_world = (int(x) for x in args.emulate_shard.split("/")) if args.emulate_shard else (rank, world)
+    r.set_tile_shard(emu_rank, emu_world, args.tile)
     u = scene.uniform(W, H, bounces=args.depth)
     build_ms = r.stats().lastBuildMs
     n_tris = scene.triangle_count
@@ -224,6 +228,10 @@ def main():
         }
         if checksum is not None:
             out["config"]["frame_checksum"] = checksum
+        if args.emulate_shard:
+            out["emulated_shard"] = args.emulate_shard
+            out["value"] = value / emu_world  # samples of this shard only
+            out["config"]["parallelism"] = f"EMULATION of rank {emu_rank} of {emu_world} (tile shard, no gather)"
         if args.backend == "wavefront" and trace_ms > 0:
             bpr = algorithmic_bytes_per_closest_ray(n_tris)
             achieved = closest_rays * bpr / (trace_ms * 1e-3) / 1e9
