@@ -50,8 +50,8 @@ PTX_API int pth_scene_animation_state(PthScene *s, PtxTransform *instanceTransfo
  * otherwise bytes must be width * height * (isFloat ? 16 : 4). */
 PTX_API int pth_decode_image(const void *file, size_t fileBytes, uint32_t info[4], void *pixels, size_t bytes);
 
-/* Output stage (row N4): OutputSaver::WriteImage (OutputSaver.cpp:227-257) for one image.  format: 0 Png, 1 Jpg
- * (not implemented: returns 1), 2 Tga, 3 Hdr.  data: RGBA8 (Png / Tga) or RGBA32F (Hdr), top row first. */
+/* Output stage (row N4): OutputSaver::WriteImage (OutputSaver.cpp:227-257) for one image.  format: 0 Png, 1 Jpg,
+ * 2 Tga, 3 Hdr.  data: RGBA8 (Png / Jpg / Tga) or RGBA32F (Hdr), top row first. */
 PTX_API int pth_write_image(const char *path, uint32_t format, uint32_t width, uint32_t height, const void *data, size_t bytes);
 /* checkpoint / resume of the running sum: { magic, width, height, totalSamples } + W*H*4 floats */
 PTX_API int pth_save_checkpoint(const char *path, uint32_t width, uint32_t height, uint32_t totalSamples, const float *rgba);

@@ -1,7 +1,9 @@
 // JpegDecoder.cpp -- TextureImporter::DecodeJpeg: baseline / extended sequential Huffman JPEG (ITU T.81),
-// 8-bit samples, 1 or 3 components, arbitrary sampling factors, restart intervals.  Chroma is upsampled by
-// replication and converted with the JFIF YCbCr matrix.  Progressive and arithmetic-coded files are rejected
+// 8-bit samples, 1 or 3 components, arbitrary sampling factors, restart intervals.  Chroma subsampled 2:1 in either
+// direction is upsampled with the triangle filter stb_image and libjpeg use (3/4 near + 1/4 far per axis), other factors
+// by replication; colour conversion is the JFIF YCbCr matrix.  Progressive and arithmetic-coded files are rejected
 // (the importer then falls back to the slot's default texture, as the reference does for any load failure).
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -321,6 +323,46 @@ DecodedImage TextureImporter::DecodeJpeg(std::span<const uint8_t> f)
     img.Height = static_cast<uint32_t>(height);
     img.Channels = static_cast<uint32_t>(ncomp);
     img.Pixels.resize(static_cast<size_t>(width) * height * 4);
+    // full-resolution planes: 2:1 triangle-filter upsampling per axis where the component is subsampled by two
+    std::vector<std::vector<uint8_t>> full(static_cast<size_t>(ncomp));
+    for (int i = 0; i < ncomp; i++)
+    {
+        const int sw = comp[i].bw * 8, sh = comp[i].bh * 8; // stored plane
+        const int cw = (width * comp[i].h + hmax - 1) / hmax, chh = (height * comp[i].v + vmax - 1) / vmax; // meaningful part
+        const bool h2 = hmax == 2 * comp[i].h, v2 = vmax == 2 * comp[i].v;
+        std::vector<uint8_t> &dst = full[static_cast<size_t>(i)];
+        dst.resize(static_cast<size_t>(width) * height);
+        if ((hmax == comp[i].h || h2) && (vmax == comp[i].v || v2) && (h2 || v2))
+        {
+            std::vector<int> row(static_cast<size_t>(cw));
+            for (int y = 0; y < height; y++)
+            {
+                // vertical: 3 * near + far (or 4 * the row when the axis is not subsampled)
+                const int sy = v2 ? y / 2 : y;
+                const int far = v2 ? std::clamp(sy + ((y & 1) ? 1 : -1), 0, chh - 1) : sy;
+                const uint8_t *pn = &comp[i].plane[static_cast<size_t>(std::min(sy, chh - 1)) * sw], *pf = &comp[i].plane[static_cast<size_t>(far) * sw];
+                for (int x = 0; x < cw; x++)
+                    row[static_cast<size_t>(x)] = v2 ? 3 * pn[x] + pf[x] : 4 * pn[x];
+                for (int x = 0; x < width; x++)
+                {
+                    int v16;
+                    if (h2)
+                    {
+                        const int sx = std::min(x / 2, cw - 1), fx = std::clamp(sx + ((x & 1) ? 1 : -1), 0, cw - 1);
+                        v16 = 3 * row[static_cast<size_t>(sx)] + row[static_cast<size_t>(fx)]; // / 16
+                    }
+                    else
+                        v16 = 4 * row[static_cast<size_t>(std::min(x, cw - 1))];
+                    dst[static_cast<size_t>(y) * width + x] = static_cast<uint8_t>((v16 + 8) >> 4);
+                }
+            }
+            (void)sh;
+        }
+        else
+            for (int y = 0; y < height; y++)
+                for (int x = 0; x < width; x++)
+                    dst[static_cast<size_t>(y) * width + x] = comp[i].plane[static_cast<size_t>(y * comp[i].v / vmax) * sw + x * comp[i].h / hmax];
+    }
     const bool ycc = ncomp == 3 && !(adobe && adobeTransform == 0);
     for (int y = 0; y < height; y++)
         for (int x = 0; x < width; x++)
@@ -328,10 +370,7 @@ DecodedImage TextureImporter::DecodeJpeg(std::span<const uint8_t> f)
             uint8_t *o = &img.Pixels[(static_cast<size_t>(y) * width + x) * 4];
             int v[3] = { 0, 128, 128 };
             for (int i = 0; i < ncomp; i++)
-            {
-                const int sx = x * comp[i].h / hmax, sy = y * comp[i].v / vmax;
-                v[i] = comp[i].plane[static_cast<size_t>(sy) * comp[i].bw * 8 + sx];
-            }
+                v[i] = full[static_cast<size_t>(i)][static_cast<size_t>(y) * width + x];
             if (ncomp == 1)
                 o[0] = o[1] = o[2] = static_cast<uint8_t>(v[0]);
             else if (ycc)

@@ -4,8 +4,8 @@
 // (RegisterOutput / StartOutputWait / EndOutput / CancelOutput, OutputSaver.cpp:64-225) and hands the
 // bytes to stb_image_write or pipes them to an ffmpeg child (WriteImage, :227-257).  Here the GPU side is
 // ptx_postprocess + ptx_read_output; this class keeps the same call sequence and the same formats, with
-// the encoders written out (no stb): PNG (zlib stream, fixed-Huffman deflate + LZ77), TGA, Radiance HDR,
-// and the raw-RGBA pipe to `ffmpeg` for MP4.  JPG is not implemented (WriteImage returns false).
+// the encoders written out (no stb): PNG (zlib stream, fixed-Huffman deflate + LZ77), baseline JPEG (quality 90,
+// 4:2:0, per-image optimal Huffman tables), TGA, Radiance HDR, and the raw-RGBA pipe to `ffmpeg` for MP4.
 //
 // Also: checkpoint / resume of the running sum -- a raw dump with a 32-byte header.
 #pragma once
@@ -61,12 +61,13 @@ public:
     void EndOutput();
     void CancelOutput();
 
-    // one image to one file (Png / Tga: RGBA8, Hdr: RGBA32F), top row first
+    // one image to one file (Png / Jpg / Tga: RGBA8, Hdr: RGBA32F), top row first
     static bool WriteImage(const OutputInfo &info, std::span<const std::byte> data, FILE *videoPipe = nullptr);
 
     // encoders, exposed for tests
     static std::vector<uint8_t> EncodePng(uint32_t width, uint32_t height, const uint8_t *rgba);
     static std::vector<uint8_t> EncodeTga(uint32_t width, uint32_t height, const uint8_t *rgba);
+    static std::vector<uint8_t> EncodeJpg(uint32_t width, uint32_t height, const uint8_t *rgba, int quality = 90); // stb's default quality
     static std::vector<uint8_t> EncodeHdr(uint32_t width, uint32_t height, const float *rgba);
 
 private:

@@ -189,8 +189,8 @@ def _bits(v, n):
 
 
 def test_baseline_jpeg_dc_only(pkg):
-    """A hand-assembled 4:2:0 baseline JPEG whose blocks carry only DC terms: every 8x8 block decodes to a flat
-    value, chroma is shared by 16x16 pixels, and the JFIF matrix maps it to RGB."""
+    """A hand-assembled 4:2:0 baseline JPEG whose blocks carry only DC terms: every 8x8 luma block decodes to a flat
+    value, one chroma sample covers 16x16 pixels, and the JFIF matrix maps it to RGB."""
     W, H = 32, 16  # 2 MCUs of 16x16
     # Huffman tables: DC categories 0..8 as 4-bit codes 0000..1000 (code = category); AC: EOB only ('0')
     dc_bits = [0] * 16
@@ -243,8 +243,75 @@ def test_baseline_jpeg_dc_only(pkg):
             y0, x0 = (k // 2) * 8, m * 16 + (k % 2) * 8
             Y, b, r = luma[m][k] + 128, cb[m], cr[m]
             want = np.clip(np.floor(np.array([Y + 1.402 * r, Y - 0.344136 * b - 0.714136 * r, Y + 1.772 * b]) + 0.5), 0, 255)
-            blk = img[y0:y0 + 8, x0:x0 + 8, :3]
+            blk = img[y0 + 2:y0 + 6, x0 + 2:x0 + 6, :3]  # the interior: chroma is interpolated across the MCU boundary
             assert (blk == blk[0, 0]).all() and np.abs(blk[0, 0].astype(int) - want).max() <= 1, (m, k)
+    # restart intervals: the same scan cut after every MCU
+    # (covered end to end by the encoder round trip in tests/test_output.py for AC coefficients and real images)
     # progressive files are refused
     with pytest.raises(pkg.PtxError):
         pkg.decode_image(jpg.replace(b"\xff\xc0", b"\xff\xc2"))
+
+
+def test_against_pillow(pkg, tmp_path):
+    """Independent encoders / decoders where the image has Pillow: its files through our decoders, our files through its."""
+    Image = pytest.importorskip("PIL.Image")
+    import io
+
+    rng = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:83, 0:125]
+    pic = np.zeros((83, 125, 3), np.uint8)
+    pic[..., 0] = (xx * 2) % 256
+    pic[..., 1] = (yy * 3) % 256
+    pic[..., 2] = ((xx // 9 + yy // 7) % 2) * 200 + rng.integers(0, 30, xx.shape)
+    im = Image.fromarray(pic)
+
+    def save(image, fmt, **kw):
+        b = io.BytesIO()
+        image.save(b, fmt, **kw)
+        return b.getvalue()
+
+    # JPEG written by libjpeg: 4:2:0, 4:4:4, 4:2:2, greyscale, optimised tables, restart markers
+    for kw in ({"quality": 85, "subsampling": 2}, {"quality": 95, "subsampling": 0}, {"quality": 75, "subsampling": 1, "optimize": True},
+               {"quality": 90, "subsampling": 2, "restart_marker_blocks": 3}):
+        data = save(im, "JPEG", **kw)
+        ours, ch = pkg.decode_image(data)
+        theirs = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+        assert ch == 3 and ours.shape[:2] == theirs.shape[:2]
+        diff = np.abs(ours[..., :3].astype(int) - theirs.astype(int))
+        # same bit stream; libjpeg's integer IDCT and its smooth ("fancy") chroma upsampling differ from ours in rounding
+        assert np.mean(diff) < 2.5 and np.percentile(diff, 99) <= 24, (kw, float(np.mean(diff)), int(diff.max()))
+    grey = save(im.convert("L"), "JPEG", quality=90)
+    ours, ch = pkg.decode_image(grey)
+    assert ch == 1 and np.abs(ours[..., 0].astype(int) - np.asarray(Image.open(io.BytesIO(grey))).astype(int)).max() <= 2
+    with pytest.raises(pkg.PtxError):
+        pkg.decode_image(save(im, "JPEG", progressive=True))
+    # PNG written by libpng / zlib: RGB, RGBA, palette, grey + alpha, 16-bit grey
+    rgba = np.dstack([pic, rng.integers(0, 256, xx.shape, dtype=np.uint8)])
+    for image, expect_ch in ((im, 3), (Image.fromarray(rgba), 4), (im.convert("P", palette=Image.ADAPTIVE, colors=64), 3),
+                             (Image.fromarray(rgba).convert("LA"), 2)):
+        data = save(image, "PNG", optimize=True)
+        ours, ch = pkg.decode_image(data)
+        assert ch == expect_ch and (ours == np.asarray(image.convert("RGBA"))).all()
+    g16 = Image.fromarray((xx * 500 + yy).astype(np.uint16))
+    ours, ch = pkg.decode_image(save(g16, "PNG"))
+    assert ch == 1 and (ours[..., 0] == (np.asarray(g16) >> 8)).all()
+    # TGA with RLE
+    data = save(Image.fromarray(rgba), "TGA", compression="tga_rle")
+    ours, ch = pkg.decode_image(data)
+    assert ch == 4 and (ours == rgba).all()
+    # and the other way round: Pillow reads what OutputSaver writes
+    pkg.write_image(tmp_path / "o.png", rgba, pkg.OUTPUT_PNG)
+    assert (np.asarray(Image.open(tmp_path / "o.png")) == rgba).all()
+    pkg.write_image(tmp_path / "o.tga", rgba, pkg.OUTPUT_TGA)
+    assert (np.asarray(Image.open(tmp_path / "o.tga")) == rgba).all()
+    pkg.write_image(tmp_path / "o.jpg", rgba, pkg.OUTPUT_JPG)
+    back = np.asarray(Image.open(tmp_path / "o.jpg").convert("RGB")).astype(np.float64)
+    mine, _ = pkg.decode_image((tmp_path / "o.jpg").read_bytes())
+    assert np.abs(back - mine[..., :3]).mean() < 1.0  # both decoders read the same picture out of our file
+    ref = np.asarray(Image.open(io.BytesIO(save(im, "JPEG", quality=90, subsampling=2)))).astype(np.float64)
+    ours_err, libjpeg_err = np.mean((back - pic) ** 2), np.mean((ref - pic) ** 2)
+    assert ours_err < 1.25 * libjpeg_err  # as faithful as libjpeg at the same quality / subsampling (4:2:0 costs this busy image a lot)
+    f = rng.uniform(0, 20, (9, 12, 4)).astype(np.float32)
+    pkg.write_image(tmp_path / "o.hdr", f, pkg.OUTPUT_HDR)
+    ours, _ = pkg.decode_image((tmp_path / "o.hdr").read_bytes())
+    assert np.abs(ours[..., :3] - f[..., :3]).max() <= f[..., :3].max() / 100

@@ -105,8 +105,26 @@ def test_image_writers_round_trip(pkg, tmp_path):
     rgbe = np.frombuffer(body, np.uint8).reshape(9, 11, 4).astype(np.float32)
     dec = rgbe[..., :3] * (2.0 ** (rgbe[..., 3:] - 136))
     assert (dec[0, 0] == 0).all() and np.abs(dec - f[..., :3]).max() <= f[..., :3].max() / 128
-    with pytest.raises(pkg.PtxError):
-        pkg.write_image(tmp_path / "a.jpg", img, pkg.OUTPUT_JPG)
+    # JPEG: lossy -- a smooth image with an edge comes back within a few levels (quality 90, 4:2:0), a noise image decodes
+    # to the right size; the file is baseline (SOF0) with its own Huffman tables
+    yy, xx = np.mgrid[0:70, 0:93]
+    pic = np.zeros((70, 93, 4), np.uint8)
+    pic[..., 0] = 40 + xx * 2
+    pic[..., 1] = 200 - yy * 2
+    pic[..., 2] = np.where(xx > 45, 220, 30)
+    pic[..., 3] = 255
+    j = tmp_path / "a.jpg"
+    pkg.write_image(j, pic, pkg.OUTPUT_JPG)
+    raw = j.read_bytes()
+    assert raw[:2] == b"\xff\xd8" and raw[-2:] == b"\xff\xd9" and b"\xff\xc0" in raw and raw.count(b"\xff\xc4") >= 4
+    dec, ch = pkg.decode_image(raw)
+    err = dec[..., :3].astype(np.float64) - pic[..., :3]
+    psnr = 10 * np.log10(255.0 ** 2 / np.mean(err ** 2))
+    assert dec.shape == pic.shape and ch == 3 and psnr > 32, psnr
+    assert len(raw) < pic.nbytes // 6
+    pkg.write_image(j, img, pkg.OUTPUT_JPG)
+    dec, _ = pkg.decode_image(j.read_bytes())
+    assert dec.shape == img.shape
     # checkpoint
     acc = rng.uniform(0, 5, (12, 7, 4)).astype(np.float32)
     c = tmp_path / "sum.ptxacc"
