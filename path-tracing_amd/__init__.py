@@ -26,7 +26,7 @@ import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
-HIP_LIB = os.path.join(PKG_DIR, "libptx_hip.so")
+HIP_LIB = os.environ.get("PTX_HIP_LIB") or os.path.join(PKG_DIR, "libptx_hip.so")  # PTX_HIP_LIB: an experimental build of the same ABI
 HOST_LIB = os.path.join(PKG_DIR, "libptx_host.so")
 
 HIPCC_FLAGS = [
