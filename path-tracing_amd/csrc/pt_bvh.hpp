@@ -1012,6 +1012,18 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
     const uint64_t below = (1ull << lane) - 1ull;
     uint32_t cursor = 0, end = 0; // wave-uniform
     bool exhausted = false;       // wave-uniform
+    // Chunk schedule.  Same-address atomics serialise at ~11 ns on MI355X, so a 16.6 M-ray launch (130 K chunks)
+    // would spend 1.4 ms of L2 time on the chunk counter alone.  Most chunks are therefore dealt statically --
+    // round r of wave w is chunk w + r * W for the first staticRounds rounds -- and only the last eighth of the
+    // queue is handed out through the atomic counter, which keeps the load balance of the dynamic scheme.
+    const uint32_t waves = gridDim.x * (blockDim.x >> 6), waveId = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t totalChunks = (count + kTraceChunk - 1) / kTraceChunk;
+#ifndef PT_STATIC_SHARE_NUM
+#define PT_STATIC_SHARE_NUM 7
+#define PT_STATIC_SHARE_DEN 8
+#endif
+    const uint32_t staticRounds = (uint32_t)(((uint64_t)totalChunks * PT_STATIC_SHARE_NUM / PT_STATIC_SHARE_DEN) / waves);
+    uint32_t round = 0;
     bool have = false;
     uint32_t item = 0;
     f3 o = F3s(0.0f), d = F3s(0.0f), id = F3s(0.0f);
@@ -1031,9 +1043,14 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
             if (cursor == end && !exhausted)
             {
                 uint32_t c = 0;
-                if (lane == 0)
-                    c = atomicAdd(chunkCounter, kTraceChunk);
-                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+                if (round < staticRounds)
+                    c = (waveId + round++ * waves) * kTraceChunk;
+                else
+                {
+                    if (lane == 0)
+                        c = atomicAdd(chunkCounter, kTraceChunk);
+                    c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c) + staticRounds * waves * kTraceChunk;
+                }
                 if (c >= count)
                     exhausted = true;
                 else

@@ -61,20 +61,25 @@ struct Wavefront // device pointers of the per-slot state (SoA)
     uint32_t *spill;    // traversal stack overflow region [kGlobalSpill][kMaxPersistentThreads]
 };
 
+// Every counter sits on its own 128-byte line: atomics to one L2 line serialise (~11 ns each on MI355X) whatever
+// word they touch, and the queue, chunk and statistics counters are all hot in the same kernels.
+constexpr int kCounterStride = 32; // uint32 words
 enum Counter
 {
-    C_ACTIVE0 = 0,
-    C_ACTIVE1 = 1,
-    C_SHADOW = 2,
-    C_HITS = 3,      // closest-hit shader invocations (= occlusion queries of the reference)
-    C_SAMPLES = 4,   // completed pixel-samples incl. retries
-    C_RETRIES = 5,
-    C_SEGMENTS = 6,  // megakernel only
-    C_OVERFLOW = 7,
-    C_CHUNK = 8, // +0 closest, +1 shadow: next unclaimed queue entry of the persistent traversal kernels
-    C_RESTART = 10, // slots re-queued by k_trace_shadow (new sample / NaN restart), drained after the bounce loop
-    C_COUNT = 12
+    C_ACTIVE0 = 0 * kCounterStride,
+    C_ACTIVE1 = 1 * kCounterStride,
+    C_SHADOW = 2 * kCounterStride,
+    C_HITS = 3 * kCounterStride,      // closest-hit shader invocations (= occlusion queries of the reference)
+    C_SAMPLES = 4 * kCounterStride,   // completed pixel-samples incl. retries
+    C_RETRIES = 5 * kCounterStride,
+    C_SEGMENTS = 6 * kCounterStride,  // megakernel only
+    C_OVERFLOW = 7 * kCounterStride,
+    C_CHUNK = 8 * kCounterStride,        // next unclaimed queue entry of k_trace_closest
+    C_CHUNK_SHADOW = 9 * kCounterStride, // ... of k_trace_shadow
+    C_RESTART = 10 * kCounterStride, // slots re-queued by k_trace_shadow (new sample / NaN restart), drained after the bounce loop
+    C_COUNT = 12 * kCounterStride
 };
+PT_DEV int queueCounter(int q) { return q ? (int)C_ACTIVE1 : (int)C_ACTIVE0; }
 
 struct LaunchParams
 {
@@ -201,6 +206,24 @@ PT_DEV void waveAddCounter(uint32_t *__restrict__ counter, uint32_t v)
         atomicAdd(counter, v);
 }
 
+// the same per block (all threads of the block must call it): one global atomic per block instead of per wave
+PT_DEV void blockAddCounter(uint32_t *__restrict__ counter, uint32_t v)
+{
+    __shared__ uint32_t s_sum;
+    if (threadIdx.x == 0)
+        s_sum = 0;
+    __syncthreads();
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_down(v, off);
+    if ((threadIdx.x & 63u) == 0 && v)
+        atomicAdd(&s_sum, v);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_sum)
+        atomicAdd(counter, s_sum);
+    __syncthreads();
+}
+
+constexpr uint32_t kShadeItems = 4; // queue entries per thread per block-wide append in k_shade
 constexpr uint32_t kDeadPair = 0xfffffffeu; // hitPair of a slot outside the image (ragged edge tiles)
 
 // No queue atomics here: queue 0 is the identity over all slots (the host sets its count);
@@ -313,11 +336,19 @@ __global__ void __launch_bounds__(kBlock) k_shade(LaunchParams p, SceneView sv, 
 {
     __shared__ uint32_t s_cnt[2], s_base[2];
     const int qout = qin ^ 1;
-    const uint32_t count = wf.counters[qin];
+    const uint32_t count = wf.counters[queueCounter(qin)];
     uint32_t nHits = 0, nSamples = 0, nRetries = 0;
-    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x)
+    // kShadeItems queue entries per thread between two block-wide appends: the appends cost one global atomic per
+    // block and queue, and same-address atomics serialise at ~11 ns -- at one entry per thread the 65 K blocks x 2
+    // queues of a 16.6 M-slot launch would keep the counter line busy for 1.4 ms of a 2 ms kernel.
+    for (uint32_t base = blockIdx.x * blockDim.x * kShadeItems; base < count; base += gridDim.x * blockDim.x * kShadeItems)
     {
-        const uint32_t i = base + threadIdx.x;
+      uint32_t slots[kShadeItems];
+      uint32_t pushBits = 0; // bit 2k: entry k joins the shadow queue, bit 2k+1: the next queue
+#pragma nounroll
+      for (uint32_t item = 0; item < kShadeItems; item++)
+      {
+        const uint32_t i = base + item * blockDim.x + threadIdx.x;
         bool pushNext = false, pushShadow = false;
         uint32_t slot = 0, pair = kDeadPair;
         if (i < count)
@@ -415,34 +446,48 @@ __global__ void __launch_bounds__(kBlock) k_shade(LaunchParams p, SceneView sv, 
         }
         // queue appends with ONE global atomic per block and queue: same-address atomics
         // serialise at ~11 ns each on MI355X, so per-wave appends would cost more than the shading
+        for (uint32_t k = 0; k < kShadeItems; k++) // no dynamic register indexing
+            if (k == item)
+                slots[k] = slot;
+        pushBits |= (pushShadow ? 1u : 0u) << (2 * item) | (pushNext ? 2u : 0u) << (2 * item);
+      }
+        // queue appends with ONE global atomic per block and queue for all kShadeItems x 256 entries
         if (threadIdx.x < 2)
             s_cnt[threadIdx.x] = 0;
         __syncthreads();
         const uint32_t lane = threadIdx.x & 63u;
-        const uint64_t maskS = __ballot(pushShadow), maskN = __ballot(pushNext);
-        uint32_t waveS = 0, waveN = 0;
-        if (lane == 0)
+        uint32_t waveS[kShadeItems], waveN[kShadeItems];
+        for (uint32_t k = 0; k < kShadeItems; k++)
         {
-            if (maskS)
-                waveS = atomicAdd(&s_cnt[0], (uint32_t)__popcll(maskS));
-            if (maskN)
-                waveN = atomicAdd(&s_cnt[1], (uint32_t)__popcll(maskN));
+            const uint64_t maskS = __ballot((pushBits >> (2 * k)) & 1u), maskN = __ballot((pushBits >> (2 * k)) & 2u);
+            uint32_t ws = 0, wn = 0;
+            if (lane == 0)
+            {
+                if (maskS)
+                    ws = atomicAdd(&s_cnt[0], (uint32_t)__popcll(maskS));
+                if (maskN)
+                    wn = atomicAdd(&s_cnt[1], (uint32_t)__popcll(maskN));
+            }
+            waveS[k] = __shfl(ws, 0);
+            waveN[k] = __shfl(wn, 0);
         }
-        waveS = __shfl(waveS, 0);
-        waveN = __shfl(waveN, 0);
         __syncthreads();
         if (threadIdx.x < 2 && s_cnt[threadIdx.x])
-            s_base[threadIdx.x] = atomicAdd(&wf.counters[threadIdx.x == 0 ? (int)C_SHADOW : qout], s_cnt[threadIdx.x]);
+            s_base[threadIdx.x] = atomicAdd(&wf.counters[threadIdx.x == 0 ? (int)C_SHADOW : queueCounter(qout)], s_cnt[threadIdx.x]);
         __syncthreads();
         const uint64_t below = (1ull << lane) - 1ull;
-        if (pushShadow)
-            wf.shadowQueue[s_base[0] + waveS + (uint32_t)__popcll(maskS & below)] = slot;
-        if (pushNext)
-            wf.queue[qout][s_base[1] + waveN + (uint32_t)__popcll(maskN & below)] = slot;
+        for (uint32_t k = 0; k < kShadeItems; k++)
+        {
+            const uint64_t maskS = __ballot((pushBits >> (2 * k)) & 1u), maskN = __ballot((pushBits >> (2 * k)) & 2u);
+            if ((pushBits >> (2 * k)) & 1u)
+                wf.shadowQueue[s_base[0] + waveS[k] + (uint32_t)__popcll(maskS & below)] = slots[k];
+            if ((pushBits >> (2 * k)) & 2u)
+                wf.queue[qout][s_base[1] + waveN[k] + (uint32_t)__popcll(maskN & below)] = slots[k];
+        }
     }
-    waveAddCounter(&wf.counters[C_HITS], nHits);
-    waveAddCounter(&wf.counters[C_SAMPLES], nSamples);
-    waveAddCounter(&wf.counters[C_RETRIES], nRetries);
+    blockAddCounter(&wf.counters[C_HITS], nHits);
+    blockAddCounter(&wf.counters[C_SAMPLES], nSamples);
+    blockAddCounter(&wf.counters[C_RETRIES], nRetries);
 }
 
 struct ShadowIO
@@ -494,7 +539,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_shadow(LaunchParams p, TraceSc
 {
     PT_DECLARE_STACK(st, kLdsStack, wf.spill)
     ShadowIO io = { p, wf, qout, 0u, 0.0f, 0u, 0u };
-    persistentTrace<true, ALPHA>(sc, io, count, &wf.counters[C_CHUNK + 1], st);
+    persistentTrace<true, ALPHA>(sc, io, count, &wf.counters[C_CHUNK_SHADOW], st);
     if (st.overflow)
         atomicAdd(&wf.counters[C_OVERFLOW], 1u);
     waveAddCounter(&wf.counters[C_SAMPLES], io.nSamples);
@@ -2124,7 +2169,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
             return fail(r, PTX_ERROR_DEVICE, "ptx_render: %u paths still active after %llu bounce iterations", bt.active,
                         (unsigned long long)maxIterations);
         const int qout = bt.qin ^ 1;
-        HIP_TRY(r, hipMemsetAsync(&q.dCounters[qout], 0, sizeof(uint32_t), q.s));
+        HIP_TRY(r, hipMemsetAsync(&q.dCounters[qout ? C_ACTIVE1 : C_ACTIVE0], 0, sizeof(uint32_t), q.s));
         HIP_TRY(r, hipMemsetAsync(&q.dCounters[C_SHADOW], 0, sizeof(uint32_t), q.s));
         HIP_TRY(r, hipMemsetAsync(&q.dCounters[C_CHUNK], 0, sizeof(uint32_t), q.s));
         HIP_TRY(r, hipEventRecord(q.evT0, q.s));
@@ -2136,9 +2181,9 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
         if (bt.shadowPending) // k_shade reads rad[slot]: the previous bounce's shadow adds must have landed
             HIP_TRY(r, hipStreamWaitEvent(q.s, q.evShadow[bt.shadowSlot], 0));
         if (textured)
-            k_shade<true><<<gridFor(bt.active), kBlock, 0, q.s>>>(bt.p, sv, bt.wf, bt.qin);
+            k_shade<true><<<gridFor((bt.active + kShadeItems - 1) / kShadeItems), kBlock, 0, q.s>>>(bt.p, sv, bt.wf, bt.qin);
         else
-            k_shade<false><<<gridFor(bt.active), kBlock, 0, q.s>>>(bt.p, sv, bt.wf, bt.qin);
+            k_shade<false><<<gridFor((bt.active + kShadeItems - 1) / kShadeItems), kBlock, 0, q.s>>>(bt.p, sv, bt.wf, bt.qin);
         HIP_TRY(r, hipEventRecord(q.evT2, q.s));
         HIP_TRY(r, hipEventRecord(q.evShade, q.s));
         HIP_TRY(r, hipMemcpyAsync(q.hCounters, q.dCounters, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, q.s));
@@ -2205,7 +2250,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
             {
                 bt.shadowSlot ^= 1;
                 HIP_TRY(r, hipStreamWaitEvent(q.x, q.evShade, 0));
-                HIP_TRY(r, hipMemsetAsync(&q.dCounters[C_CHUNK + 1], 0, sizeof(uint32_t), q.x));
+                HIP_TRY(r, hipMemsetAsync(&q.dCounters[C_CHUNK_SHADOW], 0, sizeof(uint32_t), q.x));
                 HIP_TRY(r, hipEventRecord(q.evX0[bt.shadowSlot], q.x));
                 if (alpha)
                     k_trace_shadow<true><<<traceGridFor(shadowCount), kBlock, 0, q.x>>>(bt.p, sc, bt.wfAux, qout, shadowCount);
@@ -2219,7 +2264,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
                         (unsigned long long)bt.iteration, bt.active, closestMs, bt.active / closestMs / 1e6, ms, shadowCount);
             bt.segments += bt.iteration == 1 ? (uint64_t)bt.p.ownedPixels * bt.p.frames : bt.active;
             bt.launches += 2;
-            bt.active = q.hCounters[qout];
+            bt.active = q.hCounters[qout ? C_ACTIVE1 : C_ACTIVE0];
             bt.qin = qout;
             return next(bt);
         }
