@@ -1004,6 +1004,10 @@ constexpr uint32_t kTraceChunk = PT_TRACE_CHUNK;
 constexpr int kNodeStepsPerRound = PT_NODE_STEPS;
 constexpr int kRefDone = 0x7fffffff;
 
+#ifdef PT_VISIT_STATS
+__device__ uint32_t g_visitStats[2][68]; // [closest | shadow][max, sum lo, rays, -, histogram of visits / 16]
+#endif
+
 template <bool ANY_HIT, bool ALPHA, typename IO>
 PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32_t *__restrict__ chunkCounter, Stack &st)
 {
@@ -1033,6 +1037,9 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
     int ref = kRefDone;
     st.sp = 0;
     st.overflow = false;
+#ifdef PT_VISIT_STATS
+    uint32_t visits = 0;
+#endif
 
     for (;;)
     {
@@ -1097,6 +1104,9 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
                 if (h > 2) st.push((uint32_t)r2);
                 if (h > 1) st.push((uint32_t)r1);
                 ref = h > 0 ? r0 : (st.sp ? (int)st.pop() : kRefDone);
+#ifdef PT_VISIT_STATS
+                visits++;
+#endif
             }
         }
 
@@ -1137,6 +1147,13 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
         {
             io.store(item, best, best.pair != 0xffffffffu, decal);
             have = false;
+#ifdef PT_VISIT_STATS
+            atomicMax(&g_visitStats[ANY_HIT][0], visits);
+            atomicAdd(&g_visitStats[ANY_HIT][1], visits);
+            atomicAdd(&g_visitStats[ANY_HIT][2], 1u);
+            atomicAdd(&g_visitStats[ANY_HIT][4 + (visits / 16 < 63 ? visits / 16 : 63)], 1u);
+            visits = 0;
+#endif
         }
     }
 }

@@ -291,14 +291,32 @@ struct ClosestIO
     }
 };
 
+// The traversal kernels are latency-bound: throughput follows the number of resident waves.  The opaque variants fit
+// the 64-VGPR budget of 8 waves per SIMD without spilling when asked to (74 -> 63 registers: closest 6.2 -> 4.6 ms per
+// chess_like step); the ALPHA closest variant carries the sampler and the decal and stops at 6 waves.
+#define PT_FULL_OCCUPANCY __attribute__((amdgpu_waves_per_eu(8, 8)))
+#define PT_ALPHA_CLOSEST_ATTR __attribute__((amdgpu_waves_per_eu(6, 6))) // 83 -> 80 registers, 5 -> 6 waves; 7 would spill
+#define PT_ALPHA_SHADOW_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))  // 70 -> 61 registers
 template <bool ALPHA>
-__global__ void __launch_bounds__(kBlock) k_trace_closest(TraceScene sc, Wavefront wf, int qin, uint32_t count)
+PT_DEV void traceClosestBody(const TraceScene &sc, const Wavefront &wf, int qin, uint32_t count)
 {
     PT_DECLARE_STACK(st, kLdsStack, wf.spill)
     ClosestIO io = { wf, wf.queue[qin], 0u };
     persistentTrace<false, ALPHA>(sc, io, count, &wf.counters[C_CHUNK], st);
     if (st.overflow)
         atomicAdd(&wf.counters[C_OVERFLOW], 1u);
+}
+template <bool ALPHA>
+__global__ void __launch_bounds__(kBlock) k_trace_closest(TraceScene sc, Wavefront wf, int qin, uint32_t count);
+template <>
+__global__ void __launch_bounds__(kBlock) PT_FULL_OCCUPANCY k_trace_closest<false>(TraceScene sc, Wavefront wf, int qin, uint32_t count)
+{
+    traceClosestBody<false>(sc, wf, qin, count);
+}
+template <>
+__global__ void __launch_bounds__(kBlock) PT_ALPHA_CLOSEST_ATTR k_trace_closest<true>(TraceScene sc, Wavefront wf, int qin, uint32_t count)
+{
+    traceClosestBody<true>(sc, wf, qin, count);
 }
 
 // raygen.rgen:99-112 + sample loop control for a slot whose path has ended.
@@ -331,8 +349,13 @@ PT_DEV bool finishSample(const LaunchParams &p, const Wavefront &wf, uint32_t sl
     return false;
 }
 
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_ATTR
+#else
+#define PT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(PT_SHADE_WAVES, PT_SHADE_WAVES)))
+#endif
 template <bool TEX>
-__global__ void __launch_bounds__(kBlock) k_shade(LaunchParams p, SceneView sv, Wavefront wf, int qin)
+__global__ void __launch_bounds__(kBlock) PT_SHADE_ATTR k_shade(LaunchParams p, SceneView sv, Wavefront wf, int qin)
 {
     __shared__ uint32_t s_cnt[2], s_base[2];
     const int qout = qin ^ 1;
@@ -521,13 +544,29 @@ struct ShadowIO
         }
         if (finished != 0.0f)
         {
-            uint4 meta = wf.meta[slot];
+            // finishSample without the new primary ray: constructing it here (camera matrices, lens, differentials)
+            // would set the register budget of the whole traversal loop for a path taken only by multi-sample
+            // launches and NaN restarts.  The slot joins the restart queue (k_trace_closest of the next bounce may
+            // already be consuming the next queue); k_restart generates the ray before the queue is used.
             f3 radiance = F3(r4.x, r4.y, r4.z);
-            // new sample of a multi-sample launch / NaN restart: the slot joins the restart queue
-            // (k_trace_closest of the next bounce may already be consuming the next queue)
-            if (finishSample(p, wf, slot, meta, radiance, nSamples, nRetries))
+            uint32_t smpl = wf.meta[slot].z >> 16;
+            nSamples++;
+            if (badRadiance(radiance))
+            {
+                radiance = F3s(0.0f);
+                smpl = 0;
+                nRetries++;
+            }
+            else
+                smpl = smpl + 1;
+            if (smpl < p.u.SampleCount)
+            {
+                wf.meta[slot].z = smpl << 16; // bounce = 0
+                wf.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
                 wf.restartQueue[atomicAdd(&wf.counters[C_RESTART], 1u)] = slot;
-            wf.meta[slot] = meta;
+            }
+            else
+                wf.slotRad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
         }
         else
             wf.rad[slot] = r4; // the slot is already in the next queue (k_shade)
@@ -535,7 +574,7 @@ struct ShadowIO
 };
 
 template <bool ALPHA>
-__global__ void __launch_bounds__(kBlock) k_trace_shadow(LaunchParams p, TraceScene sc, Wavefront wf, int qout, uint32_t count)
+PT_DEV void traceShadowBody(const LaunchParams &p, const TraceScene &sc, const Wavefront &wf, int qout, uint32_t count)
 {
     PT_DECLARE_STACK(st, kLdsStack, wf.spill)
     ShadowIO io = { p, wf, qout, 0u, 0.0f, 0u, 0u };
@@ -544,6 +583,34 @@ __global__ void __launch_bounds__(kBlock) k_trace_shadow(LaunchParams p, TraceSc
         atomicAdd(&wf.counters[C_OVERFLOW], 1u);
     waveAddCounter(&wf.counters[C_SAMPLES], io.nSamples);
     waveAddCounter(&wf.counters[C_RETRIES], io.nRetries);
+}
+template <bool ALPHA>
+__global__ void __launch_bounds__(kBlock) k_trace_shadow(LaunchParams p, TraceScene sc, Wavefront wf, int qout, uint32_t count);
+template <>
+__global__ void __launch_bounds__(kBlock) PT_FULL_OCCUPANCY k_trace_shadow<false>(LaunchParams p, TraceScene sc, Wavefront wf, int qout, uint32_t count)
+{
+    traceShadowBody<false>(p, sc, wf, qout, count);
+}
+template <>
+__global__ void __launch_bounds__(kBlock) PT_ALPHA_SHADOW_ATTR k_trace_shadow<true>(LaunchParams p, TraceScene sc, Wavefront wf, int qout, uint32_t count)
+{
+    traceShadowBody<true>(p, sc, wf, qout, count);
+}
+
+// The second half of finishSample for the slots the shadow kernel re-queued: next primary ray, RNG carried on.
+__global__ void __launch_bounds__(kBlock) k_restart(LaunchParams p, Wavefront wf, uint32_t count)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
+    {
+        const uint32_t slot = wf.restartQueue[i];
+        uint4 meta = wf.meta[slot];
+        f3 o, d;
+        startSlotSample(p, wf, slot, meta.y, meta.x, o, d);
+        wf.rayO[slot] = make_float4(o.x, o.y, o.z, 0.0f);
+        wf.rayD[slot] = make_float4(d.x, d.y, d.z, 0.0f);
+        wf.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        wf.meta[slot] = meta;
+    }
 }
 
 // raygen.rgen:115-117 for `frames` launches in frame order: bit-identical to issuing the
@@ -1204,6 +1271,7 @@ struct PtxRenderer
     bool anyNonOpaque = false;  // some instanced geometry lacks the opaque flag: any-hit stages run
     bool usePloc = true;        // PLOC topology instead of Karras (PTX_BUILDER=lbvh switches back)
     uint32_t plocRadius = kPlocRadius;
+    uint32_t residentClosest[2] = { 0, 0 }, residentShadow[2] = { 0, 0 }; // blocks the chip holds at once, per [ALPHA] variant
     DevBuf<float4> decal;
     DevBuf<float> decalT;
     size_t decalCapacity = 0;
@@ -1297,9 +1365,25 @@ static uint32_t gridFor(size_t n, uint32_t block = kBlock, uint32_t cap = 256 * 
 // fetches), which is many times an average ray: giving every thread several rays of a SMALL launch costs nothing, and
 // leaves compute units free for the kernel running beside it on the other stream.
 static uint32_t g_raysPerThread = 4; // PTX_RAYS_PER_THREAD; measured 1 / 2 / 4 / 8 / 16: 12.79 / 12.68 / 12.64 / 12.93 / 13.99 ms per step (3.72 / 3.67 / 3.64 / 3.65 / 4.01 on a 1/8 shard)
-static uint32_t traceGridFor(size_t n)
+// A persistent kernel must not launch more blocks than the chip holds at once: with the static chunk schedule the chunks
+// of a block that is not resident yet wait until a resident block has drained the whole queue, and then run on a mostly
+// empty chip.  residentBlocks = occupancy (blocks per CU, from the kernel's VGPR / LDS use) x compute units.
+static uint32_t g_residentCap = 1; // PTX_RESIDENT_CAP=0: the old fixed cap of 2048 blocks
+static uint32_t traceGridFor(size_t n, uint32_t residentBlocks = 0)
 {
-    return gridFor((n + g_raysPerThread - 1) / g_raysPerThread);
+    const uint32_t g = gridFor((n + g_raysPerThread - 1) / g_raysPerThread);
+    return g_residentCap && residentBlocks && g > residentBlocks ? residentBlocks : g;
+}
+
+template <typename K>
+static uint32_t residentBlocksOf(K kernel, int device)
+{
+    int perCu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, kBlock, 0) != hipSuccess || perCu < 1)
+        return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1)
+        return 0;
+    return (uint32_t)perCu * (uint32_t)cus;
 }
 
 static LaunchParams makeParams(const PtxRenderer *r, const PtxRaygenUniformData *u, uint32_t firstFrame, uint32_t frames)
@@ -1374,6 +1458,15 @@ int ptx_create(const PtxDeviceDesc *desc, PtxRenderer **out)
         g_raysPerThread = std::max(1u, (uint32_t)strtoul(e, nullptr, 10));
     if (const char *e = getenv("PTX_PLOC_RADIUS"))
         r->plocRadius = std::max(1u, (uint32_t)strtoul(e, nullptr, 10));
+    if (const char *e = getenv("PTX_RESIDENT_CAP"))
+        g_residentCap = (uint32_t)strtoul(e, nullptr, 10);
+    r->residentClosest[0] = residentBlocksOf(k_trace_closest<false>, r->device);
+    r->residentClosest[1] = residentBlocksOf(k_trace_closest<true>, r->device);
+    r->residentShadow[0] = residentBlocksOf(k_trace_shadow<false>, r->device);
+    r->residentShadow[1] = residentBlocksOf(k_trace_shadow<true>, r->device);
+    if (getenv("PTX_VERBOSE"))
+        fprintf(stderr, "[ptx] resident blocks: closest %u / %u, shadow %u / %u\n", r->residentClosest[0], r->residentClosest[1], r->residentShadow[0],
+                r->residentShadow[1]);
     (void)hipEventCreate(&r->evA);
     (void)hipEventCreate(&r->evB);
     (void)hipEventCreate(&r->evT0);
@@ -2174,9 +2267,9 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
         HIP_TRY(r, hipMemsetAsync(&q.dCounters[C_CHUNK], 0, sizeof(uint32_t), q.s));
         HIP_TRY(r, hipEventRecord(q.evT0, q.s));
         if (alpha)
-            k_trace_closest<true><<<traceGridFor(bt.active), kBlock, 0, q.s>>>(sc, bt.wf, bt.qin, bt.active);
+            k_trace_closest<true><<<traceGridFor(bt.active, r->residentClosest[1]), kBlock, 0, q.s>>>(sc, bt.wf, bt.qin, bt.active);
         else
-            k_trace_closest<false><<<traceGridFor(bt.active), kBlock, 0, q.s>>>(sc, bt.wf, bt.qin, bt.active);
+            k_trace_closest<false><<<traceGridFor(bt.active, r->residentClosest[0]), kBlock, 0, q.s>>>(sc, bt.wf, bt.qin, bt.active);
         HIP_TRY(r, hipEventRecord(q.evT1, q.s));
         if (bt.shadowPending) // k_shade reads rad[slot]: the previous bounce's shadow adds must have landed
             HIP_TRY(r, hipStreamWaitEvent(q.s, q.evShadow[bt.shadowSlot], 0));
@@ -2253,12 +2346,29 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
                 HIP_TRY(r, hipMemsetAsync(&q.dCounters[C_CHUNK_SHADOW], 0, sizeof(uint32_t), q.x));
                 HIP_TRY(r, hipEventRecord(q.evX0[bt.shadowSlot], q.x));
                 if (alpha)
-                    k_trace_shadow<true><<<traceGridFor(shadowCount), kBlock, 0, q.x>>>(bt.p, sc, bt.wfAux, qout, shadowCount);
+                    k_trace_shadow<true><<<traceGridFor(shadowCount, r->residentShadow[1]), kBlock, 0, q.x>>>(bt.p, sc, bt.wfAux, qout, shadowCount);
                 else
-                    k_trace_shadow<false><<<traceGridFor(shadowCount), kBlock, 0, q.x>>>(bt.p, sc, bt.wfAux, qout, shadowCount);
+                    k_trace_shadow<false><<<traceGridFor(shadowCount, r->residentShadow[0]), kBlock, 0, q.x>>>(bt.p, sc, bt.wfAux, qout, shadowCount);
                 HIP_TRY(r, hipEventRecord(q.evShadow[bt.shadowSlot], q.x));
                 bt.shadowPending = true;
             }
+#ifdef PT_VISIT_STATS
+            if (verbose)
+            {
+                uint32_t vs[2][68];
+                (void)hipDeviceSynchronize();
+                (void)hipMemcpyFromSymbol(vs, HIP_SYMBOL(ptd::g_visitStats), sizeof(vs));
+                for (int k = 0; k < 2; k++)
+                {
+                    fprintf(stderr, "[ptx]   %s visits: max %u mean %.1f rays %u hist/16:", k ? "shadow(prev)" : "closest", vs[k][0], vs[k][2] ? (double)vs[k][1] / vs[k][2] : 0.0, vs[k][2]);
+                    for (int i = 0; i < 64; i++)
+                        fprintf(stderr, " %u", vs[k][4 + i]);
+                    fprintf(stderr, "\n");
+                }
+                std::memset(vs, 0, sizeof(vs));
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(ptd::g_visitStats), vs, sizeof(vs));
+            }
+#endif
             if (verbose)
                 fprintf(stderr, "[ptx] batch %d bounce %llu: %u rays closest %.3f ms (%.2f Grays/s) | shade %.3f ms | %u shadow rays\n", index,
                         (unsigned long long)bt.iteration, bt.active, closestMs, bt.active / closestMs / 1e6, ms, shadowCount);
@@ -2295,6 +2405,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
                 bt.phase = PH_DONE;
                 return PTX_OK;
             }
+            k_restart<<<gridFor(restarts), kBlock, 0, q.s>>>(bt.p, bt.wf, restarts);
             HIP_TRY(r, hipMemcpyAsync(bt.wf.queue[bt.qin], bt.wf.restartQueue, (size_t)restarts * sizeof(uint32_t), hipMemcpyDeviceToDevice, q.s));
             HIP_TRY(r, hipMemsetAsync(&q.dCounters[C_RESTART], 0, sizeof(uint32_t), q.s));
             bt.active = restarts;
