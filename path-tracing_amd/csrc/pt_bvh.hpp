@@ -558,21 +558,32 @@ PT_DEV double decodeQ(float o, uint32_t q, float scale) { return (double)o + (do
 // the deindexed vertices of one triangle, next to its Tri record (see ShadeTri)
 PT_DEV void writeShadeTri(const Tri &t, const DevPair *pairs, const PtxVertex *vertices, const uint32_t *indices, ShadeTri *out)
 {
-    const DevPair *pr = &pairs[__float_as_uint(t.c.y)];
+    const DevPair pr = pairs[__float_as_uint(t.c.y)];
     const uint32_t prim = __float_as_uint(t.c.z);
-    float f[44];
+    float f[68];
+    Vtx o[3];
     for (int k = 0; k < 3; k++)
     {
-        const PtxVertex *v = &vertices[pr->vertexOffset + indices[pr->indexOffset + prim * 3 + k]];
+        const PtxVertex *v = &vertices[pr.vertexOffset + indices[pr.indexOffset + prim * 3 + k]];
         float *d = &f[14 * k];
         d[0] = v->Position[0]; d[1] = v->Position[1]; d[2] = v->Position[2];
         d[3] = v->TexCoords[0]; d[4] = v->TexCoords[1];
         d[5] = v->Normal[0]; d[6] = v->Normal[1]; d[7] = v->Normal[2];
         d[8] = v->Tangent[0]; d[9] = v->Tangent[1]; d[10] = v->Tangent[2];
         d[11] = v->Bitangent[0]; d[12] = v->Bitangent[1]; d[13] = v->Bitangent[2];
+        o[k] = loadVertex(v);
     }
     f[42] = f[43] = 0.0f;
-    for (int k = 0; k < 11; k++)
+    f3 wp[3], wn[3], gn;
+    worldCorners(pr, o[0], o[1], o[2], wp, wn, gn);
+    for (int k = 0; k < 3; k++)
+    {
+        f[44 + 3 * k] = wp[k].x; f[45 + 3 * k] = wp[k].y; f[46 + 3 * k] = wp[k].z;
+        f[53 + 3 * k] = wn[k].x; f[54 + 3 * k] = wn[k].y; f[55 + 3 * k] = wn[k].z;
+    }
+    f[62] = gn.x; f[63] = gn.y; f[64] = gn.z;
+    f[65] = f[66] = f[67] = 0.0f;
+    for (int k = 0; k < 17; k++)
         out->v[k] = make_float4(f[4 * k], f[4 * k + 1], f[4 * k + 2], f[4 * k + 3]);
 }
 

@@ -1012,12 +1012,16 @@ PT_DEV f3 ld3(const float *p) { return F3(p[0], p[1], p[2]); }
 // The three vertices of one triangle, deindexed and stored in BVH leaf order beside the traversal's Tri record:
 // the closest-hit stage reads ONE contiguous, 16-byte aligned 176-byte record per hit instead of chasing
 // hit -> pair -> 3 indices -> 3 scattered 56-byte vertices (three dependent gathers at 2 waves / SIMD).
-// Vertex k occupies floats [14 k, 14 k + 14) in PtxVertex order; the last two floats are padding.
+// Vertex k occupies floats [14 k, 14 k + 14) in PtxVertex order (object space, as common.glsl:27-46 fetches them);
+// floats 42..43 are padding.  Then what closestHit.rchit:63-74 derives from the corners alone, computed once per
+// (re)build with the very same arithmetic instead of once per hit: world-space positions [44, 53) and normals
+// [53, 62) of the three corners (sampling.glsl:5-15) and the geometric normal [62, 65) -- a quarter of the
+// normalisations of the closest-hit stage.
 struct ShadeTri
 {
-    float4 v[11];
+    float4 v[17];
 };
-static_assert(sizeof(ShadeTri) == 176, "ShadeTri is 176 B");
+static_assert(sizeof(ShadeTri) == 272, "ShadeTri is 272 B");
 
 struct SceneView // read-only device views of the uploaded scene
 {
@@ -1294,21 +1298,31 @@ PT_DEV Vtx loadVertex(const PtxVertex *p) // common.glsl:27-46
     return v;
 }
 
-struct TriVertices // the vertices of the hit triangle as common.glsl:27-46 would fetch them
+struct TriVertices // the vertices of the hit triangle as common.glsl:27-46 would fetch them, and their world-space corners
 {
     Vtx o[3];
     f2 uv[3];
+    f3 worldPosition[3], worldNormal[3], geometricNormal;
 };
+
+// closestHit.rchit:63-74 for one triangle: transformed corners and the unflipped geometric normal (see ShadeTri)
+PT_DEV void worldCorners(const DevPair &pr, const Vtx &o0, const Vtx &o1, const Vtx &o2, f3 *worldPosition, f3 *worldNormal, f3 &geometricNormal);
 
 PT_DEV TriVertices loadTriangle(const ShadeTri *st)
 {
-    float f[44];
-    for (int k = 0; k < 11; k++)
+    float f[68];
+    for (int k = 0; k < 17; k++)
     {
         const float4 q = st->v[k];
         f[4 * k] = q.x; f[4 * k + 1] = q.y; f[4 * k + 2] = q.z; f[4 * k + 3] = q.w;
     }
     TriVertices t;
+    for (int k = 0; k < 3; k++)
+    {
+        t.worldPosition[k] = F3(f[44 + 3 * k], f[45 + 3 * k], f[46 + 3 * k]);
+        t.worldNormal[k] = F3(f[53 + 3 * k], f[54 + 3 * k], f[55 + 3 * k]);
+    }
+    t.geometricNormal = F3(f[62], f[63], f[64]);
     for (int k = 0; k < 3; k++)
     {
         const float *p = &f[14 * k];
@@ -1319,6 +1333,16 @@ PT_DEV TriVertices loadTriangle(const ShadeTri *st)
         t.o[k].Bitangent = F3(p[11], p[12], p[13]);
     }
     return t;
+}
+
+PT_DEV void worldCorners(const DevPair &pr, const Vtx &o0, const Vtx &o1, const Vtx &o2, f3 *worldPosition, f3 *worldNormal, f3 &geometricNormal)
+{
+    const Vtx v0 = transformVertex(pr, o0), v1 = transformVertex(pr, o1), v2 = transformVertex(pr, o2);
+    const f3 edge1 = v1.Position - v0.Position;
+    const f3 edge2 = v2.Position - v0.Position;
+    geometricNormal = normalize(cross(edge1, edge2));
+    worldPosition[0] = v0.Position; worldPosition[1] = v1.Position; worldPosition[2] = v2.Position;
+    worldNormal[0] = v0.Normal; worldNormal[1] = v1.Normal; worldNormal[2] = v2.Normal;
 }
 
 PT_DEV f3 interp3(f3 a, f3 b, f3 c, f3 bc) { return (a * bc.x + b * bc.y) + c * bc.z; } // common.glsl:107-110
@@ -1357,11 +1381,11 @@ PT_DEV void closestHit(const SceneView &sv, f3 rayDirW, float t, float hu, float
     ov.Bitangent = interp3(o0.Bitangent, o1.Bitangent, o2.Bitangent, bary);
     Vtx vertex = transformVertex(pr, ov);
 
-    const Vtx v0 = transformVertex(pr, o0), v1 = transformVertex(pr, o1), v2 = transformVertex(pr, o2);
-
-    const f3 edge1 = v1.Position - v0.Position;
-    const f3 edge2 = v2.Position - v0.Position;
-    f3 geometricNormal = normalize(cross(edge1, edge2));
+    // :63-74 the transformed corners and normalize(cross(edge1, edge2)), precomputed per triangle (ShadeTri)
+    Vtx v0, v1, v2;
+    v0.Position = tv3.worldPosition[0]; v1.Position = tv3.worldPosition[1]; v2.Position = tv3.worldPosition[2];
+    v0.Normal = tv3.worldNormal[0]; v1.Normal = tv3.worldNormal[1]; v2.Normal = tv3.worldNormal[2];
+    f3 geometricNormal = tv3.geometricNormal;
 
     const bool isHitFromInside = dot(geometricNormal, rayDirW) > 0.0f;
     if (isHitFromInside)

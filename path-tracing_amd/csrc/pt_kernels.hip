@@ -2181,7 +2181,10 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
     // splits the frames of the call into interleaved sub-batches.  Measured on MI355X
     // (chess_like 1080p x 8): 1 -> 1204, 2 -> 1017, 3 -> 1006, 4 -> 733 Msamples/s -- sub-batches
     // pass through their throughput-bound and latency-bound phases in lockstep, so nothing
-    // complementary overlaps and co-resident persistent kernels interfere.  Default: 1.
+    // complementary overlaps and co-resident persistent kernels interfere.  Staggering them (sub-batch b + 1 starts
+    // when b enters k_tail) was measured too: 16 spp as 2 x 8 staggered 22.5 ms vs 2 x 11.2 ms back to back -- the tail
+    // kernel starves beside the full-size kernels (2 tails 4.2 ms instead of 3.0) and slows them in turn.  What does
+    // pay is a larger batch: 16 frames in one batch 19.9 ms (one tail instead of two).  Default: 1.
     int nb = 1;
     if (const char *e = getenv("PTX_BATCHES"))
         nb = atoi(e);
