@@ -349,13 +349,24 @@ PT_DEV bool finishSample(const LaunchParams &p, const Wavefront &wf, uint32_t sl
     return false;
 }
 
-#ifndef PT_SHADE_WAVES
-#define PT_SHADE_ATTR
-#else
-#define PT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(PT_SHADE_WAVES, PT_SHADE_WAVES)))
-#endif
 template <bool TEX>
-__global__ void __launch_bounds__(kBlock) PT_SHADE_ATTR k_shade(LaunchParams p, SceneView sv, Wavefront wf, int qin)
+PT_DEV void shadeBody(const LaunchParams &p, const SceneView &sv, const Wavefront &wf, int qin);
+template <bool TEX>
+__global__ void __launch_bounds__(kBlock) k_shade(LaunchParams p, SceneView sv, Wavefront wf, int qin);
+template <>
+__global__ void __launch_bounds__(kBlock) k_shade<false>(LaunchParams p, SceneView sv, Wavefront wf, int qin)
+{
+    shadeBody<false>(p, sv, wf, qin);
+}
+// the sampler pushes the TEX variant a few registers past 256, i.e. to ONE wave per SIMD: hold it at two (4 registers
+// spill; texture_test k_shade 8.3 -> 5.5 ms per step, atrium_like 17.1 -> 11.6 ms)
+template <>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) k_shade<true>(LaunchParams p, SceneView sv, Wavefront wf, int qin)
+{
+    shadeBody<true>(p, sv, wf, qin);
+}
+template <bool TEX>
+PT_DEV void shadeBody(const LaunchParams &p, const SceneView &sv, const Wavefront &wf, int qin)
 {
     __shared__ uint32_t s_cnt[2], s_base[2];
     const int qout = qin ^ 1;
@@ -2185,6 +2196,14 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
     // when b enters k_tail) was measured too: 16 spp as 2 x 8 staggered 22.5 ms vs 2 x 11.2 ms back to back -- the tail
     // kernel starves beside the full-size kernels (2 tails 4.2 ms instead of 3.0) and slows them in turn.  What does
     // pay is a larger batch: 16 frames in one batch 19.9 ms (one tail instead of two).  Default: 1.
+    //
+    // Also measured and dropped: ONE traversal launch per bounce carrying the closest-hit queries of bounce n + 1 and the
+    // shadow queries of bounce n (single stream, 64 VGPRs, 8 waves): 11.4 ms per chess_like step against 11.1 ms for the
+    // two kernels on two streams below (temple_like 26.6 vs 24.9 ms) -- the two persistent kernels already fill each
+    // other's tails.  Resetting the per-bounce counters inside the kernels instead of three 4-byte fills per bounce:
+    // the fills do wait behind the other stream's persistent kernel (up to 0.76 ms seen), but without them the closest
+    // kernel waits in their place; no gain (11.15 ms, and 3.7 instead of 3.4 ms on a 1/8 shard).  A one-entry software
+    // pipeline in k_shade (hit / meta / pair of entry k + 1 loaded while entry k is shaded): 3.50 vs 3.44 ms, no gain.
     int nb = 1;
     if (const char *e = getenv("PTX_BATCHES"))
         nb = atoi(e);
