@@ -13,6 +13,14 @@ Workload at N = 1: BASELINE configs[1] "ABeautifulGame, 1920x1080, 8 spp, depth 
 procedural stand-in `chess_like` (the glTF assets are downloaded at CMake time by the reference
 and do not exist offline).
 
+N > 1: the frame is cut into 32x32 pixel tiles dealt round-robin to the ranks; no collective inside the
+data path, one all_gather of the tile shards per step.  Default `--scaling weak`: per-GPU work is fixed --
+every GPU adds `spp` x (W*H) path samples per step, i.e. the N-GPU job is the same frame at N*spp samples
+per pixel, each rank rendering its 1/N of the tiles at N*spp (what BASELINE configs[3] and [4] do: more GPUs
+come with more samples, 256 spp on 4 and 1024 spp on 8).  `--scaling strong` splits the fixed `spp` frame
+instead; a step of 16.6 M samples is then 2 M samples per rank at N = 8 and its duration is dominated by the
+latency floor of a bounce sequence, which is why it is not the default.
+
 Launch:  python bench.py --gpus N --steps K --warmup W           (N = 1)
          python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 Rank 0 prints ONE JSON line.
@@ -32,6 +40,9 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 import __graft_entry__ as graft  # noqa: E402
 
+STAND_IN = {"chess_like": "configs[1] 'Khronos ABeautifulGame'", "temple_like": "configs[2] 'UE4 Sun Temple'",
+            "atrium_like": "configs[3] 'Intel Sponza (MAIN+CURTAINS+IVY)'", "street_like": "configs[4] 'Amazon Bistro night'",
+            "attenuation_blob": "configs[0] 'Khronos DragonAttenuation'"}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
@@ -97,6 +108,9 @@ def main():
     ap.add_argument("--backend", default="wavefront", choices=["wavefront", "megakernel"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = every GPU adds spp samples per pixel-equivalent (job = N*spp spp, tile-sharded); "
+                         "strong = the fixed spp frame is split over the GPUs")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --single-device lets the N > 1 code path be exercised on a 1-GPU box (testing only)")
     ap.add_argument("--single-device", action="store_true", help="testing only: every rank uses cuda:0")
@@ -143,6 +157,8 @@ def main():
     emu_rank, emu_world = (int(x) for x in args.emulate_shard.split("/")) if args.emulate_shard else (rank, world)
     r.set_tile_shard(emu_rank, emu_world, args.tile)
     u = scene.uniform(W, H, bounces=args.depth)
+    # samples per pixel of the whole job; a rank renders its tiles at this many frames
+    job_spp = args.spp * (emu_world if args.scaling == "weak" else 1)
     build_ms = r.stats().lastBuildMs
     n_tris = scene.triangle_count
 
@@ -154,7 +170,7 @@ def main():
 
     def step():
         r.reset()
-        r.render_frames(u, lights, 0, args.spp)
+        r.render_frames(u, lights, 0, job_spp)
         if world > 1:
             r.pack_shard(send.data_ptr())
             r.synchronize()
@@ -206,21 +222,21 @@ def main():
         img = r.readback()
         checksum = [float(img[..., :3].astype(np.float64).sum()), int(np.isfinite(img).all()), int((img[..., 3] == 1).all())]
     if rank == 0:
-        samples = W * H * args.spp * args.steps
+        samples = W * H * job_spp * args.steps
         value = samples / elapsed / 1e6
         out = {
             "metric": "Msamples/s (paths*spp/s) at 1920x1080, 8spp, depth 8",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong",  # one fixed 1080p frame is split into pixel tiles over the N GPUs
+            "scaling": args.scaling,  # weak: W*H*spp samples per GPU and step; strong: one fixed spp frame split over the GPUs
             "vs_baseline": None,   # the reference publishes no number for this metric
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"{args.scene} (procedural stand-in for BASELINE configs[1] 'Khronos ABeautifulGame'), "
-                            f"{W}x{H}, {args.spp} spp, depth {args.depth}",
+                "workload": f"{args.scene} (procedural stand-in for BASELINE {STAND_IN.get(args.scene, 'scenes')}), "
+                            f"{W}x{H}, {args.spp} spp" + (f" per GPU = {job_spp} spp" if job_spp != args.spp else "") + f", depth {args.depth}",
                 "triangles": n_tris, "backend": args.backend, "tile": args.tile,
                 "parallelism": f"pixel-tile shard x{world}" + (", 1 RCCL all_gather" if world > 1 else ""),
-                "segments_per_sample": segments / (W * H * args.spp / world) if world else None,
+                "segments_per_sample": segments / (W * H * job_spp / world) if world else None,
                 "lbvh_build_ms": build_ms, "upload_plus_build_s": upload_build_s,
                 "kernel_ms_per_step": {"k_trace_closest": trace_ms / args.steps, "k_shade": shade_ms / args.steps,
                                        "k_trace_shadow": shadow_ms / args.steps, "k_tail": tail_ms / args.steps},

@@ -109,6 +109,17 @@ def test_alpha_scene_image_matches_oracle(pkg, orc, backend):
 
 
 @pytest.mark.gpu
+def test_atrium_stand_in_image_matches_oracle(pkg, orc):
+    # the Sponza stand-in of BASELINE configs[3] (north_star's 10x-CPU / 1e-3 target scene): textures, alpha-tested ivy
+    # cards and curtains, i.e. kernel mode 2, at a size the oracle renders in seconds
+    img, ref = util.render_pair(pkg, orc, "atrium_like", 0.04, 128, 72, frames=2, depth=8)
+    assert np.isfinite(img).all()
+    assert ref[..., :3].max() > 0
+    differing = int((img.view(np.uint32) != ref.view(np.uint32)).any(axis=-1).sum())
+    assert differing == 0, f"{differing} pixels are not bit-identical (rel-L2 {util.rel_l2(img, ref)})"
+
+
+@pytest.mark.gpu
 def test_alpha_scene_tail_multi_sample_and_lens(pkg, orc, monkeypatch):
     img, ref = util.render_pair(pkg, orc, "alpha_test", 1.0, 96, 54, frames=2, depth=5, lens=0.04, sample_count=2)
     assert (img.view(np.uint32) == ref.view(np.uint32)).all()
