@@ -553,6 +553,7 @@ struct ShadowIO
             r4.y = r4.y + c.y;
             r4.z = r4.z + c.z;
         }
+        bool restart = false;
         if (finished != 0.0f)
         {
             // finishSample without the new primary ray: constructing it here (camera matrices, lens, differentials)
@@ -574,13 +575,26 @@ struct ShadowIO
             {
                 wf.meta[slot].z = smpl << 16; // bounce = 0
                 wf.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-                wf.restartQueue[atomicAdd(&wf.counters[C_RESTART], 1u)] = slot;
+                restart = true;
             }
             else
                 wf.slotRad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
         }
         else
             wf.rad[slot] = r4; // the slot is already in the next queue (k_shade)
+        // one atomic per wave and store call, not per slot: every sample but the last of a multi-sample launch ends here
+        const uint64_t mask = __ballot(restart);
+        if (mask)
+        {
+            const uint32_t lane = threadIdx.x & 63u;
+            const int leader = __ffsll((unsigned long long)mask) - 1;
+            uint32_t base = 0;
+            if ((int)lane == leader)
+                base = atomicAdd(&wf.counters[C_RESTART], (uint32_t)__popcll(mask));
+            base = __shfl(base, leader);
+            if (restart)
+                wf.restartQueue[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = slot;
+        }
     }
 };
 
@@ -659,20 +673,21 @@ struct PathCounters
     uint32_t nSeg = 0, nHit = 0, nSmp = 0, nRetry = 0;
 };
 
-// Runs a slot to the end of its launch.  `fresh` = start with a new sample (primary ray);
-// otherwise continue the current sample at `bounce` with the given ray / throughput.
+// Runs a slot to the end of its launch -- or, with stopAfterSample, to the end of the sample it is in (smpl then tells
+// the caller whether samples remain).  `fresh` = start with a new sample (primary ray); otherwise continue the
+// current sample at `bounce` with the given ray / throughput.
 // MODE 0: opaque geometry, fixed 1x1 textures; 1: + ray differentials and the sampler (TEX); 2: + any-hit stages (ALPHA)
 template <int MODE>
 PT_DEV f3 runPath(const LaunchParams &p, const SceneView &sv, const TraceScene &sc, Stack &st, uint32_t pixel, uint32_t &rng,
-                  f3 radiance, f3 throughput, f3 ro, f3 rd, DiffRays diff, float maxRoughness, uint32_t bounce, int smpl, bool fresh,
-                  PathCounters &pc)
+                  f3 radiance, f3 throughput, f3 ro, f3 rd, DiffRays diff, float maxRoughness, uint32_t bounce, int &smpl, bool fresh,
+                  PathCounters &pc, bool stopAfterSample = false)
 {
     constexpr bool TEX = MODE >= 1, ALPHA = MODE == 2;
     for (;;)
     {
         if (fresh)
         {
-            if (smpl >= (int)p.u.SampleCount)
+            if (smpl >= (int)p.u.SampleCount || stopAfterSample)
                 break;
             throughput = F3s(1.0f);
             startSample<TEX>(p, pixel, rng, ro, rd, diff);
@@ -745,7 +760,8 @@ __global__ void __launch_bounds__(kBlock) k_megakernel(LaunchParams p, SceneView
         uint32_t rng = initRng(pixel % p.width, pixel / p.width, p.width, p.firstFrame + f);
         DiffRays diff;
         diff.rxOrigin = diff.rxDirection = diff.ryOrigin = diff.ryDirection = F3s(0.0f);
-        radiance = runPath<MODE>(p, sv, sc, st, pixel, rng, F3s(0.0f), F3s(1.0f), F3s(0.0f), F3s(0.0f), diff, 0.0f, 0u, 0, true, pc);
+        int smpl = 0;
+        radiance = runPath<MODE>(p, sv, sc, st, pixel, rng, F3s(0.0f), F3s(1.0f), F3s(0.0f), F3s(0.0f), diff, 0.0f, 0u, smpl, true, pc);
     }
     if (slot < p.numSlots)
         slotRad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
@@ -758,7 +774,10 @@ __global__ void __launch_bounds__(kBlock) k_megakernel(LaunchParams p, SceneView
 }
 
 // The slots of queue `qin` sit at a bounce boundary (ray, throughput, radiance, RNG and
-// bounce/sample counters in the SoA state, no shadow query pending): run each to the end.
+// bounce/sample counters in the SoA state, no shadow query pending): run each to the end of its sample.  A slot
+// with samples left (multi-sample launch, NaN restart) goes back through the restart queue and the wavefront
+// kernels: finishing ALL its samples here, one thread per path at 2 waves / SIMD, made a SampleCount = 8 launch six
+// times slower than eight one-sample launches.
 template <int MODE>
 __global__ void __launch_bounds__(kBlock) k_tail(LaunchParams p, SceneView sv, TraceScene sc, Wavefront wf, int qin, uint32_t count)
 {
@@ -767,6 +786,8 @@ __global__ void __launch_bounds__(kBlock) k_tail(LaunchParams p, SceneView sv, T
     for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x)
     {
         const uint32_t i = base + threadIdx.x;
+        bool restart = false;
+        uint32_t restartSlot = 0;
         if (i < count)
         {
             const uint32_t slot = wf.queue[qin][i];
@@ -778,9 +799,29 @@ __global__ void __launch_bounds__(kBlock) k_tail(LaunchParams p, SceneView sv, T
                 diff = loadDiff(wf, slot);
             else
                 diff.rxOrigin = diff.rxDirection = diff.ryOrigin = diff.ryDirection = F3s(0.0f);
+            int smpl = (int)(meta.z >> 16);
             const f3 radiance = runPath<MODE>(p, sv, sc, st, meta.y, rng, F3(r4.x, r4.y, r4.z), F3(t4.x, t4.y, t4.z), F3(o4.x, o4.y, o4.z),
-                                             F3(d4.x, d4.y, d4.z), diff, o4.w, meta.z & 0xffffu, (int)(meta.z >> 16), false, pc);
-            wf.slotRad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+                                             F3(d4.x, d4.y, d4.z), diff, o4.w, meta.z & 0xffffu, smpl, false, pc, true);
+            if (smpl < (int)p.u.SampleCount)
+            {
+                wf.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+                wf.meta[slot] = make_uint4(rng, meta.y, (uint32_t)smpl << 16, meta.w);
+                restart = true;
+                restartSlot = slot;
+            }
+            else
+                wf.slotRad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+        }
+        const uint64_t mask = __ballot(restart);
+        if (mask) // k_restart draws the next primary ray before the queue is consumed
+        {
+            const uint32_t lane = threadIdx.x & 63u;
+            uint32_t at = 0;
+            if (lane == 0)
+                at = atomicAdd(&wf.counters[C_RESTART], (uint32_t)__popcll(mask));
+            at = __shfl(at, 0);
+            if (restart)
+                wf.restartQueue[at + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = restartSlot;
         }
     }
     if (st.overflow)
@@ -2321,6 +2362,9 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
             return issueDrain(bt);
         if (bt.iteration >= 1 && bt.active <= tailThreshold)
         {
+            if (++bt.iteration > maxIterations) // a slot that never yields a finite sample comes back through the restart queue for ever
+                return fail(r, PTX_ERROR_DEVICE, "ptx_render: %u paths still active after %llu bounce iterations", bt.active,
+                            (unsigned long long)maxIterations);
             if (bt.shadowPending) // k_tail continues from rad[slot]
                 HIP_TRY(r, hipStreamWaitEvent(q.s, q.evShadow[bt.shadowSlot], 0));
             HIP_TRY(r, hipEventRecord(q.evT0, q.s));
@@ -2409,7 +2453,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
                 return fail(r, PTX_ERROR_DEVICE, "ptx_render: traversal stack overflow in k_tail (depth > %d)", kLdsStackMega);
             bt.segments += q.hCounters[C_SEGMENTS];
             HIP_TRY(r, hipMemsetAsync(&q.dCounters[C_SEGMENTS], 0, sizeof(uint32_t), q.s));
-            bt.active = 0; // every path of the queue ran to the end of the launch
+            bt.active = 0; // every path of the queue ran to the end of its sample; slots with samples left are in the restart queue
             return next(bt);
         case PH_WAIT_DRAIN: {
             if (bt.shadowPending)
@@ -2430,6 +2474,8 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
             k_restart<<<gridFor(restarts), kBlock, 0, q.s>>>(bt.p, bt.wf, restarts);
             HIP_TRY(r, hipMemcpyAsync(bt.wf.queue[bt.qin], bt.wf.restartQueue, (size_t)restarts * sizeof(uint32_t), hipMemcpyDeviceToDevice, q.s));
             HIP_TRY(r, hipMemsetAsync(&q.dCounters[C_RESTART], 0, sizeof(uint32_t), q.s));
+            // k_shade takes its count from the device counter of its input queue
+            HIP_TRY(r, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&q.dCounters[bt.qin ? C_ACTIVE1 : C_ACTIVE0]), (int)restarts, 1, q.s));
             bt.active = restarts;
             return next(bt);
         }

@@ -213,6 +213,30 @@ def test_multi_sample_launch_matches_oracle(pkg, orc):
     assert (img.view(np.uint32) == ref.view(np.uint32)).all()
 
 
+@pytest.mark.parametrize("threshold", ["0", "100000000"])
+def test_multi_sample_launch_restart_queue(pkg, orc, monkeypatch, threshold):
+    # the samples after the first start from the restart queue (shadow kernel -> k_restart -> next bounce loop); with
+    # PTX_TAIL_THRESHOLD=0 they go through the wavefront bounce kernels (the path a full-size launch takes), with a
+    # huge threshold through k_tail.  Counts and image must match the oracle either way.
+    monkeypatch.setenv("PTX_TAIL_THRESHOLD", threshold)
+    scene = pkg.Scene("chess_like", 0.05)
+    lights = scene.lights
+    W, H = 128, 72
+    r = pkg.Renderer()
+    r.upload(scene)
+    r.resize(W, H)
+    u = scene.uniform(W, H, bounces=6, sample_count=4, total_samples=0)
+    r.render(u, lights)
+    st = r.stats()
+    img = r.readback()
+    r.close()
+    osc = orc.OracleScene(scene.desc)
+    ref, ost = osc.render(u, lights, W, H)
+    assert st.pathSamples == ost.pathSamples == W * H * 4 + st.retries
+    assert st.segments == ost.segments and st.shadowRays == ost.shadowRays
+    assert (img.view(np.uint32) == ref.view(np.uint32)).all()
+
+
 def test_tile_shards_compose_to_full_frame(pkg):
     import torch
 
