@@ -305,6 +305,38 @@ def test_full_size_properties(pkg):
     r.close()
 
 
+@pytest.mark.parametrize("name,frames", [("chess_like", 2), ("atrium_like", 1), ("temple_like", 1)])
+def test_full_size_frame_matches_oracle(pkg, orc, name, frames):
+    """The benchmark workload itself (chess_like at full detail, 1,999,000 triangles, 1920x1080, depth 8) and the Sponza
+    and Sun Temple stand-ins (textures + any-hit; point lights and deep paths): frames of the batch against the oracle,
+    bit for bit.  At this size a launch takes every path the small cases skip: several wavefront bounces above the tail
+    threshold, 130 K traversal chunks per launch, grids capped at the resident block count, block-wide queue appends
+    over 65 K blocks."""
+    import torch  # noqa: F401
+
+    scene = pkg.Scene(name, 1.0)
+    lights = scene.lights
+    W, H = 1920, 1080
+    r = pkg.Renderer()
+    r.upload(scene)
+    r.resize(W, H)
+    u = scene.uniform(W, H, bounces=8)
+    r.render_frames(u, lights, 0, frames)
+    img = r.readback()
+    st = r.stats()
+    r.close()
+    osc = orc.OracleScene(scene.desc)
+    ref = np.zeros((H, W, 4), np.float32)
+    seg = shadow = 0
+    for f in range(frames):
+        _, ost = osc.render(scene.uniform(W, H, bounces=8, total_samples=f), lights, W, H, accum=ref)
+        seg += ost.segments
+        shadow += ost.shadowRays
+    assert (st.segments, st.shadowRays) == (seg, shadow)
+    differing = int((img.view(np.uint32) != ref.view(np.uint32)).any(axis=-1).sum())
+    assert differing == 0, f"{differing} of {W * H} pixels are not bit-identical (rel-L2 {util.rel_l2(img, ref)})"
+
+
 def test_error_behaviour(pkg):
     import torch  # noqa: F401
 
