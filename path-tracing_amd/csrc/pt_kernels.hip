@@ -320,7 +320,11 @@ __global__ void __launch_bounds__(kBlock) PT_ALPHA_CLOSEST_ATTR k_trace_closest<
 }
 
 // raygen.rgen:99-112 + sample loop control for a slot whose path has ended.
-// Returns true if the slot continues (new primary ray written, caller enqueues it).
+// Returns true if the slot has samples left in this launch (next sample of a multi-sample launch, NaN restart): the
+// caller appends it to the restart queue and k_restart draws its next primary ray before that queue is consumed.
+// The ray is NOT constructed here: the camera matrices, the lens and the differential code would sit in the register
+// and instruction-cache budget of the shading and traversal kernels for a path the canonical schedule
+// (SampleCount = 1) takes only after a NaN.
 PT_DEV bool finishSample(const LaunchParams &p, const Wavefront &wf, uint32_t slot, uint4 &meta, f3 &radiance,
                          uint32_t &nSamples, uint32_t &nRetries)
 {
@@ -336,12 +340,7 @@ PT_DEV bool finishSample(const LaunchParams &p, const Wavefront &wf, uint32_t sl
         smpl = smpl + 1;
     if (smpl < p.u.SampleCount)
     {
-        f3 o, d;
-        startSlotSample(p, wf, slot, meta.y, meta.x, o, d);
         meta.z = smpl << 16; // bounce = 0
-        wf.rayO[slot] = make_float4(o.x, o.y, o.z, 0.0f);
-        wf.rayD[slot] = make_float4(d.x, d.y, d.z, 0.0f);
-        wf.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
         wf.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
         return true;
     }
@@ -349,12 +348,34 @@ PT_DEV bool finishSample(const LaunchParams &p, const Wavefront &wf, uint32_t sl
     return false;
 }
 
+// Appends the slots of the calling lanes (restart == true) to the restart queue with one atomic per wave.  May be
+// called under divergent control flow: the ballot sees the active lanes only.
+PT_DEV void pushRestarts(const Wavefront &wf, bool restart, uint32_t slot)
+{
+    const uint64_t mask = __ballot(restart);
+    if (!mask)
+        return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int leader = __ffsll((unsigned long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader)
+        base = atomicAdd(&wf.counters[C_RESTART], (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    if (restart)
+        wf.restartQueue[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = slot;
+}
+
 template <bool TEX>
 PT_DEV void shadeBody(const LaunchParams &p, const SceneView &sv, const Wavefront &wf, int qin);
 template <bool TEX>
 __global__ void __launch_bounds__(kBlock) k_shade(LaunchParams p, SceneView sv, Wavefront wf, int qin);
+// 190 VGPRs once the new-sample code is out of the kernel; held at 168 = three waves per SIMD for 15 spilled dwords
+// (k_shade 3.42 -> 3.18 ms per chess_like step; four waves would spill 90 and lose)
+#ifndef PT_SHADE_ATTR
+#define PT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
+#endif
 template <>
-__global__ void __launch_bounds__(kBlock) k_shade<false>(LaunchParams p, SceneView sv, Wavefront wf, int qin)
+__global__ void __launch_bounds__(kBlock) PT_SHADE_ATTR k_shade<false>(LaunchParams p, SceneView sv, Wavefront wf, int qin)
 {
     shadeBody<false>(p, sv, wf, qin);
 }
@@ -383,7 +404,7 @@ PT_DEV void shadeBody(const LaunchParams &p, const SceneView &sv, const Wavefron
       for (uint32_t item = 0; item < kShadeItems; item++)
       {
         const uint32_t i = base + item * blockDim.x + threadIdx.x;
-        bool pushNext = false, pushShadow = false;
+        bool pushNext = false, pushShadow = false, restart = false;
         uint32_t slot = 0, pair = kDeadPair;
         if (i < count)
         {
@@ -402,7 +423,7 @@ PT_DEV void shadeBody(const LaunchParams &p, const SceneView &sv, const Wavefron
                 // miss.rmiss:16-39: sky colour / skybox lookup, Pdf = -1 -> raygen.rgen:71-75
                 const float4 d4 = wf.rayD[slot];
                 radiance = radiance + throughput * missEmissive(sv, F3(d4.x, d4.y, d4.z));
-                pushNext = finishSample(p, wf, slot, meta, radiance, nSamples, nRetries);
+                restart = finishSample(p, wf, slot, meta, radiance, nSamples, nRetries);
             }
             else
             {
@@ -461,7 +482,7 @@ PT_DEV void shadeBody(const LaunchParams &p, const SceneView &sv, const Wavefron
                     wf.shC[slot] = make_float4(contribution.x, contribution.y, contribution.z, 0.0f);
                 }
                 if (finished && !pushShadow)
-                    pushNext = finishSample(p, wf, slot, meta, radiance, nSamples, nRetries);
+                    restart = finishSample(p, wf, slot, meta, radiance, nSamples, nRetries);
                 else
                 {
                     wf.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
@@ -478,6 +499,7 @@ PT_DEV void shadeBody(const LaunchParams &p, const SceneView &sv, const Wavefron
             }
             wf.meta[slot] = meta;
         }
+        pushRestarts(wf, restart, slot);
         // queue appends with ONE global atomic per block and queue: same-address atomics
         // serialise at ~11 ns each on MI355X, so per-wave appends would cost more than the shading
         for (uint32_t k = 0; k < kShadeItems; k++) // no dynamic register indexing
@@ -556,45 +578,16 @@ struct ShadowIO
         bool restart = false;
         if (finished != 0.0f)
         {
-            // finishSample without the new primary ray: constructing it here (camera matrices, lens, differentials)
-            // would set the register budget of the whole traversal loop for a path taken only by multi-sample
-            // launches and NaN restarts.  The slot joins the restart queue (k_trace_closest of the next bounce may
-            // already be consuming the next queue); k_restart generates the ray before the queue is used.
+            uint4 meta = wf.meta[slot];
             f3 radiance = F3(r4.x, r4.y, r4.z);
-            uint32_t smpl = wf.meta[slot].z >> 16;
-            nSamples++;
-            if (badRadiance(radiance))
-            {
-                radiance = F3s(0.0f);
-                smpl = 0;
-                nRetries++;
-            }
-            else
-                smpl = smpl + 1;
-            if (smpl < p.u.SampleCount)
-            {
-                wf.meta[slot].z = smpl << 16; // bounce = 0
-                wf.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-                restart = true;
-            }
-            else
-                wf.slotRad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+            restart = finishSample(p, wf, slot, meta, radiance, nSamples, nRetries);
+            if (restart)
+                wf.meta[slot].z = meta.z;
         }
         else
             wf.rad[slot] = r4; // the slot is already in the next queue (k_shade)
-        // one atomic per wave and store call, not per slot: every sample but the last of a multi-sample launch ends here
-        const uint64_t mask = __ballot(restart);
-        if (mask)
-        {
-            const uint32_t lane = threadIdx.x & 63u;
-            const int leader = __ffsll((unsigned long long)mask) - 1;
-            uint32_t base = 0;
-            if ((int)lane == leader)
-                base = atomicAdd(&wf.counters[C_RESTART], (uint32_t)__popcll(mask));
-            base = __shfl(base, leader);
-            if (restart)
-                wf.restartQueue[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = slot;
-        }
+        // the slot cannot join the next queue directly: k_trace_closest of the next bounce may already be consuming it
+        pushRestarts(wf, restart, slot);
     }
 };
 
@@ -673,21 +666,21 @@ struct PathCounters
     uint32_t nSeg = 0, nHit = 0, nSmp = 0, nRetry = 0;
 };
 
-// Runs a slot to the end of its launch -- or, with stopAfterSample, to the end of the sample it is in (smpl then tells
+// Runs a slot to the end of its launch -- or, with ONE_SAMPLE, to the end of the sample it is in (smpl then tells
 // the caller whether samples remain).  `fresh` = start with a new sample (primary ray); otherwise continue the
 // current sample at `bounce` with the given ray / throughput.
 // MODE 0: opaque geometry, fixed 1x1 textures; 1: + ray differentials and the sampler (TEX); 2: + any-hit stages (ALPHA)
-template <int MODE>
+template <int MODE, bool ONE_SAMPLE = false>
 PT_DEV f3 runPath(const LaunchParams &p, const SceneView &sv, const TraceScene &sc, Stack &st, uint32_t pixel, uint32_t &rng,
                   f3 radiance, f3 throughput, f3 ro, f3 rd, DiffRays diff, float maxRoughness, uint32_t bounce, int &smpl, bool fresh,
-                  PathCounters &pc, bool stopAfterSample = false)
+                  PathCounters &pc)
 {
     constexpr bool TEX = MODE >= 1, ALPHA = MODE == 2;
     for (;;)
     {
         if (fresh)
         {
-            if (smpl >= (int)p.u.SampleCount || stopAfterSample)
+            if (ONE_SAMPLE || smpl >= (int)p.u.SampleCount) // ONE_SAMPLE (k_tail): no sample is ever started here
                 break;
             throughput = F3s(1.0f);
             startSample<TEX>(p, pixel, rng, ro, rd, diff);
@@ -778,10 +771,41 @@ __global__ void __launch_bounds__(kBlock) k_megakernel(LaunchParams p, SceneView
 // with samples left (multi-sample launch, NaN restart) goes back through the restart queue and the wavefront
 // kernels: finishing ALL its samples here, one thread per path at 2 waves / SIMD, made a SampleCount = 8 launch six
 // times slower than eight one-sample launches.
+// k_tail is latency-bound at whatever occupancy it gets: a 32-entry LDS stack (overflow into the global region of the
+// traversal kernels) instead of 64 entries lifts the LDS limit of two blocks per CU, and 168 VGPRs (7 spilled dwords in
+// mode 0) make it three waves per SIMD: 1.50 -> 1.08 ms per chess_like step
+#ifndef PT_TAIL_ATTR
+#define PT_TAIL_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
+#endif
+#ifndef PT_TAIL_LDS
+#define PT_TAIL_LDS 32
+#endif
+#ifndef PT_TAIL_TEX_ATTR
+#define PT_TAIL_TEX_ATTR PT_TAIL_ATTR
+#endif
 template <int MODE>
-__global__ void __launch_bounds__(kBlock) k_tail(LaunchParams p, SceneView sv, TraceScene sc, Wavefront wf, int qin, uint32_t count)
+PT_DEV void tailBody(const LaunchParams &p, const SceneView &sv, const TraceScene &sc, const Wavefront &wf, int qin, uint32_t count);
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) k_tail(LaunchParams p, SceneView sv, TraceScene sc, Wavefront wf, int qin, uint32_t count);
+template <>
+__global__ void __launch_bounds__(kBlock) PT_TAIL_ATTR k_tail<0>(LaunchParams p, SceneView sv, TraceScene sc, Wavefront wf, int qin, uint32_t count)
 {
-    PT_DECLARE_STACK(st, kLdsStackMega, (uint32_t *)nullptr)
+    tailBody<0>(p, sv, sc, wf, qin, count);
+}
+template <>
+__global__ void __launch_bounds__(kBlock) PT_TAIL_TEX_ATTR k_tail<1>(LaunchParams p, SceneView sv, TraceScene sc, Wavefront wf, int qin, uint32_t count)
+{
+    tailBody<1>(p, sv, sc, wf, qin, count);
+}
+template <>
+__global__ void __launch_bounds__(kBlock) PT_TAIL_TEX_ATTR k_tail<2>(LaunchParams p, SceneView sv, TraceScene sc, Wavefront wf, int qin, uint32_t count)
+{
+    tailBody<2>(p, sv, sc, wf, qin, count);
+}
+template <int MODE>
+PT_DEV void tailBody(const LaunchParams &p, const SceneView &sv, const TraceScene &sc, const Wavefront &wf, int qin, uint32_t count)
+{
+    PT_DECLARE_STACK(st, PT_TAIL_LDS, wf.spill)
     PathCounters pc;
     for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x)
     {
@@ -800,8 +824,8 @@ __global__ void __launch_bounds__(kBlock) k_tail(LaunchParams p, SceneView sv, T
             else
                 diff.rxOrigin = diff.rxDirection = diff.ryOrigin = diff.ryDirection = F3s(0.0f);
             int smpl = (int)(meta.z >> 16);
-            const f3 radiance = runPath<MODE>(p, sv, sc, st, meta.y, rng, F3(r4.x, r4.y, r4.z), F3(t4.x, t4.y, t4.z), F3(o4.x, o4.y, o4.z),
-                                             F3(d4.x, d4.y, d4.z), diff, o4.w, meta.z & 0xffffu, smpl, false, pc, true);
+            const f3 radiance = runPath<MODE, true>(p, sv, sc, st, meta.y, rng, F3(r4.x, r4.y, r4.z), F3(t4.x, t4.y, t4.z), F3(o4.x, o4.y, o4.z),
+                                                   F3(d4.x, d4.y, d4.z), diff, o4.w, meta.z & 0xffffu, smpl, false, pc);
             if (smpl < (int)p.u.SampleCount)
             {
                 wf.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
@@ -812,17 +836,7 @@ __global__ void __launch_bounds__(kBlock) k_tail(LaunchParams p, SceneView sv, T
             else
                 wf.slotRad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
         }
-        const uint64_t mask = __ballot(restart);
-        if (mask) // k_restart draws the next primary ray before the queue is consumed
-        {
-            const uint32_t lane = threadIdx.x & 63u;
-            uint32_t at = 0;
-            if (lane == 0)
-                at = atomicAdd(&wf.counters[C_RESTART], (uint32_t)__popcll(mask));
-            at = __shfl(at, 0);
-            if (restart)
-                wf.restartQueue[at + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = restartSlot;
-        }
+        pushRestarts(wf, restart, restartSlot); // k_restart draws the next primary ray before the queue is consumed
     }
     if (st.overflow)
         atomicAdd(&wf.counters[C_OVERFLOW], 1u);
@@ -2368,7 +2382,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
             if (bt.shadowPending) // k_tail continues from rad[slot]
                 HIP_TRY(r, hipStreamWaitEvent(q.s, q.evShadow[bt.shadowSlot], 0));
             HIP_TRY(r, hipEventRecord(q.evT0, q.s));
-            const dim3 grid(gridFor(bt.active, kBlock, 1u << 20));
+            const dim3 grid(gridFor(bt.active, kBlock, kMaxPersistentThreads / kBlock)); // grid-stride loop; the spill region holds this many threads
             if (mode == 2)
                 k_tail<2><<<grid, kBlock, 0, q.s>>>(bt.p, sv, sc, bt.wf, bt.qin, bt.active);
             else if (mode == 1)
