@@ -223,7 +223,10 @@ PT_DEV void blockAddCounter(uint32_t *__restrict__ counter, uint32_t v)
     __syncthreads();
 }
 
-constexpr uint32_t kShadeItems = 4; // queue entries per thread per block-wide append in k_shade
+#ifndef PT_SHADE_ITEMS
+#define PT_SHADE_ITEMS 4
+#endif
+constexpr uint32_t kShadeItems = PT_SHADE_ITEMS; // queue entries per thread per block-wide append in k_shade
 constexpr uint32_t kDeadPair = 0xfffffffeu; // hitPair of a slot outside the image (ragged edge tiles)
 
 // No queue atomics here: queue 0 is the identity over all slots (the host sets its count);
