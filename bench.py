@@ -208,7 +208,7 @@ def main():
         shadow_ms += st.lastShadowMs
         tail_ms += st.lastTailMs
         trace_launches += st.traceLaunches // 2
-        closest_rays += st.segments
+        closest_rays += st.tracedRays
         segments, shadow = st.segments, st.shadowRays
     barrier()
     elapsed = time.perf_counter() - t0

@@ -345,6 +345,8 @@ typedef struct PtxStats {
     double lastShadeMs;      /* ... spent in k_shade                                */
     double lastShadowMs;     /* ... spent in k_trace_shadow                         */
     double lastTailMs;       /* ... spent in k_tail (fused late bounces)            */
+    uint64_t tracedRays;     /* closest-hit queries carried by the k_trace_closest launches timed in lastTraceMs
+                                (segments also counts the ones k_tail traces itself) */
 } PtxStats;
 
 typedef struct PtxRenderer PtxRenderer;

@@ -125,6 +125,7 @@ class Stats(C.Structure):
         ("pathSamples", C.c_uint64), ("segments", C.c_uint64), ("shadowRays", C.c_uint64), ("retries", C.c_uint64),
         ("triangles", C.c_uint64), ("bvhNodes", C.c_uint64), ("lastRenderMs", C.c_double), ("lastTraceMs", C.c_double),
         ("lastBuildMs", C.c_double), ("traceLaunches", C.c_uint64), ("lastShadeMs", C.c_double), ("lastShadowMs", C.c_double), ("lastTailMs", C.c_double),
+        ("tracedRays", C.c_uint64),
     ]
 
 

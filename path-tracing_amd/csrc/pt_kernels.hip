@@ -2212,6 +2212,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
 
     r->stats.pathSamples = r->stats.segments = r->stats.shadowRays = r->stats.retries = 0;
     r->stats.traceLaunches = 0;
+    r->stats.tracedRays = 0;
     r->stats.lastTraceMs = 0.0;
     r->stats.lastShadeMs = r->stats.lastShadowMs = r->stats.lastTailMs = 0.0;
     HIP_TRY(r, hipEventRecord(r->evA, r->stream));
@@ -2296,7 +2297,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
         int shadowSlot = 0;
         Phase phase = PH_ISSUE;
         double traceMs = 0, shadeMs = 0, shadowMs = 0, tailMs = 0;
-        uint64_t segments = 0, launches = 0;
+        uint64_t segments = 0, launches = 0, tracedRays = 0;
     };
     Batch B[PtxRenderer::kMaxBatches];
 
@@ -2456,6 +2457,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
                 fprintf(stderr, "[ptx] batch %d bounce %llu: %u rays closest %.3f ms (%.2f Grays/s) | shade %.3f ms | %u shadow rays\n", index,
                         (unsigned long long)bt.iteration, bt.active, closestMs, bt.active / closestMs / 1e6, ms, shadowCount);
             bt.segments += bt.iteration == 1 ? (uint64_t)bt.p.ownedPixels * bt.p.frames : bt.active;
+            bt.tracedRays += bt.iteration == 1 ? (uint64_t)bt.p.ownedPixels * bt.p.frames : bt.active;
             bt.launches += 2;
             bt.active = q.hCounters[qout ? C_ACTIVE1 : C_ACTIVE0];
             bt.qin = qout;
@@ -2545,6 +2547,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
         r->stats.lastShadowMs += bt.shadowMs;
         r->stats.lastTailMs += bt.tailMs;
         r->stats.segments += bt.segments;
+        r->stats.tracedRays += bt.tracedRays;
         r->stats.traceLaunches += bt.launches;
         // every counter block was copied to the host by the sub-batch's final drain
         hits += bt.res->hCounters[C_HITS];
