@@ -248,8 +248,8 @@ __global__ void __launch_bounds__(kBlock) k_generate(LaunchParams p, Wavefront w
             meta.x = rng;
             wf.rayO[slot] = make_float4(o.x, o.y, o.z, 0.0f); // MaxRoughness = 0, raygen.rgen:60
             wf.rayD[slot] = make_float4(d.x, d.y, d.z, 0.0f);
-            wf.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-            wf.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            // thr[slot] = 1 and rad[slot] = 0 are implied by meta.z == 0 (first bounce of the first sample): 32 bytes per
+            // slot neither written here nor read by the first k_shade
         }
         else
         {
@@ -418,7 +418,12 @@ PT_DEV void shadeBody(const LaunchParams &p, const SceneView &sv, const Wavefron
         {
             uint4 meta = wf.meta[slot];
             const float4 hit = wf.hit[slot];
-            const float4 r4 = wf.rad[slot], t4 = wf.thr[slot];
+            // first bounce of a sample: throughput = 1 (raygen.rgen:52); and of the first sample: radiance = 0 (:42)
+            float4 r4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), t4 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+            if (meta.z != 0u)
+                r4 = wf.rad[slot];
+            if ((meta.z & 0xffffu) != 0u)
+                t4 = wf.thr[slot];
             f3 radiance = F3(r4.x, r4.y, r4.z), throughput = F3(t4.x, t4.y, t4.z);
 
             if (pair == 0xffffffffu)
@@ -629,8 +634,7 @@ __global__ void __launch_bounds__(kBlock) k_restart(LaunchParams p, Wavefront wf
         startSlotSample(p, wf, slot, meta.y, meta.x, o, d);
         wf.rayO[slot] = make_float4(o.x, o.y, o.z, 0.0f);
         wf.rayD[slot] = make_float4(d.x, d.y, d.z, 0.0f);
-        wf.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-        wf.meta[slot] = meta;
+        wf.meta[slot] = meta; // bounce 0: thr[slot] = 1 is implied
     }
 }
 
@@ -819,7 +823,12 @@ PT_DEV void tailBody(const LaunchParams &p, const SceneView &sv, const TraceScen
         {
             const uint32_t slot = wf.queue[qin][i];
             const uint4 meta = wf.meta[slot];
-            const float4 o4 = wf.rayO[slot], d4 = wf.rayD[slot], t4 = wf.thr[slot], r4 = wf.rad[slot];
+            const float4 o4 = wf.rayO[slot], d4 = wf.rayD[slot];
+            float4 r4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), t4 = make_float4(1.0f, 1.0f, 1.0f, 0.0f); // see k_shade
+            if (meta.z != 0u)
+                r4 = wf.rad[slot];
+            if ((meta.z & 0xffffu) != 0u)
+                t4 = wf.thr[slot];
             uint32_t rng = meta.x;
             DiffRays diff;
             if (MODE >= 1)
