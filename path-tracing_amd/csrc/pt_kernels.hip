@@ -1300,7 +1300,6 @@ struct PtxRenderer
     int device = 0;
     uint32_t backend = PTX_BACKEND_WAVEFRONT;
     hipStream_t stream = nullptr;
-    hipStream_t aux = nullptr; // k_trace_shadow(b) runs here, beside k_trace_closest(b+1) on `stream`
     bool ownStream = false;
     std::string error;
 
@@ -1378,14 +1377,13 @@ struct PtxRenderer
     DevBuf<float4> diffs; // 3 x slotCapacity ray differentials, only for scenes with textures
     size_t diffCapacity = 0;
     DevBuf<uint4> meta;
-    DevBuf<uint32_t> hitPair, queue0, queue1, shadowQueue, restartQueue, counters, spill, spillAux;
+    DevBuf<uint32_t> hitPair, queue0, queue1, shadowQueue, restartQueue, counters, spill;
     uint32_t *hostCounters = nullptr; // pinned
 
     DevBuf<float> testIn, testOut;
     DevBuf<PtxLightsUbo> testUbo;
 
-    hipEvent_t evA = nullptr, evB = nullptr, evT0 = nullptr, evT1 = nullptr, evT2 = nullptr, evT3 = nullptr;
-    hipEvent_t evShade = nullptr, evShadow[2] = { nullptr, nullptr }, evX0[2] = { nullptr, nullptr };
+    hipEvent_t evA = nullptr, evB = nullptr, evT0 = nullptr, evT1 = nullptr; // render / build span; ptx_trace_rays kernel span
 
     // sub-batches of one ptx_render_frames call, driven as interleaved state machines
     struct BatchRes
@@ -1549,20 +1547,9 @@ int ptx_create(const PtxDeviceDesc *desc, PtxRenderer **out)
     (void)hipEventCreate(&r->evB);
     (void)hipEventCreate(&r->evT0);
     (void)hipEventCreate(&r->evT1);
-    (void)hipEventCreate(&r->evT2);
-    (void)hipEventCreate(&r->evT3);
-    (void)hipEventCreateWithFlags(&r->evShade, hipEventDisableTiming);
-    for (int k = 0; k < 2; k++)
-    {
-        (void)hipEventCreate(&r->evShadow[k]);
-        (void)hipEventCreate(&r->evX0[k]);
-    }
-    if (hipStreamCreateWithFlags(&r->aux, hipStreamNonBlocking) != hipSuccess)
-        r->aux = nullptr;
     (void)hipHostMalloc(reinterpret_cast<void **>(&r->hostCounters), C_COUNT * sizeof(uint32_t), hipHostMallocDefault);
     if (r->counters.alloc(C_COUNT) != hipSuccess || r->lights.alloc(1) != hipSuccess || !r->hostCounters ||
-        r->spill.alloc((size_t)kGlobalSpill * kMaxPersistentThreads) != hipSuccess ||
-        r->spillAux.alloc((size_t)kGlobalSpill * kMaxPersistentThreads) != hipSuccess)
+        r->spill.alloc((size_t)kGlobalSpill * kMaxPersistentThreads) != hipSuccess)
     {
         ptx_destroy(r);
         return PTX_ERROR_OUT_OF_MEMORY;
@@ -1583,7 +1570,7 @@ void ptx_destroy(PtxRenderer *r)
     r->pairs.release(); r->pairFirst.release(); r->lights.release(); r->nodes.release(); r->tris.release(); r->shadeTris.release();
     r->image.release(); r->rayO.release(); r->rayD.release(); r->thr.release(); r->rad.release(); r->hit.release();
     r->shO.release(); r->shD.release(); r->shC.release(); r->slotRad.release(); r->diffs.release(); r->diffCapacity = 0; r->decal.release(); r->decalT.release(); r->decalCapacity = 0; r->meta.release(); r->hitPair.release();
-    r->queue0.release(); r->queue1.release(); r->shadowQueue.release(); r->counters.release(); r->spill.release(); r->spillAux.release(); r->restartQueue.release();
+    r->queue0.release(); r->queue1.release(); r->shadowQueue.release(); r->counters.release(); r->spill.release(); r->restartQueue.release();
     r->testIn.release(); r->testOut.release(); r->testUbo.release();
     for (int b = 0; b < r->batchesReady; b++)
     {
@@ -1607,19 +1594,6 @@ void ptx_destroy(PtxRenderer *r)
     if (r->evB) (void)hipEventDestroy(r->evB);
     if (r->evT0) (void)hipEventDestroy(r->evT0);
     if (r->evT1) (void)hipEventDestroy(r->evT1);
-    if (r->evT2) (void)hipEventDestroy(r->evT2);
-    if (r->evT3) (void)hipEventDestroy(r->evT3);
-    if (r->evShade) (void)hipEventDestroy(r->evShade);
-    for (int k = 0; k < 2; k++)
-    {
-        if (r->evShadow[k]) (void)hipEventDestroy(r->evShadow[k]);
-        if (r->evX0[k]) (void)hipEventDestroy(r->evX0[k]);
-    }
-    if (r->aux)
-    {
-        (void)hipStreamSynchronize(r->aux);
-        (void)hipStreamDestroy(r->aux);
-    }
     if (r->ownStream && r->stream)
         (void)hipStreamDestroy(r->stream);
     delete r;
