@@ -1260,8 +1260,14 @@ static PtoHit traceClosest(const PtoScene *s, v3 o, v3 d, float tmin, float tmax
     {
         const BvhNode *n = &s->nodes[stack[--sp]];
         float tn;
-        /* <= on the current best so equal-t candidates are still visited (id tie-break) */
-        if (!slab(n, o, id, tmin, best.tri == 0xffffffffu ? tmax : best.t, &tn))
+        /* Culling against the current best must leave room for the triangle test's own error in t: Moeller-Trumbore
+         * from a far origin is good to ~1e-5 relative, so a second triangle in the same plane can report the SAME t
+         * while the point o + t d lies a few 1e-5 outside that triangle's padded box (found on street_like at
+         * 1920x1080: two overlapping coplanar triangles, bit-identical t, box entry 3e-5 later than t -- the BVH walk
+         * kept the larger id where brute force keeps the smaller).  Equal-t candidates must be visited for the id
+         * tie-break anyway; the limit is widened by 1e-4 relative. */
+        const float limit = best.tri == 0xffffffffu ? tmax : f_min(best.t * 1.0001f, tmax);
+        if (!slab(n, o, id, tmin, limit, &tn))
             continue;
         if (st)
             st->nodesVisited++;
@@ -1279,6 +1285,44 @@ static PtoHit traceClosest(const PtoScene *s, v3 o, v3 d, float tmin, float tmax
         }
     }
     return best;
+}
+
+/* debugging aid: which nodes on the way to the leaf of triangle `tri` pass the slab test of this ray? */
+PTX_API void pto_debug_path(const PtoScene *s, const float *ray, uint32_t tri)
+{
+    const v3 o = V3(ray[0], ray[1], ray[2]), d = V3(ray[4], ray[5], ray[6]);
+    const v3 id = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const float tmin = ray[3], tmax = ray[7];
+    /* parent links by one pass */
+    int32_t *parent = (int32_t *)malloc((size_t)s->nodeCount * 4);
+    int32_t leaf = -1;
+    parent[0] = -1;
+    for (uint32_t i = 0; i < s->nodeCount; i++)
+    {
+        const BvhNode *n = &s->nodes[i];
+        if (n->count)
+        {
+            for (uint32_t k = 0; k < n->count; k++)
+                if (s->bvhTris[n->left + k] == tri)
+                    leaf = (int32_t)i;
+        }
+        else
+        {
+            parent[n->left] = (int32_t)i;
+            parent[n->left + 1] = (int32_t)i;
+        }
+    }
+    int depth = 0;
+    for (int32_t i = leaf; i >= 0; i = parent[i], depth++)
+    {
+        const BvhNode *n = &s->nodes[i];
+        float tn;
+        const int ok = slab(n, o, id, tmin, tmax, &tn);
+        fprintf(stderr, "[pto] node %d (depth-from-leaf %d, count %u) slab %d tn %.9g lo (%.9g %.9g %.9g) hi (%.9g %.9g %.9g)\n", i, depth, n->count, ok, tn,
+                n->lo[0], n->lo[1], n->lo[2], n->hi[0], n->hi[1], n->hi[2]);
+    }
+    fprintf(stderr, "[pto] depth %d, id (%.9g %.9g %.9g)\n", depth, id.x, id.y, id.z);
+    free(parent);
 }
 
 /* occlusionAnyhit.rahit:35-53: a shadow ray passes through any hit whose alpha is below 1 */
@@ -1774,6 +1818,16 @@ static inline Vtx transformVertex(const Pair *pr, Vtx v)
     return v;
 }
 
+/* PTO_DEBUG_PIXEL="x,y": print the light-sampling and BSDF inputs / outputs of every hit of that pixel (bit patterns),
+ * to bisect a mismatch against the HIP path with ptx_test_eval */
+static __thread int g_dbgPixel;
+static int g_dbgX = -1, g_dbgY = -1;
+static void dbg3(const char *name, v3 a)
+{
+    fprintf(stderr, "[pto] %s %08x %08x %08x (%.9g %.9g %.9g)\n", name, f2u(a.x), f2u(a.y), f2u(a.z), a.x, a.y, a.z);
+}
+static void dbg1(const char *name, float a) { fprintf(stderr, "[pto] %s %08x (%.9g)\n", name, f2u(a), a); }
+
 /* closestHit.rchit:52-161 */
 static void closestHit(const PtoScene *s, const PtxLightsUbo *lights, v3 rayOriginW, v3 rayDirW, const PtoHit *hit,
                        Payload *payload)
@@ -1859,6 +1913,21 @@ static void closestHit(const PtoScene *s, const PtxLightsUbo *lights, v3 rayOrig
     const LightSample light = sampleLight(lights, u3, rayOrigin, &lightPdf);
     const v3 L = v_normalize(m3_mul(invTBN, v_neg(light.Direction)));
     const v3 lightBsdf = evaluateBSDF(&material, V, L, &lightSmplPdf);
+    if (g_dbgPixel)
+    {
+        dbg3("rayOriginW", rayOriginW); dbg3("rayDirW", rayDirW); dbg1("hit.t", hit->t);
+        fprintf(stderr, "[pto] hit.tri %u\n", hit->tri);
+        dbg3("u3", u3); dbg3("rayOrigin", rayOrigin); dbg3("light.Direction", light.Direction); dbg1("light.Distance", light.Distance);
+        dbg3("light.Color", light.Color); dbg1("light.Attenuation", light.Attenuation); dbg1("lightPdf", lightPdf);
+        dbg3("V", V); dbg3("L", L); dbg3("lightBsdf", lightBsdf); dbg1("lightSmplPdf", lightSmplPdf);
+        dbg3("material.Color", material.Color); dbg1("material.Roughness", material.Roughness); dbg1("material.Metalness", material.Metalness);
+        dbg1("material.Eta", material.Eta); dbg1("material.Transmission", material.Transmission); dbg3("material.EmissiveColor", material.EmissiveColor);
+        dbg3("bsdf.Direction", bsdf.Direction); dbg3("bsdf.Color", bsdf.Color); dbg1("bsdf.Pdf", bsdf.Pdf);
+        dbg3("N", N); dbg3("vertex.Position", vertex.Position); dbg3("vertex.Normal", vertex.Normal);
+        dbg3("invTBN.c0", invTBN.c0); dbg3("invTBN.c1", invTBN.c1); dbg3("invTBN.c2", invTBN.c2);
+        dbg3("v0.P", v0.Position); dbg3("v1.P", v1.Position); dbg3("v2.P", v2.Position); dbg3("v0.N", v0.Normal); dbg3("v1.N", v1.Normal); dbg3("v2.N", v2.Normal);
+        dbg3("geometricNormal", geometricNormal); dbg3("bary", bary); dbg3("vertex.Tangent", vertex.Tangent); dbg3("vertex.Bitangent", vertex.Bitangent);
+    }
 
     payload->Direction = v_normalize(m3_mul(TBN, bsdf.Direction));
     if (isRefracted)
@@ -1986,6 +2055,7 @@ static void raygenPixel(const PtoScene *s, const PtxRaygenUniformData *U, const 
     v3 radiance = v3s(0.0f);
     Payload payload;
     memset(&payload, 0, sizeof(payload));
+    g_dbgPixel = (int)px == g_dbgX && (int)py == g_dbgY;
 
     for (int smpl = 0; smpl < (int)U->SampleCount; smpl++)
     {
@@ -2085,6 +2155,9 @@ int pto_render(const PtoScene *s, const PtxRaygenUniformData *U, const PtxLights
     PtoStats total;
     memset(&total, 0, sizeof(total));
     total.triangles = s->triCount;
+    g_dbgX = g_dbgY = -1;
+    if (getenv("PTO_DEBUG_PIXEL"))
+        sscanf(getenv("PTO_DEBUG_PIXEL"), "%d,%d", &g_dbgX, &g_dbgY);
 #ifdef _OPENMP
     if (threads > 0)
         omp_set_num_threads(threads);

@@ -897,6 +897,12 @@ PT_DEV int visitNode(const BvhNode *__restrict__ np, f3 o, f3 id, float tmin, fl
     return (int)h0 + (int)h1 + (int)h2 + (int)h3;
 }
 
+// Culling against the current best leaves room for the triangle test's own error in t (Moeller-Trumbore from a far
+// origin: ~1e-5 relative): two triangles in one plane can report the SAME t while the point o + t d lies a few 1e-5
+// outside the second one's padded box; it must still be visited for the id tie-break (seen by the oracle's tree on
+// street_like at 1920x1080; this tree's quantisation margin happened to cover it).
+constexpr float kCullSlack = 1.0001f;
+
 // A ray whose origin/direction is not finite, whose direction is zero or whose interval is
 // empty hits nothing (the triangle test rejects it); without this early-out its NaN plane
 // distances would drop out of every fminf/fmaxf and it would walk the whole tree.
@@ -939,7 +945,7 @@ PT_DEV bool traceRay(const TraceScene &sc, f3 o, f3 d, float tmin, float tmax, S
             if (STATS)
                 (*nodeVisits)++;
             int r0, r1, r2, r3;
-            const int h = visitNode(&sc.nodes[ref], o, id, tmin, best.t, r0, r1, r2, r3);
+            const int h = visitNode(&sc.nodes[ref], o, id, tmin, ANY_HIT ? best.t : best.t * kCullSlack, r0, r1, r2, r3);
             if (h > 3) st.push((uint32_t)r3);
             if (h > 2) st.push((uint32_t)r2);
             if (h > 1) st.push((uint32_t)r1);
@@ -1110,7 +1116,7 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
             if (have && ref >= 0 && ref != kRefDone)
             {
                 int r0, r1, r2, r3;
-                const int h = visitNode(&sc.nodes[ref], o, id, tmin, best.t, r0, r1, r2, r3);
+                const int h = visitNode(&sc.nodes[ref], o, id, tmin, ANY_HIT ? best.t : best.t * kCullSlack, r0, r1, r2, r3);
                 if (h > 3) st.push((uint32_t)r3);
                 if (h > 2) st.push((uint32_t)r2);
                 if (h > 1) st.push((uint32_t)r1);
