@@ -338,6 +338,47 @@ def test_full_size_frame_matches_oracle(pkg, orc, name, frames):
     assert differing == 0, f"{differing} of {W * H} pixels are not bit-identical (rel-L2 {util.rel_l2(img, ref)})"
 
 
+@pytest.mark.parametrize("tag,name,W,H,frames,depth,lens,sample_count,shard,backend", [
+    ("4K depth 16", "street_like", 3840, 2160, 1, 16, 0.0, 1, None, 0),  # BASELINE configs[4] size, 64 point lights
+    ("thin lens", "chess_like", 1920, 1080, 1, 8, 0.05, 1, None, 0),
+    ("SampleCount 4 in one launch", "chess_like", 1920, 1080, 1, 8, 0.0, 4, None, 0),  # restart queue above the tail threshold
+    ("rank 3 of 8, 8 spp", "atrium_like", 1920, 1080, 2, 12, 0.0, 1, (3, 8, 32), 0),  # the shape of a weak-scaling rank
+    ("megakernel", "temple_like", 1920, 1080, 1, 8, 0.0, 1, None, 1),
+])
+def test_full_size_variants_match_oracle(pkg, orc, tag, name, W, H, frames, depth, lens, sample_count, shard, backend):
+    import torch  # noqa: F401
+
+    scene = pkg.Scene(name, 1.0)
+    lights = scene.lights
+    r = pkg.Renderer(backend=backend)
+    r.upload(scene)
+    r.resize(W, H)
+    oshard = None
+    if shard:
+        r.set_tile_shard(*shard)
+        oshard = pkg.TileShard(*shard)
+    osc = orc.OracleScene(scene.desc)
+    ref = np.zeros((H, W, 4), np.float32)
+    seg = gseg = 0
+    if sample_count == 1:
+        r.render_frames(scene.uniform(W, H, bounces=depth, lens_radius=lens, focal_distance=6.0), lights, 0, frames)
+        gseg = r.stats().segments
+    for f in range(frames):
+        u = scene.uniform(W, H, bounces=depth, sample_count=sample_count, total_samples=f * sample_count, lens_radius=lens, focal_distance=6.0)
+        if sample_count > 1:
+            r.render(u, lights)
+            gseg += r.stats().segments
+        _, ost = osc.render(u, lights, W, H, accum=ref, shard=oshard)
+        seg += ost.segments
+    img = r.readback()
+    r.close()
+    assert gseg == seg
+    if shard:  # pixels of other ranks' tiles are untouched on both sides
+        assert (img[..., :3] != 0).any()
+    differing = int((img.view(np.uint32) != ref.view(np.uint32)).any(axis=-1).sum())
+    assert differing == 0, f"{tag}: {differing} of {W * H} pixels are not bit-identical (rel-L2 {util.rel_l2(img, ref)})"
+
+
 def test_error_behaviour(pkg):
     import torch  # noqa: F401
 
