@@ -136,7 +136,7 @@ def test_image_writers_round_trip(pkg, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(72, 128), (270, 480), (9, 13), (1, 1)])
+@pytest.mark.parametrize("shape", [(72, 128), (270, 480), (9, 13), (1, 1), (1080, 1920), (2160, 3840)])  # the last two: 8 and 9 bloom levels
 def test_output_stage_matches_oracle(pkg, orc, shape):
     h, w = shape
     acc = _synthetic_sum(h, w, samples=8, seed=h) if h > 8 else np.random.default_rng(0).uniform(0, 30, (h, w, 4)).astype(np.float32)
