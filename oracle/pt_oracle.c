@@ -923,7 +923,17 @@ PtoScene *pto_scene_create_posed(const PtxSceneDesc *desc, const PtxTransform *i
                     const PtxVertex *vx = &pr->vb[pr->ib[q * 3 + c]];
                     w[c] = xformPoint(pr->M, V3(vx->Position[0], vx->Position[1], vx->Position[2]));
                 }
-                const v3 a = v_sub(w[1], w[0]), b = v_sub(w[2], w[0]);
+                v3 a = v_sub(w[1], w[0]), b = v_sub(w[2], w[0]);
+                /* A zero-area triangle (repeated or collinear vertices with an exactly vanishing edge cross product) is
+                 * never hit -- as in Vulkan, where degenerate triangles generate no intersections.  Without this,
+                 * det = e1 . (d x e2) is a rounding residue instead of 0 and the test "hits" it at a meaningless t
+                 * (atrium_like triangle 3608410 with e1 == e2: t = 16, u = v = -0 for a ray passing its vertex at
+                 * t = 29.65).  Zero edges make det exactly 0. */
+                {
+                    const v3 n = v_cross(a, b);
+                    if (n.x == 0.0f && n.y == 0.0f && n.z == 0.0f)
+                        a = b = v3s(0.0f);
+                }
                 s->v0[t * 3 + 0] = w[0].x; s->v0[t * 3 + 1] = w[0].y; s->v0[t * 3 + 2] = w[0].z;
                 s->e1[t * 3 + 0] = a.x; s->e1[t * 3 + 1] = a.y; s->e1[t * 3 + 2] = a.z;
                 s->e2[t * 3 + 0] = b.x; s->e2[t * 3 + 1] = b.y; s->e2[t * 3 + 2] = b.z;
@@ -1926,6 +1936,9 @@ static void closestHit(const PtoScene *s, const PtxLightsUbo *lights, v3 rayOrig
     {
         dbg3("rayOriginW", rayOriginW); dbg3("rayDirW", rayDirW); dbg1("hit.t", hit->t);
         fprintf(stderr, "[pto] hit.tri %u\n", hit->tri);
+        dbg3("tri.v0", V3(s->v0[hit->tri * 3], s->v0[hit->tri * 3 + 1], s->v0[hit->tri * 3 + 2]));
+        dbg3("tri.e1", V3(s->e1[hit->tri * 3], s->e1[hit->tri * 3 + 1], s->e1[hit->tri * 3 + 2]));
+        dbg3("tri.e2", V3(s->e2[hit->tri * 3], s->e2[hit->tri * 3 + 1], s->e2[hit->tri * 3 + 2]));
         dbg3("u3", u3); dbg3("rayOrigin", rayOrigin); dbg3("light.Direction", light.Direction); dbg1("light.Distance", light.Distance);
         dbg3("light.Color", light.Color); dbg1("light.Attenuation", light.Attenuation); dbg1("lightPdf", lightPdf);
         dbg3("V", V); dbg3("L", L); dbg3("lightBsdf", lightBsdf); dbg1("lightSmplPdf", lightSmplPdf);
@@ -1951,6 +1964,11 @@ static void closestHit(const PtoScene *s, const PtxLightsUbo *lights, v3 rayOrig
     payload->DirectLightPdf = lightPdf;
     payload->LightDirection = light.Direction;
     payload->LightDistance = light.Distance;
+    if (g_dbgPixel)
+    {
+        dbg3("payload.Position", payload->Position); dbg3("payload.Direction", payload->Direction);
+        dbg1("hit.u", hit->u); dbg1("hit.v", hit->v);
+    }
 
     /* :150-160 differentials of the continuation ray */
     if (isRefracted)

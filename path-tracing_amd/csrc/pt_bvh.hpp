@@ -93,7 +93,15 @@ __global__ void k_tri_setup(uint32_t n, uint32_t pairCount, const uint32_t *__re
         const uint32_t idx = indices[pr->indexOffset + prim * 3 + k];
         w[k] = xformPoint(pr->M, ld3(vertices[pr->vertexOffset + idx].Position));
     }
-    const f3 e1 = w[1] - w[0], e2 = w[2] - w[0];
+    f3 e1 = w[1] - w[0], e2 = w[2] - w[0];
+    // A zero-area triangle (exactly vanishing edge cross product: repeated or collinear vertices) is never hit, as in
+    // Vulkan.  Otherwise det = e1 . (d x e2) is a rounding residue instead of 0 and the test reports a meaningless t
+    // (found by the full-size sweep on atrium_like: e1 == e2, "hit" at t = 16 for a ray passing the vertex at 29.65).
+    {
+        const f3 n = cross(e1, e2);
+        if (n.x == 0.0f && n.y == 0.0f && n.z == 0.0f)
+            e1 = e2 = F3s(0.0f);
+    }
     Tri t;
     t.a = make_float4(w[0].x, w[0].y, w[0].z, e1.x);
     t.b = make_float4(e1.y, e1.z, e2.x, e2.y);
@@ -101,19 +109,21 @@ __global__ void k_tri_setup(uint32_t n, uint32_t pairCount, const uint32_t *__re
     triTmp[g] = t;
 
     // bounds from the same p0, p0+e1, p0+e2 the intersection test sees, padded so the slab
-    // test does not reject a ray the triangle test accepts.  ("Never" only up to the triangle test's own error:
-    // Moeller-Trumbore from a distant origin accepts points up to ~4e-4 of the triangle's size outside it -- seen on
-    // street_like 40 units from the camera, where the ORACLE's tree culled such a candidate.  Here the conservative
-    // 8-bit quantisation of the child boxes adds ~1/500 of the parent's extent on top of this padding, which covered
-    // every case found in 170 M rays; padding the leaves by 2e-3 of their extent as the oracle now does costs 2.7 %
-    // of the step and was not taken.)
+    // test does not reject a ray the triangle test accepts.  "Never" only up to the triangle test's own error:
+    // Moeller-Trumbore from a distant origin accepts points a few 1e-4 of the triangle's size outside it (seen on
+    // street_like 35 - 40 units from the camera: first the oracle's tree, then -- once in 600 M rays -- this one culled
+    // such a candidate and lost an equal-t tie to brute force).  Hence a term proportional to the triangle's extent
+    // next to the one proportional to the coordinates, the same rule as in the oracle.  Per axis: the error moves the
+    // accepted point WITHIN the triangle's plane, so a flat axis-aligned triangle needs no extra thickness (padding
+    // every axis by the largest extent makes floor-grazing shadow rays start inside their neighbours' boxes: -4 %).
+    // Cost: 2.7 % of the chess_like step.
     float l[3], h[3];
     const float p0[3] = { w[0].x, w[0].y, w[0].z }, a1[3] = { e1.x, e1.y, e1.z }, a2[3] = { e2.x, e2.y, e2.z };
     for (int a = 0; a < 3; a++)
     {
         const float q1 = p0[a] + a1[a], q2 = p0[a] + a2[a];
         const float mn = fminf(p0[a], fminf(q1, q2)), mx = fmaxf(p0[a], fmaxf(q1, q2));
-        const float pad = 1e-5f * fmaxf(fabsf(mn), fabsf(mx)) + 1e-7f;
+        const float pad = 1e-5f * fmaxf(fabsf(mn), fabsf(mx)) + 2e-3f * (mx - mn) + 1e-7f;
         l[a] = mn - pad;
         h[a] = mx + pad;
     }

@@ -379,6 +379,20 @@ def test_full_size_variants_match_oracle(pkg, orc, tag, name, W, H, frames, dept
     assert differing == 0, f"{tag}: {differing} of {W * H} pixels are not bit-identical (rel-L2 {util.rel_l2(img, ref)})"
 
 
+@pytest.mark.parametrize("name", ["street_like", "atrium_like"])
+def test_known_answer_rays_match_bruteforce(pkg, orc, name):
+    # the rays of util.known_answer_rays: the HIP tree against the oracle's brute force, bit for bit
+    scene = pkg.Scene(name, 1.0)
+    r = pkg.Renderer()
+    r.upload(scene)
+    rays = util.known_answer_ray_array(name)
+    hits, _ = r.trace_rays(rays, any_hit=False)
+    r.close()
+    b = orc.OracleScene(scene.desc, build_bvh=False).trace_closest(rays, brute_force=True)
+    for k, f in enumerate(("t", "u", "v")):
+        assert (hits[:, k].view(np.uint32) == b[f].view(np.uint32)).all(), f
+
+
 def test_error_behaviour(pkg):
     import torch  # noqa: F401
 

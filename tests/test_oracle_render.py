@@ -22,20 +22,22 @@ def test_bvh_equals_bruteforce(pkg, orc, name, detail):
     assert (osc.trace_any(rays, False) == osc.trace_any(rays, True)).all()
 
 
-def test_bvh_equal_t_tie_behind_its_own_box(pkg, orc):
-    """Known-answer regression: the primary ray of pixel (303, 666) of the 1920x1080 street_like frame crosses two
-    overlapping coplanar triangles that report the bit-identical t, while o + t d lies 2.6e-6 outside the padded box of
-    the one with the smaller id (Moeller-Trumbore from 12.5 units away).  The walk must still visit it for the id
-    tie-break, i.e. agree with brute force."""
-    s = pkg.Scene("street_like", 1.0)
+@pytest.mark.parametrize("name", ["street_like", "atrium_like"])
+def test_bvh_known_answer_rays(pkg, orc, name):
+    """Known-answer regression (util.known_answer_rays): the tree walk must agree with brute force on the rays that once
+    separated them.  The first street_like ray crosses two overlapping coplanar triangles that report the bit-identical
+    t while o + t d lies 2.6e-6 outside the padded box of the one with the smaller id (Moeller-Trumbore from 12.5 units
+    away); the atrium_like ray passes the vertex of a zero-area triangle, which must never be hit."""
+    s = pkg.Scene(name, 1.0)
     osc = orc.OracleScene(s.desc, build_bvh=True)
-    o = np.array([0xC2080000, 0x3FD9999C, 0x3F800000], np.uint32).view(np.float32)
-    d = np.array([0x3F4C1984, 0xBD9D0A84, 0xBF194709], np.uint32).view(np.float32)
-    ray = np.array([[o[0], o[1], o[2], 1e-5, d[0], d[1], d[2], 1e4]], np.float32)
-    a = osc.trace_closest(ray, brute_force=False)
-    b = osc.trace_closest(ray, brute_force=True)
-    assert b["tri"][0] == 2153290 and b["t"].view(np.uint32)[0] == 0x4148FDE3
-    assert a["tri"][0] == b["tri"][0] and a["t"][0] == b["t"][0]
+    rays = util.known_answer_ray_array(name)
+    a = osc.trace_closest(rays, brute_force=False)
+    b = osc.trace_closest(rays, brute_force=True)
+    assert (a["tri"] == b["tri"]).all() and (a["t"].view(np.uint32) == b["t"].view(np.uint32)).all()
+    if name == "street_like":
+        assert b["tri"].tolist() == [2153290, 2538466, 2475890] and b["t"].view(np.uint32)[0] == 0x4148FDE3
+    else:
+        assert b["tri"][0] != 3608410 and abs(float(b["t"][0]) - 28.1338) < 1e-3  # 3608410 has e1 == e2
 
 
 def test_render_bvh_equals_bruteforce_and_is_deterministic(pkg, orc):

@@ -104,3 +104,25 @@ def render_pair(pkg, orc, name, detail, W, H, frames, depth, backend=0, brute=Fa
     img = r.readback()
     r.close()
     return img, ref
+
+
+def known_answer_rays():
+    """Rays found by tools/full_size_sweep.py on which a tree walk once disagreed with brute force:
+    (scene, origin bits, direction bits).  street_like: equal-t ties of overlapping coplanar triangles whose accepted
+    point lies just outside the padded box of the triangle with the smaller id; atrium_like: a zero-area triangle
+    (e1 == e2) that the triangle test used to "hit" at a meaningless t."""
+    return [
+        ("street_like", (0xC2080000, 0x3FD9999C, 0x3F800000), (0x3F4C1984, 0xBD9D0A84, 0xBF194709)),
+        ("street_like", (0xC2080000, 0x3FD9999C, 0x3F800000), (0x3F7DA424, 0x3C974EA6, 0x3E09645E)),
+        ("street_like", (0xC2080000, 0x3FD9999C, 0x3F800000), (0x3F7CF07B, 0xBCDD1A10, 0x3E1B6E52)),
+        ("atrium_like", (0xC1880001, 0x3FE66663, 0xBF4CCCCD), (0x3F741F4C, 0x3E64162A, 0x3E4F6AC2)),
+    ]
+
+
+def known_answer_ray_array(scene_name):
+    rays = []
+    for name, o, d in known_answer_rays():
+        if name == scene_name:
+            ob, db = np.array(o, np.uint32).view(np.float32), np.array(d, np.uint32).view(np.float32)
+            rays.append([ob[0], ob[1], ob[2], 1e-5, db[0], db[1], db[2], 1e4])
+    return np.array(rays, np.float32)

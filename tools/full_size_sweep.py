@@ -5,7 +5,7 @@ the test-suite carries (tests/test_gpu_parity.py::test_full_size_*).  Needs an M
 coordinates, which PTO_DEBUG_PIXEL=x,y / pto_debug_path (oracle/pt_oracle.c) then help to bisect -- this is the sweep
 that found the oracle's two tree-walk culling bugs in round 1.
 
-Usage: python tools/full_size_sweep.py [--quick]"""
+Usage: python tools/full_size_sweep.py [--quick | --scale K]   (K multiplies the frame counts of the batch cases; default 4)"""
 import os
 import sys
 import time
@@ -54,6 +54,8 @@ def main():
         return len(ys)
 
     k = 1 if quick else 4
+    if "--scale" in sys.argv:
+        k = int(sys.argv[sys.argv.index("--scale") + 1])
     bad = 0
     bad += compare("batch", "chess_like", 1920, 1080, 2 * k, 8)
     bad += compare("batch", "street_like", 1920, 1080, 2 * k, 8)
