@@ -53,6 +53,32 @@ def main():
               f"{list(zip(xs.tolist(), ys.tolist()))[:6]}  ({time.time() - t0:.1f} s)", flush=True)
         return len(ys)
 
+    def animated(frames):
+        # animated_test posed at a few times: skinning + refit on the device against the oracle's posed scene
+        t0 = time.time()
+        W, H = 1920, 1080
+        scene = pkg.Scene("animated_test", 1.0)
+        r = pkg.Renderer()
+        r.upload(scene)
+        r.resize(W, H)
+        bad = 0
+        for step, dt in enumerate((0.0, 0.45, 1.3, 2.9)):
+            scene.update(dt)
+            it, bn = scene.animation_state()
+            r.update_animation(it, bn, rebuild=(step == 2))
+            r.reset()
+            u = scene.uniform(W, H, bounces=6)
+            r.render_frames(u, scene.lights, 0, frames)
+            img = r.readback()
+            osc = orc.OracleScene(scene.desc, instance_transforms=it, bones=bn)
+            ref = np.zeros((H, W, 4), np.float32)
+            for f in range(frames):
+                osc.render(scene.uniform(W, H, bounces=6, total_samples=f), scene.lights, W, H, accum=ref)
+            bad += int((img.view(np.uint32) != ref.view(np.uint32)).any(axis=-1).sum())
+        r.close()
+        print(f"{'animated':14s} {'animated_test':18s} {W}x{H} x{frames} x 4 poses: differing pixels {bad}  ({time.time() - t0:.1f} s)", flush=True)
+        return bad
+
     k = 1 if quick else 4
     if "--scale" in sys.argv:
         k = int(sys.argv[sys.argv.index("--scale") + 1])
@@ -68,6 +94,9 @@ def main():
     bad += compare("SampleCount 4", "chess_like", 1920, 1080, 1, 8, sample_count=4)
     bad += compare("rank 3 of 8", "atrium_like", 1920, 1080, 2 * k, 12, shard=(3, 8, 32))
     bad += compare("megakernel", "temple_like", 1920, 1080, 2, 8, backend=1)
+    for name in ("default", "roughness_cubes", "reuse_mesh_cubes", "texture_test", "alpha_test"):  # skyboxes, sampler, any-hit, decals
+        bad += compare("batch", name, 1920, 1080, 4 * k, 8)
+    bad += animated(k)
     print("TOTAL differing pixels:", bad)
     return 1 if bad else 0
 
