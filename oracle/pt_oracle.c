@@ -977,21 +977,35 @@ uint64_t pto_scene_triangle_count(const PtoScene *s) { return s->triCount; }
 static inline int intersectTri(const float *v0, const float *e1, const float *e2, v3 o, v3 d, float tmin, float tmax,
                                float *t, float *u, float *v)
 {
-    const v3 E1 = V3(e1[0], e1[1], e1[2]), E2 = V3(e2[0], e2[1], e2[2]);
+    const v3 E1 = V3(e1[0], e1[1], e1[2]), E2 = V3(e2[0], e2[1], e2[2]), V0 = V3(v0[0], v0[1], v0[2]);
     const v3 pvec = v_cross(d, E2);
     const float det = v_dot(E1, pvec);
     if (!(det != 0.0f))
         return 0;
     const float inv = 1.0f / det;
-    const v3 tvec = v_sub(o, V3(v0[0], v0[1], v0[2]));
-    const float uu = v_dot(tvec, pvec) * inv;
+    /* Two passes (see pt_device.hpp): plain Moeller-Trumbore from the ray origin loses (|o - v0| / size)^2 ulps in the
+     * barycentrics but its t is good; pass 1 solves from o with loose bounds on (u, v), pass 2 again from o + t1 d. */
+    v3 tvec = v_sub(o, V0);
+    float uu = v_dot(tvec, pvec) * inv;
+    if (!(uu >= -0.25f && uu <= 1.25f))
+        return 0;
+    v3 qvec = v_cross(tvec, E1);
+    float vv = v_dot(d, qvec) * inv;
+    if (!(vv >= -0.25f && uu + vv <= 1.25f))
+        return 0;
+    const float t1 = v_dot(E2, qvec) * inv;
+    if (!(t1 > -1e30f && t1 < 1e30f))
+        return 0;
+    /* pass 2 from o + t1 d: the offset to v0 is at most the triangle's size, the correction to t is tiny */
+    tvec = v_sub(v_add(o, v_scale(d, t1)), V0);
+    uu = v_dot(tvec, pvec) * inv;
     if (!(uu >= 0.0f && uu <= 1.0f))
         return 0;
-    const v3 qvec = v_cross(tvec, E1);
-    const float vv = v_dot(d, qvec) * inv;
+    qvec = v_cross(tvec, E1);
+    vv = v_dot(d, qvec) * inv;
     if (!(vv >= 0.0f && uu + vv <= 1.0f))
         return 0;
-    const float tt = v_dot(E2, qvec) * inv;
+    const float tt = t1 + v_dot(E2, qvec) * inv;
     if (!(tt > tmin && tt < tmax))
         return 0;
     *t = tt;
@@ -1066,12 +1080,10 @@ static void triBounds(const PtoScene *s, uint32_t t, float *lo, float *hi)
     }
     for (int a = 0; a < 3; a++)
     {
-        /* Padding so that the slab test does not reject a ray the triangle test accepts.  The triangle test is only
-         * as good as Moeller-Trumbore from a distant origin: 40 units from the camera it accepted a point 1.1e-4
-         * above a 0.3-unit triangle (street_like, 1920x1080, frame 1, pixel 1119,560), hence the term proportional to
-         * the triangle's extent (per axis: the error moves the point within the triangle's plane); a term proportional
-         * to the coordinates alone (1e-5) missed that. */
-        const float pad = 1e-5f * f_max(fabsf(mn[a]), fabsf(mx[a])) + 2e-3f * (mx[a] - mn[a]) + 1e-7f;
+        /* Padding so that the slab test does not reject a ray the triangle test accepts: 1e-5 of the coordinates + 5e-4
+         * of the triangle's extent per axis (the two-pass triangle test is good to ~1e-4 of the size; the error moves the
+         * point within the triangle's plane).  Same rule as on the HIP side. */
+        const float pad = 1e-5f * f_max(fabsf(mn[a]), fabsf(mx[a])) + 5e-4f * (mx[a] - mn[a]) + 1e-7f;
         lo[a] = mn[a] - pad;
         hi[a] = mx[a] + pad;
     }

@@ -108,22 +108,18 @@ __global__ void k_tri_setup(uint32_t n, uint32_t pairCount, const uint32_t *__re
     t.c = make_float4(e2.z, __uint_as_float(p), __uint_as_float(prim), __uint_as_float(pr->nonOpaque ? 1u : 0u));
     triTmp[g] = t;
 
-    // bounds from the same p0, p0+e1, p0+e2 the intersection test sees, padded so the slab
-    // test does not reject a ray the triangle test accepts.  "Never" only up to the triangle test's own error:
-    // Moeller-Trumbore from a distant origin accepts points a few 1e-4 of the triangle's size outside it (seen on
-    // street_like 35 - 40 units from the camera: first the oracle's tree, then -- once in 600 M rays -- this one culled
-    // such a candidate and lost an equal-t tie to brute force).  Hence a term proportional to the triangle's extent
-    // next to the one proportional to the coordinates, the same rule as in the oracle.  Per axis: the error moves the
-    // accepted point WITHIN the triangle's plane, so a flat axis-aligned triangle needs no extra thickness (padding
-    // every axis by the largest extent makes floor-grazing shadow rays start inside their neighbours' boxes: -4 %).
-    // Cost: 2.7 % of the chess_like step.
+    // bounds from the same p0, p0+e1, p0+e2 the intersection test sees, padded so the slab test does not reject a
+    // ray the triangle test accepts: 1e-5 of the coordinates (position of the hit point along the ray) + 5e-4 of the
+    // triangle's extent per axis (the two-pass triangle test is good to ~1e-4 of the size; per axis because that error
+    // moves the accepted point WITHIN the triangle's plane -- padding every axis by the largest extent makes
+    // floor-grazing shadow rays start inside their neighbours' boxes: -4 %).  Same rule as in the oracle.
     float l[3], h[3];
     const float p0[3] = { w[0].x, w[0].y, w[0].z }, a1[3] = { e1.x, e1.y, e1.z }, a2[3] = { e2.x, e2.y, e2.z };
     for (int a = 0; a < 3; a++)
     {
         const float q1 = p0[a] + a1[a], q2 = p0[a] + a2[a];
         const float mn = fminf(p0[a], fminf(q1, q2)), mx = fmaxf(p0[a], fmaxf(q1, q2));
-        const float pad = 1e-5f * fmaxf(fabsf(mn), fabsf(mx)) + 2e-3f * (mx - mn) + 1e-7f;
+        const float pad = 1e-5f * fmaxf(fabsf(mn), fabsf(mx)) + 5e-4f * (mx - mn) + 1e-7f;
         l[a] = mn - pad;
         h[a] = mx + pad;
     }
@@ -1040,6 +1036,8 @@ constexpr int kRefDone = 0x7fffffff;
 __device__ uint32_t g_visitStats[2][68]; // [closest | shadow][max, sum lo, rays, -, histogram of visits / 16]
 #endif
 
+// IO::kFixedTmin >= 0: every ray of the queue has this tmin (the wavefront queues: 1e-5) -> a literal, not a register
+#define PT_TMIN (IO::kFixedTmin >= 0.0f ? IO::kFixedTmin : tmin)
 template <bool ANY_HIT, bool ALPHA, typename IO>
 PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32_t *__restrict__ chunkCounter, Stack &st)
 {
@@ -1108,15 +1106,16 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
                     item = cursor + rank;
                     if (io.load(item, o, d, tmin, tmax))
                     {
+
                         have = true;
                         id = fastInverse(d);
                         best.t = tmax;
                         best.u = best.v = 0.0f;
-                        best.pair = best.prim = 0xffffffffu;
+                        best.pair = 0xffffffffu;
                         if (ALPHA)
                             decal = noDecal();
                         st.sp = 0;
-                        ref = (sc.triCount && rayIsTraceable(o, d, tmin, tmax)) ? 0 : kRefDone;
+                        ref = (sc.triCount && rayIsTraceable(o, d, PT_TMIN, tmax)) ? 0 : kRefDone;
                     }
                 }
                 cursor += take;
@@ -1131,7 +1130,7 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
             if (have && ref >= 0 && ref != kRefDone)
             {
                 int r0, r1, r2, r3;
-                const int h = visitNode(&sc.nodes[ref], o, id, tmin, ANY_HIT ? best.t : best.t * kCullSlack, r0, r1, r2, r3);
+                const int h = visitNode(&sc.nodes[ref], o, id, PT_TMIN, ANY_HIT ? best.t : best.t * kCullSlack, r0, r1, r2, r3);
                 if (h > 3) st.push((uint32_t)r3);
                 if (h > 2) st.push((uint32_t)r2);
                 if (h > 1) st.push((uint32_t)r1);
@@ -1150,25 +1149,25 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
             const float4 ta = tp->a, tb = tp->b, tc = tp->c;
             float t, u, v;
             ref = st.sp ? (int)st.pop() : kRefDone;
-            if (intersectTri(F3(ta.x, ta.y, ta.z), F3(ta.w, tb.x, tb.y), F3(tb.z, tb.w, tc.x), o, d, tmin, tmax, t, u, v) &&
+            if (intersectTri(F3(ta.x, ta.y, ta.z), F3(ta.w, tb.x, tb.y), F3(tb.z, tb.w, tc.x), o, d, PT_TMIN, tmax, t, u, v) &&
                 (!ALPHA || __float_as_uint(tc.w) == 0u ||
                  anyHitKeeps<ANY_HIT>(sc, __float_as_uint(tc.y), __float_as_uint(tc.z), (uint32_t)~leafRef, t, u, v, decal)))
             {
                 const uint32_t pair = __float_as_uint(tc.y), prim = __float_as_uint(tc.z);
+                // the prim id of the best hit is not carried in a register: an exact tie inside one (instance, mesh) pair
+                // is rare enough to re-read it from the triangle record
                 if (ANY_HIT)
                 {
                     best.pair = pair;
-                    best.prim = prim;
                     best.slot = (uint32_t)~leafRef;
                     ref = kRefDone;
                 }
-                else if (t < best.t || (t == best.t && (pair < best.pair || (pair == best.pair && prim < best.prim))))
+                else if (t < best.t || (t == best.t && (pair < best.pair || (pair == best.pair && prim < __float_as_uint(sc.tris[best.slot].c.z)))))
                 {
                     best.t = t;
                     best.u = u;
                     best.v = v;
                     best.pair = pair;
-                    best.prim = prim;
                     best.slot = (uint32_t)~leafRef;
                 }
             }
@@ -1177,6 +1176,8 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
         // ---- retire finished rays
         if (have && ref == kRefDone)
         {
+            if (IO::kNeedsPrim)
+                best.prim = best.pair != 0xffffffffu ? __float_as_uint(sc.tris[best.slot].c.z) : 0xffffffffu;
             io.store(item, best, best.pair != 0xffffffffu, decal);
             have = false;
 #ifdef PT_VISIT_STATS
@@ -1189,5 +1190,7 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
         }
     }
 }
+
+#undef PT_TMIN
 
 } // namespace ptd

@@ -1480,6 +1480,13 @@ PT_DEV void closestHit(const SceneView &sv, f3 rayDirW, float t, float hu, float
 
 // Moeller-Trumbore on (v0, e1, e2): the fixed stand-in for the driver's unspecified
 // ray-triangle test.  Hit iff det != 0, 0 <= u <= 1, v >= 0, u+v <= 1, tmin < t < tmax.
+//
+// Two passes.  Plain Moeller-Trumbore from the ray origin loses (|o - v0| / size)^2 ulps in the barycentrics: 23 units
+// from the camera it accepted a point 16 % of a 2 cm triangle's extent outside it -- a "hit" whose ray does not even
+// cross the triangle's bounding box, on which brute force and tree walks cannot agree (tools/full_size_sweep.py,
+// street_like).  Its t, however, is good.  So pass 1 solves from o with loose bounds on (u, v), and pass 2 solves again
+// from o + t1 d, where the offset to v0 is at most the triangle's size and the correction to t is tiny: accurate for far
+// small triangles AND for near hits on huge ones (re-originating through v0 instead loses t > tmin for those).
 PT_DEV bool intersectTri(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float tmin, float tmax, float &t, float &u, float &v)
 {
     const f3 pvec = cross(d, e2);
@@ -1487,15 +1494,28 @@ PT_DEV bool intersectTri(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float tmin, float tmax
     if (!(det != 0.0f))
         return false;
     const float inv = 1.0f / det;
-    const f3 tvec = o - v0;
-    const float uu = dot(tvec, pvec) * inv;
+    // pass 1 (plain, from the ray origin): good t, barycentrics off by (|o - v0| / size)^2 ulps -> loose bounds only
+    f3 tvec = o - v0;
+    float uu = dot(tvec, pvec) * inv;
+    if (!(uu >= -0.25f && uu <= 1.25f))
+        return false;
+    f3 qvec = cross(tvec, e1);
+    float vv = dot(d, qvec) * inv;
+    if (!(vv >= -0.25f && uu + vv <= 1.25f))
+        return false;
+    const float t1 = dot(e2, qvec) * inv;
+    if (!(t1 > -1e30f && t1 < 1e30f))
+        return false;
+    // pass 2 from o + t1 d: the offset to v0 is at most the triangle's size, the correction to t is tiny
+    tvec = (o + d * t1) - v0;
+    uu = dot(tvec, pvec) * inv;
     if (!(uu >= 0.0f && uu <= 1.0f))
         return false;
-    const f3 qvec = cross(tvec, e1);
-    const float vv = dot(d, qvec) * inv;
+    qvec = cross(tvec, e1);
+    vv = dot(d, qvec) * inv;
     if (!(vv >= 0.0f && uu + vv <= 1.0f))
         return false;
-    const float tt = dot(e2, qvec) * inv;
+    const float tt = t1 + dot(e2, qvec) * inv;
     if (!(tt > tmin && tt < tmax))
         return false;
     t = tt;

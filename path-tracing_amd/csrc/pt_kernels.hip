@@ -262,6 +262,8 @@ __global__ void __launch_bounds__(kBlock) k_generate(LaunchParams p, Wavefront w
 
 struct ClosestIO
 {
+    static constexpr float kFixedTmin = 0.00001f; // ray.glsl:79
+    static constexpr bool kNeedsPrim = false;    // the hit record carries (t, u, v, slot) and the pair
     const Wavefront &wf;
     const uint32_t *queue;
     uint32_t slot;
@@ -299,7 +301,7 @@ struct ClosestIO
 // chess_like step); the ALPHA closest variant carries the sampler and the decal and stops at 6 waves.
 #define PT_FULL_OCCUPANCY __attribute__((amdgpu_waves_per_eu(8, 8)))
 #define PT_ALPHA_CLOSEST_ATTR __attribute__((amdgpu_waves_per_eu(6, 6))) // 83 -> 80 registers, 5 -> 6 waves; 7 would spill
-#define PT_ALPHA_SHADOW_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))  // 70 -> 61 registers
+#define PT_ALPHA_SHADOW_ATTR __attribute__((amdgpu_waves_per_eu(7, 7)))  // 8 waves would spill 11 registers with the two-pass triangle test
 template <bool ALPHA>
 PT_DEV void traceClosestBody(const TraceScene &sc, const Wavefront &wf, int qin, uint32_t count)
 {
@@ -556,6 +558,8 @@ PT_DEV void shadeBody(const LaunchParams &p, const SceneView &sv, const Wavefron
 
 struct ShadowIO
 {
+    static constexpr float kFixedTmin = 0.00001f; // raygen.rgen:26
+    static constexpr bool kNeedsPrim = false;
     const LaunchParams &p;
     const Wavefront &wf;
     int qout;
@@ -906,6 +910,8 @@ __global__ void k_skin(const PtxAnimatedVertex *__restrict__ in, const uint32_t 
 // traceRayEXT stand-in over explicit rays (o.xyz, tmin, d.xyz, tmax): traversal parity tests
 struct RaysIO
 {
+    static constexpr float kFixedTmin = -1.0f; // per ray
+    static constexpr bool kNeedsPrim = true;     // ptx_trace_rays reports (pair, prim)
     const float4 *rays;
     float4 *outHit;
     uint2 *outIds;

@@ -25,9 +25,10 @@ def test_bvh_equals_bruteforce(pkg, orc, name, detail):
 @pytest.mark.parametrize("name", ["street_like", "atrium_like"])
 def test_bvh_known_answer_rays(pkg, orc, name):
     """Known-answer regression (util.known_answer_rays): the tree walk must agree with brute force on the rays that once
-    separated them.  The first street_like ray crosses two overlapping coplanar triangles that report the bit-identical
-    t while o + t d lies 2.6e-6 outside the padded box of the one with the smaller id (Moeller-Trumbore from 12.5 units
-    away); the atrium_like ray passes the vertex of a zero-area triangle, which must never be hit."""
+    separated them.  With plain Moeller-Trumbore from the ray origin the street_like rays were equal-t "ties" between
+    the triangle the ray really crosses and an overlapping neighbour accepted only through the test's error (points up
+    to 16 % of a triangle's extent outside it); with the two-pass test only the real one accepts.  The atrium_like ray
+    passes the vertex of a zero-area triangle (3608410, e1 == e2), which must never be hit."""
     s = pkg.Scene(name, 1.0)
     osc = orc.OracleScene(s.desc, build_bvh=True)
     rays = util.known_answer_ray_array(name)
@@ -35,9 +36,10 @@ def test_bvh_known_answer_rays(pkg, orc, name):
     b = osc.trace_closest(rays, brute_force=True)
     assert (a["tri"] == b["tri"]).all() and (a["t"].view(np.uint32) == b["t"].view(np.uint32)).all()
     if name == "street_like":
-        assert b["tri"].tolist() == [2153290, 2538466, 2475890] and b["t"].view(np.uint32)[0] == 0x4148FDE3
+        assert b["tri"].tolist() == [2153483, 2538659, 2476083]
+        assert (b["u"] < 2e-3).all()  # all three cross their triangle next to the edge shared with the former tie partner
     else:
-        assert b["tri"][0] != 3608410 and abs(float(b["t"][0]) - 28.1338) < 1e-3  # 3608410 has e1 == e2
+        assert b["tri"][0] == 4118506 and abs(float(b["t"][0]) - 28.1338) < 1e-3
 
 
 def test_render_bvh_equals_bruteforce_and_is_deterministic(pkg, orc):
