@@ -503,7 +503,11 @@ typedef enum PtxTestFunction {
     PTX_FN_POSTPROCESS_PIXEL = 31,  /* in: acc.rgb TotalSamples(bits) Exposure BloomThreshold (6) out: color bloom (6) postprocess.comp:22-37 */
     PTX_FN_COMPOSITION_PIXEL = 32,  /* in: post.rgb bloom.rgb BloomIntensity (7)    out: rgb (3)  composition.comp:23 */
     PTX_FN_TONEMAP_PIXEL = 33,      /* in: rgb (3)                                  out: rgb (3)  toneMapping.comp:20-22, SDR */
-    PTX_FN_COUNT = 34
+    PTX_FN_SAMPLE_MATERIAL = 34,    /* material.glsl:62-171 on explicit texels.  in (47): type, isHitFromInside, flipNormalY (u32 bits), the 96-byte
+                                       material record of that type (24 dwords; its texture indices are ignored), the five textureGrad
+                                       results in slot order (emissive, colour, normal, 4th, 5th; rgba each)
+                                       out (17): EmissiveColor Color Normal Roughness Metalness Transmission Eta AttenuationColor AttenuationDistance */
+    PTX_FN_COUNT = 35
 } PtxTestFunction;
 
 /* Material block used by PTX_FN_EVALUATE_BSDF / PTX_FN_SAMPLE_BSDF:

@@ -1726,6 +1726,86 @@ static inline v3 ReconstructNormalFromXY(v3 n)
 
 static inline v3 rgb(v4 t) { return V3(t.x, t.y, t.z); }
 
+/* The five textureGrad results a material branch consumes, in the slot order of its struct: emissive, colour, normal,
+ * then roughness + metallic (MetallicRoughness), specular + glossiness (SpecularGlossiness) or specular + shininess (Phong). */
+typedef struct MaterialTexels
+{
+    v4 emissive, color, normal, a, b;
+} MaterialTexels;
+
+static inline v3 specGlossMetalness(v3 specular, v3 color) /* material.glsl:109-110, :138-139 */
+{
+    return V3(f_max(specular.x - 0.04f, 0.0f) / ((color.x - 0.04f) + 0.00001f), f_max(specular.y - 0.04f, 0.0f) / ((color.y - 0.04f) + 0.00001f),
+              f_max(specular.z - 0.04f, 0.0f) / ((color.z - 0.04f) + 0.00001f));
+}
+
+/* material.glsl:62-84 as a function of the texels its textureGrad calls return */
+static MaterialSample sampleMaterialMR(const PtxMetallicRoughnessMaterial *m, const MaterialTexels *t, int isHitFromInside)
+{
+    MaterialSample ret;
+    memset(&ret, 0, sizeof(ret));
+    ret.EmissiveColor = v_scale(v_add(rgb(t->emissive), V3(m->EmissiveColor[0], m->EmissiveColor[1], m->EmissiveColor[2])), m->EmissiveIntensity);
+    ret.Color = v_mul(rgb(t->color), V3(m->Color[0], m->Color[1], m->Color[2]));
+    ret.Normal = ReconstructNormalFromXY(rgb(t->normal));
+    ret.Roughness = t->a.y * m->Roughness;
+    ret.Metalness = t->b.z * m->Metalness;
+    ret.Transmission = m->Transmission;
+    ret.AttenuationColor = V3(m->AttenuationColor[0], m->AttenuationColor[1], m->AttenuationColor[2]);
+    ret.AttenuationDistance = m->AttenuationDistance;
+    ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
+    return ret;
+}
+
+/* material.glsl:86-113 */
+static MaterialSample sampleMaterialSG(const PtxSpecularGlossinessMaterial *m, const MaterialTexels *t, int isHitFromInside)
+{
+    MaterialSample ret;
+    memset(&ret, 0, sizeof(ret));
+    ret.EmissiveColor = v_scale(v_add(rgb(t->emissive), V3(m->EmissiveColor[0], m->EmissiveColor[1], m->EmissiveColor[2])), m->EmissiveIntensity);
+    ret.Color = v_mul(rgb(t->color), V3(m->Color[0], m->Color[1], m->Color[2]));
+    ret.Normal = ReconstructNormalFromXY(rgb(t->normal));
+    ret.Transmission = m->Transmission;
+    ret.AttenuationColor = V3(m->AttenuationColor[0], m->AttenuationColor[1], m->AttenuationColor[2]);
+    ret.AttenuationDistance = m->AttenuationDistance;
+    ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
+    const v3 specular = v_mul(rgb(t->a), V3(m->Specular[0], m->Specular[1], m->Specular[2]));
+    const float glossiness = t->b.w * m->Glossiness;
+    ret.Roughness = 1.0f - glossiness;
+    const v3 diff = specGlossMetalness(specular, ret.Color);
+    ret.Metalness = (diff.x + diff.y + diff.z) / 3.0f;
+    return ret;
+}
+
+/* material.glsl:115-142 */
+static MaterialSample sampleMaterialPhong(const PtxPhongMaterial *m, const MaterialTexels *t, int isHitFromInside)
+{
+    MaterialSample ret;
+    memset(&ret, 0, sizeof(ret));
+    ret.EmissiveColor = v_scale(v_add(rgb(t->emissive), V3(m->EmissiveColor[0], m->EmissiveColor[1], m->EmissiveColor[2])), m->EmissiveIntensity);
+    ret.Color = v_mul(rgb(t->color), V3(m->Color[0], m->Color[1], m->Color[2]));
+    ret.Normal = ReconstructNormalFromXY(rgb(t->normal));
+    ret.Transmission = m->Transmission;
+    ret.AttenuationColor = V3(m->AttenuationColor[0], m->AttenuationColor[1], m->AttenuationColor[2]);
+    ret.AttenuationDistance = m->AttenuationDistance;
+    ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
+    const v3 specular = v_mul(rgb(t->a), V3(m->Specular[0], m->Specular[1], m->Specular[2]));
+    const float shininess = t->b.w * m->Shininess;
+    ret.Roughness = 1.0f - shininess;
+    const v3 diff = specGlossMetalness(specular, ret.Color);
+    ret.Metalness = (diff.x + diff.y + diff.z) / 3.0f;
+    return ret;
+}
+
+/* material.glsl:161-166: unknown material type; the fields the GLSL leaves undefined are zero here */
+static MaterialSample unknownMaterial(void)
+{
+    MaterialSample ret;
+    memset(&ret, 0, sizeof(ret));
+    ret.Color = V3(1.0f, 0.0f, 0.0f);
+    ret.EmissiveColor = V3(1.0f, 0.0f, 0.0f);
+    return ret;
+}
+
 /* material.glsl:144-171 dispatching to :62-142 */
 static MaterialSample sampleMaterial(const PtoScene *s, uint32_t materialId, v2 texCoords, v4 derivatives, int isHitFromInside,
                                      int flipNormalY)
@@ -1734,61 +1814,32 @@ static MaterialSample sampleMaterial(const PtoScene *s, uint32_t materialId, v2 
     const uint32_t materialType = materialId & 0xffu; /* ShaderTypes.incl:164-168 */
     const uint32_t materialIndex = materialId >> 8;
     MaterialSample ret;
-    memset(&ret, 0, sizeof(ret));
+    MaterialTexels t;
     switch (materialType)
     {
     case PTX_MATERIAL_TYPE_METALLIC_ROUGHNESS: {
         const PtxMetallicRoughnessMaterial *m = &s->d.metallicRoughnessMaterials[materialIndex];
-        ret.EmissiveColor = v_scale(v_add(rgb(sampleTexture(m->EmissiveIdx)), V3(m->EmissiveColor[0], m->EmissiveColor[1], m->EmissiveColor[2])), m->EmissiveIntensity);
-        ret.Color = v_mul(rgb(sampleTexture(m->ColorIdx)), V3(m->Color[0], m->Color[1], m->Color[2]));
-        ret.Normal = ReconstructNormalFromXY(rgb(sampleTexture(m->NormalIdx)));
-        ret.Roughness = sampleTexture(m->RoughnessIdx).y * m->Roughness;
-        ret.Metalness = sampleTexture(m->MetallicIdx).z * m->Metalness;
-        ret.Transmission = m->Transmission;
-        ret.AttenuationColor = V3(m->AttenuationColor[0], m->AttenuationColor[1], m->AttenuationColor[2]);
-        ret.AttenuationDistance = m->AttenuationDistance;
-        ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
+        t.emissive = sampleTexture(m->EmissiveIdx); t.color = sampleTexture(m->ColorIdx); t.normal = sampleTexture(m->NormalIdx);
+        t.a = sampleTexture(m->RoughnessIdx); t.b = sampleTexture(m->MetallicIdx);
+        ret = sampleMaterialMR(m, &t, isHitFromInside);
         break;
     }
     case PTX_MATERIAL_TYPE_SPECULAR_GLOSSINESS: {
         const PtxSpecularGlossinessMaterial *m = &s->d.specularGlossinessMaterials[materialIndex];
-        ret.EmissiveColor = v_scale(v_add(rgb(sampleTexture(m->EmissiveIdx)), V3(m->EmissiveColor[0], m->EmissiveColor[1], m->EmissiveColor[2])), m->EmissiveIntensity);
-        ret.Color = v_mul(rgb(sampleTexture(m->ColorIdx)), V3(m->Color[0], m->Color[1], m->Color[2]));
-        ret.Normal = ReconstructNormalFromXY(rgb(sampleTexture(m->NormalIdx)));
-        ret.Transmission = m->Transmission;
-        ret.AttenuationColor = V3(m->AttenuationColor[0], m->AttenuationColor[1], m->AttenuationColor[2]);
-        ret.AttenuationDistance = m->AttenuationDistance;
-        ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
-        const v3 specular = v_mul(rgb(sampleTexture(m->SpecularIdx)), V3(m->Specular[0], m->Specular[1], m->Specular[2]));
-        const float glossiness = sampleTexture(m->GlossinessIdx).w * m->Glossiness;
-        ret.Roughness = 1.0f - glossiness;
-        const v3 diff = V3(f_max(specular.x - 0.04f, 0.0f) / ((ret.Color.x - 0.04f) + 0.00001f),
-                           f_max(specular.y - 0.04f, 0.0f) / ((ret.Color.y - 0.04f) + 0.00001f),
-                           f_max(specular.z - 0.04f, 0.0f) / ((ret.Color.z - 0.04f) + 0.00001f));
-        ret.Metalness = (diff.x + diff.y + diff.z) / 3.0f;
+        t.emissive = sampleTexture(m->EmissiveIdx); t.color = sampleTexture(m->ColorIdx); t.normal = sampleTexture(m->NormalIdx);
+        t.a = sampleTexture(m->SpecularIdx); t.b = sampleTexture(m->GlossinessIdx);
+        ret = sampleMaterialSG(m, &t, isHitFromInside);
         break;
     }
     case PTX_MATERIAL_TYPE_PHONG: {
         const PtxPhongMaterial *m = &s->d.phongMaterials[materialIndex];
-        ret.EmissiveColor = v_scale(v_add(rgb(sampleTexture(m->EmissiveIdx)), V3(m->EmissiveColor[0], m->EmissiveColor[1], m->EmissiveColor[2])), m->EmissiveIntensity);
-        ret.Color = v_mul(rgb(sampleTexture(m->ColorIdx)), V3(m->Color[0], m->Color[1], m->Color[2]));
-        ret.Normal = ReconstructNormalFromXY(rgb(sampleTexture(m->NormalIdx)));
-        ret.Transmission = m->Transmission;
-        ret.AttenuationColor = V3(m->AttenuationColor[0], m->AttenuationColor[1], m->AttenuationColor[2]);
-        ret.AttenuationDistance = m->AttenuationDistance;
-        ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
-        const v3 specular = v_mul(rgb(sampleTexture(m->SpecularIdx)), V3(m->Specular[0], m->Specular[1], m->Specular[2]));
-        const float shininess = sampleTexture(m->ShininessIdx).w * m->Shininess;
-        ret.Roughness = 1.0f - shininess;
-        const v3 diff = V3(f_max(specular.x - 0.04f, 0.0f) / ((ret.Color.x - 0.04f) + 0.00001f),
-                           f_max(specular.y - 0.04f, 0.0f) / ((ret.Color.y - 0.04f) + 0.00001f),
-                           f_max(specular.z - 0.04f, 0.0f) / ((ret.Color.z - 0.04f) + 0.00001f));
-        ret.Metalness = (diff.x + diff.y + diff.z) / 3.0f;
+        t.emissive = sampleTexture(m->EmissiveIdx); t.color = sampleTexture(m->ColorIdx); t.normal = sampleTexture(m->NormalIdx);
+        t.a = sampleTexture(m->SpecularIdx); t.b = sampleTexture(m->ShininessIdx);
+        ret = sampleMaterialPhong(m, &t, isHitFromInside);
         break;
     }
     default: /* material.glsl:163-166 */
-        ret.Color = V3(1.0f, 0.0f, 0.0f);
-        ret.EmissiveColor = V3(1.0f, 0.0f, 0.0f);
+        ret = unknownMaterial();
         break;
     }
     if (flipNormalY)
@@ -2240,8 +2291,8 @@ int pto_render(const PtoScene *s, const PtxRaygenUniformData *U, const PtxLights
 /* Function-level entry (packing documented in include/ptx.h)               */
 /* ======================================================================== */
 
-static const int kInStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4, 3, 3, 2, 6, 7, 3 };
-static const int kOutStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1, 2, 3, 2, 6, 3, 3 };
+static const int kInStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4, 3, 3, 2, 6, 7, 3, 47 };
+static const int kOutStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1, 2, 3, 2, 6, 3, 3, 17 };
 
 static MaterialSample unpackMaterial(const float *p)
 {
@@ -2462,6 +2513,29 @@ int pto_test_eval(uint32_t fn, const float *in, float *out, uint32_t n)
         case PTX_FN_COMPUTE_LOD: {
             v4 dv = { a[0], a[1], a[2], a[3] };
             o[0] = computeLod(dv);
+            break;
+        }
+        case PTX_FN_SAMPLE_MATERIAL: {
+            uint32_t hdr[3];
+            memcpy(hdr, a, sizeof(hdr));
+            union { PtxMetallicRoughnessMaterial mr; PtxSpecularGlossinessMaterial sg; PtxPhongMaterial ph; } rec;
+            memcpy(&rec, a + 3, 96);
+            MaterialTexels t;
+            memcpy(&t, a + 27, sizeof(t));
+            MaterialSample m;
+            if (hdr[0] == PTX_MATERIAL_TYPE_METALLIC_ROUGHNESS)
+                m = sampleMaterialMR(&rec.mr, &t, hdr[1] != 0u);
+            else if (hdr[0] == PTX_MATERIAL_TYPE_SPECULAR_GLOSSINESS)
+                m = sampleMaterialSG(&rec.sg, &t, hdr[1] != 0u);
+            else if (hdr[0] == PTX_MATERIAL_TYPE_PHONG)
+                m = sampleMaterialPhong(&rec.ph, &t, hdr[1] != 0u);
+            else
+                m = unknownMaterial();
+            if (hdr[2])
+                m.Normal.y *= -1;
+            o[0] = m.EmissiveColor.x; o[1] = m.EmissiveColor.y; o[2] = m.EmissiveColor.z; o[3] = m.Color.x; o[4] = m.Color.y; o[5] = m.Color.z;
+            o[6] = m.Normal.x; o[7] = m.Normal.y; o[8] = m.Normal.z; o[9] = m.Roughness; o[10] = m.Metalness; o[11] = m.Transmission; o[12] = m.Eta;
+            o[13] = m.AttenuationColor.x; o[14] = m.AttenuationColor.y; o[15] = m.AttenuationColor.z; o[16] = m.AttenuationDistance;
             break;
         }
         default: return 1;

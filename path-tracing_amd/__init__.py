@@ -139,7 +139,7 @@ FN = {
     "pow": 18, "sampleLight": 19, "offsetRayOriginShadowTerminator": 20, "constructPrimaryRayLens": 21,
     "computeDpnDuv": 22, "computeDpDxy": 23, "computeDerivatives": 24, "computeReflectedDifferentialRays": 25,
     "computeRefractedDifferentialRays": 26, "computeLod": 27, "missSkyboxTexCoords": 28, "hdrToLdr": 29, "atanAsin": 30,
-    "postprocessPixel": 31, "compositionPixel": 32, "toneMapPixel": 33,
+    "postprocessPixel": 31, "compositionPixel": 32, "toneMapPixel": 33, "sampleMaterial": 34,
 }
 
 

@@ -1194,6 +1194,74 @@ PT_DEV f3 specGlossMetalness(f3 specular, f3 color) // material.glsl:109-110, :1
               fmax_(specular.z - 0.04f, 0.0f) / ((color.z - 0.04f) + 0.00001f));
 }
 
+// The five textureGrad results a material branch consumes, in the slot order of its struct: emissive, colour, normal,
+// then roughness + metallic (MetallicRoughness), specular + glossiness (SpecularGlossiness) or specular + shininess (Phong).
+struct MaterialTexels
+{
+    f4 emissive, color, normal, a, b;
+};
+
+// material.glsl:62-84, :86-113, :115-142: the three overloads, as functions of the texels their textureGrad calls
+// return (the fetches have no side effects, so taking them first changes nothing).
+PT_DEV MaterialSample sampleMaterial(const PtxMetallicRoughnessMaterial *m, const MaterialTexels &t, bool isHitFromInside)
+{
+    MaterialSample ret;
+    ret.EmissiveColor = (rgb(t.emissive) + ld3(m->EmissiveColor)) * m->EmissiveIntensity;
+    ret.Color = rgb(t.color) * ld3(m->Color);
+    ret.Normal = ReconstructNormalFromXY(rgb(t.normal));
+    ret.Roughness = t.a.y * m->Roughness;
+    ret.Metalness = t.b.z * m->Metalness;
+    ret.Transmission = m->Transmission;
+    ret.AttenuationColor = ld3(m->AttenuationColor);
+    ret.AttenuationDistance = m->AttenuationDistance;
+    ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
+    return ret;
+}
+PT_DEV MaterialSample sampleMaterial(const PtxSpecularGlossinessMaterial *m, const MaterialTexels &t, bool isHitFromInside)
+{
+    MaterialSample ret;
+    ret.EmissiveColor = (rgb(t.emissive) + ld3(m->EmissiveColor)) * m->EmissiveIntensity;
+    ret.Color = rgb(t.color) * ld3(m->Color);
+    ret.Normal = ReconstructNormalFromXY(rgb(t.normal));
+    ret.Transmission = m->Transmission;
+    ret.AttenuationColor = ld3(m->AttenuationColor);
+    ret.AttenuationDistance = m->AttenuationDistance;
+    ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
+    const f3 specular = rgb(t.a) * ld3(m->Specular);
+    const float glossiness = t.b.w * m->Glossiness;
+    ret.Roughness = 1.0f - glossiness;
+    const f3 diff = specGlossMetalness(specular, ret.Color);
+    ret.Metalness = (diff.x + diff.y + diff.z) / 3.0f;
+    return ret;
+}
+PT_DEV MaterialSample sampleMaterial(const PtxPhongMaterial *m, const MaterialTexels &t, bool isHitFromInside)
+{
+    MaterialSample ret;
+    ret.EmissiveColor = (rgb(t.emissive) + ld3(m->EmissiveColor)) * m->EmissiveIntensity;
+    ret.Color = rgb(t.color) * ld3(m->Color);
+    ret.Normal = ReconstructNormalFromXY(rgb(t.normal));
+    ret.Transmission = m->Transmission;
+    ret.AttenuationColor = ld3(m->AttenuationColor);
+    ret.AttenuationDistance = m->AttenuationDistance;
+    ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
+    const f3 specular = rgb(t.a) * ld3(m->Specular);
+    const float shininess = t.b.w * m->Shininess;
+    ret.Roughness = 1.0f - shininess;
+    const f3 diff = specGlossMetalness(specular, ret.Color);
+    ret.Metalness = (diff.x + diff.y + diff.z) / 3.0f;
+    return ret;
+}
+// material.glsl:161-171: the unknown-type default (fields the GLSL leaves undefined are zero here) and flipNormalY
+PT_DEV MaterialSample unknownMaterial()
+{
+    MaterialSample ret;
+    ret.Normal = ret.AttenuationColor = F3s(0.0f);
+    ret.Roughness = ret.Metalness = ret.Transmission = ret.Eta = ret.AttenuationDistance = 0.0f;
+    ret.Color = F3(1.0f, 0.0f, 0.0f);
+    ret.EmissiveColor = F3(1.0f, 0.0f, 0.0f);
+    return ret;
+}
+
 template <bool TEX>
 PT_DEV MaterialSample sampleMaterial(const SceneView &sv, uint32_t materialId, f2 texCoords, f4 derivatives, bool isHitFromInside) // :144-171
 {
@@ -1201,58 +1269,30 @@ PT_DEV MaterialSample sampleMaterial(const SceneView &sv, uint32_t materialId, f
     const uint32_t materialType = materialId & 0xffu;
     const uint32_t materialIndex = materialId >> 8;
     MaterialSample ret;
-    ret.EmissiveColor = ret.Color = ret.Normal = ret.AttenuationColor = F3s(0.0f);
-    ret.Roughness = ret.Metalness = ret.Transmission = ret.Eta = ret.AttenuationDistance = 0.0f;
+    MaterialTexels t;
     if (materialType == PTX_MATERIAL_TYPE_METALLIC_ROUGHNESS) // :62-84
     {
         const PtxMetallicRoughnessMaterial *m = &sv.mr[materialIndex];
-        ret.EmissiveColor = (rgb(sampleTexture(m->EmissiveIdx)) + ld3(m->EmissiveColor)) * m->EmissiveIntensity;
-        ret.Color = rgb(sampleTexture(m->ColorIdx)) * ld3(m->Color);
-        ret.Normal = ReconstructNormalFromXY(rgb(sampleTexture(m->NormalIdx)));
-        ret.Roughness = sampleTexture(m->RoughnessIdx).y * m->Roughness;
-        ret.Metalness = sampleTexture(m->MetallicIdx).z * m->Metalness;
-        ret.Transmission = m->Transmission;
-        ret.AttenuationColor = ld3(m->AttenuationColor);
-        ret.AttenuationDistance = m->AttenuationDistance;
-        ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
+        t.emissive = sampleTexture(m->EmissiveIdx); t.color = sampleTexture(m->ColorIdx); t.normal = sampleTexture(m->NormalIdx);
+        t.a = sampleTexture(m->RoughnessIdx); t.b = sampleTexture(m->MetallicIdx);
+        ret = sampleMaterial(m, t, isHitFromInside);
     }
     else if (materialType == PTX_MATERIAL_TYPE_SPECULAR_GLOSSINESS) // :86-113
     {
         const PtxSpecularGlossinessMaterial *m = &sv.sg[materialIndex];
-        ret.EmissiveColor = (rgb(sampleTexture(m->EmissiveIdx)) + ld3(m->EmissiveColor)) * m->EmissiveIntensity;
-        ret.Color = rgb(sampleTexture(m->ColorIdx)) * ld3(m->Color);
-        ret.Normal = ReconstructNormalFromXY(rgb(sampleTexture(m->NormalIdx)));
-        ret.Transmission = m->Transmission;
-        ret.AttenuationColor = ld3(m->AttenuationColor);
-        ret.AttenuationDistance = m->AttenuationDistance;
-        ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
-        const f3 specular = rgb(sampleTexture(m->SpecularIdx)) * ld3(m->Specular);
-        const float glossiness = sampleTexture(m->GlossinessIdx).w * m->Glossiness;
-        ret.Roughness = 1.0f - glossiness;
-        const f3 diff = specGlossMetalness(specular, ret.Color);
-        ret.Metalness = (diff.x + diff.y + diff.z) / 3.0f;
+        t.emissive = sampleTexture(m->EmissiveIdx); t.color = sampleTexture(m->ColorIdx); t.normal = sampleTexture(m->NormalIdx);
+        t.a = sampleTexture(m->SpecularIdx); t.b = sampleTexture(m->GlossinessIdx);
+        ret = sampleMaterial(m, t, isHitFromInside);
     }
     else if (materialType == PTX_MATERIAL_TYPE_PHONG) // :115-142
     {
         const PtxPhongMaterial *m = &sv.phong[materialIndex];
-        ret.EmissiveColor = (rgb(sampleTexture(m->EmissiveIdx)) + ld3(m->EmissiveColor)) * m->EmissiveIntensity;
-        ret.Color = rgb(sampleTexture(m->ColorIdx)) * ld3(m->Color);
-        ret.Normal = ReconstructNormalFromXY(rgb(sampleTexture(m->NormalIdx)));
-        ret.Transmission = m->Transmission;
-        ret.AttenuationColor = ld3(m->AttenuationColor);
-        ret.AttenuationDistance = m->AttenuationDistance;
-        ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
-        const f3 specular = rgb(sampleTexture(m->SpecularIdx)) * ld3(m->Specular);
-        const float shininess = sampleTexture(m->ShininessIdx).w * m->Shininess;
-        ret.Roughness = 1.0f - shininess;
-        const f3 diff = specGlossMetalness(specular, ret.Color);
-        ret.Metalness = (diff.x + diff.y + diff.z) / 3.0f;
+        t.emissive = sampleTexture(m->EmissiveIdx); t.color = sampleTexture(m->ColorIdx); t.normal = sampleTexture(m->NormalIdx);
+        t.a = sampleTexture(m->SpecularIdx); t.b = sampleTexture(m->ShininessIdx);
+        ret = sampleMaterial(m, t, isHitFromInside);
     }
     else // :163-166
-    {
-        ret.Color = F3(1.0f, 0.0f, 0.0f);
-        ret.EmissiveColor = F3(1.0f, 0.0f, 0.0f);
-    }
+        ret = unknownMaterial();
     if (sv.dxNormalTextures)
         ret.Normal.y *= -1;
     return ret;

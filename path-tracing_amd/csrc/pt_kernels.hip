@@ -1029,10 +1029,10 @@ __global__ void k_test_texture(TextureView tv, const float *__restrict__ in, flo
 
 // function-level entry (Path-Tracing-Tests/TestRenderer.cpp:79-105 dispatches a compute
 // shader that calls the production functions; packing documented in include/ptx.h)
-__constant__ int c_inStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4, 3, 3, 2, 6, 7, 3 };
-__constant__ int c_outStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1, 2, 3, 2, 6, 3, 3 };
-static const int h_inStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4, 3, 3, 2, 6, 7, 3 };
-static const int h_outStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1, 2, 3, 2, 6, 3, 3 };
+__constant__ int c_inStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4, 3, 3, 2, 6, 7, 3, 47 };
+__constant__ int c_outStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1, 2, 3, 2, 6, 3, 3, 17 };
+static const int h_inStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4, 3, 3, 2, 6, 7, 3, 47 };
+static const int h_outStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1, 2, 3, 2, 6, 3, 3, 17 };
 
 PT_DEV MaterialSample unpackMaterial(const float *p)
 {
@@ -1266,6 +1266,31 @@ __global__ void k_test_eval(uint32_t fn, const float *__restrict__ in, float *__
     case PTX_FN_COMPUTE_LOD: {
         f4 dv; dv.x = a[0]; dv.y = a[1]; dv.z = a[2]; dv.w = a[3];
         o[0] = computeLod(dv);
+        break;
+    }
+    case PTX_FN_SAMPLE_MATERIAL: {
+        const uint32_t type = __float_as_uint(a[0]);
+        const bool inside = __float_as_uint(a[1]) != 0u, flip = __float_as_uint(a[2]) != 0u;
+        MaterialTexels t;
+        f4 *tx[5] = { &t.emissive, &t.color, &t.normal, &t.a, &t.b };
+        for (int k = 0; k < 5; k++)
+        {
+            tx[k]->x = a[27 + 4 * k]; tx[k]->y = a[28 + 4 * k]; tx[k]->z = a[29 + 4 * k]; tx[k]->w = a[30 + 4 * k];
+        }
+        MaterialSample m;
+        if (type == PTX_MATERIAL_TYPE_METALLIC_ROUGHNESS)
+            m = sampleMaterial(reinterpret_cast<const PtxMetallicRoughnessMaterial *>(a + 3), t, inside);
+        else if (type == PTX_MATERIAL_TYPE_SPECULAR_GLOSSINESS)
+            m = sampleMaterial(reinterpret_cast<const PtxSpecularGlossinessMaterial *>(a + 3), t, inside);
+        else if (type == PTX_MATERIAL_TYPE_PHONG)
+            m = sampleMaterial(reinterpret_cast<const PtxPhongMaterial *>(a + 3), t, inside);
+        else
+            m = unknownMaterial();
+        if (flip)
+            m.Normal.y *= -1;
+        o[0] = m.EmissiveColor.x; o[1] = m.EmissiveColor.y; o[2] = m.EmissiveColor.z; o[3] = m.Color.x; o[4] = m.Color.y; o[5] = m.Color.z;
+        o[6] = m.Normal.x; o[7] = m.Normal.y; o[8] = m.Normal.z; o[9] = m.Roughness; o[10] = m.Metalness; o[11] = m.Transmission; o[12] = m.Eta;
+        o[13] = m.AttenuationColor.x; o[14] = m.AttenuationColor.y; o[15] = m.AttenuationColor.z; o[16] = m.AttenuationDistance;
         break;
     }
     default: break;

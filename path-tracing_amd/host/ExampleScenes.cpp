@@ -1290,6 +1290,174 @@ void CreateAlphaTestScene(SceneBuilder &sb, uint32_t seed)
     AddViewCamera(sb, Vec3(0.0f, 2.0f, -6.0f), Vec3(0.0f, 1.6f, 0.0f));
 }
 
+// Every branch of sampleMaterial (material.glsl:62-171) in one scene: MetallicRoughness, SpecularGlossiness and Phong
+// materials with and without their texture sets, a transmissive SpecularGlossiness "glass", a mesh whose material id
+// carries an unknown type (the red default of material.glsl:161-165), and HasDxNormalTextures (the normal map's green
+// channel is flipped, closestHit.rchit:101-102) -- what the ORCA scenes of BASELINE configs[2..4] bring through the
+// importer (ExampleScenes.cpp:93,96-131: Phong / SpecularGlossiness materials, DirectX normal maps).
+void CreateMaterialsTestScene(SceneBuilder &sb, float detail, uint32_t seed)
+{
+    const uint32_t tiles = sb.AddTexture(MakeTexture(TextureType::Color, "Mat Tiles", 64, 64, [](uint32_t x, uint32_t y, uint8_t *p) {
+        const bool on = ((x / 8) + (y / 8)) & 1;
+        p[0] = on ? 215 : 70; p[1] = on ? 205 : 75; p[2] = on ? 190 : 90; p[3] = 255;
+    }));
+    const uint32_t weave = sb.AddTexture(MakeTexture(TextureType::Color, "Mat Weave", 32, 48, [seed](uint32_t x, uint32_t y, uint8_t *p) {
+        const uint32_t h = HashU(x / 2, y / 3, seed);
+        p[0] = static_cast<uint8_t>(120 + (h & 63)); p[1] = static_cast<uint8_t>(60 + ((h >> 8) & 63)); p[2] = static_cast<uint8_t>(40 + ((h >> 16) & 31)); p[3] = 255;
+    }));
+    // a DirectX-convention normal map: green points DOWN the image, the scene flag flips it back
+    const uint32_t dxBumps = sb.AddTexture(MakeTexture(TextureType::Normal, "Mat DX Bumps", 64, 64, [](uint32_t x, uint32_t y, uint8_t *p) {
+        const float fx = std::cos(static_cast<float>(x) * 0.3927f), fy = std::cos(static_cast<float>(y) * 0.19635f);
+        p[0] = static_cast<uint8_t>(128.0f + 70.0f * fx); p[1] = static_cast<uint8_t>(128.0f - 95.0f * fy); p[2] = 255; p[3] = 255;
+    }));
+    const uint32_t specMap = sb.AddTexture(MakeTexture(TextureType::Specular, "Mat Specular", 32, 32, [](uint32_t x, uint32_t y, uint8_t *p) {
+        const bool stripe = ((x + y) / 6) & 1;
+        p[0] = stripe ? 250 : 90; p[1] = stripe ? 210 : 90; p[2] = stripe ? 120 : 95; p[3] = 255;
+    }));
+    // glossiness / shininess live in the ALPHA channel (material.glsl:107,136)
+    const uint32_t glossMap = sb.AddTexture(MakeTexture(TextureType::Glossiness, "Mat Gloss", 64, 16, [](uint32_t x, uint32_t, uint8_t *p) {
+        p[0] = 255; p[1] = 0; p[2] = 255; p[3] = static_cast<uint8_t>(60 + (x * 190) / 63);
+    }));
+    const uint32_t shineMap = sb.AddTexture(MakeTexture(TextureType::Shininess, "Mat Shine", 16, 64, [](uint32_t, uint32_t y, uint8_t *p) {
+        p[0] = 0; p[1] = 255; p[2] = 0; p[3] = static_cast<uint8_t>(250 - (y * 200) / 63);
+    }));
+    const uint32_t ember = sb.AddTexture(MakeTexture(TextureType::Emisive, "Mat Ember", 8, 8, [](uint32_t x, uint32_t y, uint8_t *p) {
+        const bool on = ((x ^ y) & 3) == 0;
+        p[0] = on ? 255 : 0; p[1] = on ? 90 : 0; p[2] = on ? 20 : 0; p[3] = 255;
+    }));
+
+    auto sgBase = [&]() {
+        Shaders::SpecularGlossinessMaterial m;
+        std::memset(&m, 0, sizeof(m));
+        m.Color[0] = m.Color[1] = m.Color[2] = m.Color[3] = 1.0f;
+        m.Specular[0] = m.Specular[1] = m.Specular[2] = 1.0f;
+        m.Glossiness = 1.0f;
+        m.AttenuationColor[0] = m.AttenuationColor[1] = m.AttenuationColor[2] = 1.0f;
+        m.AttenuationDistance = 1e32f;
+        m.Ior = 1.5f;
+        m.EmissiveIdx = Scene::GetDefaultTextureIndex(TextureType::Emisive);
+        m.ColorIdx = Scene::GetDefaultTextureIndex(TextureType::Color);
+        m.NormalIdx = Scene::GetDefaultTextureIndex(TextureType::Normal);
+        m.SpecularIdx = Scene::GetDefaultTextureIndex(TextureType::Specular);
+        m.GlossinessIdx = Scene::GetDefaultTextureIndex(TextureType::Glossiness);
+        return m;
+    };
+    auto phongBase = [&]() {
+        Shaders::PhongMaterial m;
+        std::memset(&m, 0, sizeof(m));
+        m.Color[0] = m.Color[1] = m.Color[2] = m.Color[3] = 1.0f;
+        m.Specular[0] = m.Specular[1] = m.Specular[2] = 1.0f;
+        m.Shininess = 1.0f;
+        m.AttenuationColor[0] = m.AttenuationColor[1] = m.AttenuationColor[2] = 1.0f;
+        m.AttenuationDistance = 1e32f;
+        m.Ior = 1.5f;
+        m.EmissiveIdx = Scene::GetDefaultTextureIndex(TextureType::Emisive);
+        m.ColorIdx = Scene::GetDefaultTextureIndex(TextureType::Color);
+        m.NormalIdx = Scene::GetDefaultTextureIndex(TextureType::Normal);
+        m.SpecularIdx = Scene::GetDefaultTextureIndex(TextureType::Specular);
+        m.ShininessIdx = Scene::GetDefaultTextureIndex(TextureType::Shininess);
+        return m;
+    };
+
+    std::vector<Shaders::MaterialId> mats;
+    {
+        auto m = MakeMaterial(Vec3(1.0f), 0.55f, 0.0f); // MetallicRoughness under the DX flag
+        m.ColorIdx = tiles;
+        m.NormalIdx = dxBumps;
+        mats.push_back(sb.AddMaterial("Mat MR Bumped", m));
+    }
+    {
+        auto m = sgBase(); // every SpecularGlossiness slot textured
+        m.ColorIdx = weave;
+        m.NormalIdx = dxBumps;
+        m.SpecularIdx = specMap;
+        m.GlossinessIdx = glossMap;
+        m.Specular[0] = 0.9f; m.Specular[1] = 0.8f; m.Specular[2] = 0.7f;
+        m.Glossiness = 0.85f;
+        mats.push_back(sb.AddMaterial("Mat SG Textured", m));
+    }
+    {
+        auto m = sgBase(); // factors only: default specular texel 1, default glossiness texel 0 -> roughness 1
+        m.Color[0] = 0.25f; m.Color[1] = 0.5f; m.Color[2] = 0.8f;
+        m.Specular[0] = m.Specular[1] = m.Specular[2] = 0.3f;
+        m.EmissiveIdx = ember;
+        m.EmissiveIntensity = 1.5f;
+        mats.push_back(sb.AddMaterial("Mat SG Plain", m));
+    }
+    {
+        auto m = sgBase(); // transmissive: Eta, attenuation and the refraction lobe through the SpecularGlossiness branch
+        m.Color[0] = 0.95f; m.Color[1] = 0.97f; m.Color[2] = 1.0f;
+        m.Specular[0] = m.Specular[1] = m.Specular[2] = 0.04f;
+        m.GlossinessIdx = glossMap;
+        m.Glossiness = 1.0f;
+        m.Transmission = 0.9f;
+        m.Ior = 1.45f;
+        m.AttenuationColor[0] = 0.6f; m.AttenuationColor[1] = 0.9f; m.AttenuationColor[2] = 0.7f;
+        m.AttenuationDistance = 0.8f;
+        mats.push_back(sb.AddMaterial("Mat SG Glass", m));
+    }
+    {
+        auto m = phongBase(); // every Phong slot textured
+        m.ColorIdx = tiles;
+        m.NormalIdx = dxBumps;
+        m.SpecularIdx = specMap;
+        m.ShininessIdx = shineMap;
+        m.Color[0] = 0.9f; m.Color[1] = 0.6f; m.Color[2] = 0.5f;
+        m.Shininess = 0.9f;
+        mats.push_back(sb.AddMaterial("Mat Phong Textured", m));
+    }
+    {
+        auto m = phongBase(); // factors only: default shininess texel 0 -> roughness 1
+        m.Color[0] = 0.7f; m.Color[1] = 0.75f; m.Color[2] = 0.3f;
+        m.Specular[0] = 0.5f; m.Specular[1] = 0.45f; m.Specular[2] = 0.2f;
+        mats.push_back(sb.AddMaterial("Mat Phong Plain", m));
+    }
+    mats.push_back(Shaders::CreateMaterialId(0u, 7u)); // unknown material type: red, emissive red (material.glsl:161-165)
+
+    auto floorM = MakeMaterial(Vec3(1.0f), 0.9f, 0.0f);
+    floorM.ColorIdx = tiles;
+    const auto floorMat = sb.AddMaterial("Mat Floor", floorM);
+    const uint32_t floor = AddGridSurface(sb, 6, 6, false, [](float u, float v) { return Vec3(-7.0f + 14.0f * u, 0.0f, -4.0f + 9.0f * v); });
+    {
+        auto &vertices = sb.GetVertices();
+        for (size_t k = vertices.size() - 49; k < vertices.size(); k++)
+        {
+            vertices[k].TexCoords[0] *= 5.0f;
+            vertices[k].TexCoords[1] *= 3.0f;
+        }
+    }
+    const uint32_t su = Scaled(48, detail, 8), svn = Scaled(24, detail, 4);
+    const uint32_t sphere = AddGridSurface(sb, su, svn, true, [](float u, float v) {
+        const float phi = 6.283185307179586f * u, theta = 3.14159265358979f * (0.02f + 0.96f * v);
+        return Vec3(std::sin(theta) * std::cos(phi), -std::cos(theta), std::sin(theta) * std::sin(phi));
+    });
+    const std::array<uint32_t, 6> cube = AddCube(sb);
+
+    const uint32_t root = sb.AddSceneNode({ 0u, Mat4::Identity(), Mat4::Identity() });
+    const std::array<MeshInfo, 1> floorMesh = { MI(floor, floorMat) };
+    sb.AddModelInstance(sb.AddModel(floorMesh), root);
+    for (size_t i = 0; i < mats.size(); i++)
+    {
+        const float x = -5.4f + 1.8f * static_cast<float>(i);
+        const std::array<MeshInfo, 1> ball = { MI(sphere, mats[i]) };
+        sb.AddModelInstance(sb.AddModel(ball), sb.AddSceneNode({ root, Scale(Translate(Mat4::Identity(), Vec3(x, 0.75f, 0.0f)), Vec3(0.72f)), Mat4::Identity() }));
+        std::array<MeshInfo, 6> box;
+        for (int k = 0; k < 6; k++)
+            box[k] = MI(cube[k], mats[(i + 3) % mats.size()]);
+        const Mat4 t = Scale(Rotate(Translate(Mat4::Identity(), Vec3(x + 0.3f, 0.4f, 2.4f)), 0.5f + 0.3f * static_cast<float>(i), Vec3(0, 1, 0)), Vec3(0.4f));
+        sb.AddModelInstance(sb.AddModel(box), sb.AddSceneNode({ root, t, Mat4::Identity() }));
+    }
+    sb.SetDxNormalTextures();
+    sb.AddLight(MakePointLight(Vec3(9.0f, 8.5f, 8.0f), Vec3(-2.0f, 4.0f, -2.5f)), root);
+    sb.AddLight(MakePointLight(Vec3(3.0f, 4.0f, 6.0f), Vec3(4.0f, 2.5f, 3.5f)), root);
+    Shaders::DirectionalLight dl;
+    std::memset(&dl, 0, sizeof(dl));
+    dl.Color[0] = 1.6f; dl.Color[1] = 1.5f; dl.Color[2] = 1.4f;
+    dl.Direction[0] = 0.35f; dl.Direction[1] = -1.0f; dl.Direction[2] = 0.45f;
+    sb.SetDirectionalLight(std::move(dl), root);
+    AddViewCamera(sb, Vec3(0.0f, 3.4f, -8.2f), Vec3(0.0f, 0.5f, 0.6f));
+}
+
 // Node animation, hierarchy and skinning in one small scene (row N3):
 //   * a platform spinning about y with a cube riding on it (child node of an animated node) that also bobs,
 //   * a skinned "tentacle": a 12-sided tube whose rings blend between consecutive bones of a 4-bone chain
@@ -1430,7 +1598,7 @@ void CreateAnimatedTestScene(SceneBuilder &sb, float detail, uint32_t seed)
 
 // ---------------------------------------------------------------------------
 
-const char *const kSceneNames = "default,roughness_cubes,attenuation_blob,chess_like,temple_like,atrium_like,street_like,texture_test,alpha_test,reuse_mesh_cubes,animated_test";
+const char *const kSceneNames = "default,roughness_cubes,attenuation_blob,chess_like,temple_like,atrium_like,street_like,texture_test,alpha_test,reuse_mesh_cubes,animated_test,materials_test";
 
 const char *GetSceneNames()
 {
@@ -1471,6 +1639,8 @@ std::shared_ptr<Scene> CreateScene(const std::string &name, float detail, uint32
         CreateAnimatedTestScene(sb, detail, seed ? seed : 9);
     else if (name == "alpha_test")
         CreateAlphaTestScene(sb, seed ? seed : 7);
+    else if (name == "materials_test")
+        CreateMaterialsTestScene(sb, detail, seed ? seed : 10);
     else
         throw error("Unknown scene: " + name);
     auto scene = sb.CreateSceneShared(name);

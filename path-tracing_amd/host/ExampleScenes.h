@@ -20,6 +20,8 @@ void CreateTempleLikeScene(SceneBuilder &sceneBuilder, float detail, uint32_t se
 void CreateAtriumLikeScene(SceneBuilder &sceneBuilder, float detail, uint32_t seed);
 void CreateStreetLikeScene(SceneBuilder &sceneBuilder, float detail, uint32_t seed);
 void CreateTextureTestScene(SceneBuilder &sceneBuilder, uint32_t seed); // sampler test content (row N1)
+// every sampleMaterial branch: MetallicRoughness / SpecularGlossiness / Phong, textured and plain, an unknown type, DX normal maps
+void CreateMaterialsTestScene(SceneBuilder &sceneBuilder, float detail, uint32_t seed);
 
 const char *GetSceneNames();
 std::shared_ptr<Scene> CreateScene(const std::string &name, float detail, uint32_t seed);

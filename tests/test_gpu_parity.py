@@ -306,7 +306,7 @@ def test_full_size_properties(pkg):
 
 
 @pytest.mark.parametrize("name,frames", [("chess_like", 2), ("atrium_like", 1), ("temple_like", 1), ("street_like", 1), ("alpha_test", 1), ("texture_test", 1),
-                                         ("roughness_cubes", 1), ("reuse_mesh_cubes", 1), ("attenuation_blob", 1), ("default", 2), ("animated_test", 1)])
+                                         ("roughness_cubes", 1), ("reuse_mesh_cubes", 1), ("attenuation_blob", 1), ("default", 2), ("animated_test", 1), ("materials_test", 1)])
 def test_full_size_frame_matches_oracle(pkg, orc, name, frames):
     """The benchmark workload itself (chess_like at full detail, 1,999,000 triangles, 1920x1080, depth 8) and the Sponza
     and Sun Temple stand-ins (textures + any-hit; point lights and deep paths): frames of the batch against the oracle,

@@ -94,7 +94,7 @@ def main():
     bad += compare("SampleCount 4", "chess_like", 1920, 1080, 1, 8, sample_count=4)
     bad += compare("rank 3 of 8", "atrium_like", 1920, 1080, 2 * k, 12, shard=(3, 8, 32))
     bad += compare("megakernel", "temple_like", 1920, 1080, 2, 8, backend=1)
-    for name in ("default", "roughness_cubes", "reuse_mesh_cubes", "texture_test", "alpha_test"):  # skyboxes, sampler, any-hit, decals
+    for name in ("default", "roughness_cubes", "reuse_mesh_cubes", "texture_test", "alpha_test", "materials_test"):  # skyboxes, sampler, any-hit, decals, SG / Phong / DX normals
         bad += compare("batch", name, 1920, 1080, 4 * k, 8)
     bad += animated(k)
     print("TOTAL differing pixels:", bad)

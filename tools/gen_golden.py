@@ -101,6 +101,20 @@ def main():
                      rewrite(lines(os.path.join(REF, "composition.comp"), [(22, 22)])) + "\n    return color;\n}")
         parts.append("vec3 toneMapPixel(vec3 color)\n{\n" +
                      rewrite(lines(os.path.join(REF, "toneMapping.comp"), [(19, 21)])) + "\n    return outColor;\n}")
+        # material.glsl:4-23 (sampleValue) and :55-171 (ReconstructNormalFromXY, the three sampleMaterial overloads and the
+        # dispatcher with flipNormalY) compile once `textures[]` / textureGrad and the three material buffers exist:
+        # a texture is ONE texel here (what textureGrad returns is the input of the arithmetic under test)
+        parts.append("// ---- material.glsl")
+        st = os.path.join(REF, "ShaderTypes.incl")
+        for n in ("MetallicRoughnessMaterial", "SpecularGlossinessMaterial", "PhongMaterial"):
+            parts.append(extract_struct(st, n))
+        parts.append(rewrite(lines(st, [(18, 19), (143, 145), (164, 168)])))
+        parts.append(rewrite(lines(os.path.join(REF, "Debug", "DebugShaderTypes.incl"), [(33, 39)])))
+        parts.append("struct Sampler2D { vec4 texel; }; Sampler2D textures[8];\n"
+                     "inline vec4 textureGrad(const Sampler2D &s, vec2, vec2, vec2) { return s.texel; }\n"
+                     "MetallicRoughnessMaterial metallicRoughnessMaterials[1]; SpecularGlossinessMaterial specularGlossinessMaterials[1]; "
+                     "PhongMaterial phongMaterials[1];")
+        parts.append(rewrite(lines(os.path.join(REF, "material.glsl"), [(4, 23), (55, 171)])))
         parts.append("} // namespace glsl")
         parts.append('#include "%s/golden_main.inc"' % HERE)
         cpp = os.path.join(tmp, "golden.cpp")
