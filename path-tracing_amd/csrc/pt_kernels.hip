@@ -1301,10 +1301,16 @@ __global__ void k_test_eval(uint32_t fn, const float *__restrict__ in, float *__
 // Host side: the renderer object behind the C-ABI
 // =====================================================================================
 
+// Owning device allocation: freed when it goes out of scope, so error returns (HIP_TRY / BUILD_TRY) and ptx_destroy
+// release everything without a list of names to keep in step.
 template <typename T> struct DevBuf
 {
     T *p = nullptr;
     size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
     hipError_t alloc(size_t count)
     {
         if (count <= n && p)
@@ -1596,13 +1602,7 @@ void ptx_destroy(PtxRenderer *r)
     (void)hipSetDevice(r->device);
     if (r->stream)
         (void)hipStreamSynchronize(r->stream);
-    r->textures.release(); r->texels8.release(); r->texelsF.release(); r->srgbLut.release();
-    r->vertices.release(); r->indices.release(); r->mr.release(); r->sg.release(); r->phong.release();
-    r->pairs.release(); r->pairFirst.release(); r->lights.release(); r->nodes.release(); r->tris.release(); r->shadeTris.release();
-    r->image.release(); r->rayO.release(); r->rayD.release(); r->thr.release(); r->rad.release(); r->hit.release();
-    r->shO.release(); r->shD.release(); r->shC.release(); r->slotRad.release(); r->diffs.release(); r->diffCapacity = 0; r->decal.release(); r->decalT.release(); r->decalCapacity = 0; r->meta.release(); r->hitPair.release();
-    r->queue0.release(); r->queue1.release(); r->shadowQueue.release(); r->counters.release(); r->spill.release(); r->restartQueue.release();
-    r->testIn.release(); r->testOut.release(); r->testUbo.release();
+    // every DevBuf member (scene, tree, build state, wavefront state, animation, output stage) frees itself in `delete r`
     for (int b = 0; b < r->batchesReady; b++)
     {
         PtxRenderer::BatchRes &q = r->batch[b];
@@ -2234,6 +2234,18 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
     if (p.numSlots == 0)
     {
         HIP_TRY(r, hipEventRecord(r->evB, r->stream));
+        return PTX_OK;
+    }
+
+    if (uniform->BounceCount == 0 && r->backend != PTX_BACKEND_MEGAKERNEL)
+    {
+        // raygen.rgen:62: the bounce loop never runs, every sample ends with radiance 0 -- nothing is generated, traced or
+        // shaded (the wavefront kernels test the bounce limit only AFTER a bounce); the image still gets its alpha
+        HIP_TRY(r, hipMemsetAsync(r->slotRad.p, 0, (size_t)p.numSlots * sizeof(float4), r->stream));
+        k_accumulate<<<gridFor(p.slotsPerFrame), kBlock, 0, r->stream>>>(p, r->slotRad.p, imagePtr(r));
+        HIP_TRY(r, hipEventRecord(r->evB, r->stream));
+        HIP_TRY(r, hipGetLastError());
+        r->stats.pathSamples = (uint64_t)p.ownedPixels * frames * uniform->SampleCount;
         return PTX_OK;
     }
 

@@ -209,6 +209,7 @@ DecodedImage TextureImporter::DecodeJpeg(std::span<const uint8_t> f)
         else if (marker == 0xc0 || marker == 0xc1) // SOF0 / SOF1
         {
             if (len < 8 || f[seg] != 8) throw error("JPEG: only 8-bit samples are supported");
+            if (haveFrame) throw error("JPEG: more than one frame header");
             height = be16(seg + 1);
             width = be16(seg + 3);
             ncomp = f[seg + 5];
@@ -229,7 +230,10 @@ DecodedImage TextureImporter::DecodeJpeg(std::span<const uint8_t> f)
         else if (marker >= 0xc2 && marker <= 0xcf && marker != 0xc8 && marker != 0xcc)
             throw error("JPEG: progressive / lossless / arithmetic files are not supported");
         else if (marker == 0xdd)
+        {
+            if (len < 4) throw error("JPEG: bad DRI");
             restartInterval = be16(seg);
+        }
         else if (marker == 0xee && len >= 14 && !std::memcmp(&f[seg], "Adobe", 5))
         {
             adobe = true;
@@ -238,8 +242,10 @@ DecodedImage TextureImporter::DecodeJpeg(std::span<const uint8_t> f)
         else if (marker == 0xda) // SOS
         {
             if (!haveFrame) throw error("JPEG: scan before frame");
+            if (seg >= segEnd) throw error("JPEG: bad SOS");
             const int ns = f[seg];
             if (ns != ncomp) throw error("JPEG: multi-scan files are not supported");
+            if (seg + 1 + 2 * static_cast<size_t>(ns) + 3 > segEnd) throw error("JPEG: bad SOS");
             for (int i = 0; i < ns; i++)
             {
                 const int cs = f[seg + 1 + i * 2], tdta = f[seg + 2 + i * 2];

@@ -84,10 +84,13 @@ struct Gltf
     {
         const Json &view = json["bufferViews"][static_cast<size_t>(viewIndex)];
         const int64_t buffer = view["buffer"].Int(), offset = view["byteOffset"].Int(0), length = view["byteLength"].Int(0);
-        if (view.IsNull() || buffer < 0 || static_cast<size_t>(buffer) >= buffers.size() ||
-            static_cast<size_t>(offset + length) > buffers[static_cast<size_t>(buffer)].size())
+        if (viewIndex < 0 || view.IsNull() || buffer < 0 || static_cast<size_t>(buffer) >= buffers.size() || offset < 0 || length < 0)
             throw error("glTF: buffer view out of range");
-        return { buffers[static_cast<size_t>(buffer)].data() + offset, static_cast<size_t>(length) };
+        // unsigned, overflow-free: offset <= size and length <= size - offset
+        const uint64_t size = buffers[static_cast<size_t>(buffer)].size(), uo = static_cast<uint64_t>(offset), ul = static_cast<uint64_t>(length);
+        if (uo > size || ul > size - uo)
+            throw error("glTF: buffer view out of range");
+        return { buffers[static_cast<size_t>(buffer)].data() + uo, static_cast<size_t>(ul) };
     }
 
 private:
@@ -108,10 +111,17 @@ private:
         if (acc["bufferView"].IsNull())
             return out; // all zeros by definition
         const std::span<const uint8_t> view = BufferView(acc["bufferView"].Int());
-        const size_t offset = static_cast<size_t>(acc["byteOffset"].Int(0));
+        const int64_t accOffset = acc["byteOffset"].Int(0);
         const int64_t declaredStride = json["bufferViews"][static_cast<size_t>(acc["bufferView"].Int())]["byteStride"].Int(0);
+        if (accOffset < 0 || declaredStride < 0 || declaredStride > 0xffff)
+            throw error("glTF: negative accessor offset or bad byteStride");
+        const size_t offset = static_cast<size_t>(accOffset);
         const size_t stride = declaredStride > 0 ? static_cast<size_t>(declaredStride) : cs * components;
-        if (count && offset + stride * (static_cast<size_t>(count) - 1) + cs * components > view.size())
+        // count elements of `stride` bytes, the last one cs * components long, all inside the view (no wrap-around:
+        // every term is checked against what is left)
+        const uint64_t elem = cs * static_cast<uint64_t>(components);
+        if (count && (offset > view.size() || elem > view.size() - offset ||
+                      (static_cast<uint64_t>(count) - 1) > (view.size() - offset - elem) / stride))
             throw error("glTF: accessor reads past its buffer view");
         const bool norm = normalise && acc["normalized"].kind == Json::Kind::Bool && acc["normalized"].boolean;
         for (size_t i = 0; i < static_cast<size_t>(count); i++)

@@ -250,6 +250,14 @@ def test_baseline_jpeg_dc_only(pkg):
     # progressive files are refused
     with pytest.raises(pkg.PtxError):
         pkg.decode_image(jpg.replace(b"\xff\xc0", b"\xff\xc2"))
+    # segments too short for what they declare: a 2-byte DRI (no interval), an SOS that ends inside its component list
+    head = b"\xff\xd8" + seg(0xDB, dqt) + seg(0xC0, sof) + seg(0xC4, dht)
+    for bad in (head + b"\xff\xdd\x00\x02" + seg(0xDA, sos) + bytes(scan) + b"\xff\xd9",
+                head + seg(0xDA, sos[:3]) + bytes(scan) + b"\xff\xd9",
+                head + b"\xff\xda\x00\x02",
+                head + seg(0xC0, sof) + seg(0xDA, sos) + bytes(scan) + b"\xff\xd9"):
+        with pytest.raises(pkg.PtxError):
+            pkg.decode_image(bad)
 
 
 def test_against_pillow(pkg, tmp_path):

@@ -393,6 +393,59 @@ def test_known_answer_rays_match_bruteforce(pkg, orc, name):
         assert (hits[:, k].view(np.uint32) == b[f].view(np.uint32)).all(), f
 
 
+@pytest.mark.parametrize("backend", [0, 1])
+def test_zero_bounces_is_a_black_frame(pkg, orc, backend):
+    # raygen.rgen:62: `for (bounce = 0; bounce < BounceCount; ...)` never runs -> radiance 0, alpha 1, nothing traced
+    import torch  # noqa: F401
+
+    scene = pkg.Scene("default")
+    W, H = 64, 40
+    r = pkg.Renderer(backend=backend)
+    r.upload(scene)
+    r.resize(W, H)
+    u = scene.uniform(W, H, bounces=0, sample_count=2)
+    r.render(u, scene.lights)
+    img, st = r.readback(), r.stats()
+    r.render_frames(scene.uniform(W, H, bounces=0), scene.lights, 2, 3)
+    img2 = r.readback()
+    r.close()
+    ref, ost = orc.OracleScene(scene.desc).render(u, scene.lights, W, H)
+    assert (img.view(np.uint32) == ref.view(np.uint32)).all() and (img[..., :3] == 0).all() and (img[..., 3] == 1).all()
+    assert (st.segments, st.shadowRays, st.pathSamples) == (ost.segments, ost.shadowRays, ost.pathSamples) == (0, 0, W * H * 2)
+    assert (img2 == img).all()
+
+
+def test_destroy_releases_device_memory(pkg):
+    """ptx_destroy frees everything a renderer allocated -- tree-build state kept for refits, skinning buffers, the
+    output stage -- so create / destroy cycles do not eat HBM."""
+    import torch
+
+    scene = pkg.Scene("animated_test", 1.0)
+    W, H = 256, 144
+
+    def cycle():
+        r = pkg.Renderer()
+        r.upload(scene)
+        r.resize(W, H)
+        scene.update(0.25)
+        it, bn = scene.animation_state()
+        r.update_animation(it, bn, rebuild=False)  # keeps the build state alive
+        r.render_frames(scene.uniform(W, H, bounces=3), scene.lights, 0, 2)
+        r.postprocess(2)
+        r.read_output()
+        r.trace_rays(util.random_rays(np.random.default_rng(0), 64, -2.0, 2.0))
+        r.close()
+
+    cycle()  # first use also pays one-off runtime allocations
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(6):
+        cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 8 << 20, f"{(free0 - free1) / 2**20:.1f} MiB lost over 6 create / destroy cycles"
+
+
 def test_error_behaviour(pkg):
     import torch  # noqa: F401
 

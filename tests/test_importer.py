@@ -192,6 +192,35 @@ def test_importer_errors(pkg, tmp_path):
         pkg.Scene("file:" + str(tmp_path / "broken.gltf"))
     with pytest.raises(pkg.PtxError):
         pkg.Scene("file:" + str(tmp_path / "missing.glb"))
+    # crafted offsets / lengths / strides: a span before or past its buffer must be refused, not read
+    import json
+
+    def variant(name, edit):
+        w = GltfWriter()
+        pos, nrm, uv, idx = quad(1.0)
+        w.node(mesh=w.mesh([w.primitive(pos, idx, nrm, uv)]))
+        p = tmp_path / name
+        w.write_gltf(p, external_bin=False)
+        doc = json.loads(p.read_text())
+        edit(doc)
+        p.write_text(json.dumps(doc))
+        return p
+
+    ok = variant("ok.gltf", lambda d: None)
+    assert pkg.Scene("file:" + str(ok)).triangle_count == 2
+    edits = {
+        "neg_offset": lambda d: d["bufferViews"][0].update(byteOffset=-16, byteLength=64),
+        "neg_length": lambda d: d["bufferViews"][0].update(byteOffset=16, byteLength=-8),
+        "huge_length": lambda d: d["bufferViews"][0].update(byteLength=2**62),
+        "offset_past_end": lambda d: d["bufferViews"][0].update(byteOffset=2**40, byteLength=-(2**40) + 8),
+        "neg_accessor_offset": lambda d: d["accessors"][0].update(byteOffset=-4),
+        "huge_accessor_offset": lambda d: d["accessors"][0].update(byteOffset=2**63 - 1),
+        "neg_stride": lambda d: d["bufferViews"][0].update(byteStride=-12),
+        "huge_count": lambda d: d["accessors"][0].update(count=2**40),
+    }
+    for name, edit in edits.items():
+        with pytest.raises(pkg.PtxError):
+            pkg.Scene("file:" + str(variant(name + ".gltf", edit)))
 
 
 @pytest.mark.gpu
