@@ -1,25 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the path-tracing hot path on MI355X.
 
-Metric (BASELINE.json): Msamples/s = W*H*spp / wall-seconds / 1e6 at 1920x1080, 8 spp, depth 8.
-A "step" is one pass of the hot path over one frame batch: reset the accumulation image, add
-`spp` samples per pixel (canonical schedule: one sample per launch, RNG frame = launch index,
-SURVEY.md 8a) and -- with N > 1 GPUs -- gather the pixel-tile shards to rank 0 (the single RCCL
-exchange of SURVEY.md 8e).  Scene upload and the LBVH build are outside the timed region (the
-reference builds its acceleration structures in UpdateSceneData, not in Render).  Inputs are
-resident in HBM when the timed region starts.
+Metric (BASELINE.json): Msamples/s = W*H*spp / wall-seconds / 1e6 at 1920x1080, 8 spp, depth 8, "including the final
+readback / gather" (SURVEY.md 8d).
+A "step" is one pass of the hot path over one frame batch: reset the accumulation image, add `spp` samples per pixel
+(canonical schedule: one sample per launch, RNG frame = launch index), with N > 1 GPUs gather the
+pixel-tile shards to rank 0 (the single RCCL exchange of SURVEY.md 8e), and read the RGBA32F sum back to page-locked
+host memory.  The read-back of step k overlaps the rendering of step k + 1 (ptx_readback_begin: device-side snapshot,
+PCIe copy on a second stream -- the reference reads its output back a frame late too, OutputSaver.cpp:120-199); the
+timed region ends when the last image is on the host.  `value` is that read-back-inclusive rate; the rate without any
+read-back is reported beside it (`no_readback`).  Scene upload and the tree build are outside the timed region (the
+reference builds its acceleration structures in UpdateSceneData, not in Render).  Inputs are resident in HBM when the
+timed region starts.
 
-Workload at N = 1: BASELINE configs[1] "ABeautifulGame, 1920x1080, 8 spp, depth 8" through its
-procedural stand-in `chess_like` (the glTF assets are downloaded at CMake time by the reference
-and do not exist offline).
+Workload at N = 1: BASELINE configs[1] "ABeautifulGame, 1920x1080, 8 spp, depth 8" through its procedural stand-in
+`chess_like` (the glTF assets are downloaded at CMake time by the reference and do not exist offline).
+The same line for the stand-ins of configs[3] (north_star's target scene), [2] and [4] rides in `configs`.
 
-N > 1: the frame is cut into 32x32 pixel tiles dealt round-robin to the ranks; no collective inside the
-data path, one all_gather of the tile shards per step.  Default `--scaling weak`: per-GPU work is fixed --
-every GPU adds `spp` x (W*H) path samples per step, i.e. the N-GPU job is the same frame at N*spp samples
-per pixel, each rank rendering its 1/N of the tiles at N*spp (what BASELINE configs[3] and [4] do: more GPUs
-come with more samples, 256 spp on 4 and 1024 spp on 8).  `--scaling strong` splits the fixed `spp` frame
-instead; a step of 16.6 M samples is then 2 M samples per rank at N = 8 and its duration is dominated by the
-latency floor of a bounce sequence, which is why it is not the default.
+N > 1: the frame is cut into 32x32 pixel tiles dealt round-robin to the ranks; no collective inside the data path, one
+all_gather of the tile shards per step.  The reported metric is the NAMED frame split over the GPUs (`"scaling":
+"strong"`: each rank renders its tiles of the same 8-spp frame); the weak-scaling figure (every GPU adds 8 spp: the job
+is the same frame at 8 N spp, which is how BASELINE configs[3] and [4] are posed) is measured in the same run and
+printed in `weak`.
+
+The timed region of K steps is repeated (`--repeats`, default: until >= 2 s have been timed) and the line reports the
+MEDIAN region; min / max ride in `spread`.
 
 Launch:  python bench.py --gpus N --steps K --warmup W           (N = 1)
          python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
@@ -28,6 +33,8 @@ Rank 0 prints ONE JSON line.
 from __future__ import annotations
 
 import argparse
+import glob
+import hashlib
 import json
 import math
 import os
@@ -43,6 +50,7 @@ import __graft_entry__ as graft  # noqa: E402
 STAND_IN = {"chess_like": "configs[1] 'Khronos ABeautifulGame'", "temple_like": "configs[2] 'UE4 Sun Temple'",
             "atrium_like": "configs[3] 'Intel Sponza (MAIN+CURTAINS+IVY)'", "street_like": "configs[4] 'Amazon Bistro night'",
             "attenuation_blob": "configs[0] 'Khronos DragonAttenuation'"}
+EXTRA_SCENES = ("atrium_like", "temple_like", "street_like")
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
@@ -66,7 +74,15 @@ def effective_cores() -> int:
     return n
 
 
-def cpu_baseline(orc, pkg, scene, width, height, depth, seconds):
+def source_digest(pkg) -> str:
+    """Identity of the kernels being measured: the HIP sources the library is built from."""
+    h = hashlib.sha256()
+    for f in ("pt_kernels.hip", "pt_bvh.hpp", "pt_device.hpp", "pt_post.hpp"):
+        h.update(open(os.path.join(pkg.PKG_DIR, "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(orc, scene, width, height, depth, seconds):
     """The oracle (a scalar C port of the shader path: OpenMP over 16x16 pixel tiles, binned-SAH BVH)
     on the host cores, on a bounded sample of the same workload: the same full frame, one sample
     per launch, as many frames as fit in `seconds` (a rate, so comparable with the 8-spp GPU run)."""
@@ -86,6 +102,7 @@ def cpu_baseline(orc, pkg, scene, width, height, depth, seconds):
         el = time.time() - t0
         if el >= seconds or frames >= 64:
             break
+    osc.close()
     return {
         "value": width * height * frames / el / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
         "sample": f"oracle (C, OpenMP dynamic over 16x16 tiles, SAH BVH) on the same {width}x{height} frame, "
@@ -93,11 +110,200 @@ def cpu_baseline(orc, pkg, scene, width, height, depth, seconds):
     }
 
 
+class Job:
+    """One renderer + scene + the step() of the metric, for any (rank, world)."""
+
+    def __init__(self, args, pkg, torch, dist, scene_name, rank, world, local_rank, shard=None):
+        self.args, self.pkg, self.torch, self.dist = args, pkg, torch, dist
+        self.rank, self.world = rank, world
+        self.W, self.H = args.width, args.height
+        self.scene = pkg.Scene(scene_name, args.detail)
+        self.lights = self.scene.lights
+        backend = pkg.BACKEND_WAVEFRONT if args.backend == "wavefront" else pkg.BACKEND_MEGAKERNEL
+        self.r = pkg.Renderer(device=local_rank, backend=backend)
+        t0 = time.time()
+        self.r.upload(self.scene)
+        self.r.synchronize()
+        self.upload_build_s = time.time() - t0
+        self.r.resize(self.W, self.H)
+        self.shard_rank, self.shard_world = shard if shard else (rank, world)
+        self.r.set_tile_shard(self.shard_rank, self.shard_world, args.tile)
+        self.u = self.scene.uniform(self.W, self.H, bounces=args.depth)
+        self.build_ms = self.r.stats().lastBuildMs
+        self.n_tris = self.scene.triangle_count
+        self.nbytes = self.W * self.H * 16
+        # page-locked host images for the pipelined read-back (two: step k + 1 must not overwrite what the caller of
+        # step k is still looking at)
+        self.host = [torch.empty(self.W * self.H * 4, dtype=torch.float32, pin_memory=True) for _ in range(2)] if rank == 0 else []
+        self.flip = 0
+        if world > 1:  # gather plumbing: equal-size padded shard buffers, one all_gather
+            self.shard_floats = max(self.r.shard_bytes(k) for k in range(world)) // 4
+            self.send = torch.zeros(self.shard_floats, dtype=torch.float32, device="cuda")
+            self.recv = torch.zeros(world * self.shard_floats, dtype=torch.float32, device="cuda")
+
+    def step(self, job_spp, readback=True):
+        r, torch, dist = self.r, self.torch, self.dist
+        r.reset()
+        r.render_frames(self.u, self.lights, 0, job_spp)
+        if self.world > 1:
+            r.pack_shard(self.send.data_ptr())
+            r.synchronize()  # the pack ran on the renderer's stream; the collective runs on torch's
+            if self.args.dist_backend == "nccl":
+                dist.all_gather_into_tensor(self.recv, self.send)  # RCCL: every shard straight over its own xGMI link
+            else:  # gloo (testing): staged through the host
+                parts = [torch.empty(self.shard_floats) for _ in range(self.world)]
+                dist.all_gather(parts, self.send.cpu())
+                self.recv.copy_(torch.cat(parts))
+            # every rank: the next step's pack_shard (renderer stream) must not overwrite `send` under the collective
+            torch.cuda.current_stream().synchronize()
+            if self.rank == 0:
+                for k in range(self.world):
+                    r.unpack_shard(k, self.recv.data_ptr() + k * self.shard_floats * 4)
+        if readback and self.rank == 0:
+            r.readback_begin(self.host[self.flip].data_ptr(), self.nbytes)
+            self.flip ^= 1
+
+    def finish(self):
+        self.r.readback_end()
+        self.r.synchronize()
+
+    def last_image(self):
+        return self.host[self.flip ^ 1].numpy().reshape(self.H, self.W, 4)
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+        self.r.synchronize()
+
+    def timed(self, job_spp, steps, readback=True, collect=None):
+        """EXACTLY `steps` steps between two barriers; max over ranks.  collect: dict of per-kernel accumulators."""
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step(job_spp, readback)
+            if collect is not None:
+                st = self.r.stats()
+                collect["trace_ms"] += st.lastTraceMs
+                collect["shade_ms"] += st.lastShadeMs
+                collect["shadow_ms"] += st.lastShadowMs
+                collect["tail_ms"] += st.lastTailMs
+                collect["launches"] += st.traceLaunches // 2
+                collect["rays"] += st.tracedRays
+                collect["segments"], collect["shadow"] = st.segments, st.shadowRays
+        self.finish()
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        if self.world > 1:
+            t = self.torch.tensor([elapsed], dtype=self.torch.float64, device="cuda" if self.args.dist_backend == "nccl" else "cpu")
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
+
+    def measure(self, job_spp, steps, warmup, repeats, min_seconds, readback=True):
+        """Warm up, then repeat the K-step timed region; returns (median, all regions, kernel stats of the median-like last)."""
+        for _ in range(warmup):
+            self.step(job_spp, readback)
+        self.finish()
+        regions, stats = [], None
+        total = 0.0
+        while True:
+            c = {"trace_ms": 0.0, "shade_ms": 0.0, "shadow_ms": 0.0, "tail_ms": 0.0, "launches": 0, "rays": 0, "segments": 0, "shadow": 0}
+            el = self.timed(job_spp, steps, readback, c)
+            regions.append(el)
+            stats = c
+            total += el
+            done = len(regions) >= repeats if repeats > 0 else (total >= min_seconds or len(regions) >= 50)
+            if self.world > 1:  # every rank must take the same decision
+                flag = self.torch.tensor([1 if done else 0], dtype=self.torch.int32, device="cuda" if self.args.dist_backend == "nccl" else "cpu")
+                self.dist.broadcast(flag, 0)
+                done = bool(flag.item())
+            if done:
+                break
+        return float(np.median(regions)), regions, stats
+
+    def close(self):
+        self.r.close()
+        self.scene.close()
+
+
+def roofline(job, stats, digest):
+    """Dominant kernel k_trace_closest: algorithmic bytes (SURVEY.md 8d model) and counter-measured HBM bytes, both over
+    the kernel's live HIP-event time.  The kernel is latency-bound (dependent node fetches), not HBM-bound: `bound` says
+    so, `frac` prices the model bytes against the HBM peak as the contract asks, `frac_counter` the bytes that moved."""
+    bpr = algorithmic_bytes_per_closest_ray(job.n_tris)
+    trace_s = stats["trace_ms"] * 1e-3
+    launches = max(stats["launches"], 1)
+    achieved = stats["rays"] * bpr / trace_s / 1e9
+    out = {
+        "bound": "latency", "priced_against": "hbm", "kernel": "k_trace_closest", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS, "traffic": None, "achieved_counter": None, "frac_counter": None,
+        "model_bytes_per_ray": bpr, "model_bytes_per_launch": bpr * stats["rays"] / launches,
+        "rays_per_launch": stats["rays"] / launches, "avg_launch_ms": stats["trace_ms"] / launches, "launches": stats["launches"],
+        "grays_per_s": stats["rays"] / trace_s / 1e9,
+        "limiter": "dependent-fetch latency: SQ_WAIT_ANY / SQ_WAVE_CYCLES of this kernel in profiles/*_sq.txt",
+    }
+    # HBM traffic comes from separate rocprofv3 --pmc passes of this same command (PMC counters cannot be read from
+    # inside the process): the newest committed summary is attached when it was collected on this workload, and marked
+    # stale when the kernels have changed since.
+    a = job.args
+    tj = a.traffic_json or (sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic.json")), key=os.path.getmtime) or [None])[-1]
+    default_workload = (job.scene.name, a.detail, job.W, job.H, a.spp, a.depth, job.world) == ("chess_like", 1.0, 1920, 1080, 8, 8, 1)
+    if tj and os.path.exists(tj) and default_workload:
+        doc = json.load(open(tj))
+        t = doc.get("k_trace_closest")
+        if t:
+            traffic = t["hbm_bytes_per_launch"]
+            out["traffic"] = traffic
+            out["achieved_counter"] = traffic / (out["avg_launch_ms"] * 1e-3) / 1e9
+            out["frac_counter"] = out["achieved_counter"] / HBM_PEAK_GBS
+            out["traffic_source"] = os.path.relpath(tj, REPO) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, (2*FETCH+WRITE)*1024)"
+            out["traffic_stale"] = doc.get("source_digest") != digest
+    return out
+
+
+def scene_line(args, pkg, torch, dist, orc, name, rank, world, local_rank, steps, warmup, min_seconds, with_cpu, digest):
+    """Measure one scene: the read-back-inclusive rate (value), the rate without read-back, roofline, CPU baseline."""
+    job = Job(args, pkg, torch, dist, name, rank, world, local_rank)
+    W, H = job.W, job.H
+    spp = args.spp
+    med, regions, stats = job.measure(spp, steps, warmup, args.repeats, min_seconds, readback=True)
+    med_nr, regions_nr, _ = job.measure(spp, steps, 0, max(1, min(len(regions), 3)), 0.0, readback=False)
+    line = None
+    if rank == 0:
+        samples = W * H * spp * steps
+        img = job.last_image()
+        line = {
+            "value": samples / med / 1e6, "unit": "Msamples/s", "ms_per_step": med / steps * 1e3, "steps": steps,
+            "no_readback": {"value": samples / med_nr / 1e6, "ms_per_step": med_nr / steps * 1e3},
+            "spread": {"regions": len(regions), "timed_s": float(sum(regions)), "min_ms_per_step": min(regions) / steps * 1e3,
+                       "max_ms_per_step": max(regions) / steps * 1e3},
+            "config": {
+                "workload": f"{name} (procedural stand-in for BASELINE {STAND_IN.get(name, 'scenes')}), {W}x{H}, {spp} spp, depth {args.depth}",
+                "triangles": job.n_tris, "backend": args.backend, "tile": args.tile,
+                "segments_per_sample": stats["segments"] / (W * H * spp / world),
+                "tree_build_ms": job.build_ms, "upload_plus_build_s": job.upload_build_s,
+                "kernel_ms_per_step": {"k_trace_closest": stats["trace_ms"] / steps, "k_shade": stats["shade_ms"] / steps,
+                                       "k_trace_shadow": stats["shadow_ms"] / steps, "k_tail": stats["tail_ms"] / steps},
+                "frame_checksum": [float(img[..., :3].astype(np.float64).sum()), bool(np.isfinite(img).all()), bool((img[..., 3] == 1).all())],
+            },
+        }
+        if args.backend == "wavefront" and stats["trace_ms"] > 0:
+            line["roofline"] = roofline(job, stats, digest)
+        if with_cpu:
+            line["cpu_baseline"] = cpu_baseline(orc, job.scene, W, H, args.depth, args.cpu_seconds)
+            line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+    job.close()
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--repeats", type=int, default=0, help="timed regions of K steps; 0 = until --min-seconds have been timed")
+    ap.add_argument("--min-seconds", type=float, default=2.0)
     ap.add_argument("--scene", default="chess_like")
     ap.add_argument("--detail", type=float, default=1.0)
     ap.add_argument("--width", type=int, default=1920)
@@ -106,19 +312,19 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--tile", type=int, default=32)
     ap.add_argument("--backend", default="wavefront", choices=["wavefront", "megakernel"])
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N > 1: weak = every GPU adds spp samples per pixel-equivalent (job = N*spp spp, tile-sharded); "
-                         "strong = the fixed spp frame is split over the GPUs")
+    ap.add_argument("--no-extra-scenes", action="store_true", help="N = 1: skip the `configs` lines of the other stand-in scenes")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --single-device lets the N > 1 code path be exercised on a 1-GPU box (testing only)")
     ap.add_argument("--single-device", action="store_true", help="testing only: every rank uses cuda:0")
     ap.add_argument("--emulate-shard", default=None, metavar="R/N",
                     help="experiments only: one process renders the tile shard of rank R of N (no gather) to see what a rank of an "
                          "N-GPU run costs; the printed line is marked and is not a benchmark result")
+    ap.add_argument("--emulate-scaling", default="strong", choices=["weak", "strong"])
     ap.add_argument("--traffic-json", default=None,
                     help="per-kernel HBM bytes per launch from tools/pmc_traffic.py (default: newest profiles/r*_traffic.json)")
+    ap.add_argument("--dump-image", default=None, help="testing: rank 0 saves the last frame (npy)")
     args = ap.parse_args()
 
     import torch
@@ -144,139 +350,71 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     pkg = graft.load_package()  # after torch: one HIP runtime in the process
+    orc = graft.load_oracle() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    digest = source_digest(pkg)
     W, H = args.width, args.height
-    scene = pkg.Scene(args.scene, args.detail)
-    lights = scene.lights
-    backend = pkg.BACKEND_WAVEFRONT if args.backend == "wavefront" else pkg.BACKEND_MEGAKERNEL
-    r = pkg.Renderer(device=local_rank, backend=backend)
-    t0 = time.time()
-    r.upload(scene)
-    r.synchronize()
-    upload_build_s = time.time() - t0
-    r.resize(W, H)
-    emu_rank, emu_world = (int(x) for x in args.emulate_shard.split("/")) if args.emulate_shard else (rank, world)
-    r.set_tile_shard(emu_rank, emu_world, args.tile)
-    u = scene.uniform(W, H, bounces=args.depth)
-    # samples per pixel of the whole job; a rank renders its tiles at this many frames
-    job_spp = args.spp * (emu_world if args.scaling == "weak" else 1)
-    build_ms = r.stats().lastBuildMs
-    n_tris = scene.triangle_count
+    metric = "Msamples/s (paths*spp/s) at 1920x1080, 8spp, depth 8"
+    common = {"metric": metric, "unit": "Msamples/s", "n_gpus": world, "warmup": args.warmup, "higher_is_better": True,
+              "vs_baseline": None,  # the reference publishes no number for this metric
+              "dtype": "f32", "data": "synthetic", "source_digest": digest}
 
-    # gather plumbing (N > 1): equal-size padded shard buffers, one all_gather
-    if world > 1:
-        shard_floats = max(r.shard_bytes(k) for k in range(world)) // 4
-        send = torch.zeros(shard_floats, dtype=torch.float32, device="cuda")
-        recv = torch.zeros(world * shard_floats, dtype=torch.float32, device="cuda") if True else None
-
-    def step():
-        r.reset()
-        r.render_frames(u, lights, 0, job_spp)
-        if world > 1:
-            r.pack_shard(send.data_ptr())
-            r.synchronize()
-            if args.dist_backend == "nccl":
-                dist.all_gather_into_tensor(recv, send)  # RCCL: every shard straight over its own xGMI link
-            else:  # gloo (testing): staged through the host
-                parts = [torch.empty(shard_floats) for _ in range(world)]
-                dist.all_gather(parts, send.cpu())
-                recv.copy_(torch.cat(parts))
-            if rank == 0:
-                torch.cuda.current_stream().synchronize()
-                for k in range(world):
-                    r.unpack_shard(k, recv.data_ptr() + k * shard_floats * 4)
-        r.synchronize()
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        r.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    trace_ms = shade_ms = shadow_ms = tail_ms = 0.0
-    trace_launches = 0
-    closest_rays = 0
-    segments = shadow = 0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        st = r.stats()
-        trace_ms += st.lastTraceMs
-        shade_ms += st.lastShadeMs
-        shadow_ms += st.lastShadowMs
-        tail_ms += st.lastTailMs
-        trace_launches += st.traceLaunches // 2
-        closest_rays += st.tracedRays
-        segments, shadow = st.segments, st.shadowRays
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    checksum = None
-    if rank == 0 and os.environ.get("BENCH_CHECKSUM"):
-        img = r.readback()
-        checksum = [float(img[..., :3].astype(np.float64).sum()), int(np.isfinite(img).all()), int((img[..., 3] == 1).all())]
-    if rank == 0:
-        samples = W * H * job_spp * args.steps
-        value = samples / elapsed / 1e6
-        out = {
-            "metric": "Msamples/s (paths*spp/s) at 1920x1080, 8spp, depth 8",
-            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": args.scaling,  # weak: W*H*spp samples per GPU and step; strong: one fixed spp frame split over the GPUs
-            "vs_baseline": None,   # the reference publishes no number for this metric
-            "dtype": "f32", "data": "synthetic",
-            "config": {
-                "workload": f"{args.scene} (procedural stand-in for BASELINE {STAND_IN.get(args.scene, 'scenes')}), "
-                            f"{W}x{H}, {args.spp} spp" + (f" per GPU = {job_spp} spp" if job_spp != args.spp else "") + f", depth {args.depth}",
-                "triangles": n_tris, "backend": args.backend, "tile": args.tile,
-                "parallelism": f"pixel-tile shard x{world}" + (", 1 RCCL all_gather" if world > 1 else ""),
-                "segments_per_sample": segments / (W * H * job_spp / world) if world else None,
-                "lbvh_build_ms": build_ms, "upload_plus_build_s": upload_build_s,
-                "kernel_ms_per_step": {"k_trace_closest": trace_ms / args.steps, "k_shade": shade_ms / args.steps,
-                                       "k_trace_shadow": shadow_ms / args.steps, "k_tail": tail_ms / args.steps},
-            },
-        }
-        if checksum is not None:
-            out["config"]["frame_checksum"] = checksum
-        if args.emulate_shard:
-            out["emulated_shard"] = args.emulate_shard
-            out["value"] = value / emu_world  # samples of this shard only
-            out["config"]["parallelism"] = f"EMULATION of rank {emu_rank} of {emu_world} (tile shard, no gather)"
-        if args.backend == "wavefront" and trace_ms > 0:
-            bpr = algorithmic_bytes_per_closest_ray(n_tris)
-            achieved = closest_rays * bpr / (trace_ms * 1e-3) / 1e9
-            out["roofline"] = {
-                "bound": "hbm", "kernel": "k_trace_closest", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "bytes_per_ray": bpr, "rays_per_launch": closest_rays / max(trace_launches, 1),
-                "avg_launch_ms": trace_ms / max(trace_launches, 1), "launches": trace_launches,
-                "grays_per_s": closest_rays / (trace_ms * 1e-3) / 1e9,
-            }
-            # HBM traffic comes from separate rocprofv3 --pmc passes of this same command (PMC counters
-            # cannot be read from inside the process); the committed summary is attached when the
-            # workload is the default one it was collected on.
-            import glob
-            tj = args.traffic_json or (sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic.json"))) or [None])[-1]
-            default_workload = (args.scene, args.detail, W, H, args.spp, args.depth, world) == ("chess_like", 1.0, 1920, 1080, 8, 8, 1)
-            if tj and os.path.exists(tj) and default_workload:
-                t = json.load(open(tj)).get("k_trace_closest")
-                if t:
-                    out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = os.path.relpath(tj, REPO) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, (2*FETCH+WRITE)*1024)"
-                    out["roofline"]["algorithmic_bytes_per_launch"] = bpr * closest_rays / max(trace_launches, 1)
-        if world == 1 and not args.no_cpu_baseline:
-            orc = graft.load_oracle()
-            out["cpu_baseline"] = cpu_baseline(orc, pkg, scene, W, H, args.depth, args.cpu_seconds)
+    if args.emulate_shard:  # experiments: what one rank of an N-GPU job costs, on one GPU, no gather
+        er, ew = (int(x) for x in args.emulate_shard.split("/"))
+        job = Job(args, pkg, torch, dist, args.scene, 0, 1, local_rank, shard=(er, ew))
+        job_spp = args.spp * (ew if args.emulate_scaling == "weak" else 1)
+        med, regions, stats = job.measure(job_spp, args.steps, args.warmup, args.repeats, args.min_seconds, readback=False)
+        out = dict(common, emulated_shard=args.emulate_shard, scaling=args.emulate_scaling, steps=args.steps,
+                   value=W * H * job_spp * args.steps / med / 1e6 / ew, ms_per_step=med / args.steps * 1e3,
+                   config={"workload": f"EMULATION of rank {er} of {ew} ({args.scene}, tile shard, no gather, {job_spp} spp)",
+                           "kernel_ms_per_step": {k: stats[k] / args.steps for k in ("trace_ms", "shade_ms", "shadow_ms", "tail_ms")}})
         print(json.dumps(out), flush=True)
-    r.close()
-    if world > 1:
-        dist.destroy_process_group()
+        job.close()
+        return
+
+    if world == 1:
+        line = scene_line(args, pkg, torch, dist, orc, args.scene, 0, 1, local_rank, args.steps, args.warmup, args.min_seconds,
+                          not args.no_cpu_baseline, digest)
+        out = dict(common, scaling="strong", **line)  # N = 1 of the strong-scaling series: the named 8-spp frame
+        out["config"]["parallelism"] = "pixel-tile shard x1"
+        if not args.no_extra_scenes and args.scene == "chess_like":
+            # the same measurement on the other stand-ins; fewer steps per region: their steps are longer
+            out["configs"] = []
+            for name in EXTRA_SCENES:
+                steps = max(3, args.steps // 4)
+                l = scene_line(args, pkg, torch, dist, orc, name, 0, 1, local_rank, steps, 1, min(args.min_seconds, 1.5),
+                               not args.no_cpu_baseline, digest)
+                out["configs"].append(l)
+        print(json.dumps(out), flush=True)
+        return
+
+    # ---- N > 1: strong scaling of the named frame is the metric; weak scaling beside it
+    job = Job(args, pkg, torch, dist, args.scene, rank, world, local_rank)
+    med_s, regions_s, stats_s = job.measure(args.spp, args.steps, args.warmup, args.repeats, args.min_seconds, readback=True)
+    img = job.last_image().copy() if rank == 0 else None
+    weak_spp = args.spp * world
+    med_w, regions_w, stats_w = job.measure(weak_spp, args.steps, 1, args.repeats, args.min_seconds, readback=True)
+    if rank == 0:
+        samples = W * H * args.spp * args.steps
+        out = dict(common, scaling="strong", steps=args.steps, value=samples / med_s / 1e6, ms_per_step=med_s / args.steps * 1e3,
+                   spread={"regions": len(regions_s), "timed_s": float(sum(regions_s)), "min_ms_per_step": min(regions_s) / args.steps * 1e3,
+                           "max_ms_per_step": max(regions_s) / args.steps * 1e3},
+                   weak={"scaling": "weak", "value": W * H * weak_spp * args.steps / med_w / 1e6, "ms_per_step": med_w / args.steps * 1e3,
+                         "workload": f"{weak_spp} spp in total = {args.spp} spp per GPU"},
+                   config={"workload": f"{args.scene} (procedural stand-in for BASELINE {STAND_IN.get(args.scene, 'scenes')}), {W}x{H}, "
+                                       f"{args.spp} spp, depth {args.depth}",
+                           "triangles": job.n_tris, "backend": args.backend, "tile": args.tile,
+                           "parallelism": f"pixel-tile shard x{world}, 1 RCCL all_gather + read-back on rank 0 per step",
+                           "rank0_kernel_ms_per_step": {"k_trace_closest": stats_s["trace_ms"] / args.steps, "k_shade": stats_s["shade_ms"] / args.steps,
+                                                        "k_trace_shadow": stats_s["shadow_ms"] / args.steps, "k_tail": stats_s["tail_ms"] / args.steps},
+                           "frame_checksum": [float(img[..., :3].astype(np.float64).sum()), bool(np.isfinite(img).all()), bool((img[..., 3] == 1).all())]})
+        if args.backend == "wavefront" and stats_w["trace_ms"] > 0:
+            out["roofline"] = roofline(job, stats_w, digest)
+            out["roofline"]["measured_on"] = "rank 0 of the weak-scaling run (per-GPU work of the 1-GPU benchmark)"
+        if args.dump_image:
+            np.save(args.dump_image, img)
+        print(json.dumps(out), flush=True)
+    job.close()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

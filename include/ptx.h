@@ -385,6 +385,12 @@ PTX_API int ptx_render_frames(PtxRenderer *r, const PtxRaygenUniformData *unifor
 PTX_API int ptx_synchronize(PtxRenderer *r);
 /* imageLoad of the accumulation image: device -> host, W*H*4 floats (running SUM). */
 PTX_API int ptx_readback(PtxRenderer *r, float *rgba, size_t bytes);
+/* The same read-back, overlapped with whatever is launched next: _begin snapshots the image on the render stream and
+ * starts the copy into `pinnedHost` (page-locked memory, width*height*16 bytes) on a second stream; _end waits for it.
+ * A second _begin before _end queues behind the first.  (OutputSaver reads its output back a frame late in the same
+ * way, OutputSaver.cpp:120-199.) */
+PTX_API int ptx_readback_begin(PtxRenderer *r, float *pinnedHost, size_t bytes);
+PTX_API int ptx_readback_end(PtxRenderer *r);
 /* Device pointer of the accumulation image (for the RCCL gather) and its size. */
 PTX_API void *ptx_device_accum_ptr(PtxRenderer *r);
 PTX_API size_t ptx_accum_bytes(const PtxRenderer *r);

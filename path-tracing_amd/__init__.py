@@ -40,7 +40,7 @@ HOST_FLAGS = ["-std=c++20", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-fvi
 PTX_SYMBOLS = [
     "ptx_create", "ptx_destroy", "ptx_last_error", "ptx_device_count", "ptx_scene_upload", "ptx_build_accel",
     "ptx_resize", "ptx_set_tile_shard", "ptx_set_backend", "ptx_reset_accumulation", "ptx_render",
-    "ptx_render_frames", "ptx_synchronize", "ptx_readback", "ptx_device_accum_ptr", "ptx_accum_bytes",
+    "ptx_render_frames", "ptx_synchronize", "ptx_readback", "ptx_readback_begin", "ptx_readback_end", "ptx_device_accum_ptr", "ptx_accum_bytes",
     "ptx_shard_bytes", "ptx_pack_shard", "ptx_unpack_shard", "ptx_get_stats", "ptx_bind_accumulation",
     "ptx_trace_rays", "ptx_test_input_stride", "ptx_test_output_stride", "ptx_test_eval", "ptx_test_texture",
     "ptx_postprocess", "ptx_read_output", "ptx_write_accumulation", "ptx_update_animation",
@@ -237,6 +237,8 @@ def load_hip() -> C.CDLL:
         lib.ptx_render_frames.argtypes = [P, C.POINTER(RaygenUniformData), C.POINTER(LightsUbo), C.c_uint32, C.c_uint32]
         lib.ptx_synchronize.argtypes = [P]
         lib.ptx_readback.argtypes = [P, P, C.c_size_t]
+        lib.ptx_readback_begin.argtypes = [P, P, C.c_size_t]
+        lib.ptx_readback_end.argtypes = [P]
         lib.ptx_device_accum_ptr.argtypes = [P]
         lib.ptx_device_accum_ptr.restype = P
         lib.ptx_accum_bytes.argtypes = [P]
@@ -391,6 +393,13 @@ class Renderer:
         img = np.empty((self.height, self.width, 4), dtype=np.float32)
         self._check(self.lib.ptx_readback(self.handle, img.ctypes.data, img.nbytes))
         return img
+
+    def readback_begin(self, pinned_ptr: int, nbytes: int):
+        """ptx_readback_begin into page-locked host memory (e.g. a torch tensor with pin_memory=True)."""
+        self._check(self.lib.ptx_readback_begin(self.handle, pinned_ptr, nbytes))
+
+    def readback_end(self):
+        self._check(self.lib.ptx_readback_end(self.handle))
 
     def update_animation(self, instance_transforms=None, bones=None, rebuild: bool = False):
         """ptx_update_animation: n x 12 instance transforms and / or m x 12 bone matrices, then refit (or rebuild)."""

@@ -1407,6 +1407,11 @@ struct PtxRenderer
     DevBuf<uint32_t> outSrgb8;
     bool outputReady = false;
     float4 *boundImage = nullptr; // external accumulation buffer, if bound
+    // pipelined read-back (ptx_readback_begin / _end): snapshot of the image, copied out on its own stream
+    DevBuf<float4> staging;
+    hipStream_t copyStream = nullptr;
+    hipEvent_t evSnapshot = nullptr, evCopied = nullptr;
+    bool copyInFlight = false;
 
     // wavefront state
     size_t slotCapacity = 0;
@@ -1619,6 +1624,9 @@ void ptx_destroy(PtxRenderer *r)
     }
     if (r->evStart)
         (void)hipEventDestroy(r->evStart);
+    if (r->copyStream) { (void)hipStreamSynchronize(r->copyStream); (void)hipStreamDestroy(r->copyStream); }
+    if (r->evSnapshot) (void)hipEventDestroy(r->evSnapshot);
+    if (r->evCopied) (void)hipEventDestroy(r->evCopied);
     if (r->hostCounters)
         (void)hipHostFree(r->hostCounters);
     if (r->evA) (void)hipEventDestroy(r->evA);
@@ -2622,6 +2630,44 @@ int ptx_readback(PtxRenderer *r, float *rgba, size_t bytes)
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_readback: buffer must be width*height*16 bytes");
     HIP_TRY(r, hipMemcpyAsync(rgba, imagePtr(r), bytes, hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(r, hipStreamSynchronize(r->stream));
+    return PTX_OK;
+}
+
+// Read-back that overlaps the next launches: a device-to-device snapshot of the image on the render stream (33 MB at
+// 1080p: ~20 us), then the PCIe copy on a second stream while the render stream goes on.  The reference reads its
+// output back the same way, a frame late (OutputSaver.cpp:120-199).
+int ptx_readback_begin(PtxRenderer *r, float *pinnedHost, size_t bytes)
+{
+    if (!r || !pinnedHost || !imagePtr(r) || bytes != (size_t)r->width * r->height * sizeof(float4))
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_readback_begin: buffer must be width*height*16 bytes");
+    HIP_TRY(r, hipSetDevice(r->device));
+    if (!r->copyStream)
+    {
+        HIP_TRY(r, hipStreamCreateWithFlags(&r->copyStream, hipStreamNonBlocking));
+        HIP_TRY(r, hipEventCreateWithFlags(&r->evSnapshot, hipEventDisableTiming));
+        HIP_TRY(r, hipEventCreateWithFlags(&r->evCopied, hipEventDisableTiming));
+    }
+    HIP_TRY(r, r->staging.alloc((size_t)r->width * r->height));
+    if (r->copyInFlight) // the previous copy still reads the staging image
+        HIP_TRY(r, hipStreamWaitEvent(r->stream, r->evCopied, 0));
+    HIP_TRY(r, hipMemcpyAsync(r->staging.p, imagePtr(r), bytes, hipMemcpyDeviceToDevice, r->stream));
+    HIP_TRY(r, hipEventRecord(r->evSnapshot, r->stream));
+    HIP_TRY(r, hipStreamWaitEvent(r->copyStream, r->evSnapshot, 0));
+    HIP_TRY(r, hipMemcpyAsync(pinnedHost, r->staging.p, bytes, hipMemcpyDeviceToHost, r->copyStream));
+    HIP_TRY(r, hipEventRecord(r->evCopied, r->copyStream));
+    r->copyInFlight = true;
+    return PTX_OK;
+}
+
+int ptx_readback_end(PtxRenderer *r)
+{
+    if (!r)
+        return PTX_ERROR_INVALID_ARGUMENT;
+    if (r->copyInFlight)
+    {
+        HIP_TRY(r, hipStreamSynchronize(r->copyStream));
+        r->copyInFlight = false;
+    }
     return PTX_OK;
 }
 

@@ -16,8 +16,19 @@ absolute value is an upper estimate (the guide: other patterns are uncalibrated)
 import collections
 import csv
 import glob
+import hashlib
 import json
+import os
 import sys
+
+
+def source_digest():
+    """Same digest as bench.py's: which kernels these counters were collected on."""
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "path-tracing_amd", "csrc")
+    h = hashlib.sha256()
+    for f in ("pt_kernels.hip", "pt_bvh.hpp", "pt_device.hpp", "pt_post.hpp"):
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def load(d):
@@ -43,8 +54,10 @@ def main():
         f_kib, w_kib = (vf / nf if nf else 0.0), (vw / nw if nw else 0.0)
         out[k] = {"launches": n, "fetch_size_kib_per_launch": f_kib, "write_size_kib_per_launch": w_kib,
                   "hbm_bytes_per_launch": (2.0 * f_kib + w_kib) * 1024.0}
+    ranked = sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])
+    out["source_digest"] = source_digest()
     json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
-    for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:8]:
+    for k, v in ranked[:8]:
         print(f"{k:28s} launches {v['launches']:4d}  {v['hbm_bytes_per_launch'] / 1e6:10.2f} MB/launch")
 
 

@@ -1,0 +1,26 @@
+#!/bin/bash
+# tools/profile_set.sh TAG [bench.py args ...] -- run ON THE GPU BOX (through gpurun): the profile set of one build.
+#   gpurun_out/TAG_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the default bench.py workload
+#   gpurun_out/TAG_traffic.json       per-kernel HBM bytes per launch from two PMC passes (FETCH_SIZE, WRITE_SIZE; separate
+#                                     passes, no trace domains beside --kernel-trace, as the guide prescribes)
+#   gpurun_out/TAG_sq.txt             SQ counter summary (wave cycles / waiting / issuing, instruction mix)
+#   gpurun_out/TAG_bench.json         the un-profiled bench.py line of the same build
+# Copy what is to be judged into profiles/ afterwards.
+TAG=${1:?tag}; shift
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+CMD="python3 bench.py --steps 5 --warmup 1 --repeats 1 --no-cpu-baseline --no-extra-scenes $*"
+for d in trace fetch write sq1 sq2; do rm -rf gpurun_out/${TAG}_$d; done
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace -o $TAG -- $CMD > gpurun_out/${TAG}_trace.log 2>&1; echo "trace rc=$?"
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${TAG}_fetch -o $TAG -- $CMD > gpurun_out/${TAG}_fetch.log 2>&1; echo "fetch rc=$?"
+timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${TAG}_write -o $TAG -- $CMD > gpurun_out/${TAG}_write.log 2>&1; echo "write rc=$?"
+python3 tools/pmc_traffic.py gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write gpurun_out/${TAG}_traffic.json
+python3 tools/trace_gaps.py gpurun_out/${TAG}_trace | grep step | tail -3
+CMD3="python3 bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-extra-scenes $*"
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/${TAG}_sq1 -o sq -- $CMD3 > gpurun_out/${TAG}_sq1.log 2>&1; echo "sq1 rc=$?"
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU --output-format csv -d gpurun_out/${TAG}_sq2 -o sq -- $CMD3 > gpurun_out/${TAG}_sq2.log 2>&1; echo "sq2 rc=$?"
+python3 tools/pmc_sq.py gpurun_out/${TAG}_sq1 gpurun_out/${TAG}_sq2 > gpurun_out/${TAG}_sq.txt 2>&1
+cp "$(find gpurun_out/${TAG}_trace -name '*kernel_stats.csv' | head -1)" gpurun_out/${TAG}_kernel_stats.csv 2>/dev/null
+find gpurun_out/${TAG}_trace gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write gpurun_out/${TAG}_sq1 gpurun_out/${TAG}_sq2 -name "*.csv" -size +1M -delete
+timeout 900 python3 bench.py $* > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; tail -c 2500 gpurun_out/${TAG}_bench.json
