@@ -71,7 +71,7 @@ PT_DEV float unorderedFloat(uint32_t u)
 __global__ void k_tri_setup(uint32_t n, uint32_t pairCount, const uint32_t *__restrict__ pairFirst,
                             const DevPair *__restrict__ pairs, const PtxVertex *__restrict__ vertices,
                             const uint32_t *__restrict__ indices, Tri *__restrict__ triTmp, float4 *__restrict__ boxLo,
-                            float4 *__restrict__ boxHi, uint32_t *__restrict__ sceneBounds)
+                            float4 *__restrict__ boxHi, uint32_t *__restrict__ sceneBounds, uint8_t *__restrict__ inert, int refit)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n)
@@ -97,11 +97,22 @@ __global__ void k_tri_setup(uint32_t n, uint32_t pairCount, const uint32_t *__re
     // A zero-area triangle (exactly vanishing edge cross product: repeated or collinear vertices) is never hit, as in
     // Vulkan.  Otherwise det = e1 . (d x e2) is a rounding residue instead of 0 and the test reports a meaningless t
     // (found by the full-size sweep on atrium_like: e1 == e2, "hit" at t = 16 for a ray passing the vertex at 29.65).
+    bool isInert;
     {
         const f3 n = cross(e1, e2);
-        if (n.x == 0.0f && n.y == 0.0f && n.z == 0.0f)
+        isInert = n.x == 0.0f && n.y == 0.0f && n.z == 0.0f;
+        if (isInert)
             e1 = e2 = F3s(0.0f);
     }
+    // Inert triangles take no part in the tree: a full build sorts them behind the others (k_morton) and builds over the
+    // rest.  (Kept in the tree as point boxes they cannot be hit either, but the rings of them at the poles of lathed
+    // meshes tie in PLOC's area order and merge one pair per iteration: 346 instead of 107 iterations for chess_like.)
+    // A refit keeps the order of the last full build: a triangle that has gone inert since stays where it is, unhittable;
+    // one that has come to life is not in the tree, and the caller has to rebuild (sceneBounds[7]).
+    if (!refit)
+        inert[g] = isInert ? 1 : 0;
+    else if (inert[g] && !isInert)
+        sceneBounds[7] = 1u;
     Tri t;
     t.a = make_float4(w[0].x, w[0].y, w[0].z, e1.x);
     t.b = make_float4(e1.y, e1.z, e2.x, e2.y);
@@ -125,7 +136,7 @@ __global__ void k_tri_setup(uint32_t n, uint32_t pairCount, const uint32_t *__re
     }
     boxLo[g] = make_float4(l[0], l[1], l[2], 0.0f);
     boxHi[g] = make_float4(h[0], h[1], h[2], 0.0f);
-    for (int a = 0; a < 3; a++)
+    for (int a = 0; a < 3 && !isInert; a++)
     {
         const float c = 0.5f * (l[a] + h[a]);
         if (c == c && fabsf(c) < 3.0e38f)
@@ -147,12 +158,21 @@ PT_DEV uint64_t expandBits21(uint32_t v) // 21 bits -> every third bit of 63
     return x;
 }
 
+constexpr uint64_t kInertKey = ~0ull; // above every 63-bit Morton code: inert triangles end up behind the sorted rest
+
 __global__ void k_morton(uint32_t n, const float4 *__restrict__ boxLo, const float4 *__restrict__ boxHi,
-                         const uint32_t *__restrict__ sceneBounds, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+                         const uint32_t *__restrict__ sceneBounds, const uint8_t *__restrict__ inert, uint64_t *__restrict__ keys,
+                         uint32_t *__restrict__ vals)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n)
         return;
+    if (inert[g])
+    {
+        keys[g] = kInertKey;
+        vals[g] = g;
+        return;
+    }
     const float4 lo = boxLo[g], hi = boxHi[g];
     const float c[3] = { 0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z) };
     uint32_t q[3];
@@ -167,6 +187,21 @@ __global__ void k_morton(uint32_t n, const float4 *__restrict__ boxLo, const flo
     }
     keys[g] = (expandBits21(q[0]) << 2) | (expandBits21(q[1]) << 1) | expandBits21(q[2]);
     vals[g] = g;
+}
+
+// number of sorted keys below the inert sentinel (one thread: ~log2 n dependent loads)
+__global__ void k_count_valid(uint32_t n, const uint64_t *__restrict__ sortedKeys, uint32_t *__restrict__ out)
+{
+    uint32_t lo = 0, hi = n; // first index whose key is the sentinel
+    while (lo < hi)
+    {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (sortedKeys[mid] == kInertKey)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    *out = lo;
 }
 
 // ---- LSD radix sort, 8-bit digits, 64-bit keys + 32-bit values --------------------
@@ -218,6 +253,56 @@ __global__ void __launch_bounds__(1024) k_scan_exclusive(uint32_t count, uint32_
         data[i] = run;
         run += v;
     }
+}
+
+// the same scan in three passes over any number of blocks (the single block above takes 0.4 ms for the 250 K counters of
+// a 2 M-key pass: eight of them were a quarter of the sort): block sums, scan of the sums, apply
+constexpr uint32_t kScan32Block = 2048;
+__global__ void __launch_bounds__(256) k_scan32_sums(uint32_t count, const uint32_t *__restrict__ data, uint32_t *__restrict__ sums)
+{
+    __shared__ uint32_t part[256];
+    const uint32_t base = blockIdx.x * kScan32Block;
+    uint32_t s = 0;
+    for (uint32_t k = threadIdx.x; k < kScan32Block; k += 256)
+        if (base + k < count)
+            s += data[base + k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t off = 128; off > 0; off >>= 1)
+    {
+        if (threadIdx.x < off)
+            part[threadIdx.x] += part[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        sums[blockIdx.x] = part[0];
+}
+__global__ void __launch_bounds__(256) k_scan32_apply(uint32_t count, uint32_t *__restrict__ data, const uint32_t *__restrict__ sums)
+{
+    __shared__ uint32_t part[256];
+    const uint32_t base = blockIdx.x * kScan32Block + threadIdx.x * 8;
+    uint32_t v[8], s = 0;
+    for (int k = 0; k < 8; k++)
+    {
+        v[k] = base + k < count ? data[base + k] : 0u;
+        s += v[k];
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1)
+    {
+        const uint32_t t = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t run = sums[blockIdx.x] + (threadIdx.x ? part[threadIdx.x - 1] : 0u);
+    for (int k = 0; k < 8; k++)
+        if (base + k < count)
+        {
+            data[base + k] = run;
+            run += v[k];
+        }
 }
 
 __global__ void __launch_bounds__(64) k_sort_scatter(uint32_t n, const uint64_t *__restrict__ keysIn,
@@ -706,14 +791,15 @@ __global__ void k_emit(int n, const uint32_t *__restrict__ vals, const float4 *_
 }
 
 // a one-triangle scene has no internal node: give it a root with one leaf child
-__global__ void k_single_leaf_root(const float4 *boxLo, const float4 *boxHi, const Tri *triTmp, BvhNode *nodes, Tri *tris, const DevPair *pairs,
-                                   const PtxVertex *vertices, const uint32_t *indices, ShadeTri *shadeTris)
+__global__ void k_single_leaf_root(const uint32_t *vals, const float4 *boxLo, const float4 *boxHi, const Tri *triTmp, BvhNode *nodes, Tri *tris,
+                                   const DevPair *pairs, const PtxVertex *vertices, const uint32_t *indices, ShadeTri *shadeTris)
 {
-    writeShadeTri(triTmp[0], pairs, vertices, indices, &shadeTris[0]);
-    tris[0] = triTmp[0];
+    const uint32_t g = vals[0]; // the one triangle of the tree (the others, if any, are inert)
+    writeShadeTri(triTmp[g], pairs, vertices, indices, &shadeTris[0]);
+    tris[0] = triTmp[g];
     BvhNode nd;
     // origin below the box, scale covering it: child 0 spans the whole quantised range
-    const float lo[3] = { boxLo[0].x, boxLo[0].y, boxLo[0].z }, hi[3] = { boxHi[0].x, boxHi[0].y, boxHi[0].z };
+    const float lo[3] = { boxLo[g].x, boxLo[g].y, boxLo[g].z }, hi[3] = { boxHi[g].x, boxHi[g].y, boxHi[g].z };
     uint32_t eb[3];
     for (int a = 0; a < 3; a++)
     {

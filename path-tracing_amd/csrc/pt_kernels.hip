@@ -1369,7 +1369,9 @@ struct PtxRenderer
     {
         DevBuf<Tri> triTmp;
         DevBuf<float4> boxLo, boxHi, nodeLo, nodeHi;
-        DevBuf<uint32_t> sceneBounds, vals0, vals1, hist, flags;
+        DevBuf<uint32_t> sceneBounds, vals0, vals1, hist, histSums, flags;
+        DevBuf<uint8_t> inert; // per flattened triangle: left out of the tree (zero area) by the last full build
+        uint32_t treeTris = 0; // triangles in the tree = the first treeTris entries of the sorted order
         DevBuf<uint64_t> keys0, keys1;
         DevBuf<int2> children;
         DevBuf<int> parentOfNode, parentOfLeaf;
@@ -1377,7 +1379,7 @@ struct PtxRenderer
         void release()
         {
             triTmp.release(); boxLo.release(); boxHi.release(); nodeLo.release(); nodeHi.release(); sceneBounds.release();
-            vals0.release(); vals1.release(); hist.release(); flags.release(); keys0.release(); keys1.release();
+            vals0.release(); vals1.release(); hist.release(); histSums.release(); flags.release(); inert.release(); keys0.release(); keys1.release();
             children.release(); parentOfNode.release(); parentOfLeaf.release();
             valid = false;
         }
@@ -1390,6 +1392,7 @@ struct PtxRenderer
     DevBuf<float> decalT;
     size_t decalCapacity = 0;
     uint32_t pairCount = 0, triCount = 0, dxNormalTextures = 0;
+    uint32_t treeTris = 0; // triCount minus the zero-area triangles, which are not in the tree
     bool sceneReady = false, accelReady = false;
 
     // accel
@@ -1920,7 +1923,6 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
 {
     HIP_TRY(r, hipSetDevice(r->device));
     const uint32_t n = r->triCount;
-    r->stats.bvhNodes = n > 1 ? n - 1 : (n ? 1 : 0);
     if (!refit)
     {
         HIP_TRY(r, r->nodes.alloc(n > 1 ? n - 1 : 1));
@@ -1930,11 +1932,14 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
     if (n == 0)
     {
         r->accelReady = true;
+        r->treeTris = 0;
+        r->stats.bvhNodes = 0;
         r->stats.lastBuildMs = 0.0;
         return PTX_OK;
     }
     PtxRenderer::BuildState &B = r->build;
     const uint32_t numTiles = (n + kSortTile - 1) / kSortTile;
+    const uint32_t histCount = 256 * numTiles, histBlocks = (histCount + kScan32Block - 1) / kScan32Block;
 #define BUILD_TRY(expr)                                                                                                    \
     do                                                                                                                     \
     {                                                                                                                      \
@@ -1950,38 +1955,55 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
     {
         B.valid = false;
         BUILD_TRY(B.triTmp.alloc(n)); BUILD_TRY(B.boxLo.alloc(n)); BUILD_TRY(B.boxHi.alloc(n)); BUILD_TRY(B.nodeLo.alloc(n));
-        BUILD_TRY(B.nodeHi.alloc(n)); BUILD_TRY(B.sceneBounds.alloc(6)); BUILD_TRY(B.vals0.alloc(n)); BUILD_TRY(B.vals1.alloc(n));
-        BUILD_TRY(B.hist.alloc((size_t)256 * numTiles)); BUILD_TRY(B.flags.alloc(n)); BUILD_TRY(B.keys0.alloc(n)); BUILD_TRY(B.keys1.alloc(n));
+        BUILD_TRY(B.nodeHi.alloc(n)); BUILD_TRY(B.sceneBounds.alloc(8)); BUILD_TRY(B.vals0.alloc(n)); BUILD_TRY(B.vals1.alloc(n));
+        BUILD_TRY(B.hist.alloc(histCount)); BUILD_TRY(B.histSums.alloc(histBlocks)); BUILD_TRY(B.flags.alloc(n)); BUILD_TRY(B.inert.alloc(n));
+        BUILD_TRY(B.keys0.alloc(n)); BUILD_TRY(B.keys1.alloc(n));
         BUILD_TRY(B.children.alloc(n)); BUILD_TRY(B.parentOfNode.alloc(n)); BUILD_TRY(B.parentOfLeaf.alloc(n));
     }
 
-    const uint32_t initBounds[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
+    // [0..5] centroid bounds (ordered floats), [6] triangles in the tree (k_count_valid), [7] a refit found a revived triangle
+    const uint32_t initBounds[8] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u };
     BUILD_TRY(hipMemcpyAsync(B.sceneBounds.p, initBounds, sizeof(initBounds), hipMemcpyHostToDevice, r->stream));
     BUILD_TRY(hipMemsetAsync(B.flags.p, 0, (size_t)n * 4, r->stream));
     BUILD_TRY(hipEventRecord(r->evA, r->stream));
 
     const uint32_t blocks = (n + 255) / 256;
     k_tri_setup<<<blocks, 256, 0, r->stream>>>(n, r->pairCount, r->pairFirst.p, r->pairs.p, r->vertices.p, r->indices.p, B.triTmp.p,
-                                               B.boxLo.p, B.boxHi.p, B.sceneBounds.p);
+                                               B.boxLo.p, B.boxHi.p, B.sceneBounds.p, B.inert.p, refit ? 1 : 0);
     // 8 radix passes ping-pong the buffers an even number of times: the sorted order ends in keys0 / vals0
     uint64_t *kin = B.keys0.p, *kout = B.keys1.p;
     uint32_t *vin = B.vals0.p, *vout = B.vals1.p;
+    uint32_t nv = B.treeTris; // triangles in the tree: all but the zero-area ones, which sort to the end
     if (!refit)
     {
-        k_morton<<<blocks, 256, 0, r->stream>>>(n, B.boxLo.p, B.boxHi.p, B.sceneBounds.p, B.keys0.p, B.vals0.p);
-        for (uint32_t shift = 0; shift < 64; shift += 8) // 63-bit keys: 8 passes
+        k_morton<<<blocks, 256, 0, r->stream>>>(n, B.boxLo.p, B.boxHi.p, B.sceneBounds.p, B.inert.p, B.keys0.p, B.vals0.p);
+        for (uint32_t shift = 0; shift < 64; shift += 8) // 63-bit keys + the all-ones sentinel of inert triangles: 8 passes
         {
             k_sort_hist<<<numTiles, 64, 0, r->stream>>>(n, kin, shift, numTiles, B.hist.p);
-            k_scan_exclusive<<<1, 1024, 0, r->stream>>>(256 * numTiles, B.hist.p);
+            if (histBlocks > 1)
+            {
+                k_scan32_sums<<<histBlocks, 256, 0, r->stream>>>(histCount, B.hist.p, B.histSums.p);
+                k_scan_exclusive<<<1, 1024, 0, r->stream>>>(histBlocks, B.histSums.p);
+                k_scan32_apply<<<histBlocks, 256, 0, r->stream>>>(histCount, B.hist.p, B.histSums.p);
+            }
+            else
+                k_scan_exclusive<<<1, 1024, 0, r->stream>>>(histCount, B.hist.p);
             k_sort_scatter<<<numTiles, 64, 0, r->stream>>>(n, kin, vin, kout, vout, shift, numTiles, B.hist.p);
             std::swap(kin, kout);
             std::swap(vin, vout);
         }
+        k_count_valid<<<1, 1, 0, r->stream>>>(n, kin, &B.sceneBounds.p[6]);
+        BUILD_TRY(hipMemcpyAsync(&nv, &B.sceneBounds.p[6], sizeof(nv), hipMemcpyDeviceToHost, r->stream));
+        BUILD_TRY(hipStreamSynchronize(r->stream));
+        B.treeTris = nv;
     }
-    if (n == 1)
-        k_single_leaf_root<<<1, 1, 0, r->stream>>>(B.boxLo.p, B.boxHi.p, B.triTmp.p, r->nodes.p, r->tris.p, r->pairs.p, r->vertices.p, r->indices.p,
-                                                   r->shadeTris.p);
-    else
+    r->treeTris = nv;
+    r->stats.bvhNodes = nv > 1 ? nv - 1 : (nv ? 1 : 0);
+    const uint32_t vblocks = (nv + 255) / 256;
+    if (nv == 1)
+        k_single_leaf_root<<<1, 1, 0, r->stream>>>(vin, B.boxLo.p, B.boxHi.p, B.triTmp.p, r->nodes.p, r->tris.p, r->pairs.p, r->vertices.p,
+                                                   r->indices.p, r->shadeTris.p);
+    else if (nv > 1)
     {
         bool boxesDone = false;
         if (!refit && r->usePloc)
@@ -1991,14 +2013,14 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
             DevBuf<float4> lo0, hi0, lo1, hi1;
             DevBuf<uint32_t> nn;
             DevBuf<unsigned long long> flags, sums, total;
-            const uint32_t scanBlocks = (n + kScanBlock - 1) / kScanBlock;
-            BUILD_TRY(cl0.alloc(n)); BUILD_TRY(cl1.alloc(n)); BUILD_TRY(lo0.alloc(n)); BUILD_TRY(hi0.alloc(n)); BUILD_TRY(lo1.alloc(n));
-            BUILD_TRY(hi1.alloc(n)); BUILD_TRY(nn.alloc(n)); BUILD_TRY(flags.alloc(n)); BUILD_TRY(sums.alloc(scanBlocks)); BUILD_TRY(total.alloc(1));
-            k_ploc_init<<<blocks, 256, 0, r->stream>>>(n, vin, B.boxLo.p, B.boxHi.p, cl0.p, lo0.p, hi0.p);
+            const uint32_t scanBlocks = (nv + kScanBlock - 1) / kScanBlock;
+            BUILD_TRY(cl0.alloc(nv)); BUILD_TRY(cl1.alloc(nv)); BUILD_TRY(lo0.alloc(nv)); BUILD_TRY(hi0.alloc(nv)); BUILD_TRY(lo1.alloc(nv));
+            BUILD_TRY(hi1.alloc(nv)); BUILD_TRY(nn.alloc(nv)); BUILD_TRY(flags.alloc(nv)); BUILD_TRY(sums.alloc(scanBlocks)); BUILD_TRY(total.alloc(1));
+            k_ploc_init<<<vblocks, 256, 0, r->stream>>>(nv, vin, B.boxLo.p, B.boxHi.p, cl0.p, lo0.p, hi0.p);
             int *cIn = cl0.p, *cOut = cl1.p;
             float4 *lIn = lo0.p, *hIn = hi0.p, *lOut = lo1.p, *hOut = hi1.p;
-            uint32_t count = n;
-            int nextId = (int)n - 2;
+            uint32_t count = nv;
+            int nextId = (int)nv - 2;
             uint32_t iterations = 0;
             while (count > 1)
             {
@@ -2027,22 +2049,25 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
                 iterations++;
             }
             if (getenv("PTX_VERBOSE"))
-                std::fprintf(stderr, "[ptx] PLOC: %u triangles, %u iterations\n", n, iterations);
+                std::fprintf(stderr, "[ptx] PLOC: %u triangles (%u inert left out), %u iterations\n", nv, n - nv, iterations);
             boxesDone = true;
-            cl0.release(); cl1.release(); lo0.release(); hi0.release(); lo1.release(); hi1.release(); nn.release(); flags.release(); sums.release();
-            total.release();
         }
         else if (!refit)
-            k_karras<<<blocks, 256, 0, r->stream>>>((int)n, kin, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p);
+            k_karras<<<vblocks, 256, 0, r->stream>>>((int)nv, kin, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p);
         if (!boxesDone)
-            k_refit<<<blocks, 256, 0, r->stream>>>((int)n, vin, B.boxLo.p, B.boxHi.p, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p,
+            k_refit<<<vblocks, 256, 0, r->stream>>>((int)nv, vin, B.boxLo.p, B.boxHi.p, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p,
                                                B.nodeLo.p, B.nodeHi.p, B.flags.p);
-        k_emit<<<blocks, 256, 0, r->stream>>>((int)n, vin, B.boxLo.p, B.boxHi.p, B.children.p, B.nodeLo.p, B.nodeHi.p, B.triTmp.p,
+        k_emit<<<vblocks, 256, 0, r->stream>>>((int)nv, vin, B.boxLo.p, B.boxHi.p, B.children.p, B.nodeLo.p, B.nodeHi.p, B.triTmp.p,
                                               r->nodes.p, r->tris.p, r->pairs.p, r->vertices.p, r->indices.p, r->shadeTris.p);
     }
+    uint32_t revived = 0;
+    if (refit)
+        BUILD_TRY(hipMemcpyAsync(&revived, &B.sceneBounds.p[7], sizeof(revived), hipMemcpyDeviceToHost, r->stream));
     BUILD_TRY(hipEventRecord(r->evB, r->stream));
     BUILD_TRY(hipStreamSynchronize(r->stream));
     BUILD_TRY(hipGetLastError());
+    if (revived) // a triangle the last full build left out has an area now: it is not in the kept topology
+        return buildAccel(r, false, keepState);
     float ms = 0.0f;
     (void)hipEventElapsedTime(&ms, r->evA, r->evB);
     r->stats.lastBuildMs = ms;
@@ -2230,7 +2255,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
     const int mode = kernelMode(r);
     const bool textured = mode >= 1, alpha = mode == 2;
     TraceScene sc;
-    sc.nodes = r->nodes.p; sc.tris = r->tris.p; sc.triCount = r->triCount; sc.sv = sv;
+    sc.nodes = r->nodes.p; sc.tris = r->tris.p; sc.triCount = r->treeTris; sc.sv = sv;
 
     r->stats.pathSamples = r->stats.segments = r->stats.shadowRays = r->stats.retries = 0;
     r->stats.traceLaunches = 0;
@@ -2877,7 +2902,7 @@ int ptx_trace_rays(PtxRenderer *r, const float *rays, uint32_t n, int anyHit, fl
     HIP_TRY(r, dHits.alloc(n));
     HIP_TRY(r, dIds.alloc(n));
     TraceScene sc;
-    sc.nodes = r->nodes.p; sc.tris = r->tris.p; sc.triCount = r->triCount; sc.sv = makeSceneView(r);
+    sc.nodes = r->nodes.p; sc.tris = r->tris.p; sc.triCount = r->treeTris; sc.sv = makeSceneView(r);
     hipError_t e = hipMemcpyAsync(dRays.p, rays, (size_t)n * 32, hipMemcpyHostToDevice, r->stream);
     if (e == hipSuccess)
     {

@@ -157,3 +157,39 @@ def test_refit_of_a_large_static_scene_is_cheaper_than_a_rebuild(pkg):
     print(f"chess_like x0.5: rebuild {rebuild:.2f} ms, refit {refit:.2f} ms")
     assert refit < rebuild
     r.close()
+
+
+@pytest.mark.gpu
+def test_triangles_left_out_of_the_tree_come_back(pkg, orc):
+    """Zero-area triangles take no part in the tree (the full build sorts them behind the rest).  An instance collapsed
+    to a point by its transform is all such triangles; when a later frame gives it a size again a REFIT cannot use the
+    kept topology (they are not in it) and falls back to a full build -- results equal a fresh renderer's and the oracle's."""
+    scene = pkg.Scene("animated_test", 0.4)
+    scene.update(0.3)
+    it, bn = scene.animation_state()
+    flat = it.copy()
+    flat[1] = 0.0  # the spinning platform: linear part and translation zero -> every triangle of it degenerates to a point
+    r = pkg.Renderer()
+    r.upload(scene)
+    n_all = r.stats().bvhNodes
+    r.update_animation(flat, bn, rebuild=True)
+    n_flat = r.stats().bvhNodes
+    assert n_flat < n_all, "collapsed triangles must leave the tree"
+    rays = util.random_rays(np.random.default_rng(9), 8000, -3.0, 3.0)
+    rays[:, 1] = np.abs(rays[:, 1]) + 0.05
+    want_flat = orc.OracleScene(scene.desc, build_bvh=False, instance_transforms=flat, bones=bn).trace_closest(rays, brute_force=True)
+    hits, ids = r.trace_rays(rays)
+    assert (hits[:, 0].view(np.uint32) == want_flat["t"].view(np.uint32)).all()
+    r.update_animation(it, bn, rebuild=False)  # refit requested; the revived platform forces the rebuild
+    assert r.stats().bvhNodes == n_all
+    hits, ids = r.trace_rays(rays)
+    want = orc.OracleScene(scene.desc, build_bvh=False, instance_transforms=it, bones=bn).trace_closest(rays, brute_force=True)
+    first = util.pair_first(scene.desc)
+    miss = ids[:, 0] == 0xFFFFFFFF
+    gid = np.where(miss, 0xFFFFFFFF, first[np.minimum(ids[:, 0], len(first) - 2)] + ids[:, 1]).astype(np.uint32)
+    assert (gid == want["tri"]).all() and (hits[:, 0].view(np.uint32) == want["t"].view(np.uint32)).all()
+    # and the other way round: valid -> collapsed under a refit stays in the tree, unhittable
+    r.update_animation(flat, bn, rebuild=False)
+    hits, _ = r.trace_rays(rays)
+    assert (hits[:, 0].view(np.uint32) == want_flat["t"].view(np.uint32)).all()
+    r.close()
