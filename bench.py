@@ -23,6 +23,11 @@ all_gather of the tile shards per step.  The reported metric is the NAMED frame 
 is the same frame at 8 N spp, which is how BASELINE configs[3] and [4] are posed) is measured in the same run and
 printed in `weak`.
 
+Frames in flight (`--in-flight`, default 3): consecutive steps run on renderers that take turns, each on its own stream
+with its own path state, as the reference keeps frames in flight (Renderer.cpp:1454-1460): ptx_render only enqueues a
+frame -- the bounce loop is driven from the device -- so the latency-bound end of one frame overlaps the head of the
+next.  Every step is still one complete frame: reset, 8 spp, gather, read-back.
+
 The timed region of K steps is repeated (`--repeats`, default: until >= 2 s have been timed) and the line reports the
 MEDIAN region; min / max ride in `spread`.
 
@@ -111,7 +116,13 @@ def cpu_baseline(orc, scene, width, height, depth, seconds):
 
 
 class Job:
-    """One renderer + scene + the step() of the metric, for any (rank, world)."""
+    """The scene, `in_flight` renderers on one GPU and the step() of the metric, for any (rank, world).
+
+    Frames in flight: step k runs on renderer k % F, each renderer on its own stream with its own path state, so the
+    latency-bound end of one frame (few live paths, every kernel waiting on its longest ray) overlaps the head of the
+    next -- the reference keeps frames in flight for the same reason (Swapchain in-flight count, one set of rendering
+    resources per frame: Renderer.cpp:1454-1460,1617-1618).  ptx_render only ENQUEUES a frame (the bounce loop is driven
+    from the device), so nothing in a step waits for the GPU; a renderer's statistics are read when its turn comes again."""
 
     def __init__(self, args, pkg, torch, dist, scene_name, rank, world, local_rank, shard=None):
         self.args, self.pkg, self.torch, self.dist = args, pkg, torch, dist
@@ -120,80 +131,97 @@ class Job:
         self.scene = pkg.Scene(scene_name, args.detail)
         self.lights = self.scene.lights
         backend = pkg.BACKEND_WAVEFRONT if args.backend == "wavefront" else pkg.BACKEND_MEGAKERNEL
-        self.r = pkg.Renderer(device=local_rank, backend=backend)
-        t0 = time.time()
-        self.r.upload(self.scene)
-        self.r.synchronize()
-        self.upload_build_s = time.time() - t0
-        self.r.resize(self.W, self.H)
+        self.F = max(1, args.in_flight)
+        self.streams = [torch.cuda.Stream() for _ in range(self.F)]
+        self.rs = [pkg.Renderer(device=local_rank, backend=backend, stream=s.cuda_stream) for s in self.streams]
         self.shard_rank, self.shard_world = shard if shard else (rank, world)
-        self.r.set_tile_shard(self.shard_rank, self.shard_world, args.tile)
+        t0 = time.time()
+        for r in self.rs:
+            r.upload(self.scene)
+            r.synchronize()
+        self.upload_build_s = (time.time() - t0) / self.F
+        for r in self.rs:
+            r.resize(self.W, self.H)
+            r.set_tile_shard(self.shard_rank, self.shard_world, args.tile)
         self.u = self.scene.uniform(self.W, self.H, bounces=args.depth)
-        self.build_ms = self.r.stats().lastBuildMs
+        self.build_ms = self.rs[0].stats().lastBuildMs
         self.n_tris = self.scene.triangle_count
         self.nbytes = self.W * self.H * 16
-        # page-locked host images for the pipelined read-back (two: step k + 1 must not overwrite what the caller of
-        # step k is still looking at)
-        self.host = [torch.empty(self.W * self.H * 4, dtype=torch.float32, pin_memory=True) for _ in range(2)] if rank == 0 else []
-        self.flip = 0
-        if world > 1:  # gather plumbing: equal-size padded shard buffers, one all_gather
-            self.shard_floats = max(self.r.shard_bytes(k) for k in range(world)) // 4
-            self.send = torch.zeros(self.shard_floats, dtype=torch.float32, device="cuda")
-            self.recv = torch.zeros(world * self.shard_floats, dtype=torch.float32, device="cuda")
+        # page-locked host images for the pipelined read-back, one per renderer
+        self.host = [torch.empty(self.W * self.H * 4, dtype=torch.float32, pin_memory=True) for _ in range(self.F)] if rank == 0 else []
+        self.k = 0
+        self.issued = [False] * self.F
+        self.collect = None
+        if world > 1:  # gather plumbing: equal-size padded shard buffers per frame in flight, one all_gather per step
+            self.shard_floats = max(self.rs[0].shard_bytes(k) for k in range(world)) // 4
+            self.send = [torch.zeros(self.shard_floats, dtype=torch.float32, device="cuda") for _ in range(self.F)]
+            self.recv = [torch.zeros(world * self.shard_floats, dtype=torch.float32, device="cuda") for _ in range(self.F)]
+
+    def _take_stats(self, i):
+        if self.issued[i] and self.collect is not None:
+            st = self.rs[i].stats()  # waits for that renderer's frame: F steps old by now
+            c = self.collect
+            c["trace_ms"] += st.lastTraceMs
+            c["shade_ms"] += st.lastShadeMs
+            c["shadow_ms"] += st.lastShadowMs
+            c["tail_ms"] += st.lastTailMs
+            c["launches"] += st.traceLaunches // 2
+            c["rays"] += st.tracedRays
+            c["segments"], c["shadow"] = st.segments, st.shadowRays
+        self.issued[i] = False
 
     def step(self, job_spp, readback=True):
-        r, torch, dist = self.r, self.torch, self.dist
+        torch, dist = self.torch, self.dist
+        i = self.k % self.F
+        self.k += 1
+        r = self.rs[i]
+        self._take_stats(i)
         r.reset()
         r.render_frames(self.u, self.lights, 0, job_spp)
+        self.issued[i] = True
         if self.world > 1:
-            r.pack_shard(self.send.data_ptr())
-            r.synchronize()  # the pack ran on the renderer's stream; the collective runs on torch's
-            if self.args.dist_backend == "nccl":
-                dist.all_gather_into_tensor(self.recv, self.send)  # RCCL: every shard straight over its own xGMI link
-            else:  # gloo (testing): staged through the host
-                parts = [torch.empty(self.shard_floats) for _ in range(self.world)]
-                dist.all_gather(parts, self.send.cpu())
-                self.recv.copy_(torch.cat(parts))
-            # every rank: the next step's pack_shard (renderer stream) must not overwrite `send` under the collective
-            torch.cuda.current_stream().synchronize()
+            send, recv = self.send[i], self.recv[i]
+            r.pack_shard(send.data_ptr())
+            with torch.cuda.stream(self.streams[i]):  # the renderer runs on this torch stream: the collective is ordered behind the pack
+                if self.args.dist_backend == "nccl":
+                    dist.all_gather_into_tensor(recv, send)  # RCCL: every shard straight over its own xGMI link
+                else:  # gloo (testing): staged through the host
+                    parts = [torch.empty(self.shard_floats) for _ in range(self.world)]
+                    dist.all_gather(parts, send.cpu())
+                    recv.copy_(torch.cat(parts))
             if self.rank == 0:
                 for k in range(self.world):
-                    r.unpack_shard(k, self.recv.data_ptr() + k * self.shard_floats * 4)
+                    r.unpack_shard(k, recv.data_ptr() + k * self.shard_floats * 4)
         if readback and self.rank == 0:
-            r.readback_begin(self.host[self.flip].data_ptr(), self.nbytes)
-            self.flip ^= 1
+            r.readback_begin(self.host[i].data_ptr(), self.nbytes)
 
     def finish(self):
-        self.r.readback_end()
-        self.r.synchronize()
+        for i, r in enumerate(self.rs):
+            r.readback_end()
+            r.synchronize()
+            self._take_stats(i)
 
     def last_image(self):
-        return self.host[self.flip ^ 1].numpy().reshape(self.H, self.W, 4)
+        return self.host[(self.k - 1) % self.F].numpy().reshape(self.H, self.W, 4)
 
     def barrier(self):
         if self.world > 1:
             self.dist.barrier()
         self.torch.cuda.synchronize()
-        self.r.synchronize()
+        for r in self.rs:
+            r.synchronize()
 
     def timed(self, job_spp, steps, readback=True, collect=None):
         """EXACTLY `steps` steps between two barriers; max over ranks.  collect: dict of per-kernel accumulators."""
         self.barrier()
+        self.collect = collect
         t0 = time.perf_counter()
         for _ in range(steps):
             self.step(job_spp, readback)
-            if collect is not None:
-                st = self.r.stats()
-                collect["trace_ms"] += st.lastTraceMs
-                collect["shade_ms"] += st.lastShadeMs
-                collect["shadow_ms"] += st.lastShadowMs
-                collect["tail_ms"] += st.lastTailMs
-                collect["launches"] += st.traceLaunches // 2
-                collect["rays"] += st.tracedRays
-                collect["segments"], collect["shadow"] = st.segments, st.shadowRays
         self.finish()
         self.barrier()
         elapsed = time.perf_counter() - t0
+        self.collect = None
         if self.world > 1:
             t = self.torch.tensor([elapsed], dtype=self.torch.float64, device="cuda" if self.args.dist_backend == "nccl" else "cpu")
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
@@ -201,7 +229,7 @@ class Job:
         return elapsed
 
     def measure(self, job_spp, steps, warmup, repeats, min_seconds, readback=True):
-        """Warm up, then repeat the K-step timed region; returns (median, all regions, kernel stats of the median-like last)."""
+        """Warm up, then repeat the K-step timed region; returns (median, all regions, kernel stats of the last region)."""
         for _ in range(warmup):
             self.step(job_spp, readback)
         self.finish()
@@ -223,7 +251,8 @@ class Job:
         return float(np.median(regions)), regions, stats
 
     def close(self):
-        self.r.close()
+        for r in self.rs:
+            r.close()
         self.scene.close()
 
 
@@ -280,7 +309,7 @@ def scene_line(args, pkg, torch, dist, orc, name, rank, world, local_rank, steps
                        "max_ms_per_step": max(regions) / steps * 1e3},
             "config": {
                 "workload": f"{name} (procedural stand-in for BASELINE {STAND_IN.get(name, 'scenes')}), {W}x{H}, {spp} spp, depth {args.depth}",
-                "triangles": job.n_tris, "backend": args.backend, "tile": args.tile,
+                "triangles": job.n_tris, "backend": args.backend, "tile": args.tile, "frames_in_flight": job.F,
                 "segments_per_sample": stats["segments"] / (W * H * spp / world),
                 "tree_build_ms": job.build_ms, "upload_plus_build_s": job.upload_build_s,
                 "kernel_ms_per_step": {"k_trace_closest": stats["trace_ms"] / steps, "k_shade": stats["shade_ms"] / steps,
@@ -311,6 +340,7 @@ def main():
     ap.add_argument("--spp", type=int, default=8)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--tile", type=int, default=32)
+    ap.add_argument("--in-flight", type=int, default=3, help="frames in flight: renderers (own stream, own path state) taking the steps in turn")
     ap.add_argument("--backend", default="wavefront", choices=["wavefront", "megakernel"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -402,7 +432,7 @@ def main():
                          "workload": f"{weak_spp} spp in total = {args.spp} spp per GPU"},
                    config={"workload": f"{args.scene} (procedural stand-in for BASELINE {STAND_IN.get(args.scene, 'scenes')}), {W}x{H}, "
                                        f"{args.spp} spp, depth {args.depth}",
-                           "triangles": job.n_tris, "backend": args.backend, "tile": args.tile,
+                           "triangles": job.n_tris, "backend": args.backend, "tile": args.tile, "frames_in_flight": job.F,
                            "parallelism": f"pixel-tile shard x{world}, 1 RCCL all_gather + read-back on rank 0 per step",
                            "rank0_kernel_ms_per_step": {"k_trace_closest": stats_s["trace_ms"] / args.steps, "k_shade": stats_s["shade_ms"] / args.steps,
                                                         "k_trace_shadow": stats_s["shadow_ms"] / args.steps, "k_tail": stats_s["tail_ms"] / args.steps},

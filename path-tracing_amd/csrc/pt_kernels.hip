@@ -64,22 +64,61 @@ struct Wavefront // device pointers of the per-slot state (SoA)
 // Every counter sits on its own 128-byte line: atomics to one L2 line serialise (~11 ns each on MI355X) whatever
 // word they touch, and the queue, chunk and statistics counters are all hot in the same kernels.
 constexpr int kCounterStride = 32; // uint32 words
+constexpr int kMaxTimedBounces = 64; // per-bounce bookkeeping (live counts for the statistics, kernel timing events) up to this depth
 enum Counter
 {
     C_ACTIVE0 = 0 * kCounterStride,
     C_ACTIVE1 = 1 * kCounterStride,
-    C_SHADOW = 2 * kCounterStride,
+    C_SHADOW = 2 * kCounterStride,    // shadow queue of even bounces (the shadow kernel of bounce b runs beside bounce b + 1: two sets)
     C_HITS = 3 * kCounterStride,      // closest-hit shader invocations (= occlusion queries of the reference)
     C_SAMPLES = 4 * kCounterStride,   // completed pixel-samples incl. retries
     C_RETRIES = 5 * kCounterStride,
-    C_SEGMENTS = 6 * kCounterStride,  // megakernel only
+    C_SEGMENTS = 6 * kCounterStride,  // closest-hit queries traced inside k_tail / the megakernel
     C_OVERFLOW = 7 * kCounterStride,
     C_CHUNK = 8 * kCounterStride,        // next unclaimed queue entry of k_trace_closest
-    C_CHUNK_SHADOW = 9 * kCounterStride, // ... of k_trace_shadow
-    C_RESTART = 10 * kCounterStride, // slots re-queued by k_trace_shadow (new sample / NaN restart), drained after the bounce loop
-    C_COUNT = 12 * kCounterStride
+    C_CHUNK_SHADOW = 9 * kCounterStride, // ... of k_trace_shadow, even bounces
+    C_RESTART = 10 * kCounterStride, // slots re-queued for their next sample (multi-sample launch, NaN restart), drained after the bounce loop
+    C_SHADOW1 = 11 * kCounterStride,       // odd bounces
+    C_CHUNK_SHADOW1 = 12 * kCounterStride,
+    C_WAVE_SEGMENTS = 13 * kCounterStride, // 64-bit: closest-hit queries traced by k_trace_closest (k_prologue adds each bounce's queue length)
+    C_TAIL_PATHS = 14 * kCounterStride,    // paths k_tail took over
+    C_BOUNCE_ACTIVE = 15 * kCounterStride, // [kMaxTimedBounces + 1]: queue length at the start of each bounce of the last round
+    C_COUNT = C_BOUNCE_ACTIVE + ((kMaxTimedBounces + 1 + kCounterStride - 1) / kCounterStride) * kCounterStride
 };
 PT_DEV int queueCounter(int q) { return q ? (int)C_ACTIVE1 : (int)C_ACTIVE0; }
+PT_DEV int shadowCounter(int parity) { return parity ? (int)C_SHADOW1 : (int)C_SHADOW; }
+PT_DEV int shadowChunkCounter(int parity) { return parity ? (int)C_CHUNK_SHADOW1 : (int)C_CHUNK_SHADOW; }
+
+// The bounce loop is driven from the device: every kernel of a bounce takes its queue length from the counter block, so
+// the host enqueues the whole schedule (BounceCount bounces) without a single read-back in between.
+//   * A queue at or below `tailBelow` paths (after the first bounce) belongs to k_tail, which runs them to the end of
+//     their sample in one launch: the wavefront kernels of the following bounces see that and return at once.
+//   * k_prologue, one thread ahead of each bounce, clears the counters that bounce appends to (the shadow queue has two
+//     sets: the shadow kernel of bounce b runs beside bounce b + 1) and keeps the statistics.
+struct BounceCtl
+{
+    uint32_t bounce;    // 1-based index inside the round
+    uint32_t tailBelow; // queues of at most this many paths go to k_tail (never the first bounce of a round)
+};
+PT_DEV bool bounceRuns(const BounceCtl &c, uint32_t count) { return count != 0u && (c.bounce <= 1u || count > c.tailBelow); }
+
+__global__ void k_prologue(Wavefront wf, int qin, BounceCtl ctl)
+{
+    const uint32_t count = wf.counters[queueCounter(qin)];
+    const int parity = (int)(ctl.bounce & 1u);
+    wf.counters[queueCounter(qin ^ 1)] = 0u;
+    wf.counters[shadowCounter(parity)] = 0u;
+    wf.counters[shadowChunkCounter(parity)] = 0u;
+    wf.counters[C_CHUNK] = 0u;
+    if (ctl.bounce <= (uint32_t)kMaxTimedBounces)
+        wf.counters[C_BOUNCE_ACTIVE + ctl.bounce] = count;
+    if (bounceRuns(ctl, count))
+    {
+        unsigned long long *seg = reinterpret_cast<unsigned long long *>(&wf.counters[C_WAVE_SEGMENTS]);
+        *seg += count;
+    }
+}
+
 
 struct LaunchParams
 {
@@ -303,8 +342,11 @@ struct ClosestIO
 #define PT_ALPHA_CLOSEST_ATTR __attribute__((amdgpu_waves_per_eu(6, 6))) // 83 -> 80 registers, 5 -> 6 waves; 7 would spill
 #define PT_ALPHA_SHADOW_ATTR __attribute__((amdgpu_waves_per_eu(7, 7)))  // 8 waves would spill 11 registers with the two-pass triangle test
 template <bool ALPHA>
-PT_DEV void traceClosestBody(const TraceScene &sc, const Wavefront &wf, int qin, uint32_t count)
+PT_DEV void traceClosestBody(const TraceScene &sc, const Wavefront &wf, int qin, const BounceCtl &ctl)
 {
+    const uint32_t count = wf.counters[queueCounter(qin)];
+    if (!bounceRuns(ctl, count))
+        return;
     PT_DECLARE_STACK(st, kLdsStack, wf.spill)
     ClosestIO io = { wf, wf.queue[qin], 0u };
     persistentTrace<false, ALPHA>(sc, io, count, &wf.counters[C_CHUNK], st);
@@ -312,16 +354,16 @@ PT_DEV void traceClosestBody(const TraceScene &sc, const Wavefront &wf, int qin,
         atomicAdd(&wf.counters[C_OVERFLOW], 1u);
 }
 template <bool ALPHA>
-__global__ void __launch_bounds__(kBlock) k_trace_closest(TraceScene sc, Wavefront wf, int qin, uint32_t count);
+__global__ void __launch_bounds__(kBlock) k_trace_closest(TraceScene sc, Wavefront wf, int qin, BounceCtl ctl);
 template <>
-__global__ void __launch_bounds__(kBlock) PT_FULL_OCCUPANCY k_trace_closest<false>(TraceScene sc, Wavefront wf, int qin, uint32_t count)
+__global__ void __launch_bounds__(kBlock) PT_FULL_OCCUPANCY k_trace_closest<false>(TraceScene sc, Wavefront wf, int qin, BounceCtl ctl)
 {
-    traceClosestBody<false>(sc, wf, qin, count);
+    traceClosestBody<false>(sc, wf, qin, ctl);
 }
 template <>
-__global__ void __launch_bounds__(kBlock) PT_ALPHA_CLOSEST_ATTR k_trace_closest<true>(TraceScene sc, Wavefront wf, int qin, uint32_t count)
+__global__ void __launch_bounds__(kBlock) PT_ALPHA_CLOSEST_ATTR k_trace_closest<true>(TraceScene sc, Wavefront wf, int qin, BounceCtl ctl)
 {
-    traceClosestBody<true>(sc, wf, qin, count);
+    traceClosestBody<true>(sc, wf, qin, ctl);
 }
 
 // raygen.rgen:99-112 + sample loop control for a slot whose path has ended.
@@ -371,32 +413,35 @@ PT_DEV void pushRestarts(const Wavefront &wf, bool restart, uint32_t slot)
 }
 
 template <bool TEX>
-PT_DEV void shadeBody(const LaunchParams &p, const SceneView &sv, const Wavefront &wf, int qin);
+PT_DEV void shadeBody(const LaunchParams &p, const SceneView &sv, const Wavefront &wf, int qin, const BounceCtl &ctl);
 template <bool TEX>
-__global__ void __launch_bounds__(kBlock) k_shade(LaunchParams p, SceneView sv, Wavefront wf, int qin);
+__global__ void __launch_bounds__(kBlock) k_shade(LaunchParams p, SceneView sv, Wavefront wf, int qin, BounceCtl ctl);
 // 190 VGPRs once the new-sample code is out of the kernel; held at 168 = three waves per SIMD for 15 spilled dwords
 // (k_shade 3.42 -> 3.18 ms per chess_like step; four waves would spill 90 and lose)
 #ifndef PT_SHADE_ATTR
 #define PT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
 #endif
 template <>
-__global__ void __launch_bounds__(kBlock) PT_SHADE_ATTR k_shade<false>(LaunchParams p, SceneView sv, Wavefront wf, int qin)
+__global__ void __launch_bounds__(kBlock) PT_SHADE_ATTR k_shade<false>(LaunchParams p, SceneView sv, Wavefront wf, int qin, BounceCtl ctl)
 {
-    shadeBody<false>(p, sv, wf, qin);
+    shadeBody<false>(p, sv, wf, qin, ctl);
 }
 // the sampler pushes the TEX variant a few registers past 256, i.e. to ONE wave per SIMD: hold it at two (4 registers
 // spill; texture_test k_shade 8.3 -> 5.5 ms per step, atrium_like 17.1 -> 11.6 ms)
 template <>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) k_shade<true>(LaunchParams p, SceneView sv, Wavefront wf, int qin)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) k_shade<true>(LaunchParams p, SceneView sv, Wavefront wf, int qin, BounceCtl ctl)
 {
-    shadeBody<true>(p, sv, wf, qin);
+    shadeBody<true>(p, sv, wf, qin, ctl);
 }
 template <bool TEX>
-PT_DEV void shadeBody(const LaunchParams &p, const SceneView &sv, const Wavefront &wf, int qin)
+PT_DEV void shadeBody(const LaunchParams &p, const SceneView &sv, const Wavefront &wf, int qin, const BounceCtl &ctl)
 {
     __shared__ uint32_t s_cnt[2], s_base[2];
     const int qout = qin ^ 1;
     const uint32_t count = wf.counters[queueCounter(qin)];
+    if (!bounceRuns(ctl, count)) // empty, or k_tail's
+        return;
+    const int shadowSet = shadowCounter((int)(ctl.bounce & 1u));
     uint32_t nHits = 0, nSamples = 0, nRetries = 0;
     // kShadeItems queue entries per thread between two block-wide appends: the appends cost one global atomic per
     // block and queue, and same-address atomics serialise at ~11 ns -- at one entry per thread the 65 K blocks x 2
@@ -539,7 +584,7 @@ PT_DEV void shadeBody(const LaunchParams &p, const SceneView &sv, const Wavefron
         }
         __syncthreads();
         if (threadIdx.x < 2 && s_cnt[threadIdx.x])
-            s_base[threadIdx.x] = atomicAdd(&wf.counters[threadIdx.x == 0 ? (int)C_SHADOW : queueCounter(qout)], s_cnt[threadIdx.x]);
+            s_base[threadIdx.x] = atomicAdd(&wf.counters[threadIdx.x == 0 ? shadowSet : queueCounter(qout)], s_cnt[threadIdx.x]);
         __syncthreads();
         const uint64_t below = (1ull << lane) - 1ull;
         for (uint32_t k = 0; k < kShadeItems; k++)
@@ -604,27 +649,30 @@ struct ShadowIO
 };
 
 template <bool ALPHA>
-PT_DEV void traceShadowBody(const LaunchParams &p, const TraceScene &sc, const Wavefront &wf, int qout, uint32_t count)
+PT_DEV void traceShadowBody(const LaunchParams &p, const TraceScene &sc, const Wavefront &wf, int qout, int parity)
 {
+    const uint32_t count = wf.counters[shadowCounter(parity)];
+    if (count == 0u)
+        return;
     PT_DECLARE_STACK(st, kLdsStack, wf.spill)
     ShadowIO io = { p, wf, qout, 0u, 0.0f, 0u, 0u };
-    persistentTrace<true, ALPHA>(sc, io, count, &wf.counters[C_CHUNK_SHADOW], st);
+    persistentTrace<true, ALPHA>(sc, io, count, &wf.counters[shadowChunkCounter(parity)], st);
     if (st.overflow)
         atomicAdd(&wf.counters[C_OVERFLOW], 1u);
     waveAddCounter(&wf.counters[C_SAMPLES], io.nSamples);
     waveAddCounter(&wf.counters[C_RETRIES], io.nRetries);
 }
 template <bool ALPHA>
-__global__ void __launch_bounds__(kBlock) k_trace_shadow(LaunchParams p, TraceScene sc, Wavefront wf, int qout, uint32_t count);
+__global__ void __launch_bounds__(kBlock) k_trace_shadow(LaunchParams p, TraceScene sc, Wavefront wf, int qout, int parity);
 template <>
-__global__ void __launch_bounds__(kBlock) PT_FULL_OCCUPANCY k_trace_shadow<false>(LaunchParams p, TraceScene sc, Wavefront wf, int qout, uint32_t count)
+__global__ void __launch_bounds__(kBlock) PT_FULL_OCCUPANCY k_trace_shadow<false>(LaunchParams p, TraceScene sc, Wavefront wf, int qout, int parity)
 {
-    traceShadowBody<false>(p, sc, wf, qout, count);
+    traceShadowBody<false>(p, sc, wf, qout, parity);
 }
 template <>
-__global__ void __launch_bounds__(kBlock) PT_ALPHA_SHADOW_ATTR k_trace_shadow<true>(LaunchParams p, TraceScene sc, Wavefront wf, int qout, uint32_t count)
+__global__ void __launch_bounds__(kBlock) PT_ALPHA_SHADOW_ATTR k_trace_shadow<true>(LaunchParams p, TraceScene sc, Wavefront wf, int qout, int parity)
 {
-    traceShadowBody<true>(p, sc, wf, qout, count);
+    traceShadowBody<true>(p, sc, wf, qout, parity);
 }
 
 // The second half of finishSample for the slots the shadow kernel re-queued: next primary ray, RNG carried on.
@@ -644,8 +692,13 @@ __global__ void __launch_bounds__(kBlock) k_restart(LaunchParams p, Wavefront wf
 
 // raygen.rgen:115-117 for `frames` launches in frame order: bit-identical to issuing the
 // launches one after another.
-__global__ void __launch_bounds__(kBlock) k_accumulate(LaunchParams p, const float4 *__restrict__ slotRad, float4 *__restrict__ image)
+// pendingRestarts: counter of slots still waiting for another sample (multi-sample launch, NaN restart): their slotRad is
+// not final, the host runs further rounds and accumulates afterwards
+__global__ void __launch_bounds__(kBlock) k_accumulate(LaunchParams p, const float4 *__restrict__ slotRad, float4 *__restrict__ image,
+                                                        const uint32_t *__restrict__ pendingRestarts)
 {
+    if (pendingRestarts && *pendingRestarts != 0u)
+        return;
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < p.slotsPerFrame; s += gridDim.x * blockDim.x)
     {
         const uint32_t pixel = slotPixel(p, s);
@@ -675,7 +728,11 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(LaunchParams p, const flo
 struct PathCounters
 {
     uint32_t nSeg = 0, nHit = 0, nSmp = 0, nRetry = 0;
+    bool stuck = false; // some path never produced a finite sample and was given up (kMaxSampleRetries)
 };
+// A slot whose samples keep coming out NaN / Inf would spin for ever (it hangs the GPU in the reference): after this many
+// restarts in a row it is given up with radiance 0 and the launch reports an error.
+constexpr uint32_t kMaxSampleRetries = 256;
 
 // Runs a slot to the end of its launch -- or, with ONE_SAMPLE, to the end of the sample it is in (smpl then tells
 // the caller whether samples remain).  `fresh` = start with a new sample (primary ray); otherwise continue the
@@ -687,6 +744,7 @@ PT_DEV f3 runPath(const LaunchParams &p, const SceneView &sv, const TraceScene &
                   PathCounters &pc)
 {
     constexpr bool TEX = MODE >= 1, ALPHA = MODE == 2;
+    uint32_t restartsInARow = 0;
     for (;;)
     {
         if (fresh)
@@ -741,9 +799,17 @@ PT_DEV f3 runPath(const LaunchParams &p, const SceneView &sv, const TraceScene &
             radiance = F3s(0.0f);
             smpl = 0;
             pc.nRetry++;
+            if (++restartsInARow >= kMaxSampleRetries)
+            {
+                pc.stuck = true;
+                smpl = (int)p.u.SampleCount;
+            }
         }
         else
+        {
             smpl++;
+            restartsInARow = 0;
+        }
         fresh = true;
     }
     return radiance;
@@ -771,6 +837,8 @@ __global__ void __launch_bounds__(kBlock) k_megakernel(LaunchParams p, SceneView
         slotRad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
     if (st.overflow)
         atomicAdd(&counters[C_OVERFLOW], 1u);
+    if (pc.stuck)
+        atomicAdd(&counters[C_OVERFLOW + 1], 1u);
     waveAddCounter(&counters[C_SEGMENTS], pc.nSeg);
     waveAddCounter(&counters[C_HITS], pc.nHit);
     waveAddCounter(&counters[C_SAMPLES], pc.nSmp);
@@ -795,27 +863,38 @@ __global__ void __launch_bounds__(kBlock) k_megakernel(LaunchParams p, SceneView
 #define PT_TAIL_TEX_ATTR PT_TAIL_ATTR
 #endif
 template <int MODE>
-PT_DEV void tailBody(const LaunchParams &p, const SceneView &sv, const TraceScene &sc, const Wavefront &wf, int qin, uint32_t count);
+PT_DEV void tailBody(const LaunchParams &p, const SceneView &sv, const TraceScene &sc, const Wavefront &wf, int qin, const BounceCtl &ctl);
 template <int MODE>
-__global__ void __launch_bounds__(kBlock) k_tail(LaunchParams p, SceneView sv, TraceScene sc, Wavefront wf, int qin, uint32_t count);
+__global__ void __launch_bounds__(kBlock) k_tail(LaunchParams p, SceneView sv, TraceScene sc, Wavefront wf, int qin, BounceCtl ctl);
 template <>
-__global__ void __launch_bounds__(kBlock) PT_TAIL_ATTR k_tail<0>(LaunchParams p, SceneView sv, TraceScene sc, Wavefront wf, int qin, uint32_t count)
+__global__ void __launch_bounds__(kBlock) PT_TAIL_ATTR k_tail<0>(LaunchParams p, SceneView sv, TraceScene sc, Wavefront wf, int qin, BounceCtl ctl)
 {
-    tailBody<0>(p, sv, sc, wf, qin, count);
+    tailBody<0>(p, sv, sc, wf, qin, ctl);
 }
 template <>
-__global__ void __launch_bounds__(kBlock) PT_TAIL_TEX_ATTR k_tail<1>(LaunchParams p, SceneView sv, TraceScene sc, Wavefront wf, int qin, uint32_t count)
+__global__ void __launch_bounds__(kBlock) PT_TAIL_TEX_ATTR k_tail<1>(LaunchParams p, SceneView sv, TraceScene sc, Wavefront wf, int qin, BounceCtl ctl)
 {
-    tailBody<1>(p, sv, sc, wf, qin, count);
+    tailBody<1>(p, sv, sc, wf, qin, ctl);
 }
 template <>
-__global__ void __launch_bounds__(kBlock) PT_TAIL_TEX_ATTR k_tail<2>(LaunchParams p, SceneView sv, TraceScene sc, Wavefront wf, int qin, uint32_t count)
+__global__ void __launch_bounds__(kBlock) PT_TAIL_TEX_ATTR k_tail<2>(LaunchParams p, SceneView sv, TraceScene sc, Wavefront wf, int qin, BounceCtl ctl)
 {
-    tailBody<2>(p, sv, sc, wf, qin, count);
+    tailBody<2>(p, sv, sc, wf, qin, ctl);
 }
+// Launched after the shadow kernel of every bounce, on that kernel's stream (so the NEE adds of the bounce have landed
+// in rad[slot]): it takes the queue over once it is short enough -- the complement of bounceRuns() for the bounces that
+// follow, which then find the queue is not theirs and return.
 template <int MODE>
-PT_DEV void tailBody(const LaunchParams &p, const SceneView &sv, const TraceScene &sc, const Wavefront &wf, int qin, uint32_t count)
+PT_DEV void tailBody(const LaunchParams &p, const SceneView &sv, const TraceScene &sc, const Wavefront &wf, int qin, const BounceCtl &ctl)
 {
+    const uint32_t count = wf.counters[queueCounter(qin)];
+    if (count == 0u || count > ctl.tailBelow) // ctl.bounce = the bounce whose shade kernel filled the queue
+        return;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+    {
+        wf.counters[C_TAIL_PATHS] = count;
+        wf.counters[C_TAIL_PATHS + 1] = ctl.bounce;
+    }
     PT_DECLARE_STACK(st, PT_TAIL_LDS, wf.spill)
     PathCounters pc;
     for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x)
@@ -856,6 +935,43 @@ PT_DEV void tailBody(const LaunchParams &p, const SceneView &sv, const TraceScen
     }
     if (st.overflow)
         atomicAdd(&wf.counters[C_OVERFLOW], 1u);
+    waveAddCounter(&wf.counters[C_SEGMENTS], pc.nSeg);
+    waveAddCounter(&wf.counters[C_HITS], pc.nHit);
+    waveAddCounter(&wf.counters[C_SAMPLES], pc.nSmp);
+    waveAddCounter(&wf.counters[C_RETRIES], pc.nRetry);
+}
+
+// The rare slots whose sample came out NaN / Inf in a canonical (SampleCount = 1) launch: raygen.rgen:99-112 restarts
+// the sample with the RNG carried on.  They sit in the restart queue with radiance 0 and smpl = 0; this kernel runs each
+// of them to the end of the launch the way the megakernel would (new primary ray, whole path, again if the radiance is
+// bad again), so that a launch completes on the device without the host looking at the queue.  Multi-sample launches do
+// NOT come here: their restart queue holds every slot once per extra sample, and goes through the wavefront kernels
+// round by round (renderImpl).
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) PT_TAIL_TEX_ATTR k_finish_restarts(LaunchParams p, SceneView sv, TraceScene sc, Wavefront wf)
+{
+    const uint32_t count = wf.counters[C_RESTART];
+    if (count == 0u)
+        return;
+    PT_DECLARE_STACK(st, PT_TAIL_LDS, wf.spill)
+    PathCounters pc;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
+    {
+        const uint32_t slot = wf.restartQueue[i];
+        const uint4 meta = wf.meta[slot];
+        const float4 r4 = wf.rad[slot];
+        uint32_t rng = meta.x;
+        DiffRays diff;
+        diff.rxOrigin = diff.rxDirection = diff.ryOrigin = diff.ryDirection = F3s(0.0f);
+        int smpl = (int)(meta.z >> 16);
+        const f3 radiance = runPath<MODE>(p, sv, sc, st, meta.y, rng, F3(r4.x, r4.y, r4.z), F3s(1.0f), F3s(0.0f), F3s(0.0f), diff, 0.0f, 0u, smpl,
+                                          true, pc);
+        wf.slotRad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+    }
+    if (st.overflow)
+        atomicAdd(&wf.counters[C_OVERFLOW], 1u);
+    if (pc.stuck)
+        atomicAdd(&wf.counters[C_OVERFLOW + 1], 1u);
     waveAddCounter(&wf.counters[C_SEGMENTS], pc.nSeg);
     waveAddCounter(&wf.counters[C_HITS], pc.nHit);
     waveAddCounter(&wf.counters[C_SAMPLES], pc.nSmp);
@@ -1430,19 +1546,22 @@ struct PtxRenderer
 
     hipEvent_t evA = nullptr, evB = nullptr, evT0 = nullptr, evT1 = nullptr; // render / build span; ptx_trace_rays kernel span
 
-    // sub-batches of one ptx_render_frames call, driven as interleaved state machines
-    struct BatchRes
+    // bounce schedule of the wavefront backend (renderImpl): closest + shade on `stream`, shadow + tail on `auxStream`
+    hipStream_t auxStream = nullptr;
+    DevBuf<uint32_t> spillAux; // traversal-stack overflow region of the kernels on auxStream
+    struct BounceEvents
     {
-        hipStream_t s = nullptr, x = nullptr; // closest + shade + tail | shadow
-        hipEvent_t evReady = nullptr, evShade = nullptr, evShadow[2] = { nullptr, nullptr }, evX0[2] = { nullptr, nullptr };
-        hipEvent_t evT0 = nullptr, evT1 = nullptr, evT2 = nullptr, evDone = nullptr;
-        uint32_t *dCounters = nullptr, *hCounters = nullptr;
-        uint32_t *spill = nullptr, *spillAux = nullptr;
+        hipEvent_t t0 = nullptr, t1 = nullptr, t2 = nullptr; // stream: before closest, after closest, after shade
+        hipEvent_t x0 = nullptr, x1 = nullptr, x2 = nullptr; // auxStream: before shadow, after shadow, after tail
     };
-    static constexpr int kMaxBatches = 4;
-    BatchRes batch[kMaxBatches];
-    int batchesReady = 0;
-    hipEvent_t evStart = nullptr;
+    std::vector<BounceEvents> bounceEvents; // [min(BounceCount, kMaxTimedBounces)], reused cyclically beyond
+    // what the last launch left for ptx_get_stats / the next launch to pick up once the device is done
+    bool statsPending = false;
+    uint32_t pendingBounces = 0, pendingTailBelow = 0, pendingSlots = 0;
+    uint32_t pendingDeadSlots = 0; // slots of ragged edge tiles outside the image: in the first queue, not rays
+    bool pendingVerbose = false;
+    std::vector<uint32_t> hintActive; // queue length per bounce of the last canonical launch: sizes the grids of the next one
+    uint32_t hintSlots = 0, hintBounces = 0;
     PtxStats stats = {};
 };
 
@@ -1611,22 +1730,11 @@ void ptx_destroy(PtxRenderer *r)
     if (r->stream)
         (void)hipStreamSynchronize(r->stream);
     // every DevBuf member (scene, tree, build state, wavefront state, animation, output stage) frees itself in `delete r`
-    for (int b = 0; b < r->batchesReady; b++)
-    {
-        PtxRenderer::BatchRes &q = r->batch[b];
-        if (q.s) { (void)hipStreamSynchronize(q.s); (void)hipStreamDestroy(q.s); }
-        if (q.x) { (void)hipStreamSynchronize(q.x); (void)hipStreamDestroy(q.x); }
-        hipEvent_t evs[] = { q.evReady, q.evShade, q.evShadow[0], q.evShadow[1], q.evX0[0], q.evX0[1], q.evT0, q.evT1, q.evT2, q.evDone };
-        for (hipEvent_t e : evs)
-            if (e)
-                (void)hipEventDestroy(e);
-        if (q.dCounters) (void)hipFree(q.dCounters);
-        if (q.hCounters) (void)hipHostFree(q.hCounters);
-        if (q.spill) (void)hipFree(q.spill);
-        if (q.spillAux) (void)hipFree(q.spillAux);
-    }
-    if (r->evStart)
-        (void)hipEventDestroy(r->evStart);
+    if (r->auxStream) { (void)hipStreamSynchronize(r->auxStream); (void)hipStreamDestroy(r->auxStream); }
+    for (PtxRenderer::BounceEvents &e : r->bounceEvents)
+        for (hipEvent_t ev : { e.t0, e.t1, e.t2, e.x0, e.x1, e.x2 })
+            if (ev)
+                (void)hipEventDestroy(ev);
     if (r->copyStream) { (void)hipStreamSynchronize(r->copyStream); (void)hipStreamDestroy(r->copyStream); }
     if (r->evSnapshot) (void)hipEventDestroy(r->evSnapshot);
     if (r->evCopied) (void)hipEventDestroy(r->evCopied);
@@ -2200,32 +2308,188 @@ static int ensureSlots(PtxRenderer *r, size_t slots)
     return PTX_OK;
 }
 
-static int ensureBatches(PtxRenderer *r, int nb)
+__global__ void k_upload_lights(PtxLightsUbo lights, PtxLightsUbo *dst) // 3,120 bytes as a kernel argument: no staging buffer to keep alive
 {
-    for (int b = r->batchesReady; b < nb; b++)
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(&lights);
+    uint32_t *d = reinterpret_cast<uint32_t *>(dst);
+    for (uint32_t i = threadIdx.x; i < sizeof(PtxLightsUbo) / 4; i += blockDim.x)
+        d[i] = src[i];
+}
+
+static int ensureRenderResources(PtxRenderer *r, uint32_t bounces)
+{
+    if (!r->auxStream)
     {
-        PtxRenderer::BatchRes &q = r->batch[b];
-        HIP_TRY(r, hipStreamCreateWithFlags(&q.s, hipStreamNonBlocking));
-        HIP_TRY(r, hipStreamCreateWithFlags(&q.x, hipStreamNonBlocking));
-        HIP_TRY(r, hipEventCreateWithFlags(&q.evReady, hipEventDisableTiming));
-        HIP_TRY(r, hipEventCreateWithFlags(&q.evShade, hipEventDisableTiming));
-        HIP_TRY(r, hipEventCreateWithFlags(&q.evDone, hipEventDisableTiming));
-        for (int k = 0; k < 2; k++)
-        {
-            HIP_TRY(r, hipEventCreate(&q.evShadow[k]));
-            HIP_TRY(r, hipEventCreate(&q.evX0[k]));
-        }
-        HIP_TRY(r, hipEventCreate(&q.evT0));
-        HIP_TRY(r, hipEventCreate(&q.evT1));
-        HIP_TRY(r, hipEventCreate(&q.evT2));
-        HIP_TRY(r, hipMalloc(reinterpret_cast<void **>(&q.dCounters), C_COUNT * sizeof(uint32_t)));
-        HIP_TRY(r, hipHostMalloc(reinterpret_cast<void **>(&q.hCounters), C_COUNT * sizeof(uint32_t), hipHostMallocDefault));
-        HIP_TRY(r, hipMalloc(reinterpret_cast<void **>(&q.spill), (size_t)kGlobalSpill * kMaxPersistentThreads * sizeof(uint32_t)));
-        HIP_TRY(r, hipMalloc(reinterpret_cast<void **>(&q.spillAux), (size_t)kGlobalSpill * kMaxPersistentThreads * sizeof(uint32_t)));
-        r->batchesReady = b + 1;
+        HIP_TRY(r, hipStreamCreateWithFlags(&r->auxStream, hipStreamNonBlocking));
+        HIP_TRY(r, r->spillAux.alloc((size_t)kGlobalSpill * kMaxPersistentThreads));
     }
-    if (!r->evStart)
-        HIP_TRY(r, hipEventCreateWithFlags(&r->evStart, hipEventDisableTiming));
+    const size_t want = bounces < (uint32_t)kMaxTimedBounces ? bounces : (uint32_t)kMaxTimedBounces;
+    while (r->bounceEvents.size() < want)
+    {
+        PtxRenderer::BounceEvents e;
+        for (hipEvent_t *ev : { &e.t0, &e.t1, &e.t2, &e.x0, &e.x1, &e.x2 })
+            HIP_TRY(r, hipEventCreate(ev));
+        r->bounceEvents.push_back(e);
+    }
+    return PTX_OK;
+}
+
+// What the kernels of one launch share.
+struct RenderPlan
+{
+    LaunchParams p;
+    SceneView sv;
+    TraceScene sc;
+    int mode;           // kernelMode()
+    uint32_t bounces;   // BounceCount
+    uint32_t tailBelow; // queues of at most this many paths are finished by k_tail
+    Wavefront wf, wfAux;
+};
+
+// One ROUND of the wavefront: the slots listed in queue 0 (ACTIVE0 set by the caller, at most `upperBound`) start at
+// bounce 0 of a sample and are advanced BounceCount times, or until the queue is short enough for k_tail.  Nothing here
+// waits for the device: every kernel reads its queue length from the counter block (BounceCtl).  `hint` = queue lengths
+// of an earlier launch of the same shape, used only to size grids.
+//
+//   stream     P(b)  closest(b)  [wait aux(b-1)]  shade(b)                      P(b+1) closest(b+1) ...
+//   auxStream                                     [wait shade(b)] shadow(b) tail(b)
+//
+// shadow(b) only adds into rad[slot], which shade(b + 1) reads -- not closest(b + 1) -- so it runs beside the next
+// traversal; k_tail follows it in stream order (the NEE adds it continues from have landed) and the last shadow query
+// before the tail needs no event of its own.
+//
+// With a hint the schedule stops one bounce after the one whose queue k_tail took over last time, and the tail launch
+// behind that last bounce takes whatever is left, however much (results do not depend on who finishes a path): the
+// bounces k_tail made redundant are not enqueued as kernels that look at a counter and return.
+static int enqueueRound(PtxRenderer *r, const RenderPlan &pl, uint32_t upperBound, const uint32_t *hint)
+{
+    const bool textured = pl.mode >= 1, alpha = pl.mode == 2;
+    hipStream_t S = r->stream, X = r->auxStream;
+    uint32_t last = pl.bounces;
+    if (hint && pl.tailBelow)
+        for (uint32_t b = 1; b < pl.bounces && b < (uint32_t)kMaxTimedBounces; b++)
+            if (hint[b + 1] <= pl.tailBelow) // k_tail took the queue of bounce b (or nothing was left of it)
+            {
+                last = b + 1 < pl.bounces ? b + 1 : pl.bounces;
+                break;
+            }
+    int qin = 0;
+    for (uint32_t b = 1; b <= last; b++)
+    {
+        PtxRenderer::BounceEvents &ev = r->bounceEvents[(b - 1) % r->bounceEvents.size()];
+        const BounceCtl ctl = { b, pl.tailBelow };
+        uint32_t est = upperBound; // exact for the first bounce; later ones shrink
+        if (b > 1 && hint && b <= (uint32_t)kMaxTimedBounces)
+        {
+            const uint64_t e = (uint64_t)hint[b] + hint[b] / 4 + 4096;
+            est = e < upperBound ? (uint32_t)e : upperBound;
+        }
+        const int qout = qin ^ 1;
+        k_prologue<<<1, 1, 0, S>>>(pl.wf, qin, ctl);
+        HIP_TRY(r, hipEventRecord(ev.t0, S));
+        if (alpha)
+            k_trace_closest<true><<<traceGridFor(est, r->residentClosest[1]), kBlock, 0, S>>>(pl.sc, pl.wf, qin, ctl);
+        else
+            k_trace_closest<false><<<traceGridFor(est, r->residentClosest[0]), kBlock, 0, S>>>(pl.sc, pl.wf, qin, ctl);
+        HIP_TRY(r, hipEventRecord(ev.t1, S));
+        if (b > 1) // shade reads rad[slot]: the previous bounce's shadow adds (and its tail, if it ran) must have landed
+            HIP_TRY(r, hipStreamWaitEvent(S, r->bounceEvents[(b - 2) % r->bounceEvents.size()].x2, 0));
+        const uint32_t shadeGrid = gridFor((est + kShadeItems - 1) / kShadeItems);
+        if (textured)
+            k_shade<true><<<shadeGrid, kBlock, 0, S>>>(pl.p, pl.sv, pl.wf, qin, ctl);
+        else
+            k_shade<false><<<shadeGrid, kBlock, 0, S>>>(pl.p, pl.sv, pl.wf, qin, ctl);
+        HIP_TRY(r, hipEventRecord(ev.t2, S));
+        HIP_TRY(r, hipStreamWaitEvent(X, ev.t2, 0));
+        HIP_TRY(r, hipEventRecord(ev.x0, X));
+        if (alpha)
+            k_trace_shadow<true><<<traceGridFor(est, r->residentShadow[1]), kBlock, 0, X>>>(pl.p, pl.sc, pl.wfAux, qout, (int)(b & 1u));
+        else
+            k_trace_shadow<false><<<traceGridFor(est, r->residentShadow[0]), kBlock, 0, X>>>(pl.p, pl.sc, pl.wfAux, qout, (int)(b & 1u));
+        HIP_TRY(r, hipEventRecord(ev.x1, X));
+        if (pl.tailBelow && b < pl.bounces) // the queue shade(b) produced; after the last bounce it is empty by construction
+        {
+            const bool takeAll = b == last; // nothing is enqueued behind this bounce
+            const BounceCtl tctl = { b, takeAll ? 0xffffffffu : pl.tailBelow };
+            const uint32_t most = est < pl.tailBelow ? est : pl.tailBelow;
+            const dim3 grid(gridFor(most, kBlock, kMaxPersistentThreads / kBlock)); // grid-stride loop; the spill region holds this many threads
+            if (pl.mode == 2)
+                k_tail<2><<<grid, kBlock, 0, X>>>(pl.p, pl.sv, pl.sc, pl.wfAux, qout, tctl);
+            else if (pl.mode == 1)
+                k_tail<1><<<grid, kBlock, 0, X>>>(pl.p, pl.sv, pl.sc, pl.wfAux, qout, tctl);
+            else
+                k_tail<0><<<grid, kBlock, 0, X>>>(pl.p, pl.sv, pl.sc, pl.wfAux, qout, tctl);
+        }
+        HIP_TRY(r, hipEventRecord(ev.x2, X));
+        qin = qout;
+    }
+    if (last)
+        HIP_TRY(r, hipStreamWaitEvent(S, r->bounceEvents[(last - 1) % r->bounceEvents.size()].x2, 0));
+    HIP_TRY(r, hipGetLastError());
+    return PTX_OK;
+}
+
+// Statistics and errors of the last wavefront launch, once the device is done with it (blocks until then).
+static int collectRender(PtxRenderer *r)
+{
+    if (!r->statsPending)
+        return PTX_OK;
+    r->statsPending = false;
+    HIP_TRY(r, hipEventSynchronize(r->evB));
+    const uint32_t *h = r->hostCounters;
+    if (h[C_OVERFLOW])
+        return fail(r, PTX_ERROR_DEVICE, "ptx_render: traversal stack overflow (tree deeper than %d levels)", kLdsStack + kGlobalSpill);
+    if (h[C_OVERFLOW + 1])
+        return fail(r, PTX_ERROR_DEVICE, "ptx_render: %u paths never produced a finite sample in %u attempts", h[C_OVERFLOW + 1], kMaxSampleRetries);
+    unsigned long long waveSegments = 0;
+    std::memcpy(&waveSegments, &h[C_WAVE_SEGMENTS], sizeof(waveSegments));
+    waveSegments -= r->pendingDeadSlots; // k_prologue counted the whole first queue
+    r->stats.segments = waveSegments + h[C_SEGMENTS];
+    r->stats.tracedRays = waveSegments;
+    r->stats.shadowRays = h[C_HITS];
+    r->stats.pathSamples = h[C_SAMPLES];
+    r->stats.retries = h[C_RETRIES];
+    // kernel times of the bounces that ran (the others returned at once), from the events around every launch
+    const uint32_t timed = r->pendingBounces < (uint32_t)kMaxTimedBounces ? r->pendingBounces : (uint32_t)kMaxTimedBounces;
+    const uint32_t tailPaths = h[C_TAIL_PATHS], tailBounce = h[C_TAIL_PATHS + 1]; // k_tail took the queue shade(tailBounce) filled
+    for (uint32_t b = 1; b <= timed; b++)
+    {
+        const PtxRenderer::BounceEvents &ev = r->bounceEvents[b - 1];
+        const uint32_t active = h[C_BOUNCE_ACTIVE + b];
+        const bool ran = active != 0u && (b <= 1u || active > r->pendingTailBelow) && !(tailPaths && b > tailBounce);
+        if (!ran)
+            continue;
+        float closestMs = 0.0f, shadeMs = 0.0f, shadowMs = 0.0f, tailMs = 0.0f;
+        (void)hipEventElapsedTime(&closestMs, ev.t0, ev.t1);
+        (void)hipEventElapsedTime(&shadeMs, ev.t1, ev.t2);
+        (void)hipEventElapsedTime(&shadowMs, ev.x0, ev.x1);
+        r->stats.lastTraceMs += closestMs;
+        r->stats.lastShadeMs += shadeMs;
+        r->stats.lastShadowMs += shadowMs;
+        r->stats.traceLaunches += 2;
+        if (tailPaths && tailBounce == b)
+        {
+            (void)hipEventElapsedTime(&tailMs, ev.x1, ev.x2);
+            r->stats.lastTailMs += tailMs;
+        }
+        if (r->pendingVerbose)
+        {
+            fprintf(stderr, "[ptx] bounce %u: %u rays closest %.3f ms (%.2f Grays/s) | shade (incl. wait for the previous shadow kernel) %.3f ms | shadow %.3f ms\n",
+                    b, active, closestMs, active / closestMs / 1e6, shadeMs, shadowMs);
+            if (tailMs > 0.0f)
+                fprintf(stderr, "[ptx] tail: %u paths, %u segments, %.3f ms\n", tailPaths, h[C_SEGMENTS], tailMs);
+        }
+    }
+    if (r->pendingVerbose && h[C_RETRIES])
+        fprintf(stderr, "[ptx] %u NaN / Inf sample restarts\n", h[C_RETRIES]);
+    // grid / schedule hints for the next launch of this shape.  The queue k_tail took over is part of them (a truncated
+    // schedule has no prologue behind its last bounce to record it); a tail that had to take more than its threshold
+    // means the hints were off: forget them, the next launch runs the full schedule and learns again.
+    r->hintActive.assign(h + C_BOUNCE_ACTIVE, h + C_BOUNCE_ACTIVE + kMaxTimedBounces + 1);
+    if (tailPaths && tailBounce + 1 <= (uint32_t)kMaxTimedBounces)
+        r->hintActive[tailBounce + 1] = tailPaths;
+    r->hintSlots = tailPaths > r->pendingTailBelow ? 0u : r->pendingSlots;
+    r->hintBounces = r->pendingBounces;
     return PTX_OK;
 }
 
@@ -2240,6 +2504,11 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
     if (lights->LightCount > PTX_MAX_LIGHT_COUNT)
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_render: LightCount %u exceeds MaxLightCount", lights->LightCount);
     HIP_TRY(r, hipSetDevice(r->device));
+    {
+        const int rcPrev = collectRender(r); // statistics / errors of the previous launch; the counter block is reused below
+        if (rcPrev != PTX_OK)
+            return rcPrev;
+    }
 
     const LaunchParams p = makeParams(r, uniform, firstFrame, frames);
     if ((uint64_t)p.slotsPerFrame * frames > 0x7fffffffull)
@@ -2248,14 +2517,18 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
     if (rc != PTX_OK)
         return rc;
 
-    HIP_TRY(r, hipMemcpyAsync(r->lights.p, lights, sizeof(PtxLightsUbo), hipMemcpyHostToDevice, r->stream));
+    k_upload_lights<<<1, 256, 0, r->stream>>>(*lights, r->lights.p);
     HIP_TRY(r, hipMemsetAsync(r->counters.p, 0, C_COUNT * sizeof(uint32_t), r->stream));
 
-    const SceneView sv = makeSceneView(r);
-    const int mode = kernelMode(r);
-    const bool textured = mode >= 1, alpha = mode == 2;
-    TraceScene sc;
-    sc.nodes = r->nodes.p; sc.tris = r->tris.p; sc.triCount = r->treeTris; sc.sv = sv;
+    RenderPlan pl;
+    pl.p = p;
+    pl.sv = makeSceneView(r);
+    pl.mode = kernelMode(r);
+    pl.sc.nodes = r->nodes.p; pl.sc.tris = r->tris.p; pl.sc.triCount = r->treeTris; pl.sc.sv = pl.sv;
+    pl.bounces = uniform->BounceCount;
+    const SceneView &sv = pl.sv;
+    const TraceScene &sc = pl.sc;
+    const int mode = pl.mode;
 
     r->stats.pathSamples = r->stats.segments = r->stats.shadowRays = r->stats.retries = 0;
     r->stats.traceLaunches = 0;
@@ -2275,7 +2548,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
         // raygen.rgen:62: the bounce loop never runs, every sample ends with radiance 0 -- nothing is generated, traced or
         // shaded (the wavefront kernels test the bounce limit only AFTER a bounce); the image still gets its alpha
         HIP_TRY(r, hipMemsetAsync(r->slotRad.p, 0, (size_t)p.numSlots * sizeof(float4), r->stream));
-        k_accumulate<<<gridFor(p.slotsPerFrame), kBlock, 0, r->stream>>>(p, r->slotRad.p, imagePtr(r));
+        k_accumulate<<<gridFor(p.slotsPerFrame), kBlock, 0, r->stream>>>(p, r->slotRad.p, imagePtr(r), nullptr);
         HIP_TRY(r, hipEventRecord(r->evB, r->stream));
         HIP_TRY(r, hipGetLastError());
         r->stats.pathSamples = (uint64_t)p.ownedPixels * frames * uniform->SampleCount;
@@ -2291,13 +2564,16 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
             k_megakernel<1><<<grid, kBlock, 0, r->stream>>>(p, sv, sc, r->slotRad.p, r->counters.p);
         else
             k_megakernel<0><<<grid, kBlock, 0, r->stream>>>(p, sv, sc, r->slotRad.p, r->counters.p);
-        k_accumulate<<<gridFor(p.slotsPerFrame), kBlock, 0, r->stream>>>(p, r->slotRad.p, imagePtr(r));
+        k_accumulate<<<gridFor(p.slotsPerFrame), kBlock, 0, r->stream>>>(p, r->slotRad.p, imagePtr(r), nullptr);
         HIP_TRY(r, hipMemcpyAsync(r->hostCounters, r->counters.p, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
         HIP_TRY(r, hipEventRecord(r->evB, r->stream));
         HIP_TRY(r, hipStreamSynchronize(r->stream));
         HIP_TRY(r, hipGetLastError());
         if (r->hostCounters[C_OVERFLOW])
             return fail(r, PTX_ERROR_DEVICE, "ptx_render: traversal stack overflow in the megakernel (depth > %d)", kLdsStackMega);
+        if (r->hostCounters[C_OVERFLOW + 1])
+            return fail(r, PTX_ERROR_DEVICE, "ptx_render: %u paths never produced a finite sample in %u attempts", r->hostCounters[C_OVERFLOW + 1],
+                        kMaxSampleRetries);
         r->stats.segments = r->hostCounters[C_SEGMENTS];
         r->stats.shadowRays = r->hostCounters[C_HITS];
         r->stats.pathSamples = r->hostCounters[C_SAMPLES];
@@ -2305,322 +2581,93 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
         return PTX_OK;
     }
 
-    // ---- wavefront: the bounce loop is a small state machine per sub-batch (whole frames each)
-    // on its own stream pair; every bounce ends in a 48-B counter read-back.  PTX_BATCHES > 1
-    // splits the frames of the call into interleaved sub-batches.  Measured on MI355X
-    // (chess_like 1080p x 8): 1 -> 1204, 2 -> 1017, 3 -> 1006, 4 -> 733 Msamples/s -- sub-batches
-    // pass through their throughput-bound and latency-bound phases in lockstep, so nothing
-    // complementary overlaps and co-resident persistent kernels interfere.  Staggering them (sub-batch b + 1 starts
-    // when b enters k_tail) was measured too: 16 spp as 2 x 8 staggered 22.5 ms vs 2 x 11.2 ms back to back -- the tail
-    // kernel starves beside the full-size kernels (2 tails 4.2 ms instead of 3.0) and slows them in turn.  What does
-    // pay is a larger batch: 16 frames in one batch 19.9 ms (one tail instead of two).  Default: 1.
+    // ---- wavefront.  The whole launch is enqueued without waiting for the device (enqueueRound): the kernels take their
+    // queue lengths from the counter block, k_tail decides for itself when to take a queue over, and the rare NaN / Inf
+    // restarts of a canonical launch are finished on the device too (k_finish_restarts).  The host reads ONE counter
+    // block per launch, after the fact (collectRender: statistics, errors, grid hints).  A step of the benchmark used
+    // to carry 26 host round trips (0.33 ms of idle GPU per 10 ms step, 6 % of a 1/8 tile shard's step).
     //
-    // Also measured and dropped: ONE traversal launch per bounce carrying the closest-hit queries of bounce n + 1 and the
-    // shadow queries of bounce n (single stream, 64 VGPRs, 8 waves): 11.4 ms per chess_like step against 11.1 ms for the
-    // two kernels on two streams below (temple_like 26.6 vs 24.9 ms) -- the two persistent kernels already fill each
-    // other's tails.  Resetting the per-bounce counters inside the kernels instead of three 4-byte fills per bounce:
-    // the fills do wait behind the other stream's persistent kernel (up to 0.76 ms seen), but without them the closest
-    // kernel waits in their place; no gain (11.15 ms, and 3.7 instead of 3.4 ms on a 1/8 shard).  A one-entry software
-    // pipeline in k_shade (hit / meta / pair of entry k + 1 loaded while entry k is shaded): 3.50 vs 3.44 ms, no gain.
-    int nb = 1;
-    if (const char *e = getenv("PTX_BATCHES"))
-        nb = atoi(e);
-    if (nb < 1) nb = 1;
-    if (nb > PtxRenderer::kMaxBatches) nb = PtxRenderer::kMaxBatches;
-    if ((uint32_t)nb > frames) nb = (int)frames;
+    // Measured and dropped along the way: sub-batches of one call as interleaved state machines
+    // (PTX_BATCHES: 1 -> 1204, 2 -> 1017, 3 -> 1006, 4 -> 733 Msamples/s -- they pass through their throughput- and
+    // latency-bound phases in lockstep), staggered sub-batches (the tail kernel starves beside full-size kernels), ONE
+    // traversal launch per bounce carrying closest(b + 1) and shadow(b) (11.4 vs 11.1 ms), a one-entry software pipeline
+    // in k_shade (3.50 vs 3.44 ms).
     {
-        const int rcb = ensureBatches(r, nb);
-        if (rcb != PTX_OK)
-            return rcb;
+        const int rcr = ensureRenderResources(r, pl.bounces);
+        if (rcr != PTX_OK)
+            return rcr;
     }
-    const bool verbose = getenv("PTX_VERBOSE") != nullptr;
-    // every iteration advances each active path by one bounce; NaN/Inf restarts
-    // (raygen.rgen:99-112) can add iterations but a path that never yields a finite
-    // sample would spin forever (it hangs the GPU in the reference): give up instead
-    const uint64_t maxIterations = ((uint64_t)uniform->BounceCount + 1) * uniform->SampleCount * 64 + 64;
-    // below this many live paths the remaining bounces of a sub-batch run fused in k_tail
-    uint32_t tailThreshold = 300000; // measured: flat from 100 K to 400 K live paths, worse beyond
+    pl.tailBelow = 300000; // measured: flat from 100 K to 400 K live paths, worse beyond
     if (const char *e = getenv("PTX_TAIL_THRESHOLD"))
-        tailThreshold = (uint32_t)strtoul(e, nullptr, 10);
+        pl.tailBelow = (uint32_t)strtoul(e, nullptr, 10);
+    Wavefront &wf = pl.wf;
+    wf.rayO = r->rayO.p; wf.rayD = r->rayD.p; wf.thr = r->thr.p; wf.rad = r->rad.p;
+    wf.meta = r->meta.p; wf.hit = r->hit.p; wf.hitPair = r->hitPair.p;
+    wf.shO = r->shO.p; wf.shD = r->shD.p; wf.shC = r->shC.p; wf.slotRad = r->slotRad.p;
+    wf.queue[0] = r->queue0.p; wf.queue[1] = r->queue1.p; wf.shadowQueue = r->shadowQueue.p;
+    wf.restartQueue = r->restartQueue.p;
+    for (int k = 0; k < 3; k++)
+        wf.diff[k] = mode >= 1 ? r->diffs.p + (size_t)k * r->diffCapacity : nullptr;
+    wf.decal = mode == 2 ? r->decal.p : nullptr;
+    wf.decalT = mode == 2 ? r->decalT.p : nullptr;
+    wf.counters = r->counters.p;
+    wf.spill = r->spill.p;
+    pl.wfAux = wf;
+    pl.wfAux.spill = r->spillAux.p;
 
-    enum Phase { PH_ISSUE, PH_WAIT_BOUNCE, PH_WAIT_TAIL, PH_WAIT_DRAIN, PH_DONE };
-    struct Batch
+    const bool canonical = uniform->SampleCount == 1;
+    const uint32_t *hint = (canonical && r->hintSlots == p.numSlots && r->hintBounces == pl.bounces && !r->hintActive.empty()) ? r->hintActive.data() : nullptr;
+    k_generate<<<gridFor(p.numSlots), kBlock, 0, r->stream>>>(p, wf);
+    HIP_TRY(r, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&r->counters.p[C_ACTIVE0]), (int)p.numSlots, 1, r->stream));
+    int rcq = enqueueRound(r, pl, p.numSlots, hint);
+    if (rcq != PTX_OK)
+        return rcq;
+    if (canonical)
     {
-        LaunchParams p;
-        Wavefront wf, wfAux;
-        PtxRenderer::BatchRes *res;
-        uint32_t active = 0;
-        int qin = 0;
-        uint64_t iteration = 0;
-        bool shadowPending = false;
-        int shadowSlot = 0;
-        Phase phase = PH_ISSUE;
-        double traceMs = 0, shadeMs = 0, shadowMs = 0, tailMs = 0;
-        uint64_t segments = 0, launches = 0, tracedRays = 0;
-    };
-    Batch B[PtxRenderer::kMaxBatches];
-
-    HIP_TRY(r, hipEventRecord(r->evStart, r->stream)); // lights upload, earlier resets
-    for (int b = 0; b < nb; b++)
-    {
-        const uint32_t f0 = (uint32_t)((uint64_t)frames * b / nb), f1 = (uint32_t)((uint64_t)frames * (b + 1) / nb);
-        Batch &bt = B[b];
-        bt.res = &r->batch[b];
-        bt.p = makeParams(r, uniform, firstFrame + f0, f1 - f0);
-        const size_t off = (size_t)f0 * p.slotsPerFrame;
-        Wavefront &wf = bt.wf;
-        wf.rayO = r->rayO.p + off; wf.rayD = r->rayD.p + off; wf.thr = r->thr.p + off; wf.rad = r->rad.p + off;
-        wf.meta = r->meta.p + off; wf.hit = r->hit.p + off; wf.hitPair = r->hitPair.p + off;
-        wf.shO = r->shO.p + off; wf.shD = r->shD.p + off; wf.shC = r->shC.p + off; wf.slotRad = r->slotRad.p + off;
-        wf.queue[0] = r->queue0.p + off; wf.queue[1] = r->queue1.p + off; wf.shadowQueue = r->shadowQueue.p + off;
-        wf.restartQueue = r->restartQueue.p + off;
-        for (int k = 0; k < 3; k++)
-            wf.diff[k] = textured ? r->diffs.p + (size_t)k * r->diffCapacity + off : nullptr;
-        wf.decal = alpha ? r->decal.p + off : nullptr;
-        wf.decalT = alpha ? r->decalT.p + off : nullptr;
-        wf.counters = bt.res->dCounters;
-        wf.spill = bt.res->spill;
-        bt.wfAux = wf;
-        bt.wfAux.spill = bt.res->spillAux;
-        HIP_TRY(r, hipStreamWaitEvent(bt.res->s, r->evStart, 0));
-        HIP_TRY(r, hipMemsetAsync(bt.res->dCounters, 0, C_COUNT * sizeof(uint32_t), bt.res->s));
-        k_generate<<<gridFor(bt.p.numSlots), kBlock, 0, bt.res->s>>>(bt.p, wf);
-        HIP_TRY(r, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&bt.res->dCounters[C_ACTIVE0]), (int)bt.p.numSlots, 1, bt.res->s));
-        bt.active = bt.p.numSlots;
-        bt.phase = bt.active ? PH_ISSUE : PH_DONE;
+        const dim3 grid(64);
+        if (mode == 2)
+            k_finish_restarts<2><<<grid, kBlock, 0, r->stream>>>(p, sv, sc, wf);
+        else if (mode == 1)
+            k_finish_restarts<1><<<grid, kBlock, 0, r->stream>>>(p, sv, sc, wf);
+        else
+            k_finish_restarts<0><<<grid, kBlock, 0, r->stream>>>(p, sv, sc, wf);
     }
-
-    auto readShadowTime = [&](Batch &bt) {
-        float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, bt.res->evX0[bt.shadowSlot], bt.res->evShadow[bt.shadowSlot]) == hipSuccess)
-            bt.shadowMs += ms;
-    };
-    // one bounce: closest -> (wait previous shadow) -> shade -> counters to the host
-    auto issueBounce = [&](Batch &bt) -> int {
-        PtxRenderer::BatchRes &q = *bt.res;
-        if (++bt.iteration > maxIterations)
-            return fail(r, PTX_ERROR_DEVICE, "ptx_render: %u paths still active after %llu bounce iterations", bt.active,
-                        (unsigned long long)maxIterations);
-        const int qout = bt.qin ^ 1;
-        HIP_TRY(r, hipMemsetAsync(&q.dCounters[qout ? C_ACTIVE1 : C_ACTIVE0], 0, sizeof(uint32_t), q.s));
-        HIP_TRY(r, hipMemsetAsync(&q.dCounters[C_SHADOW], 0, sizeof(uint32_t), q.s));
-        HIP_TRY(r, hipMemsetAsync(&q.dCounters[C_CHUNK], 0, sizeof(uint32_t), q.s));
-        HIP_TRY(r, hipEventRecord(q.evT0, q.s));
-        if (alpha)
-            k_trace_closest<true><<<traceGridFor(bt.active, r->residentClosest[1]), kBlock, 0, q.s>>>(sc, bt.wf, bt.qin, bt.active);
-        else
-            k_trace_closest<false><<<traceGridFor(bt.active, r->residentClosest[0]), kBlock, 0, q.s>>>(sc, bt.wf, bt.qin, bt.active);
-        HIP_TRY(r, hipEventRecord(q.evT1, q.s));
-        if (bt.shadowPending) // k_shade reads rad[slot]: the previous bounce's shadow adds must have landed
-            HIP_TRY(r, hipStreamWaitEvent(q.s, q.evShadow[bt.shadowSlot], 0));
-        if (textured)
-            k_shade<true><<<gridFor((bt.active + kShadeItems - 1) / kShadeItems), kBlock, 0, q.s>>>(bt.p, sv, bt.wf, bt.qin);
-        else
-            k_shade<false><<<gridFor((bt.active + kShadeItems - 1) / kShadeItems), kBlock, 0, q.s>>>(bt.p, sv, bt.wf, bt.qin);
-        HIP_TRY(r, hipEventRecord(q.evT2, q.s));
-        HIP_TRY(r, hipEventRecord(q.evShade, q.s));
-        HIP_TRY(r, hipMemcpyAsync(q.hCounters, q.dCounters, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, q.s));
-        HIP_TRY(r, hipEventRecord(q.evReady, q.s));
-        bt.phase = PH_WAIT_BOUNCE;
-        return PTX_OK;
-    };
-    auto issueDrain = [&](Batch &bt) -> int {
-        PtxRenderer::BatchRes &q = *bt.res;
-        if (bt.shadowPending)
-            HIP_TRY(r, hipStreamWaitEvent(q.s, q.evShadow[bt.shadowSlot], 0));
-        HIP_TRY(r, hipMemcpyAsync(q.hCounters, q.dCounters, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, q.s));
-        HIP_TRY(r, hipEventRecord(q.evReady, q.s));
-        bt.phase = PH_WAIT_DRAIN;
-        return PTX_OK;
-    };
-    auto next = [&](Batch &bt) -> int { // choose what follows a completed bounce / tail / drain
-        PtxRenderer::BatchRes &q = *bt.res;
-        if (!bt.active)
-            return issueDrain(bt);
-        if (bt.iteration >= 1 && bt.active <= tailThreshold)
+    else
+    {
+        // multi-sample launch: every slot comes back through the restart queue once per extra sample (and per NaN / Inf
+        // restart, raygen.rgen:99-112), one round each; a path that never yields a finite sample would go round for ever
+        // (it hangs the GPU in the reference): give up instead
+        const uint64_t maxRounds = (uint64_t)uniform->SampleCount * 64 + 64;
+        for (uint64_t round = 1;; round++)
         {
-            if (++bt.iteration > maxIterations) // a slot that never yields a finite sample comes back through the restart queue for ever
-                return fail(r, PTX_ERROR_DEVICE, "ptx_render: %u paths still active after %llu bounce iterations", bt.active,
-                            (unsigned long long)maxIterations);
-            if (bt.shadowPending) // k_tail continues from rad[slot]
-                HIP_TRY(r, hipStreamWaitEvent(q.s, q.evShadow[bt.shadowSlot], 0));
-            HIP_TRY(r, hipEventRecord(q.evT0, q.s));
-            const dim3 grid(gridFor(bt.active, kBlock, kMaxPersistentThreads / kBlock)); // grid-stride loop; the spill region holds this many threads
-            if (mode == 2)
-                k_tail<2><<<grid, kBlock, 0, q.s>>>(bt.p, sv, sc, bt.wf, bt.qin, bt.active);
-            else if (mode == 1)
-                k_tail<1><<<grid, kBlock, 0, q.s>>>(bt.p, sv, sc, bt.wf, bt.qin, bt.active);
-            else
-                k_tail<0><<<grid, kBlock, 0, q.s>>>(bt.p, sv, sc, bt.wf, bt.qin, bt.active);
-            HIP_TRY(r, hipEventRecord(q.evT1, q.s));
-            HIP_TRY(r, hipMemcpyAsync(q.hCounters, q.dCounters, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, q.s));
-            HIP_TRY(r, hipEventRecord(q.evReady, q.s));
-            bt.phase = PH_WAIT_TAIL;
-            return PTX_OK;
-        }
-        return issueBounce(bt);
-    };
-    auto advance = [&](Batch &bt, int index) -> int {
-        PtxRenderer::BatchRes &q = *bt.res;
-        float ms = 0.0f;
-        switch (bt.phase)
-        {
-        case PH_ISSUE:
-            return issueBounce(bt);
-        case PH_WAIT_BOUNCE: {
-            if (bt.shadowPending) // its event completed before k_shade started
-            {
-                readShadowTime(bt);
-                bt.shadowPending = false;
-            }
-            (void)hipEventElapsedTime(&ms, q.evT0, q.evT1);
-            bt.traceMs += ms;
-            const float closestMs = ms;
-            (void)hipEventElapsedTime(&ms, q.evT1, q.evT2);
-            bt.shadeMs += ms;
-            const int qout = bt.qin ^ 1;
-            const uint32_t shadowCount = q.hCounters[C_SHADOW];
-            if (q.hCounters[C_OVERFLOW])
+            HIP_TRY(r, hipMemcpyAsync(r->hostCounters, r->counters.p, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
+            HIP_TRY(r, hipStreamSynchronize(r->stream));
+            if (r->hostCounters[C_OVERFLOW])
                 return fail(r, PTX_ERROR_DEVICE, "ptx_render: traversal stack overflow (tree deeper than %d levels)", kLdsStack + kGlobalSpill);
-            if (shadowCount)
-            {
-                bt.shadowSlot ^= 1;
-                HIP_TRY(r, hipStreamWaitEvent(q.x, q.evShade, 0));
-                HIP_TRY(r, hipMemsetAsync(&q.dCounters[C_CHUNK_SHADOW], 0, sizeof(uint32_t), q.x));
-                HIP_TRY(r, hipEventRecord(q.evX0[bt.shadowSlot], q.x));
-                if (alpha)
-                    k_trace_shadow<true><<<traceGridFor(shadowCount, r->residentShadow[1]), kBlock, 0, q.x>>>(bt.p, sc, bt.wfAux, qout, shadowCount);
-                else
-                    k_trace_shadow<false><<<traceGridFor(shadowCount, r->residentShadow[0]), kBlock, 0, q.x>>>(bt.p, sc, bt.wfAux, qout, shadowCount);
-                HIP_TRY(r, hipEventRecord(q.evShadow[bt.shadowSlot], q.x));
-                bt.shadowPending = true;
-            }
-#ifdef PT_VISIT_STATS
-            if (verbose)
-            {
-                uint32_t vs[2][68];
-                (void)hipDeviceSynchronize();
-                (void)hipMemcpyFromSymbol(vs, HIP_SYMBOL(ptd::g_visitStats), sizeof(vs));
-                for (int k = 0; k < 2; k++)
-                {
-                    fprintf(stderr, "[ptx]   %s visits: max %u mean %.1f rays %u hist/16:", k ? "shadow(prev)" : "closest", vs[k][0], vs[k][2] ? (double)vs[k][1] / vs[k][2] : 0.0, vs[k][2]);
-                    for (int i = 0; i < 64; i++)
-                        fprintf(stderr, " %u", vs[k][4 + i]);
-                    fprintf(stderr, "\n");
-                }
-                std::memset(vs, 0, sizeof(vs));
-                (void)hipMemcpyToSymbol(HIP_SYMBOL(ptd::g_visitStats), vs, sizeof(vs));
-            }
-#endif
-            if (verbose)
-                fprintf(stderr, "[ptx] batch %d bounce %llu: %u rays closest %.3f ms (%.2f Grays/s) | shade %.3f ms | %u shadow rays\n", index,
-                        (unsigned long long)bt.iteration, bt.active, closestMs, bt.active / closestMs / 1e6, ms, shadowCount);
-            bt.segments += bt.iteration == 1 ? (uint64_t)bt.p.ownedPixels * bt.p.frames : bt.active;
-            bt.tracedRays += bt.iteration == 1 ? (uint64_t)bt.p.ownedPixels * bt.p.frames : bt.active;
-            bt.launches += 2;
-            bt.active = q.hCounters[qout ? C_ACTIVE1 : C_ACTIVE0];
-            bt.qin = qout;
-            return next(bt);
-        }
-        case PH_WAIT_TAIL:
-            (void)hipEventElapsedTime(&ms, q.evT0, q.evT1);
-            bt.tailMs += ms;
-            if (verbose)
-                fprintf(stderr, "[ptx] batch %d tail: %u paths, %u segments, %.3f ms\n", index, bt.active, q.hCounters[C_SEGMENTS], ms);
-            if (q.hCounters[C_OVERFLOW])
-                return fail(r, PTX_ERROR_DEVICE, "ptx_render: traversal stack overflow in k_tail (depth > %d)", kLdsStackMega);
-            bt.segments += q.hCounters[C_SEGMENTS];
-            HIP_TRY(r, hipMemsetAsync(&q.dCounters[C_SEGMENTS], 0, sizeof(uint32_t), q.s));
-            bt.active = 0; // every path of the queue ran to the end of its sample; slots with samples left are in the restart queue
-            return next(bt);
-        case PH_WAIT_DRAIN: {
-            if (bt.shadowPending)
-            {
-                readShadowTime(bt);
-                bt.shadowPending = false;
-            }
-            if (q.hCounters[C_OVERFLOW])
-                return fail(r, PTX_ERROR_DEVICE, "ptx_render: traversal stack overflow");
-            // paths re-queued by the shadow kernel (next sample of a multi-sample launch, NaN restart)
-            const uint32_t restarts = q.hCounters[C_RESTART];
+            const uint32_t restarts = r->hostCounters[C_RESTART];
             if (!restarts)
-            {
-                HIP_TRY(r, hipEventRecord(q.evDone, q.s));
-                bt.phase = PH_DONE;
-                return PTX_OK;
-            }
-            k_restart<<<gridFor(restarts), kBlock, 0, q.s>>>(bt.p, bt.wf, restarts);
-            HIP_TRY(r, hipMemcpyAsync(bt.wf.queue[bt.qin], bt.wf.restartQueue, (size_t)restarts * sizeof(uint32_t), hipMemcpyDeviceToDevice, q.s));
-            HIP_TRY(r, hipMemsetAsync(&q.dCounters[C_RESTART], 0, sizeof(uint32_t), q.s));
-            // k_shade takes its count from the device counter of its input queue
-            HIP_TRY(r, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&q.dCounters[bt.qin ? C_ACTIVE1 : C_ACTIVE0]), (int)restarts, 1, q.s));
-            bt.active = restarts;
-            return next(bt);
+                break;
+            if (round > maxRounds)
+                return fail(r, PTX_ERROR_DEVICE, "ptx_render: %u paths still active after %llu rounds", restarts, (unsigned long long)maxRounds);
+            k_restart<<<gridFor(restarts), kBlock, 0, r->stream>>>(p, wf, restarts); // next primary ray of every re-queued slot
+            HIP_TRY(r, hipMemcpyAsync(wf.queue[0], wf.restartQueue, (size_t)restarts * sizeof(uint32_t), hipMemcpyDeviceToDevice, r->stream));
+            HIP_TRY(r, hipMemsetAsync(&r->counters.p[C_RESTART], 0, sizeof(uint32_t), r->stream));
+            HIP_TRY(r, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&r->counters.p[C_ACTIVE0]), (int)restarts, 1, r->stream));
+            rcq = enqueueRound(r, pl, restarts, nullptr);
+            if (rcq != PTX_OK)
+                return rcq;
         }
-        default:
-            return PTX_OK;
-        }
-    };
-
-    for (;;)
-    {
-        int pending = 0;
-        bool progressed = false;
-        for (int b = 0; b < nb; b++)
-        {
-            Batch &bt = B[b];
-            if (bt.phase == PH_DONE)
-                continue;
-            pending++;
-            if (bt.phase != PH_ISSUE)
-            {
-                const hipError_t q = hipEventQuery(bt.res->evReady);
-                if (q == hipErrorNotReady)
-                    continue;
-                HIP_TRY(r, q);
-            }
-            const int rca = advance(bt, b);
-            if (rca != PTX_OK)
-            {
-                for (int k = 0; k < nb; k++) // leave no work in flight behind an error
-                {
-                    (void)hipStreamSynchronize(r->batch[k].s);
-                    (void)hipStreamSynchronize(r->batch[k].x);
-                }
-                return rca;
-            }
-            progressed = true;
-        }
-        if (!pending)
-            break;
-        if (!progressed)
-            __builtin_ia32_pause();
     }
-    double traceMs = 0.0;
-    uint64_t hits = 0, samples = 0, retries = 0;
-    for (int b = 0; b < nb; b++)
-    {
-        const Batch &bt = B[b];
-        traceMs += bt.traceMs;
-        r->stats.lastShadeMs += bt.shadeMs;
-        r->stats.lastShadowMs += bt.shadowMs;
-        r->stats.lastTailMs += bt.tailMs;
-        r->stats.segments += bt.segments;
-        r->stats.tracedRays += bt.tracedRays;
-        r->stats.traceLaunches += bt.launches;
-        // every counter block was copied to the host by the sub-batch's final drain
-        hits += bt.res->hCounters[C_HITS];
-        samples += bt.res->hCounters[C_SAMPLES];
-        retries += bt.res->hCounters[C_RETRIES];
-        HIP_TRY(r, hipStreamWaitEvent(r->stream, bt.res->evDone, 0)); // k_accumulate follows every sub-batch
-    }
-    k_accumulate<<<gridFor(p.slotsPerFrame), kBlock, 0, r->stream>>>(p, r->slotRad.p, imagePtr(r));
+    k_accumulate<<<gridFor(p.slotsPerFrame), kBlock, 0, r->stream>>>(p, r->slotRad.p, imagePtr(r), nullptr);
+    HIP_TRY(r, hipMemcpyAsync(r->hostCounters, r->counters.p, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(r, hipEventRecord(r->evB, r->stream));
     HIP_TRY(r, hipGetLastError());
-    r->stats.shadowRays = hits;
-    r->stats.pathSamples = samples;
-    r->stats.retries = retries;
-    r->stats.lastTraceMs = traceMs;
+    r->statsPending = true;
+    r->pendingBounces = pl.bounces;
+    r->pendingTailBelow = pl.tailBelow;
+    r->pendingSlots = canonical ? p.numSlots : 0u;
+    r->pendingDeadSlots = p.numSlots - p.ownedPixels * frames;
+    r->pendingVerbose = getenv("PTX_VERBOSE") != nullptr;
     return PTX_OK;
 }
 
@@ -2646,7 +2693,7 @@ int ptx_synchronize(PtxRenderer *r)
     if (!r)
         return PTX_ERROR_INVALID_ARGUMENT;
     HIP_TRY(r, hipStreamSynchronize(r->stream));
-    return PTX_OK;
+    return collectRender(r); // errors of an asynchronous launch surface here
 }
 
 int ptx_readback(PtxRenderer *r, float *rgba, size_t bytes)
@@ -2655,7 +2702,7 @@ int ptx_readback(PtxRenderer *r, float *rgba, size_t bytes)
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_readback: buffer must be width*height*16 bytes");
     HIP_TRY(r, hipMemcpyAsync(rgba, imagePtr(r), bytes, hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(r, hipStreamSynchronize(r->stream));
-    return PTX_OK;
+    return collectRender(r); // an error of the launch that produced the image surfaces with it
 }
 
 // Read-back that overlaps the next launches: a device-to-device snapshot of the image on the render stream (33 MB at
@@ -2827,6 +2874,11 @@ int ptx_get_stats(PtxRenderer *r, PtxStats *stats)
     if (!r || !stats)
         return PTX_ERROR_INVALID_ARGUMENT;
     HIP_TRY(r, hipStreamSynchronize(r->stream));
+    {
+        const int rcc = collectRender(r);
+        if (rcc != PTX_OK)
+            return rcc;
+    }
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, r->evA, r->evB) == hipSuccess)
         r->stats.lastRenderMs = ms;

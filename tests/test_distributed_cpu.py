@@ -92,3 +92,46 @@ def test_two_rank_tile_shard_gather(tmp_path, pkg, orc):
     for f in range(2):
         osc.render(s.uniform(W, H, bounces=4, total_samples=f), s.lights, W, H, accum=ref)
     assert (got.view(np.uint32) == ref.view(np.uint32)).all()
+
+
+# ---------------------------------------------------------------------------------------
+# the real N > 1 path: bench.py under torch.distributed.run, two ranks sharing GPU 0
+# ---------------------------------------------------------------------------------------
+def _run_bench_two_ranks(tmp_path, backend, extra=()):
+    import json
+    import subprocess
+
+    out = tmp_path / f"gathered_{backend}.npy"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--single-device", "--dist-backend", backend,
+           "--steps", "2", "--warmup", "1", "--repeats", "1", "--scene", "chess_like", "--detail", "0.05", "--width", "328", "--height", "200",
+           "--spp", "4", "--depth", "6", "--dump-image", str(out), *extra]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    return p, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_bench_two_ranks_gather_the_single_rank_frame(pkg, tmp_path, backend):
+    """bench.py's own step() -- ptx_pack_shard, all_gather, ptx_unpack_shard, pipelined read-back, two frames in flight --
+    with two ranks on one GPU: rank 0's gathered frame must be the single-rank frame bit for bit, and the JSON line must
+    carry the strong-scaling metric with the weak one beside it."""
+    import json
+
+    p, out = _run_bench_two_ranks(tmp_path, backend)
+    if p.returncode != 0 and backend == "nccl":
+        pytest.skip("RCCL refuses two ranks on one device here: " + p.stderr.strip().splitlines()[-1][:200])
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["weak"]["scaling"] == "weak" and line["value"] > 0
+    got = np.load(out)
+    W, H = 328, 200  # ragged: 328 is not a multiple of the 32-pixel tile
+    scene = pkg.Scene("chess_like", 0.05)
+    r = pkg.Renderer()
+    r.upload(scene)
+    r.resize(W, H)
+    r.render_frames(scene.uniform(W, H, bounces=6), scene.lights, 0, 4)
+    ref = r.readback()
+    r.close()
+    assert (got.view(np.uint32) == ref.view(np.uint32)).all()

@@ -393,6 +393,43 @@ def test_known_answer_rays_match_bruteforce(pkg, orc, name):
         assert (hits[:, k].view(np.uint32) == b[f].view(np.uint32)).all(), f
 
 
+@pytest.mark.parametrize("backend,threshold", [(0, "0"), (0, "100000000"), (0, None), (1, None)])
+def test_nan_inf_samples_restart_like_the_reference(pkg, orc, monkeypatch, backend, threshold):
+    """raygen.rgen:99-112: a sample whose radiance is NaN / Inf is thrown away and ALL samples of the launch restart with the
+    RNG carried on.  A point light of infinite colour makes that happen whenever it is the light picked (1 of 12 + the
+    directional one: probability 1/13 per bounce) and not occluded.  The canonical launch finishes its restarts on the device (k_finish_restarts), the
+    multi-sample launch through the restart queue round by round: both must give the oracle's image and counters."""
+    import torch  # noqa: F401
+
+    if threshold is not None:
+        monkeypatch.setenv("PTX_TAIL_THRESHOLD", threshold)
+    scene = pkg.Scene("default")
+    lights = scene.lights
+    lights.LightCount = 12  # eleven dark ones keep the restart rate low enough for three finite samples in a row
+    for i in range(12):
+        for k in range(3):
+            lights.Lights[i].Color[k] = float("inf") if i == 0 else 0.0
+        lights.Lights[i].Position[0], lights.Lights[i].Position[1], lights.Lights[i].Position[2] = 1.0, -2.0, 0.5
+        lights.Lights[i].AttenuationConstant = 1.0
+    W, H = 96, 54
+    r = pkg.Renderer(backend=backend)
+    r.upload(scene)
+    r.resize(W, H)
+    osc = orc.OracleScene(scene.desc)
+    ref = np.zeros((H, W, 4), np.float32)
+    for f, sc_ in enumerate((1, 1, 3)):
+        u = scene.uniform(W, H, bounces=4, sample_count=sc_, total_samples=f)
+        r.render(u, lights)
+        st = r.stats()
+        _, ost = osc.render(u, lights, W, H, accum=ref)
+        assert ost.retries > 0, "the scene must provoke restarts"
+        assert (st.retries, st.pathSamples, st.segments, st.shadowRays) == (ost.retries, ost.pathSamples, ost.segments, ost.shadowRays)
+    img = r.readback()
+    r.close()
+    assert np.isfinite(img).all()
+    assert (img.view(np.uint32) == ref.view(np.uint32)).all()
+
+
 @pytest.mark.parametrize("backend", [0, 1])
 def test_zero_bounces_is_a_black_frame(pkg, orc, backend):
     # raygen.rgen:62: `for (bounce = 0; bounce < BounceCount; ...)` never runs -> radiance 0, alpha 1, nothing traced
