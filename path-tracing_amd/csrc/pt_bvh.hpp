@@ -1114,6 +1114,9 @@ PT_DEV bool traceRay(const TraceScene &sc, f3 o, f3 d, float tmin, float tmax, S
 #ifndef PT_NODE_STEPS
 #define PT_NODE_STEPS 2 // measured: 1 -> 1040, 2 -> 1064, 3 -> 1055, 4 -> 1034, 6 -> 975, 10 -> 872 Msamples/s
 #endif
+#ifndef PT_UNIFORM_NODE
+#define PT_UNIFORM_NODE 0 // wave-uniform node fetch through the scalar path (see persistentTrace); measured, DESIGN.md section 4
+#endif
 constexpr uint32_t kTraceChunk = PT_TRACE_CHUNK;
 constexpr int kNodeStepsPerRound = PT_NODE_STEPS;
 constexpr int kRefDone = 0x7fffffff;
@@ -1216,7 +1219,19 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
             if (have && ref >= 0 && ref != kRefDone)
             {
                 int r0, r1, r2, r3;
+#if PT_UNIFORM_NODE
+                // Wave-uniform node fetch: when every lane that takes this step is at the SAME node (the 8x8-pixel wave of
+                // primary rays in the upper levels of the tree) the 64 bytes come once through the scalar path
+                // (s_load_dwordx16 into SGPRs) instead of as 64 x 4 dwordx4 through the vector memory pipeline.
+                const int uref = __builtin_amdgcn_readfirstlane(ref);
+                int h;
+                if (__ballot(ref != uref) == 0ull)
+                    h = visitNode(&sc.nodes[uref], o, id, PT_TMIN, ANY_HIT ? best.t : best.t * kCullSlack, r0, r1, r2, r3);
+                else
+                    h = visitNode(&sc.nodes[ref], o, id, PT_TMIN, ANY_HIT ? best.t : best.t * kCullSlack, r0, r1, r2, r3);
+#else
                 const int h = visitNode(&sc.nodes[ref], o, id, PT_TMIN, ANY_HIT ? best.t : best.t * kCullSlack, r0, r1, r2, r3);
+#endif
                 if (h > 3) st.push((uint32_t)r3);
                 if (h > 2) st.push((uint32_t)r2);
                 if (h > 1) st.push((uint32_t)r1);

@@ -99,6 +99,7 @@ struct BounceCtl
 {
     uint32_t bounce;    // 1-based index inside the round
     uint32_t tailBelow; // queues of at most this many paths go to k_tail (never the first bounce of a round)
+    uint32_t sortShade; // k_shade puts its block's queue entries in material-type order first (scenes that mix types)
 };
 PT_DEV bool bounceRuns(const BounceCtl &c, uint32_t count) { return count != 0u && (c.bounce <= 1u || count > c.tailBelow); }
 
@@ -264,6 +265,9 @@ PT_DEV void blockAddCounter(uint32_t *__restrict__ counter, uint32_t v)
 
 #ifndef PT_SHADE_ITEMS
 #define PT_SHADE_ITEMS 4
+#endif
+#ifndef PT_SHADE_SORT
+#define PT_SHADE_SORT 1 // material-sorted shade queue compiled in (see shadeBody); used when the scene mixes material types
 #endif
 constexpr uint32_t kShadeItems = PT_SHADE_ITEMS; // queue entries per thread per block-wide append in k_shade
 constexpr uint32_t kDeadPair = 0xfffffffeu; // hitPair of a slot outside the image (ragged edge tiles)
@@ -448,6 +452,81 @@ PT_DEV void shadeBody(const LaunchParams &p, const SceneView &sv, const Wavefron
     // queues of a 16.6 M-slot launch would keep the counter line busy for 1.4 ms of a 2 ms kernel.
     for (uint32_t base = blockIdx.x * blockDim.x * kShadeItems; base < count; base += gridDim.x * blockDim.x * kShadeItems)
     {
+#if PT_SHADE_SORT
+      // Material-sorted shade queue: the block's kBlock x kShadeItems entries are put in the order
+      //   sky (miss.rmiss) | MetallicRoughness | SpecularGlossiness | Phong | unknown type | dead slot
+      // (ShaderTypes.incl:143-145, the dispatch of material.glsl:144-166) before they are shaded, so that a wave runs one
+      // branch of sampleMaterial / the miss stage instead of all that its 64 entries happen to need.  A stable counting
+      // sort: per wave one ballot per (entry, key) gives the counts, a prefix over (key, wave) the bases, the same ballots
+      // the ranks; the sorted slots go through LDS.  Deterministic: the order inside a key is the queue order.
+      // Measured (1 MI355X, 1080p, 8 spp, one frame in flight): materials_test (three material types + an unknown one side
+      // by side) 1,313 -> 1,536 Msamples/s, k_shade 8.06 -> 6.29 ms; scenes of ONE material type pay for the sort and get
+      // nothing back (temple_like 614 -> 600, chess_like and atrium_like +-0.5 %), hence the switch.
+      __shared__ uint32_t s_sorted[kBlock * kShadeItems];
+      if (ctl.sortShade)
+      {
+        constexpr uint32_t kKeys = 6, kWaves = kBlock / 64;
+        __shared__ uint32_t s_keyCount[kWaves][kKeys], s_keyBase[kWaves][kKeys];
+        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        const uint64_t lower = (1ull << lane) - 1ull;
+        uint32_t mySlot[kShadeItems], myKey[kShadeItems];
+        uint32_t cnt[kKeys];
+        for (uint32_t k = 0; k < kKeys; k++)
+            cnt[k] = 0;
+        for (uint32_t item = 0; item < kShadeItems; item++)
+        {
+            const uint32_t i = base + item * blockDim.x + threadIdx.x;
+            uint32_t sl = 0, key = 5u;
+            if (i < count)
+            {
+                sl = wf.queue[qin][i];
+                const uint32_t pr = wf.hitPair[sl];
+                if (pr == 0xffffffffu)
+                    key = 0u;
+                else if (pr != kDeadPair)
+                {
+                    const uint32_t type = sv.pairs[pr].materialId & 0xffu;
+                    key = type <= PTX_MATERIAL_TYPE_PHONG ? 1u + type : 4u;
+                }
+            }
+            mySlot[item] = sl;
+            myKey[item] = key;
+            for (uint32_t k = 0; k < kKeys; k++)
+                cnt[k] += (uint32_t)__popcll(__ballot(key == k));
+        }
+        if (lane < kKeys)
+        {
+            uint32_t c = 0;
+            for (uint32_t k = 0; k < kKeys; k++) // no dynamic register indexing
+                c = lane == k ? cnt[k] : c;
+            s_keyCount[wave][lane] = c;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+        {
+            uint32_t run = 0;
+            for (uint32_t k = 0; k < kKeys; k++)
+                for (uint32_t w = 0; w < kWaves; w++)
+                {
+                    s_keyBase[w][k] = run;
+                    run += s_keyCount[w][k];
+                }
+        }
+        __syncthreads();
+        uint32_t done[kKeys];
+        for (uint32_t k = 0; k < kKeys; k++)
+            done[k] = s_keyBase[wave][k];
+        for (uint32_t item = 0; item < kShadeItems; item++)
+            for (uint32_t k = 0; k < kKeys; k++)
+            {
+                const uint64_t m = __ballot(myKey[item] == k);
+                if (myKey[item] == k)
+                    s_sorted[done[k] + (uint32_t)__popcll(m & lower)] = mySlot[item];
+                done[k] += (uint32_t)__popcll(m);
+            }
+        __syncthreads();
+      }
+#endif
       uint32_t slots[kShadeItems];
       uint32_t pushBits = 0; // bit 2k: entry k joins the shadow queue, bit 2k+1: the next queue
 #pragma nounroll
@@ -458,7 +537,12 @@ PT_DEV void shadeBody(const LaunchParams &p, const SceneView &sv, const Wavefron
         uint32_t slot = 0, pair = kDeadPair;
         if (i < count)
         {
+#if PT_SHADE_SORT
+            // entries past the block's share of the queue were sorted last, as dead slots
+            slot = ctl.sortShade ? s_sorted[item * blockDim.x + threadIdx.x] : wf.queue[qin][i];
+#else
             slot = wf.queue[qin][i];
+#endif
             pair = wf.hitPair[slot];
         }
         if (pair != kDeadPair)
@@ -1501,6 +1585,7 @@ struct PtxRenderer
         }
     } build;
     bool anyNonOpaque = false;  // some instanced geometry lacks the opaque flag: any-hit stages run
+    bool mixedMaterialTypes = false; // the instanced meshes use more than one material type (ShaderTypes.incl:143-145): k_shade sorts its queue
     bool usePloc = true;        // PLOC topology instead of Karras (PTX_BUILDER=lbvh switches back)
     uint32_t plocRadius = kPlocRadius;
     uint32_t residentClosest[2] = { 0, 0 }, residentShadow[2] = { 0, 0 }; // blocks the chip holds at once, per [ALPHA] variant
@@ -1891,6 +1976,12 @@ int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *s)
     if (tri >= 0x7fffffffull)
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "scene has %llu triangles; limit is 2^31-1", (unsigned long long)tri);
     pairFirst.push_back(static_cast<uint32_t>(tri));
+    {
+        uint32_t typesSeen = 0; // bit per material type, unknown types share bit 3
+        for (const DevPair &pr : pairs)
+            typesSeen |= 1u << ((pr.materialId & 0xffu) <= PTX_MATERIAL_TYPE_PHONG ? (pr.materialId & 0xffu) : 3u);
+        r->mixedMaterialTypes = (typesSeen & (typesSeen - 1u)) != 0u;
+    }
     r->pairCount = static_cast<uint32_t>(pairs.size());
     r->triCount = static_cast<uint32_t>(tri);
     r->dxNormalTextures = s->dxNormalTextures;
@@ -2343,6 +2434,7 @@ struct RenderPlan
     int mode;           // kernelMode()
     uint32_t bounces;   // BounceCount
     uint32_t tailBelow; // queues of at most this many paths are finished by k_tail
+    uint32_t sortShade; // material-sorted shade queue (scenes that mix material types; PTX_SHADE_SORT=0 / 1 overrides)
     Wavefront wf, wfAux;
 };
 
@@ -2377,7 +2469,7 @@ static int enqueueRound(PtxRenderer *r, const RenderPlan &pl, uint32_t upperBoun
     for (uint32_t b = 1; b <= last; b++)
     {
         PtxRenderer::BounceEvents &ev = r->bounceEvents[(b - 1) % r->bounceEvents.size()];
-        const BounceCtl ctl = { b, pl.tailBelow };
+        const BounceCtl ctl = { b, pl.tailBelow, pl.sortShade };
         uint32_t est = upperBound; // exact for the first bounce; later ones shrink
         if (b > 1 && hint && b <= (uint32_t)kMaxTimedBounces)
         {
@@ -2410,7 +2502,7 @@ static int enqueueRound(PtxRenderer *r, const RenderPlan &pl, uint32_t upperBoun
         if (pl.tailBelow && b < pl.bounces) // the queue shade(b) produced; after the last bounce it is empty by construction
         {
             const bool takeAll = b == last; // nothing is enqueued behind this bounce
-            const BounceCtl tctl = { b, takeAll ? 0xffffffffu : pl.tailBelow };
+            const BounceCtl tctl = { b, takeAll ? 0xffffffffu : pl.tailBelow, 0u };
             const uint32_t most = est < pl.tailBelow ? est : pl.tailBelow;
             const dim3 grid(gridFor(most, kBlock, kMaxPersistentThreads / kBlock)); // grid-stride loop; the spill region holds this many threads
             if (pl.mode == 2)
@@ -2597,6 +2689,9 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
         if (rcr != PTX_OK)
             return rcr;
     }
+    pl.sortShade = r->mixedMaterialTypes ? 1u : 0u;
+    if (const char *e = getenv("PTX_SHADE_SORT"))
+        pl.sortShade = atoi(e) ? 1u : 0u;
     pl.tailBelow = 300000; // measured: flat from 100 K to 400 K live paths, worse beyond
     if (const char *e = getenv("PTX_TAIL_THRESHOLD"))
         pl.tailBelow = (uint32_t)strtoul(e, nullptr, 10);

@@ -121,6 +121,18 @@ def test_materials_scene_image_matches_oracle(pkg, orc, backend):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sort", ["0", "1"])
+def test_material_sorted_shade_queue_changes_nothing(pkg, orc, monkeypatch, sort):
+    """k_shade's material-sorted queue (on by default for scenes that mix material types, PTX_SHADE_SORT overrides) only
+    reorders which lane shades which path: image and counters equal the oracle's with and without it, above and below
+    the k_tail threshold (PTX_TAIL_THRESHOLD=0: every bounce goes through k_shade)."""
+    monkeypatch.setenv("PTX_SHADE_SORT", sort)
+    monkeypatch.setenv("PTX_TAIL_THRESHOLD", "0")
+    img, ref = util.render_pair(pkg, orc, "materials_test", 0.4, 200, 120, frames=2, depth=6)
+    assert (img.view(np.uint32) == ref.view(np.uint32)).all()
+
+
+@pytest.mark.gpu
 def test_materials_scene_multi_sample_and_lens(pkg, orc):
     img, ref = util.render_pair(pkg, orc, "materials_test", 0.3, 96, 54, frames=2, depth=5, lens=0.04, sample_count=3)
     assert (img.view(np.uint32) == ref.view(np.uint32)).all()

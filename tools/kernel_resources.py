@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Build libptx_hip.so with -Rpass-analysis=kernel-resource-usage and print one line per kernel: registers, spills,
 scratch, LDS, occupancy.  (The same flags as path_tracing_amd.build(); the library written is the product library.)
-Usage: tools/kernel_resources.py [filter-substring] [-- extra hipcc flags]"""
+Usage: tools/kernel_resources.py [filter-substring] [-o other.so] [-- extra hipcc flags]
+(-o: an experimental build beside the product library, to be loaded through PTX_HIP_LIB)"""
 import os
 import re
 import subprocess
@@ -18,10 +19,15 @@ def main():
     if "--" in args:
         k = args.index("--")
         args, extra = args[:k], args[k + 1:]
+    out = None
+    if "-o" in args:
+        k = args.index("-o")
+        out = args[k + 1]
+        args = args[:k] + args[k + 2:]
     flt = args[0] if args else ""
     pkg = graft.load_package()
     src = os.path.join(pkg.PKG_DIR, "csrc", "pt_kernels.hip")
-    cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + pkg.HIPCC_FLAGS + extra + ["-Rpass-analysis=kernel-resource-usage", "-o", pkg.HIP_LIB, src]
+    cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + pkg.HIPCC_FLAGS + extra + ["-Rpass-analysis=kernel-resource-usage", "-o", out or pkg.HIP_LIB, src]
     p = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
     cur, rows = None, []
     for line in p.stderr.splitlines():
