@@ -285,7 +285,9 @@ typedef struct PtxSceneDesc {
     uint32_t dxNormalTextures; /* HitFlagsDxNormalTextures, ShaderRendererTypes.incl:96-99 */
     const PtxTextureDesc *textures; /* Scene::GetTextures(); may be NULL: indices >= 9 then sample the white placeholder */
     uint32_t textureCount;
-    uint32_t reserved;
+    uint32_t forceFullTextureSize; /* Scene::GetForceFullTextureSize(): TextureUploader::DetermineMaxTextureSizes never halves
+                                    * (TextureUploader.cpp:551-569); recorded for the budget rule -- with 288 GB per GPU the
+                                    * reference's 80 %-of-VRAM / textureCount budget never bites below the 1,024-texture cap */
     const PtxTextureDesc *skybox; /* Scene::GetSkybox(): 1 (2D) or 6 (cube, equal square faces) images, one level each
                                    * (TextureUploader.cpp:203-262); ignored for PTX_SKYBOX_CLEAR_COLOR */
     /* Scene::GetAnimatedVertices() / GetAnimatedIndices(): geometries with IsAnimated index THESE arrays

@@ -18,7 +18,14 @@ typedef struct PthScene PthScene;
 
 /* comma-separated registry: default, roughness_cubes, attenuation_blob, chess_like, ... */
 PTX_API const char *pth_scene_names(void);
-/* detail in (0,1] scales tessellation of the procedural stand-ins; seed 0 = scene default */
+/* detail in (0,1] scales tessellation of the procedural stand-ins; seed 0 = scene default.
+ * Besides the registry names:
+ *   "file:<path>"            one glTF 2.0 / GLB asset through SceneImporter::AddFile (a CombinedSceneLoader with one
+ *                            component, ExampleScenes.cpp:41-66)
+ *   "description:<json>"     a SceneDescription (SceneManager.h:48-57; the aggregates of ExampleScenes.cpp:87-236):
+ *   "description:@<file>"    {"components": [...], "skybox": "x.hdr", "mapping": "orca" | "none",
+ *                            "dxNormalTextures": bool, "forceFullTextureSize": bool}; components and skybox that do not
+ *                            exist are dropped as SceneDescription::ToLoader does, none left = error */
 PTX_API PthScene *pth_scene_create(const char *name, float detail, uint32_t seed);
 PTX_API void pth_scene_destroy(PthScene *s);
 PTX_API const char *pth_last_error(void);

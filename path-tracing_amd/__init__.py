@@ -71,7 +71,7 @@ class SceneDesc(C.Structure):
         ("models", C.c_void_p), ("modelCount", C.c_uint32),
         ("instances", C.c_void_p), ("instanceCount", C.c_uint32),
         ("skyboxKind", C.c_uint32), ("dxNormalTextures", C.c_uint32),
-        ("textures", C.c_void_p), ("textureCount", C.c_uint32), ("reserved", C.c_uint32),
+        ("textures", C.c_void_p), ("textureCount", C.c_uint32), ("forceFullTextureSize", C.c_uint32),
         ("skybox", C.c_void_p),
         ("animatedVertices", C.c_void_p), ("animatedVertexCount", C.c_uint64),
         ("animatedIndices", C.c_void_p), ("animatedIndexCount", C.c_uint64),
@@ -165,8 +165,8 @@ def build(force: bool = False, verbose: bool = True) -> None:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
     host = os.path.join(PKG_DIR, "host")
-    host_src = [os.path.join(host, f) for f in ("Scene.cpp", "Camera.cpp", "ExampleScenes.cpp", "OutputSaver.cpp", "TextureImporter.cpp", "JpegDecoder.cpp", "SceneImporter.cpp", "host_capi.cpp")]
-    host_dep = host_src + [os.path.join(host, f) for f in ("Scene.h", "Camera.h", "ExampleScenes.h", "OutputSaver.h", "TextureImporter.h", "SceneImporter.h", "Json.h", "Math.h")] + [
+    host_src = [os.path.join(host, f) for f in ("Scene.cpp", "Camera.cpp", "ExampleScenes.cpp", "OutputSaver.cpp", "TextureImporter.cpp", "JpegDecoder.cpp", "SceneImporter.cpp", "SceneManager.cpp", "host_capi.cpp")]
+    host_dep = host_src + [os.path.join(host, f) for f in ("Scene.h", "Camera.h", "ExampleScenes.h", "OutputSaver.h", "TextureImporter.h", "SceneImporter.h", "SceneManager.h", "Json.h", "Math.h")] + [
         os.path.join(REPO_DIR, "include", "ptx_host.h"), os.path.join(REPO_DIR, "include", "ptx.h")]
     if force or _newer(HOST_LIB, host_dep):
         cmd = ["g++"] + HOST_FLAGS + ["-o", HOST_LIB] + host_src

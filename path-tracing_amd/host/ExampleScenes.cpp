@@ -11,6 +11,10 @@
 //    and do not exist offline.
 #include "ExampleScenes.h"
 #include "SceneImporter.h"
+#include "SceneManager.h"
+
+#include <fstream>
+#include <sstream>
 
 #include <array>
 #include <cmath>
@@ -1609,8 +1613,29 @@ std::shared_ptr<Scene> CreateScene(const std::string &name, float detail, uint32
 {
     SceneBuilder sb;
     bool useSceneCamera = true;
-    if (name.rfind("file:", 0) == 0) // a glTF 2.0 asset through the importer (SceneManager's file scenes, ExampleScenes.cpp:87-236)
+    if (name.rfind("file:", 0) == 0) // a glTF 2.0 asset through the importer (SceneManager's file scenes, ExampleScenes.cpp:41-66)
         SceneImporter::AddFile(sb, name.substr(5));
+    else if (name.rfind("description:", 0) == 0)
+    {
+        // a SceneDescription (ExampleScenes.cpp:87-236): inline JSON, or "description:@file.json" with paths relative to it
+        std::string text = name.substr(12);
+        std::filesystem::path base;
+        if (!text.empty() && text[0] == '@')
+        {
+            const std::filesystem::path file(text.substr(1));
+            std::ifstream in(file);
+            if (!in)
+                throw error("Scene description not found: " + file.string());
+            std::stringstream ss;
+            ss << in.rdbuf();
+            text = ss.str();
+            base = file.parent_path();
+        }
+        const auto loader = SceneDescription::FromJson(text, base).ToLoader();
+        if (!loader->HasContent())
+            throw error("Entire scene not found"); // AddSceneByDescription, ExampleScenes.cpp:76-85
+        loader->Load(sb);
+    }
     else if (name == "default")
     {
         CreateDefaultScene(sb);

@@ -230,6 +230,7 @@ PtxSceneDesc Scene::GetDesc() const
     d.animatedIndices = m_AnimatedIndices.empty() ? nullptr : m_AnimatedIndices.data();
     d.animatedIndexCount = m_AnimatedIndices.size();
     d.dxNormalTextures = m_HasDxNormalTextures ? 1u : 0u;
+    d.forceFullTextureSize = m_ForceFullTextureSize ? 1u : 0u;
     return d;
 }
 
@@ -286,6 +287,7 @@ void SceneBuilder::Reset()
     m_DirectionalLightInfo = { RootNodeIndex, Vec3(-0.4f, -1.0f, -0.2f) };
     m_CameraInfos.clear();
     m_HasDxNormalTextures = false;
+    m_ForceFullTextureSize = false;
 }
 
 uint32_t SceneBuilder::AddSceneNode(SceneNode &&node)
@@ -438,6 +440,7 @@ std::shared_ptr<Scene> SceneBuilder::CreateSceneShared(const std::string &name)
     scene->m_PhongMaterials = std::move(m_PhongMaterials);
     scene->m_Textures = std::move(m_Textures);
     scene->m_HasDxNormalTextures = m_HasDxNormalTextures;
+    scene->m_ForceFullTextureSize = m_ForceFullTextureSize;
     scene->m_Models = std::move(m_Models);
     scene->m_SceneNodes = std::move(m_SceneNodes);
     scene->m_IsRelativeTransform = std::move(m_IsRelativeTransform);

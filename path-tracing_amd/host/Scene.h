@@ -288,6 +288,7 @@ public:
     [[nodiscard]] std::span<const Model> GetModels() const { return m_Models; }
     [[nodiscard]] std::span<const ModelInstance> GetModelInstances() const { return m_ModelInstances; }
     [[nodiscard]] bool HasDxNormalTextures() const { return m_HasDxNormalTextures; }
+    [[nodiscard]] bool GetForceFullTextureSize() const { return m_ForceFullTextureSize; } // Scene.h: TextureUploader's downscale off
     [[nodiscard]] std::span<const Shaders::PointLight> GetPointLights() const { return m_PointLights; }
     [[nodiscard]] const Shaders::DirectionalLight &GetDirectionalLight() const { return m_DirectionalLight; }
     [[nodiscard]] const SkyboxVariant &GetSkybox() const { return m_Skybox; }
@@ -320,6 +321,7 @@ private:
     std::vector<Shaders::PhongMaterial> m_PhongMaterials;
     std::vector<TextureInfo> m_Textures;
     bool m_HasDxNormalTextures = false;
+    bool m_ForceFullTextureSize = false;
     std::vector<Model> m_Models;
     std::vector<ModelInstance> m_ModelInstances;
     std::vector<SceneNode> m_SceneNodes;
@@ -391,6 +393,7 @@ public:
     void AddCamera(CameraInfo &&camera);
 
     void SetDxNormalTextures() { m_HasDxNormalTextures = true; }
+    void ForceFullTextureSize() { m_ForceFullTextureSize = true; }
     [[nodiscard]] std::shared_ptr<Scene> CreateSceneShared(const std::string &name);
 
 public:
@@ -415,6 +418,7 @@ private:
     std::vector<TextureInfo> m_Textures;
     std::unordered_map<std::string, uint32_t> m_TextureIndices;
     bool m_HasDxNormalTextures = false;
+    bool m_ForceFullTextureSize = false;
 
     std::vector<Model> m_Models;
     std::vector<std::pair<uint32_t, uint32_t>> m_ModelInstanceInfos;

@@ -236,3 +236,127 @@ def test_imported_scene_renders_like_the_oracle(pkg, orc, tmp_path):
     ref, st = orc.OracleScene(scene.desc).render(u, scene.lights, W, H)
     assert r.stats().segments == st.segments and (r.readback().view(np.uint32) == ref.view(np.uint32)).all()
     r.close()
+
+
+# ---------------------------------------------------------------------------------------
+# scene descriptions (SceneManager.h:48-57, ExampleScenes.cpp:87-236): several components, a skybox file, flags
+# ---------------------------------------------------------------------------------------
+def _component(pkg, tmp_path, name, build):
+    w = GltfWriter()
+    build(w)
+    path = tmp_path / name
+    if name.endswith(".glb"):
+        w.write_glb(path)
+    else:
+        w.write_gltf(path, external_bin=False)
+    return path
+
+
+def _description_assets(pkg, tmp_path):
+    """Three components in the style of Intel Sponza (main + two add-ons), one of them with a
+    KHR_materials_pbrSpecularGlossiness material and textures, and an .hdr sky."""
+    rng = np.random.default_rng(3)
+    diffuse = np.zeros((16, 16, 4), np.uint8)
+    diffuse[..., :3] = rng.integers(60, 255, (16, 16, 3))
+    diffuse[..., 3] = 255
+    spec_gloss = np.zeros((8, 8, 4), np.uint8)
+    spec_gloss[..., :3] = 200
+    spec_gloss[..., 3] = np.linspace(40, 250, 8, dtype=np.uint8)[None, :]   # glossiness in alpha (material.glsl:107)
+    nrm = np.zeros((8, 8, 4), np.uint8)
+    nrm[..., 0], nrm[..., 1], nrm[..., 2], nrm[..., 3] = 140, 110, 255, 255
+
+    def main(w):
+        pos, n, uv, idx = quad(5.0)
+        w.node(mesh=w.mesh([w.primitive(pos, idx, n, uv, material=w.material(name="Main Floor", pbrMetallicRoughness={"baseColorFactor": [0.7, 0.7, 0.75, 1], "metallicFactor": 0.0, "roughnessFactor": 0.8}))]))
+        w.doc["extensions"] = {"KHR_lights_punctual": {"lights": [{"type": "directional", "color": [1, 1, 1], "intensity": 2.5}]}}
+        w.node(rotation=[-math.sin(math.pi / 4), 0, 0, math.cos(math.pi / 4)], extensions={"KHR_lights_punctual": {"light": 0}})
+        w.doc["cameras"] = [{"type": "perspective", "perspective": {"yfov": 0.8, "znear": 0.05, "zfar": 200.0, "aspectRatio": 1.5}}]
+        w.node(translation=[0.0, 2.0, 6.0], camera=0)
+
+    def curtains(w):
+        td = w.image_texture(_png_bytes(pkg, tmp_path, diffuse, "d.png"), "view", tmp_path, "d.png")
+        ts = w.image_texture(_png_bytes(pkg, tmp_path, spec_gloss, "s.png"), "view", tmp_path, "s.png")
+        tn = w.image_texture(_png_bytes(pkg, tmp_path, nrm, "n.png"), "view", tmp_path, "n.png")
+        sg = w.material(name="Curtain SG", normalTexture={"index": tn},
+                        extensions={"KHR_materials_pbrSpecularGlossiness": {"diffuseFactor": [0.9, 0.8, 0.7, 1.0], "diffuseTexture": {"index": td},
+                                                                            "specularFactor": [0.8, 0.7, 0.6], "glossinessFactor": 0.9,
+                                                                            "specularGlossinessTexture": {"index": ts}}})
+        cp, cn, ci = cube(0.6)
+        uv = np.float32([[(k % 4) in (1, 2), (k % 4) in (2, 3)] for k in range(len(cp))])
+        w.node(mesh=w.mesh([w.primitive(cp, ci, cn, uv, material=sg)]), translation=[-1.2, 0.6, 0.0])
+
+    def ivy(w):
+        cp, cn, ci = cube(0.4)
+        w.node(mesh=w.mesh([w.primitive(cp, ci, cn, material=w.material(name="Ivy", pbrMetallicRoughness={"baseColorFactor": [0.2, 0.6, 0.25, 1], "metallicFactor": 0.0}))]),
+               translation=[1.3, 0.4, 0.5])
+
+    paths = [_component(pkg, tmp_path, "main.gltf", main), _component(pkg, tmp_path, "curtains.glb", curtains), _component(pkg, tmp_path, "ivy.gltf", ivy)]
+    sky = np.zeros((16, 32, 4), np.float32)
+    sky[..., 0], sky[..., 1], sky[..., 2], sky[..., 3] = 0.3, 0.5, np.linspace(0.2, 1.4, 16, dtype=np.float32)[:, None], 1.0
+    pkg.write_image(tmp_path / "sky.hdr", sky, pkg.OUTPUT_HDR)
+    return paths
+
+
+def _describe(tmp_path, **fields):
+    import json
+
+    (tmp_path / "scene.json").write_text(json.dumps(fields))
+    return "description:@" + str(tmp_path / "scene.json")
+
+
+def test_scene_description_combines_components_sky_and_flags(pkg, orc, tmp_path):
+    paths = _description_assets(pkg, tmp_path)
+    parts = [pkg.Scene("file:" + str(p)).triangle_count for p in paths]
+    name = _describe(tmp_path, components=[p.name for p in paths], skybox="sky.hdr", dxNormalTextures=True, forceFullTextureSize=True)
+    s = pkg.Scene(name)
+    d = s.desc
+    assert s.triangle_count == sum(parts) == 2 + 12 + 12
+    assert d.skyboxKind == 1 and d.dxNormalTextures == 1 and d.forceFullTextureSize == 1   # Skybox2D (equirectangular .hdr)
+    assert d.specularGlossinessMaterialCount == 1 and d.metallicRoughnessMaterialCount >= 2 and d.textureCount == 3
+    sg = np.frombuffer((C.c_uint8 * 96).from_address(d.specularGlossinessMaterials), np.uint32)
+    assert (sg[18:23] == [4, 9, 10, 11, 11]).all()   # emissive default; diffuse, normal; specular and glossiness share the SG texture
+    assert np.allclose(sg.view(np.float32)[4:12], [0.9, 0.8, 0.7, 1.0, 0.8, 0.7, 0.6, 0.9])
+    # one light, one camera came with the main component; a finite render whose misses see the sky file
+    W, H = 96, 64
+    s.set_active_camera(0)
+    img, st = orc.OracleScene(d).render(s.uniform(W, H, bounces=3, sample_count=4), s.lights, W, H)
+    assert np.isfinite(img).all() and st.retries == 0
+    top = img[:6, :, :3].mean(axis=(0, 1)) / 4
+    assert top[2] > 0.1 and abs(top[0] / top[1] - 0.6) < 0.15   # hdrToLdr keeps the hue of the (0.3, 0.5, z) sky
+    # same description without flags: they are off; a missing component is dropped, a missing sky too
+    s2 = pkg.Scene(_describe(tmp_path, components=[paths[0].name, "not_there.gltf", paths[2].name], skybox="no_sky.hdr"))
+    assert s2.triangle_count == parts[0] + parts[2] and s2.desc.skyboxKind == 0 and s2.desc.dxNormalTextures == 0 and s2.desc.forceFullTextureSize == 0
+    with pytest.raises(pkg.PtxError):
+        pkg.Scene(_describe(tmp_path, components=["a.gltf", "b.gltf"]))   # "Entire scene not found"
+    with pytest.raises(pkg.PtxError):
+        pkg.Scene(_describe(tmp_path, components=[paths[0].name], mapping="bogus"))
+    # the ORCA slot remap (ExampleScenes.cpp:113-118): every material becomes MetallicRoughness, roughness and metalness
+    # both read the texture assimp files under "specular" -- for a glTF SG material its specularGlossinessTexture
+    s3 = pkg.Scene(_describe(tmp_path, components=[paths[1].name], mapping="orca"))
+    d3 = s3.desc
+    assert d3.specularGlossinessMaterialCount == 0
+    mr = np.frombuffer((C.c_uint8 * (96 * d3.metallicRoughnessMaterialCount)).from_address(d3.metallicRoughnessMaterials), np.uint32).reshape(-1, 24)
+    curtain = mr[[r[22] >= 9 for r in mr]][0]   # dwords 19..23: emissive, colour, normal, roughness, metallic
+    assert curtain[22] == curtain[23] and curtain[21] >= 9 and curtain[21] != curtain[22]
+
+
+@pytest.mark.gpu
+def test_described_scene_with_specular_glossiness_renders_like_the_oracle(pkg, orc, tmp_path):
+    paths = _description_assets(pkg, tmp_path)
+    scene = pkg.Scene(_describe(tmp_path, components=[p.name for p in paths], skybox="sky.hdr", dxNormalTextures=True, forceFullTextureSize=True))
+    scene.set_active_camera(0)
+    W, H = 192, 128
+    r = pkg.Renderer()
+    r.upload(scene)
+    r.resize(W, H)
+    ref = np.zeros((H, W, 4), np.float32)
+    osc = orc.OracleScene(scene.desc)
+    for f in range(3):
+        u = scene.uniform(W, H, bounces=5, total_samples=f)
+        r.render(u, scene.lights)
+        _, ost = osc.render(u, scene.lights, W, H, accum=ref)
+        st = r.stats()
+        assert (st.segments, st.shadowRays) == (ost.segments, ost.shadowRays)
+    img = r.readback()
+    r.close()
+    assert (img.view(np.uint32) == ref.view(np.uint32)).all()
