@@ -2160,6 +2160,18 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
         BUILD_TRY(B.children.alloc(n)); BUILD_TRY(B.parentOfNode.alloc(n)); BUILD_TRY(B.parentOfLeaf.alloc(n));
     }
 
+    // PLOC temporaries: two cluster sequences, neighbour indices, scan flags (sized for all n; freed when this returns)
+    DevBuf<int> cl0, cl1;
+    DevBuf<float4> lo0, hi0, lo1, hi1;
+    DevBuf<uint32_t> nn;
+    DevBuf<unsigned long long> flags, sums, total;
+    if (!refit && r->usePloc && n > 1)
+    {
+        BUILD_TRY(cl0.alloc(n)); BUILD_TRY(cl1.alloc(n)); BUILD_TRY(lo0.alloc(n)); BUILD_TRY(hi0.alloc(n)); BUILD_TRY(lo1.alloc(n));
+        BUILD_TRY(hi1.alloc(n)); BUILD_TRY(nn.alloc(n)); BUILD_TRY(flags.alloc(n)); BUILD_TRY(sums.alloc((n + kScanBlock - 1) / kScanBlock));
+        BUILD_TRY(total.alloc(1));
+    }
+
     // [0..5] centroid bounds (ordered floats), [6] triangles in the tree (k_count_valid), [7] a refit found a revived triangle
     const uint32_t initBounds[8] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u };
     BUILD_TRY(hipMemcpyAsync(B.sceneBounds.p, initBounds, sizeof(initBounds), hipMemcpyHostToDevice, r->stream));
@@ -2207,14 +2219,7 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
         bool boxesDone = false;
         if (!refit && r->usePloc)
         {
-            // PLOC over the sorted leaves; temporaries: two cluster sequences, neighbour indices, scan flags
-            DevBuf<int> cl0, cl1;
-            DevBuf<float4> lo0, hi0, lo1, hi1;
-            DevBuf<uint32_t> nn;
-            DevBuf<unsigned long long> flags, sums, total;
-            const uint32_t scanBlocks = (nv + kScanBlock - 1) / kScanBlock;
-            BUILD_TRY(cl0.alloc(nv)); BUILD_TRY(cl1.alloc(nv)); BUILD_TRY(lo0.alloc(nv)); BUILD_TRY(hi0.alloc(nv)); BUILD_TRY(lo1.alloc(nv));
-            BUILD_TRY(hi1.alloc(nv)); BUILD_TRY(nn.alloc(nv)); BUILD_TRY(flags.alloc(nv)); BUILD_TRY(sums.alloc(scanBlocks)); BUILD_TRY(total.alloc(1));
+            // PLOC over the sorted leaves (temporaries allocated above, outside the timed span)
             k_ploc_init<<<vblocks, 256, 0, r->stream>>>(nv, vin, B.boxLo.p, B.boxHi.p, cl0.p, lo0.p, hi0.p);
             int *cIn = cl0.p, *cOut = cl1.p;
             float4 *lIn = lo0.p, *hIn = hi0.p, *lOut = lo1.p, *hOut = hi1.p;
@@ -2438,82 +2443,133 @@ struct RenderPlan
     Wavefront wf, wfAux;
 };
 
-// One ROUND of the wavefront: the slots listed in queue 0 (ACTIVE0 set by the caller, at most `upperBound`) start at
-// bounce 0 of a sample and are advanced BounceCount times, or until the queue is short enough for k_tail.  Nothing here
-// waits for the device: every kernel reads its queue length from the counter block (BounceCtl).  `hint` = queue lengths
-// of an earlier launch of the same shape, used only to size grids.
+// One BOUNCE of the wavefront over queue `qin` (length in the counter block, at most `est`), enqueued without waiting
+// for the device: every kernel reads its queue length from the counter block (BounceCtl).
 //
 //   stream     P(b)  closest(b)  [wait aux(b-1)]  shade(b)                      P(b+1) closest(b+1) ...
-//   auxStream                                     [wait shade(b)] shadow(b) tail(b)
+//   auxStream                                     [wait shade(b)] shadow(b) [tail(b)]
 //
 // shadow(b) only adds into rad[slot], which shade(b + 1) reads -- not closest(b + 1) -- so it runs beside the next
-// traversal; k_tail follows it in stream order (the NEE adds it continues from have landed) and the last shadow query
-// before the tail needs no event of its own.
-//
-// With a hint the schedule stops one bounce after the one whose queue k_tail took over last time, and the tail launch
-// behind that last bounce takes whatever is left, however much (results do not depend on who finishes a path): the
-// bounces k_tail made redundant are not enqueued as kernels that look at a counter and return.
-static int enqueueRound(PtxRenderer *r, const RenderPlan &pl, uint32_t upperBound, const uint32_t *hint)
+// traversal; k_tail, where the schedule has one, follows it in stream order (the NEE adds it continues from have
+// landed): the last shadow query before the tail needs no event of its own.
+// tail: 0 = none, 1 = k_tail takes the queue shade(b) filled if it holds at most pl.tailBelow paths, 2 = takes it whatever
+// its length (nothing is enqueued behind this bounce).
+static int enqueueBounce(PtxRenderer *r, const RenderPlan &pl, uint32_t b, int qin, uint32_t est, uint32_t skipBelow, int tail)
 {
     const bool textured = pl.mode >= 1, alpha = pl.mode == 2;
     hipStream_t S = r->stream, X = r->auxStream;
-    uint32_t last = pl.bounces;
-    if (hint && pl.tailBelow)
-        for (uint32_t b = 1; b < pl.bounces && b < (uint32_t)kMaxTimedBounces; b++)
-            if (hint[b + 1] <= pl.tailBelow) // k_tail took the queue of bounce b (or nothing was left of it)
+    PtxRenderer::BounceEvents &ev = r->bounceEvents[(b - 1) % r->bounceEvents.size()];
+    const BounceCtl ctl = { b, skipBelow, pl.sortShade };
+    const int qout = qin ^ 1;
+    k_prologue<<<1, 1, 0, S>>>(pl.wf, qin, ctl);
+    HIP_TRY(r, hipEventRecord(ev.t0, S));
+    if (alpha)
+        k_trace_closest<true><<<traceGridFor(est, r->residentClosest[1]), kBlock, 0, S>>>(pl.sc, pl.wf, qin, ctl);
+    else
+        k_trace_closest<false><<<traceGridFor(est, r->residentClosest[0]), kBlock, 0, S>>>(pl.sc, pl.wf, qin, ctl);
+    HIP_TRY(r, hipEventRecord(ev.t1, S));
+    if (b > 1) // shade reads rad[slot]: the previous bounce's shadow adds must have landed
+        HIP_TRY(r, hipStreamWaitEvent(S, r->bounceEvents[(b - 2) % r->bounceEvents.size()].x2, 0));
+    const uint32_t shadeGrid = gridFor((est + kShadeItems - 1) / kShadeItems);
+    if (textured)
+        k_shade<true><<<shadeGrid, kBlock, 0, S>>>(pl.p, pl.sv, pl.wf, qin, ctl);
+    else
+        k_shade<false><<<shadeGrid, kBlock, 0, S>>>(pl.p, pl.sv, pl.wf, qin, ctl);
+    HIP_TRY(r, hipEventRecord(ev.t2, S));
+    HIP_TRY(r, hipStreamWaitEvent(X, ev.t2, 0));
+    HIP_TRY(r, hipEventRecord(ev.x0, X));
+    if (alpha)
+        k_trace_shadow<true><<<traceGridFor(est, r->residentShadow[1]), kBlock, 0, X>>>(pl.p, pl.sc, pl.wfAux, qout, (int)(b & 1u));
+    else
+        k_trace_shadow<false><<<traceGridFor(est, r->residentShadow[0]), kBlock, 0, X>>>(pl.p, pl.sc, pl.wfAux, qout, (int)(b & 1u));
+    HIP_TRY(r, hipEventRecord(ev.x1, X));
+    if (tail)
+    {
+        const BounceCtl tctl = { b, tail == 2 ? 0xffffffffu : pl.tailBelow, 0u };
+        const uint32_t most = est < pl.tailBelow ? est : pl.tailBelow;
+        const dim3 grid(gridFor(most, kBlock, kMaxPersistentThreads / kBlock)); // grid-stride loop; the spill region holds this many threads
+        if (pl.mode == 2)
+            k_tail<2><<<grid, kBlock, 0, X>>>(pl.p, pl.sv, pl.sc, pl.wfAux, qout, tctl);
+        else if (pl.mode == 1)
+            k_tail<1><<<grid, kBlock, 0, X>>>(pl.p, pl.sv, pl.sc, pl.wfAux, qout, tctl);
+        else
+            k_tail<0><<<grid, kBlock, 0, X>>>(pl.p, pl.sv, pl.sc, pl.wfAux, qout, tctl);
+    }
+    HIP_TRY(r, hipEventRecord(ev.x2, X));
+    return PTX_OK;
+}
+
+// One ROUND: the slots listed in queue 0 (ACTIVE0 set by the caller, at most `upperBound`) start at bounce 0 of a sample
+// and are advanced BounceCount times, or until the queue is short enough for k_tail to finish them in one launch.
+//
+// With a hint (queue lengths of the previous canonical launch of this shape) the whole round is enqueued at once: the
+// bounces that ran as wavefront kernels last time, then k_tail for whatever is left -- results do not depend on who
+// finishes a path, only the time does, and collectRender drops a hint that turned out wrong.  No kernel is launched just
+// to find its queue empty, and the host does not wait for the device.
+// Without one (first launch of a shape, rounds of a multi-sample launch) the round is driven bounce by bounce: the host
+// reads the counter block after every shade kernel and decides -- which is also how the hint is learned.
+static int enqueueRound(PtxRenderer *r, const RenderPlan &pl, uint32_t upperBound, const uint32_t *hint)
+{
+    hipStream_t S = r->stream;
+    uint32_t last = 0;
+    int qin = 0;
+    if (hint)
+    {
+        last = pl.bounces;
+        if (pl.tailBelow)
+            for (uint32_t b = 1; b < pl.bounces && b < (uint32_t)kMaxTimedBounces; b++)
+                if (hint[b + 1] <= pl.tailBelow) // k_tail took the queue of bounce b (or nothing was left of it)
+                {
+                    last = b;
+                    break;
+                }
+        for (uint32_t b = 1; b <= last; b++)
+        {
+            uint32_t est = upperBound; // exact for the first bounce; later ones shrink
+            if (b > 1 && b <= (uint32_t)kMaxTimedBounces)
             {
-                last = b + 1 < pl.bounces ? b + 1 : pl.bounces;
+                const uint64_t e = (uint64_t)hint[b] + hint[b] / 4 + 4096;
+                est = e < upperBound ? (uint32_t)e : upperBound;
+            }
+            const int rcb = enqueueBounce(r, pl, b, qin, est, 0u, (b == last && last < pl.bounces) ? 2 : 0);
+            if (rcb != PTX_OK)
+                return rcb;
+            qin ^= 1;
+        }
+    }
+    else
+    {
+        uint32_t est = upperBound;
+        for (uint32_t b = 1; b <= pl.bounces; b++)
+        {
+            const int rcb = enqueueBounce(r, pl, b, qin, est, 0u, 0);
+            if (rcb != PTX_OK)
+                return rcb;
+            last = b;
+            qin ^= 1;
+            HIP_TRY(r, hipMemcpyAsync(r->hostCounters, r->counters.p, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, S));
+            HIP_TRY(r, hipStreamSynchronize(S));
+            if (r->hostCounters[C_OVERFLOW])
+                return fail(r, PTX_ERROR_DEVICE, "ptx_render: traversal stack overflow (tree deeper than %d levels)", kLdsStack + kGlobalSpill);
+            est = r->hostCounters[qin ? C_ACTIVE1 : C_ACTIVE0];
+            if (est == 0u)
+                break;
+            if (b < pl.bounces && est <= pl.tailBelow)
+            {
+                // the queue is short: k_tail finishes it, behind the shadow kernel of this bounce on its stream
+                PtxRenderer::BounceEvents &ev = r->bounceEvents[(b - 1) % r->bounceEvents.size()];
+                const BounceCtl tctl = { b, 0xffffffffu, 0u };
+                const dim3 grid(gridFor(est, kBlock, kMaxPersistentThreads / kBlock));
+                if (pl.mode == 2)
+                    k_tail<2><<<grid, kBlock, 0, r->auxStream>>>(pl.p, pl.sv, pl.sc, pl.wfAux, qin, tctl);
+                else if (pl.mode == 1)
+                    k_tail<1><<<grid, kBlock, 0, r->auxStream>>>(pl.p, pl.sv, pl.sc, pl.wfAux, qin, tctl);
+                else
+                    k_tail<0><<<grid, kBlock, 0, r->auxStream>>>(pl.p, pl.sv, pl.sc, pl.wfAux, qin, tctl);
+                HIP_TRY(r, hipEventRecord(ev.x2, r->auxStream)); // re-recorded behind the tail: what the stream waits for below
                 break;
             }
-    int qin = 0;
-    for (uint32_t b = 1; b <= last; b++)
-    {
-        PtxRenderer::BounceEvents &ev = r->bounceEvents[(b - 1) % r->bounceEvents.size()];
-        const BounceCtl ctl = { b, pl.tailBelow, pl.sortShade };
-        uint32_t est = upperBound; // exact for the first bounce; later ones shrink
-        if (b > 1 && hint && b <= (uint32_t)kMaxTimedBounces)
-        {
-            const uint64_t e = (uint64_t)hint[b] + hint[b] / 4 + 4096;
-            est = e < upperBound ? (uint32_t)e : upperBound;
         }
-        const int qout = qin ^ 1;
-        k_prologue<<<1, 1, 0, S>>>(pl.wf, qin, ctl);
-        HIP_TRY(r, hipEventRecord(ev.t0, S));
-        if (alpha)
-            k_trace_closest<true><<<traceGridFor(est, r->residentClosest[1]), kBlock, 0, S>>>(pl.sc, pl.wf, qin, ctl);
-        else
-            k_trace_closest<false><<<traceGridFor(est, r->residentClosest[0]), kBlock, 0, S>>>(pl.sc, pl.wf, qin, ctl);
-        HIP_TRY(r, hipEventRecord(ev.t1, S));
-        if (b > 1) // shade reads rad[slot]: the previous bounce's shadow adds (and its tail, if it ran) must have landed
-            HIP_TRY(r, hipStreamWaitEvent(S, r->bounceEvents[(b - 2) % r->bounceEvents.size()].x2, 0));
-        const uint32_t shadeGrid = gridFor((est + kShadeItems - 1) / kShadeItems);
-        if (textured)
-            k_shade<true><<<shadeGrid, kBlock, 0, S>>>(pl.p, pl.sv, pl.wf, qin, ctl);
-        else
-            k_shade<false><<<shadeGrid, kBlock, 0, S>>>(pl.p, pl.sv, pl.wf, qin, ctl);
-        HIP_TRY(r, hipEventRecord(ev.t2, S));
-        HIP_TRY(r, hipStreamWaitEvent(X, ev.t2, 0));
-        HIP_TRY(r, hipEventRecord(ev.x0, X));
-        if (alpha)
-            k_trace_shadow<true><<<traceGridFor(est, r->residentShadow[1]), kBlock, 0, X>>>(pl.p, pl.sc, pl.wfAux, qout, (int)(b & 1u));
-        else
-            k_trace_shadow<false><<<traceGridFor(est, r->residentShadow[0]), kBlock, 0, X>>>(pl.p, pl.sc, pl.wfAux, qout, (int)(b & 1u));
-        HIP_TRY(r, hipEventRecord(ev.x1, X));
-        if (pl.tailBelow && b < pl.bounces) // the queue shade(b) produced; after the last bounce it is empty by construction
-        {
-            const bool takeAll = b == last; // nothing is enqueued behind this bounce
-            const BounceCtl tctl = { b, takeAll ? 0xffffffffu : pl.tailBelow, 0u };
-            const uint32_t most = est < pl.tailBelow ? est : pl.tailBelow;
-            const dim3 grid(gridFor(most, kBlock, kMaxPersistentThreads / kBlock)); // grid-stride loop; the spill region holds this many threads
-            if (pl.mode == 2)
-                k_tail<2><<<grid, kBlock, 0, X>>>(pl.p, pl.sv, pl.sc, pl.wfAux, qout, tctl);
-            else if (pl.mode == 1)
-                k_tail<1><<<grid, kBlock, 0, X>>>(pl.p, pl.sv, pl.sc, pl.wfAux, qout, tctl);
-            else
-                k_tail<0><<<grid, kBlock, 0, X>>>(pl.p, pl.sv, pl.sc, pl.wfAux, qout, tctl);
-        }
-        HIP_TRY(r, hipEventRecord(ev.x2, X));
-        qin = qout;
     }
     if (last)
         HIP_TRY(r, hipStreamWaitEvent(S, r->bounceEvents[(last - 1) % r->bounceEvents.size()].x2, 0));
@@ -2548,7 +2604,7 @@ static int collectRender(PtxRenderer *r)
     {
         const PtxRenderer::BounceEvents &ev = r->bounceEvents[b - 1];
         const uint32_t active = h[C_BOUNCE_ACTIVE + b];
-        const bool ran = active != 0u && (b <= 1u || active > r->pendingTailBelow) && !(tailPaths && b > tailBounce);
+        const bool ran = active != 0u && !(tailPaths && b > tailBounce);
         if (!ran)
             continue;
         float closestMs = 0.0f, shadeMs = 0.0f, shadowMs = 0.0f, tailMs = 0.0f;
