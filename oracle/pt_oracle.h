@@ -14,11 +14,15 @@
  *
  * PARITY PIN: the pure-math functions are pinned to the reference by golden vectors
  * generated from the reference's own GLSL sources (tools/gen_golden.py compiles
- * shading.glsl / bsdf.glsl / common.glsl / ray.glsl / sampling.glsl / tracing.glsl as
- * C++ through a builtin shim; vectors in tests/golden/).  Image-level parity is
- * UNPINNED by the reference: it holds no reference image, its tests assert finiteness
- * only, and it cannot be built here (Vulkan RT + 11 absent submodules) -- see
- * DESIGN.md "Oracle".
+ * shading.glsl / bsdf.glsl / common.glsl / ray.glsl / sampling.glsl / tracing.glsl /
+ * material.glsl:55-171 as C++ through a builtin shim; vectors in tests/golden/).  The
+ * shim's bit-exact mode takes pow / sin / cos from pt_oracle_math.h, so for those three
+ * builtins the pin is structural; golden_libm.json (glibc) checks the kernels
+ * independently.  The stage-level code (raygen, closestHit, miss, any-hit, traversal,
+ * sampler) is restated by reading and checked by the closed forms of
+ * tests/test_analytic.py.  Image-level parity is UNPINNED by the reference -- "parity
+ * unpinned": it holds no reference image, its tests assert finiteness only, and it
+ * cannot be built here (Vulkan RT + 11 absent submodules) -- see DESIGN.md section 2.
  *
  * Arithmetic conventions (GLSL leaves these implementation-defined; both this oracle
  * and the HIP kernels fix them identically so images can be compared bit-for-bit):
