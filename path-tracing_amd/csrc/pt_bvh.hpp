@@ -850,8 +850,9 @@ PT_DEV bool anyHitKeeps(const TraceScene &sc, uint32_t pair, uint32_t prim, uint
         if (decal.dist == -1.0f || t < decal.dist || (t == decal.dist && (pair < decal.pair || (pair == decal.pair && prim < decal.prim))))
         {
             decal.dist = t;
-            decal.color = F3(color.x, color.y, color.z);
-            decal.alpha = color.w;
+            decal.slot = slot;
+            decal.u = u;
+            decal.v = v;
             decal.pair = pair;
             decal.prim = prim;
         }

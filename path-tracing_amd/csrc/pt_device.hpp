@@ -1053,17 +1053,17 @@ struct DevPair
 // anyhit.rahit:54-61 that closestHit.rchit:105-106 can observe.
 struct Decal
 {
-    float dist; // -1 = none (payload.DirectLightPdf)
-    f3 color;   // payload.LightDirection
-    float alpha; // payload.LightDistance
-    uint32_t pair, prim;
+    float dist;          // -1 = none (payload.DirectLightPdf)
+    uint32_t slot;       // which triangle (leaf order) and where on it: its colour (payload.LightDirection) and alpha
+    float u, v;          // (payload.LightDistance) are fetched by the closest-hit stage, and only if the hit lies behind it
+    uint32_t pair, prim; // tie-break of equal distances, and the material of the colour fetch
 };
 PT_DEV Decal noDecal()
 {
     Decal d;
     d.dist = -1.0f;
-    d.color = F3s(0.0f);
-    d.alpha = 0.0f;
+    d.slot = 0u;
+    d.u = d.v = 0.0f;
     d.pair = d.prim = 0xffffffffu;
     return d;
 }
@@ -1406,8 +1406,7 @@ struct HitOut
 // closestHit.rchit:52-161.  (u, v) = hitAttributeEXT barycentrics, t = gl_RayTmaxEXT.
 template <bool TEX>
 PT_DEV void closestHit(const SceneView &sv, f3 rayDirW, float t, float hu, float hv, uint32_t pairIdx, uint32_t slot,
-                       float maxRoughnessIn, uint32_t &rngState, HitOut &out, DiffRays &diff, float decalDist = -1.0f,
-                       f3 decalColor = F3s(0.0f), float decalAlpha = 0.0f)
+                       float maxRoughnessIn, uint32_t &rngState, HitOut &out, DiffRays &diff, const Decal &decal)
 {
     const f3 bary = F3(1.0f - hu - hv, hu, hv);
     const DevPair pr = sv.pairs[pairIdx];
@@ -1456,8 +1455,13 @@ PT_DEV void closestHit(const SceneView &sv, f3 rayDirW, float t, float hu, float
     MaterialSample material = sampleMaterial<TEX>(sv, pr.materialId, texCoords, derivatives, isHitFromInside);
 
     // :105-106 decals: an ignored alpha < 0.5 candidate in front of this hit tints the base colour
-    if (decalDist != -1.0f && t > decalDist)
-        material.Color = mix(material.Color, decalColor, decalAlpha);
+    // (the any-hit stage only remembered WHICH candidate it ignored: its colour is fetched here, when it matters; the
+    // traversal kernel carries six decal words instead of a colour, and its sampler call keeps the alpha only)
+    if (TEX && decal.dist != -1.0f && t > decal.dist) // non-opaque geometry implies the TEX variants (kernelMode)
+    {
+        const f4 dc = hitBaseColor(sv, decal.pair, decal.slot, decal.u, decal.v);
+        material.Color = mix(material.Color, rgb(dc), dc.w);
+    }
 
     out.MaxRoughness = fmax_(material.Roughness, maxRoughnessIn); // :109
     material.Roughness = fmax_(out.MaxRoughness, 0.01f);          // :112

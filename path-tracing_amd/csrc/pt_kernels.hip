@@ -51,8 +51,9 @@ struct Wavefront // device pointers of the per-slot state (SoA)
     float4 *shD;    // shadow direction.xyz, w = 1 if the path ends after this bounce
     float4 *shC;    // NEE contribution throughput * DirectLight / DirectLightPdf
     float4 *slotRad; // final radiance of the slot (consumed by k_accumulate)
-    float4 *decal;   // nearest ignored any-hit candidate: rgb, alpha (payload.LightDirection / LightDistance); null unless the
-    float *decalT;   // scene has non-opaque geometry.  decalT = its distance or -1 (payload.DirectLightPdf)
+    float4 *decal;   // nearest ignored any-hit candidate: (triangle slot, u, v, pair) -- k_shade fetches its colour and alpha
+    float *decalT;   // (payload.LightDirection / LightDistance) if the hit lies behind it; null unless the scene has non-opaque
+                     // geometry.  decalT = its distance or -1 (payload.DirectLightPdf)
     float4 *diff[3]; // payload.RayDifferentials0..2 (rx origin, rx dir, ry origin, ry dir); null unless the scene has textures
     uint32_t *queue[2];
     uint32_t *shadowQueue;
@@ -334,7 +335,7 @@ struct ClosestIO
         {
             wf.decalT[slot] = dc.dist;
             if (dc.dist != -1.0f)
-                wf.decal[slot] = make_float4(dc.color.x, dc.color.y, dc.color.z, dc.alpha);
+                wf.decal[slot] = make_float4(__uint_as_float(dc.slot), dc.u, dc.v, __uint_as_float(dc.pair));
         }
     }
 };
@@ -343,7 +344,8 @@ struct ClosestIO
 // the 64-VGPR budget of 8 waves per SIMD without spilling when asked to (74 -> 63 registers: closest 6.2 -> 4.6 ms per
 // chess_like step); the ALPHA closest variant carries the sampler and the decal and stops at 6 waves.
 #define PT_FULL_OCCUPANCY __attribute__((amdgpu_waves_per_eu(8, 8)))
-#define PT_ALPHA_CLOSEST_ATTR __attribute__((amdgpu_waves_per_eu(6, 6))) // 83 -> 80 registers, 5 -> 6 waves; 7 would spill
+// (round 2: forcing 7 / 8 waves on the ALPHA variants costs 18 / 31 spilled registers and scratch: atrium_like 460 -> 414 / 389 Msamples/s)
+#define PT_ALPHA_CLOSEST_ATTR __attribute__((amdgpu_waves_per_eu(6, 6))) // 83 -> 78 registers, 5 -> 6 waves; 7 would spill
 #define PT_ALPHA_SHADOW_ATTR __attribute__((amdgpu_waves_per_eu(7, 7)))  // 8 waves would spill 11 registers with the two-pass triangle test
 template <bool ALPHA>
 PT_DEV void traceClosestBody(const TraceScene &sc, const Wavefront &wf, int qin, const BounceCtl &ctl)
@@ -571,16 +573,20 @@ PT_DEV void shadeBody(const LaunchParams &p, const SceneView &sv, const Wavefron
                 DiffRays diff;
                 if (TEX)
                     diff = loadDiff(wf, slot);
-                float decalT = -1.0f;
-                float4 decal = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (wf.decalT)
+                Decal decal = noDecal();
+                if (TEX && wf.decalT)
                 {
-                    decalT = wf.decalT[slot];
-                    if (decalT != -1.0f)
-                        decal = wf.decal[slot];
+                    decal.dist = wf.decalT[slot];
+                    if (decal.dist != -1.0f)
+                    {
+                        const float4 dq = wf.decal[slot];
+                        decal.slot = __float_as_uint(dq.x);
+                        decal.u = dq.y;
+                        decal.v = dq.z;
+                        decal.pair = __float_as_uint(dq.w);
+                    }
                 }
-                closestHit<TEX>(sv, F3(d4.x, d4.y, d4.z), hit.x, hit.y, hit.z, pair, __float_as_uint(hit.w), o4.w, meta.x, out, diff, decalT,
-                                F3(decal.x, decal.y, decal.z), decal.w);
+                closestHit<TEX>(sv, F3(d4.x, d4.y, d4.z), hit.x, hit.y, hit.z, pair, __float_as_uint(hit.w), o4.w, meta.x, out, diff, decal);
                 nHits++;
 
                 radiance = radiance + throughput * out.Emissive; // raygen.rgen:77
@@ -852,7 +858,7 @@ PT_DEV f3 runPath(const LaunchParams &p, const SceneView &sv, const TraceScene &
                 break;
             }
             HitOut out;
-            closestHit<TEX>(sv, rd, h.t, h.u, h.v, h.pair, h.slot, maxRoughness, rng, out, diff, decal.dist, decal.color, decal.alpha);
+            closestHit<TEX>(sv, rd, h.t, h.u, h.v, h.pair, h.slot, maxRoughness, rng, out, diff, decal);
             pc.nHit++;
             maxRoughness = out.MaxRoughness;
             radiance = radiance + throughput * out.Emissive;
