@@ -1131,7 +1131,6 @@ __device__ uint32_t g_visitStats[2][68]; // [closest | shadow][max, sum lo, rays
 template <bool ANY_HIT, bool ALPHA, typename IO>
 PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32_t *__restrict__ chunkCounter, Stack &st)
 {
-    Decal decal = noDecal();
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t below = (1ull << lane) - 1ull;
     uint32_t cursor = 0, end = 0; // wave-uniform
@@ -1202,8 +1201,6 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
                         best.t = tmax;
                         best.u = best.v = 0.0f;
                         best.pair = 0xffffffffu;
-                        if (ALPHA)
-                            decal = noDecal();
                         st.sp = 0;
                         ref = (sc.triCount && rayIsTraceable(o, d, PT_TMIN, tmax)) ? 0 : kRefDone;
                     }
@@ -1251,9 +1248,18 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
             const float4 ta = tp->a, tb = tp->b, tc = tp->c;
             float t, u, v;
             ref = st.sp ? (int)st.pop() : kRefDone;
-            if (intersectTri(F3(ta.x, ta.y, ta.z), F3(ta.w, tb.x, tb.y), F3(tb.z, tb.w, tc.x), o, d, PT_TMIN, tmax, t, u, v) &&
-                (!ALPHA || __float_as_uint(tc.w) == 0u ||
-                 anyHitKeeps<ANY_HIT>(sc, __float_as_uint(tc.y), __float_as_uint(tc.z), (uint32_t)~leafRef, t, u, v, decal)))
+            bool candidate = intersectTri(F3(ta.x, ta.y, ta.z), F3(ta.w, tb.x, tb.y), F3(tb.z, tb.w, tc.x), o, d, PT_TMIN, tmax, t, u, v);
+            if (ALPHA && candidate && __float_as_uint(tc.w) != 0u)
+            {
+                // the any-hit stage; the nearest ignored candidate of a closest ray (the decal) is kept by the IO in the slot's
+                // record in memory -- a read-modify-write per ignored candidate, which is rare -- not in six registers of
+                // every lane: 78 -> 72 VGPRs = 7 instead of 6 waves per SIMD.  One behind the hit found so far cannot matter.
+                const float alpha = hitBaseColor(sc.sv, __float_as_uint(tc.y), (uint32_t)~leafRef, u, v).w;
+                candidate = ANY_HIT ? !(alpha < 1.0f) : !(alpha < 0.5f);
+                if (!ANY_HIT && !candidate && t <= best.t)
+                    io.ignored(t, u, v, __float_as_uint(tc.y), __float_as_uint(tc.z), (uint32_t)~leafRef, sc);
+            }
+            if (candidate)
             {
                 const uint32_t pair = __float_as_uint(tc.y), prim = __float_as_uint(tc.z);
                 // the prim id of the best hit is not carried in a register: an exact tie inside one (instance, mesh) pair
@@ -1280,7 +1286,7 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
         {
             if (IO::kNeedsPrim)
                 best.prim = best.pair != 0xffffffffu ? __float_as_uint(sc.tris[best.slot].c.z) : 0xffffffffu;
-            io.store(item, best, best.pair != 0xffffffffu, decal);
+            io.store(item, best, best.pair != 0xffffffffu);
             have = false;
 #ifdef PT_VISIT_STATS
             atomicMax(&g_visitStats[ANY_HIT][0], visits);

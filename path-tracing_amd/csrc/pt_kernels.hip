@@ -325,17 +325,31 @@ struct ClosestIO
         d = F3(d4.x, d4.y, d4.z);
         tmin = 0.00001f; // ray.glsl:79-80: tmin = 1e-5, tmax = 1e4 on every segment
         tmax = 10000.0f;
+        if (wf.decalT)
+            wf.decalT[slot] = -1.0f; // anyhit.rahit state of a fresh ray: nothing ignored yet
         return true;
     }
-    PT_DEV void store(uint32_t, const Hit &h, bool, const Decal &dc)
+    PT_DEV void store(uint32_t, const Hit &h, bool)
     {
         wf.hit[slot] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot)); // w = triangle slot in leaf order
         wf.hitPair[slot] = h.pair;
-        if (wf.decalT)
+    }
+    // anyhit.rahit:54-61: the nearest ignored candidate (ties: smaller (pair, prim)) is the decal.  It lives in the slot's
+    // record -- (triangle slot, u, v, pair) + its distance -- and k_shade fetches its colour if the hit lies behind it.
+    PT_DEV void ignored(float t, float u, float v, uint32_t pair, uint32_t prim, uint32_t triSlot, const TraceScene &sc)
+    {
+        const float cur = wf.decalT[slot];
+        bool nearer = cur == -1.0f || t < cur;
+        if (!nearer && t == cur)
         {
-            wf.decalT[slot] = dc.dist;
-            if (dc.dist != -1.0f)
-                wf.decal[slot] = make_float4(__uint_as_float(dc.slot), dc.u, dc.v, __uint_as_float(dc.pair));
+            const float4 dq = wf.decal[slot];
+            const uint32_t curPair = __float_as_uint(dq.w), curPrim = __float_as_uint(sc.tris[__float_as_uint(dq.x)].c.z);
+            nearer = pair < curPair || (pair == curPair && prim < curPrim);
+        }
+        if (nearer)
+        {
+            wf.decalT[slot] = t;
+            wf.decal[slot] = make_float4(__uint_as_float(triSlot), u, v, __uint_as_float(pair));
         }
     }
 };
@@ -345,7 +359,10 @@ struct ClosestIO
 // chess_like step); the ALPHA closest variant carries the sampler and the decal and stops at 6 waves.
 #define PT_FULL_OCCUPANCY __attribute__((amdgpu_waves_per_eu(8, 8)))
 // (round 2: forcing 7 / 8 waves on the ALPHA variants costs 18 / 31 spilled registers and scratch: atrium_like 460 -> 414 / 389 Msamples/s)
-#define PT_ALPHA_CLOSEST_ATTR __attribute__((amdgpu_waves_per_eu(6, 6))) // 83 -> 78 registers, 5 -> 6 waves; 7 would spill
+#ifndef PT_ALPHA_CLOSEST_WAVES
+#define PT_ALPHA_CLOSEST_WAVES 7 // the decal lives in memory (ClosestIO::ignored): 78 -> 72 registers
+#endif
+#define PT_ALPHA_CLOSEST_ATTR __attribute__((amdgpu_waves_per_eu(PT_ALPHA_CLOSEST_WAVES, PT_ALPHA_CLOSEST_WAVES)))
 #define PT_ALPHA_SHADOW_ATTR __attribute__((amdgpu_waves_per_eu(7, 7)))  // 8 waves would spill 11 registers with the two-pass triangle test
 template <bool ALPHA>
 PT_DEV void traceClosestBody(const TraceScene &sc, const Wavefront &wf, int qin, const BounceCtl &ctl)
@@ -712,7 +729,8 @@ struct ShadowIO
         finished = d4.w;
         return true;
     }
-    PT_DEV void store(uint32_t, const Hit &, bool occluded, const Decal &)
+    PT_DEV void ignored(float, float, float, uint32_t, uint32_t, uint32_t, const TraceScene &) {} // shadow rays keep no decal
+    PT_DEV void store(uint32_t, const Hit &, bool occluded)
     {
         float4 r4 = wf.rad[slot];
         if (!occluded)
@@ -1130,7 +1148,8 @@ struct RaysIO
         tmax = d4.w;
         return true;
     }
-    PT_DEV void store(uint32_t item, const Hit &h, bool hitAny, const Decal &)
+    PT_DEV void ignored(float, float, float, uint32_t, uint32_t, uint32_t, const TraceScene &) {}
+    PT_DEV void store(uint32_t item, const Hit &h, bool hitAny)
     {
         outHit[item] = make_float4(h.t, h.u, h.v, hitAny ? 1.0f : 0.0f);
         outIds[item] = make_uint2(h.pair, h.prim);
