@@ -339,7 +339,7 @@ typedef struct PtxStats {
     uint64_t shadowRays;     /* occlusion queries traced                            */
     uint64_t retries;        /* NaN/Inf sample restarts (raygen.rgen:99-112)        */
     uint64_t triangles;      /* flattened world-space triangles in the LBVH         */
-    uint64_t bvhNodes;       /* internal LBVH nodes                                 */
+    uint64_t bvhNodes;       /* nodes of the 4-wide tree (reachable from the root)  */
     double lastRenderMs;     /* device time of the last ptx_render (HIP events)     */
     double lastTraceMs;      /* ... spent in k_trace_closest (HIP events on the stream) */
     double lastBuildMs;      /* device time of the last ptx_build_accel             */

@@ -17,10 +17,12 @@ GPU is visible.  The CPU oracle lives in /oracle and is test infrastructure only
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import os
 import subprocess
 import sys
+import weakref
 
 import numpy as np
 
@@ -337,6 +339,17 @@ class Scene:
         self.lib.pth_scene_set_camera_pose(self.handle, p, d)
 
 
+_live_renderers: "weakref.WeakSet[Renderer]" = weakref.WeakSet()
+
+
+@atexit.register
+def _close_renderers():
+    # A renderer still alive at interpreter exit would be destroyed by __del__ during module teardown, possibly after
+    # the HIP runtime's own exit handlers have run (seen as "double free or corruption" at exit): destroy them first.
+    for r in list(_live_renderers):
+        r.close()
+
+
 class Renderer:
     """include/ptx.h as an object.  Raises PtxError (with ptx_last_error) on any failure."""
 
@@ -349,6 +362,7 @@ class Renderer:
             self.handle = None
             raise PtxError(f"ptx_create failed with status {rc} (no HIP device? there is no CPU fallback)")
         self.width = self.height = 0
+        _live_renderers.add(self)
 
     def close(self):
         if getattr(self, "handle", None):

@@ -790,6 +790,50 @@ __global__ void k_emit(int n, const uint32_t *__restrict__ vals, const float4 *_
     nodes[i] = nd;
 }
 
+// Breadth-first relayout of the emitted nodes.  k_emit writes a 4-wide node at the index of every BINARY node, but only
+// about half of them is ever referenced from the root (the others sit inside another node's expansion): in that array
+// the live nodes are scattered between dead ones, about one live node per 128-byte line, and a node's children are
+// anywhere.  One launch per level copies the live nodes into a compact array in breadth-first order -- the top of the tree
+// is a dense prefix, the (up to four) children of a node are adjacent, a line holds two live nodes -- and rewrites the child
+// refs.  Nodes [lo, hi) of the new array are placed already (oldOf[i] = index in the emitted array); their internal
+// children take the next free indices, one atomic per wave.  The order of the waves' atomics is not fixed, so the layout
+// below the root can differ between two builds; what a ray hits does not depend on it.
+__global__ void __launch_bounds__(256) k_relayout_level(uint32_t lo, uint32_t hi, const BvhNode *__restrict__ raw, uint32_t *__restrict__ oldOf,
+                                                        uint32_t *__restrict__ nextFree, BvhNode *__restrict__ out)
+{
+    const uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
+    BvhNode nd;
+    nd.refs = make_int4(kEmptyRef, kEmptyRef, kEmptyRef, kEmptyRef);
+    if (i < hi)
+        nd = raw[oldOf[i]];
+    int refs[4] = { nd.refs.x, nd.refs.y, nd.refs.z, nd.refs.w };
+    uint32_t c = 0;
+    for (int k = 0; k < 4; k++)
+        c += (refs[k] >= 0 && refs[k] != kEmptyRef) ? 1u : 0u;
+    uint32_t incl = c; // inclusive prefix over the wave
+    for (uint32_t d = 1; d < 64; d <<= 1)
+    {
+        const uint32_t up = __shfl_up(incl, d);
+        if (lane >= d)
+            incl += up;
+    }
+    const uint32_t total = __shfl(incl, 63);
+    uint32_t base = 0;
+    if (lane == 0 && total)
+        base = atomicAdd(nextFree, total);
+    base = __shfl(base, 0) + incl - c;
+    if (i >= hi)
+        return;
+    for (int k = 0; k < 4; k++)
+        if (refs[k] >= 0 && refs[k] != kEmptyRef)
+        {
+            oldOf[base] = (uint32_t)refs[k];
+            refs[k] = (int)base++;
+        }
+    nd.refs = make_int4(refs[0], refs[1], refs[2], refs[3]);
+    out[i] = nd;
+}
+
 // a one-triangle scene has no internal node: give it a root with one leaf child
 __global__ void k_single_leaf_root(const uint32_t *vals, const float4 *boxLo, const float4 *boxHi, const Tri *triTmp, BvhNode *nodes, Tri *tris,
                                    const DevPair *pairs, const PtxVertex *vertices, const uint32_t *indices, ShadeTri *shadeTris)
@@ -819,6 +863,9 @@ __global__ void k_single_leaf_root(const uint32_t *vals, const float4 *boxLo, co
 // Traversal
 // ---------------------------------------------------------------------------------
 
+#ifndef PT_REFILL_MIN
+#define PT_REFILL_MIN 16 // idle lanes before the refill runs (while any lane has work); measured: 1 -> 1590, 8 -> 1619, 16 -> 1630, 24 -> 1632, 32 -> 1613, 48 -> 1575 Msamples/s (chess_like, one frame in flight)
+#endif
 #ifndef PT_LDS_STACK
 #define PT_LDS_STACK 16 // measured flat from 8 to 24 (889 +- 4 Msamples/s); 16 leaves LDS room
 #endif
@@ -1124,6 +1171,8 @@ constexpr int kRefDone = 0x7fffffff;
 
 #ifdef PT_VISIT_STATS
 __device__ uint32_t g_visitStats[2][68]; // [closest | shadow][max, sum lo, rays, -, histogram of visits / 16]
+// [closest | shadow][rounds, refill phases run, lanes refilled, node steps run, lanes in them, leaf phases run, lanes in them, waves]
+__device__ unsigned long long g_roundStats[2][8];
 #endif
 
 // IO::kFixedTmin >= 0: every ray of the queue has this tmin (the wavefront queues: 1e-5) -> a literal, not a register
@@ -1158,12 +1207,23 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
     st.overflow = false;
 #ifdef PT_VISIT_STATS
     uint32_t visits = 0;
+    uint32_t rs[7] = { 0, 0, 0, 0, 0, 0, 0 }; // wave-uniform
 #endif
 
     for (;;)
     {
         // ---- refill idle lanes from the wave's chunk
-        const uint64_t idleMask = __ballot(!have);
+        uint64_t idleMask = __ballot(!have);
+#if PT_REFILL_MIN > 1
+        // postponed while only a few lanes are idle and the others have work (wave-uniform decision)
+        if ((uint32_t)__popcll(idleMask) < (uint32_t)PT_REFILL_MIN && idleMask != ~0ull && !(cursor == end && exhausted))
+            idleMask = 0ull;
+#endif
+#ifdef PT_VISIT_STATS
+        rs[0]++;
+        if (idleMask)
+            rs[1]++;
+#endif
         if (idleMask)
         {
             if (cursor == end && !exhausted)
@@ -1195,7 +1255,6 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
                     item = cursor + rank;
                     if (io.load(item, o, d, tmin, tmax))
                     {
-
                         have = true;
                         id = fastInverse(d);
                         best.t = tmax;
@@ -1206,6 +1265,9 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
                     }
                 }
                 cursor += take;
+#ifdef PT_VISIT_STATS
+                rs[2] += take;
+#endif
             }
             else if (exhausted && __ballot(have) == 0)
                 break;
@@ -1214,6 +1276,13 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
         // ---- node phase: a few visits per lane; lanes at a leaf (ref < 0) wait for the leaf phase
         for (int step = 0; step < kNodeStepsPerRound; step++)
         {
+#ifdef PT_VISIT_STATS
+            {
+                const uint32_t nl = (uint32_t)__popcll(__ballot(have && ref >= 0 && ref != kRefDone));
+                rs[3] += nl ? 1u : 0u;
+                rs[4] += nl;
+            }
+#endif
             if (have && ref >= 0 && ref != kRefDone)
             {
                 int r0, r1, r2, r3;
@@ -1241,6 +1310,13 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
         }
 
         // ---- leaf phase (single-triangle leaves: ref = ~slot)
+#ifdef PT_VISIT_STATS
+        {
+            const uint32_t ll = (uint32_t)__popcll(__ballot(have && ref < 0));
+            rs[5] += ll ? 1u : 0u;
+            rs[6] += ll;
+        }
+#endif
         if (have && ref < 0)
         {
             const int leafRef = ref;
@@ -1297,6 +1373,14 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
 #endif
         }
     }
+#ifdef PT_VISIT_STATS
+    if (lane == 0)
+    {
+        for (int k = 0; k < 7; k++)
+            atomicAdd(&g_roundStats[ANY_HIT][k], (unsigned long long)rs[k]);
+        atomicAdd(&g_roundStats[ANY_HIT][7], 1ull);
+    }
+#endif
 }
 
 #undef PT_TMIN

@@ -1600,12 +1600,14 @@ struct PtxRenderer
         DevBuf<uint64_t> keys0, keys1;
         DevBuf<int2> children;
         DevBuf<int> parentOfNode, parentOfLeaf;
+        DevBuf<BvhNode> rawNodes; // k_emit's output, one slot per binary node; k_relayout_level compacts it into `nodes`
+        DevBuf<uint32_t> oldOf;   // [0] onwards: emitted index of every node of the compact array; the last entry is the level counter
         bool valid = false;
         void release()
         {
             triTmp.release(); boxLo.release(); boxHi.release(); nodeLo.release(); nodeHi.release(); sceneBounds.release();
             vals0.release(); vals1.release(); hist.release(); histSums.release(); flags.release(); inert.release(); keys0.release(); keys1.release();
-            children.release(); parentOfNode.release(); parentOfLeaf.release();
+            children.release(); parentOfNode.release(); parentOfLeaf.release(); rawNodes.release(); oldOf.release();
             valid = false;
         }
     } build;
@@ -2183,6 +2185,7 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
         BUILD_TRY(B.hist.alloc(histCount)); BUILD_TRY(B.histSums.alloc(histBlocks)); BUILD_TRY(B.flags.alloc(n)); BUILD_TRY(B.inert.alloc(n));
         BUILD_TRY(B.keys0.alloc(n)); BUILD_TRY(B.keys1.alloc(n));
         BUILD_TRY(B.children.alloc(n)); BUILD_TRY(B.parentOfNode.alloc(n)); BUILD_TRY(B.parentOfLeaf.alloc(n));
+        BUILD_TRY(B.rawNodes.alloc(n)); BUILD_TRY(B.oldOf.alloc((size_t)n + 1));
     }
 
     // PLOC temporaries: two cluster sequences, neighbour indices, scan flags (sized for all n; freed when this returns)
@@ -2287,7 +2290,31 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
             k_refit<<<vblocks, 256, 0, r->stream>>>((int)nv, vin, B.boxLo.p, B.boxHi.p, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p,
                                                B.nodeLo.p, B.nodeHi.p, B.flags.p);
         k_emit<<<vblocks, 256, 0, r->stream>>>((int)nv, vin, B.boxLo.p, B.boxHi.p, B.children.p, B.nodeLo.p, B.nodeHi.p, B.triTmp.p,
-                                              r->nodes.p, r->tris.p, r->pairs.p, r->vertices.p, r->indices.p, r->shadeTris.p);
+                                              B.rawNodes.p, r->tris.p, r->pairs.p, r->vertices.p, r->indices.p, r->shadeTris.p);
+        // breadth-first relayout into the compact array (k_relayout_level): the host reads the level's end after each launch
+        uint32_t *nextFree = B.oldOf.p + n;
+        const uint32_t first[1] = { 0u }, one = 1u;
+        BUILD_TRY(hipMemcpyAsync(B.oldOf.p, first, sizeof(first), hipMemcpyHostToDevice, r->stream)); // the root stays node 0
+        BUILD_TRY(hipMemcpyAsync(nextFree, &one, sizeof(one), hipMemcpyHostToDevice, r->stream));
+        uint32_t lo = 0, hi = 1, levels = 0;
+        while (lo < hi)
+        {
+            k_relayout_level<<<(hi - lo + 255) / 256, 256, 0, r->stream>>>(lo, hi, B.rawNodes.p, B.oldOf.p, nextFree, r->nodes.p);
+            uint32_t end = 0;
+            BUILD_TRY(hipMemcpyAsync(&end, nextFree, sizeof(end), hipMemcpyDeviceToHost, r->stream));
+            BUILD_TRY(hipStreamSynchronize(r->stream));
+            if (end < hi || end > nv - 1)
+            {
+                B.release();
+                return fail(r, PTX_ERROR_DEVICE, "ptx_build_accel: relayout placed %u nodes of at most %u", end, nv - 1);
+            }
+            lo = hi;
+            hi = end;
+            levels++;
+        }
+        r->stats.bvhNodes = hi;
+        if (getenv("PTX_VERBOSE"))
+            std::fprintf(stderr, "[ptx] relayout: %u of %u emitted nodes are live, %u levels\n", hi, nv - 1, levels);
     }
     uint32_t revived = 0;
     if (refit)
@@ -3167,5 +3194,26 @@ int ptx_bind_accumulation(PtxRenderer *r, void *devPtr, size_t bytes)
     r->boundImage = static_cast<float4 *>(devPtr);
     return PTX_OK;
 }
+
+#ifdef PT_VISIT_STATS
+// Instrumented builds only (tools/visit_histogram.py): node visits per ray of the queue traversal kernels,
+// out[2][68] = [closest | shadow][max, sum, rays, -, 64 bins of 16 visits]; rounds[2][8] = per kernel the wave-level loop
+// counts (rounds, refill phases run, lanes refilled, node steps run, lanes in them, leaf phases run, lanes in them, waves);
+// reset != 0 clears the counters afterwards.
+__attribute__((visibility("default"))) int ptx_debug_visit_stats(uint32_t *out, unsigned long long *rounds, int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(out, HIP_SYMBOL(ptd::g_visitStats), sizeof(uint32_t) * 2 * 68) != hipSuccess ||
+        hipMemcpyFromSymbol(rounds, HIP_SYMBOL(ptd::g_roundStats), sizeof(unsigned long long) * 2 * 8) != hipSuccess)
+        return PTX_ERROR_DEVICE;
+    if (reset)
+    {
+        static const unsigned long long zero[2 * 68] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ptd::g_visitStats), zero, sizeof(uint32_t) * 2 * 68) != hipSuccess ||
+            hipMemcpyToSymbol(HIP_SYMBOL(ptd::g_roundStats), zero, sizeof(unsigned long long) * 2 * 8) != hipSuccess)
+            return PTX_ERROR_DEVICE;
+    }
+    return PTX_OK;
+}
+#endif
 
 } // extern "C"

@@ -28,7 +28,7 @@ iv = inp.view(np.uint32)
 iv[:, 0] = px; iv[:, 1] = py; iv[:, 2] = W; iv[:, 3] = H
 inp[:, 4:6] = 0.5
 inp[:, 6:22] = np.array(u.ViewInverse, np.float32); inp[:, 22:38] = np.array(u.ProjInverse, np.float32)
-od = orc.test_eval(pkg.FN["constructPrimaryRay"], inp, 6).view(np.float32)
+od = orc.test_eval(pkg.FN["constructPrimaryRay"], inp, 18).view(np.float32)  # the ray and its two offset rays
 rays = np.zeros((n, 8), np.float32)
 rays[:, 0:3] = od[:, 0:3]; rays[:, 3] = 1e-5; rays[:, 4:7] = od[:, 3:6]; rays[:, 7] = 1e4
 
