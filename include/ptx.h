@@ -247,8 +247,10 @@ typedef struct PtxAnimatedVertex {
 typedef struct PtxTextureDesc {
     uint32_t width, height;
     uint32_t format;   /* PtxTextureFormat */
-    uint32_t reserved;
-    const void *data;  /* level 0, row-major, width*height texels */
+    uint32_t levels;   /* TextureInfo::Levels: mip levels in `data` (0 or 1: level 0 only).  A full chain (floor(log2(max(w, h))) + 1
+                        * levels) is uploaded as it is; from any other count only level 0 is used and the chain is generated by
+                        * linear blits (TextureUploader.cpp:440-456).  Skybox images: level 0 only */
+    const void *data;  /* level 0 first, then max(w >> l, 1) x max(h >> l, 1) texels per level, row-major, tightly packed */
 } PtxTextureDesc;
 
 enum {
@@ -286,8 +288,7 @@ typedef struct PtxSceneDesc {
     const PtxTextureDesc *textures; /* Scene::GetTextures(); may be NULL: indices >= 9 then sample the white placeholder */
     uint32_t textureCount;
     uint32_t forceFullTextureSize; /* Scene::GetForceFullTextureSize(): TextureUploader::DetermineMaxTextureSizes never halves
-                                    * (TextureUploader.cpp:551-569); recorded for the budget rule -- with 288 GB per GPU the
-                                    * reference's 80 %-of-VRAM / textureCount budget never bites below the 1,024-texture cap */
+                                    * (TextureUploader.cpp:551-569): every texture keeps its size up to 4096 x 4096 */
     const PtxTextureDesc *skybox; /* Scene::GetSkybox(): 1 (2D) or 6 (cube, equal square faces) images, one level each
                                    * (TextureUploader.cpp:203-262); ignored for PTX_SKYBOX_CLEAR_COLOR */
     /* Scene::GetAnimatedVertices() / GetAnimatedIndices(): geometries with IsAnimated index THESE arrays
@@ -297,6 +298,11 @@ typedef struct PtxSceneDesc {
     uint64_t animatedVertexCount;
     const uint32_t *animatedIndices;
     uint64_t animatedIndexCount;
+    /* Config MaxTextureMemoryBudgetAbsolute / ...VramPercent (Config.h:63-64,162-163; TextureUploader.cpp:29-37): bytes the scene
+     * textures may take together.  Each gets budget / textureCount; a larger one is scaled down by an integer factor on upload
+     * (TextureUploader.cpp:409-415,479-501).  0 = the reference's default, min(80 % of the device memory, 1 GiB);
+     * ~0 = no limit.  Ignored with forceFullTextureSize. */
+    uint64_t textureMemoryBudget;
 } PtxSceneDesc;
 
 /* ------------------------------------------------------------------------- */

@@ -56,6 +56,10 @@ PTX_API int pth_scene_animation_state(PthScene *s, PtxTransform *instanceTransfo
  * BC1 / BC3 / BC5).  info = { width, height, channels in the file, isFloat }.  pixels may be NULL (query only);
  * otherwise bytes must be width * height * (isFloat ? 16 : 4). */
 PTX_API int pth_decode_image(const void *file, size_t fileBytes, uint32_t info[4], void *pixels, size_t bytes);
+/* TextureInfo::Levels of the same file: 1, or the number of mip levels a DDS file carries (0 = not decodable).  With more
+ * than one level pth_decode_image also takes `bytes` = the size of the whole chain (level 0 first, max(w >> l, 1) x
+ * max(h >> l, 1) texels per level, tightly packed) and returns all of it. */
+PTX_API uint32_t pth_decode_image_levels(const void *file, size_t fileBytes);
 
 /* Output stage (row N4): OutputSaver::WriteImage (OutputSaver.cpp:227-257) for one image.  format: 0 Png, 1 Jpg,
  * 2 Tga, 3 Hdr.  data: RGBA8 (Png / Jpg / Tga) or RGBA32F (Hdr), top row first. */

@@ -1539,37 +1539,46 @@ static v4 textureGradSample(const PtoScene *s, const OTexture *t, float u, float
     return sum;
 }
 
-/* mip chain: each level is a linear blit of the previous one (Image.cpp:264-300): decode,
- * bilinear at the destination texel centre with clamp-to-edge, re-encode in the image format */
-static void generateMips(PtoScene *s, OTexture *t)
+/* vkCmdBlitImage with a linear filter (Image.cpp:264-300, TextureUploader.cpp:479-490): level dstLevel of td = level
+ * srcLevel of ts decoded, filtered bilinearly at the destination texel centre with clamp-to-edge, re-encoded in the
+ * image format.  One level of a mip chain is the blit from the level above it (ts == td). */
+static void blitLevel(PtoScene *s, const OTexture *ts, uint32_t srcLevel, const OTexture *td, uint32_t dstLevel)
 {
-    for (uint32_t l = 1; l < t->levels; l++)
-    {
-        const uint32_t sw = levelDim(t->width, l - 1), sh = levelDim(t->height, l - 1);
-        const uint32_t dw = levelDim(t->width, l), dh = levelDim(t->height, l);
-        for (uint32_t j = 0; j < dh; j++)
-            for (uint32_t i = 0; i < dw; i++)
+    const uint32_t sw = levelDim(ts->width, srcLevel), sh = levelDim(ts->height, srcLevel);
+    const uint32_t dw = levelDim(td->width, dstLevel), dh = levelDim(td->height, dstLevel);
+    for (uint32_t j = 0; j < dh; j++)
+        for (uint32_t i = 0; i < dw; i++)
+        {
+            const float x = ((float)i + 0.5f) * ((float)sw / (float)dw) - 0.5f, y = ((float)j + 0.5f) * ((float)sh / (float)dh) - 0.5f;
+            const float x0 = floorf(x), y0 = floorf(y), ax = x - x0, ay = y - y0;
+            const float cx0 = f_clamp(x0, 0.0f, (float)(sw - 1)), cx1 = f_clamp(x0 + 1.0f, 0.0f, (float)(sw - 1));
+            const float cy0 = f_clamp(y0, 0.0f, (float)(sh - 1)), cy1 = f_clamp(y0 + 1.0f, 0.0f, (float)(sh - 1));
+            const v4 top = v4_lerp(fetchTexel(s, ts, srcLevel, (uint32_t)cx0, (uint32_t)cy0), fetchTexel(s, ts, srcLevel, (uint32_t)cx1, (uint32_t)cy0), ax);
+            const v4 bot = v4_lerp(fetchTexel(s, ts, srcLevel, (uint32_t)cx0, (uint32_t)cy1), fetchTexel(s, ts, srcLevel, (uint32_t)cx1, (uint32_t)cy1), ax);
+            const v4 c = v4_lerp(top, bot, ay);
+            const size_t idx = td->levelOffset[dstLevel] + (size_t)j * dw + i;
+            if (td->format == PTX_TEXTURE_RGBA32F)
             {
-                const float x = ((float)i + 0.5f) * ((float)sw / (float)dw) - 0.5f, y = ((float)j + 0.5f) * ((float)sh / (float)dh) - 0.5f;
-                const float x0 = floorf(x), y0 = floorf(y), ax = x - x0, ay = y - y0;
-                const float cx0 = f_clamp(x0, 0.0f, (float)(sw - 1)), cx1 = f_clamp(x0 + 1.0f, 0.0f, (float)(sw - 1));
-                const float cy0 = f_clamp(y0, 0.0f, (float)(sh - 1)), cy1 = f_clamp(y0 + 1.0f, 0.0f, (float)(sh - 1));
-                const v4 top = v4_lerp(fetchTexel(s, t, l - 1, (uint32_t)cx0, (uint32_t)cy0), fetchTexel(s, t, l - 1, (uint32_t)cx1, (uint32_t)cy0), ax);
-                const v4 bot = v4_lerp(fetchTexel(s, t, l - 1, (uint32_t)cx0, (uint32_t)cy1), fetchTexel(s, t, l - 1, (uint32_t)cx1, (uint32_t)cy1), ax);
-                const v4 c = v4_lerp(top, bot, ay);
-                const size_t idx = t->levelOffset[l] + (size_t)j * dw + i;
-                if (t->format == PTX_TEXTURE_RGBA32F)
-                {
-                    s->texelsF[idx * 4] = c.x; s->texelsF[idx * 4 + 1] = c.y; s->texelsF[idx * 4 + 2] = c.z; s->texelsF[idx * 4 + 3] = c.w;
-                }
-                else if (t->format == PTX_TEXTURE_RGBA8_SRGB)
-                    s->texels8[idx] = quantize8(linearToSrgb(c.x)) | quantize8(linearToSrgb(c.y)) << 8 | quantize8(linearToSrgb(c.z)) << 16 | quantize8(c.w) << 24;
-                else
-                    s->texels8[idx] = quantize8(c.x) | quantize8(c.y) << 8 | quantize8(c.z) << 16 | quantize8(c.w) << 24;
+                s->texelsF[idx * 4] = c.x; s->texelsF[idx * 4 + 1] = c.y; s->texelsF[idx * 4 + 2] = c.z; s->texelsF[idx * 4 + 3] = c.w;
             }
-    }
+            else if (td->format == PTX_TEXTURE_RGBA8_SRGB)
+                s->texels8[idx] = quantize8(linearToSrgb(c.x)) | quantize8(linearToSrgb(c.y)) << 8 | quantize8(linearToSrgb(c.z)) << 16 | quantize8(c.w) << 24;
+            else
+                s->texels8[idx] = quantize8(c.x) | quantize8(c.y) << 8 | quantize8(c.z) << 16 | quantize8(c.w) << 24;
+        }
 }
 
+static uint32_t fullLevels(uint32_t w, uint32_t h)
+{
+    uint32_t m = w > h ? w : h, levels = 1;
+    while (m > 1) { m >>= 1; levels++; } /* floor(log2(max)) + 1, Image.cpp:14-17 */
+    return levels > 16 ? 16 : levels;
+}
+
+/* TextureUploader::UploadTexturesBlocking / UploadTexture (TextureUploader.cpp:400-511) and DetermineMaxTextureSizes
+ * (:551-569): the per-texture share of the budget gives a maximal square extent per format; a larger texture is scaled
+ * down by an integer factor -- from the file's own chain when it has one, else by linear blits that halve it --; a
+ * texture that fits keeps a complete file chain and gets a generated one otherwise. */
 static void uploadTextures(PtoScene *s, const PtxSceneDesc *desc)
 {
     for (int c = 0; c < 256; c++)
@@ -1581,20 +1590,72 @@ static void uploadTextures(PtoScene *s, const PtxSceneDesc *desc)
     const uint32_t total = s->textureCount + skyCount;
     if (!total)
         return;
+    uint32_t maxExtent[3] = { 4096u, 4096u, 4096u }; /* TextureUploader.h:74 */
+    if (!desc->forceFullTextureSize && s->textureCount && desc->textureMemoryBudget != ~0ull)
+    {
+        /* Config.h:63-64: 1 GiB absolute; the 80 %-of-device-memory term (Config.h:163) is the larger one on any device this
+         * runs beside, and the host has no device memory to ask about */
+        const uint64_t budget = desc->textureMemoryBudget ? desc->textureMemoryBudget : (1024ull << 20);
+        const uint64_t perTexture = budget / s->textureCount;
+        for (uint32_t f = 0; f <= PTX_TEXTURE_RGBA32F; f++)
+            while (maxExtent[f] > 1u)
+            {
+                uint64_t texels = 0;
+                for (uint32_t e = maxExtent[f]; e; e >>= 1)
+                    texels += (uint64_t)e * e;
+                if (texels * (f == PTX_TEXTURE_RGBA32F ? 16u : 4u) <= perTexture)
+                    break;
+                maxExtent[f] >>= 1;
+            }
+    }
     s->textures = (OTexture *)calloc(total, sizeof(OTexture));
-    size_t n8 = 0, nf = 0;
+    uint32_t *srcW = (uint32_t *)calloc(total, 4), *srcH = (uint32_t *)calloc(total, 4), *firstFile = (uint32_t *)calloc(total, 4);
+    uint32_t *halvings = (uint32_t *)calloc(total, 4);
+    uint8_t *useFile = (uint8_t *)calloc(total, 1), *scaled = (uint8_t *)calloc(total, 1);
+    size_t n8 = 0, nf = 0, scratch8 = 0, scratchF = 0;
     for (uint32_t i = 0; i < total; i++)
     {
         const PtxTextureDesc *d = i < s->textureCount ? &desc->textures[i] : &desc->skybox[i - s->textureCount];
         OTexture *t = &s->textures[i];
-        t->width = d->width ? d->width : 1;
-        t->height = d->height ? d->height : 1;
+        srcW[i] = d->width ? d->width : 1;
+        srcH[i] = d->height ? d->height : 1;
+        t->width = srcW[i];
+        t->height = srcH[i];
         t->format = d->format;
-        uint32_t m = t->width > t->height ? t->width : t->height, levels = 1;
-        while (m > 1) { m >>= 1; levels++; } /* floor(log2(max)) + 1, Image.cpp:14-17 */
-        if (i >= s->textureCount)
-            levels = 1;
-        t->levels = levels > 16 ? 16 : levels;
+        t->levels = 1;
+        if (i < s->textureCount)
+        {
+            const uint32_t fileLevels = d->levels ? d->levels : 1u;
+            const uint32_t mx = maxExtent[d->format];
+            const uint32_t sx = (srcW[i] + mx - 1) / mx, sy = (srcH[i] + mx - 1) / mx, scale = sx > sy ? sx : sy; /* :409-415 */
+            t->width = srcW[i] / scale ? srcW[i] / scale : 1;
+            t->height = srcH[i] / scale ? srcH[i] / scale : 1;
+            t->levels = fullLevels(t->width, t->height);
+            if (scale == 1)
+                useFile[i] = fileLevels == t->levels && t->levels > 1; /* :440 */
+            else
+            {
+                const uint32_t skip = fileLevels > t->levels ? fileLevels - t->levels : 0u; /* :492-501 */
+                if (skip && levelDim(srcW[i], skip) == t->width && levelDim(srcH[i], skip) == t->height)
+                {
+                    useFile[i] = 1;
+                    firstFile[i] = skip;
+                }
+                else
+                {
+                    scaled[i] = 1;
+                    while (levelDim(srcW[i], halvings[i] + 1) >= t->width && levelDim(srcH[i], halvings[i] + 1) >= t->height &&
+                           (levelDim(srcW[i], halvings[i]) > t->width || levelDim(srcH[i], halvings[i]) > t->height))
+                        halvings[i]++;
+                    size_t need = 0;
+                    for (uint32_t l = 0; l <= halvings[i]; l++)
+                        need += (size_t)levelDim(srcW[i], l) * levelDim(srcH[i], l);
+                    size_t *sc = d->format == PTX_TEXTURE_RGBA32F ? &scratchF : &scratch8;
+                    if (need > *sc)
+                        *sc = need;
+                }
+            }
+        }
         size_t *cursor = t->format == PTX_TEXTURE_RGBA32F ? &nf : &n8;
         for (uint32_t l = 0; l < t->levels; l++)
         {
@@ -1602,22 +1663,56 @@ static void uploadTextures(PtoScene *s, const PtxSceneDesc *desc)
             *cursor += (size_t)levelDim(t->width, l) * levelDim(t->height, l);
         }
     }
-    s->texels8 = (uint32_t *)calloc(n8 ? n8 : 1, 4);
-    s->texelsF = (float *)calloc(nf ? nf : 1, 16);
+    s->texels8 = (uint32_t *)calloc(n8 + scratch8 ? n8 + scratch8 : 1, 4);
+    s->texelsF = (float *)calloc(nf + scratchF ? nf + scratchF : 1, 16);
     for (uint32_t i = 0; i < total; i++)
     {
         const PtxTextureDesc *d = i < s->textureCount ? &desc->textures[i] : &desc->skybox[i - s->textureCount];
         OTexture *t = &s->textures[i];
-        const size_t n0 = (size_t)t->width * t->height;
-        if (d->data)
+        const int isFloat = t->format == PTX_TEXTURE_RGBA32F;
+        const size_t texel = isFloat ? 16 : 4;
+        uint8_t *pool = isFloat ? (uint8_t *)s->texelsF : (uint8_t *)s->texels8;
+        if (d->data && useFile[i])
         {
-            if (t->format == PTX_TEXTURE_RGBA32F)
-                memcpy(&s->texelsF[t->levelOffset[0] * 4], d->data, n0 * 16);
-            else
-                memcpy(&s->texels8[t->levelOffset[0]], d->data, n0 * 4);
+            const uint8_t *p = (const uint8_t *)d->data;
+            for (uint32_t l = 0; l < firstFile[i]; l++)
+                p += (size_t)levelDim(srcW[i], l) * levelDim(srcH[i], l) * texel;
+            for (uint32_t l = 0; l < t->levels; l++)
+            {
+                const size_t nl = (size_t)levelDim(t->width, l) * levelDim(t->height, l);
+                memcpy(pool + t->levelOffset[l] * texel, p, nl * texel);
+                p += nl * texel;
+            }
+            continue;
         }
-        generateMips(s, t);
+        if (d->data && scaled[i])
+        {
+            OTexture tmp; /* the scratch chain behind the textures of the pool */
+            memset(&tmp, 0, sizeof(tmp));
+            tmp.width = srcW[i];
+            tmp.height = srcH[i];
+            tmp.format = t->format;
+            tmp.levels = halvings[i] + 1;
+            size_t cursor = isFloat ? nf : n8;
+            for (uint32_t l = 0; l < tmp.levels; l++)
+            {
+                tmp.levelOffset[l] = cursor;
+                cursor += (size_t)levelDim(tmp.width, l) * levelDim(tmp.height, l);
+            }
+            memcpy(pool + tmp.levelOffset[0] * texel, d->data, (size_t)srcW[i] * srcH[i] * texel);
+            for (uint32_t l = 1; l <= halvings[i]; l++)
+                blitLevel(s, &tmp, l - 1, &tmp, l);
+            if (levelDim(srcW[i], halvings[i]) == t->width && levelDim(srcH[i], halvings[i]) == t->height)
+                memcpy(pool + t->levelOffset[0] * texel, pool + tmp.levelOffset[halvings[i]] * texel, (size_t)t->width * t->height * texel);
+            else
+                blitLevel(s, &tmp, halvings[i], t, 0);
+        }
+        else if (d->data)
+            memcpy(pool + t->levelOffset[0] * texel, d->data, (size_t)t->width * t->height * texel);
+        for (uint32_t l = 1; l < t->levels; l++)
+            blitLevel(s, t, l - 1, t, l);
     }
+    free(srcW); free(srcH); free(firstFile); free(halvings); free(useFile); free(scaled);
 }
 
 int pto_test_texture(const PtoScene *s, const float *in, float *out, uint32_t n, int implicitLod)

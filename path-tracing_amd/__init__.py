@@ -50,7 +50,7 @@ PTX_SYMBOLS = [
 PTH_SYMBOLS = [
     "pth_scene_names", "pth_scene_create", "pth_scene_destroy", "pth_last_error", "pth_scene_desc",
     "pth_scene_lights", "pth_scene_triangle_count", "pth_scene_raygen_uniform", "pth_scene_set_active_camera",
-    "pth_scene_set_camera_pose", "pth_scene_update", "pth_scene_bone_count", "pth_scene_animation_state", "pth_decode_image", "pth_write_image", "pth_save_checkpoint", "pth_load_checkpoint",
+    "pth_scene_set_camera_pose", "pth_scene_update", "pth_scene_bone_count", "pth_scene_animation_state", "pth_decode_image", "pth_decode_image_levels", "pth_write_image", "pth_save_checkpoint", "pth_load_checkpoint",
 ]
 
 BACKEND_WAVEFRONT = 0
@@ -77,6 +77,7 @@ class SceneDesc(C.Structure):
         ("skybox", C.c_void_p),
         ("animatedVertices", C.c_void_p), ("animatedVertexCount", C.c_uint64),
         ("animatedIndices", C.c_void_p), ("animatedIndexCount", C.c_uint64),
+        ("textureMemoryBudget", C.c_uint64),
     ]
 
 
@@ -208,6 +209,8 @@ def load_host() -> C.CDLL:
         lib.pth_scene_bone_count.restype = C.c_uint32
         lib.pth_scene_animation_state.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
         lib.pth_decode_image.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.c_void_p, C.c_size_t]
+        lib.pth_decode_image_levels.argtypes = [C.c_char_p, C.c_size_t]
+        lib.pth_decode_image_levels.restype = C.c_uint32
         lib.pth_write_image.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t]
         lib.pth_save_checkpoint.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         lib.pth_load_checkpoint.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_size_t]
@@ -493,6 +496,24 @@ def decode_image(data: bytes):
     if lib.pth_decode_image(data, len(data), info, img.ctypes.data, img.nbytes):
         raise PtxError(lib.pth_last_error().decode())
     return img, int(info[2])
+
+
+def decode_image_levels(data: bytes):
+    """The file's whole mip chain (DDS): list of H_l x W_l x 4 arrays, level 0 first."""
+    lib = load_host()
+    info = (C.c_uint32 * 4)()
+    levels = lib.pth_decode_image_levels(data, len(data))
+    if not levels or lib.pth_decode_image(data, len(data), info, None, 0):
+        raise PtxError(lib.pth_last_error().decode())
+    dims = [(max(info[1] >> l, 1), max(info[0] >> l, 1)) for l in range(levels)]
+    flat = np.empty(sum(h * w for h, w in dims) * 4, np.float32 if info[3] else np.uint8)
+    if lib.pth_decode_image(data, len(data), info, flat.ctypes.data, flat.nbytes):
+        raise PtxError(lib.pth_last_error().decode())
+    out, at = [], 0
+    for h, w in dims:
+        out.append(flat[at:at + h * w * 4].reshape(h, w, 4))
+        at += h * w * 4
+    return out
 
 
 def write_image(path: str, img: np.ndarray, fmt: int = OUTPUT_PNG):

@@ -1208,13 +1208,14 @@ __global__ void k_build_srgb_lut(float *lut)
         lut[c] = srgbToLinear((float)c / 255.0f);
 }
 
-// one level of the chain = linear blit of the previous one (Image.cpp:264-300): decode, bilinear at
-// the destination texel centre with clamp-to-edge, re-encode in the image format
-__global__ void k_generate_mip(TextureView tv, uint32_t textureIndex, uint32_t level, uint32_t *texels8, float4 *texelsF)
+// vkCmdBlitImage with a linear filter (Image.cpp:264-300, TextureUploader.cpp:479-490): every texel of level `dstLevel` of
+// texture `dst` = the source level decoded and filtered bilinearly at the destination texel centre with clamp-to-edge,
+// re-encoded in the image format.  One level of a mip chain is the blit from the level above it (src == dst).
+__global__ void k_blit_level(TextureView tv, uint32_t src, uint32_t srcLevel, uint32_t dst, uint32_t dstLevel, uint32_t *texels8, float4 *texelsF)
 {
-    const DevTexture t = tv.textures[textureIndex];
-    const uint32_t sw = levelDim(t.width, level - 1), sh = levelDim(t.height, level - 1);
-    const uint32_t dw = levelDim(t.width, level), dh = levelDim(t.height, level);
+    const DevTexture ts = tv.textures[src], td = tv.textures[dst];
+    const uint32_t sw = levelDim(ts.width, srcLevel), sh = levelDim(ts.height, srcLevel);
+    const uint32_t dw = levelDim(td.width, dstLevel), dh = levelDim(td.height, dstLevel);
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= dw * dh)
         return;
@@ -1223,13 +1224,13 @@ __global__ void k_generate_mip(TextureView tv, uint32_t textureIndex, uint32_t l
     const float x0 = __builtin_floorf(x), y0 = __builtin_floorf(y), ax = x - x0, ay = y - y0;
     const float cx0 = clamp_(x0, 0.0f, (float)(sw - 1)), cx1 = clamp_(x0 + 1.0f, 0.0f, (float)(sw - 1));
     const float cy0 = clamp_(y0, 0.0f, (float)(sh - 1)), cy1 = clamp_(y0 + 1.0f, 0.0f, (float)(sh - 1));
-    const f4 top = lerp4(fetchTexel(tv, t, level - 1, (uint32_t)cx0, (uint32_t)cy0), fetchTexel(tv, t, level - 1, (uint32_t)cx1, (uint32_t)cy0), ax);
-    const f4 bot = lerp4(fetchTexel(tv, t, level - 1, (uint32_t)cx0, (uint32_t)cy1), fetchTexel(tv, t, level - 1, (uint32_t)cx1, (uint32_t)cy1), ax);
+    const f4 top = lerp4(fetchTexel(tv, ts, srcLevel, (uint32_t)cx0, (uint32_t)cy0), fetchTexel(tv, ts, srcLevel, (uint32_t)cx1, (uint32_t)cy0), ax);
+    const f4 bot = lerp4(fetchTexel(tv, ts, srcLevel, (uint32_t)cx0, (uint32_t)cy1), fetchTexel(tv, ts, srcLevel, (uint32_t)cx1, (uint32_t)cy1), ax);
     const f4 c = lerp4(top, bot, ay);
-    const size_t idx = (size_t)t.levelOffset[level] + (size_t)j * dw + i;
-    if (t.format == PTX_TEXTURE_RGBA32F)
+    const size_t idx = (size_t)td.levelOffset[dstLevel] + (size_t)j * dw + i;
+    if (td.format == PTX_TEXTURE_RGBA32F)
         texelsF[idx] = make_float4(c.x, c.y, c.z, c.w);
-    else if (t.format == PTX_TEXTURE_RGBA8_SRGB)
+    else if (td.format == PTX_TEXTURE_RGBA8_SRGB)
         texels8[idx] = quantize8(linearToSrgb(c.x)) | quantize8(linearToSrgb(c.y)) << 8 | quantize8(linearToSrgb(c.z)) << 16 | quantize8(c.w) << 24;
     else
         texels8[idx] = quantize8(c.x) | quantize8(c.y) << 8 | quantize8(c.z) << 16 | quantize8(c.w) << 24;
@@ -2065,35 +2066,138 @@ int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *s)
             for (uint32_t f = 0; f < 6; f++)
                 if (s->skybox[f].width != s->skybox[0].width || s->skybox[f].height != s->skybox[0].width || s->skybox[f].format != s->skybox[0].format)
                     return fail(r, PTX_ERROR_INVALID_ARGUMENT, "cube skybox: the six faces must be equal squares of one format");
+        // TextureUploader::DetermineMaxTextureSizes (TextureUploader.cpp:551-569): the largest square extent whose full chain
+        // fits the per-texture share of the budget (Config.h:63-64,162-163: min(80 % of the device memory, 1 GiB)), per format;
+        // forceFullTextureSize keeps MaxTextureDataSize = 4096 (TextureUploader.h:74).  Block-compressed files arrive decoded
+        // to RGBA8 and are budgeted as that.
+        uint32_t maxExtent[3] = { 4096u, 4096u, 4096u };
+        if (!s->forceFullTextureSize && r->textureCount && s->textureMemoryBudget != ~0ull)
+        {
+            uint64_t budget = s->textureMemoryBudget;
+            if (!budget)
+            {
+                size_t freeB = 0, totalB = 0;
+                HIP_TRY(r, hipMemGetInfo(&freeB, &totalB));
+                budget = (uint64_t)totalB / 100u * 80u;
+                if (budget > (1024ull << 20))
+                    budget = 1024ull << 20;
+            }
+            const uint64_t perTexture = budget / r->textureCount;
+            for (uint32_t f = 0; f <= PTX_TEXTURE_RGBA32F; f++)
+                while (maxExtent[f] > 1u)
+                {
+                    uint64_t texels = 0;
+                    for (uint32_t e = maxExtent[f]; e; e >>= 1)
+                        texels += (uint64_t)e * e;
+                    if (texels * (f == PTX_TEXTURE_RGBA32F ? 16u : 4u) <= perTexture)
+                        break;
+                    maxExtent[f] >>= 1;
+                }
+        }
+        auto fullLevels = [](uint32_t w, uint32_t h) {
+            uint32_t m = w > h ? w : h, levels = 1;
+            while (m > 1) { m >>= 1; levels++; } // floor(log2(max)) + 1, Image.cpp:14-17
+            return levels > 16u ? 16u : levels;
+        };
+        auto dim = [](uint32_t v, uint32_t l) { return v >> l ? v >> l : 1u; };
+        // per texture: what lands in the table, and how its level 0 is produced
+        struct Placement
+        {
+            uint32_t srcW, srcH;  // the file's level 0
+            uint32_t fileLevels;  // levels in the caller's data
+            uint32_t firstFile;   // file level that becomes level 0 when the file's own chain is used
+            bool useFileChain;    // every level comes from the file (TextureUploader.cpp:440,492-501)
+            uint32_t halvings;    // blits from the file's level 0 down towards the budgeted extent (:479-490)
+            int temp;             // table entry of the scratch chain, or -1
+        };
+        std::vector<Placement> place(total);
         std::vector<DevTexture> table(total);
-        size_t n8 = 0, nf = 0;
+        size_t n8 = 0, nf = 0, scratch8 = 0, scratchF = 0;
+        uint32_t scaled = 0;
         for (uint32_t i = 0; i < total; i++)
         {
             const PtxTextureDesc &d = descOf(i);
             DevTexture &t = table[i];
+            Placement &pl = place[i];
             if (d.format > PTX_TEXTURE_RGBA32F)
                 return fail(r, PTX_ERROR_INVALID_ARGUMENT, "texture %u: unknown format %u", i, d.format);
-            t.width = d.width ? d.width : 1;
-            t.height = d.height ? d.height : 1;
+            pl.srcW = d.width ? d.width : 1;
+            pl.srcH = d.height ? d.height : 1;
+            pl.fileLevels = d.levels ? d.levels : 1u;
+            pl.firstFile = 0;
+            pl.useFileChain = false;
+            pl.halvings = 0;
+            pl.temp = -1;
+            t.width = pl.srcW;
+            t.height = pl.srcH;
             t.format = d.format;
-            uint32_t m = t.width > t.height ? t.width : t.height, levels = 1;
-            while (m > 1) { m >>= 1; levels++; } // floor(log2(max)) + 1, Image.cpp:14-17
-            if (i >= r->textureCount)
-                levels = 1;
-            t.levels = levels > 16 ? 16 : levels;
+            if (i < r->textureCount)
+            {
+                // TextureUploader::UploadTexture (:409-415): integer scale that brings both sides under the limit
+                const uint32_t mx = maxExtent[d.format];
+                const uint32_t scale = std::max((pl.srcW + mx - 1) / mx, (pl.srcH + mx - 1) / mx);
+                t.width = std::max(pl.srcW / scale, 1u);
+                t.height = std::max(pl.srcH / scale, 1u);
+                t.levels = fullLevels(t.width, t.height);
+                if (pl.fileLevels > fullLevels(pl.srcW, pl.srcH))
+                    return fail(r, PTX_ERROR_INVALID_ARGUMENT, "texture %u: %u levels for a %u x %u image", i, pl.fileLevels, pl.srcW, pl.srcH);
+                if (scale == 1)
+                    pl.useFileChain = pl.fileLevels == t.levels && t.levels > 1;
+                else
+                {
+                    // a file with its own chain: the levels from the budgeted extent down are taken as they are (:492-501)
+                    const uint32_t skip = pl.fileLevels > t.levels ? pl.fileLevels - t.levels : 0u;
+                    if (skip && dim(pl.srcW, skip) == t.width && dim(pl.srcH, skip) == t.height)
+                    {
+                        pl.useFileChain = true;
+                        pl.firstFile = skip;
+                    }
+                    else
+                    {
+                        while (dim(pl.srcW, pl.halvings + 1) >= t.width && dim(pl.srcH, pl.halvings + 1) >= t.height &&
+                               (dim(pl.srcW, pl.halvings) > t.width || dim(pl.srcH, pl.halvings) > t.height))
+                            pl.halvings++;
+                        pl.temp = (int)(total + scaled++);
+                        size_t need = 0;
+                        for (uint32_t l = 0; l <= pl.halvings; l++)
+                            need += (size_t)dim(pl.srcW, l) * dim(pl.srcH, l);
+                        size_t &sc = d.format == PTX_TEXTURE_RGBA32F ? scratchF : scratch8;
+                        sc = std::max(sc, need);
+                    }
+                }
+            }
+            else
+                t.levels = 1;
             size_t &cursor = t.format == PTX_TEXTURE_RGBA32F ? nf : n8;
             for (uint32_t l = 0; l < t.levels; l++)
             {
-                if (cursor > 0xffffffffull)
-                    return fail(r, PTX_ERROR_INVALID_ARGUMENT, "texture pool exceeds 2^32 texels");
                 t.levelOffset[l] = (uint32_t)cursor;
-                const uint32_t lw = t.width >> l ? t.width >> l : 1, lh = t.height >> l ? t.height >> l : 1;
-                cursor += (size_t)lw * lh;
+                cursor += (size_t)dim(t.width, l) * dim(t.height, l);
             }
         }
-        HIP_TRY(r, r->textures.alloc(total));
-        HIP_TRY(r, r->texels8.alloc(n8));
-        HIP_TRY(r, r->texelsF.alloc(nf));
+        // scratch chains of the textures that are scaled down: one region per pool behind the textures, used by one
+        // texture after the other (stream order); their table entries follow the real ones
+        table.resize(total + scaled);
+        for (uint32_t i = 0; i < total; i++)
+            if (place[i].temp >= 0)
+            {
+                DevTexture &t = table[(size_t)place[i].temp];
+                t.width = place[i].srcW;
+                t.height = place[i].srcH;
+                t.format = table[i].format;
+                t.levels = place[i].halvings + 1;
+                size_t cursor = t.format == PTX_TEXTURE_RGBA32F ? nf : n8;
+                for (uint32_t l = 0; l < t.levels; l++)
+                {
+                    t.levelOffset[l] = (uint32_t)cursor;
+                    cursor += (size_t)dim(t.width, l) * dim(t.height, l);
+                }
+            }
+        if (n8 + scratch8 > 0xffffffffull || nf + scratchF > 0xffffffffull)
+            return fail(r, PTX_ERROR_INVALID_ARGUMENT, "texture pool exceeds 2^32 texels");
+        HIP_TRY(r, r->textures.alloc(total + scaled));
+        HIP_TRY(r, r->texels8.alloc(n8 + scratch8));
+        HIP_TRY(r, r->texelsF.alloc(nf + scratchF));
         if (n8)
             HIP_TRY(r, hipMemsetAsync(r->texels8.p, 0, n8 * 4, r->stream)); // a texture without data reads as zeros
         if (nf)
@@ -2106,11 +2210,11 @@ int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *s)
         {
             const PtxTextureDesc &d = s->textures[i];
             const bool whitePlaceholder = table[i].width == 1 && table[i].height == 1 && d.format != PTX_TEXTURE_RGBA32F && d.data &&
-                                          *static_cast<const uint32_t *>(d.data) == 0xffffffffu;
+                                          *static_cast<const uint32_t *>(d.data) == 0xffffffffu && place[i].srcW == 1 && place[i].srcH == 1;
             if (!whitePlaceholder)
                 r->samplerNeeded = true;
         }
-        if (total)
+        if (!table.empty())
             HIP_TRY(r, hipMemcpyAsync(r->textures.p, table.data(), table.size() * sizeof(DevTexture), hipMemcpyHostToDevice, r->stream));
         TextureView tv;
         tv.textures = r->textures.p; tv.textureCount = r->textureCount; tv.texels8 = r->texels8.p; tv.texelsF = r->texelsF.p;
@@ -2119,19 +2223,45 @@ int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *s)
         {
             const PtxTextureDesc &d = descOf(i);
             const DevTexture &t = table[i];
-            const size_t n0 = (size_t)t.width * t.height;
-            if (d.data)
+            const Placement &pl = place[i];
+            const bool isFloat = t.format == PTX_TEXTURE_RGBA32F;
+            const size_t texel = isFloat ? 16 : 4;
+            auto poolAt = [&](uint32_t offset) -> void * { return isFloat ? (void *)(r->texelsF.p + offset) : (void *)(r->texels8.p + offset); };
+            auto blit = [&](uint32_t src, uint32_t srcLevel, uint32_t dst, uint32_t dstLevel) {
+                const uint32_t dw = dim(table[dst].width, dstLevel), dh = dim(table[dst].height, dstLevel);
+                k_blit_level<<<(dw * dh + 255) / 256, 256, 0, r->stream>>>(tv, src, srcLevel, dst, dstLevel, r->texels8.p, r->texelsF.p);
+            };
+            if (d.data && pl.useFileChain)
             {
-                if (t.format == PTX_TEXTURE_RGBA32F)
-                    HIP_TRY(r, hipMemcpyAsync(r->texelsF.p + t.levelOffset[0], d.data, n0 * 16, hipMemcpyHostToDevice, r->stream));
+                // the file's own levels, from the one that has the budgeted extent
+                const uint8_t *p = static_cast<const uint8_t *>(d.data);
+                for (uint32_t l = 0; l < pl.firstFile; l++)
+                    p += (size_t)dim(pl.srcW, l) * dim(pl.srcH, l) * texel;
+                for (uint32_t l = 0; l < t.levels; l++)
+                {
+                    const size_t nl = (size_t)dim(t.width, l) * dim(t.height, l);
+                    HIP_TRY(r, hipMemcpyAsync(poolAt(t.levelOffset[l]), p, nl * texel, hipMemcpyHostToDevice, r->stream));
+                    p += nl * texel;
+                }
+                continue;
+            }
+            if (d.data && pl.temp >= 0)
+            {
+                // scaled down: the file's level 0 into the scratch chain, halved by linear blits, then into level 0
+                const DevTexture &tt = table[(size_t)pl.temp];
+                HIP_TRY(r, hipMemcpyAsync(poolAt(tt.levelOffset[0]), d.data, (size_t)pl.srcW * pl.srcH * texel, hipMemcpyHostToDevice, r->stream));
+                for (uint32_t l = 1; l <= pl.halvings; l++)
+                    blit((uint32_t)pl.temp, l - 1, (uint32_t)pl.temp, l);
+                if (dim(pl.srcW, pl.halvings) == t.width && dim(pl.srcH, pl.halvings) == t.height)
+                    HIP_TRY(r, hipMemcpyAsync(poolAt(t.levelOffset[0]), poolAt(tt.levelOffset[pl.halvings]), (size_t)t.width * t.height * texel,
+                                              hipMemcpyDeviceToDevice, r->stream));
                 else
-                    HIP_TRY(r, hipMemcpyAsync(r->texels8.p + t.levelOffset[0], d.data, n0 * 4, hipMemcpyHostToDevice, r->stream));
+                    blit((uint32_t)pl.temp, pl.halvings, i, 0);
             }
+            else if (d.data)
+                HIP_TRY(r, hipMemcpyAsync(poolAt(t.levelOffset[0]), d.data, (size_t)t.width * t.height * texel, hipMemcpyHostToDevice, r->stream));
             for (uint32_t l = 1; l < t.levels; l++)
-            {
-                const uint32_t lw = t.width >> l ? t.width >> l : 1, lh = t.height >> l ? t.height >> l : 1;
-                k_generate_mip<<<(lw * lh + 255) / 256, 256, 0, r->stream>>>(tv, i, l, r->texels8.p, r->texelsF.p);
-            }
+                blit(i, l - 1, i, l);
         }
         HIP_TRY(r, hipStreamSynchronize(r->stream)); // `table` and the caller's texel arrays may go away
         HIP_TRY(r, hipGetLastError());

@@ -192,7 +192,7 @@ PtxSceneDesc Scene::GetDesc() const
         rec.width = t.Width;
         rec.height = t.Height;
         rec.format = t.Format == TextureFormat::RGBAF32 ? PTX_TEXTURE_RGBA32F : (isColor ? PTX_TEXTURE_RGBA8_SRGB : PTX_TEXTURE_RGBA8_UNORM);
-        rec.reserved = 0;
+        rec.levels = t.Pixels.empty() ? 1u : t.Levels;
         rec.data = t.Pixels.empty() ? nullptr : t.Pixels.data();
         if (t.Pixels.empty()) // no data: a 1x1 white placeholder
         {
@@ -231,6 +231,7 @@ PtxSceneDesc Scene::GetDesc() const
     d.animatedIndexCount = m_AnimatedIndices.size();
     d.dxNormalTextures = m_HasDxNormalTextures ? 1u : 0u;
     d.forceFullTextureSize = m_ForceFullTextureSize ? 1u : 0u;
+    d.textureMemoryBudget = m_TextureMemoryBudget;
     return d;
 }
 

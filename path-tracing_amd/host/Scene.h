@@ -85,6 +85,7 @@ struct TextureInfo
     std::string Name;
     TextureFormat Format = TextureFormat::RGBAU8;
     std::vector<uint8_t> Pixels; // RGBAU8: 4 bytes per texel; RGBAF32: 16 bytes per texel
+    uint32_t Levels = 1;         // mip levels in Pixels (a DDS file's own chain), level 0 first, tightly packed
 };
 
 using Geometry = PtxGeometry; // Scene.h:63-71
@@ -289,6 +290,10 @@ public:
     [[nodiscard]] std::span<const ModelInstance> GetModelInstances() const { return m_ModelInstances; }
     [[nodiscard]] bool HasDxNormalTextures() const { return m_HasDxNormalTextures; }
     [[nodiscard]] bool GetForceFullTextureSize() const { return m_ForceFullTextureSize; } // Scene.h: TextureUploader's downscale off
+    // Application::GetConfig().MaxTextureMemoryBudget* (TextureUploader.cpp:29-37) as a property of the scene handed to the
+    // backend: 0 = the reference's default (min(80 % of the device memory, 1 GiB)), ~0 = no limit
+    void SetTextureMemoryBudget(uint64_t bytes) { m_TextureMemoryBudget = bytes; }
+    [[nodiscard]] uint64_t GetTextureMemoryBudget() const { return m_TextureMemoryBudget; }
     [[nodiscard]] std::span<const Shaders::PointLight> GetPointLights() const { return m_PointLights; }
     [[nodiscard]] const Shaders::DirectionalLight &GetDirectionalLight() const { return m_DirectionalLight; }
     [[nodiscard]] const SkyboxVariant &GetSkybox() const { return m_Skybox; }
@@ -322,6 +327,7 @@ private:
     std::vector<TextureInfo> m_Textures;
     bool m_HasDxNormalTextures = false;
     bool m_ForceFullTextureSize = false;
+    uint64_t m_TextureMemoryBudget = 0;
     std::vector<Model> m_Models;
     std::vector<ModelInstance> m_ModelInstances;
     std::vector<SceneNode> m_SceneNodes;

@@ -570,43 +570,65 @@ DecodedImage TextureImporter::DecodeDds(std::span<const uint8_t> f)
         throw error("Unsupported texture format");
     if (!w || !h)
         throw error("DDS: empty image");
-    const uint32_t bw = (w + 3) / 4, bh = (h + 3) / 4;
+    // the file's own mip chain (dwMipMapCount, valid with DDSD_MIPMAPCOUNT): the reference uploads it as it is
+    // (TextureImporter.cpp GetTextureInfo: Levels = texture.levels(); TextureUploader.cpp:440,492-501)
+    uint32_t levels = (le32(8) & 0x20000u) ? le32(28) : 1u;
+    if (levels == 0)
+        levels = 1;
+    {
+        uint32_t m = w > h ? w : h, full = 1;
+        while (m > 1) { m >>= 1; full++; }
+        if (levels > full)
+            throw error("DDS: more mip levels than the image has");
+    }
     const size_t blockBytes = fmt == BC1 ? 8 : 16;
-    if (offset + static_cast<size_t>(bw) * bh * blockBytes > f.size())
-        throw error("DDS: truncated data");
     DecodedImage img;
     img.Width = w;
     img.Height = h;
+    img.Levels = levels;
     img.Channels = fmt == BC5 ? 2 : 4;
-    img.Pixels.resize(static_cast<size_t>(w) * h * 4);
-    for (uint32_t by = 0; by < bh; by++)
-        for (uint32_t bx = 0; bx < bw; bx++)
-        {
-            const uint8_t *b = &f[offset + (static_cast<size_t>(by) * bw + bx) * blockBytes];
-            uint8_t px[16][4];
-            if (fmt == BC1)
-                DecodeBc1Colors(b, px, true);
-            else if (fmt == BC3)
+    size_t texels = 0;
+    for (uint32_t l = 0; l < levels; l++)
+        texels += static_cast<size_t>(std::max(w >> l, 1u)) * std::max(h >> l, 1u);
+    img.Pixels.resize(texels * 4);
+    size_t out = 0;
+    for (uint32_t l = 0; l < levels; l++)
+    {
+        const uint32_t lw = std::max(w >> l, 1u), lh = std::max(h >> l, 1u);
+        const uint32_t bw = (lw + 3) / 4, bh = (lh + 3) / 4;
+        if (offset + static_cast<size_t>(bw) * bh * blockBytes > f.size())
+            throw error("DDS: truncated data");
+        for (uint32_t by = 0; by < bh; by++)
+            for (uint32_t bx = 0; bx < bw; bx++)
             {
-                uint8_t alpha[16];
-                DecodeBc4Channel(b, alpha);
-                DecodeBc1Colors(b + 8, px, false);
-                for (int i = 0; i < 16; i++) px[i][3] = alpha[i];
+                const uint8_t *b = &f[offset + (static_cast<size_t>(by) * bw + bx) * blockBytes];
+                uint8_t px[16][4];
+                if (fmt == BC1)
+                    DecodeBc1Colors(b, px, true);
+                else if (fmt == BC3)
+                {
+                    uint8_t alpha[16];
+                    DecodeBc4Channel(b, alpha);
+                    DecodeBc1Colors(b + 8, px, false);
+                    for (int i = 0; i < 16; i++) px[i][3] = alpha[i];
+                }
+                else
+                {
+                    uint8_t r[16], g[16];
+                    DecodeBc4Channel(b, r);
+                    DecodeBc4Channel(b + 8, g);
+                    for (int i = 0; i < 16; i++) { px[i][0] = r[i]; px[i][1] = g[i]; px[i][2] = 0; px[i][3] = 255; }
+                }
+                for (int i = 0; i < 16; i++)
+                {
+                    const uint32_t x = bx * 4 + (i & 3), y = by * 4 + (i >> 2);
+                    if (x < lw && y < lh)
+                        std::memcpy(&img.Pixels[(out + static_cast<size_t>(y) * lw + x) * 4], px[i], 4);
+                }
             }
-            else
-            {
-                uint8_t r[16], g[16];
-                DecodeBc4Channel(b, r);
-                DecodeBc4Channel(b + 8, g);
-                for (int i = 0; i < 16; i++) { px[i][0] = r[i]; px[i][1] = g[i]; px[i][2] = 0; px[i][3] = 255; }
-            }
-            for (int i = 0; i < 16; i++)
-            {
-                const uint32_t x = bx * 4 + (i & 3), y = by * 4 + (i >> 2);
-                if (x < w && y < h)
-                    std::memcpy(&img.Pixels[(static_cast<size_t>(y) * w + x) * 4], px[i], 4);
-            }
-        }
+        offset += static_cast<size_t>(bw) * bh * blockBytes;
+        out += static_cast<size_t>(lw) * lh;
+    }
     return img;
 }
 
@@ -639,6 +661,7 @@ TextureInfo ToTextureInfo(DecodedImage &&img, TextureType type, std::string &&na
     info.Height = img.Height;
     info.Name = std::move(name);
     info.Format = img.IsFloat ? TextureFormat::RGBAF32 : TextureFormat::RGBAU8;
+    info.Levels = img.Levels;
     info.Pixels = std::move(img.Pixels);
     if (type == TextureType::Color && img.Channels == 4 && !img.IsFloat) // PremultiplyTextureData, :24-51
         for (size_t i = 0; i + 3 < info.Pixels.size(); i += 4)

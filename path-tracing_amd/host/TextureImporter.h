@@ -9,8 +9,8 @@
 //         progressive / arithmetic files are rejected
 //   TGA   uncompressed and RLE true colour / greyscale, 8 / 24 / 32 bit
 //   HDR   Radiance RGBE, run-length and flat scanlines -> RGBA32F
-//   DDS   BC1 / BC3 / BC5 blocks decoded to RGBA8 (level 0; the mip chain is regenerated on the device, where
-//         the reference uploads the file's own levels)
+//   DDS   BC1 / BC3 / BC5 blocks decoded to RGBA8, with the file's own mip levels (a complete chain is uploaded as it
+//         is, like the reference's; an incomplete one is regenerated from level 0: TextureUploader.cpp:440-456)
 // A file that cannot be decoded throws PathTracing::error, which the importer turns into the default texture
 // of the slot (SceneImporter.cpp:97-101).
 //
@@ -35,6 +35,7 @@ struct DecodedImage
     uint32_t Width = 0, Height = 0;
     uint32_t Channels = 0;      // channels in the file (1..4)
     bool IsFloat = false;       // RGBA32F (HDR) instead of RGBA8
+    uint32_t Levels = 1;        // mip levels in Pixels (DDS files carry their own chain), level 0 first
     std::vector<uint8_t> Pixels; // RGBA8: 4 bytes per texel, RGBA32F: 16 bytes per texel
 };
 

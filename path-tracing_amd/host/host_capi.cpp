@@ -152,7 +152,8 @@ int pth_decode_image(const void *file, size_t fileBytes, uint32_t info[4], void 
         info[0] = img.Width; info[1] = img.Height; info[2] = img.Channels; info[3] = img.IsFloat ? 1u : 0u;
         if (pixels)
         {
-            if (bytes != img.Pixels.size())
+            const size_t level0 = static_cast<size_t>(img.Width) * img.Height * (img.IsFloat ? 16 : 4);
+            if (bytes != img.Pixels.size() && bytes != level0)
                 return PTX_ERROR_INVALID_ARGUMENT;
             std::memcpy(pixels, img.Pixels.data(), bytes);
         }
@@ -162,6 +163,21 @@ int pth_decode_image(const void *file, size_t fileBytes, uint32_t info[4], void 
     {
         g_error = e.what();
         return PTX_ERROR_INVALID_ARGUMENT;
+    }
+}
+
+uint32_t pth_decode_image_levels(const void *file, size_t fileBytes)
+{
+    if (!file)
+        return 0;
+    try
+    {
+        return TextureImporter::Decode(std::span<const uint8_t>(static_cast<const uint8_t *>(file), fileBytes)).Levels;
+    }
+    catch (const std::exception &e)
+    {
+        g_error = e.what();
+        return 0;
     }
 }
 

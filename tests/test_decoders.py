@@ -184,6 +184,35 @@ def test_block_compressed_dds(pkg):
     assert ch == 2 and (img[..., 0] == 10).all() and (img[..., 1] == (1 * 250 + 6 * 10) // 7).all() and (img[..., 2] == 0).all()
 
 
+def test_dds_carries_its_own_mip_chain(pkg):
+    """TextureInfo::Levels: the levels stored in the file arrive as they are (the reference uploads them instead of
+    regenerating the chain, TextureUploader.cpp:440,492-501)."""
+    def header(w, h, levels):
+        hd = bytearray(128)
+        hd[0:4] = b"DDS "
+        struct.pack_into("<IIII", hd, 4, 124, 0x1007 | (0x20000 if levels else 0), h, w)
+        struct.pack_into("<I", hd, 28, levels)
+        struct.pack_into("<II", hd, 76, 32, 4)
+        hd[84:88] = b"DXT1"
+        return bytes(hd)
+
+    def solid(c565, blocks):
+        return struct.pack("<HHI", c565, c565, 0) * blocks
+
+    colours = [0xF800, 0x07E0, 0x001F, 0xFFFF]  # red 8x8, green 4x4, blue 2x2, white 1x1
+    data = header(8, 8, 4) + solid(colours[0], 4) + solid(colours[1], 1) + solid(colours[2], 1) + solid(colours[3], 1)
+    levels = pkg.decode_image_levels(data)
+    assert [l.shape for l in levels] == [(8, 8, 4), (4, 4, 4), (2, 2, 4), (1, 1, 4)]
+    for l, rgb in zip(levels, ([255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255])):
+        assert (l[..., :3] == rgb).all() and (l[..., 3] == 255).all()
+    img, ch = pkg.decode_image(data)  # the level-0 view of the same file
+    assert img.shape == (8, 8, 4) and (img[..., 0] == 255).all()
+    assert len(pkg.decode_image_levels(header(8, 8, 0) + solid(colours[0], 4))) == 1
+    for bad in (header(8, 8, 4) + solid(colours[0], 5), header(8, 8, 5) + solid(colours[0], 9)):  # truncated chain; too many levels
+        with pytest.raises(pkg.PtxError):
+            pkg.decode_image_levels(bad)
+
+
 def _bits(v, n):
     return [(v >> (n - 1 - i)) & 1 for i in range(n)]
 

@@ -10,7 +10,7 @@ from gltf_util import GltfWriter, cube, quad
 
 
 class _Tex(C.Structure):
-    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("format", C.c_uint32), ("reserved", C.c_uint32), ("data", C.c_void_p)]
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("format", C.c_uint32), ("levels", C.c_uint32), ("data", C.c_void_p)]
 
 
 def _mr(desc, i):

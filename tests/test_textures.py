@@ -25,7 +25,7 @@ def test_texture_descs_follow_reference_format_rule(pkg):
     import ctypes as C
 
     class TextureDesc(C.Structure):
-        _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("format", C.c_uint32), ("reserved", C.c_uint32), ("data", C.c_void_p)]
+        _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("format", C.c_uint32), ("levels", C.c_uint32), ("data", C.c_void_p)]
 
     s = pkg.Scene("texture_test")
     d = s.desc
@@ -168,3 +168,132 @@ def test_textured_tail_and_wavefront_agree(pkg, monkeypatch):
         imgs.append(r.readback())
         r.close()
     assert (imgs[0].view(np.uint32) == imgs[1].view(np.uint32)).all()
+
+
+# ---------------------------------------------------------------------------------------
+# upload rules of TextureUploader::UploadTexture: file-supplied mip chains and the memory budget
+# ---------------------------------------------------------------------------------------
+import ctypes as C  # noqa: E402
+
+
+class _TextureDesc(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("format", C.c_uint32), ("levels", C.c_uint32), ("data", C.c_void_p)]
+
+
+UNORM, SRGB, F32 = 0, 1, 2
+
+
+def _chain(w, h, texel_of_level, dtype=np.uint8):
+    """All levels of a w x h image, level 0 first: texel_of_level(l, ys, xs) -> (h_l, w_l, 4)."""
+    out = []
+    l = 0
+    while True:
+        lw, lh = max(w >> l, 1), max(h >> l, 1)
+        ys, xs = np.mgrid[0:lh, 0:lw]
+        out.append(np.ascontiguousarray(texel_of_level(l, ys, xs), dtype).reshape(-1))
+        if lw == 1 and lh == 1:
+            return out
+        l += 1
+
+
+def _desc_with(pkg, scene, textures, budget=0, force_full=False):
+    """A copy of the scene's description whose texture table is `textures` = [(w, h, format, levels, flat array)]."""
+    arr = (_TextureDesc * len(textures))()
+    for i, (w, h, fmt, levels, data) in enumerate(textures):
+        arr[i] = _TextureDesc(w, h, fmt, levels, data.ctypes.data)
+    d = type(scene.desc).from_buffer_copy(scene.desc)
+    d.textures = C.addressof(arr)
+    d.textureCount = len(textures)
+    d.textureMemoryBudget = budget
+    d.forceFullTextureSize = 1 if force_full else 0
+    return d, (arr, textures, scene)  # keep alive
+
+
+def _upload_rule_textures():
+    rng = np.random.default_rng(11)
+    flat = lambda l, ys, xs: np.broadcast_to(np.uint8([20 + 30 * l, 200 - 25 * l, 7 * l, 255]), ys.shape + (4,))  # noqa: E731
+    blocks = lambda l, ys, xs: np.stack([((xs // 2) * 7 + (ys // 2) * 3) % 256, (xs // 2) * 4, (ys // 2) * 4, np.full_like(xs, 255)], -1)  # noqa: E731
+    noise37 = rng.integers(0, 256, (21, 37, 4)).astype(np.uint8)
+    ramp = rng.uniform(0, 4, (16, 64, 4)).astype(np.float32)
+    return [
+        (8, 8, UNORM, 4, np.concatenate(_chain(8, 8, flat))),           # 0: complete file chain
+        (8, 8, UNORM, 2, np.concatenate(_chain(8, 8, flat)[:2])),       # 1: incomplete chain -> generated from level 0
+        (64, 64, UNORM, 1, _chain(64, 64, blocks)[0]),                  # 2: level 0 only, constant 2 x 2 blocks
+        (64, 64, SRGB, 7, np.concatenate(_chain(64, 64, flat))),        # 3: complete chain, scaled by skipping levels
+        (37, 21, SRGB, 1, noise37.reshape(-1)),                         # 4: odd size: halve once, then a 18 x 10 -> 12 x 7 blit
+        (64, 16, F32, 1, ramp.reshape(-1)),                             # 5: float pool
+    ]
+
+
+# the per-texture share that makes 32 x 32 the largest RGBA8 extent (chain of 32: 5,460 B; of 64: 21,844 B) and, for the
+# float pool, 16 x 16 (5,456 B; chain of 32: 21,840 B)
+_BUDGET_32 = 6 * 6000
+
+
+def test_oracle_upload_rules_file_chain_and_budget(pkg, orc):
+    s = pkg.Scene("texture_test")
+    tex = _upload_rule_textures()
+    lod = lambda k: dict(dudx=np.float32(2.0 ** k / 8), dvdy=np.float32(2.0 ** k / 8))  # noqa: E731  (8 x 8 texture: LOD k)
+    u = np.float32([0.3, 0.7])
+    # no limit: a complete file chain is used level by level, an incomplete one is replaced by blits of level 0
+    d, keep = _desc_with(pkg, s, tex, budget=2**64 - 1)
+    osc = orc.OracleScene(d, build_bvh=False)
+    for k in range(4):
+        a = osc.test_texture(_inputs(9, u, u, **lod(k))).view(np.float32)
+        assert np.allclose(a[:, :3], np.float32([20 + 30 * k, 200 - 25 * k, 7 * k]) / 255, atol=1e-7), k
+        b = osc.test_texture(_inputs(10, u, u, **lod(k))).view(np.float32)
+        assert np.allclose(b[:, :3], np.float32([20, 200, 0]) / 255, atol=1e-6), k
+    full = osc.test_texture(_inputs(11, (np.arange(64, dtype=np.float32) + 0.5) / 64, np.full(64, 0.5 / 64, np.float32)), implicit_lod=True).view(np.float32)
+    assert np.allclose(full[:, 0] * 255, ((np.arange(64) // 2) * 7) % 256, atol=1e-4)
+    # budget: 64 x 64 becomes 32 x 32 -- one halving blit of level 0 (constant 2 x 2 blocks survive it exactly) ...
+    d, keep2 = _desc_with(pkg, s, tex, budget=_BUDGET_32)
+    osc = orc.OracleScene(d, build_bvh=False)
+    xs = np.arange(32, dtype=np.float32)
+    got = osc.test_texture(_inputs(11, (xs + 0.5) / 32, np.full(32, 4.5 / 32, np.float32)), implicit_lod=True).view(np.float32)
+    assert np.allclose(got[:, 0] * 255, (np.arange(32) * 7 + 4 * 3) % 256, atol=1e-4) and np.allclose(got[:, 1] * 255, np.arange(32) * 4, atol=1e-4)
+    # ... a file with its own chain gives up its first level instead (level k of the image = level k + 1 of the file) ...
+    for k in range(3):
+        g = dict(dudx=np.float32(2.0 ** k / 32), dvdy=np.float32(2.0 ** k / 32))
+        a = osc.test_texture(_inputs(12, u, u, **g)).view(np.float32)
+        assert np.allclose(a[:, :3], _srgb_to_linear([20 + 30 * (k + 1), 200 - 25 * (k + 1), 7 * (k + 1)]), atol=1e-6), k
+    # ... small textures are untouched, the float pool has its own limit (64 x 16 -> 16 x 4), forceFullTextureSize switches it off
+    a = osc.test_texture(_inputs(9, u, u, **lod(2))).view(np.float32)
+    assert np.allclose(a[:, :3], np.float32([80, 150, 14]) / 255, atol=1e-7)
+    ramp = tex[5][4].reshape(16, 64, 4)
+    f = osc.test_texture(_inputs(14, np.float32([(3 + 0.5) / 16]), np.float32([(1 + 0.5) / 4])), implicit_lod=True).view(np.float32)[0]
+    assert np.allclose(f, ramp[4:8, 12:16].mean(axis=(0, 1)), rtol=2e-6)
+    d, keep3 = _desc_with(pkg, s, tex, budget=_BUDGET_32, force_full=True)
+    osc = orc.OracleScene(d, build_bvh=False)
+    again = osc.test_texture(_inputs(11, (np.arange(64, dtype=np.float32) + 0.5) / 64, np.full(64, 0.5 / 64, np.float32)), implicit_lod=True)
+    assert (again.view(np.float32) == full).all()
+
+
+@pytest.mark.gpu
+def test_upload_rules_match_oracle_bitexact(pkg, orc, gpu_renderer):
+    s = pkg.Scene("texture_test")
+    tex = _upload_rule_textures()
+    rng = np.random.default_rng(6)
+    n = 20000
+    idx = rng.integers(9, 16, n).astype(np.uint32)
+    uv = rng.uniform(-1.5, 2.5, (n, 2)).astype(np.float32)
+    g = (10.0 ** rng.uniform(-4, 0.3, (n, 4)) * rng.choice([-1, 1], (n, 4))).astype(np.float32)
+    inp = _inputs(idx, uv[:, 0], uv[:, 1], g[:, 0], g[:, 1], g[:, 2], g[:, 3])
+    for budget, force in ((2**64 - 1, False), (_BUDGET_32, False), (_BUDGET_32 // 5, False), (_BUDGET_32, True), (0, False)):
+        d, keep = _desc_with(pkg, s, tex, budget=budget, force_full=force)
+        gpu_renderer.upload(d)
+        osc = orc.OracleScene(d, build_bvh=False)
+        for implicit in (False, True):
+            a, b = gpu_renderer.test_texture(inp, implicit), osc.test_texture(inp, implicit)
+            assert (a == b).all(), f"{int((a != b).any(axis=1).sum())} samples differ (budget {budget}, force {force}, implicit {implicit})"
+    # and through the path: the scene rendered with its textures squeezed to a quarter
+    d = type(s.desc).from_buffer_copy(s.desc)
+    d.textureMemoryBudget = 7 * 1500
+    gpu_renderer.upload(d)
+    gpu_renderer.resize(96, 64)
+    gpu_renderer.reset()
+    u = s.uniform(96, 64, bounces=3)
+    gpu_renderer.render(u, s.lights)
+    ref, _ = orc.OracleScene(d).render(u, s.lights, 96, 64)
+    full, _ = orc.OracleScene(s.desc).render(u, s.lights, 96, 64)
+    img = gpu_renderer.readback()
+    assert (img.view(np.uint32) == ref.view(np.uint32)).all() and not (ref == full).all()
