@@ -2151,54 +2151,117 @@ static inline v2 missSkyboxTexCoords(v3 dir)
     return uv;
 }
 
-/* clamp-to-edge bilinear inside one cube face */
-static v4 sampleFace(const PtoScene *s, const OTexture *t, float u, float v)
+/* Cube map face selection of the Vulkan specification (largest magnitude, z before y before x on ties): face and the
+ * face coordinates (sc, tc) with major axis length ma. */
+static inline void cubeFace(v3 r, uint32_t *face, float *sc, float *tc, float *ma)
 {
-    const uint32_t w = t->width, h = t->height;
+    const float ax = fabsf(r.x), ay = fabsf(r.y), az = fabsf(r.z);
+    if (az >= ax && az >= ay)
+    {
+        *face = r.z < 0.0f ? 5u : 4u;
+        *sc = r.z < 0.0f ? -r.x : r.x;
+        *tc = -r.y;
+        *ma = az;
+    }
+    else if (ay >= ax)
+    {
+        *face = r.y < 0.0f ? 3u : 2u;
+        *sc = r.x;
+        *tc = r.y < 0.0f ? -r.z : r.z;
+        *ma = ay;
+    }
+    else
+    {
+        *face = r.x < 0.0f ? 1u : 0u;
+        *sc = r.x < 0.0f ? r.z : -r.z;
+        *tc = -r.y;
+        *ma = ax;
+    }
+}
+
+/* Texel (ix, iy) of a face, where ONE of the indices may lie one step outside 0 .. n-1: the texel across that edge.
+ * (Seamless cube maps: Vulkan samples "Cube Map Edge Handling" -- the reference's sampler filters across face borders.)
+ * The texel centre, folded over the edge onto the cube's surface, is looked up again through the face selection: the
+ * index along the edge is kept, the index across it becomes the neighbour's border row. */
+static v4 cubeTexel(const PtoScene *s, const OTexture *faces, uint32_t face, int ix, int iy)
+{
+    const int n = (int)faces[face].width;
+    if (ix >= 0 && ix < n && iy >= 0 && iy < n)
+        return fetchTexel(s, &faces[face], 0, (uint32_t)ix, (uint32_t)iy);
+    float sc = 2.0f * (((float)ix + 0.5f) / (float)n) - 1.0f, tc = 2.0f * (((float)iy + 0.5f) / (float)n) - 1.0f, ma = 1.0f;
+    if (ix < 0 || ix >= n)
+    {
+        ma = 1.0f - (fabsf(sc) - 1.0f);
+        sc = sc < 0.0f ? -1.0f : 1.0f;
+    }
+    else
+    {
+        ma = 1.0f - (fabsf(tc) - 1.0f);
+        tc = tc < 0.0f ? -1.0f : 1.0f;
+    }
+    v3 r;
+    switch (face) /* inverse of the selection table */
+    {
+    case 0: r = V3(ma, -tc, -sc); break;
+    case 1: r = V3(-ma, -tc, sc); break;
+    case 2: r = V3(sc, ma, tc); break;
+    case 3: r = V3(sc, -ma, -tc); break;
+    case 4: r = V3(sc, -tc, ma); break;
+    default: r = V3(-sc, -tc, -ma); break;
+    }
+    uint32_t f2;
+    float s2, t2, m2;
+    cubeFace(r, &f2, &s2, &t2, &m2);
+    const float mx = (float)(n - 1);
+    const uint32_t jx = (uint32_t)f_clamp(floorf((0.5f * (s2 / m2) + 0.5f) * (float)n), 0.0f, mx);
+    const uint32_t jy = (uint32_t)f_clamp(floorf((0.5f * (t2 / m2) + 0.5f) * (float)n), 0.0f, mx);
+    return fetchTexel(s, &faces[f2], 0, jx, jy);
+}
+
+/* bilinear lookup at (u, v) of a face with the footprint continuing on the neighbouring faces; at a corner of the cube,
+ * where three faces meet and the fourth texel does not exist, it is the mean of the other three (Vulkan "Cube Map
+ * Corner Handling") */
+static v4 sampleFaceSeamless(const PtoScene *s, const OTexture *faces, uint32_t face, float u, float v)
+{
+    const int n = (int)faces[face].width;
     if (!(fabsf(u) < 1e9f)) u = 0.0f;
     if (!(fabsf(v) < 1e9f)) v = 0.0f;
-    const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    const float x = u * (float)n - 0.5f, y = v * (float)n - 0.5f;
     const float x0 = floorf(x), y0 = floorf(y);
     const float ax = x - x0, ay = y - y0;
-    const float mx = (float)(w - 1), my = (float)(h - 1);
-    const uint32_t ix0 = (uint32_t)f_clamp(x0, 0.0f, mx), ix1 = (uint32_t)f_clamp(x0 + 1.0f, 0.0f, mx);
-    const uint32_t iy0 = (uint32_t)f_clamp(y0, 0.0f, my), iy1 = (uint32_t)f_clamp(y0 + 1.0f, 0.0f, my);
-    const v4 top = v4_lerp(fetchTexel(s, t, 0, ix0, iy0), fetchTexel(s, t, 0, ix1, iy0), ax);
-    const v4 bot = v4_lerp(fetchTexel(s, t, 0, ix0, iy1), fetchTexel(s, t, 0, ix1, iy1), ax);
+    const int ix0 = (int)x0, iy0 = (int)y0, ix1 = ix0 + 1, iy1 = iy0 + 1;
+    const int ox0 = ix0 < 0, ox1 = ix1 >= n, oy0 = iy0 < 0, oy1 = iy1 >= n;
+    v4 c00, c10, c01, c11;
+    const v4 zero = { 0.0f, 0.0f, 0.0f, 0.0f };
+    c00 = (ox0 && oy0) ? zero : cubeTexel(s, faces, face, ix0, iy0);
+    c10 = (ox1 && oy0) ? zero : cubeTexel(s, faces, face, ix1, iy0);
+    c01 = (ox0 && oy1) ? zero : cubeTexel(s, faces, face, ix0, iy1);
+    c11 = (ox1 && oy1) ? zero : cubeTexel(s, faces, face, ix1, iy1);
+    if ((ox0 || ox1) && (oy0 || oy1))
+    {
+        const float third = 1.0f / 3.0f;
+        const v4 sum = { (c00.x + c10.x) + (c01.x + c11.x), (c00.y + c10.y) + (c01.y + c11.y), (c00.z + c10.z) + (c01.z + c11.z),
+                         (c00.w + c10.w) + (c01.w + c11.w) };
+        const v4 mean = { sum.x * third, sum.y * third, sum.z * third, sum.w * third };
+        if (ox0 && oy0) c00 = mean;
+        else if (ox1 && oy0) c10 = mean;
+        else if (ox0 && oy1) c01 = mean;
+        else c11 = mean;
+    }
+    const v4 top = v4_lerp(c00, c10, ax);
+    const v4 bot = v4_lerp(c01, c11, ax);
     return v4_lerp(top, bot, ay);
 }
 
 /* texture(samplerCube, dir): face selection and (s, t) of the Vulkan spec's cube map face selection
- * tables (largest magnitude, z before y before x on ties); filtering stays inside the selected face
- * (the seamless edge blend of the hardware sampler is not reproduced). */
+ * tables; bilinear filtering with seamless edges. */
 static v4 sampleCube(const PtoScene *s, const OTexture *faces, v3 r)
 {
-    const float ax = fabsf(r.x), ay = fabsf(r.y), az = fabsf(r.z);
     uint32_t face;
     float sc, tc, ma;
-    if (az >= ax && az >= ay)
-    {
-        face = r.z < 0.0f ? 5u : 4u;
-        sc = r.z < 0.0f ? -r.x : r.x;
-        tc = -r.y;
-        ma = az;
-    }
-    else if (ay >= ax)
-    {
-        face = r.y < 0.0f ? 3u : 2u;
-        sc = r.x;
-        tc = r.y < 0.0f ? -r.z : r.z;
-        ma = ay;
-    }
-    else
-    {
-        face = r.x < 0.0f ? 1u : 0u;
-        sc = r.x < 0.0f ? r.z : -r.z;
-        tc = -r.y;
-        ma = ax;
-    }
+    cubeFace(r, &face, &sc, &tc, &ma);
     const float u = 0.5f * (sc / ma) + 0.5f, v = 0.5f * (tc / ma) + 0.5f;
-    return sampleFace(s, &faces[face], u, v);
+    return sampleFaceSeamless(s, faces, face, u, v);
 }
 
 /* miss.rmiss:16-39 */

@@ -1126,29 +1126,11 @@ PT_DEV f2 missSkyboxTexCoords(f3 dir) // miss.rmiss:20-25
     return F2(longitude / 2.0f / PI + 0.5f, latitude / PI + 0.5f);
 }
 
-PT_DEV f4 sampleFace(const TextureView &tv, const DevTexture &t, float u, float v) // clamp-to-edge bilinear inside one cube face
-{
-    const uint32_t w = t.width, h = t.height;
-    if (!(abs_(u) < 1e9f)) u = 0.0f;
-    if (!(abs_(v) < 1e9f)) v = 0.0f;
-    const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
-    const float x0 = __builtin_floorf(x), y0 = __builtin_floorf(y);
-    const float ax = x - x0, ay = y - y0;
-    const float mx = (float)(w - 1), my = (float)(h - 1);
-    const uint32_t ix0 = (uint32_t)clamp_(x0, 0.0f, mx), ix1 = (uint32_t)clamp_(x0 + 1.0f, 0.0f, mx);
-    const uint32_t iy0 = (uint32_t)clamp_(y0, 0.0f, my), iy1 = (uint32_t)clamp_(y0 + 1.0f, 0.0f, my);
-    const f4 top = lerp4(fetchTexel(tv, t, 0, ix0, iy0), fetchTexel(tv, t, 0, ix1, iy0), ax);
-    const f4 bot = lerp4(fetchTexel(tv, t, 0, ix0, iy1), fetchTexel(tv, t, 0, ix1, iy1), ax);
-    return lerp4(top, bot, ay);
-}
-
-// texture(samplerCube, dir): face and (s, t) by the Vulkan cube map face selection tables (largest
-// magnitude, z before y before x on ties); filtering stays inside the selected face.
-PT_DEV f4 sampleCube(const TextureView &tv, const DevTexture *faces, f3 r)
+// Cube map face selection of the Vulkan specification (largest magnitude, z before y before x on ties): face and the
+// face coordinates (sc, tc) with major axis length ma.
+PT_DEV void cubeFace(f3 r, uint32_t &face, float &sc, float &tc, float &ma)
 {
     const float ax = abs_(r.x), ay = abs_(r.y), az = abs_(r.z);
-    uint32_t face;
-    float sc, tc, ma;
     if (az >= ax && az >= ay)
     {
         face = r.z < 0.0f ? 5u : 4u;
@@ -1170,8 +1152,90 @@ PT_DEV f4 sampleCube(const TextureView &tv, const DevTexture *faces, f3 r)
         tc = -r.y;
         ma = ax;
     }
+}
+
+// Texel (ix, iy) of a face, where ONE of the indices may lie one step outside 0 .. n-1: the texel across that edge
+// (seamless cube maps, Vulkan "Cube Map Edge Handling": the reference's sampler filters across face borders).  The texel
+// centre, folded over the edge onto the cube's surface, goes through the face selection again: the index along the edge is
+// kept, the index across it becomes the neighbour's border row.
+PT_DEV f4 cubeTexel(const TextureView &tv, const DevTexture *faces, uint32_t face, int ix, int iy)
+{
+    const int n = (int)faces[face].width;
+    if (ix >= 0 && ix < n && iy >= 0 && iy < n)
+        return fetchTexel(tv, faces[face], 0, (uint32_t)ix, (uint32_t)iy);
+    float sc = 2.0f * (((float)ix + 0.5f) / (float)n) - 1.0f, tc = 2.0f * (((float)iy + 0.5f) / (float)n) - 1.0f, ma = 1.0f;
+    if (ix < 0 || ix >= n)
+    {
+        ma = 1.0f - (abs_(sc) - 1.0f);
+        sc = sc < 0.0f ? -1.0f : 1.0f;
+    }
+    else
+    {
+        ma = 1.0f - (abs_(tc) - 1.0f);
+        tc = tc < 0.0f ? -1.0f : 1.0f;
+    }
+    f3 r; // inverse of the selection table
+    if (face == 0u) r = F3(ma, -tc, -sc);
+    else if (face == 1u) r = F3(-ma, -tc, sc);
+    else if (face == 2u) r = F3(sc, ma, tc);
+    else if (face == 3u) r = F3(sc, -ma, -tc);
+    else if (face == 4u) r = F3(sc, -tc, ma);
+    else r = F3(-sc, -tc, -ma);
+    uint32_t f2;
+    float s2, t2, m2;
+    cubeFace(r, f2, s2, t2, m2);
+    const float mx = (float)(n - 1);
+    const uint32_t jx = (uint32_t)clamp_(__builtin_floorf((0.5f * (s2 / m2) + 0.5f) * (float)n), 0.0f, mx);
+    const uint32_t jy = (uint32_t)clamp_(__builtin_floorf((0.5f * (t2 / m2) + 0.5f) * (float)n), 0.0f, mx);
+    return fetchTexel(tv, faces[f2], 0, jx, jy);
+}
+
+// bilinear lookup at (u, v) of a face with the footprint continuing on the neighbouring faces; at a corner of the cube,
+// where three faces meet and the fourth texel does not exist, it is the mean of the other three (Vulkan "Cube Map Corner
+// Handling")
+PT_DEV f4 sampleFaceSeamless(const TextureView &tv, const DevTexture *faces, uint32_t face, float u, float v)
+{
+    const int n = (int)faces[face].width;
+    if (!(abs_(u) < 1e9f)) u = 0.0f;
+    if (!(abs_(v) < 1e9f)) v = 0.0f;
+    const float x = u * (float)n - 0.5f, y = v * (float)n - 0.5f;
+    const float x0 = __builtin_floorf(x), y0 = __builtin_floorf(y);
+    const float ax = x - x0, ay = y - y0;
+    const int ix0 = (int)x0, iy0 = (int)y0, ix1 = ix0 + 1, iy1 = iy0 + 1;
+    const bool ox0 = ix0 < 0, ox1 = ix1 >= n, oy0 = iy0 < 0, oy1 = iy1 >= n;
+    f4 zero;
+    zero.x = zero.y = zero.z = zero.w = 0.0f;
+    f4 c00 = (ox0 && oy0) ? zero : cubeTexel(tv, faces, face, ix0, iy0);
+    f4 c10 = (ox1 && oy0) ? zero : cubeTexel(tv, faces, face, ix1, iy0);
+    f4 c01 = (ox0 && oy1) ? zero : cubeTexel(tv, faces, face, ix0, iy1);
+    f4 c11 = (ox1 && oy1) ? zero : cubeTexel(tv, faces, face, ix1, iy1);
+    if ((ox0 || ox1) && (oy0 || oy1))
+    {
+        const float third = 1.0f / 3.0f;
+        f4 mean;
+        mean.x = ((c00.x + c10.x) + (c01.x + c11.x)) * third;
+        mean.y = ((c00.y + c10.y) + (c01.y + c11.y)) * third;
+        mean.z = ((c00.z + c10.z) + (c01.z + c11.z)) * third;
+        mean.w = ((c00.w + c10.w) + (c01.w + c11.w)) * third;
+        if (ox0 && oy0) c00 = mean;
+        else if (ox1 && oy0) c10 = mean;
+        else if (ox0 && oy1) c01 = mean;
+        else c11 = mean;
+    }
+    const f4 top = lerp4(c00, c10, ax);
+    const f4 bot = lerp4(c01, c11, ax);
+    return lerp4(top, bot, ay);
+}
+
+// texture(samplerCube, dir): face and (s, t) by the Vulkan cube map face selection tables; bilinear filtering with
+// seamless edges.
+PT_DEV f4 sampleCube(const TextureView &tv, const DevTexture *faces, f3 r)
+{
+    uint32_t face;
+    float sc, tc, ma;
+    cubeFace(r, face, sc, tc, ma);
     const float u = 0.5f * (sc / ma) + 0.5f, v = 0.5f * (tc / ma) + 0.5f;
-    return sampleFace(tv, faces[face], u, v);
+    return sampleFaceSeamless(tv, faces, face, u, v);
 }
 
 // payload.Emissive of miss.rmiss:16-39 (Pdf = -1 is the caller's path termination)

@@ -93,3 +93,73 @@ def test_reuse_mesh_cubes_image_matches_oracle(pkg, orc, backend):
     img, ref = util.render_pair(pkg, orc, "reuse_mesh_cubes", 1.0, 160, 90, frames=2, depth=6, backend=backend)
     differing = int((img.view(np.uint32) != ref.view(np.uint32)).any(axis=-1).sum())
     assert differing == 0, f"{differing} pixels are not bit-identical (rel-L2 {util.rel_l2(img, ref)})"
+
+
+class _TextureDesc(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("format", C.c_uint32), ("levels", C.c_uint32), ("data", C.c_void_p)]
+
+
+_FACE_COLOURS = np.float32([[1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 0], [0, 1, 1], [1, 0, 1]])  # +X -X +Y -Y +Z -Z
+
+
+def _flat_cube_sky(scene, n=4):
+    """The scene's description with no geometry and a cube sky of six constant n x n float faces."""
+    faces = [np.broadcast_to(np.append(c, 1).astype(np.float32), (n, n, 4)).copy() for c in _FACE_COLOURS]
+    arr = (_TextureDesc * 6)(*[_TextureDesc(n, n, 2, 1, f.ctypes.data) for f in faces])
+    d = _empty_copy(scene.desc)
+    d.skyboxKind = 2
+    d.skybox = C.addressof(arr)
+    return d, (arr, faces, scene)
+
+
+def _look(scene, direction, W, H):
+    scene.set_camera_pose((0, 0, 0), direction)
+    return scene.uniform(W, H, bounces=1, sample_count=1)
+
+
+def test_cube_sky_filters_across_face_edges(pkg, orc):
+    """Vulkan cube maps are seamless: within half a texel of a face border the bilinear footprint continues on the
+    neighbouring face, and at a corner of the cube the missing fourth texel is the mean of the other three."""
+    s = pkg.Scene("reuse_mesh_cubes")
+    d, keep = _flat_cube_sky(s)
+    osc = orc.OracleScene(d)
+    W, H = 97, 55
+    # the +X / +Z edge: the centre column looks exactly along the border
+    img, _ = osc.render(_look(s, (1, 0, 1), W, H), s.lights, W, H)
+    row = img[H // 2, :, :3]
+    px, pz = _FACE_COLOURS[0], _FACE_COLOURS[4]
+    wx = row @ px / (px @ px)  # share of the +X colour along the row (the two colours are orthogonal)
+    wz = row @ pz / (pz @ pz)
+    assert np.allclose(wx + wz, 1, atol=1e-5) and abs(wx[W // 2] - 0.5) < 0.06
+    mixed = (wx > 0.05) & (wx < 0.95)
+    assert mixed.sum() >= 5, "a hard step between the faces: the footprint stopped at the border"
+    assert (np.abs(np.diff(wx)) < 0.2).all(), "no jump along the row"
+    assert {round(float(wx[0])), round(float(wx[-1]))} == {0, 1}
+    # the +X +Y +Z corner: its centre pixel sees the three faces in equal parts
+    img, _ = osc.render(_look(s, (1, 1, 1), W, H), s.lights, W, H)
+    c = img[H // 2, W // 2, :3]
+    assert np.allclose(c, (_FACE_COLOURS[0] + _FACE_COLOURS[2] + _FACE_COLOURS[4]) / 3, atol=0.05), c
+    # far from any border nothing changes: a face's own colour
+    img, _ = osc.render(_look(s, (0, -1, 0.001), W, H), s.lights, W, H)
+    assert np.allclose(img[H // 2, W // 2, :3], _FACE_COLOURS[3], atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_seamless_cube_sky_matches_oracle(pkg, orc, gpu_renderer):
+    s = pkg.Scene("reuse_mesh_cubes")
+    W, H = 160, 90
+    for n in (1, 4, 7):
+        d, keep = _flat_cube_sky(s, n)
+        rng = np.random.default_rng(n)
+        for f in keep[1]:  # texels that differ: every neighbour relation shows
+            f[...] = rng.uniform(0, 2, f.shape).astype(np.float32)
+        gpu_renderer.upload(d)
+        gpu_renderer.resize(W, H)
+        osc = orc.OracleScene(d)
+        for look in ((1, 0, 1), (1, 1, 1), (-1, 1, -1), (0, 1, 0.01), (-1, -0.02, 1), (0.3, -1, -1)):
+            u = _look(s, look, W, H)
+            gpu_renderer.reset()
+            gpu_renderer.render(u, s.lights)
+            ref, _ = osc.render(u, s.lights, W, H)
+            img = gpu_renderer.readback()
+            assert (img.view(np.uint32) == ref.view(np.uint32)).all(), (n, look)
