@@ -1,4 +1,5 @@
 #include "SceneImporter.h"
+#include "FbxReader.h"
 
 #include <algorithm>
 #include <cmath>
@@ -151,6 +152,12 @@ Gltf LoadGltf(const std::filesystem::path &path)
     const std::vector<uint8_t> file = ReadFileBytes(path);
     std::vector<uint8_t> glbBin;
     std::string text;
+    if (IsBinaryFbx(file)) // FbxReader.h: the same document, built from the FBX records
+    {
+        g.buffers.emplace_back();
+        ConvertFbxToGltf(file, g.json, g.buffers.back());
+        return g;
+    }
     if (file.size() >= 20 && !std::memcmp(file.data(), "glTF", 4))
     {
         auto le32 = [&](size_t o) { return uint32_t(file[o]) | (uint32_t(file[o + 1]) << 8) | (uint32_t(file[o + 2]) << 16) | (uint32_t(file[o + 3]) << 24); };
@@ -258,6 +265,20 @@ const Json &TextureRef(const Json &material, TextureType type, bool specGloss)
     static const Json none;
     const Json &pbr = material["pbrMetallicRoughness"];
     const Json &sg = material["extensions"]["KHR_materials_pbrSpecularGlossiness"];
+    if (material["extras"].Has("assimp")) // an FBX material: the aiTextureType lists of GetTextureTypes (SceneImporter.cpp:33-66)
+    {
+        const Json &slots = material["extras"]["assimp"]["textures"];
+        switch (type)
+        {
+        case TextureType::Color: return slots["DIFFUSE"];
+        case TextureType::Normal: return slots["NORMALS"];
+        case TextureType::Emisive: return slots["EMISSIVE"];
+        case TextureType::Specular: return slots["SPECULAR"];
+        case TextureType::Glossiness:
+        case TextureType::Shininess: return slots["SHININESS"];
+        default: return none; // DIFFUSE_ROUGHNESS / METALNESS: the FBX converter never fills them
+        }
+    }
     switch (type)
     {
     case TextureType::Color: return specGloss ? sg["diffuseTexture"] : pbr["baseColorTexture"];
@@ -299,7 +320,7 @@ uint32_t AddTexture(SceneBuilder &sb, const Gltf &g, const Json &material, Textu
             info = TextureImporter::GetTextureInfo(bytes, slot, std::move(name), isTransparent);
         }
         else
-            info = TextureImporter::GetTextureInfo(g.base / UriDecode(image["uri"].Str()), slot, std::move(name), isTransparent);
+            info = TextureImporter::GetTextureInfo((g.base / UriDecode(image["uri"].Str())).lexically_normal(), slot, std::move(name), isTransparent);
         return sb.AddTexture(std::move(info));
     }
     catch (const error &)
@@ -317,6 +338,15 @@ void Copy3(float *dst, const Json &a, float fallback)
 // SceneImporter.cpp:300-319 on what assimp would expose for a glTF material
 MaterialType ChooseMaterialType(const Json &material)
 {
+    if (material["extras"].Has("assimp")) // what assimp's FBX converter sets: never the metallic / roughness factors
+    {
+        const Json &a = material["extras"]["assimp"];
+        if (a.Has("shininess"))
+            return MaterialType::Phong;
+        if (a.Has("specularFactor"))
+            return MaterialType::SpecularGlossiness;
+        return MaterialType::MetallicRoughness;
+    }
     if (material.Has("pbrMetallicRoughness"))
         return MaterialType::MetallicRoughness;
     if (material["extensions"].Has("KHR_materials_pbrSpecularGlossiness"))
@@ -340,6 +370,12 @@ std::vector<MaterialInfo> LoadMaterials(SceneBuilder &sb, const Gltf &g, const T
         MaterialType type = ChooseMaterialType(m);
         if (std::holds_alternative<MetallicRoughnessTextureMapping>(textureMapping)) type = MaterialType::MetallicRoughness;
         if (std::holds_alternative<SpecularGlossinessTextureMapping>(textureMapping)) type = MaterialType::SpecularGlossiness;
+        if (std::holds_alternative<PhongTextureMapping>(textureMapping)) type = MaterialType::Phong;
+        // SceneImporter.cpp:390-393: the Phong case has no `break` and runs into `default: throw` -- a material that assimp
+        // describes by a shininess (every classic FBX / OBJ material) loads only under a mapping that forces another model,
+        // which is how the reference's own FBX scenes are set up (ExampleScenes.cpp:96-141).  Reproduced, not fixed.
+        if (type == MaterialType::Phong)
+            throw error("Unsupported material type");
 
         // LoadEmissive (:104-141) / LoadTransmission (:151-167)
         float emissiveColor[3] = { 0, 0, 0 }, emissiveIntensity = 1.0f;
@@ -396,9 +432,13 @@ std::vector<MaterialInfo> LoadMaterials(SceneBuilder &sb, const Gltf &g, const T
             std::memset(&out, 0, sizeof(out));
             std::memcpy(out.EmissiveColor, emissiveColor, 12);
             out.EmissiveIntensity = emissiveIntensity;
+            const Json &fbx = m["extras"]["assimp"]; // AI_MATKEY_COLOR_DIFFUSE / SPECULAR_FACTOR of an FBX material
+            const Json &diffuse = fbx.Has("diffuse") ? fbx["diffuse"] : sg["diffuseFactor"];
             for (size_t k = 0; k < 4; k++)
-                out.Color[k] = sg["diffuseFactor"].Size() > k ? static_cast<float>(sg["diffuseFactor"][k].Num()) : 1.0f;
+                out.Color[k] = diffuse.Size() > k ? static_cast<float>(diffuse[k].Num()) : 1.0f;
             Copy3(out.Specular, sg["specularFactor"], 1.0f);
+            if (fbx.Has("specularFactor")) // a float read as a colour: only the first component arrives
+                out.Specular[0] = static_cast<float>(fbx["specularFactor"].Num(1.0));
             out.Glossiness = static_cast<float>(sg["glossinessFactor"].Num(1.0));
             std::memcpy(out.AttenuationColor, attenuationColor, 12);
             out.AttenuationDistance = attenuationDistance;
@@ -557,6 +597,37 @@ SceneBuilder &SceneImporter::AddFile(SceneBuilder &sb, const std::filesystem::pa
                 }
             }
 
+            // aiProcess_CalcTangentSpace (the reference's import flags, SceneImporter.cpp:1066-1068) for a mesh that has texture
+            // coordinates but no tangents -- every FBX mesh, glTF primitives without TANGENT: per triangle the directions of
+            // increasing u and v (on the coordinates aiProcess_FlipUVs has already turned), summed per vertex, then made
+            // orthogonal to the normal.  assimp joins the per-face results of vertices within 45 degrees; the shared indexed
+            // vertex does the same job here.
+            std::vector<float> faceT, faceB;
+            if (tan.empty() && !uv.empty())
+            {
+                faceT.assign(pos.size(), 0.0f);
+                faceB.assign(pos.size(), 0.0f);
+                for (size_t f = 0; f + 2 < idx.size(); f += 3)
+                {
+                    const uint32_t i0 = idx[f], i1 = idx[f + 1], i2 = idx[f + 2];
+                    const Vec3 p0(pos[i0 * 3], pos[i0 * 3 + 1], pos[i0 * 3 + 2]);
+                    const Vec3 e1 = Vec3(pos[i1 * 3], pos[i1 * 3 + 1], pos[i1 * 3 + 2]) - p0, e2 = Vec3(pos[i2 * 3], pos[i2 * 3 + 1], pos[i2 * 3 + 2]) - p0;
+                    float sx = uv[i1 * 2] - uv[i0 * 2], sy = (1.0f - uv[i1 * 2 + 1]) - (1.0f - uv[i0 * 2 + 1]);
+                    float tx = uv[i2 * 2] - uv[i0 * 2], ty = (1.0f - uv[i2 * 2 + 1]) - (1.0f - uv[i0 * 2 + 1]);
+                    const float dir = (tx * sy - ty * sx) < 0.0f ? -1.0f : 1.0f;
+                    if (sx * ty == sy * tx) // degenerate mapping: assimp substitutes an axis-aligned one
+                    {
+                        sx = 0.0f; sy = 1.0f; tx = 1.0f; ty = 0.0f;
+                    }
+                    const Vec3 ft = (e2 * sy - e1 * ty) * dir, fb = (e1 * tx - e2 * sx) * dir; // towards growing u, growing v
+                    for (uint32_t v : { i0, i1, i2 })
+                    {
+                        faceT[v * 3] += ft.x; faceT[v * 3 + 1] += ft.y; faceT[v * 3 + 2] += ft.z;
+                        faceB[v * 3] += fb.x; faceB[v * 3 + 1] += fb.y; faceB[v * 3 + 2] += fb.z;
+                    }
+                }
+            }
+
             const uint32_t vo = static_cast<uint32_t>(out.animated ? animatedVertices.size() : vertices.size());
             const uint32_t io = static_cast<uint32_t>(out.animated ? animatedIndices.size() : indices.size());
             for (uint32_t v = 0; v < vertexCount; v++)
@@ -567,6 +638,24 @@ SceneBuilder &SceneImporter::AddFile(SceneBuilder &sb, const std::filesystem::pa
                 {
                     t = Vec3(tan[v * 4], tan[v * 4 + 1], tan[v * 4 + 2]);
                     b = Cross(n, t) * tan[v * 4 + 3];
+                    if (Same(n, t) || Same(n, b) || Same(t, b)) // :520-528
+                        std::tie(t, b) = ComputeTangentSpace(n);
+                }
+                else if (!faceT.empty())
+                {
+                    const Vec3 st(faceT[v * 3], faceT[v * 3 + 1], faceT[v * 3 + 2]), sb(faceB[v * 3], faceB[v * 3 + 1], faceB[v * 3 + 2]);
+                    Vec3 lt = st - n * Dot(n, st);
+                    const float tl = std::sqrt(Dot(lt, lt));
+                    if (tl > 0.0f && std::isfinite(tl))
+                    {
+                        lt = lt * (1.0f / tl);
+                        Vec3 lb = sb - n * Dot(n, sb) - lt * Dot(lt, sb);
+                        const float bl = std::sqrt(Dot(lb, lb));
+                        t = lt;
+                        b = (bl > 0.0f && std::isfinite(bl)) ? lb * (1.0f / bl) : Cross(n, lt);
+                    }
+                    else
+                        std::tie(t, b) = ComputeTangentSpace(n);
                     if (Same(n, t) || Same(n, b) || Same(t, b)) // :520-528
                         std::tie(t, b) = ComputeTangentSpace(n);
                 }
