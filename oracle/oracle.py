@@ -49,6 +49,8 @@ def load() -> C.CDLL:
         lib.pto_trace_closest.argtypes = [P, P, C.c_uint32, P, C.c_int]
         lib.pto_trace_any.argtypes = [P, P, C.c_uint32, P, C.c_int]
         lib.pto_test_eval.argtypes = [C.c_uint32, P, P, C.c_uint32]
+        lib.pto_test_raygen.argtypes = [P, P, C.c_uint32]
+        lib.pto_test_closest_hit.argtypes = [P, P, P, P, C.c_uint32]
         lib.pto_test_texture.argtypes = [P, P, P, C.c_uint32, C.c_int]
         lib.pto_postprocess.argtypes = [P, C.c_uint32, C.c_uint32, P, C.c_uint32, P]
         lib.pto_encode_output.argtypes = [P, C.c_uint32, C.c_uint32, C.c_uint32, P]
@@ -98,6 +100,14 @@ class OracleScene:
         self.lib.pto_test_texture(self.handle, inputs.ctypes.data, out.ctypes.data, inputs.shape[0], int(implicit_lod))
         return out
 
+    def test_closest_hit(self, lights, inputs: np.ndarray) -> np.ndarray:
+        """pto_test_closest_hit: closestHit.rchit main() on triangle 0 for rows of 28 words (layout in pt_oracle.c)."""
+        inputs = np.ascontiguousarray(inputs, np.uint32).reshape(-1, 28)
+        out = np.zeros((inputs.shape[0], 35), np.uint32)
+        if self.lib.pto_test_closest_hit(self.handle, C.addressof(lights), inputs.ctypes.data, out.ctypes.data, inputs.shape[0]):
+            raise RuntimeError("pto_test_closest_hit failed")
+        return out
+
     def trace_closest(self, rays: np.ndarray, brute_force: bool = False):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
         hits = np.zeros(rays.shape[0], dtype=[("t", "f4"), ("u", "f4"), ("v", "f4"), ("tri", "u4")])
@@ -127,6 +137,21 @@ def test_eval(fn: int, inputs: np.ndarray, nout: int) -> np.ndarray:
     rc = lib.pto_test_eval(fn, inputs.ctypes.data, out.ctypes.data, n)
     if rc:
         raise RuntimeError("pto_test_eval failed")
+    return out
+
+
+RAYGEN_IN_WORDS, RAYGEN_OUT_WORDS = 44 + 12 * 23, 7
+
+
+def test_raygen(inputs: np.ndarray) -> np.ndarray:
+    """pto_test_raygen: raygen.rgen main() for one pixel per row, trace calls scripted (layout in pt_oracle.c)."""
+    lib = load()
+    inputs = np.ascontiguousarray(inputs, np.uint32)
+    if inputs.ndim != 2 or inputs.shape[1] != RAYGEN_IN_WORDS:
+        raise ValueError(f"a case is {RAYGEN_IN_WORDS} words, got {inputs.shape}")
+    out = np.zeros((inputs.shape[0], RAYGEN_OUT_WORDS), np.uint32)
+    if lib.pto_test_raygen(inputs.ctypes.data, out.ctypes.data, inputs.shape[0]):
+        raise RuntimeError("pto_test_raygen failed")
     return out
 
 

@@ -2287,11 +2287,67 @@ static inline void missShader(const PtoScene *s, v3 rayDir, Payload *payload)
 /* raygen.rgen                                                              */
 /* ======================================================================== */
 
+/* Scripted trace calls (pto_test_raygen): the stage-level golden vectors of tests/golden/golden_stage_*.json run the
+ * reference's raygen.rgen main() with traceRayEXT replaced by a script -- record k of the script is what the closest-hit /
+ * miss stage leaves in the payload on the k-th primary trace (and whether the shadow query of that bounce is occluded);
+ * past the end of the script a trace misses into black.  The same script drives raygenPixel here, so the loop itself
+ * (RNG draws, the order of the radiance / throughput updates, roulette, the NaN / inf restart) is compared with the
+ * reference's text, not with a second restatement.  Every ray handed to a trace call is folded into a hash. */
+#define PTO_SCRIPT_RECORDS 12
+#define PTO_SCRIPT_RECORD_WORDS 23
+typedef struct
+{
+    const uint32_t *records; /* PTO_SCRIPT_RECORDS x PTO_SCRIPT_RECORD_WORDS */
+    uint32_t calls0, calls1, hash;
+} TraceScript;
+static __thread TraceScript *g_script;
+
+static void scriptHashRay(v3 o, float tmin, v3 d, float tmax)
+{
+    const float f[8] = { o.x, o.y, o.z, tmin, d.x, d.y, d.z, tmax };
+    for (int k = 0; k < 8; k++)
+        g_script->hash = (g_script->hash ^ f2u(f[k])) * 16777619u;
+}
+
+static void scriptedClosest(Payload *payload, Ray ray)
+{
+    scriptHashRay(ray.Origin, ray.tmin, ray.Direction, ray.tmax);
+    const uint32_t k = g_script->calls0++;
+    if (k >= PTO_SCRIPT_RECORDS)
+    {
+        payload->Emissive = v3s(0.0f);
+        payload->Pdf = -1.0f;
+        return;
+    }
+    const uint32_t *r = &g_script->records[k * PTO_SCRIPT_RECORD_WORDS];
+    payload->Position = V3(u2f(r[0]), u2f(r[1]), u2f(r[2]));
+    payload->Direction = V3(u2f(r[3]), u2f(r[4]), u2f(r[5]));
+    payload->Emissive = V3(u2f(r[6]), u2f(r[7]), u2f(r[8]));
+    payload->Bsdf = V3(u2f(r[9]), u2f(r[10]), u2f(r[11]));
+    payload->Pdf = u2f(r[12]);
+    payload->DirectLight = V3(u2f(r[13]), u2f(r[14]), u2f(r[15]));
+    payload->DirectLightPdf = u2f(r[16]);
+    payload->LightDirection = V3(u2f(r[17]), u2f(r[18]), u2f(r[19]));
+    payload->LightDistance = u2f(r[20]);
+    for (uint32_t d = 0; d < r[21]; d++) /* the draws the hit stage would have made */
+        (void)rnd(&payload->RngState);
+}
+
+static int scriptedOccluded(v3 position, v3 direction, float tmin, float tmax)
+{
+    scriptHashRay(position, tmin, direction, tmax);
+    g_script->calls1++;
+    const uint32_t k = g_script->calls0 - 1; /* the bounce that asked */
+    return k < PTO_SCRIPT_RECORDS ? g_script->records[k * PTO_SCRIPT_RECORD_WORDS + 22] != 0u : 1;
+}
+
 /* raygen.rgen:22-34 */
 static inline int checkOccluded(const PtoScene *s, v3 lightDir, v3 position, float dist, int brute, PtoStats *st)
 {
     const v3 direction = v_neg(v_normalize(lightDir));
     st->shadowRays++;
+    if (g_script)
+        return scriptedOccluded(position, direction, 0.00001f, dist);
     return traceAny(s, position, direction, 0.00001f, dist, brute, st);
 }
 
@@ -2335,18 +2391,23 @@ static void raygenPixel(const PtoScene *s, const PtxRaygenUniformData *U, const 
             payload.LightDirection = v3s(0.0f);
             payload.LightDistance = 0.0f;
             st->segments++;
-            Decal decal;
-            const PtoHit hit = traceClosest(s, ray.Origin, ray.Direction, ray.tmin, ray.tmax, brute, st, &decal);
-            if (decal.dist != -1.0f) /* anyhit.rahit:57-59 */
-            {
-                payload.LightDirection = decal.color;
-                payload.LightDistance = decal.alpha;
-                payload.DirectLightPdf = decal.dist;
-            }
-            if (hit.tri == 0xffffffffu)
-                missShader(s, ray.Direction, &payload);
+            if (g_script)
+                scriptedClosest(&payload, ray);
             else
-                closestHit(s, lights, ray.Origin, ray.Direction, &hit, &payload);
+            {
+                Decal decal;
+                const PtoHit hit = traceClosest(s, ray.Origin, ray.Direction, ray.tmin, ray.tmax, brute, st, &decal);
+                if (decal.dist != -1.0f) /* anyhit.rahit:57-59 */
+                {
+                    payload.LightDirection = decal.color;
+                    payload.LightDistance = decal.alpha;
+                    payload.DirectLightPdf = decal.dist;
+                }
+                if (hit.tri == 0xffffffffu)
+                    missShader(s, ray.Direction, &payload);
+                else
+                    closestHit(s, lights, ray.Origin, ray.Direction, &hit, &payload);
+            }
             rngState = payload.RngState;
 
             if (payload.Pdf == -1.0f)
@@ -2698,6 +2759,103 @@ int pto_test_eval(uint32_t fn, const float *in, float *out, uint32_t n)
         }
         default: return 1;
         }
+    }
+    return 0;
+}
+
+/* raygen.rgen:36-118 with scripted trace calls.  One case = 44 + 12 x 23 words:
+ *   [0] pixel x, [1] pixel y, [2] width, [3] height, [4] TotalSamples, [5] SampleCount, [6] BounceCount, [7] LensRadius,
+ *   [8] FocalDistance, [9..24] ViewInverse, [25..40] ProjInverse (column-major), [41..43] the pixel's previous sum,
+ *   then 12 records { Position, Direction, Emissive, Bsdf, Pdf, DirectLight, DirectLightPdf, LightDirection,
+ *   LightDistance, draws, occluded }.
+ * Output, 7 words: the stored pixel (rgba), primary trace calls, shadow trace calls, hash of every traced ray. */
+int pto_test_raygen(const uint32_t *in, uint32_t *out, uint32_t n)
+{
+    if (!in || !out)
+        return 1;
+    const uint32_t stride = 44 + PTO_SCRIPT_RECORDS * PTO_SCRIPT_RECORD_WORDS;
+    for (uint32_t i = 0; i < n; i++)
+    {
+        const uint32_t *a = &in[(size_t)i * stride];
+        PtxRaygenUniformData U;
+        memset(&U, 0, sizeof(U));
+        for (int k = 0; k < 16; k++)
+        {
+            U.ViewInverse[k] = u2f(a[9 + k]);
+            U.ProjInverse[k] = u2f(a[25 + k]);
+        }
+        U.TotalSamples = a[4];
+        U.SampleCount = a[5];
+        U.BounceCount = a[6];
+        U.LensRadius = u2f(a[7]);
+        U.FocalDistance = u2f(a[8]);
+        const uint32_t W = a[2], H = a[3];
+        if (a[0] >= W || a[1] >= H || (uint64_t)W * H > (1u << 24))
+            return 1;
+        TraceScript script = { &a[44], 0u, 0u, 2166136261u };
+        PtoStats st;
+        memset(&st, 0, sizeof(st));
+        /* raygenPixel addresses the image by pixel: give it a one-pixel window */
+        float *accum = (float *)calloc((size_t)W * H, 16);
+        if (!accum)
+            return 1;
+        float *p = &accum[((size_t)a[1] * W + a[0]) * 4];
+        p[0] = u2f(a[41]); p[1] = u2f(a[42]); p[2] = u2f(a[43]);
+        g_script = &script;
+        raygenPixel(NULL, &U, NULL, a[0], a[1], W, H, accum, 0, &st);
+        g_script = NULL;
+        uint32_t *o = &out[(size_t)i * 7];
+        for (int k = 0; k < 4; k++)
+            o[k] = f2u(p[k]);
+        o[4] = script.calls0;
+        o[5] = script.calls1;
+        o[6] = script.hash;
+        free(accum);
+    }
+    return 0;
+}
+
+/* closestHit.rchit:52-161 on triangle 0 of the scene.  One case = 28 words: ray origin, direction, hit distance, the two
+ * hit attributes (barycentrics of vertex 1 and 2), then the payload as raygen / the any-hit stage leave it: RngState,
+ * MaxRoughness, DirectLightPdf (decal distance or -1), LightDirection (decal colour), LightDistance (decal alpha) and the
+ * two differential rays (origin, direction each).  Output, 35 words: Position, Direction, MaxRoughness, Bsdf, Pdf,
+ * Emissive, RngState, DirectLight, DirectLightPdf, LightDirection, LightDistance, the differential rays.
+ * Checked against tests/golden/golden_stage_*.json (the reference's closestHit.rchit text, tools/gen_golden.py). */
+int pto_test_closest_hit(const PtoScene *s, const PtxLightsUbo *lights, const uint32_t *in, uint32_t *out, uint32_t n)
+{
+    if (!s || !lights || !in || !out || s->triCount == 0)
+        return 1;
+    for (uint32_t i = 0; i < n; i++)
+    {
+        const uint32_t *a = &in[(size_t)i * 28];
+        const v3 origin = V3(u2f(a[0]), u2f(a[1]), u2f(a[2])), dir = V3(u2f(a[3]), u2f(a[4]), u2f(a[5]));
+        PtoHit hit;
+        memset(&hit, 0, sizeof(hit));
+        hit.t = u2f(a[6]);
+        hit.u = u2f(a[7]);
+        hit.v = u2f(a[8]);
+        hit.tri = 0u;
+        Payload p;
+        memset(&p, 0, sizeof(p));
+        p.RngState = a[9];
+        p.MaxRoughness = u2f(a[10]);
+        p.DirectLightPdf = u2f(a[11]);
+        p.LightDirection = V3(u2f(a[12]), u2f(a[13]), u2f(a[14]));
+        p.LightDistance = u2f(a[15]);
+        p.diff.rxOrigin = V3(u2f(a[16]), u2f(a[17]), u2f(a[18]));
+        p.diff.rxDirection = V3(u2f(a[19]), u2f(a[20]), u2f(a[21]));
+        p.diff.ryOrigin = V3(u2f(a[22]), u2f(a[23]), u2f(a[24]));
+        p.diff.ryDirection = V3(u2f(a[25]), u2f(a[26]), u2f(a[27]));
+        closestHit(s, lights, origin, dir, &hit, &p);
+        const float o[35] = { p.Position.x, p.Position.y, p.Position.z, p.Direction.x, p.Direction.y, p.Direction.z, p.MaxRoughness,
+                              p.Bsdf.x, p.Bsdf.y, p.Bsdf.z, p.Pdf, p.Emissive.x, p.Emissive.y, p.Emissive.z, 0.0f,
+                              p.DirectLight.x, p.DirectLight.y, p.DirectLight.z, p.DirectLightPdf,
+                              p.LightDirection.x, p.LightDirection.y, p.LightDirection.z, p.LightDistance,
+                              p.diff.rxOrigin.x, p.diff.rxOrigin.y, p.diff.rxOrigin.z, p.diff.rxDirection.x, p.diff.rxDirection.y, p.diff.rxDirection.z,
+                              p.diff.ryOrigin.x, p.diff.ryOrigin.y, p.diff.ryOrigin.z, p.diff.ryDirection.x, p.diff.ryDirection.y, p.diff.ryDirection.z };
+        for (int k = 0; k < 35; k++)
+            out[(size_t)i * 35 + (size_t)k] = f2u(o[k]);
+        out[(size_t)i * 35 + 14] = p.RngState;
     }
     return 0;
 }

@@ -18,8 +18,11 @@
  * material.glsl:55-171 as C++ through a builtin shim; vectors in tests/golden/).  The
  * shim's bit-exact mode takes pow / sin / cos from pt_oracle_math.h, so for those three
  * builtins the pin is structural; golden_libm.json (glibc) checks the kernels
- * independently.  The stage-level code (raygen, closestHit, miss, any-hit, traversal,
- * sampler) is restated by reading and checked by the closed forms of
+ * independently.  Two stage bodies are pinned the same way (golden_stage_*.json): the
+ * main() of raygen.rgen with its trace calls scripted (pto_test_raygen) and the main() of
+ * closestHit.rchit over a one-triangle scene (pto_test_closest_hit).  What the Vulkan
+ * driver and sampler do (tree, ray / triangle test, textureGrad) and the small miss /
+ * any-hit bodies are restated by reading and checked by the closed forms of
  * tests/test_analytic.py.  Image-level parity is UNPINNED by the reference -- "parity
  * unpinned": it holds no reference image, its tests assert finiteness only, and it
  * cannot be built here (Vulkan RT + 11 absent submodules) -- see DESIGN.md section 2.
@@ -93,6 +96,11 @@ PTX_API int pto_test_post(uint32_t which, const float *in, float *out, uint32_t 
 
 /* Function-level entry, same packing as ptx_test_eval (include/ptx.h). */
 PTX_API int pto_test_eval(uint32_t fn, const float *in, float *out, uint32_t n);
+/* Stage level: raygen.rgen main() for one pixel with scripted trace calls (layout at the definition); checked against
+ * tests/golden/golden_stage_*.json, which tools/gen_golden.py produces from the reference's raygen.rgen text. */
+PTX_API int pto_test_raygen(const uint32_t *in, uint32_t *out, uint32_t n);
+/* closestHit.rchit main() on triangle 0 of a scene, for given hits and incoming payloads (layout at the definition) */
+PTX_API int pto_test_closest_hit(const PtoScene *s, const PtxLightsUbo *lights, const uint32_t *in, uint32_t *out, uint32_t n);
 
 #ifdef __cplusplus
 }

@@ -40,6 +40,130 @@ def test_oracle_against_reference_glsl_with_libm(orc):
         assert err.max() <= TRANSCENDENTAL[name], f"{name}: {err.max()}"
 
 
+def test_oracle_raygen_loop_against_reference_main(orc):
+    """Stage level: raygen.rgen's main() -- compiled from the reference's text with the trace calls scripted -- against
+    the oracle's raygenPixel driven by the same script: the stored pixel, the number of primary and shadow trace calls
+    and a hash of every ray handed to them.  Covers the draws per sample (pixel jitter, lens), the order of the radiance /
+    throughput updates, the 0.001 gates, roulette, paths that end on a miss, and the NaN / inf restart of the sample loop."""
+    import json
+    import os
+
+    for mode in ("fixed", "libm"):
+        with open(os.path.join(util.GOLDEN_DIR, f"golden_stage_{mode}.json")) as f:
+            c = json.load(f)["raygenMain"]
+        inp = np.array(c["in"], np.uint32).reshape(-1, c["nin"])
+        exp = np.array(c["out"], np.uint32).reshape(-1, c["nout"])
+        out = orc.test_raygen(inp)
+        lens = inp[:, 7] != 0  # a thin-lens case draws through sin / cos: exact in the fixed build only
+        exact = np.ones(len(inp), bool) if mode == "fixed" else ~lens
+        ok = util.bits_equal_or_both_nan(out, exp).all(axis=1)
+        assert ok[exact].all(), f"{mode}: {int((~ok[exact]).sum())} of {int(exact.sum())} cases differ"
+        assert (out[:, 4:6] == exp[:, 4:6]).all(), "trace call counts"
+        of, ef = out[~exact, :3].view(np.float32), exp[~exact, :3].view(np.float32)
+        assert np.allclose(of, ef, rtol=1e-5, atol=1e-6)
+        # the cases do exercise what they are meant to
+        if mode == "fixed":
+            calls0, calls1 = exp[:, 4].astype(int), exp[:, 5].astype(int)
+            assert calls0.max() >= 12 and (calls0 == 0).any() and calls1.max() >= 3 and lens.sum() >= 50
+            restarted = calls0 > inp[:, 5].astype(int) * np.maximum(inp[:, 6].astype(int), 1)
+            assert restarted.sum() >= 5, "some scripts must poison a sample and make the loop start over"
+
+
+def _one_triangle_scene(pkg, words):
+    """PtxSceneDesc + lights of one closestHitMain case: a triangle with identity transforms, one material of the case's
+    model, five 1 x 1 float textures (a lookup returns the texel, whatever the coordinates), 0..3 point lights."""
+    import ctypes as C
+
+    class Tex(C.Structure):
+        _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("format", C.c_uint32), ("levels", C.c_uint32), ("data", C.c_void_p)]
+
+    f = words.view(np.float32)
+    keep = {}
+    keep["v"] = np.ascontiguousarray(f[0:42])
+    keep["i"] = np.uint32([0, 1, 2])
+    ident = np.float32([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0])
+    keep["t"] = ident.copy()
+    keep["g"] = np.zeros(1, util.GEOMETRY_DT)
+    keep["g"][0] = (0, 3, 0, 3, 1, 0, (0, 0))
+    mtype, flip = int(words[42]), int(words[43])
+    image = words[44:68].copy()
+    first = 19 if mtype == 0 else 18  # the five texture indices of the 96-byte record (include/ptx.h)
+    image[first:first + 5] += 9       # scene textures follow the nine default ones
+    keep["m"] = image
+    keep["mesh"] = np.zeros(1, util.MESH_DT)
+    keep["mesh"][0] = (0, mtype, 0)
+    keep["model"] = np.zeros(1, util.MODEL_DT)
+    keep["model"][0] = (0, 1)
+    keep["inst"] = np.zeros(1, util.INSTANCE_DT)
+    keep["inst"][0] = (0, ident)
+    keep["texels"] = [np.ascontiguousarray(f[68 + 4 * k:72 + 4 * k]) for k in range(5)]
+    keep["tex"] = (Tex * 5)(*[Tex(1, 1, 2, 1, t.ctypes.data) for t in keep["texels"]])
+    d = pkg.SceneDesc()
+    d.vertices, d.vertexCount = keep["v"].ctypes.data, 3
+    d.indices, d.indexCount = keep["i"].ctypes.data, 3
+    d.transforms, d.transformCount = keep["t"].ctypes.data, 1
+    d.geometries, d.geometryCount = keep["g"].ctypes.data, 1
+    for k, (ptr, cnt) in enumerate((("metallicRoughnessMaterials", "metallicRoughnessMaterialCount"), ("specularGlossinessMaterials", "specularGlossinessMaterialCount"),
+                                     ("phongMaterials", "phongMaterialCount"))):
+        if k == mtype:
+            setattr(d, ptr, keep["m"].ctypes.data)
+            setattr(d, cnt, 1)
+    d.meshes, d.meshCount = keep["mesh"].ctypes.data, 1
+    d.models, d.modelCount = keep["model"].ctypes.data, 1
+    d.instances, d.instanceCount = keep["inst"].ctypes.data, 1
+    d.textures, d.textureCount = C.addressof(keep["tex"]), 5
+    d.dxNormalTextures = flip
+    d.textureMemoryBudget = 2**64 - 1
+    L = pkg.LightsUbo()
+    L.LightCount = int(words[88])
+    for k in range(3):
+        L.Directional.Direction[k], L.Directional.Color[k] = f[89 + k], f[92 + k]
+    for n in range(3):
+        b = 95 + 9 * n
+        for k in range(3):
+            L.Lights[n].Position[k], L.Lights[n].Color[k] = f[b + k], f[b + 3 + k]
+        L.Lights[n].AttenuationConstant, L.Lights[n].AttenuationLinear, L.Lights[n].AttenuationQuadratic = f[b + 6], f[b + 7], f[b + 8]
+    return d, L, keep
+
+
+def test_oracle_closest_hit_against_reference_main(orc, pkg):
+    """Stage level: closestHit.rchit's main() -- the reference's text over a one-triangle vertex buffer, with its own
+    vertex fetch, interpolation and transform() -- against the oracle's closestHit on the same triangle, material, lights,
+    hit and incoming payload: every payload field bit for bit (fixed build; the libm build within the tolerance of its
+    transcendentals).  Covers the order of the RNG draws (BSDF lobe, then three for the light), hits from inside
+    (flipped frame, Beer-Lambert on the hit distance, refracted origin and differential rays), the decal mix, the
+    roughness ratchet, all three material models with DX normal maps, 0..3 point lights + the directional one."""
+    import json
+    import os
+
+    for mode in ("fixed", "libm"):
+        with open(os.path.join(util.GOLDEN_DIR, f"golden_stage_{mode}.json")) as f:
+            c = json.load(f)["closestHitMain"]
+        inp = np.array(c["in"], np.uint32).reshape(-1, c["nin"])
+        exp = np.array(c["out"], np.uint32).reshape(-1, c["nout"])
+        assert inp.shape[1] == 150 and exp.shape[1] == 35 and len(inp) >= 300
+        bad = 0
+        inside = refracted = decals = 0
+        for row, want in zip(inp, exp):
+            d, L, keep = _one_triangle_scene(pkg, row)
+            got = orc.OracleScene(d, build_bvh=False).test_closest_hit(L, row[122:150])[0]
+            wf = want.view(np.float32)
+            inside += int(wf[10] != 0 and keep["m"].view(np.float32)[11 if int(row[42]) == 0 else 21] > 0)
+            decals += int(row[133:134].view(np.float32)[0] != -1.0)
+            if mode == "fixed":
+                bad += int(not util.bits_equal_or_both_nan(got, want).all())
+            else:
+                assert got[14] == want[14], "RNG state"
+                gf = got.view(np.float32)
+                fin = np.isfinite(wf) & np.isfinite(gf)
+                assert (np.isfinite(wf) == np.isfinite(gf)).all()
+                err = np.abs(gf[fin].astype(np.float64) - wf[fin]) / np.maximum(1.0, np.abs(wf[fin]))
+                err[14] = 0.0
+                assert err.max() < 2e-4, float(err.max())
+        assert bad == 0, f"{bad} of {len(inp)} payloads differ"
+        assert decals >= 20
+
+
 def test_reference_test_properties(orc):
     """The three properties the reference's own tests assert (ShadingTest.cpp: finite outputs on
     the TestData.h grids; BsdfTest.cpp:34-40: lobe weights sum to 1 within 4 ULP)."""

@@ -14,7 +14,9 @@ once the GLSL builtins are supplied by tools/glsl_shim.hpp.  This script
   3. writes the result into a TEMP directory (reference text is never copied into the
      repo), appends tools/golden_main.inc and compiles with g++ -ffp-contract=off,
   4. runs it twice -- libm transcendentals (golden_libm.json) and the fixed polynomial
-     kernels (-DSHIM_FIXED, golden_fixed.json) -- and stores the vectors.
+     kernels (-DSHIM_FIXED, golden_fixed.json) -- and stores the vectors; each build also
+     emits the stage-level cases (golden_stage_*.json): raygen.rgen's main() with scripted
+     trace calls and closestHit.rchit's main() over a one-triangle scene.
 
 Only inputs/outputs (uint32 bit patterns) are committed.
 """
@@ -50,7 +52,7 @@ def rewrite(text: str) -> str:
     text = re.sub(r"\binout\s+(\w+)\s+(\w+)", r"\1& \2", text)
     text = re.sub(r"\bout\s+(\w+)\s+(\w+)", r"\1& \2", text)
     text = FLOAT_LIT.sub(r"\1f", text)
-    text = re.sub(r"\.(xyz|xy|yz|zw|rgb)\b", r".\1()", text)
+    text = re.sub(r"\.(xyz|yzw|xy|yz|zw|rgb)\b", r".\1()", text)
     # GLSL evaluates call arguments left to right (GLSL 4.60 6.1.1); C++ only does so
     # for braced initialisers, and the draw order of rand() is part of the contract.
     text = re.sub(r"\bvec([23])\(((?:rand\(rngState\)(?:,\s*)?)+)\)", r"vec\1{\2}", text)
@@ -115,6 +117,40 @@ def main():
                      "MetallicRoughnessMaterial metallicRoughnessMaterials[1]; SpecularGlossinessMaterial specularGlossinessMaterials[1]; "
                      "PhongMaterial phongMaterials[1];")
         parts.append(rewrite(lines(os.path.join(REF, "material.glsl"), [(4, 23), (55, 171)])))
+        # ---- stage level: raygen.rgen:22-118 (checkOccluded + main) with the trace calls scripted.  The launch built-ins, the
+        # uniform block, the payload and the image become globals of a nested namespace; traceRayEXT hands out the records
+        # of a script (golden_main.inc) -- so what is pinned is the loop itself: RNG draws, the order of the radiance /
+        # throughput updates, roulette, the NaN / inf restart
+        parts.append("// ---- raygen.rgen")
+        parts.append("namespace stage_raygen {")
+        sr = os.path.join(REF, "ShaderRendererTypes.incl")
+        parts.append(extract_struct(sr, "RaygenUniformData"))
+        parts.append(extract_struct(sr, "Payload"))
+        parts.append(rewrite(lines(sr, [(124, 127)])))
+        parts.append("RaygenUniformData mainUniform; Payload payload; bool isOccluded; uvec2 gl_LaunchIDEXT, gl_LaunchSizeEXT;\n"
+                     "const int u_TopLevelAS = 0, gl_RayFlagsTerminateOnFirstHitEXT = 4, gl_RayFlagsNoneEXT = 0;\n"
+                     "struct Image { vec4 previous, stored; } u_Image;\n"
+                     "inline vec4 imageLoad(Image &i, ivec2) { return i.previous; }\n"
+                     "inline void imageStore(Image &i, ivec2, vec4 v) { i.stored = v; }\n"
+                     "void traceRayEXT(int, int, int, uint, int, uint, vec3 origin, float tmin, vec3 direction, float tmax, int payloadLocation);")
+        parts.append(rewrite(lines(os.path.join(REF, "raygen.rgen"), [(22, 118)])).replace("void main()", "void raygenMain()"))
+        parts.append("} // namespace stage_raygen")
+        # ---- stage level: closestHit.rchit:52-161 main().  Buffers, the shader record, the hit attributes and the ray
+        # built-ins become globals; the vertex fetch (common.glsl:27-46, 124-130) and transform() (sampling.glsl:5-15) are
+        # the reference's text over a one-triangle vertex / index buffer; textures are one texel each, as for sampleMaterial
+        parts.append("// ---- closestHit.rchit")
+        parts.append("namespace stage_hit {")
+        parts.append(extract_struct(sr, "Payload"))
+        parts.append(extract_struct(sr, "SBTBuffer"))
+        parts.append(rewrite(lines(sr, [(97, 99)])))  # HitFlags*
+        parts.append("struct VertexBuffer { const vec2 *v; }; struct IndexBuffer { const uint *v; };\n"
+                     "struct Geometry { VertexBuffer Vertices; IndexBuffer Indices; };\n"
+                     "Geometry geometries[1]; mat3x4 transforms[1]; mat3x4 gl_ObjectToWorld3x4EXT; SBTBuffer sbt; Payload payload; vec3 attribs;\n"
+                     "uint s_HitFlags; int gl_PrimitiveID; vec3 gl_WorldRayOriginEXT, gl_WorldRayDirectionEXT; float gl_RayTmaxEXT;")
+        parts.append(rewrite(lines(os.path.join(REF, "common.glsl"), [(27, 46), (124, 130)])))
+        parts.append(rewrite(lines(os.path.join(REF, "sampling.glsl"), [(5, 15)])))
+        parts.append(rewrite(lines(os.path.join(REF, "closestHit.rchit"), [(52, 161)])).replace("void main()", "void closestHitMain()"))
+        parts.append("} // namespace stage_hit")
         parts.append("} // namespace glsl")
         parts.append('#include "%s/golden_main.inc"' % HERE)
         cpp = os.path.join(tmp, "golden.cpp")
@@ -125,6 +161,10 @@ def main():
             subprocess.check_call(cmd)
             data = subprocess.check_output([exe])
             dst = os.path.join(OUT, "golden_%s.json" % mode)
+            open(dst, "wb").write(data)
+            print("wrote", os.path.relpath(dst), len(data), "bytes")
+            data = subprocess.check_output([exe, "stage"])  # the stage-level cases go into their own file
+            dst = os.path.join(OUT, "golden_stage_%s.json" % mode)
             open(dst, "wb").write(data)
             print("wrote", os.path.relpath(dst), len(data), "bytes")
 

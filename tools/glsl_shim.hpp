@@ -25,6 +25,13 @@ struct uvec2
     uint x, y;
     uvec2() {}
     uvec2(uint a, uint b) : x(a), y(b) {}
+    uvec2 xy() const { return *this; }
+};
+struct ivec2
+{
+    int x, y;
+    ivec2() {}
+    explicit ivec2(uvec2 u) : x((int)u.x), y((int)u.y) {}
 };
 struct vec2
 {
@@ -66,6 +73,9 @@ struct vec4
     explicit vec4(float s) : x(s), y(s), z(s), w(s) {}
     vec4(float a_, float b_, float c, float d) : x(a_), y(b_), z(c), w(d) {}
     vec4(vec3 v, float d) : x(v.x), y(v.y), z(v.z), w(d) {}
+    vec4(vec2 a_, vec2 b_) : x(a_.x), y(a_.y), z(b_.x), w(b_.y) {}
+    vec4(float a_, vec3 v) : x(a_), y(v.x), z(v.y), w(v.z) {}
+    vec3 yzw() const { return vec3(y, z, w); }
     vec3 xyz() const { return vec3(x, y, z); }
     vec3 rgb() const { return vec3(x, y, z); }
     vec2 xy() const { return vec2(x, y); }
@@ -77,9 +87,20 @@ struct mat3
     mat3() {}
     mat3(vec3 a, vec3 b, vec3 d) { c[0] = a; c[1] = b; c[2] = d; }
 };
+struct mat3x4 // 3 columns of 4 rows (the transposed affine transform the reference stores per mesh)
+{
+    vec4 c[3];
+    mat3x4() {}
+};
 struct mat4
 {
     float m[16]; // [col*4+row]
+    mat4() {}
+    explicit mat4(const mat3x4 &a) // GLSL: the missing column comes from the identity
+    {
+        for (int k = 0; k < 3; k++) { m[k * 4] = a.c[k].x; m[k * 4 + 1] = a.c[k].y; m[k * 4 + 2] = a.c[k].z; m[k * 4 + 3] = a.c[k].w; }
+        m[12] = m[13] = m[14] = 0.0f; m[15] = 1.0f;
+    }
 };
 
 // ---- operators -------------------------------------------------------------
@@ -106,6 +127,7 @@ inline vec3 operator*(float s, vec3 a) { return vec3(s * a.x, s * a.y, s * a.z);
 inline vec3 operator/(vec3 a, float s) { return vec3(a.x / s, a.y / s, a.z / s); }
 inline vec3 operator/(vec3 a, uint s) { return a / (float)s; } // implicit uint -> float conversion
 inline vec3 operator/(vec3 a, vec3 b) { return vec3(a.x / b.x, a.y / b.y, a.z / b.z); }
+inline vec3 &operator/=(vec3 &a, vec3 b) { a = a / b; return a; }
 
 inline vec3 operator*(const mat3 &m, vec3 v)
 {
@@ -116,6 +138,61 @@ inline vec4 operator*(const mat4 &m, vec4 v)
 {
     const v4 r = m4_mul(m.m, v.x, v.y, v.z, v.w);
     return vec4(r.x, r.y, r.z, r.w);
+}
+
+inline float dot(vec4 a, vec4 b) { return ((a.x * b.x + a.y * b.y) + a.z * b.z) + a.w * b.w; }
+inline vec3 operator*(vec4 v, const mat3x4 &m) { return vec3(dot(v, m.c[0]), dot(v, m.c[1]), dot(v, m.c[2])); } // row vector x matrix
+inline vec4 operator*(vec4 v, const mat4 &m)
+{
+    vec4 r;
+    float *o = &r.x;
+    for (int c = 0; c < 4; c++)
+        o[c] = dot(v, vec4(m.m[c * 4], m.m[c * 4 + 1], m.m[c * 4 + 2], m.m[c * 4 + 3]));
+    return r;
+}
+inline mat3x4 operator*(const mat4 &a, const mat3x4 &b) // (4 x 4) . (4 rows x 3 columns)
+{
+    mat3x4 r;
+    for (int c = 0; c < 3; c++)
+    {
+        const vec4 col = a * b.c[c];
+        r.c[c] = col;
+    }
+    return r;
+}
+inline mat4 transpose(const mat4 &a)
+{
+    mat4 r;
+    for (int c = 0; c < 4; c++)
+        for (int k = 0; k < 4; k++)
+            r.m[c * 4 + k] = a.m[k * 4 + c];
+    return r;
+}
+inline mat4 inverse(const mat4 &a) // cofactor expansion
+{
+    const float *m = a.m;
+    float inv[16];
+    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    const float det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    mat4 r;
+    for (int k = 0; k < 16; k++)
+        r.m[k] = inv[k] / det;
+    return r;
 }
 
 // ---- builtins --------------------------------------------------------------
