@@ -1027,6 +1027,23 @@ typedef struct Decal
 
 static v4 hitBaseColor(const PtoScene *s, uint32_t tri, float u, float v);
 
+/* anyhit.rahit:36-64 for one candidate of a non-opaque geometry: 1 = ignoreIntersectionEXT (alpha < 0.5), having
+ * remembered the candidate as the decal if it is nearer than the one the payload holds */
+static inline int anyHitIgnores(const PtoScene *s, uint32_t tri, float t, float u, float v, Decal *decal)
+{
+    const v4 color = hitBaseColor(s, tri, u, v);
+    if (!(color.w < 0.5f))
+        return 0;
+    if (decal && (decal->dist == -1.0f || t < decal->dist || (t == decal->dist && tri < decal->tri)))
+    {
+        decal->dist = t;
+        decal->color = V3(color.x, color.y, color.z);
+        decal->alpha = color.w;
+        decal->tri = tri;
+    }
+    return 1;
+}
+
 /* closest hit: min t, ties broken by the smaller global triangle id */
 static inline void considerTri(const PtoScene *s, uint32_t tri, v3 o, v3 d, float tmin, float tmax, PtoHit *best, Decal *decal)
 {
@@ -1035,21 +1052,8 @@ static inline void considerTri(const PtoScene *s, uint32_t tri, v3 o, v3 d, floa
     /* accept t == best.t only for a smaller id: test against nextafter(lim) via <= below */
     if (!intersectTri(&s->v0[tri * 3], &s->e1[tri * 3], &s->e2[tri * 3], o, d, tmin, tmax, &t, &u, &v))
         return;
-    if (s->pairs[s->triPair[tri]].nonOpaque) /* anyhit.rahit:36-64 */
-    {
-        const v4 color = hitBaseColor(s, tri, u, v);
-        if (color.w < 0.5f)
-        {
-            if (decal && (decal->dist == -1.0f || t < decal->dist || (t == decal->dist && tri < decal->tri)))
-            {
-                decal->dist = t;
-                decal->color = V3(color.x, color.y, color.z);
-                decal->alpha = color.w;
-                decal->tri = tri;
-            }
-            return; /* ignoreIntersectionEXT */
-        }
-    }
+    if (s->pairs[s->triPair[tri]].nonOpaque && anyHitIgnores(s, tri, t, u, v, decal))
+        return; /* ignoreIntersectionEXT */
     if (best->tri == 0xffffffffu || t < lim || (t == lim && tri < best->tri))
     {
         best->t = t;
@@ -2856,6 +2860,32 @@ int pto_test_closest_hit(const PtoScene *s, const PtxLightsUbo *lights, const ui
         for (int k = 0; k < 35; k++)
             out[(size_t)i * 35 + (size_t)k] = f2u(o[k]);
         out[(size_t)i * 35 + 14] = p.RngState;
+    }
+    return 0;
+}
+
+/* anyhit.rahit:36-64 and occlusionAnyhit.rahit:35-53 for one candidate hit on triangle 0 (which must belong to a
+ * non-opaque geometry).  One case = 8 words: hit attributes u, v, the candidate's distance, then the decal the payload
+ * holds: DirectLightPdf (distance or -1), LightDirection (colour), LightDistance (alpha).  Output, 7 words: ignored by the
+ * closest-hit query (0 / 1), ignored by the shadow query, and the payload's decal fields afterwards. */
+int pto_test_any_hit(const PtoScene *s, const uint32_t *in, uint32_t *out, uint32_t n)
+{
+    if (!s || !in || !out || s->triCount == 0)
+        return 1;
+    for (uint32_t i = 0; i < n; i++)
+    {
+        const uint32_t *a = &in[(size_t)i * 8];
+        Decal d;
+        d.dist = u2f(a[3]);
+        d.color = V3(u2f(a[4]), u2f(a[5]), u2f(a[6]));
+        d.alpha = u2f(a[7]);
+        d.tri = 0u; /* not above the candidate's id: an equal distance keeps the payload's decal, as `dist < payload.DirectLightPdf` does */
+        uint32_t *o = &out[(size_t)i * 7];
+        o[0] = (uint32_t)anyHitIgnores(s, 0u, u2f(a[2]), u2f(a[0]), u2f(a[1]), &d);
+        o[1] = (uint32_t)occlusionIgnores(s, 0u, u2f(a[0]), u2f(a[1]));
+        o[2] = f2u(d.dist);
+        o[3] = f2u(d.color.x); o[4] = f2u(d.color.y); o[5] = f2u(d.color.z);
+        o[6] = f2u(d.alpha);
     }
     return 0;
 }

@@ -164,6 +164,36 @@ def test_oracle_closest_hit_against_reference_main(orc, pkg):
         assert decals >= 20
 
 
+def test_oracle_any_hit_against_reference_mains(orc, pkg):
+    """Stage level: anyhit.rahit's and occlusionAnyhit.rahit's main() from the reference's text against the oracle's
+    any-hit decisions for one candidate: ignored by the closest-hit query (alpha < 0.5), ignored by the shadow query
+    (alpha < 1), and the decal the payload holds afterwards (replaced only by a nearer candidate)."""
+    import ctypes as C
+    import json
+    import os
+
+    with open(os.path.join(util.GOLDEN_DIR, "golden_stage_fixed.json")) as f:
+        c = json.load(f)["anyHitMain"]
+    inp = np.array(c["in"], np.uint32).reshape(-1, c["nin"])
+    exp = np.array(c["out"], np.uint32).reshape(-1, c["nout"])
+    assert len(inp) >= 300 and 0.2 < exp[:, 0].mean() < 0.8 and exp[:, 1].mean() > exp[:, 0].mean()
+    replaced = 0
+    for row, want in zip(inp, exp):
+        # the closestHitMain scene builder wants 122 words: vertices, type, flag, material, five texels, lights
+        words = np.zeros(150, np.uint32)
+        words[0:42] = row[0:42]
+        words[42] = row[42]
+        words[44:68] = row[43:67]
+        words[44 + (20 if int(row[42]) == 0 else 19)] = 1  # ColorIdx -> the second one-texel texture
+        words[72:76] = row[67:71]
+        d, L, keep = _one_triangle_scene(pkg, words)
+        keep["g"][0]["IsOpaque"] = 0  # the any-hit stages run for non-opaque geometry only
+        got = orc.OracleScene(d, build_bvh=False).test_any_hit(row[71:79])[0]
+        assert util.bits_equal_or_both_nan(got[None], want[None]).all(), (row[71:79].view(np.float32), got, want)
+        replaced += int(got[2] != row[74])
+    assert replaced >= 50
+
+
 def test_reference_test_properties(orc):
     """The three properties the reference's own tests assert (ShadingTest.cpp: finite outputs on
     the TestData.h grids; BsdfTest.cpp:34-40: lobe weights sum to 1 within 4 ULP)."""

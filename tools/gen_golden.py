@@ -150,6 +150,14 @@ def main():
         parts.append(rewrite(lines(os.path.join(REF, "common.glsl"), [(27, 46), (124, 130)])))
         parts.append(rewrite(lines(os.path.join(REF, "sampling.glsl"), [(5, 15)])))
         parts.append(rewrite(lines(os.path.join(REF, "closestHit.rchit"), [(52, 161)])).replace("void main()", "void closestHitMain()"))
+        # the two any-hit stages (anyhit.rahit:36-64, occlusionAnyhit.rahit:35-53) over the same globals; material.glsl:25-54
+        # supplies getColorTextureIdx / getColorFactor; ignoreIntersectionEXT sets a flag
+        parts.append("bool g_ignored;\n#define ignoreIntersectionEXT g_ignored = true\n"
+                     "inline vec4 texture(const Sampler2D &s, vec2) { return s.texel; }")
+        parts.append(rewrite(lines(os.path.join(REF, "material.glsl"), [(25, 54)])))
+        parts.append(rewrite(lines(os.path.join(REF, "anyhit.rahit"), [(36, 65)])).replace("void main()", "void anyHitMain()"))
+        parts.append(rewrite(lines(os.path.join(REF, "occlusionAnyhit.rahit"), [(35, 54)])).replace("void main()", "void occlusionAnyHitMain()"))
+        parts.append("#undef ignoreIntersectionEXT")
         parts.append("} // namespace stage_hit")
         parts.append("} // namespace glsl")
         parts.append('#include "%s/golden_main.inc"' % HERE)

@@ -140,6 +140,7 @@ inline vec4 operator*(const mat4 &m, vec4 v)
     return vec4(r.x, r.y, r.z, r.w);
 }
 
+inline vec4 operator*(vec4 a, vec4 b) { return vec4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 inline float dot(vec4 a, vec4 b) { return ((a.x * b.x + a.y * b.y) + a.z * b.z) + a.w * b.w; }
 inline vec3 operator*(vec4 v, const mat3x4 &m) { return vec3(dot(v, m.c[0]), dot(v, m.c[1]), dot(v, m.c[2])); } // row vector x matrix
 inline vec4 operator*(vec4 v, const mat4 &m)
