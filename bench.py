@@ -23,7 +23,7 @@ all_gather of the tile shards per step.  The reported metric is the NAMED frame 
 is the same frame at 8 N spp, which is how BASELINE configs[3] and [4] are posed) is measured in the same run and
 printed in `weak`.
 
-Frames in flight (`--in-flight`, default 3 on one GPU, 4 on two, 8 on four and more): consecutive steps run on renderers that take turns, each on its own stream
+Frames in flight (`--in-flight`, default 3 on one GPU, 12 per rank on several -- a tile shard is a small frame): consecutive steps run on renderers that take turns, each on its own stream
 with its own path state, as the reference keeps frames in flight (Renderer.cpp:1454-1460): ptx_render only enqueues a
 frame -- the bounce loop is driven from the device -- so the latency-bound end of one frame overlaps the head of the
 next.  Every step is still one complete frame: reset, 8 spp, gather, read-back.
@@ -131,7 +131,7 @@ class Job:
         self.scene = pkg.Scene(scene_name, args.detail)
         self.lights = self.scene.lights
         backend = pkg.BACKEND_WAVEFRONT if args.backend == "wavefront" else pkg.BACKEND_MEGAKERNEL
-        self.F = args.in_flight if args.in_flight > 0 else (3 if self.shard_world_hint(shard, world) == 1 else 4 if self.shard_world_hint(shard, world) <= 2 else 8)
+        self.F = args.in_flight if args.in_flight > 0 else (3 if self.shard_world_hint(shard, world) == 1 else 12)
         self.streams = [torch.cuda.Stream() for _ in range(self.F)]
         self.rs = [pkg.Renderer(device=local_rank, backend=backend, stream=s.cuda_stream) for s in self.streams]
         self.shard_rank, self.shard_world = shard if shard else (rank, world)
@@ -345,9 +345,9 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--tile", type=int, default=32)
     ap.add_argument("--in-flight", type=int, default=0,
-                    help="frames in flight: renderers (own stream, own path state) taking the steps in turn; 0 = 3 on one GPU, 4 on two, "
-                         "8 on four and more (a rank's share of the frame shrinks with the world size and its kernels with it: measured on "
-                         "one GPU, a 1/8 tile shard takes 3.21 / 2.01 / 1.96 / 1.80 ms per step with 1 / 2 / 4 / 8 frames in flight)")
+                    help="frames in flight: renderers (own stream, own path state) taking the steps in turn; 0 = 3 on one GPU, 12 per "
+                         "rank on several (a rank's share of the frame shrinks with the world size and its kernels with it: measured on "
+                         "one GPU, a 1/8 tile shard takes 3.0 / 1.92 / 1.82 / 1.73 ms per step with 1 / 4 / 8 / 12 frames in flight)")
     ap.add_argument("--backend", default="wavefront", choices=["wavefront", "megakernel"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
