@@ -11,7 +11,8 @@
 //   k_generate        raygen.rgen:38-60   RNG seed, primary ray
 //   k_trace_closest   raygen.rgen:68      closest-hit query over the active queue
 //   k_shade           closestHit.rchit / miss.rmiss + raygen.rgen:71-96 bookkeeping
-//   k_trace_shadow    raygen.rgen:22-34,79-81  occlusion query + NEE add, path finish
+//   k_trace_shadow    raygen.rgen:22-34   occlusion query: one answer per shadow-queue entry
+//   k_apply_shadow    raygen.rgen:79-81   NEE add of the visible lights, finish of the paths that ended on this bounce
 //   k_accumulate      raygen.rgen:115-117  image += radiance, in frame order
 //
 // Every path slot is (frame, pixel); its state lives in SoA arrays in HBM; queues hold
@@ -57,6 +58,7 @@ struct Wavefront // device pointers of the per-slot state (SoA)
     float4 *diff[3]; // payload.RayDifferentials0..2 (rx origin, rx dir, ry origin, ry dir); null unless the scene has textures
     uint32_t *queue[2];
     uint32_t *shadowQueue;
+    uint8_t *shadowResult; // per shadow queue entry: bit 0 = the light is visible, bit 1 = the path ends here (k_apply_shadow)
     uint32_t *restartQueue;
     uint32_t *counters; // see enum Counter
     uint32_t *spill;    // traversal stack overflow region [kGlobalSpill][kMaxPersistentThreads]
@@ -712,15 +714,11 @@ struct ShadowIO
 {
     static constexpr float kFixedTmin = 0.00001f; // raygen.rgen:26
     static constexpr bool kNeedsPrim = false;
-    const LaunchParams &p;
     const Wavefront &wf;
-    int qout;
-    uint32_t slot;
     float finished;
-    uint32_t nSamples, nRetries;
     PT_DEV bool load(uint32_t item, f3 &o, f3 &d, float &tmin, float &tmax)
     {
-        slot = wf.shadowQueue[item];
+        const uint32_t slot = wf.shadowQueue[item];
         const float4 o4 = wf.shO[slot], d4 = wf.shD[slot];
         o = F3(o4.x, o4.y, o4.z);
         d = F3(d4.x, d4.y, d4.z);
@@ -730,30 +728,10 @@ struct ShadowIO
         return true;
     }
     PT_DEV void ignored(float, float, float, uint32_t, uint32_t, uint32_t, const TraceScene &) {} // shadow rays keep no decal
-    PT_DEV void store(uint32_t, const Hit &, bool occluded)
-    {
-        float4 r4 = wf.rad[slot];
-        if (!occluded)
-        {
-            const float4 c = wf.shC[slot];
-            r4.x = r4.x + c.x;
-            r4.y = r4.y + c.y;
-            r4.z = r4.z + c.z;
-        }
-        bool restart = false;
-        if (finished != 0.0f)
-        {
-            uint4 meta = wf.meta[slot];
-            f3 radiance = F3(r4.x, r4.y, r4.z);
-            restart = finishSample(p, wf, slot, meta, radiance, nSamples, nRetries);
-            if (restart)
-                wf.meta[slot].z = meta.z;
-        }
-        else
-            wf.rad[slot] = r4; // the slot is already in the next queue (k_shade)
-        // the slot cannot join the next queue directly: k_trace_closest of the next bounce may already be consuming it
-        pushRestarts(wf, restart, slot);
-    }
+    // The traversal only records the answer.  What follows from it -- the NEE add into rad[slot], finishing the sample of a
+    // path that ended on this bounce -- is k_apply_shadow's: inside the traversal loop those dependent loads and stores
+    // sat in the retire phase of nearly every round for a handful of lanes (shadow rounds took 1.8x a closest round).
+    PT_DEV void store(uint32_t item, const Hit &, bool occluded) { wf.shadowResult[item] = (uint8_t)((occluded ? 0u : 1u) | (finished != 0.0f ? 2u : 0u)); }
 };
 
 template <bool ALPHA>
@@ -763,12 +741,56 @@ PT_DEV void traceShadowBody(const LaunchParams &p, const TraceScene &sc, const W
     if (count == 0u)
         return;
     PT_DECLARE_STACK(st, kLdsStack, wf.spill)
-    ShadowIO io = { p, wf, qout, 0u, 0.0f, 0u, 0u };
+    ShadowIO io = { wf, 0.0f };
     persistentTrace<true, ALPHA>(sc, io, count, &wf.counters[shadowChunkCounter(parity)], st);
     if (st.overflow)
         atomicAdd(&wf.counters[C_OVERFLOW], 1u);
-    waveAddCounter(&wf.counters[C_SAMPLES], io.nSamples);
-    waveAddCounter(&wf.counters[C_RETRIES], io.nRetries);
+    (void)p;
+    (void)qout;
+}
+
+// raygen.rgen:79-81 after the occlusion query, one thread per shadow queue entry: a visible light adds the contribution
+// k_shade prepared; a path that ended on this bounce is finished (its slot may be due a new sample: restart queue).
+__global__ void __launch_bounds__(kBlock) k_apply_shadow(LaunchParams p, Wavefront wf, int parity)
+{
+    const uint32_t count = wf.counters[shadowCounter(parity)];
+    uint32_t nSamples = 0, nRetries = 0;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x)
+    {
+        const uint32_t item = base + threadIdx.x;
+        bool restart = false;
+        uint32_t slot = 0;
+        if (item < count)
+        {
+            const uint32_t result = wf.shadowResult[item];
+            slot = wf.shadowQueue[item];
+            if (result)
+            {
+                float4 r4 = wf.rad[slot];
+                if (result & 1u)
+                {
+                    const float4 c = wf.shC[slot];
+                    r4.x = r4.x + c.x;
+                    r4.y = r4.y + c.y;
+                    r4.z = r4.z + c.z;
+                }
+                if (result & 2u)
+                {
+                    uint4 meta = wf.meta[slot];
+                    f3 radiance = F3(r4.x, r4.y, r4.z);
+                    restart = finishSample(p, wf, slot, meta, radiance, nSamples, nRetries);
+                    if (restart)
+                        wf.meta[slot].z = meta.z;
+                }
+                else
+                    wf.rad[slot] = r4; // the slot is already in the next queue (k_shade)
+            }
+        }
+        // the slot cannot join the next queue directly: k_trace_closest of the next bounce may already be consuming it
+        pushRestarts(wf, restart, slot);
+    }
+    blockAddCounter(&wf.counters[C_SAMPLES], nSamples);
+    blockAddCounter(&wf.counters[C_RETRIES], nRetries);
 }
 template <bool ALPHA>
 __global__ void __launch_bounds__(kBlock) k_trace_shadow(LaunchParams p, TraceScene sc, Wavefront wf, int qout, int parity);
@@ -1652,6 +1674,7 @@ struct PtxRenderer
     size_t diffCapacity = 0;
     DevBuf<uint4> meta;
     DevBuf<uint32_t> hitPair, queue0, queue1, shadowQueue, restartQueue, counters, spill;
+    DevBuf<uint8_t> shadowResult;
     uint32_t *hostCounters = nullptr; // pinned
 
     DevBuf<float> testIn, testOut;
@@ -2580,7 +2603,7 @@ static int ensureSlots(PtxRenderer *r, size_t slots)
     HIP_TRY(r, r->rayO.alloc(slots)); HIP_TRY(r, r->rayD.alloc(slots)); HIP_TRY(r, r->thr.alloc(slots)); HIP_TRY(r, r->rad.alloc(slots));
     HIP_TRY(r, r->hit.alloc(slots)); HIP_TRY(r, r->shO.alloc(slots)); HIP_TRY(r, r->shD.alloc(slots)); HIP_TRY(r, r->shC.alloc(slots));
     HIP_TRY(r, r->meta.alloc(slots)); HIP_TRY(r, r->hitPair.alloc(slots));
-    HIP_TRY(r, r->queue0.alloc(slots)); HIP_TRY(r, r->queue1.alloc(slots)); HIP_TRY(r, r->shadowQueue.alloc(slots));
+    HIP_TRY(r, r->queue0.alloc(slots)); HIP_TRY(r, r->queue1.alloc(slots)); HIP_TRY(r, r->shadowQueue.alloc(slots)); HIP_TRY(r, r->shadowResult.alloc(slots));
     HIP_TRY(r, r->restartQueue.alloc(slots));
     r->slotCapacity = slots;
     return PTX_OK;
@@ -2664,6 +2687,7 @@ static int enqueueBounce(PtxRenderer *r, const RenderPlan &pl, uint32_t b, int q
         k_trace_shadow<true><<<traceGridFor(est, r->residentShadow[1]), kBlock, 0, X>>>(pl.p, pl.sc, pl.wfAux, qout, (int)(b & 1u));
     else
         k_trace_shadow<false><<<traceGridFor(est, r->residentShadow[0]), kBlock, 0, X>>>(pl.p, pl.sc, pl.wfAux, qout, (int)(b & 1u));
+    k_apply_shadow<<<gridFor(est, kBlock, 4096u), kBlock, 0, X>>>(pl.p, pl.wfAux, (int)(b & 1u));
     HIP_TRY(r, hipEventRecord(ev.x1, X));
     if (tail)
     {
@@ -2937,7 +2961,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
     wf.rayO = r->rayO.p; wf.rayD = r->rayD.p; wf.thr = r->thr.p; wf.rad = r->rad.p;
     wf.meta = r->meta.p; wf.hit = r->hit.p; wf.hitPair = r->hitPair.p;
     wf.shO = r->shO.p; wf.shD = r->shD.p; wf.shC = r->shC.p; wf.slotRad = r->slotRad.p;
-    wf.queue[0] = r->queue0.p; wf.queue[1] = r->queue1.p; wf.shadowQueue = r->shadowQueue.p;
+    wf.queue[0] = r->queue0.p; wf.queue[1] = r->queue1.p; wf.shadowQueue = r->shadowQueue.p; wf.shadowResult = r->shadowResult.p;
     wf.restartQueue = r->restartQueue.p;
     for (int k = 0; k < 3; k++)
         wf.diff[k] = mode >= 1 ? r->diffs.p + (size_t)k * r->diffCapacity : nullptr;

@@ -11,8 +11,11 @@ cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 CMD="python3 bench.py --steps 5 --warmup 1 --repeats 1 --no-cpu-baseline --no-extra-scenes $*"
+# the kernel trace runs the default step count, so that its per-kernel average is taken over the same mix of launches as the
+# live average of the un-profiled line (few steps weigh the host-driven learning frames of each renderer too much)
+TRACE_CMD="python3 bench.py --repeats 1 --no-cpu-baseline --no-extra-scenes $*"
 for d in trace fetch write sq1 sq2; do rm -rf gpurun_out/${TAG}_$d; done
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace -o $TAG -- $CMD > gpurun_out/${TAG}_trace.log 2>&1; echo "trace rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace -o $TAG -- $TRACE_CMD > gpurun_out/${TAG}_trace.log 2>&1; echo "trace rc=$?"
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${TAG}_fetch -o $TAG -- $CMD > gpurun_out/${TAG}_fetch.log 2>&1; echo "fetch rc=$?"
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${TAG}_write -o $TAG -- $CMD > gpurun_out/${TAG}_write.log 2>&1; echo "write rc=$?"
 python3 tools/pmc_traffic.py gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write gpurun_out/${TAG}_traffic.json
