@@ -453,7 +453,7 @@ void ConvertFbxToGltf(std::span<const uint8_t> file, Json &json, std::vector<uin
     json.object["asset"].object["version"] = Str("2.0");
     json.object["asset"].object["generator"] = Str("FbxReader (binary FBX " + std::to_string(version) + ")");
     BufferWriter writer { buffer };
-    Json nodes = Arr(), meshes = Arr(), materials = Arr(), textures = Arr(), images = Arr(), lights = Arr();
+    Json nodes = Arr(), meshes = Arr(), materials = Arr(), textures = Arr(), images = Arr(), lights = Arr(), cameras = Arr();
 
     // ---- textures / materials (aiMaterial of assimp's FBX converter)
     std::unordered_map<int64_t, int64_t> textureIndexOf, materialIndexOf;
@@ -672,6 +672,32 @@ void ConvertFbxToGltf(std::span<const uint8_t> file, Json &json, std::vector<uin
         for (const Link *l : childrenOf(id, "NodeAttribute"))
         {
             const FbxNode *attr = byId.at(l->child);
+            if (attr->props.size() >= 3 && attr->props[2].bytes == "Camera")
+            {
+                // assimp's FBX converter: aspect = AspectWidth / AspectHeight, horizontal field of view = FieldOfView, the
+                // camera at the node's origin looking along +X with +Y up; LoadCameras (SceneImporter.cpp:997-1020) turns
+                // that into a vertical angle.  The document's cameras look along -Z: a child node turns -Z into +X.
+                const Props70 cp(*attr);
+                const double aspect = cp.Number("AspectWidth", 1.0) / std::max(cp.Number("AspectHeight", 1.0), 1e-9);
+                const double horizontal = cp.Number("FieldOfView", 25.114999771118164) * 3.14159265358979323846 / 180.0;
+                Json perspective = Obj();
+                perspective.object["yfov"] = Num(2.0 * std::atan(std::tan(horizontal / 2.0) / (aspect == 0.0 ? 16.0 / 9.0 : aspect)));
+                perspective.object["aspectRatio"] = Num(aspect);
+                perspective.object["znear"] = Num(cp.Number("NearPlane", 10.0));
+                perspective.object["zfar"] = Num(cp.Number("FarPlane", 4000.0));
+                Json camera = Obj();
+                camera.object["type"] = Str("perspective");
+                camera.object["perspective"] = std::move(perspective);
+                cameras.array.push_back(std::move(camera));
+                Json child = Obj();
+                child.object["name"] = Str(ObjectName(*model) + " (camera axis)");
+                const double quarter[3] = { 0.0, -90.0, 0.0 };
+                child.object["matrix"] = matrixJson(EulerXyz(quarter));
+                child.object["camera"] = Num(static_cast<double>(cameras.array.size() - 1));
+                nodes.array.push_back(std::move(child));
+                nodes.array[nodeOfModel[id]].object["children"].array.push_back(Num(static_cast<double>(nodes.array.size() - 1)));
+                continue;
+            }
             if (attr->props.size() < 3 || attr->props[2].bytes != "Light")
                 continue;
             const Props70 lp(*attr);
@@ -722,6 +748,8 @@ void ConvertFbxToGltf(std::span<const uint8_t> file, Json &json, std::vector<uin
     json.object["materials"] = std::move(materials);
     json.object["textures"] = std::move(textures);
     json.object["images"] = std::move(images);
+    if (!cameras.array.empty())
+        json.object["cameras"] = std::move(cameras);
     json.object["accessors"] = std::move(writer.accessors);
     json.object["bufferViews"] = std::move(writer.views);
     Json buf = Obj();

@@ -50,13 +50,14 @@ def _write_scene(pkg, tmp_path, version=7400, name="scene.fbx"):
         img = np.zeros((4, 4, 4), np.uint8)
         img[..., :3], img[..., 3] = rgb, 255
         pkg.write_image(tmp_path / fn, img, pkg.OUTPUT_PNG)
-    ROOT, BOX, FLOOR, LAMP, SUN = 100, 101, 102, 103, 104
+    ROOT, BOX, FLOOR, LAMP, SUN, CAM = 100, 101, 102, 103, 104, 105
     objects = F.node("Objects", [], [
         F.obj("Model", ROOT, "Group", "Model", "Null", [F.p70(Lcl_Translation=(1.0, 0.5, 0.0), Lcl_Rotation=(0.0, 45.0, 0.0))]),
         F.obj("Model", BOX, "Box", "Model", "Mesh", [F.p70(Lcl_Scaling=(1.0, 2.0, 1.0), GeometricTranslation=(0.0, 0.25, 0.0))]),
         F.obj("Model", FLOOR, "Floor", "Model", "Mesh", [F.p70(PreRotation=(0.0, 0.0, 0.0))]),
         F.obj("Model", LAMP, "Lamp", "Model", "Light", [F.p70(Lcl_Translation=(0.0, 3.0, 1.0))]),
         F.obj("Model", SUN, "Sun", "Model", "Light", [F.p70(Lcl_Rotation=(0.0, 0.0, 0.0))]),
+        F.obj("Model", CAM, "Cam", "Model", "Camera", [F.p70(Lcl_Translation=(-6.0, 2.0, 0.0))]),
         _cube_geometry(200, True),
         _floor_geometry(201),
         F.obj("Material", 300, "Floor Phong", "Material", "", [F.p70(DiffuseColor=(0.5, 0.6, 0.7), ShininessExponent=20.0, SpecularFactor=0.5,
@@ -68,12 +69,13 @@ def _write_scene(pkg, tmp_path, version=7400, name="scene.fbx"):
         F.obj("Texture", 402, "n", "Texture", "", [F.node("FileName", ["floor_n.png"])]),
         F.obj("NodeAttribute", 500, "LampAttr", "NodeAttribute", "Light", [F.p70(LightType=0, Color=(1.0, 0.5, 0.25), Intensity=800.0)]),
         F.obj("NodeAttribute", 501, "SunAttr", "NodeAttribute", "Light", [F.p70(LightType=1, Color=(1.0, 1.0, 1.0), Intensity=200.0)]),
+        F.obj("NodeAttribute", 502, "CamAttr", "NodeAttribute", "Camera", [F.p70(FieldOfView=60.0, AspectWidth=3.0, AspectHeight=2.0, NearPlane=0.1, FarPlane=500.0)]),
     ])
     connections = F.node("Connections", [], [
-        F.oo(ROOT, 0), F.oo(FLOOR, 0), F.oo(LAMP, 0), F.oo(SUN, 0), F.oo(BOX, ROOT),
+        F.oo(ROOT, 0), F.oo(FLOOR, 0), F.oo(LAMP, 0), F.oo(SUN, 0), F.oo(CAM, 0), F.oo(BOX, ROOT),
         F.oo(200, BOX), F.oo(301, BOX), F.oo(302, BOX), F.oo(201, FLOOR), F.oo(300, FLOOR),
         F.op(400, 300, "DiffuseColor"), F.op(401, 300, "SpecularColor"), F.op(402, 300, "NormalMap"),
-        F.oo(500, LAMP), F.oo(501, SUN),
+        F.oo(500, LAMP), F.oo(501, SUN), F.oo(502, CAM),
     ])
     header = F.node("FBXHeaderExtension", [], [F.node("FBXVersion", [version])])
     F.write(tmp_path / name, [header, objects, connections], version)
@@ -128,8 +130,15 @@ def test_binary_fbx_import(pkg, orc, tmp_path, version):
     L = s.lights
     assert L.LightCount == 1 and np.allclose(list(L.Lights[0].Position), [0, 3, 1]) and np.allclose(list(L.Lights[0].Color), [8, 4, 2])
     assert np.allclose(list(L.Directional.Direction), [0, -1, 0], atol=1e-6) and np.allclose(list(L.Directional.Color), [2, 2, 2])
-    img, st = osc.render(s.uniform(48, 32, bounces=3, sample_count=2), L, 48, 32)
-    assert np.isfinite(img).all() and st.shadowRays > 0
+    # the camera: at its node, looking along the node's +X (towards the scene), vertical angle from the horizontal 60 degrees at 3:2
+    s.set_active_camera(0)
+    u = s.uniform(48, 32, bounces=3, sample_count=2)
+    view = np.array(u.ViewInverse, np.float32).reshape(4, 4)
+    assert np.allclose(view[3, :3], [-6, 2, 0], atol=1e-5) and np.allclose(view[2, :3], [1, 0, 0], atol=1e-5)  # LookAtLH: the view z axis is the forward direction
+    proj = np.array(u.ProjInverse, np.float32).reshape(4, 4)
+    assert np.isclose(abs(proj[1, 1]), math.tan(math.radians(60) / 2) / 1.5, rtol=1e-4)
+    img, st = osc.render(u, L, 48, 32)
+    assert np.isfinite(img).all() and st.shadowRays > 0 and st.segments > 48 * 32 * 2
 
 
 def test_fbx_reader_rejects_malformed_files(pkg, tmp_path):
