@@ -168,7 +168,7 @@ def build(force: bool = False, verbose: bool = True) -> None:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
     host = os.path.join(PKG_DIR, "host")
-    host_src = [os.path.join(host, f) for f in ("Scene.cpp", "Camera.cpp", "ExampleScenes.cpp", "OutputSaver.cpp", "TextureImporter.cpp", "JpegDecoder.cpp", "SceneImporter.cpp", "SceneManager.cpp", "FbxReader.cpp", "host_capi.cpp")]
+    host_src = [os.path.join(host, f) for f in ("Scene.cpp", "Camera.cpp", "ExampleScenes.cpp", "OutputSaver.cpp", "TextureImporter.cpp", "JpegDecoder.cpp", "SceneImporter.cpp", "SceneManager.cpp", "FbxReader.cpp", "ObjReader.cpp", "host_capi.cpp")]
     host_dep = host_src + [os.path.join(host, f) for f in ("Scene.h", "Camera.h", "ExampleScenes.h", "OutputSaver.h", "TextureImporter.h", "SceneImporter.h", "SceneManager.h", "Json.h", "Math.h")] + [
         os.path.join(REPO_DIR, "include", "ptx_host.h"), os.path.join(REPO_DIR, "include", "ptx.h")]
     if force or _newer(HOST_LIB, host_dep):

@@ -1,5 +1,6 @@
 #include "SceneImporter.h"
 #include "FbxReader.h"
+#include "ObjReader.h"
 
 #include <algorithm>
 #include <cmath>
@@ -152,6 +153,14 @@ Gltf LoadGltf(const std::filesystem::path &path)
     const std::vector<uint8_t> file = ReadFileBytes(path);
     std::vector<uint8_t> glbBin;
     std::string text;
+    std::string extension = path.extension().string();
+    std::transform(extension.begin(), extension.end(), extension.begin(), [](unsigned char c) { return static_cast<char>(std::tolower(c)); });
+    if (extension == ".obj") // ObjReader.h
+    {
+        g.buffers.emplace_back();
+        ConvertObjToGltf(file, g.base, g.json, g.buffers.back());
+        return g;
+    }
     if (IsBinaryFbx(file)) // FbxReader.h: the same document, built from the FBX records
     {
         g.buffers.emplace_back();

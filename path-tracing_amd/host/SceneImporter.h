@@ -1,4 +1,4 @@
-// SceneImporter.h -- host mirror of Path-Tracing/SceneImporter.{h,cpp} (row N2) for glTF 2.0 and binary FBX (FbxReader.h).
+// SceneImporter.h -- host mirror of Path-Tracing/SceneImporter.{h,cpp} (row N2) for glTF 2.0, binary FBX (FbxReader.h) and Wavefront OBJ (ObjReader.h).
 //
 // The reference hands every format to assimp and then walks the aiScene (SceneImporter.cpp:1048-1114).  assimp is
 // not available, so this importer reads glTF 2.0 itself (.gltf with external / data-URI buffers, .glb) and then

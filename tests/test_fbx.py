@@ -185,3 +185,50 @@ def test_fbx_scene_renders_like_the_oracle(pkg, orc, tmp_path, gpu_renderer):
         osc.render(u, s.lights, W, H, accum=ref)
     img = gpu_renderer.readback()
     assert (img.view(np.uint32) == ref.view(np.uint32)).all() and img[..., :3].max() > 0.05
+
+
+def test_wavefront_obj_import(pkg, orc, tmp_path):
+    """OBJ + MTL through the same pipeline.  assimp's OBJ importer gives every material a shininess, so -- like FBX -- a file
+    loads only under a mapping that forces another model than Phong (the reference's missing `break`)."""
+    img = np.zeros((4, 4, 4), np.uint8)
+    img[..., :3], img[..., 3] = (90, 160, 220), 255
+    pkg.write_image(tmp_path / "kd.png", img, pkg.OUTPUT_PNG)
+    (tmp_path / "textures").mkdir()
+    pkg.write_image(tmp_path / "textures" / "kd.png", img, pkg.OUTPUT_PNG)
+    (tmp_path / "scene.mtl").write_text(
+        "newmtl Floor\nKd 0.5 0.6 0.7\nKe 0.1 0.2 0.3\nNs 40\nmap_Kd -bm 1.0 kd.png\nmap_Ks textures\\kd.png\nmap_bump kd.png\n"
+        "newmtl Lid\nKd 1 0 0\nd 0.5\n")
+    (tmp_path / "scene.obj").write_text(
+        "# a floor quad with uvs and normals, and a box top referenced by negative indices\n"
+        "mtllib scene.mtl\n"
+        "v -4 0 4\nv 4 0 4\nv 4 0 -4\nv -4 0 -4\n"
+        "vt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\n"
+        "vn 0 1 0\n"
+        "o Floor\nusemtl Floor\nf 1/1/1 2/2/1 3/3/1 4/4/1\n"
+        "o Lid\nusemtl Lid\n"
+        "v -1 1 1\nv 1 1 1\nv 1 1 -1\nv -1 1 -1\nv 0 2 0\n"
+        "f -5 -4 -1\nf -4 -3 -1\nf -3 -2 \\\n -1\nf -2 -5 -1\n"
+        "usemtl Missing\nf 5//1 6//1 7//1\n")
+    with pytest.raises(pkg.PtxError, match="Unsupported material type"):
+        pkg.Scene("file:" + str(tmp_path / "scene.obj"))
+    s = pkg.Scene(_describe(tmp_path, components=["scene.obj"], mapping="orca"))
+    d = s.desc
+    a = util.desc_arrays(d)
+    assert s.triangle_count == 2 + 4 + 1 and d.meshCount == 3
+    assert d.phongMaterialCount == 0 and d.specularGlossinessMaterialCount == 0
+    mr = np.frombuffer((C.c_uint8 * (96 * d.metallicRoughnessMaterialCount)).from_address(d.metallicRoughnessMaterials), np.uint32).reshape(-1, 24)
+    floor = int([m for m in a["meshes"] if a["geometries"][m["GeometryIndex"]]["IndexLength"] == 6][0]["MaterialId"]) >> 8
+    f = mr.view(np.float32)[floor]
+    assert np.allclose(f[0:3], [0.1, 0.2, 0.3]) and np.allclose(f[4:8], 1.0)   # MetallicRoughness under the ORCA mapping: white base colour
+    ids = mr[floor, 19:24]
+    assert ids[1] >= 9 and ids[3] == ids[4] >= 9 and ids[2] == 1   # map_Kd, map_Ks (backslash path); map_bump is HEIGHT: no slot reads it
+    fg = [g for g in a["geometries"] if g["IndexLength"] == 6][0]
+    fv = a["vertices"][fg["VertexOffset"]:fg["VertexOffset"] + 4]
+    assert np.allclose(fv[:, 3:5], [[0, 1], [1, 1], [1, 0], [0, 0]]) and np.allclose(fv[:, 5:8], [0, 1, 0])   # FlipUVs
+    osc = orc.OracleScene(d, build_bvh=False)
+    hit = osc.trace_closest(np.float32([[-3, 5, -3, 1e-5, 0, -1, 0, 1e4], [0.0, 5, 0.0, 1e-5, 0, -1, 0, 1e4], [0.5, 5, 0.25, 1e-5, 0, -1, 0, 1e4]]))
+    assert np.allclose(hit["t"], [5.0, 3.0, 3.5], atol=1e-5)   # the floor, the pyramid's apex (0, 2, 0), its slope at x = 0.5
+    for bad in ("f 1 2 99\n", "f 0 1 2\n", "v 1 2 3\n"):   # index past the end, zero index, no faces at all
+        (tmp_path / "bad.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\n" + bad if bad.startswith("f") else bad)
+        with pytest.raises(pkg.PtxError):
+            pkg.Scene(_describe(tmp_path, components=["bad.obj"], mapping="orca"))
