@@ -305,6 +305,42 @@ def test_full_size_properties(pkg):
     r.close()
 
 
+@pytest.mark.parametrize("tag,name,spp,depth,shard", [
+    ("configs[2]: 64 spp, depth 8", "temple_like", 64, 8, None),
+    ("configs[3]: 256 spp, depth 12, a rank of 4", "atrium_like", 256, 12, (1, 4, 32)),
+    ("configs[4]: 1024 spp, depth 16, a rank of 8", "street_like", 1024, 16, (5, 8, 32)),
+])
+def test_long_sample_schedules_match_oracle(pkg, orc, tag, name, spp, depth, shard):
+    """The sample counts and depths of BASELINE configs[2..4] run in full -- every frame of the schedule, in batches of 64
+    frames per launch as a production run would issue them -- on a small image, against the oracle's frame-by-frame sum.
+    (The full-size frames of the same scenes are compared elsewhere; this covers what only a long schedule reaches: the RNG
+    frame index up to 1023, depth-16 paths, accumulation over a thousand additions in frame order.)"""
+    import torch  # noqa: F401
+
+    scene = pkg.Scene(name, 0.2)
+    lights = scene.lights
+    W, H = 64, 48
+    r = pkg.Renderer()
+    r.upload(scene)
+    r.resize(W, H)
+    sh = None
+    if shard:
+        r.set_tile_shard(*shard)
+        sh = pkg.TileShard(*shard)
+    batch = 64
+    for first in range(0, spp, batch):
+        r.render_frames(scene.uniform(W, H, bounces=depth), lights, first, min(batch, spp - first))
+    img = r.readback()
+    r.close()
+    osc = orc.OracleScene(scene.desc)
+    ref = np.zeros((H, W, 4), np.float32)
+    for f in range(spp):
+        osc.render(scene.uniform(W, H, bounces=depth, total_samples=f), lights, W, H, accum=ref, shard=sh)
+    assert (img.view(np.uint32) == ref.view(np.uint32)).all(), tag
+    owned = ref[..., 3] == 1
+    assert owned.any() and (shard is None) == bool(owned.all()) and np.isfinite(img).all()
+
+
 @pytest.mark.parametrize("name,frames", [("chess_like", 2), ("atrium_like", 1), ("temple_like", 1), ("street_like", 1), ("alpha_test", 1), ("texture_test", 1),
                                          ("roughness_cubes", 1), ("reuse_mesh_cubes", 1), ("attenuation_blob", 1), ("default", 2), ("animated_test", 1), ("materials_test", 1)])
 def test_full_size_frame_matches_oracle(pkg, orc, name, frames):
