@@ -738,6 +738,151 @@ void ConvertFbxToGltf(std::span<const uint8_t> file, Json &json, std::vector<uin
         }
     }
 
+    // ---- animation: AnimationStack <- AnimationLayer <- AnimationCurveNode (-> a Model's Lcl Translation / Rotation / Scaling)
+    // <- AnimationCurve per component (d|X, d|Y, d|Z; KeyTime in 1 / 46,186,158,000 s, KeyValueFloat).  A stack becomes one
+    // animation of the document: per animated model and property a linear sampler over the union of its components' key
+    // times.  Only models whose local transform is a plain T * R * S are animated (no pre- / post-rotation, pivots or
+    // offsets: assimp spreads those over helper nodes); such a model is written as translation / rotation / scale.
+    Json animations = Arr();
+    {
+        auto plainTrs = [&](const Props70 &p) {
+            double v[3];
+            for (const char *name : { "PreRotation", "PostRotation", "RotationPivot", "ScalingPivot", "RotationOffset", "ScalingOffset" })
+                if (p.Vector(name, v) && (v[0] != 0.0 || v[1] != 0.0 || v[2] != 0.0))
+                    return false;
+            return true;
+        };
+        auto eulerQuaternion = [](const double degrees[3], double q[4]) { // x, y, z, w of Rz * Ry * Rx
+            const double k = 3.14159265358979323846 / 360.0;
+            const double cx = std::cos(degrees[0] * k), sx = std::sin(degrees[0] * k), cy = std::cos(degrees[1] * k), sy = std::sin(degrees[1] * k),
+                         cz = std::cos(degrees[2] * k), sz = std::sin(degrees[2] * k);
+            q[0] = sx * cy * cz - cx * sy * sz;
+            q[1] = cx * sy * cz + sx * cy * sz;
+            q[2] = cx * cy * sz - sx * sy * cz;
+            q[3] = cx * cy * cz + sx * sy * sz;
+        };
+        struct Curve { std::vector<double> time, value; };
+        auto readCurve = [&](int64_t id, Curve &c) {
+            const FbxNode *n = byId.at(id);
+            const std::vector<int64_t> *t = IntArray(n->Child("KeyTime"));
+            const std::vector<double> *v = RealArray(n->Child("KeyValueFloat"));
+            if (!t || !v || t->size() != v->size())
+                return;
+            for (size_t k = 0; k < t->size(); k++)
+            {
+                c.time.push_back(static_cast<double>((*t)[k]) / 46186158000.0);
+                c.value.push_back((*v)[k]);
+            }
+        };
+        auto evaluate = [](const Curve &c, double t, double fallback) {
+            if (c.time.empty())
+                return fallback;
+            if (t <= c.time.front())
+                return c.value.front();
+            if (t >= c.time.back())
+                return c.value.back();
+            const size_t hi = static_cast<size_t>(std::upper_bound(c.time.begin(), c.time.end(), t) - c.time.begin());
+            const double span = c.time[hi] - c.time[hi - 1], a = span > 0.0 ? (t - c.time[hi - 1]) / span : 0.0;
+            return c.value[hi - 1] * (1.0 - a) + c.value[hi] * a;
+        };
+        std::unordered_map<int64_t, bool> writtenAsTrs;
+        for (const FbxNode &stack : objects->children)
+        {
+            if (stack.name != "AnimationStack" || stack.props.empty())
+                continue;
+            Json samplers = Arr(), channels = Arr();
+            for (const Link *layer : childrenOf(stack.props[0].integer, "AnimationLayer"))
+                for (const Link *curveNode : childrenOf(layer->child, "AnimationCurveNode"))
+                {
+                    // which model property this curve node drives
+                    int64_t model = 0;
+                    std::string property;
+                    for (const Link &l : links)
+                        if (l.child == curveNode->child && !l.property.empty() && nodeOfModel.count(l.parent))
+                        {
+                            model = l.parent;
+                            property = l.property;
+                        }
+                    const char *path = property == "Lcl Translation" ? "translation" : property == "Lcl Rotation" ? "rotation" : property == "Lcl Scaling" ? "scale" : nullptr;
+                    if (!model || !path)
+                        continue;
+                    const Props70 mp(*byId.at(model));
+                    if (!plainTrs(mp))
+                        continue;
+                    Curve xyz[3];
+                    for (const Link *curve : childrenOf(curveNode->child, "AnimationCurve"))
+                    {
+                        const int axis = curve->property == "d|X" ? 0 : curve->property == "d|Y" ? 1 : curve->property == "d|Z" ? 2 : -1;
+                        if (axis >= 0)
+                            readCurve(curve->child, xyz[axis]);
+                    }
+                    std::vector<double> times;
+                    for (const Curve &c : xyz)
+                        times.insert(times.end(), c.time.begin(), c.time.end());
+                    std::sort(times.begin(), times.end());
+                    times.erase(std::unique(times.begin(), times.end()), times.end());
+                    if (times.empty())
+                        continue;
+                    double rest[3] = { 0, 0, 0 };
+                    if (std::strcmp(path, "scale") == 0)
+                        rest[0] = rest[1] = rest[2] = 1.0;
+                    mp.Vector(property, rest);
+                    std::vector<float> input, output;
+                    for (double t : times)
+                    {
+                        const double v[3] = { evaluate(xyz[0], t, rest[0]), evaluate(xyz[1], t, rest[1]), evaluate(xyz[2], t, rest[2]) };
+                        input.push_back(static_cast<float>(t));
+                        if (std::strcmp(path, "rotation") == 0)
+                        {
+                            double q[4];
+                            eulerQuaternion(v, q);
+                            for (double c : q)
+                                output.push_back(static_cast<float>(c));
+                        }
+                        else
+                            for (double c : v)
+                                output.push_back(static_cast<float>(c));
+                    }
+                    Json sampler = Obj();
+                    sampler.object["input"] = Num(static_cast<double>(writer.Add(input.data(), input.size() * 4, input.size(), 5126, "SCALAR")));
+                    const bool rotation = std::strcmp(path, "rotation") == 0;
+                    sampler.object["output"] = Num(static_cast<double>(writer.Add(output.data(), output.size() * 4, input.size(), 5126, rotation ? "VEC4" : "VEC3")));
+                    sampler.object["interpolation"] = Str("LINEAR");
+                    samplers.array.push_back(std::move(sampler));
+                    Json target = Obj();
+                    target.object["node"] = Num(static_cast<double>(nodeOfModel[model]));
+                    target.object["path"] = Str(path);
+                    Json channel = Obj();
+                    channel.object["sampler"] = Num(static_cast<double>(samplers.array.size() - 1));
+                    channel.object["target"] = std::move(target);
+                    channels.array.push_back(std::move(channel));
+                    if (!writtenAsTrs[model])
+                    {
+                        // the animated node carries translation / rotation / scale instead of a matrix
+                        writtenAsTrs[model] = true;
+                        Json &node = nodes.array[nodeOfModel[model]];
+                        node.object.erase("matrix");
+                        double t[3] = { 0, 0, 0 }, r[3] = { 0, 0, 0 }, sc[3] = { 1, 1, 1 }, q[4];
+                        mp.Vector("Lcl Translation", t);
+                        mp.Vector("Lcl Rotation", r);
+                        mp.Vector("Lcl Scaling", sc);
+                        eulerQuaternion(r, q);
+                        node.object["translation"] = Nums(t, 3);
+                        node.object["rotation"] = Nums(q, 4);
+                        node.object["scale"] = Nums(sc, 3);
+                    }
+                }
+            if (!channels.array.empty())
+            {
+                Json animation = Obj();
+                animation.object["name"] = Str(ObjectName(stack));
+                animation.object["samplers"] = std::move(samplers);
+                animation.object["channels"] = std::move(channels);
+                animations.array.push_back(std::move(animation));
+            }
+        }
+    }
+
     Json scene = Obj();
     scene.object["nodes"] = std::move(roots);
     json.object["scene"] = Num(0);
@@ -750,6 +895,8 @@ void ConvertFbxToGltf(std::span<const uint8_t> file, Json &json, std::vector<uin
     json.object["images"] = std::move(images);
     if (!cameras.array.empty())
         json.object["cameras"] = std::move(cameras);
+    if (!animations.array.empty())
+        json.object["animations"] = std::move(animations);
     json.object["accessors"] = std::move(writer.accessors);
     json.object["bufferViews"] = std::move(writer.views);
     Json buf = Obj();

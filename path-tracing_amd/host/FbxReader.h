@@ -16,8 +16,9 @@
 // Read: the node records (32- and 64-bit offsets), every property type incl. zlib-deflated arrays; Objects: Geometry
 // (control points, polygons of any size -> triangle fans, normals and UVs ByPolygonVertex / ByVertice, Direct /
 // IndexToDirect, materials AllSame / ByPolygon), Model (Lcl translation / rotation / scaling, pre- and post-rotation,
-// pivots and offsets, geometric transform; Euler order XYZ), Material, Texture, NodeAttribute lights and cameras; Connections.
-// Not read: ASCII FBX, skin deformers and animation curves (the two reference scenes are static), embedded media.
+// pivots and offsets, geometric transform; Euler order XYZ), Material, Texture, NodeAttribute lights and cameras, animation
+// stacks (curves on Lcl Translation / Rotation / Scaling of models with a plain T * R * S transform, sampled linearly);
+// Connections.  Not read: ASCII FBX, skin deformers, curves on models with pivots, embedded media.
 #pragma once
 
 #include <cstdint>

@@ -45,7 +45,7 @@ def _floor_geometry(oid):
     ])
 
 
-def _write_scene(pkg, tmp_path, version=7400, name="scene.fbx"):
+def _write_scene(pkg, tmp_path, version=7400, name="scene.fbx", animated=False):
     for fn, rgb in (("floor_d.png", (200, 180, 60)), ("floor_s.png", (0, 120, 30)), ("floor_n.png", (128, 128, 255))):
         img = np.zeros((4, 4, 4), np.uint8)
         img[..., :3], img[..., 3] = rgb, 255
@@ -71,7 +71,20 @@ def _write_scene(pkg, tmp_path, version=7400, name="scene.fbx"):
         F.obj("NodeAttribute", 501, "SunAttr", "NodeAttribute", "Light", [F.p70(LightType=1, Color=(1.0, 1.0, 1.0), Intensity=200.0)]),
         F.obj("NodeAttribute", 502, "CamAttr", "NodeAttribute", "Camera", [F.p70(FieldOfView=60.0, AspectWidth=3.0, AspectHeight=2.0, NearPlane=0.1, FarPlane=500.0)]),
     ])
-    connections = F.node("Connections", [], [
+    extra_objects, extra_links = [], []
+    if animated:
+        # one stack: the group turns about y from 45 to 135 degrees and slides along x from 1 to 3, over two seconds
+        second = 46186158000
+        extra_objects = [
+            F.obj("AnimationStack", 600, "Take", "AnimStack", ""), F.obj("AnimationLayer", 601, "Base", "AnimLayer", ""),
+            F.obj("AnimationCurveNode", 610, "R", "AnimCurveNode", ""), F.obj("AnimationCurveNode", 611, "T", "AnimCurveNode", ""),
+            F.obj("AnimationCurve", 620, "", "AnimCurve", "", [F.node("KeyTime", [np.int64([0, 2 * second])]), F.node("KeyValueFloat", [np.float32([45.0, 135.0])])]),
+            F.obj("AnimationCurve", 621, "", "AnimCurve", "", [F.node("KeyTime", [np.int64([0, second, 2 * second])]), F.node("KeyValueFloat", [np.float32([1.0, 2.0, 3.0])])]),
+        ]
+        extra_links = [F.oo(601, 600), F.oo(610, 601), F.oo(611, 601), F.op(610, ROOT, "Lcl Rotation"), F.op(611, ROOT, "Lcl Translation"),
+                       F.op(620, 610, "d|Y"), F.op(621, 611, "d|X")]
+    objects[2].extend(extra_objects)
+    connections = F.node("Connections", [], extra_links + [
         F.oo(ROOT, 0), F.oo(FLOOR, 0), F.oo(LAMP, 0), F.oo(SUN, 0), F.oo(CAM, 0), F.oo(BOX, ROOT),
         F.oo(200, BOX), F.oo(301, BOX), F.oo(302, BOX), F.oo(201, FLOOR), F.oo(300, FLOOR),
         F.op(400, 300, "DiffuseColor"), F.op(401, 300, "SpecularColor"), F.op(402, 300, "NormalMap"),
@@ -232,3 +245,27 @@ def test_wavefront_obj_import(pkg, orc, tmp_path):
         (tmp_path / "bad.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\n" + bad if bad.startswith("f") else bad)
         with pytest.raises(pkg.PtxError):
             pkg.Scene(_describe(tmp_path, components=["bad.obj"], mapping="orca"))
+
+
+def test_fbx_animation_stack(pkg, orc, tmp_path):
+    """Curves on Lcl Rotation / Lcl Translation of a model: the animated node becomes an instance root (LoadModels), its keys
+    arrive as milliseconds at 1000 ticks per second, components without a curve keep the model's own value."""
+    path = _write_scene(pkg, tmp_path, animated=True, name="anim.fbx")
+    s = pkg.Scene(_describe(tmp_path, components=[path.name], mapping="orca"))
+    d = s.desc
+    assert d.instanceCount == 2 and s.triangle_count == 2 + 12   # the static floor; the group with the box below it
+    assert s.update(0.0)
+    it0, _ = s.animation_state()
+    box = [i for i in range(2) if abs(it0[i].reshape(3, 4)[1, 3] - 0.5) < 1e-5]
+    assert len(box) == 1
+    m0 = it0[box[0]].reshape(3, 4)
+    c = math.cos(math.pi / 4)
+    assert np.allclose(m0[:, 3], [1, 0.5, 0], atol=1e-5) and np.allclose(m0[:, :3], [[c, 0, c], [0, 1, 0], [-c, 0, c]], atol=1e-5)
+    s.update(1.0)   # half way: 90 degrees about y, x = 2; y and z keep the model's own translation
+    it1, _ = s.animation_state()
+    m1 = it1[box[0]].reshape(3, 4)
+    assert np.allclose(m1[:, 3], [2, 0.5, 0], atol=1e-4) and np.allclose(m1[:, :3], [[0, 0, 1], [0, 1, 0], [-1, 0, 0]], atol=1e-4)
+    # the posed scene through the oracle: the box (2 high on the group) now stands at x = 2
+    osc = orc.OracleScene(d, build_bvh=False, instance_transforms=it1)
+    hit = osc.trace_closest(np.float32([[2.0, 5, 0.0, 1e-5, 0, -1, 0, 1e4], [0.2, 5, 0.0, 1e-5, 0, -1, 0, 1e4]]))
+    assert np.allclose(hit["t"], [3.0, 5.0], atol=1e-4)
