@@ -278,6 +278,26 @@ DMat TransposeRotation(const DMat &r) // inverse of a rotation
     return t;
 }
 
+DMat InverseAffine(const DMat &a) // inverse of [ L t ; 0 1 ] by the cofactors of L
+{
+    const double (*m)[4] = a.m;
+    const double c00 = m[1][1] * m[2][2] - m[1][2] * m[2][1], c01 = m[1][2] * m[2][0] - m[1][0] * m[2][2], c02 = m[1][0] * m[2][1] - m[1][1] * m[2][0];
+    const double det = m[0][0] * c00 + m[0][1] * c01 + m[0][2] * c02;
+    if (det == 0.0 || !std::isfinite(det))
+        throw error("FBX: a cluster's bind pose is not invertible");
+    DMat r = DMat::Identity();
+    r.m[0][0] = c00 / det; r.m[1][0] = c01 / det; r.m[2][0] = c02 / det;
+    r.m[0][1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) / det;
+    r.m[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) / det;
+    r.m[2][1] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) / det;
+    r.m[0][2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) / det;
+    r.m[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) / det;
+    r.m[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) / det;
+    for (int i = 0; i < 3; i++)
+        r.m[i][3] = -(r.m[i][0] * m[0][3] + r.m[i][1] * m[1][3] + r.m[i][2] * m[2][3]);
+    return r;
+}
+
 // FBX SDK: WorldTransform = ParentWorld * T * Roff * Rp * Rpre * R * Rpost^-1 * Rp^-1 * Soff * Sp * S * Sp^-1
 DMat LocalTransform(const Props70 &p)
 {
@@ -453,7 +473,7 @@ void ConvertFbxToGltf(std::span<const uint8_t> file, Json &json, std::vector<uin
     json.object["asset"].object["version"] = Str("2.0");
     json.object["asset"].object["generator"] = Str("FbxReader (binary FBX " + std::to_string(version) + ")");
     BufferWriter writer { buffer };
-    Json nodes = Arr(), meshes = Arr(), materials = Arr(), textures = Arr(), images = Arr(), lights = Arr(), cameras = Arr();
+    Json nodes = Arr(), meshes = Arr(), materials = Arr(), textures = Arr(), images = Arr(), lights = Arr(), cameras = Arr(), skins = Arr();
 
     // ---- textures / materials (aiMaterial of assimp's FBX converter)
     std::unordered_map<int64_t, int64_t> textureIndexOf, materialIndexOf;
@@ -521,7 +541,9 @@ void ConvertFbxToGltf(std::span<const uint8_t> file, Json &json, std::vector<uin
     };
 
     // ---- geometry: one mesh per (Geometry, material list of the model that uses it)
-    auto buildMesh = [&](const FbxNode &geometry, const std::vector<int64_t> &materialOfSlot) -> int64_t {
+    // per control point: up to four (joint, weight) pairs, largest first, weights renormalised (aiProcess_LimitBoneWeights)
+    struct Influence { uint16_t joint[4] = { 0, 0, 0, 0 }; float weight[4] = { 0, 0, 0, 0 }; };
+    auto buildMesh = [&](const FbxNode &geometry, const std::vector<int64_t> &materialOfSlot, const std::vector<Influence> *skin) -> int64_t {
         const std::vector<double> *points = RealArray(geometry.Child("Vertices"));
         const std::vector<int64_t> *polygons = IntArray(geometry.Child("PolygonVertexIndex"));
         if (!points || !polygons || points->size() < 9)
@@ -539,7 +561,7 @@ void ConvertFbxToGltf(std::span<const uint8_t> file, Json &json, std::vector<uin
         struct Part
         {
             std::vector<float> position, normal, uv;
-            std::vector<uint32_t> index;
+            std::vector<uint32_t> index, controlPoint; // controlPoint: per vertex, for the skin weights
             std::map<std::tuple<int64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, uint32_t> seen;
         };
         std::map<int64_t, Part> parts; // by material slot
@@ -574,6 +596,7 @@ void ConvertFbxToGltf(std::span<const uint8_t> file, Json &json, std::vector<uin
                         part.position.push_back(static_cast<float>((*points)[static_cast<size_t>(cp) * 3 + static_cast<size_t>(c)]));
                     part.normal.insert(part.normal.end(), n, n + 3);
                     part.uv.insert(part.uv.end(), t, t + 2);
+                    part.controlPoint.push_back(static_cast<uint32_t>(cp));
                     it = part.seen.emplace(key, id).first;
                 }
                 corner.push_back(it->second);
@@ -598,6 +621,19 @@ void ConvertFbxToGltf(std::span<const uint8_t> file, Json &json, std::vector<uin
                 attributes.object["NORMAL"] = Num(static_cast<double>(writer.Add(part.normal.data(), part.normal.size() * 4, part.normal.size() / 3, 5126, "VEC3")));
             if (haveUvs)
                 attributes.object["TEXCOORD_0"] = Num(static_cast<double>(writer.Add(part.uv.data(), part.uv.size() * 4, part.uv.size() / 2, 5126, "VEC2")));
+            if (skin)
+            {
+                std::vector<uint16_t> joints;
+                std::vector<float> weights;
+                for (uint32_t cp : part.controlPoint)
+                {
+                    const Influence &in = cp < skin->size() ? (*skin)[cp] : Influence();
+                    joints.insert(joints.end(), in.joint, in.joint + 4);
+                    weights.insert(weights.end(), in.weight, in.weight + 4);
+                }
+                attributes.object["JOINTS_0"] = Num(static_cast<double>(writer.Add(joints.data(), joints.size() * 2, joints.size() / 4, 5123, "VEC4")));
+                attributes.object["WEIGHTS_0"] = Num(static_cast<double>(writer.Add(weights.data(), weights.size() * 4, weights.size() / 4, 5126, "VEC4")));
+            }
             Json prim = Obj();
             prim.object["attributes"] = std::move(attributes);
             prim.object["indices"] = Num(static_cast<double>(writer.Add(part.index.data(), part.index.size() * 4, part.index.size(), 5125, "SCALAR")));
@@ -654,6 +690,27 @@ void ConvertFbxToGltf(std::span<const uint8_t> file, Json &json, std::vector<uin
         else
             roots.array.push_back(Num(static_cast<double>(nodeOfModel[id])));
     }
+    std::unordered_map<int64_t, int64_t> parentModel;
+    for (int64_t id : models)
+        for (const Link &l : links)
+            if (l.child == id && l.property.empty() && l.parent != id && nodeOfModel.count(l.parent))
+            {
+                parentModel[id] = l.parent;
+                break;
+            }
+    auto globalOf = [&](int64_t id) {
+        DMat g = DMat::Identity();
+        int guard = 0;
+        for (int64_t at = id; guard < 4096; guard++)
+        {
+            g = LocalTransform(Props70(*byId.at(at))) * g;
+            const auto up = parentModel.find(at);
+            if (up == parentModel.end())
+                break;
+            at = up->second;
+        }
+        return g;
+    };
     for (int64_t id : models)
     {
         const FbxNode *model = byId.at(id);
@@ -665,9 +722,76 @@ void ConvertFbxToGltf(std::span<const uint8_t> file, Json &json, std::vector<uin
         Json attach = Obj(); // mesh / light go onto the node itself, or onto a child when a geometric transform applies
         for (const Link *l : childrenOf(id, "Geometry"))
         {
-            const int64_t mesh = buildMesh(*byId.at(l->child), materialOfSlot);
+            // a Skin deformer on the geometry: Cluster sub-deformers, each with the control points it moves, their weights,
+            // the bone Model it follows and that bone's bind pose (TransformLink).  assimp: offset matrix =
+            // TransformLink^-1 * the mesh node's global transform (FBXConverter::ConvertCluster).
+            std::vector<Influence> influences;
+            Json joints = Arr();
+            std::vector<float> inverseBind;
+            for (const Link *skinLink : childrenOf(l->child, "Deformer"))
+                for (const Link *clusterLink : childrenOf(skinLink->child, "Deformer"))
+                {
+                    const FbxNode *cluster = byId.at(clusterLink->child);
+                    const std::vector<int64_t> *indexes = IntArray(cluster->Child("Indexes"));
+                    const std::vector<double> *weights = RealArray(cluster->Child("Weights")), *bindPose = RealArray(cluster->Child("TransformLink"));
+                    const std::vector<const Link *> bones = childrenOf(clusterLink->child, "Model");
+                    if (bones.empty() || !nodeOfModel.count(bones[0]->child) || !bindPose || bindPose->size() != 16)
+                        continue;
+                    DMat link;
+                    for (int c = 0; c < 4; c++)
+                        for (int r = 0; r < 4; r++)
+                            link.m[r][c] = (*bindPose)[static_cast<size_t>(c * 4 + r)];
+                    const DMat offset = InverseAffine(link) * globalOf(id);
+                    for (int c = 0; c < 4; c++)
+                        for (int r = 0; r < 4; r++)
+                            inverseBind.push_back(static_cast<float>(offset.m[r][c]));
+                    const uint16_t joint = static_cast<uint16_t>(joints.array.size());
+                    joints.array.push_back(Num(static_cast<double>(nodeOfModel[bones[0]->child])));
+                    if (!indexes || !weights)
+                        continue;
+                    for (size_t k = 0; k < indexes->size() && k < weights->size(); k++)
+                    {
+                        const int64_t cp = (*indexes)[k];
+                        const float w = static_cast<float>((*weights)[k]);
+                        if (cp < 0 || cp > (1 << 28) || !(w > 0.0f))
+                            continue;
+                        if (static_cast<size_t>(cp) >= influences.size())
+                            influences.resize(static_cast<size_t>(cp) + 1);
+                        Influence &in = influences[static_cast<size_t>(cp)];
+                        int slot = 3; // keep the four largest, largest first
+                        if (w <= in.weight[3])
+                            continue;
+                        while (slot > 0 && w > in.weight[slot - 1])
+                        {
+                            in.weight[slot] = in.weight[slot - 1];
+                            in.joint[slot] = in.joint[slot - 1];
+                            slot--;
+                        }
+                        in.weight[slot] = w;
+                        in.joint[slot] = joint;
+                    }
+                }
+            for (Influence &in : influences)
+            {
+                const float sum = in.weight[0] + in.weight[1] + in.weight[2] + in.weight[3];
+                if (sum > 0.0f)
+                    for (float &w : in.weight)
+                        w /= sum;
+            }
+            const bool skinned = !joints.array.empty();
+            const int64_t mesh = buildMesh(*byId.at(l->child), materialOfSlot, skinned ? &influences : nullptr);
             if (mesh >= 0 && !attach.Has("mesh"))
+            {
                 attach.object["mesh"] = Num(static_cast<double>(mesh));
+                if (skinned)
+                {
+                    Json skin = Obj();
+                    skin.object["joints"] = std::move(joints);
+                    skin.object["inverseBindMatrices"] = Num(static_cast<double>(writer.Add(inverseBind.data(), inverseBind.size() * 4, inverseBind.size() / 16, 5126, "MAT4")));
+                    skins.array.push_back(std::move(skin));
+                    attach.object["skin"] = Num(static_cast<double>(skins.array.size() - 1));
+                }
+            }
         }
         for (const Link *l : childrenOf(id, "NodeAttribute"))
         {
@@ -725,13 +849,19 @@ void ConvertFbxToGltf(std::span<const uint8_t> file, Json &json, std::vector<uin
         {
             const DMat geometric = GeometricTransform(p);
             if (geometric.IsIdentity())
+            {
                 nodes.array[nodeOfModel[id]].object["mesh"] = attach["mesh"];
+                if (attach.Has("skin"))
+                    nodes.array[nodeOfModel[id]].object["skin"] = attach["skin"];
+            }
             else
             {
                 Json child = Obj();
                 child.object["name"] = Str(ObjectName(*model) + " (geometric transform)");
                 child.object["matrix"] = matrixJson(geometric);
                 child.object["mesh"] = attach["mesh"];
+                if (attach.Has("skin"))
+                    child.object["skin"] = attach["skin"];
                 nodes.array.push_back(std::move(child));
                 nodes.array[nodeOfModel[id]].object["children"].array.push_back(Num(static_cast<double>(nodes.array.size() - 1)));
             }
@@ -897,6 +1027,8 @@ void ConvertFbxToGltf(std::span<const uint8_t> file, Json &json, std::vector<uin
         json.object["cameras"] = std::move(cameras);
     if (!animations.array.empty())
         json.object["animations"] = std::move(animations);
+    if (!skins.array.empty())
+        json.object["skins"] = std::move(skins);
     json.object["accessors"] = std::move(writer.accessors);
     json.object["bufferViews"] = std::move(writer.views);
     Json buf = Obj();

@@ -17,8 +17,8 @@
 // (control points, polygons of any size -> triangle fans, normals and UVs ByPolygonVertex / ByVertice, Direct /
 // IndexToDirect, materials AllSame / ByPolygon), Model (Lcl translation / rotation / scaling, pre- and post-rotation,
 // pivots and offsets, geometric transform; Euler order XYZ), Material, Texture, NodeAttribute lights and cameras, animation
-// stacks (curves on Lcl Translation / Rotation / Scaling of models with a plain T * R * S transform, sampled linearly);
-// Connections.  Not read: ASCII FBX, skin deformers, curves on models with pivots, embedded media.
+// stacks (curves on Lcl Translation / Rotation / Scaling of models with a plain T * R * S transform, sampled linearly),
+// Skin / Cluster deformers; Connections.  Not read: ASCII FBX, curves on models with pivots, embedded media.
 #pragma once
 
 #include <cstdint>

@@ -269,3 +269,59 @@ def test_fbx_animation_stack(pkg, orc, tmp_path):
     osc = orc.OracleScene(d, build_bvh=False, instance_transforms=it1)
     hit = osc.trace_closest(np.float32([[2.0, 5, 0.0, 1e-5, 0, -1, 0, 1e4], [0.2, 5, 0.0, 1e-5, 0, -1, 0, 1e4]]))
     assert np.allclose(hit["t"], [3.0, 5.0], atol=1e-4)
+
+
+def test_fbx_skin_deformer(pkg, orc, tmp_path):
+    """Skin / Cluster deformers: bones from the clusters' Models, offset matrices from TransformLink, per control point the
+    four largest weights; a curve on a bone bends the strip (the same rig as the glTF test of tests/test_importer.py)."""
+    second = 46186158000
+    pts = np.float64([[-0.1, 0, 0], [0.1, 0, 0], [-0.1, 1, 0], [0.1, 1, 0], [-0.1, 2, 0], [0.1, 2, 0]]) + np.float64([2, 0, 0])
+    geo = F.obj("Geometry", 200, "StripGeo", "Geometry", "Mesh", [
+        F.node("Vertices", [pts.reshape(-1)]),
+        F.node("PolygonVertexIndex", [np.int32([0, 1, 3, ~2, 2, 3, 5, ~4])]),
+        F.node("LayerElementNormal", [0], [F.node("MappingInformationType", ["ByVertice"]), F.node("ReferenceInformationType", ["Direct"]),
+                                           F.node("Normals", [np.float64([[0, 0, 1]] * 6).reshape(-1)])]),
+    ])
+
+    def bind(t):
+        m = np.eye(4)
+        m[:3, 3] = t
+        return m.T.reshape(-1).copy()   # column-major, translation in elements 12..14
+
+    objects = F.node("Objects", [], [
+        F.obj("Model", 100, "Strip", "Model", "Mesh"),
+        F.obj("Model", 101, "J0", "Model", "LimbNode", [F.p70(Lcl_Translation=(2.0, 0.0, 0.0))]),
+        F.obj("Model", 102, "J1", "Model", "LimbNode", [F.p70(Lcl_Translation=(0.0, 1.0, 0.0))]),
+        geo,
+        F.obj("Material", 300, "Skin", "Material", "", [F.p70(DiffuseColor=(0.8, 0.3, 0.2))]),
+        F.obj("Deformer", 400, "", "Deformer", "Skin"),
+        F.obj("Deformer", 401, "", "SubDeformer", "Cluster", [F.node("Indexes", [np.int32([0, 1, 2, 3])]), F.node("Weights", [np.float64([1, 1, 0.5, 0.5])]),
+                                                               F.node("Transform", [bind([-2, 0, 0])]), F.node("TransformLink", [bind([2, 0, 0])])]),
+        F.obj("Deformer", 402, "", "SubDeformer", "Cluster", [F.node("Indexes", [np.int32([2, 3, 4, 5])]), F.node("Weights", [np.float64([0.5, 0.5, 1, 1])]),
+                                                               F.node("Transform", [bind([-2, -1, 0])]), F.node("TransformLink", [bind([2, 1, 0])])]),
+        F.obj("AnimationStack", 600, "Take", "AnimStack", ""), F.obj("AnimationLayer", 601, "Base", "AnimLayer", ""),
+        F.obj("AnimationCurveNode", 610, "R", "AnimCurveNode", ""),
+        F.obj("AnimationCurve", 620, "", "AnimCurve", "", [F.node("KeyTime", [np.int64([0, second, 2 * second])]), F.node("KeyValueFloat", [np.float32([0.0, 90.0, 0.0])])]),
+    ])
+    connections = F.node("Connections", [], [
+        F.oo(100, 0), F.oo(101, 0), F.oo(102, 101), F.oo(200, 100), F.oo(300, 100),
+        F.oo(400, 200), F.oo(401, 400), F.oo(402, 400), F.oo(101, 401), F.oo(102, 402),
+        F.oo(601, 600), F.oo(610, 601), F.op(610, 102, "Lcl Rotation"), F.op(620, 610, "d|Z"),
+    ])
+    F.write(tmp_path / "skin.fbx", [objects, connections], 7400)
+    s = pkg.Scene(_describe(tmp_path, components=["skin.fbx"], mapping="orca"))
+    d = s.desc
+    a = util.desc_arrays(d)
+    assert d.animatedVertexCount == 6 and d.animatedIndexCount == 12 and s.lib.pth_scene_bone_count(s.handle) == 2
+    assert [int(g["IsAnimated"]) for g in a["geometries"]] == [1]
+    assert s.update(0.0)
+    it0, bn0 = s.animation_state()
+    assert np.allclose(bn0[0].reshape(3, 4), np.eye(4)[:3], atol=1e-6) and np.allclose(bn0[1].reshape(3, 4), np.eye(4)[:3], atol=1e-6)
+    s.update(0.5)   # J1 at 45 degrees about z, around its own origin (2, 1, 0)
+    it1, bn1 = s.animation_state()
+    c = math.cos(math.pi / 4)
+    assert np.allclose(bn1[1].reshape(3, 4)[:, :3], [[c, -c, 0], [c, c, 0], [0, 0, 1]], atol=1e-5)
+    assert np.allclose(bn1[1].reshape(3, 4) @ [2, 1, 0, 1], [2, 1, 0], atol=1e-5)
+    osc = orc.OracleScene(d, build_bvh=False, instance_transforms=it1, bones=bn1)
+    hit = osc.trace_closest(np.float32([[2.0 - c * 0.9, 1.0 + c * 0.9, 5.0, 1e-5, 0, 0, -1, 1e4], [2.0, 1.9, 5.0, 1e-5, 0, 0, -1, 1e4]]))
+    assert hit["tri"][0] != 0xFFFFFFFF and hit["tri"][1] == 0xFFFFFFFF and np.isclose(hit["t"][0], 5.0, atol=1e-4)
