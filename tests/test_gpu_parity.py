@@ -308,7 +308,7 @@ def test_full_size_properties(pkg):
 @pytest.mark.parametrize("tag,name,spp,depth,shard", [
     ("configs[2]: 64 spp, depth 8", "temple_like", 64, 8, None),
     ("configs[3]: 256 spp, depth 12, a rank of 4", "atrium_like", 256, 12, (1, 4, 32)),
-    ("configs[4]: 1024 spp, depth 16, a rank of 8", "street_like", 1024, 16, (5, 8, 32)),
+    ("configs[4]: 1024 spp, depth 16, a rank of 8", "street_like", 1024, 16, (5, 8, 16)),
 ])
 def test_long_sample_schedules_match_oracle(pkg, orc, tag, name, spp, depth, shard):
     """The sample counts and depths of BASELINE configs[2..4] run in full -- every frame of the schedule, in batches of 64
