@@ -52,6 +52,7 @@ def load() -> C.CDLL:
         lib.pto_test_raygen.argtypes = [P, P, C.c_uint32]
         lib.pto_test_closest_hit.argtypes = [P, P, P, P, C.c_uint32]
         lib.pto_test_any_hit.argtypes = [P, P, P, C.c_uint32]
+        lib.pto_test_miss.argtypes = [P, P, P, C.c_uint32]
         lib.pto_test_texture.argtypes = [P, P, P, C.c_uint32, C.c_int]
         lib.pto_postprocess.argtypes = [P, C.c_uint32, C.c_uint32, P, C.c_uint32, P]
         lib.pto_encode_output.argtypes = [P, C.c_uint32, C.c_uint32, C.c_uint32, P]
@@ -99,6 +100,14 @@ class OracleScene:
         inputs = np.ascontiguousarray(inputs).view(np.uint32).reshape(-1, 7)
         out = np.zeros((inputs.shape[0], 4), np.uint32)
         self.lib.pto_test_texture(self.handle, inputs.ctypes.data, out.ctypes.data, inputs.shape[0], int(implicit_lod))
+        return out
+
+    def test_miss(self, directions: np.ndarray) -> np.ndarray:
+        """pto_test_miss: miss.rmiss main() for rows of 3 words (the ray direction) -> Emissive, Pdf."""
+        directions = np.ascontiguousarray(directions, np.uint32).reshape(-1, 3)
+        out = np.zeros((directions.shape[0], 4), np.uint32)
+        if self.lib.pto_test_miss(self.handle, directions.ctypes.data, out.ctypes.data, directions.shape[0]):
+            raise RuntimeError("pto_test_miss failed")
         return out
 
     def test_any_hit(self, inputs: np.ndarray) -> np.ndarray:

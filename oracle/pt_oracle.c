@@ -2889,3 +2889,20 @@ int pto_test_any_hit(const PtoScene *s, const uint32_t *in, uint32_t *out, uint3
     }
     return 0;
 }
+
+/* miss.rmiss:16-39 for given ray directions (3 words each).  Output, 4 words: payload.Emissive, payload.Pdf. */
+int pto_test_miss(const PtoScene *s, const uint32_t *in, uint32_t *out, uint32_t n)
+{
+    if (!s || !in || !out)
+        return 1;
+    for (uint32_t i = 0; i < n; i++)
+    {
+        Payload p;
+        memset(&p, 0, sizeof(p));
+        p.Pdf = 7.0f;
+        missShader(s, V3(u2f(in[i * 3]), u2f(in[i * 3 + 1]), u2f(in[i * 3 + 2])), &p);
+        out[i * 4] = f2u(p.Emissive.x); out[i * 4 + 1] = f2u(p.Emissive.y); out[i * 4 + 2] = f2u(p.Emissive.z);
+        out[i * 4 + 3] = f2u(p.Pdf);
+    }
+    return 0;
+}

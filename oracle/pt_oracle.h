@@ -21,8 +21,8 @@
  * independently.  Two stage bodies are pinned the same way (golden_stage_*.json): the
  * main() of raygen.rgen with its trace calls scripted (pto_test_raygen) and the main() of
  * closestHit.rchit over a one-triangle scene (pto_test_closest_hit), and the two any-hit
- * mains for one candidate (pto_test_any_hit).  What the Vulkan driver and sampler do
- * (tree, ray / triangle test, textureGrad) and the miss body are restated by reading and checked by the closed forms of
+ * mains for one candidate (pto_test_any_hit), the miss main (pto_test_miss).  What the
+ * Vulkan driver and sampler do (tree, ray / triangle test, textureGrad) is restated by reading and checked by the closed forms of
  * tests/test_analytic.py.  Image-level parity is UNPINNED by the reference -- "parity
  * unpinned": it holds no reference image, its tests assert finiteness only, and it
  * cannot be built here (Vulkan RT + 11 absent submodules) -- see DESIGN.md section 2.
@@ -100,6 +100,8 @@ PTX_API int pto_test_eval(uint32_t fn, const float *in, float *out, uint32_t n);
  * tests/golden/golden_stage_*.json, which tools/gen_golden.py produces from the reference's raygen.rgen text. */
 PTX_API int pto_test_raygen(const uint32_t *in, uint32_t *out, uint32_t n);
 /* closestHit.rchit main() on triangle 0 of a scene, for given hits and incoming payloads (layout at the definition) */
+/* miss.rmiss main() for ray directions */
+PTX_API int pto_test_miss(const PtoScene *s, const uint32_t *in, uint32_t *out, uint32_t n);
 /* anyhit.rahit / occlusionAnyhit.rahit main() for candidate hits on triangle 0 (layout at the definition) */
 PTX_API int pto_test_any_hit(const PtoScene *s, const uint32_t *in, uint32_t *out, uint32_t n);
 PTX_API int pto_test_closest_hit(const PtoScene *s, const PtxLightsUbo *lights, const uint32_t *in, uint32_t *out, uint32_t n);

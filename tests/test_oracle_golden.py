@@ -194,6 +194,36 @@ def test_oracle_any_hit_against_reference_mains(orc, pkg):
     assert replaced >= 50
 
 
+def test_oracle_miss_against_reference_main(orc, pkg):
+    """Stage level: miss.rmiss's main() from the reference's text against the oracle's miss stage: the clear colour, a
+    2-D sky through hdrToLdr, a cube sky as it is, and Pdf = -1 in every case (one-texel sky images: the lookup itself is
+    the sampler's business)."""
+    import ctypes as C
+    import json
+    import os
+
+    class Tex(C.Structure):
+        _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("format", C.c_uint32), ("levels", C.c_uint32), ("data", C.c_void_p)]
+
+    with open(os.path.join(util.GOLDEN_DIR, "golden_stage_fixed.json")) as f:
+        c = json.load(f)["missMain"]
+    inp = np.array(c["in"], np.uint32).reshape(-1, c["nin"])
+    exp = np.array(c["out"], np.uint32).reshape(-1, c["nout"])
+    assert len(inp) >= 90 and set(inp[:, 0].tolist()) == {0, 1, 2}
+    for row, want in zip(inp, exp):
+        texel = np.ascontiguousarray(row[4:8].view(np.float32))
+        kind = int(row[0])
+        sky = (Tex * 6)(*[Tex(1, 1, 2, 1, texel.ctypes.data) for _ in range(6)])
+        d = pkg.SceneDesc()
+        d.skyboxKind = kind
+        d.skybox = C.addressof(sky) if kind else None
+        got = orc.OracleScene(d, build_bvh=False).test_miss(row[1:4])[0]
+        if kind == 2:  # the seamless bilinear blend of six equal 1 x 1 faces returns the texel up to the rounding of its lerps
+            assert np.allclose(got.view(np.float32), want.view(np.float32), rtol=3e-7, atol=0), (got.view(np.float32), want.view(np.float32))
+        else:
+            assert (got == want).all(), (kind, got.view(np.float32), want.view(np.float32))
+
+
 def test_reference_test_properties(orc):
     """The three properties the reference's own tests assert (ShadingTest.cpp: finite outputs on
     the TestData.h grids; BsdfTest.cpp:34-40: lobe weights sum to 1 within 4 ULP)."""

@@ -158,6 +158,11 @@ def main():
         parts.append(rewrite(lines(os.path.join(REF, "anyhit.rahit"), [(36, 65)])).replace("void main()", "void anyHitMain()"))
         parts.append(rewrite(lines(os.path.join(REF, "occlusionAnyhit.rahit"), [(35, 54)])).replace("void main()", "void occlusionAnyHitMain()"))
         parts.append("#undef ignoreIntersectionEXT")
+        # miss.rmiss:16-39 main(): the sky constant, or a one-texel 2-D / cube sky (the lookup itself is the sampler's)
+        parts.append(rewrite(lines(sr, [(92, 95)])))  # MissFlags*
+        parts.append("uint s_MissFlags; Sampler2D skybox2D; struct SamplerCube { vec4 texel; } skyboxCube;\n"
+                     "inline vec4 texture(const SamplerCube &s, vec3) { return s.texel; }")
+        parts.append(rewrite(lines(os.path.join(REF, "miss.rmiss"), [(16, 39)])).replace("void main()", "void missMain()"))
         parts.append("} // namespace stage_hit")
         parts.append("} // namespace glsl")
         parts.append('#include "%s/golden_main.inc"' % HERE)
