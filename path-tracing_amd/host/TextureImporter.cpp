@@ -253,22 +253,45 @@ DecodedImage TextureImporter::DecodePng(std::span<const uint8_t> f)
             end = true;
         pos += 12 + len;
     }
-    if (!w || !h || interlace)
-        throw error(interlace ? "PNG: interlaced files are not supported" : "PNG: missing IHDR");
+    if (!w || !h)
+        throw error("PNG: missing IHDR");
+    if (interlace > 1)
+        throw error("PNG: unknown interlace method");
     const int samples = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!samples || !(depth == 8 || depth == 16 || (depth < 8 && (ctype == 0 || ctype == 3))))
         throw error("PNG: unsupported colour type / bit depth");
     const size_t bpp = std::max<size_t>(1, static_cast<size_t>(samples) * depth / 8);
-    const size_t stride = (static_cast<size_t>(w) * samples * depth + 7) / 8;
     std::vector<uint8_t> raw = Inflate(idat);
-    if (raw.size() < (stride + 1) * h)
+    // The image data is one pass (the whole image) or the seven reduced images of Adam7 (PNG spec 8.2), each a sequence of
+    // filtered scanlines of its own width; a pass of zero width or height is absent from the stream.
+    struct Pass { uint32_t x0, y0, dx, dy; };
+    static const Pass adam7[7] = { { 0, 0, 8, 8 }, { 4, 0, 8, 8 }, { 0, 4, 4, 8 }, { 2, 0, 4, 4 }, { 0, 2, 2, 4 }, { 1, 0, 2, 2 }, { 0, 1, 1, 2 } };
+    static const Pass whole = { 0, 0, 1, 1 };
+    const Pass *passes = interlace ? adam7 : &whole;
+    const int passCount = interlace ? 7 : 1;
+    DecodedImage img;
+    img.Width = w;
+    img.Height = h;
+    img.Channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 4 ? 2 : ctype == 6 ? 4 : (trns.empty() ? 3 : 4);
+    if ((ctype == 0 || ctype == 2) && !trns.empty())
+        img.Channels++; // a colour key adds an alpha channel
+    img.Pixels.resize(static_cast<size_t>(w) * h * 4);
+    size_t at = 0; // position in the inflated stream
+    for (int pass = 0; pass < passCount; pass++)
+    {
+    const Pass &ps = passes[pass];
+    const uint32_t pw = w > ps.x0 ? (w - ps.x0 + ps.dx - 1) / ps.dx : 0, ph = h > ps.y0 ? (h - ps.y0 + ps.dy - 1) / ps.dy : 0;
+    if (!pw || !ph)
+        continue;
+    const size_t stride = (static_cast<size_t>(pw) * samples * depth + 7) / 8;
+    if (raw.size() < at || raw.size() - at < (stride + 1) * ph)
         throw error("PNG: not enough image data");
     // unfilter in place (PNG spec 9.2)
-    for (uint32_t y = 0; y < h; y++)
+    for (uint32_t y = 0; y < ph; y++)
     {
-        uint8_t *cur = &raw[(stride + 1) * y + 1];
-        const uint8_t *up = y ? &raw[(stride + 1) * (y - 1) + 1] : nullptr;
-        const int filter = raw[(stride + 1) * y];
+        uint8_t *cur = &raw[at + (stride + 1) * y + 1];
+        const uint8_t *up = y ? &raw[at + (stride + 1) * (y - 1) + 1] : nullptr;
+        const int filter = raw[at + (stride + 1) * y];
         for (size_t i = 0; i < stride; i++)
         {
             const int a = i >= bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= bpp) ? up[i - bpp] : 0;
@@ -290,19 +313,12 @@ DecodedImage TextureImporter::DecodePng(std::span<const uint8_t> f)
             cur[i] = static_cast<uint8_t>(cur[i] + pred);
         }
     }
-    DecodedImage img;
-    img.Width = w;
-    img.Height = h;
-    img.Channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 4 ? 2 : ctype == 6 ? 4 : (trns.empty() ? 3 : 4);
-    if ((ctype == 0 || ctype == 2) && !trns.empty())
-        img.Channels++; // a colour key adds an alpha channel
-    img.Pixels.resize(static_cast<size_t>(w) * h * 4);
-    for (uint32_t y = 0; y < h; y++)
+    for (uint32_t py = 0; py < ph; py++)
     {
-        const uint8_t *row = &raw[(stride + 1) * y + 1];
-        for (uint32_t x = 0; x < w; x++)
+        const uint8_t *row = &raw[at + (stride + 1) * py + 1];
+        for (uint32_t x = 0; x < pw; x++) // x: the pixel's column inside the pass
         {
-            uint8_t *o = &img.Pixels[(static_cast<size_t>(y) * w + x) * 4];
+            uint8_t *o = &img.Pixels[((static_cast<size_t>(ps.y0) + static_cast<size_t>(py) * ps.dy) * w + ps.x0 + static_cast<size_t>(x) * ps.dx) * 4];
             auto sample = [&](int k) -> uint32_t { // k-th sample of pixel x at the file's bit depth
                 if (depth == 8)
                     return row[static_cast<size_t>(x) * samples + k];
@@ -342,6 +358,8 @@ DecodedImage TextureImporter::DecodePng(std::span<const uint8_t> f)
                     o[3] = 0;
             }
         }
+    }
+    at += (stride + 1) * ph;
     }
     return img;
 }

@@ -3,8 +3,8 @@
 //
 // The reference calls stb_image (PNG / JPG / TGA / HDR ...) and gli (DDS BC1 / BC3 / BC5); neither library is
 // available here, so the decoders are written out:
-//   PNG   all colour types, 8 / 16 bit (16 -> high byte, as stb), zlib inflate with stored / fixed / dynamic blocks;
-//         interlaced files are rejected
+//   PNG   all colour types, 1 - 16 bit (16 -> high byte, as stb), zlib inflate with stored / fixed / dynamic blocks,
+//         Adam7 interlacing
 //   JPG   baseline sequential DCT (Huffman, 8-bit, 1 or 3 components, any sampling factors, restart intervals);
 //         progressive / arithmetic files are rejected
 //   TGA   uncompressed and RLE true colour / greyscale, 8 / 24 / 32 bit

@@ -53,6 +53,40 @@ def _png(w, h, ctype, depth, rows, palette=None, trns=None, filters=None, level=
     return data + chunk(b"IEND", b"")
 
 
+def _adam7_png(w, h, ctype, depth, pixels, filters=None):
+    """An interlaced PNG: pixels is (h, w, samples) uint8 for 8-bit types, or (h, w) of 0 / 1 for 1-bit greyscale."""
+    def chunk(t, b):
+        return struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b) & 0xFFFFFFFF)
+
+    samples = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    bpp = max(1, samples * depth // 8)
+    raw = bytearray()
+    n = 0
+    for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+        sub = pixels[y0::dy, x0::dx]
+        if sub.shape[0] == 0 or sub.shape[1] == 0:
+            continue
+        prev = None
+        for line in sub:
+            row = bytes(np.packbits(line)) if depth == 1 else line.tobytes()
+            ft = filters[n % len(filters)] if filters else 0
+            n += 1
+            up = prev if prev is not None else bytes(len(row))
+            out = bytearray(len(row))
+            for i in range(len(row)):
+                a = row[i - bpp] if i >= bpp else 0
+                b = up[i]
+                c = up[i - bpp] if i >= bpp else 0
+                q = a + b - c
+                pa, pb, pc = abs(q - a), abs(q - b), abs(q - c)
+                p = [0, a, b, (a + b) >> 1, a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)][ft]
+                out[i] = (row[i] - p) & 255
+            raw.append(ft)
+            raw += out
+            prev = row
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1)) + chunk(b"IDAT", zlib.compress(bytes(raw))) + chunk(b"IEND", b"")
+
+
 def test_inflate_and_png_variants(pkg):
     rng = np.random.default_rng(0)
     w, h = 37, 23
@@ -99,9 +133,17 @@ def test_inflate_and_png_variants(pkg):
         pkg.write_image(os.path.join(d, "x.hdr"), f, pkg.OUTPUT_HDR)
         img, ch = pkg.decode_image(open(os.path.join(d, "x.hdr"), "rb").read())
         assert img.dtype == np.float32 and ch == 3 and np.abs(img[..., :3] - f[..., :3]).max() <= f[..., :3].max() / 100 and (img[..., 3] == 1).all()
-    # errors: truncated stream, interlaced file, garbage
+    # Adam7: the seven reduced images, each filtered on its own width (8-bit RGBA and 1-bit grey, sizes that leave passes empty)
+    for iw, ih in ((37, 23), (1, 1), (2, 5), (9, 3)):
+        px = rng.integers(0, 256, (ih, iw, 4), dtype=np.uint8)
+        img, ch = pkg.decode_image(_adam7_png(iw, ih, 6, 8, px, filters=[4, 1, 0, 2, 3]))
+        assert ch == 4 and (img == px).all(), (iw, ih)
+    bw = rng.integers(0, 2, (11, 19)).astype(np.uint8)
+    img, _ = pkg.decode_image(_adam7_png(19, 11, 0, 1, bw))
+    assert (img[..., 0] == bw * 255).all()
+    # errors: truncated stream, unknown interlace method, garbage
     good = _png(w, h, 6, 8, [rgba[y].tobytes() for y in range(h)])
-    for bad in (good[:100], good.replace(b"IHDR" + good[16:28] + b"\x00", b"IHDR" + good[16:28] + b"\x01"), b"not an image at all" * 4):
+    for bad in (good[:100], good.replace(b"IHDR" + good[16:28] + b"\x00", b"IHDR" + good[16:28] + b"\x02"), b"not an image at all" * 4):
         with pytest.raises(pkg.PtxError):
             pkg.decode_image(bad)
 
