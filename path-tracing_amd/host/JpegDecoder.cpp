@@ -1,7 +1,7 @@
-// JpegDecoder.cpp -- TextureImporter::DecodeJpeg: baseline / extended sequential Huffman JPEG (ITU T.81),
-// 8-bit samples, 1 or 3 components, arbitrary sampling factors, restart intervals.  Chroma subsampled 2:1 in either
+// JpegDecoder.cpp -- TextureImporter::DecodeJpeg: baseline / extended sequential and progressive Huffman JPEG (ITU T.81,
+// SOF0 / SOF1 / SOF2), 8-bit samples, 1 or 3 components, arbitrary sampling factors, restart intervals.  Chroma subsampled 2:1 in either
 // direction is upsampled with the triangle filter stb_image and libjpeg use (3/4 near + 1/4 far per axis), other factors
-// by replication; colour conversion is the JFIF YCbCr matrix.  Progressive and arithmetic-coded files are rejected
+// by replication; colour conversion is the JFIF YCbCr matrix.  Lossless and arithmetic-coded files are rejected
 // (the importer then falls back to the slot's default texture, as the reference does for any load failure).
 #include <algorithm>
 #include <cmath>
@@ -44,6 +44,7 @@ struct Component
     int pred = 0;
     int bw = 0, bh = 0; // size of the component plane in blocks (padded to whole MCUs)
     std::vector<uint8_t> plane;
+    std::vector<int16_t> coef; // progressive: 64 coefficients per block of the padded plane, in natural order
 };
 
 struct Reader
@@ -155,7 +156,7 @@ DecodedImage TextureImporter::DecodeJpeg(std::span<const uint8_t> f)
     HuffTable dc[4], ac[4];
     Component comp[3];
     int ncomp = 0, width = 0, height = 0, restartInterval = 0, hmax = 1, vmax = 1;
-    bool haveFrame = false, adobe = false;
+    bool haveFrame = false, adobe = false, progressive = false;
     int adobeTransform = -1;
     size_t pos = 2;
     auto be16 = [&](size_t o) { return (f[o] << 8) | f[o + 1]; };
@@ -206,8 +207,9 @@ DecodedImage TextureImporter::DecodeJpeg(std::span<const uint8_t> f)
                 t.Build();
             }
         }
-        else if (marker == 0xc0 || marker == 0xc1) // SOF0 / SOF1
+        else if (marker == 0xc0 || marker == 0xc1 || marker == 0xc2) // SOF0 / SOF1 / SOF2 (progressive)
         {
+            progressive = marker == 0xc2;
             if (len < 8 || f[seg] != 8) throw error("JPEG: only 8-bit samples are supported");
             if (haveFrame) throw error("JPEG: more than one frame header");
             height = be16(seg + 1);
@@ -227,8 +229,8 @@ DecodedImage TextureImporter::DecodeJpeg(std::span<const uint8_t> f)
             }
             haveFrame = true;
         }
-        else if (marker >= 0xc2 && marker <= 0xcf && marker != 0xc8 && marker != 0xcc)
-            throw error("JPEG: progressive / lossless / arithmetic files are not supported");
+        else if (marker >= 0xc3 && marker <= 0xcf && marker != 0xc8 && marker != 0xcc)
+            throw error("JPEG: lossless / arithmetic files are not supported");
         else if (marker == 0xdd)
         {
             if (len < 4) throw error("JPEG: bad DRI");
@@ -244,6 +246,8 @@ DecodedImage TextureImporter::DecodeJpeg(std::span<const uint8_t> f)
             if (!haveFrame) throw error("JPEG: scan before frame");
             if (seg >= segEnd) throw error("JPEG: bad SOS");
             const int ns = f[seg];
+            if (progressive)
+                break; // the scans of a progressive file are read below, starting again from this marker
             if (ns != ncomp) throw error("JPEG: multi-scan files are not supported");
             if (seg + 1 + 2 * static_cast<size_t>(ns) + 3 > segEnd) throw error("JPEG: bad SOS");
             for (int i = 0; i < ns; i++)
@@ -280,9 +284,229 @@ DecodedImage TextureImporter::DecodeJpeg(std::span<const uint8_t> f)
         comp[0].plane.assign(static_cast<size_t>(mcusX1) * 8 * mcusY1 * 8, 0);
     }
 
+    if (progressive)
+    {
+        // ---- T.81 Annex G: several scans, each a band of coefficients (Ss..Se) at some precision (Ah, Al) of one component,
+        // or the DC terms of all of them; coefficients accumulate in `coef` and are transformed once at the end
+        for (int i = 0; i < ncomp; i++)
+            comp[i].coef.assign(static_cast<size_t>(comp[i].bw) * comp[i].bh * 64, 0);
+        size_t at = pos - 1; // `pos` is just past the SOS marker byte: step back onto it
+        while (at > 0 && f[at] != 0xda) at--;
+        at--; // the 0xff in front of it
+        int scans = 0;
+        for (;;)
+        {
+            while (at < f.size() && f[at] != 0xff) at++;
+            while (at < f.size() && f[at] == 0xff) at++;
+            if (at >= f.size())
+                break; // no EOI: use what has arrived
+            const int marker = f[at++];
+            if (marker == 0xd9)
+                break;
+            if (marker >= 0xd0 && marker <= 0xd7)
+                continue;
+            if (at + 2 > f.size()) throw error("JPEG: truncated segment");
+            const size_t len = static_cast<size_t>(be16(at));
+            if (len < 2 || at + len > f.size()) throw error("JPEG: bad segment length");
+            const size_t seg = at + 2, segEnd = at + len;
+            if (marker == 0xc4) // DHT between scans
+            {
+                size_t q = seg;
+                while (q + 17 <= segEnd)
+                {
+                    const int tc = f[q] >> 4, th = f[q] & 15;
+                    if (tc > 1 || th > 3) throw error("JPEG: bad DHT");
+                    HuffTable &t = tc ? ac[th] : dc[th];
+                    int total = 0;
+                    for (int i = 1; i <= 16; i++) { t.bits[i] = f[q + i]; total += t.bits[i]; }
+                    q += 17;
+                    if (total > 256 || q + total > segEnd) throw error("JPEG: bad DHT");
+                    std::memcpy(t.vals, &f[q], static_cast<size_t>(total));
+                    q += static_cast<size_t>(total);
+                    t.Build();
+                }
+            }
+            else if (marker == 0xdd)
+            {
+                if (len < 4) throw error("JPEG: bad DRI");
+                restartInterval = be16(seg);
+            }
+            else if (marker == 0xdb)
+                throw error("JPEG: quantisation tables redefined between scans are not supported");
+            if (marker != 0xda)
+            {
+                at = segEnd;
+                continue;
+            }
+            // ---- one scan
+            if (seg >= segEnd) throw error("JPEG: bad SOS");
+            const int ns = f[seg];
+            if (ns < 1 || ns > ncomp || seg + 1 + 2 * static_cast<size_t>(ns) + 3 > segEnd) throw error("JPEG: bad SOS");
+            int which[3] = { 0, 0, 0 };
+            for (int i = 0; i < ns; i++)
+            {
+                const int cs = f[seg + 1 + i * 2], tdta = f[seg + 2 + i * 2];
+                int k = 0;
+                while (k < ncomp && comp[k].id != cs) k++;
+                if (k == ncomp) throw error("JPEG: bad SOS");
+                which[i] = k;
+                comp[k].td = tdta >> 4;
+                comp[k].ta = tdta & 15;
+                if (comp[k].td > 3 || comp[k].ta > 3) throw error("JPEG: bad SOS");
+            }
+            const int Ss = f[seg + 1 + 2 * ns], Se = f[seg + 2 + 2 * ns], Ah = f[seg + 3 + 2 * ns] >> 4, Al = f[seg + 3 + 2 * ns] & 15;
+            if (Ss > Se || Se > 63 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1) || Al > 13) throw error("JPEG: bad progressive scan parameters");
+            for (int i = 0; i < ns; i++)
+                if ((Ss == 0 && Ah == 0 && !dc[comp[which[i]].td].present) || (Ss > 0 && !ac[comp[which[i]].ta].present))
+                    throw error("JPEG: missing Huffman table");
+            if (++scans > 1000) throw error("JPEG: too many scans");
+            Reader r { f.data() + segEnd, f.data() + f.size() };
+            int eobrun = 0, restartCount = 0;
+            for (int i = 0; i < ncomp; i++) comp[i].pred = 0;
+            const int p1 = 1 << Al, m1 = -(1 << Al);
+            auto block = [&](Component &c, int bx, int by) {
+                int16_t *b = &c.coef[(static_cast<size_t>(by) * c.bw + bx) * 64];
+                if (Ss == 0)
+                {
+                    if (Ah == 0) // DC first
+                    {
+                        const int t = DecodeSymbol(r, dc[c.td]);
+                        if (t > 11) throw error("JPEG: bad DC category");
+                        c.pred += Extend(r.Bits(t), t);
+                        b[0] = static_cast<int16_t>(c.pred * p1);
+                    }
+                    else if (r.Bit()) // DC refinement
+                        b[0] = static_cast<int16_t>(b[0] | p1);
+                    return;
+                }
+                if (Ah == 0) // AC first
+                {
+                    if (eobrun > 0)
+                    {
+                        eobrun--;
+                        return;
+                    }
+                    for (int k = Ss; k <= Se;)
+                    {
+                        const int rs = DecodeSymbol(r, ac[c.ta]), run = rs >> 4, size = rs & 15;
+                        if (size == 0)
+                        {
+                            if (run < 15)
+                            {
+                                eobrun = (1 << run) - 1;
+                                if (run) eobrun += r.Bits(run);
+                                break;
+                            }
+                            k += 16;
+                            continue;
+                        }
+                        k += run;
+                        if (k > Se) throw error("JPEG: bad AC run");
+                        b[kZigzag[k]] = static_cast<int16_t>(Extend(r.Bits(size), size) * p1);
+                        k++;
+                    }
+                    return;
+                }
+                // AC refinement (G.1.2.3)
+                int k = Ss;
+                auto correct = [&](int16_t &v) {
+                    if (r.Bit() && (v & p1) == 0)
+                        v = static_cast<int16_t>(v + (v >= 0 ? p1 : m1));
+                };
+                if (eobrun == 0)
+                {
+                    for (; k <= Se; k++)
+                    {
+                        const int rs = DecodeSymbol(r, ac[c.ta]);
+                        int run = rs >> 4;
+                        int value = 0;
+                        if (rs & 15)
+                            value = r.Bit() ? p1 : m1; // a newly non-zero coefficient: always magnitude 1 at this precision
+                        else if (run != 15)
+                        {
+                            eobrun = 1 << run;
+                            if (run) eobrun += r.Bits(run);
+                            break;
+                        }
+                        while (k <= Se)
+                        {
+                            int16_t &v = b[kZigzag[k]];
+                            if (v != 0)
+                                correct(v);
+                            else if (--run < 0)
+                                break;
+                            k++;
+                        }
+                        if (value && k <= Se)
+                            b[kZigzag[k]] = static_cast<int16_t>(value);
+                    }
+                }
+                if (eobrun > 0)
+                {
+                    for (; k <= Se; k++)
+                        if (b[kZigzag[k]] != 0)
+                            correct(b[kZigzag[k]]);
+                    eobrun--;
+                }
+            };
+            auto restartIfDue = [&]() {
+                if (restartInterval && restartCount == restartInterval)
+                {
+                    r.Reset();
+                    while (r.p + 1 < r.end && !(r.p[0] == 0xff && r.p[1] >= 0xd0 && r.p[1] <= 0xd7)) r.p++;
+                    if (r.p + 1 < r.end) r.p += 2;
+                    for (int i = 0; i < ncomp; i++) comp[i].pred = 0;
+                    eobrun = 0;
+                    restartCount = 0;
+                }
+                restartCount++;
+            };
+            if (ns > 1) // interleaved (DC) scan: MCU order
+            {
+                for (int my = 0; my < mcusY1; my++)
+                    for (int mx = 0; mx < mcusX1; mx++)
+                    {
+                        restartIfDue();
+                        for (int i = 0; i < ns; i++)
+                        {
+                            Component &c = comp[which[i]];
+                            for (int by = 0; by < c.v; by++)
+                                for (int bx = 0; bx < c.h; bx++)
+                                    block(c, mx * c.h + bx, my * c.v + by);
+                        }
+                    }
+            }
+            else // one component: its blocks row by row, only those that carry image samples
+            {
+                Component &c = comp[which[0]];
+                const int cw = (width * c.h + hmax - 1) / hmax, chh = (height * c.v + vmax - 1) / vmax;
+                const int blocksX = (cw + 7) / 8, blocksY = (chh + 7) / 8;
+                for (int by = 0; by < blocksY; by++)
+                    for (int bx = 0; bx < blocksX; bx++)
+                    {
+                        restartIfDue();
+                        block(c, bx, by);
+                    }
+            }
+            at = static_cast<size_t>(r.p - f.data()); // on or before the next marker
+            if (at < segEnd) at = segEnd;
+        }
+        if (!scans) throw error("JPEG: no scan");
+        for (int i = 0; i < ncomp; i++)
+            for (int by = 0; by < comp[i].bh; by++)
+                for (int bx = 0; bx < comp[i].bw; bx++)
+                {
+                    const int16_t *b = &comp[i].coef[(static_cast<size_t>(by) * comp[i].bw + bx) * 64];
+                    float deq[64];
+                    for (int z = 0; z < 64; z++)
+                        deq[z] = static_cast<float>(b[z] * quant[comp[i].tq][z]);
+                    const int stride = comp[i].bw * 8;
+                    Idct(deq, &comp[i].plane[static_cast<size_t>(by) * 8 * stride + bx * 8], stride);
+                }
+    }
     Reader r { f.data() + pos, f.data() + f.size() };
     int restartCount = 0;
-    for (int my = 0; my < mcusY1; my++)
+    for (int my = 0; !progressive && my < mcusY1; my++)
         for (int mx = 0; mx < mcusX1; mx++)
         {
             if (restartInterval && restartCount == restartInterval)

@@ -5,8 +5,8 @@
 // available here, so the decoders are written out:
 //   PNG   all colour types, 1 - 16 bit (16 -> high byte, as stb), zlib inflate with stored / fixed / dynamic blocks,
 //         Adam7 interlacing
-//   JPG   baseline sequential DCT (Huffman, 8-bit, 1 or 3 components, any sampling factors, restart intervals);
-//         progressive / arithmetic files are rejected
+//   JPG   baseline / extended sequential and progressive DCT (Huffman, 8-bit, 1 or 3 components, any sampling factors,
+//         restart intervals); arithmetic-coded and lossless files are rejected
 //   TGA   uncompressed and RLE true colour / greyscale, 8 / 24 / 32 bit
 //   HDR   Radiance RGBE, run-length and flat scanlines -> RGBA32F
 //   DDS   BC1 / BC3 / BC5 blocks decoded to RGBA8, with the file's own mip levels (a complete chain is uploaded as it

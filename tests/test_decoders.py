@@ -362,8 +362,26 @@ def test_against_pillow(pkg, tmp_path):
     grey = save(im.convert("L"), "JPEG", quality=90)
     ours, ch = pkg.decode_image(grey)
     assert ch == 1 and np.abs(ours[..., 0].astype(int) - np.asarray(Image.open(io.BytesIO(grey))).astype(int)).max() <= 2
-    with pytest.raises(pkg.PtxError):
-        pkg.decode_image(save(im, "JPEG", progressive=True))
+    # progressive files (SOF2): spectral selection + successive approximation, the scan script libjpeg writes by default
+    for kw in ({"quality": 85, "subsampling": 2}, {"quality": 95, "subsampling": 0}, {"quality": 60, "subsampling": 1, "optimize": True},
+               {"quality": 90, "subsampling": 2, "restart_marker_blocks": 5}):
+        data = save(im, "JPEG", progressive=True, **kw)
+        assert b"\xff\xc2" in data
+        ours, ch = pkg.decode_image(data)
+        theirs = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+        diff = np.abs(ours[..., :3].astype(int) - theirs.astype(int))
+        assert ch == 3 and np.mean(diff) < 2.5 and np.percentile(diff, 99) <= 24, (kw, float(np.mean(diff)), int(diff.max()))
+        # the same picture as a baseline file decodes to (nearly) the same pixels: the coefficients are identical
+        base, _ = pkg.decode_image(save(im, "JPEG", **kw))
+        assert np.abs(ours.astype(int) - base.astype(int)).max() <= 1, kw
+    pgrey = save(im.convert("L"), "JPEG", quality=90, progressive=True)
+    ours, ch = pkg.decode_image(pgrey)
+    assert ch == 1 and np.abs(ours[..., 0].astype(int) - np.asarray(Image.open(io.BytesIO(pgrey))).astype(int)).max() <= 2
+    for cut in (len(pgrey) // 3, len(pgrey) // 2):   # a truncated progressive file still decodes (coarser), or raises: never crashes
+        try:
+            pkg.decode_image(pgrey[:cut])
+        except pkg.PtxError:
+            pass
     # PNG written by libpng / zlib: RGB, RGBA, palette, grey + alpha, 16-bit grey
     rgba = np.dstack([pic, rng.integers(0, 256, xx.shape, dtype=np.uint8)])
     for image, expect_ch in ((im, 3), (Image.fromarray(rgba), 4), (im.convert("P", palette=Image.ADAPTIVE, colors=64), 3),
