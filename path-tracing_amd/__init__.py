@@ -29,7 +29,7 @@ import numpy as np
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
 HIP_LIB = os.environ.get("PTX_HIP_LIB") or os.path.join(PKG_DIR, "libptx_hip.so")  # PTX_HIP_LIB: an experimental build of the same ABI
-HOST_LIB = os.path.join(PKG_DIR, "libptx_host.so")
+HOST_LIB = os.environ.get("PTX_HOST_LIB") or os.path.join(PKG_DIR, "libptx_host.so")  # PTX_HOST_LIB: e.g. a sanitizer build
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",

@@ -217,6 +217,8 @@ DecodedImage TextureImporter::DecodeJpeg(std::span<const uint8_t> f)
             ncomp = f[seg + 5];
             if (!(ncomp == 1 || ncomp == 3) || !width || !height || seg + 6 + static_cast<size_t>(ncomp) * 3 > segEnd)
                 throw error("JPEG: unsupported component count");
+            if (static_cast<uint64_t>(width) * static_cast<uint64_t>(height) > 16384ull * 16384ull)
+                throw error("JPEG: image too large");
             for (int i = 0; i < ncomp; i++)
             {
                 comp[i].id = f[seg + 6 + i * 3];

@@ -109,9 +109,12 @@ private:
         const size_t cs = (ct == 5120 || ct == 5121) ? 1 : (ct == 5122 || ct == 5123) ? 2 : (ct == 5125 || ct == 5126) ? 4 : 0;
         if (!components || !cs || count < 0)
             throw error("glTF: unsupported accessor type");
-        std::vector<double> out(static_cast<size_t>(count) * components, 0.0);
         if (acc["bufferView"].IsNull())
-            return out; // all zeros by definition
+        {
+            if (count > (1 << 28))
+                throw error("glTF: accessor without a buffer view is too large");
+            return std::vector<double>(static_cast<size_t>(count) * components, 0.0); // all zeros by definition
+        }
         const std::span<const uint8_t> view = BufferView(acc["bufferView"].Int());
         const int64_t accOffset = acc["byteOffset"].Int(0);
         const int64_t declaredStride = json["bufferViews"][static_cast<size_t>(acc["bufferView"].Int())]["byteStride"].Int(0);
@@ -125,6 +128,7 @@ private:
         if (count && (offset > view.size() || elem > view.size() - offset ||
                       (static_cast<uint64_t>(count) - 1) > (view.size() - offset - elem) / stride))
             throw error("glTF: accessor reads past its buffer view");
+        std::vector<double> out(static_cast<size_t>(count) * components, 0.0); // only now: the count has been checked against the view
         const bool norm = normalise && acc["normalized"].kind == Json::Kind::Bool && acc["normalized"].boolean;
         for (size_t i = 0; i < static_cast<size_t>(count); i++)
             for (int k = 0; k < components; k++)

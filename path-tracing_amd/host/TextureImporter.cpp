@@ -8,8 +8,16 @@
 namespace PathTracing
 {
 
+// A decoded image is at most this many pixels (the reference keeps textures within 4096 x 4096, TextureUploader.h:74):
+// a corrupted header must not turn into a multi-gigabyte allocation.
+constexpr uint64_t kMaxImagePixels = 16384ull * 16384ull;
+
+
 std::vector<uint8_t> ReadFileBytes(const std::filesystem::path &path)
 {
+    std::error_code ec;
+    if (!std::filesystem::is_regular_file(path, ec)) // fopen() opens a directory too, and ftell() on it answers LONG_MAX
+        throw error("Could not open " + path.string());
     FILE *f = std::fopen(path.string().c_str(), "rb");
     if (!f)
         throw error("Could not open " + path.string());
@@ -255,6 +263,8 @@ DecodedImage TextureImporter::DecodePng(std::span<const uint8_t> f)
     }
     if (!w || !h)
         throw error("PNG: missing IHDR");
+    if (static_cast<uint64_t>(w) * h > kMaxImagePixels)
+        throw error("PNG: image too large");
     if (interlace > 1)
         throw error("PNG: unknown interlace method");
     const int samples = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
@@ -381,6 +391,9 @@ DecodedImage TextureImporter::DecodeTga(std::span<const uint8_t> f)
         throw error("TGA: unsupported pixel depth");
     const size_t px = bpp / 8;
     size_t pos = 18 + static_cast<size_t>(idLen);
+    // every pixel costs at least 1 / 128 packet byte (an RLE packet covers up to 128): a header that promises more is corrupt
+    if (static_cast<uint64_t>(w) * h > kMaxImagePixels || static_cast<uint64_t>(w) * h / 128 > f.size())
+        throw error("TGA: image too large for its data");
     DecodedImage img;
     img.Width = w;
     img.Height = h;
@@ -445,6 +458,8 @@ DecodedImage TextureImporter::DecodeHdr(std::span<const uint8_t> f)
     if (std::sscanf(std::string(all.substr(pos, eol - pos)).c_str(), "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0)
         throw error("HDR: unsupported orientation");
     pos = eol + 1;
+    if (static_cast<uint64_t>(w) * static_cast<uint64_t>(h) > kMaxImagePixels || static_cast<uint64_t>(h) * 4 > all.size())
+        throw error("HDR: image too large for its data"); // a scanline takes at least 4 bytes
     DecodedImage img;
     img.Width = static_cast<uint32_t>(w);
     img.Height = static_cast<uint32_t>(h);
@@ -588,6 +603,8 @@ DecodedImage TextureImporter::DecodeDds(std::span<const uint8_t> f)
         throw error("Unsupported texture format");
     if (!w || !h)
         throw error("DDS: empty image");
+    if (static_cast<uint64_t>(w) * h > kMaxImagePixels)
+        throw error("DDS: image too large");
     // the file's own mip chain (dwMipMapCount, valid with DDSD_MIPMAPCOUNT): the reference uploads it as it is
     // (TextureImporter.cpp GetTextureInfo: Levels = texture.levels(); TextureUploader.cpp:440,492-501)
     uint32_t levels = (le32(8) & 0x20000u) ? le32(28) : 1u;
