@@ -28,8 +28,10 @@ with its own path state, as the reference keeps frames in flight (Renderer.cpp:1
 frame -- the bounce loop is driven from the device -- so the latency-bound end of one frame overlaps the head of the
 next.  Every step is still one complete frame: reset, 8 spp, gather, read-back.
 
-The timed region of K steps is repeated (`--repeats`, default: until >= 2 s have been timed) and the line reports the
-MEDIAN region; min / max ride in `spread`.
+Order of a run: setup (scene, tree build, and one frame per renderer of the ring so that its buffers exist and its bounce
+schedule has been learnt -- preparation per renderer, like the build), W warm-up steps, then the timed region of exactly K
+steps.  The region is repeated (`--repeats`, default: until >= 2 s have been timed) and the line reports the MEDIAN
+region; min / max ride in `spread`.
 
 Launch:  python bench.py --gpus N --steps K --warmup W           (N = 1)
          python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
@@ -233,7 +235,14 @@ class Job:
         return elapsed
 
     def measure(self, job_spp, steps, warmup, repeats, min_seconds, readback=True):
-        """Warm up, then repeat the K-step timed region; returns (median, all regions, kernel stats of the last region)."""
+        """Warm up, then repeat the K-step timed region; returns (median, all regions, kernel stats of the last region).
+
+        Setup before the W warm-up steps: every renderer of the ring renders one frame of the job's shape, so that its
+        path-state buffers exist and its bounce schedule has been learnt (the first launch of a shape is driven bounce by
+        bounce from the host) -- per-renderer preparation like the BVH build, not a step of the benchmark."""
+        for _ in range(self.F):
+            self.step(job_spp, readback)
+        self.finish()
         for _ in range(warmup):
             self.step(job_spp, readback)
         self.finish()
