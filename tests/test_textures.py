@@ -297,3 +297,49 @@ def test_upload_rules_match_oracle_bitexact(pkg, orc, gpu_renderer):
     full, _ = orc.OracleScene(s.desc).render(u, s.lights, 96, 64)
     img = gpu_renderer.readback()
     assert (img.view(np.uint32) == ref.view(np.uint32)).all() and not (ref == full).all()
+
+
+def test_isotropic_texture_grad_against_float64_formulas(pkg, orc):
+    """An independent restatement of the sampler for the isotropic case, in float64 from the Vulkan specification's
+    formulas (texel coordinates u * w - 1/2 with repeat addressing, bilinear weights, lambda = log2(rho), linear blend of
+    the two nearest levels of a 2 x 2-mean chain), on a float texture (no quantisation anywhere): the oracle's
+    textureGrad agrees to float precision."""
+    rng = np.random.default_rng(8)
+    W = H = 32
+    base = rng.uniform(0, 3, (H, W, 4)).astype(np.float32)
+    s = pkg.Scene("texture_test")
+    d, keep = _desc_with(pkg, s, [(W, H, F32, 1, base.reshape(-1))], budget=2**64 - 1)
+    osc = orc.OracleScene(d, build_bvh=False)
+    chain = [base.astype(np.float64)]
+    while chain[-1].shape[0] > 1:
+        c = chain[-1]
+        chain.append((c[0::2, 0::2] + c[1::2, 0::2] + c[0::2, 1::2] + c[1::2, 1::2]) / 4)
+
+    def bilinear(level, u, v):
+        img = chain[level]
+        h, w = img.shape[:2]
+        x, y = u * w - 0.5, v * h - 0.5
+        x0, y0 = np.floor(x), np.floor(y)
+        ax, ay = (x - x0)[:, None], (y - y0)[:, None]
+        i0, i1, j0, j1 = (x0.astype(int) % w), ((x0.astype(int) + 1) % w), (y0.astype(int) % h), ((y0.astype(int) + 1) % h)
+        return (img[j0, i0] * (1 - ax) + img[j0, i1] * ax) * (1 - ay) + (img[j1, i0] * (1 - ax) + img[j1, i1] * ax) * ay
+
+    n = 4000
+    u, v = rng.uniform(-1.5, 2.5, n), rng.uniform(-1.5, 2.5, n)
+    rho = 2.0 ** rng.uniform(-1.0, 5.5, n)          # footprint in texels: below one texel up to beyond the 1 x 1 level
+    ang = rng.uniform(0, 2 * np.pi, n)               # a square footprint, rotated: isotropic (eta = 1)
+    dudx, dvdx = rho * np.cos(ang) / W, rho * np.sin(ang) / H
+    dudy, dvdy = -rho * np.sin(ang) / W, rho * np.cos(ang) / H
+    got = osc.test_texture(_inputs(9, np.float32(u), np.float32(v), np.float32(dudx), np.float32(dvdx), np.float32(dudy), np.float32(dvdy))).view(np.float32)
+    uf, vf = np.float64(np.float32(u)), np.float64(np.float32(v))
+    lam = np.clip(np.log2(rho), 0, len(chain) - 1)
+    l0 = np.floor(lam).astype(int)
+    l1 = np.minimum(l0 + 1, len(chain) - 1)
+    f = (lam - l0)[:, None]
+    want = np.zeros((n, 4))
+    for level in range(len(chain)):
+        for sel, wgt in ((l0 == level, 1 - f), (l1 == level, f)):
+            if sel.any():
+                want[sel] += bilinear(level, uf[sel], vf[sel]) * wgt[sel]
+    err = np.abs(got - want) / np.maximum(1.0, np.abs(want))
+    assert err.max() < 3e-5, float(err.max())
