@@ -27,6 +27,23 @@
 namespace ptd
 {
 
+#ifndef PT_WIDE8
+#define PT_WIDE8 0 // experiment: 8 children per node (128-byte nodes); measured, DESIGN.md section 4
+#endif
+#if PT_WIDE8
+constexpr int kNodeWidth = 8;
+struct BvhNode
+{
+    float4 a;    // origin.xyz, w = bits: biased exponents ex | ey << 8 | ez << 16 (scale = 2^(e-127))
+    int4 refs;   // child refs 0..3
+    int4 refsB;  // child refs 4..7
+    uint4 qx;    // x = lo.x bytes of children 0..3, y = hi.x bytes 0..3, z = lo.x bytes 4..7, w = hi.x bytes 4..7
+    uint4 qy, qz;
+    uint4 pad0, pad1;
+};
+static_assert(sizeof(BvhNode) == 128, "BvhNode is 128 B");
+#else
+constexpr int kNodeWidth = 4;
 struct BvhNode
 {
     float4 a; // origin.xyz, w = bits: biased exponents ex | ey << 8 | ez << 16 (scale = 2^(e-127))
@@ -35,6 +52,7 @@ struct BvhNode
     uint4 q1; // x = lo.z bytes, y = hi.z bytes, z, w unused
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode is 64 B");
+#endif
 constexpr int kEmptyRef = 0x7ffffffe;
 
 struct Tri
@@ -698,18 +716,18 @@ __global__ void k_emit(int n, const uint32_t *__restrict__ vals, const float4 *_
     }
     if (i >= n - 1)
         return;
-    ChildBox c[4];
+    ChildBox c[kNodeWidth];
     int count = 2;
     {
         const int2 ch = children[i];
         fetchChild(ch.x, vals, boxLo, boxHi, nodeLo, nodeHi, c[0]);
         fetchChild(ch.y, vals, boxLo, boxHi, nodeLo, nodeHi, c[1]);
     }
-    for (int round = 0; round < 2; round++)
+    for (int round = 0; round < kNodeWidth - 2; round++)
     {
         int pick = -1;
         float best = -1.0f;
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < kNodeWidth; k++)
             if (k < count && c[k].ref >= 0)
             {
                 const float a = childArea(c[k]);
@@ -721,10 +739,10 @@ __global__ void k_emit(int n, const uint32_t *__restrict__ vals, const float4 *_
         ChildBox a, b;
         fetchChild(ch.x, vals, boxLo, boxHi, nodeLo, nodeHi, a);
         fetchChild(ch.y, vals, boxLo, boxHi, nodeLo, nodeHi, b);
-        for (int k = 0; k < 4; k++) // no dynamic register indexing
+        for (int k = 0; k < kNodeWidth; k++) // no dynamic register indexing
             if (k == pick)
                 c[k] = a;
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < kNodeWidth; k++)
             if (k == count)
                 c[k] = b;
         count++;
@@ -733,6 +751,9 @@ __global__ void k_emit(int n, const uint32_t *__restrict__ vals, const float4 *_
     const float4 nl = nodeLo[i], nh = nodeHi[i];
     const float o[3] = { nl.x, nl.y, nl.z }, top[3] = { nh.x, nh.y, nh.z };
     uint32_t ebits[3], qlo[3] = { 0, 0, 0 }, qhi[3] = { 0, 0, 0 };
+#if PT_WIDE8
+    uint32_t qloB[3] = { 0, 0, 0 }, qhiB[3] = { 0, 0, 0 }; // children 4..7
+#endif
     for (int a = 0; a < 3; a++)
     {
         // smallest power of two with 255 * scale >= extent, then grow until every child box
@@ -751,7 +772,10 @@ __global__ void k_emit(int n, const uint32_t *__restrict__ vals, const float4 *_
             const float scale = __uint_as_float((uint32_t)e << 23);
             bool ok = true;
             uint32_t wl = 0, wh = 0;
-            for (int k = 0; k < 4; k++)
+#if PT_WIDE8
+            uint32_t wlB = 0, whB = 0;
+#endif
+            for (int k = 0; k < kNodeWidth; k++)
             {
                 uint32_t ql = 255, qh = 0; // empty slot: inverted box, never hit
                 if (k < count)
@@ -769,14 +793,28 @@ __global__ void k_emit(int n, const uint32_t *__restrict__ vals, const float4 *_
                     if (decodeQ(o[a], qh, scale) < (double)c[k].hi[a])
                         ok = false;
                 }
-                wl |= ql << (8 * k);
-                wh |= qh << (8 * k);
+#if PT_WIDE8
+                if (k >= 4)
+                {
+                    wlB |= ql << (8 * (k - 4));
+                    whB |= qh << (8 * (k - 4));
+                }
+                else
+#endif
+                {
+                    wl |= ql << (8 * k);
+                    wh |= qh << (8 * k);
+                }
             }
             if (ok || e >= 254)
             {
                 ebits[a] = (uint32_t)e;
                 qlo[a] = wl;
                 qhi[a] = wh;
+#if PT_WIDE8
+                qloB[a] = wlB;
+                qhiB[a] = whB;
+#endif
                 break;
             }
             e++;
@@ -785,8 +823,16 @@ __global__ void k_emit(int n, const uint32_t *__restrict__ vals, const float4 *_
     BvhNode nd;
     nd.a = make_float4(o[0], o[1], o[2], __uint_as_float(ebits[0] | (ebits[1] << 8) | (ebits[2] << 16)));
     nd.refs = make_int4(c[0].ref, c[1].ref, count > 2 ? c[2].ref : kEmptyRef, count > 3 ? c[3].ref : kEmptyRef);
+#if PT_WIDE8
+    nd.refsB = make_int4(count > 4 ? c[4].ref : kEmptyRef, count > 5 ? c[5].ref : kEmptyRef, count > 6 ? c[6].ref : kEmptyRef, count > 7 ? c[7].ref : kEmptyRef);
+    nd.qx = make_uint4(qlo[0], qhi[0], qloB[0], qhiB[0]);
+    nd.qy = make_uint4(qlo[1], qhi[1], qloB[1], qhiB[1]);
+    nd.qz = make_uint4(qlo[2], qhi[2], qloB[2], qhiB[2]);
+    nd.pad0 = nd.pad1 = make_uint4(0u, 0u, 0u, 0u);
+#else
     nd.q0 = make_uint4(qlo[0], qhi[0], qlo[1], qhi[1]);
     nd.q1 = make_uint4(qlo[2], qhi[2], 0u, 0u);
+#endif
     nodes[i] = nd;
 }
 
@@ -804,11 +850,18 @@ __global__ void __launch_bounds__(256) k_relayout_level(uint32_t lo, uint32_t hi
     const uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
     BvhNode nd;
     nd.refs = make_int4(kEmptyRef, kEmptyRef, kEmptyRef, kEmptyRef);
+#if PT_WIDE8
+    nd.refsB = nd.refs;
+#endif
     if (i < hi)
         nd = raw[oldOf[i]];
-    int refs[4] = { nd.refs.x, nd.refs.y, nd.refs.z, nd.refs.w };
+#if PT_WIDE8
+    int refs[kNodeWidth] = { nd.refs.x, nd.refs.y, nd.refs.z, nd.refs.w, nd.refsB.x, nd.refsB.y, nd.refsB.z, nd.refsB.w };
+#else
+    int refs[kNodeWidth] = { nd.refs.x, nd.refs.y, nd.refs.z, nd.refs.w };
+#endif
     uint32_t c = 0;
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < kNodeWidth; k++)
         c += (refs[k] >= 0 && refs[k] != kEmptyRef) ? 1u : 0u;
     uint32_t incl = c; // inclusive prefix over the wave
     for (uint32_t d = 1; d < 64; d <<= 1)
@@ -824,13 +877,16 @@ __global__ void __launch_bounds__(256) k_relayout_level(uint32_t lo, uint32_t hi
     base = __shfl(base, 0) + incl - c;
     if (i >= hi)
         return;
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < kNodeWidth; k++)
         if (refs[k] >= 0 && refs[k] != kEmptyRef)
         {
             oldOf[base] = (uint32_t)refs[k];
             refs[k] = (int)base++;
         }
     nd.refs = make_int4(refs[0], refs[1], refs[2], refs[3]);
+#if PT_WIDE8
+    nd.refsB = make_int4(refs[4], refs[5], refs[6], refs[7]);
+#endif
     out[i] = nd;
 }
 
@@ -854,8 +910,14 @@ __global__ void k_single_leaf_root(const uint32_t *vals, const float4 *boxLo, co
     }
     nd.a = make_float4(lo[0], lo[1], lo[2], __uint_as_float(eb[0] | (eb[1] << 8) | (eb[2] << 16)));
     nd.refs = make_int4(~0, kEmptyRef, kEmptyRef, kEmptyRef);
+#if PT_WIDE8
+    nd.refsB = make_int4(kEmptyRef, kEmptyRef, kEmptyRef, kEmptyRef);
+    nd.qx = nd.qy = nd.qz = make_uint4(0xffffff00u, 0x000000ffu, 0xffffffffu, 0x00000000u);
+    nd.pad0 = nd.pad1 = make_uint4(0u, 0u, 0u, 0u);
+#else
     nd.q0 = make_uint4(0xffffff00u, 0x000000ffu, 0xffffff00u, 0x000000ffu);
     nd.q1 = make_uint4(0xffffff00u, 0x000000ffu, 0u, 0u);
+#endif
     nodes[0] = nd;
 }
 
@@ -871,7 +933,7 @@ __global__ void k_single_leaf_root(const uint32_t *vals, const float4 *boxLo, co
 #endif
 constexpr int kLdsStack = PT_LDS_STACK; // entries per lane kept in LDS (lane-interleaved: no bank conflicts)
 constexpr int kLdsStackMega = 64;       // the megakernel runs 2 blocks/CU anyway (195 VGPRs): deep LDS stack, no spill
-constexpr int kGlobalSpill = 80;        // overflow entries per persistent thread, in a global buffer (LDS 16 + 80 >= 3 x 32 levels)
+constexpr int kGlobalSpill = PT_WIDE8 ? 176 : 80;        // overflow entries per persistent thread, in a global buffer (LDS 16 + 80 >= 3 x 32 levels)
 constexpr uint32_t kMaxPersistentThreads = 2048u * 256u;
 constexpr uint32_t kMaxNodeVisits = 1u << 20;
 
@@ -985,6 +1047,64 @@ PT_DEV bool slab(float lx, float ly, float lz, float hx, float hy, float hz, f3 
 // box o + q * scale contains the child, leaf boxes are padded by 1e-5 relative, and the
 // interval test keeps the (1 + 2^-21) slack.  NaNs (0 * inf for axis-parallel rays) drop out
 // of fminf / fmaxf, which only makes the test more permissive.
+#if PT_WIDE8
+// The 8-wide variant of the same visit: two words per plane (children 0..3 and 4..7), a 19-comparator network.
+PT_DEV int visitNode(const BvhNode *__restrict__ np, f3 o, f3 id, float tmin, float lim, int (&r)[8])
+{
+    const float4 na = np->a;
+    const int4 refs = np->refs, refsB = np->refsB;
+    const uint4 qx = np->qx, qy = np->qy, qz = np->qz;
+    const uint32_t eb = __float_as_uint(na.w);
+    const float ax = __uint_as_float((eb & 0xffu) << 23) * id.x, ay = __uint_as_float(((eb >> 8) & 0xffu) << 23) * id.y,
+                az = __uint_as_float(((eb >> 16) & 0xffu) << 23) * id.z;
+    const float bx = (na.x - o.x) * id.x, by = (na.y - o.y) * id.y, bz = (na.z - o.z) * id.z;
+    const bool ngx = id.x < 0.0f, ngy = id.y < 0.0f, ngz = id.z < 0.0f;
+    const uint32_t nx = ngx ? qx.y : qx.x, fx = ngx ? qx.x : qx.y, nxB = ngx ? qx.w : qx.z, fxB = ngx ? qx.z : qx.w;
+    const uint32_t ny = ngy ? qy.y : qy.x, fy = ngy ? qy.x : qy.y, nyB = ngy ? qy.w : qy.z, fyB = ngy ? qy.z : qy.w;
+    const uint32_t nz = ngz ? qz.y : qz.x, fz = ngz ? qz.x : qz.y, nzB = ngz ? qz.w : qz.z, fzB = ngz ? qz.z : qz.w;
+    const float inf = __uint_as_float(0x7f800000u);
+    float key[8];
+    int hits = 0;
+#define PT_CHILD(k, NX, NY, NZ, FX, FY, FZ, j, REF)                                                                        \
+    {                                                                                                                      \
+        const float lo = fmaxf(fmaxf(__builtin_fmaf(PT_BYTE(NX, j), ax, bx), __builtin_fmaf(PT_BYTE(NY, j), ay, by)),      \
+                               fmaxf(__builtin_fmaf(PT_BYTE(NZ, j), az, bz), tmin));                                       \
+        const float hi = fminf(fminf(__builtin_fmaf(PT_BYTE(FX, j), ax, bx), __builtin_fmaf(PT_BYTE(FY, j), ay, by)),      \
+                               fminf(__builtin_fmaf(PT_BYTE(FZ, j), az, bz), lim));                                        \
+        const bool h = lo <= hi * 1.0000004f && (REF) != kEmptyRef;                                                        \
+        key[k] = h ? lo : inf;                                                                                             \
+        r[k] = (REF);                                                                                                      \
+        hits += (int)h;                                                                                                    \
+    }
+    PT_CHILD(0, nx, ny, nz, fx, fy, fz, 0, refs.x)
+    PT_CHILD(1, nx, ny, nz, fx, fy, fz, 1, refs.y)
+    PT_CHILD(2, nx, ny, nz, fx, fy, fz, 2, refs.z)
+    PT_CHILD(3, nx, ny, nz, fx, fy, fz, 3, refs.w)
+    PT_CHILD(4, nxB, nyB, nzB, fxB, fyB, fzB, 0, refsB.x)
+    PT_CHILD(5, nxB, nyB, nzB, fxB, fyB, fzB, 1, refsB.y)
+    PT_CHILD(6, nxB, nyB, nzB, fxB, fyB, fzB, 2, refsB.z)
+    PT_CHILD(7, nxB, nyB, nzB, fxB, fyB, fzB, 3, refsB.w)
+#undef PT_CHILD
+#define PT_CSWAP(i, j)                                                                                                     \
+    {                                                                                                                      \
+        const bool sw = key[j] < key[i];                                                                                   \
+        const float tk = sw ? key[j] : key[i];                                                                             \
+        key[j] = sw ? key[i] : key[j];                                                                                     \
+        key[i] = tk;                                                                                                       \
+        const int tr = sw ? r[j] : r[i];                                                                                   \
+        r[j] = sw ? r[i] : r[j];                                                                                           \
+        r[i] = tr;                                                                                                         \
+    }
+    PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(4, 5) PT_CSWAP(6, 7)
+    PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(4, 6) PT_CSWAP(5, 7)
+    PT_CSWAP(1, 2) PT_CSWAP(5, 6)
+    PT_CSWAP(0, 4) PT_CSWAP(1, 5) PT_CSWAP(2, 6) PT_CSWAP(3, 7)
+    PT_CSWAP(2, 4) PT_CSWAP(3, 5)
+    PT_CSWAP(1, 2) PT_CSWAP(3, 4) PT_CSWAP(5, 6)
+#undef PT_CSWAP
+    return hits;
+}
+#else
 PT_DEV int visitNode(const BvhNode *__restrict__ np, f3 o, f3 id, float tmin, float lim, int &r0, int &r1, int &r2, int &r3)
 {
     const float4 na = np->a;
@@ -1041,6 +1161,7 @@ PT_DEV int visitNode(const BvhNode *__restrict__ np, f3 o, f3 id, float tmin, fl
 #undef PT_CSWAP
     return (int)h0 + (int)h1 + (int)h2 + (int)h3;
 }
+#endif
 
 // Culling against the current best leaves room for the triangle test's own error in t (Moeller-Trumbore from a far
 // origin: ~1e-5 relative): two triangles in one plane can report the SAME t while the point o + t d lies a few 1e-5
@@ -1089,11 +1210,20 @@ PT_DEV bool traceRay(const TraceScene &sc, f3 o, f3 d, float tmin, float tmax, S
         {
             if (STATS)
                 (*nodeVisits)++;
+#if PT_WIDE8
+            int r[8];
+            const int h = visitNode(&sc.nodes[ref], o, id, tmin, ANY_HIT ? best.t : best.t * kCullSlack, r);
+#pragma unroll
+            for (int k = 7; k >= 1; k--)
+                if (h > k) st.push((uint32_t)r[k]);
+            const int r0 = r[0];
+#else
             int r0, r1, r2, r3;
             const int h = visitNode(&sc.nodes[ref], o, id, tmin, ANY_HIT ? best.t : best.t * kCullSlack, r0, r1, r2, r3);
             if (h > 3) st.push((uint32_t)r3);
             if (h > 2) st.push((uint32_t)r2);
             if (h > 1) st.push((uint32_t)r1);
+#endif
             if (h > 0)
                 ref = r0;
             else
@@ -1285,6 +1415,14 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
 #endif
             if (have && ref >= 0 && ref != kRefDone)
             {
+#if PT_WIDE8
+                int r[8];
+                const int h = visitNode(&sc.nodes[ref], o, id, PT_TMIN, ANY_HIT ? best.t : best.t * kCullSlack, r);
+#pragma unroll
+                for (int k = 7; k >= 1; k--)
+                    if (h > k) st.push((uint32_t)r[k]);
+                const int r0 = r[0];
+#else
                 int r0, r1, r2, r3;
 #if PT_UNIFORM_NODE
                 // Wave-uniform node fetch: when every lane that takes this step is at the SAME node (the 8x8-pixel wave of
@@ -1302,6 +1440,7 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
                 if (h > 3) st.push((uint32_t)r3);
                 if (h > 2) st.push((uint32_t)r2);
                 if (h > 1) st.push((uint32_t)r1);
+#endif
                 ref = h > 0 ? r0 : (st.sp ? (int)st.pop() : kRefDone);
 #ifdef PT_VISIT_STATS
                 visits++;

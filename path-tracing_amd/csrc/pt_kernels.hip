@@ -359,7 +359,10 @@ struct ClosestIO
 // The traversal kernels are latency-bound: throughput follows the number of resident waves.  The opaque variants fit
 // the 64-VGPR budget of 8 waves per SIMD without spilling when asked to (74 -> 63 registers: closest 6.2 -> 4.6 ms per
 // chess_like step); the ALPHA closest variant carries the sampler and the decal and stops at 6 waves.
-#define PT_FULL_OCCUPANCY __attribute__((amdgpu_waves_per_eu(8, 8)))
+#ifndef PT_TRACE_WAVES
+#define PT_TRACE_WAVES 8
+#endif
+#define PT_FULL_OCCUPANCY __attribute__((amdgpu_waves_per_eu(PT_TRACE_WAVES, PT_TRACE_WAVES)))
 // (round 2: forcing 7 / 8 waves on the ALPHA variants costs 18 / 31 spilled registers and scratch: atrium_like 460 -> 414 / 389 Msamples/s)
 #ifndef PT_ALPHA_CLOSEST_WAVES
 #define PT_ALPHA_CLOSEST_WAVES 7 // the decal lives in memory (ClosestIO::ignored): 78 -> 72 registers

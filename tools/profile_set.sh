@@ -26,4 +26,6 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INS
 python3 tools/pmc_sq.py gpurun_out/${TAG}_sq1 gpurun_out/${TAG}_sq2 > gpurun_out/${TAG}_sq.txt 2>&1
 cp "$(find gpurun_out/${TAG}_trace -name '*kernel_stats.csv' | head -1)" gpurun_out/${TAG}_kernel_stats.csv 2>/dev/null
 find gpurun_out/${TAG}_trace gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write gpurun_out/${TAG}_sq1 gpurun_out/${TAG}_sq2 -name "*.csv" -size +1M -delete
+# the un-profiled line quotes the traffic of THIS build: it looks for the newest profiles/r*_traffic.json
+cp gpurun_out/${TAG}_traffic.json profiles/${TAG}_traffic.json
 timeout 900 python3 bench.py $* > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; tail -c 2500 gpurun_out/${TAG}_bench.json
