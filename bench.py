@@ -23,7 +23,7 @@ all_gather of the tile shards per step.  The reported metric is the NAMED frame 
 is the same frame at 8 N spp, which is how BASELINE configs[3] and [4] are posed) is measured in the same run and
 printed in `weak`.
 
-Frames in flight (`--in-flight`, default 3 on one GPU, 12 per rank on several -- a tile shard is a small frame): consecutive steps run on renderers that take turns, each on its own stream
+Frames in flight (`--in-flight`, default 4 on one GPU, 12 per rank on several -- a tile shard is a small frame): consecutive steps run on renderers that take turns, each on its own stream
 with its own path state, as the reference keeps frames in flight (Renderer.cpp:1454-1460): ptx_render only enqueues a
 frame -- the bounce loop is driven from the device -- so the latency-bound end of one frame overlaps the head of the
 next.  Every step is still one complete frame: reset, 8 spp, gather, read-back.
@@ -47,6 +47,9 @@ import math
 import os
 import sys
 import time
+
+# before anything initialises HIP: one hardware queue per stream of the frames in flight (path-tracing_amd/__init__.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np
 
@@ -133,7 +136,7 @@ class Job:
         self.scene = pkg.Scene(scene_name, args.detail)
         self.lights = self.scene.lights
         backend = pkg.BACKEND_WAVEFRONT if args.backend == "wavefront" else pkg.BACKEND_MEGAKERNEL
-        self.F = args.in_flight if args.in_flight > 0 else (3 if self.shard_world_hint(shard, world) == 1 else 12)
+        self.F = args.in_flight if args.in_flight > 0 else (4 if self.shard_world_hint(shard, world) == 1 else 12)
         self.streams = [torch.cuda.Stream() for _ in range(self.F)]
         self.rs = [pkg.Renderer(device=local_rank, backend=backend, stream=s.cuda_stream) for s in self.streams]
         self.shard_rank, self.shard_world = shard if shard else (rank, world)
@@ -263,6 +266,21 @@ class Job:
                 break
         return float(np.median(regions)), regions, stats
 
+    def exclusive(self, job_spp, steps):
+        """The same frames ONE at a time (every step waits for its frame), outside the timed region: the kernels' durations
+        without other frames' kernels sharing the machine.  With frames in flight a launch's duration counts the time it
+        shares the CUs with the launches of the other frames, so the per-launch figure of the timed region falls as the
+        overlap (and the throughput) rises; this one is the kernel's own."""
+        self.finish()
+        c = {"trace_ms": 0.0, "shade_ms": 0.0, "shadow_ms": 0.0, "tail_ms": 0.0, "launches": 0, "rays": 0, "segments": 0, "shadow": 0}
+        self.collect = c
+        for _ in range(steps):
+            self.step(job_spp, readback=False)
+            self.rs[(self.k - 1) % self.F].synchronize()
+        self.finish()
+        self.collect = None
+        return c
+
     def close(self):
         for r in self.rs:
             r.close()
@@ -311,6 +329,7 @@ def scene_line(args, pkg, torch, dist, orc, name, rank, world, local_rank, steps
     spp = args.spp
     med, regions, stats = job.measure(spp, steps, warmup, args.repeats, min_seconds, readback=True)
     med_nr, regions_nr, _ = job.measure(spp, steps, 0, max(1, min(len(regions), 3)), 0.0, readback=False)
+    stats_x = job.exclusive(spp, 3) if world == 1 and args.backend == "wavefront" else None
     line = None
     if rank == 0:
         samples = W * H * spp * steps
@@ -332,6 +351,13 @@ def scene_line(args, pkg, torch, dist, orc, name, rank, world, local_rank, steps
         }
         if args.backend == "wavefront" and stats["trace_ms"] > 0:
             line["roofline"] = roofline(job, stats, digest)
+            if stats_x and stats_x["trace_ms"] > 0:
+                x = roofline(job, stats_x, digest)
+                line["roofline"]["frac_exclusive"] = x["frac"]
+                line["roofline"]["exclusive"] = {
+                    "what": "the same frames one at a time, after the timed region: launch durations without other frames' kernels on the machine",
+                    "avg_launch_ms": x["avg_launch_ms"], "launches": x["launches"], "achieved": x["achieved"], "frac": x["frac"],
+                    "achieved_counter": x["achieved_counter"], "frac_counter": x["frac_counter"], "grays_per_s": x["grays_per_s"]}
         if with_cpu:
             line["cpu_baseline"] = cpu_baseline(orc, job.scene, W, H, args.depth, args.cpu_seconds)
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
@@ -354,7 +380,7 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--tile", type=int, default=32)
     ap.add_argument("--in-flight", type=int, default=0,
-                    help="frames in flight: renderers (own stream, own path state) taking the steps in turn; 0 = 3 on one GPU, 12 per "
+                    help="frames in flight: renderers (own stream, own path state) taking the steps in turn; 0 = 4 on one GPU, 12 per "
                          "rank on several (a rank's share of the frame shrinks with the world size and its kernels with it: measured on "
                          "one GPU, a 1/8 tile shard takes 3.0 / 1.92 / 1.82 / 1.73 ms per step with 1 / 4 / 8 / 12 frames in flight)")
     ap.add_argument("--backend", default="wavefront", choices=["wavefront", "megakernel"])
@@ -424,10 +450,11 @@ def main():
         out["config"]["parallelism"] = "pixel-tile shard x1"
         if not args.no_extra_scenes and args.scene == "chess_like":
             # the same measurement on the other stand-ins; fewer steps per region: their steps are longer
+            # (not too few: a region starts and ends with an empty ring of frames in flight)
             out["configs"] = []
             for name in EXTRA_SCENES:
-                steps = max(3, args.steps // 4)
-                l = scene_line(args, pkg, torch, dist, orc, name, 0, 1, local_rank, steps, 1, min(args.min_seconds, 1.5),
+                steps = max(3, args.steps // 2)
+                l = scene_line(args, pkg, torch, dist, orc, name, 0, 1, local_rank, steps, 2, min(args.min_seconds, 1.5),
                                not args.no_cpu_baseline, digest)
                 out["configs"].append(l)
         print(json.dumps(out), flush=True)

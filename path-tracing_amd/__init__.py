@@ -26,6 +26,11 @@ import weakref
 
 import numpy as np
 
+# The runtime maps all HIP streams of the process onto GPU_MAX_HW_QUEUES hardware queues (default 4); frames in flight need
+# one per stream to overlap (csrc/pt_kernels.hip, defaultHardwareQueueCount).  It is read at the first HIP call, so it has
+# to be in the environment before torch initialises the device.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
 HIP_LIB = os.environ.get("PTX_HIP_LIB") or os.path.join(PKG_DIR, "libptx_hip.so")  # PTX_HIP_LIB: an experimental build of the same ABI

@@ -34,6 +34,23 @@ def test_headers_and_libraries_agree(pkg):
         assert hasattr(host, name), name
 
 
+def test_library_sets_the_hardware_queue_default(pkg):
+    """Loading the HIP library puts GPU_MAX_HW_QUEUES=16 into the environment (frames in flight need a hardware queue per
+    stream; the runtime reads the variable at its first call) and leaves a value the host has chosen alone."""
+    import subprocess
+    import sys
+
+    code = ("import ctypes, os, sys; ctypes.CDLL(sys.argv[1]); libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; "
+            "print(libc.getenv(b'GPU_MAX_HW_QUEUES').decode())")
+    for preset, expect in ((None, "16"), ("6", "6")):
+        env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+        if preset:
+            env["GPU_MAX_HW_QUEUES"] = preset
+        out = subprocess.run([sys.executable, "-c", code, pkg.HIP_LIB], env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        assert out.stdout.strip() == expect
+
+
 def test_no_cpu_fallback(pkg):
     """Without a GPU the product refuses to run instead of falling back to a CPU path."""
     hip = pkg.load_hip()

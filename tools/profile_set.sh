@@ -1,6 +1,7 @@
 #!/bin/bash
 # tools/profile_set.sh TAG [bench.py args ...] -- run ON THE GPU BOX (through gpurun): the profile set of one build.
 #   gpurun_out/TAG_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the default bench.py workload
+#   gpurun_out/TAG_kernel_stats_one_in_flight.csv   the same with --in-flight 1
 #   gpurun_out/TAG_traffic.json       per-kernel HBM bytes per launch from two PMC passes (FETCH_SIZE, WRITE_SIZE; separate
 #                                     passes, no trace domains beside --kernel-trace, as the guide prescribes)
 #   gpurun_out/TAG_sq.txt             SQ counter summary (wave cycles / waiting / issuing, instruction mix)
@@ -16,6 +17,12 @@ CMD="python3 bench.py --steps 5 --warmup 1 --repeats 1 --no-cpu-baseline --no-ex
 TRACE_CMD="python3 bench.py --repeats 1 --no-cpu-baseline --no-extra-scenes $*"
 for d in trace fetch write sq1 sq2; do rm -rf gpurun_out/${TAG}_$d; done
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace -o $TAG -- $TRACE_CMD > gpurun_out/${TAG}_trace.log 2>&1; echo "trace rc=$?"
+# the same workload with ONE frame in flight: what bench.py's roofline.exclusive measures live (launch durations without other
+# frames' kernels on the machine; tracing perturbs the overlap of the default command, not this)
+rm -rf gpurun_out/${TAG}_trace1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace1 -o $TAG -- $TRACE_CMD --in-flight 1 > gpurun_out/${TAG}_trace1.log 2>&1; echo "trace1 rc=$?"
+cp "$(find gpurun_out/${TAG}_trace1 -name '*kernel_stats.csv' | head -1)" gpurun_out/${TAG}_kernel_stats_one_in_flight.csv 2>/dev/null
+find gpurun_out/${TAG}_trace1 -name "*.csv" -size +1M -delete
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${TAG}_fetch -o $TAG -- $CMD > gpurun_out/${TAG}_fetch.log 2>&1; echo "fetch rc=$?"
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${TAG}_write -o $TAG -- $CMD > gpurun_out/${TAG}_write.log 2>&1; echo "write rc=$?"
 python3 tools/pmc_traffic.py gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write gpurun_out/${TAG}_traffic.json
