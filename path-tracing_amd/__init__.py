@@ -228,6 +228,14 @@ def load_hip() -> C.CDLL:
     one HIP runtime (the soname libamdhip64.so.7 is resolved to the copy already loaded)."""
     global _hip
     if _hip is None:
+        if "torch" not in sys.modules:
+            # torch brings its own libamdhip64; loaded after this library the process would hold two HIP runtimes, and the
+            # one this library is bound to then finds no device (seen as ptx_create -> PTX_ERROR_NO_DEVICE when
+            # __graft_entry__.build() and smoke() ran in one process)
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         if not os.path.exists(HIP_LIB):
             raise RuntimeError(f"{HIP_LIB} missing: the HIP extension is not built (run __graft_entry__.build())")
         lib = C.CDLL(HIP_LIB)
