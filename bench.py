@@ -354,6 +354,11 @@ def scene_line(args, pkg, torch, dist, orc, name, rank, world, local_rank, steps
             if stats_x and stats_x["trace_ms"] > 0:
                 x = roofline(job, stats_x, digest)
                 line["roofline"]["frac_exclusive"] = x["frac"]
+                line["roofline"]["note"] = (
+                    f"frac is taken over the timed region, where {job.F} frames are in flight and a launch's duration counts the time it shares "
+                    "the machine with the other frames' launches (it falls as overlap and throughput rise); frac_exclusive is the same launch "
+                    "alone on the machine -- the figure comparable with a one-frame-in-flight measurement and with "
+                    "profiles/*_kernel_stats_one_in_flight.csv")
                 line["roofline"]["exclusive"] = {
                     "what": "the same frames one at a time, after the timed region: launch durations without other frames' kernels on the machine",
                     "avg_launch_ms": x["avg_launch_ms"], "launches": x["launches"], "achieved": x["achieved"], "frac": x["frac"],
