@@ -359,7 +359,10 @@ typedef struct PtxStats {
 
 typedef struct PtxRenderer PtxRenderer;
 
-/* Renderer::Init / Renderer::Shutdown (Renderer.cpp:77-218) */
+/* Renderer::Init / Renderer::Shutdown (Renderer.cpp:77-218).  One handle = one frame in flight (the reference's per-frame
+ * rendering resources, Renderer.cpp:1454-1460): two HIP streams each.  The HIP runtime maps a process's streams onto
+ * GPU_MAX_HW_QUEUES hardware queues (4 by default, which serialises frames in flight); loading this library puts
+ * GPU_MAX_HW_QUEUES=16 into the environment unless the host has set it -- effective when HIP has not been used yet. */
 PTX_API int ptx_create(const PtxDeviceDesc *desc, PtxRenderer **out);
 PTX_API void ptx_destroy(PtxRenderer *r);
 PTX_API const char *ptx_last_error(const PtxRenderer *r);
