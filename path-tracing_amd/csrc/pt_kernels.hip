@@ -2969,7 +2969,10 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
     pl.sortShade = r->mixedMaterialTypes ? 1u : 0u;
     if (const char *e = getenv("PTX_SHADE_SORT"))
         pl.sortShade = atoi(e) ? 1u : 0u;
-    pl.tailBelow = 200000; // measured: full frame flat from 100 K to 400 K live paths, worse beyond; tile shards of 1/2 and 1/4 of the frame 4 % / 12 % faster at <= 200 K than at 300 K
+    // measured with 16 hardware queues (chess_like, ms per step at 25 / 50 / 75 / 100 / 200 / 400 K live paths): whole frame 8.04 / 7.82 /
+    // 7.85 / 7.80 / 8.14 / 8.13, a rank's tile shard of 8: 1.44 / 1.44 / 1.39 / 1.39 / 1.54 / 1.55, of 4: 2.29 / 2.24 / 2.24 / 2.33 / 2.34 /
+    // 2.77, of 2: 3.93 / 3.89 / 3.91 / 3.98 / 4.06 / 4.41; the other scenes are flat from 50 K to 200 K
+    pl.tailBelow = 75000;
     if (const char *e = getenv("PTX_TAIL_THRESHOLD"))
         pl.tailBelow = (uint32_t)strtoul(e, nullptr, 10);
     Wavefront &wf = pl.wf;
