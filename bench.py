@@ -387,8 +387,8 @@ def main():
     ap.add_argument("--in-flight", type=int, default=0,
                     help="frames in flight: renderers (own stream, own path state) taking the steps in turn; 0 = 4 on one GPU, 12 per "
                          "rank on several (a rank's share of the frame shrinks with the world size and its kernels with it: measured on "
-                         "one GPU with 16 hardware queues, a 1/8 tile shard takes 1.55 / 1.54 ms per step with 6 / 12 frames in flight, the whole frame "
-                         "8.40 / 7.93 / 7.88 / 7.94 with 2 / 3 / 4 / 6)")
+                         "one GPU with 16 hardware queues, a 1/8 tile shard takes 1.39 ms per step with 12 frames in flight (6 do as well), the whole "
+                         "frame 8.40 / 7.93 / 7.88 / 7.94 with 2 / 3 / 4 / 6 before the tail threshold moved to 75 K, 7.85 with 4 after)")
     ap.add_argument("--backend", default="wavefront", choices=["wavefront", "megakernel"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
