@@ -141,10 +141,11 @@ class Job:
         self.rs = [pkg.Renderer(device=local_rank, backend=backend, stream=s.cuda_stream) for s in self.streams]
         self.shard_rank, self.shard_world = shard if shard else (rank, world)
         t0 = time.time()
-        for r in self.rs:
-            r.upload(self.scene)
-            r.synchronize()
-        self.upload_build_s = (time.time() - t0) / self.F
+        self.rs[0].upload(self.scene)
+        self.rs[0].synchronize()
+        self.upload_build_s = time.time() - t0
+        for r in self.rs[1:]:  # the frames in flight share one scene and one tree, as the reference's per-frame resources do
+            r.share_scene(self.rs[0])
         for r in self.rs:
             r.resize(self.W, self.H)
             r.set_tile_shard(self.shard_rank, self.shard_world, args.tile)

@@ -373,6 +373,15 @@ PTX_API int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *scene);
 /* AccelerationStructure::Build (AccelerationStructure.cpp:26-46; BLAS :64-247, TLAS
  * :250-301), replaced by a software LBVH over the flattened world-space triangles. */
 PTX_API int ptx_build_accel(PtxRenderer *r);
+/* Frames in flight share ONE scene: the reference keeps GetInFlightCount() sets of per-frame rendering resources
+ * (Renderer.cpp:1454-1460) over one set of scene buffers and one acceleration structure (s_StaticSceneData / s_SceneData,
+ * Renderer.cpp:238-439).  `r` from now on renders the scene and the tree of `owner` (same device, uploaded and built)
+ * instead of holding copies; its own scene, if any, is released.  Lights, camera, image, path state stay per renderer.
+ * The borrowing ends with ptx_scene_upload on `r`, or when either renderer is destroyed (a borrower whose owner is gone
+ * reports PTX_ERROR_NOT_READY).  ptx_build_accel / ptx_update_animation are the owner's calls; they, and a new
+ * ptx_scene_upload on the owner, first wait for the borrowers' frames in flight.  Not thread-safe across the two
+ * renderers, like the rest of the interface (the reference's Renderer is driven from one thread). */
+PTX_API int ptx_share_scene(PtxRenderer *r, PtxRenderer *owner);
 
 /* Renderer::OnResize / CreateSceneRenderingResources: (re)allocate the RGBA32F
  * accumulation image (Renderer.cpp:1284-1287) and the wavefront path state. */

@@ -45,7 +45,7 @@ HOST_FLAGS = ["-std=c++20", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-fvi
 
 # every symbol include/ptx.h and include/ptx_host.h declare
 PTX_SYMBOLS = [
-    "ptx_create", "ptx_destroy", "ptx_last_error", "ptx_device_count", "ptx_scene_upload", "ptx_build_accel",
+    "ptx_create", "ptx_destroy", "ptx_last_error", "ptx_device_count", "ptx_scene_upload", "ptx_build_accel", "ptx_share_scene",
     "ptx_resize", "ptx_set_tile_shard", "ptx_set_backend", "ptx_reset_accumulation", "ptx_render",
     "ptx_render_frames", "ptx_synchronize", "ptx_readback", "ptx_readback_begin", "ptx_readback_end", "ptx_device_accum_ptr", "ptx_accum_bytes",
     "ptx_shard_bytes", "ptx_pack_shard", "ptx_unpack_shard", "ptx_get_stats", "ptx_bind_accumulation",
@@ -247,6 +247,7 @@ def load_hip() -> C.CDLL:
         lib.ptx_last_error.restype = C.c_char_p
         lib.ptx_scene_upload.argtypes = [P, C.POINTER(SceneDesc)]
         lib.ptx_build_accel.argtypes = [P]
+        lib.ptx_share_scene.argtypes = [P, P]
         lib.ptx_resize.argtypes = [P, C.c_uint32, C.c_uint32]
         lib.ptx_set_tile_shard.argtypes = [P, C.POINTER(TileShard)]
         lib.ptx_set_backend.argtypes = [P, C.c_uint32]
@@ -395,6 +396,10 @@ class Renderer:
         d = scene.desc if isinstance(scene, Scene) else scene
         self._check(self.lib.ptx_scene_upload(self.handle, C.byref(d)))
         self._check(self.lib.ptx_build_accel(self.handle))
+
+    def share_scene(self, owner: "Renderer"):
+        """Render `owner`'s scene and tree instead of holding copies (ptx_share_scene): frames in flight share one scene."""
+        self._check(self.lib.ptx_share_scene(self.handle, owner.handle))
 
     def resize(self, width: int, height: int):
         self._check(self.lib.ptx_resize(self.handle, width, height))

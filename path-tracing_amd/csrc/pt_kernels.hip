@@ -1648,6 +1648,10 @@ struct PtxRenderer
     uint32_t pairCount = 0, triCount = 0, dxNormalTextures = 0;
     uint32_t treeTris = 0; // triCount minus the zero-area triangles, which are not in the tree
     bool sceneReady = false, accelReady = false;
+    // ptx_share_scene: this renderer renders the scene and tree of `sceneOwner` instead of holding copies (frames in flight
+    // share one scene, as the reference's per-frame resources do); the owner knows who borrows from it
+    PtxRenderer *sceneOwner = nullptr;
+    std::vector<PtxRenderer *> sceneSharers;
 
     // accel
     DevBuf<BvhNode> nodes;
@@ -1724,6 +1728,39 @@ static int fail(PtxRenderer *r, int code, const char *fmt, ...)
             return fail(r, e_ == hipErrorOutOfMemory ? PTX_ERROR_OUT_OF_MEMORY : PTX_ERROR_DEVICE, "%s: %s", #expr,       \
                         hipGetErrorString(e_));                                                                            \
     } while (0)
+
+// the renderer whose scene buffers, tree and scene flags `r` renders with
+static const PtxRenderer *sceneOf(const PtxRenderer *r)
+{
+    return r->sceneOwner ? r->sceneOwner : r;
+}
+
+static void detachSharedScene(PtxRenderer *r)
+{
+    if (!r->sceneOwner)
+        return;
+    std::vector<PtxRenderer *> &v = r->sceneOwner->sceneSharers;
+    for (size_t i = 0; i < v.size(); i++)
+        if (v[i] == r)
+        {
+            v.erase(v.begin() + (long)i);
+            break;
+        }
+    r->sceneOwner = nullptr;
+    r->accelReady = false; // ptx_share_scene released the borrower's own scene: it needs ptx_scene_upload + ptx_build_accel again
+}
+
+// Before the owner of a shared scene changes it (upload, rebuild, animation step): the borrowers' frames in flight end.
+static void quiesceSharers(PtxRenderer *r)
+{
+    for (PtxRenderer *sh : r->sceneSharers)
+    {
+        if (sh->stream)
+            (void)hipStreamSynchronize(sh->stream);
+        if (sh->auxStream)
+            (void)hipStreamSynchronize(sh->auxStream);
+    }
+}
 
 static float4 *imagePtr(PtxRenderer *r)
 {
@@ -1880,6 +1917,17 @@ void ptx_destroy(PtxRenderer *r)
     (void)hipSetDevice(r->device);
     if (r->stream)
         (void)hipStreamSynchronize(r->stream);
+    detachSharedScene(r);
+    for (PtxRenderer *sh : r->sceneSharers) // borrowers of this scene: wait for their frames, then they have no scene
+    {
+        if (sh->stream)
+            (void)hipStreamSynchronize(sh->stream);
+        if (sh->auxStream)
+            (void)hipStreamSynchronize(sh->auxStream);
+        sh->sceneOwner = nullptr;
+        sh->accelReady = false;
+    }
+    r->sceneSharers.clear();
     // every DevBuf member (scene, tree, build state, wavefront state, animation, output stage) frees itself in `delete r`
     if (r->auxStream) { (void)hipStreamSynchronize(r->auxStream); (void)hipStreamDestroy(r->auxStream); }
     for (PtxRenderer::BounceEvents &e : r->bounceEvents)
@@ -1955,11 +2003,46 @@ template <typename T> static int upload(PtxRenderer *r, DevBuf<T> &buf, const T 
 
 extern "C" {
 
+int ptx_share_scene(PtxRenderer *r, PtxRenderer *owner)
+{
+    if (!r || !owner || r == owner)
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_share_scene: need two different renderers");
+    if (owner->sceneOwner || !r->sceneSharers.empty())
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_share_scene: the owner must hold its own scene, and a renderer others share from cannot borrow");
+    if (owner->device != r->device)
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_share_scene: renderers on different devices (%d, %d)", r->device, owner->device);
+    if (!owner->sceneReady || !owner->accelReady)
+        return fail(r, PTX_ERROR_NOT_READY, "ptx_share_scene: the owner needs ptx_scene_upload and ptx_build_accel first");
+    HIP_TRY(r, hipSetDevice(r->device));
+    // the owner's uploads and build are enqueued on ITS stream: finished before any stream of the borrower reads them;
+    // the borrower's own frames in flight end before its scene goes away
+    HIP_TRY(r, hipStreamSynchronize(owner->stream));
+    HIP_TRY(r, hipStreamSynchronize(r->stream));
+    if (r->auxStream)
+        HIP_TRY(r, hipStreamSynchronize(r->auxStream));
+    detachSharedScene(r);
+    // its own copies are not needed any more
+    r->vertices.release(); r->indices.release(); r->mr.release(); r->sg.release(); r->phong.release(); r->pairs.release();
+    r->pairFirst.release(); r->textures.release(); r->texels8.release(); r->texelsF.release(); r->srgbLut.release();
+    r->animatedVertices.release(); r->skinSource.release(); r->bones.release();
+    r->nodes.release(); r->tris.release(); r->shadeTris.release();
+    r->build.release();
+    r->sceneReady = false;
+    r->sceneOwner = owner;
+    owner->sceneSharers.push_back(r);
+    r->accelReady = true;
+    r->stats.triangles = owner->stats.triangles;
+    r->stats.bvhNodes = owner->stats.bvhNodes;
+    return PTX_OK;
+}
+
 int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *s)
 {
     if (!r || !s)
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_scene_upload: null argument");
     HIP_TRY(r, hipSetDevice(r->device));
+    detachSharedScene(r); // a renderer that was borrowing a scene gets its own again
+    quiesceSharers(r);
     r->sceneReady = r->accelReady = false;
 
     // validate indices the kernels will dereference (the reference trusts its importer)
@@ -2506,8 +2589,11 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
 
 int ptx_build_accel(PtxRenderer *r)
 {
+    if (r && r->sceneOwner)
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_build_accel: this renderer shares another renderer's scene (ptx_share_scene)");
     if (!r || !r->sceneReady)
         return fail(r, PTX_ERROR_NOT_READY, "ptx_build_accel: no scene uploaded");
+    quiesceSharers(r);
     return buildAccel(r, false, false);
 }
 
@@ -2517,8 +2603,11 @@ int ptx_update_animation(PtxRenderer *r, const PtxTransform *instanceTransforms,
 {
     if (!r || accelUpdate > PTX_ACCEL_REBUILD)
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_update_animation: bad argument");
+    if (r->sceneOwner)
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_update_animation: this renderer shares another renderer's scene (ptx_share_scene)");
     if (!r->sceneReady)
         return fail(r, PTX_ERROR_NOT_READY, "ptx_update_animation: no scene uploaded");
+    quiesceSharers(r);
     if (instanceTransforms && instanceCount != r->instanceCount)
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_update_animation: %u instance transforms for a scene of %u instances", instanceCount,
                     r->instanceCount);
@@ -2584,18 +2673,21 @@ int ptx_reset_accumulation(PtxRenderer *r)
 // differentials + software sampler, 2 = 1 + the any-hit stages (alpha test, decals).
 static int kernelMode(const PtxRenderer *r)
 {
-    return r->anyNonOpaque ? 2 : (r->samplerNeeded ? 1 : 0);
+    const PtxRenderer *s = sceneOf(r);
+    return s->anyNonOpaque ? 2 : (s->samplerNeeded ? 1 : 0);
 }
 
 static SceneView makeSceneView(const PtxRenderer *r)
 {
+    const PtxRenderer *s = sceneOf(r);
     SceneView sv;
-    sv.shadeTris = r->shadeTris.p;
-    sv.vertices = r->vertices.p; sv.indices = r->indices.p; sv.mr = r->mr.p; sv.sg = r->sg.p; sv.phong = r->phong.p;
-    sv.pairs = r->pairs.p; sv.lights = r->lights.p; sv.dxNormalTextures = r->dxNormalTextures;
-    sv.tex.textures = r->textures.p; sv.tex.textureCount = r->textureCount; sv.tex.texels8 = r->texels8.p; sv.tex.texelsF = r->texelsF.p;
-    sv.tex.srgbLut = r->srgbLut.p;
-    sv.skyKind = r->skyKind;
+    sv.shadeTris = s->shadeTris.p;
+    sv.vertices = s->vertices.p; sv.indices = s->indices.p; sv.mr = s->mr.p; sv.sg = s->sg.p; sv.phong = s->phong.p;
+    sv.pairs = s->pairs.p; sv.dxNormalTextures = s->dxNormalTextures;
+    sv.lights = r->lights.p; // the lights come with every launch: each frame in flight has its own
+    sv.tex.textures = s->textures.p; sv.tex.textureCount = s->textureCount; sv.tex.texels8 = s->texels8.p; sv.tex.texelsF = s->texelsF.p;
+    sv.tex.srgbLut = s->srgbLut.p;
+    sv.skyKind = s->skyKind;
     return sv;
 }
 
@@ -2866,8 +2958,8 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
 {
     if (!r || !uniform || !lights)
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_render: null argument");
-    if (!r->accelReady || !imagePtr(r))
-        return fail(r, PTX_ERROR_NOT_READY, "ptx_render: need ptx_scene_upload, ptx_build_accel and ptx_resize first");
+    if (!r->accelReady || !imagePtr(r) || (r->sceneOwner && !r->sceneOwner->accelReady))
+        return fail(r, PTX_ERROR_NOT_READY, "ptx_render: need ptx_scene_upload (or ptx_share_scene), ptx_build_accel and ptx_resize first");
     if (uniform->SampleCount == 0 || uniform->SampleCount > 0xffffu || uniform->BounceCount > 0xffffu || frames == 0)
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_render: SampleCount must be in [1, 65535], BounceCount <= 65535");
     if (lights->LightCount > PTX_MAX_LIGHT_COUNT)
@@ -2893,7 +2985,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
     pl.p = p;
     pl.sv = makeSceneView(r);
     pl.mode = kernelMode(r);
-    pl.sc.nodes = r->nodes.p; pl.sc.tris = r->tris.p; pl.sc.triCount = r->treeTris; pl.sc.sv = pl.sv;
+    pl.sc.nodes = sceneOf(r)->nodes.p; pl.sc.tris = sceneOf(r)->tris.p; pl.sc.triCount = sceneOf(r)->treeTris; pl.sc.sv = pl.sv;
     pl.bounces = uniform->BounceCount;
     const SceneView &sv = pl.sv;
     const TraceScene &sc = pl.sc;
@@ -2966,7 +3058,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
         if (rcr != PTX_OK)
             return rcr;
     }
-    pl.sortShade = r->mixedMaterialTypes ? 1u : 0u;
+    pl.sortShade = sceneOf(r)->mixedMaterialTypes ? 1u : 0u;
     if (const char *e = getenv("PTX_SHADE_SORT"))
         pl.sortShade = atoi(e) ? 1u : 0u;
     // measured with 16 hardware queues (chess_like, ms per step at 25 / 50 / 75 / 100 / 200 / 400 K live paths): whole frame 8.04 / 7.82 /
@@ -3329,13 +3421,13 @@ int ptx_trace_rays(PtxRenderer *r, const float *rays, uint32_t n, int anyHit, fl
     HIP_TRY(r, dHits.alloc(n));
     HIP_TRY(r, dIds.alloc(n));
     TraceScene sc;
-    sc.nodes = r->nodes.p; sc.tris = r->tris.p; sc.triCount = r->treeTris; sc.sv = makeSceneView(r);
+    sc.nodes = sceneOf(r)->nodes.p; sc.tris = sceneOf(r)->tris.p; sc.triCount = sceneOf(r)->treeTris; sc.sv = makeSceneView(r);
     hipError_t e = hipMemcpyAsync(dRays.p, rays, (size_t)n * 32, hipMemcpyHostToDevice, r->stream);
     if (e == hipSuccess)
     {
         (void)hipEventRecord(r->evT0, r->stream);
         (void)hipMemsetAsync(&r->counters.p[C_CHUNK], 0, sizeof(uint32_t), r->stream);
-        if (r->anyNonOpaque)
+        if (sceneOf(r)->anyNonOpaque)
             k_trace_rays<true><<<gridFor(n), kBlock, 0, r->stream>>>(sc, dRays.p, n, anyHit, dHits.p, dIds.p, &r->counters.p[C_CHUNK], r->spill.p);
         else
             k_trace_rays<false><<<gridFor(n), kBlock, 0, r->stream>>>(sc, dRays.p, n, anyHit, dHits.p, dIds.p, &r->counters.p[C_CHUNK], r->spill.p);
