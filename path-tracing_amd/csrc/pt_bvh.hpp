@@ -27,22 +27,6 @@
 namespace ptd
 {
 
-#ifndef PT_WIDE8
-#define PT_WIDE8 0 // experiment: 8 children per node (128-byte nodes); measured, DESIGN.md section 4
-#endif
-#if PT_WIDE8
-constexpr int kNodeWidth = 8;
-struct BvhNode
-{
-    float4 a;    // origin.xyz, w = bits: biased exponents ex | ey << 8 | ez << 16 (scale = 2^(e-127))
-    int4 refs;   // child refs 0..3
-    int4 refsB;  // child refs 4..7
-    uint4 qx;    // x = lo.x bytes of children 0..3, y = hi.x bytes 0..3, z = lo.x bytes 4..7, w = hi.x bytes 4..7
-    uint4 qy, qz;
-    uint4 pad0, pad1;
-};
-static_assert(sizeof(BvhNode) == 128, "BvhNode is 128 B");
-#else
 constexpr int kNodeWidth = 4;
 struct BvhNode
 {
@@ -52,16 +36,17 @@ struct BvhNode
     uint4 q1; // x = lo.z bytes, y = hi.z bytes, z, w unused
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode is 64 B");
-#endif
 constexpr int kEmptyRef = 0x7ffffffe;
 
 struct Tri
 {
     float4 a; // v0.xyz, e1.x
     float4 b; // e1.yz, e2.xy
-    float4 c; // e2.z, pair (bits), prim (bits), flags (bits): 1 = non-opaque geometry (any-hit stages run)
+    float4 c; // e2.z, pair (bits), prim (bits), w (bits): bit 31 = non-opaque geometry (any-hit stages run), bits 0..30 = the
+              // triangle's index in the flattened instance / mesh / primitive order -- the order of (pair, prim)
 };
 static_assert(sizeof(Tri) == 48, "Tri is 48 B");
+constexpr uint32_t kTriNonOpaque = 0x80000000u; // Tri::c.w
 
 struct Hit
 {
@@ -134,7 +119,7 @@ __global__ void k_tri_setup(uint32_t n, uint32_t pairCount, const uint32_t *__re
     Tri t;
     t.a = make_float4(w[0].x, w[0].y, w[0].z, e1.x);
     t.b = make_float4(e1.y, e1.z, e2.x, e2.y);
-    t.c = make_float4(e2.z, __uint_as_float(p), __uint_as_float(prim), __uint_as_float(pr->nonOpaque ? 1u : 0u));
+    t.c = make_float4(e2.z, __uint_as_float(p), __uint_as_float(prim), __uint_as_float((pr->nonOpaque ? kTriNonOpaque : 0u) | g));
     triTmp[g] = t;
 
     // bounds from the same p0, p0+e1, p0+e2 the intersection test sees, padded so the slab test does not reject a
@@ -751,9 +736,6 @@ __global__ void k_emit(int n, const uint32_t *__restrict__ vals, const float4 *_
     const float4 nl = nodeLo[i], nh = nodeHi[i];
     const float o[3] = { nl.x, nl.y, nl.z }, top[3] = { nh.x, nh.y, nh.z };
     uint32_t ebits[3], qlo[3] = { 0, 0, 0 }, qhi[3] = { 0, 0, 0 };
-#if PT_WIDE8
-    uint32_t qloB[3] = { 0, 0, 0 }, qhiB[3] = { 0, 0, 0 }; // children 4..7
-#endif
     for (int a = 0; a < 3; a++)
     {
         // smallest power of two with 255 * scale >= extent, then grow until every child box
@@ -772,9 +754,6 @@ __global__ void k_emit(int n, const uint32_t *__restrict__ vals, const float4 *_
             const float scale = __uint_as_float((uint32_t)e << 23);
             bool ok = true;
             uint32_t wl = 0, wh = 0;
-#if PT_WIDE8
-            uint32_t wlB = 0, whB = 0;
-#endif
             for (int k = 0; k < kNodeWidth; k++)
             {
                 uint32_t ql = 255, qh = 0; // empty slot: inverted box, never hit
@@ -793,14 +772,6 @@ __global__ void k_emit(int n, const uint32_t *__restrict__ vals, const float4 *_
                     if (decodeQ(o[a], qh, scale) < (double)c[k].hi[a])
                         ok = false;
                 }
-#if PT_WIDE8
-                if (k >= 4)
-                {
-                    wlB |= ql << (8 * (k - 4));
-                    whB |= qh << (8 * (k - 4));
-                }
-                else
-#endif
                 {
                     wl |= ql << (8 * k);
                     wh |= qh << (8 * k);
@@ -811,10 +782,6 @@ __global__ void k_emit(int n, const uint32_t *__restrict__ vals, const float4 *_
                 ebits[a] = (uint32_t)e;
                 qlo[a] = wl;
                 qhi[a] = wh;
-#if PT_WIDE8
-                qloB[a] = wlB;
-                qhiB[a] = whB;
-#endif
                 break;
             }
             e++;
@@ -823,16 +790,8 @@ __global__ void k_emit(int n, const uint32_t *__restrict__ vals, const float4 *_
     BvhNode nd;
     nd.a = make_float4(o[0], o[1], o[2], __uint_as_float(ebits[0] | (ebits[1] << 8) | (ebits[2] << 16)));
     nd.refs = make_int4(c[0].ref, c[1].ref, count > 2 ? c[2].ref : kEmptyRef, count > 3 ? c[3].ref : kEmptyRef);
-#if PT_WIDE8
-    nd.refsB = make_int4(count > 4 ? c[4].ref : kEmptyRef, count > 5 ? c[5].ref : kEmptyRef, count > 6 ? c[6].ref : kEmptyRef, count > 7 ? c[7].ref : kEmptyRef);
-    nd.qx = make_uint4(qlo[0], qhi[0], qloB[0], qhiB[0]);
-    nd.qy = make_uint4(qlo[1], qhi[1], qloB[1], qhiB[1]);
-    nd.qz = make_uint4(qlo[2], qhi[2], qloB[2], qhiB[2]);
-    nd.pad0 = nd.pad1 = make_uint4(0u, 0u, 0u, 0u);
-#else
     nd.q0 = make_uint4(qlo[0], qhi[0], qlo[1], qhi[1]);
     nd.q1 = make_uint4(qlo[2], qhi[2], 0u, 0u);
-#endif
     nodes[i] = nd;
 }
 
@@ -850,16 +809,9 @@ __global__ void __launch_bounds__(256) k_relayout_level(uint32_t lo, uint32_t hi
     const uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
     BvhNode nd;
     nd.refs = make_int4(kEmptyRef, kEmptyRef, kEmptyRef, kEmptyRef);
-#if PT_WIDE8
-    nd.refsB = nd.refs;
-#endif
     if (i < hi)
         nd = raw[oldOf[i]];
-#if PT_WIDE8
-    int refs[kNodeWidth] = { nd.refs.x, nd.refs.y, nd.refs.z, nd.refs.w, nd.refsB.x, nd.refsB.y, nd.refsB.z, nd.refsB.w };
-#else
     int refs[kNodeWidth] = { nd.refs.x, nd.refs.y, nd.refs.z, nd.refs.w };
-#endif
     uint32_t c = 0;
     for (int k = 0; k < kNodeWidth; k++)
         c += (refs[k] >= 0 && refs[k] != kEmptyRef) ? 1u : 0u;
@@ -884,9 +836,6 @@ __global__ void __launch_bounds__(256) k_relayout_level(uint32_t lo, uint32_t hi
             refs[k] = (int)base++;
         }
     nd.refs = make_int4(refs[0], refs[1], refs[2], refs[3]);
-#if PT_WIDE8
-    nd.refsB = make_int4(refs[4], refs[5], refs[6], refs[7]);
-#endif
     out[i] = nd;
 }
 
@@ -910,14 +859,8 @@ __global__ void k_single_leaf_root(const uint32_t *vals, const float4 *boxLo, co
     }
     nd.a = make_float4(lo[0], lo[1], lo[2], __uint_as_float(eb[0] | (eb[1] << 8) | (eb[2] << 16)));
     nd.refs = make_int4(~0, kEmptyRef, kEmptyRef, kEmptyRef);
-#if PT_WIDE8
-    nd.refsB = make_int4(kEmptyRef, kEmptyRef, kEmptyRef, kEmptyRef);
-    nd.qx = nd.qy = nd.qz = make_uint4(0xffffff00u, 0x000000ffu, 0xffffffffu, 0x00000000u);
-    nd.pad0 = nd.pad1 = make_uint4(0u, 0u, 0u, 0u);
-#else
     nd.q0 = make_uint4(0xffffff00u, 0x000000ffu, 0xffffff00u, 0x000000ffu);
     nd.q1 = make_uint4(0xffffff00u, 0x000000ffu, 0u, 0u);
-#endif
     nodes[0] = nd;
 }
 
@@ -925,25 +868,159 @@ __global__ void k_single_leaf_root(const uint32_t *vals, const float4 *boxLo, co
 // Traversal
 // ---------------------------------------------------------------------------------
 
-#ifndef PT_REFILL_MIN
-#define PT_REFILL_MIN 16 // idle lanes before the refill runs (while any lane has work); measured: 1 -> 1590, 8 -> 1619, 16 -> 1630, 24 -> 1632, 32 -> 1613, 48 -> 1575 Msamples/s (chess_like, one frame in flight)
-#endif
-#ifndef PT_LDS_STACK
-#define PT_LDS_STACK 16 // measured flat from 8 to 24 (889 +- 4 Msamples/s); 16 leaves LDS room
-#endif
-constexpr int kLdsStack = PT_LDS_STACK; // entries per lane kept in LDS (lane-interleaved: no bank conflicts)
+constexpr uint32_t kRefillMin = 16; // idle lanes before the refill runs (while any lane has work); measured: 1 -> 1590, 8 -> 1619, 16 -> 1630, 24 -> 1632, 32 -> 1613, 48 -> 1575 Msamples/s (chess_like, one frame in flight)
+constexpr int kLdsStack = 16;       // entries per lane kept in LDS (lane-interleaved: no bank conflicts); measured flat from 8 to 24
 constexpr int kLdsStackMega = 64;       // the megakernel runs 2 blocks/CU anyway (195 VGPRs): deep LDS stack, no spill
-constexpr int kGlobalSpill = PT_WIDE8 ? 176 : 80;        // overflow entries per persistent thread, in a global buffer (LDS 16 + 80 >= 3 x 32 levels)
+constexpr int kGlobalSpill = 80; // overflow entries per persistent thread, in a global buffer (LDS 16 + 80 >= 3 x 32 levels)
 constexpr uint32_t kMaxPersistentThreads = 2048u * 256u;
 constexpr uint32_t kMaxNodeVisits = 1u << 20;
+
+// What the any-hit stages read, laid out for them (the ALPHA kernel variants only).  anyhit.rahit:38-52 and
+// occlusionAnyhit.rahit:37-50 need ONE number per candidate, texture(textures[colorIdx], uv).a * colorFactor.a.  Through the
+// general path (hitBaseColor: pair -> material -> texture table -> four texels, uv from five float4 of the 272-byte shading
+// record) that was four dependent fetches and enough live state to cost the traversal kernels their eighth wave per SIMD.
+//   AlphaTri   32 B per triangle slot: the three texture coordinates, the alpha texture and the material's alpha factor
+//   AlphaTex   16 B per colour texture: base-level extent and where its quads start
+//   quads      per base-level texel (x, y) the alphas of the 2 x 2 bilinear footprint whose top-left texel it is --
+//              (x, y), (x+1, y), (x, y+1), (x+1, y+1) with repeat addressing -- so the footprint is ONE dwordx4 load
+struct AlphaTri
+{
+    float4 a; // u0, v0, u1, v1
+    float4 b; // u2, v2, alpha texture (bits; kNoAlphaTex: constant alpha), colour factor alpha (or the constant alpha itself)
+};
+struct AlphaTex
+{
+    uint32_t width, height, offset, pad;
+};
+constexpr uint32_t kNoAlphaTex = 0xffffffffu;
 
 struct TraceScene
 {
     const BvhNode *nodes;
     const Tri *tris;
     uint32_t triCount;
-    SceneView sv; // read by the ALPHA variants only (base colour of non-opaque candidates)
+    const AlphaTri *alphaTris; // ALPHA variants only
+    const AlphaTex *alphaTex;
+    const float4 *alphaQuads;
 };
+
+// An index the compiler cannot prove equal to the one it came from, available only once `after` has been computed: what is
+// loaded through it is loaded THEN, not kept in registers from an earlier load of the same address.
+PT_DEV uint32_t fetchAgainAfter(uint32_t index, float after)
+{
+    asm volatile("" : "+v"(index) : "v"(after));
+    return index;
+}
+
+// texture(textures[colorIdx], uv).a * colorFactor.a at a candidate hit: the .w of hitBaseColor(), bit for bit -- the same
+// interpolation of the texture coordinates, the same bilinear weights and operation order as sampleLevel / lerp4 on the
+// alpha channel alone.
+PT_DEV float hitAlpha(const TraceScene &sc, uint32_t slot, float u, float v)
+{
+    const float4 ta = sc.alphaTris[slot].a, tb = sc.alphaTris[slot].b;
+    const uint32_t tex = __float_as_uint(tb.z);
+    if (tex == kNoAlphaTex)
+        return tb.w;
+    const f3 bary = F3(1.0f - u - v, u, v);
+    float tu = (ta.x * bary.x + ta.z * bary.y) + tb.x * bary.z;
+    float tv = (ta.y * bary.x + ta.w * bary.y) + tb.y * bary.z;
+    const AlphaTex at = sc.alphaTex[tex];
+    const float4 *quads = sc.alphaQuads + at.offset;
+    const uint32_t w = at.width, h = at.height;
+    float alpha;
+    if (w == 1 && h == 1)
+        alpha = quads[0].x;
+    else
+    {
+        if (!(abs_(tu) < 1e9f)) tu = 0.0f;
+        if (!(abs_(tv) < 1e9f)) tv = 0.0f;
+        const float x = tu * (float)w - 0.5f, y = tv * (float)h - 0.5f;
+        const float x0 = __builtin_floorf(x), y0 = __builtin_floorf(y);
+        const float ax = x - x0, ay = y - y0;
+        const uint32_t ix0 = wrapRepeat(x0, w), ix1 = wrapRepeat(x0 + 1.0f, w), iy0 = wrapRepeat(y0, h), iy1 = wrapRepeat(y0 + 1.0f, h);
+        float a00, a10, a01, a11;
+        if (ix1 == (ix0 + 1 == w ? 0u : ix0 + 1) && iy1 == (iy0 + 1 == h ? 0u : iy0 + 1))
+        {
+            const float4 q = quads[(size_t)iy0 * w + ix0];
+            a00 = q.x; a10 = q.y; a01 = q.z; a11 = q.w;
+        }
+        else
+        {
+            // coordinates so large that x0 + 1 is not the next texel in float arithmetic: the four texels one by one (a quad's
+            // first entry is its own texel)
+            a00 = a10 = a01 = a11 = 0.0f;
+#pragma nounroll
+            for (int k = 0; k < 4; k++)
+            {
+                const float a = quads[(size_t)((k & 2) ? iy1 : iy0) * w + ((k & 1) ? ix1 : ix0)].x;
+                if (k == 0) a00 = a;
+                else if (k == 1) a10 = a;
+                else if (k == 2) a01 = a;
+                else a11 = a;
+            }
+        }
+        const float top = a00 * (1.0f - ax) + a10 * ax, bot = a01 * (1.0f - ax) + a11 * ax;
+        alpha = top * (1.0f - ay) + bot * ay;
+    }
+    return alpha * tb.w;
+}
+
+// One thread per triangle slot of the tree: the any-hit record of a triangle of a non-opaque geometry.  The texture
+// coordinates come from the shading record k_emit wrote (floats 3..4, 17..18, 31..32), the colour texture and factor by
+// the rules of material.glsl:25-54 (getColorTextureIdx / getColorFactor; an unknown material type: texture 0, factor 1).
+__global__ void k_alpha_tris(uint32_t n, const Tri *__restrict__ tris, const ShadeTri *__restrict__ shadeTris, SceneView sv,
+                             const uint32_t *__restrict__ alphaTexOf, AlphaTri *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    AlphaTri r;
+    r.a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    r.b = make_float4(0.0f, 0.0f, __uint_as_float(kNoAlphaTex), 1.0f);
+    const float4 tc = tris[i].c;
+    if (__float_as_uint(tc.w) & kTriNonOpaque)
+    {
+        const ShadeTri *st = &shadeTris[i];
+        const float4 q0 = st->v[0], q1 = st->v[1], q4 = st->v[4], q7 = st->v[7], q8 = st->v[8];
+        r.a = make_float4(q0.w, q1.x, q4.y, q4.z);
+        const DevPair *pr = &sv.pairs[__float_as_uint(tc.y)];
+        const uint32_t materialType = pr->materialId & 0xffu, materialIndex = pr->materialId >> 8;
+        uint32_t idx = 0;
+        float factor = 1.0f;
+        if (materialType == PTX_MATERIAL_TYPE_METALLIC_ROUGHNESS)
+        {
+            idx = sv.mr[materialIndex].ColorIdx;
+            factor = sv.mr[materialIndex].Color[3];
+        }
+        else if (materialType == PTX_MATERIAL_TYPE_SPECULAR_GLOSSINESS)
+        {
+            idx = sv.sg[materialIndex].ColorIdx;
+            factor = sv.sg[materialIndex].Color[3];
+        }
+        else if (materialType == PTX_MATERIAL_TYPE_PHONG)
+        {
+            idx = sv.phong[materialIndex].ColorIdx;
+            factor = sv.phong[materialIndex].Color[3];
+        }
+        uint32_t tex = kNoAlphaTex;
+        if (idx >= PTX_SCENE_TEXTURE_OFFSET && idx - PTX_SCENE_TEXTURE_OFFSET < sv.tex.textureCount)
+            tex = alphaTexOf[idx - PTX_SCENE_TEXTURE_OFFSET];
+        else
+            factor = sampleTexture(idx).w * factor; // a fixed 1x1 default (or the white placeholder past the table): constant alpha
+        r.b = make_float4(q7.w, q8.x, __uint_as_float(tex), factor);
+    }
+    out[i] = r;
+}
+
+// The quads of one colour texture from its decoded base level.
+__global__ void k_alpha_quads(uint32_t w, uint32_t h, const float4 *__restrict__ level0, float4 *__restrict__ quads)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= w * h)
+        return;
+    const uint32_t x = k % w, y = k / w, x1 = x + 1 == w ? 0u : x + 1, y1 = y + 1 == h ? 0u : y + 1;
+    quads[k] = make_float4(level0[(size_t)y * w + x].w, level0[(size_t)y * w + x1].w, level0[(size_t)y1 * w + x].w, level0[(size_t)y1 * w + x1].w);
+}
 
 // The any-hit stage for one candidate of a non-opaque geometry; true = the candidate stays.
 //   closest rays  anyhit.rahit:36-64: alpha < 0.5 -> remembered as the decal if it is the nearest so far, ignored
@@ -951,10 +1028,10 @@ struct TraceScene
 template <bool ANY_HIT>
 PT_DEV bool anyHitKeeps(const TraceScene &sc, uint32_t pair, uint32_t prim, uint32_t slot, float t, float u, float v, Decal &decal)
 {
-    const f4 color = hitBaseColor(sc.sv, pair, slot, u, v);
+    const float alpha = hitAlpha(sc, slot, u, v);
     if (ANY_HIT)
-        return !(color.w < 1.0f);
-    if (color.w < 0.5f)
+        return !(alpha < 1.0f);
+    if (alpha < 0.5f)
     {
         if (decal.dist == -1.0f || t < decal.dist || (t == decal.dist && (pair < decal.pair || (pair == decal.pair && prim < decal.prim))))
         {
@@ -1047,64 +1124,6 @@ PT_DEV bool slab(float lx, float ly, float lz, float hx, float hy, float hz, f3 
 // box o + q * scale contains the child, leaf boxes are padded by 1e-5 relative, and the
 // interval test keeps the (1 + 2^-21) slack.  NaNs (0 * inf for axis-parallel rays) drop out
 // of fminf / fmaxf, which only makes the test more permissive.
-#if PT_WIDE8
-// The 8-wide variant of the same visit: two words per plane (children 0..3 and 4..7), a 19-comparator network.
-PT_DEV int visitNode(const BvhNode *__restrict__ np, f3 o, f3 id, float tmin, float lim, int (&r)[8])
-{
-    const float4 na = np->a;
-    const int4 refs = np->refs, refsB = np->refsB;
-    const uint4 qx = np->qx, qy = np->qy, qz = np->qz;
-    const uint32_t eb = __float_as_uint(na.w);
-    const float ax = __uint_as_float((eb & 0xffu) << 23) * id.x, ay = __uint_as_float(((eb >> 8) & 0xffu) << 23) * id.y,
-                az = __uint_as_float(((eb >> 16) & 0xffu) << 23) * id.z;
-    const float bx = (na.x - o.x) * id.x, by = (na.y - o.y) * id.y, bz = (na.z - o.z) * id.z;
-    const bool ngx = id.x < 0.0f, ngy = id.y < 0.0f, ngz = id.z < 0.0f;
-    const uint32_t nx = ngx ? qx.y : qx.x, fx = ngx ? qx.x : qx.y, nxB = ngx ? qx.w : qx.z, fxB = ngx ? qx.z : qx.w;
-    const uint32_t ny = ngy ? qy.y : qy.x, fy = ngy ? qy.x : qy.y, nyB = ngy ? qy.w : qy.z, fyB = ngy ? qy.z : qy.w;
-    const uint32_t nz = ngz ? qz.y : qz.x, fz = ngz ? qz.x : qz.y, nzB = ngz ? qz.w : qz.z, fzB = ngz ? qz.z : qz.w;
-    const float inf = __uint_as_float(0x7f800000u);
-    float key[8];
-    int hits = 0;
-#define PT_CHILD(k, NX, NY, NZ, FX, FY, FZ, j, REF)                                                                        \
-    {                                                                                                                      \
-        const float lo = fmaxf(fmaxf(__builtin_fmaf(PT_BYTE(NX, j), ax, bx), __builtin_fmaf(PT_BYTE(NY, j), ay, by)),      \
-                               fmaxf(__builtin_fmaf(PT_BYTE(NZ, j), az, bz), tmin));                                       \
-        const float hi = fminf(fminf(__builtin_fmaf(PT_BYTE(FX, j), ax, bx), __builtin_fmaf(PT_BYTE(FY, j), ay, by)),      \
-                               fminf(__builtin_fmaf(PT_BYTE(FZ, j), az, bz), lim));                                        \
-        const bool h = lo <= hi * 1.0000004f && (REF) != kEmptyRef;                                                        \
-        key[k] = h ? lo : inf;                                                                                             \
-        r[k] = (REF);                                                                                                      \
-        hits += (int)h;                                                                                                    \
-    }
-    PT_CHILD(0, nx, ny, nz, fx, fy, fz, 0, refs.x)
-    PT_CHILD(1, nx, ny, nz, fx, fy, fz, 1, refs.y)
-    PT_CHILD(2, nx, ny, nz, fx, fy, fz, 2, refs.z)
-    PT_CHILD(3, nx, ny, nz, fx, fy, fz, 3, refs.w)
-    PT_CHILD(4, nxB, nyB, nzB, fxB, fyB, fzB, 0, refsB.x)
-    PT_CHILD(5, nxB, nyB, nzB, fxB, fyB, fzB, 1, refsB.y)
-    PT_CHILD(6, nxB, nyB, nzB, fxB, fyB, fzB, 2, refsB.z)
-    PT_CHILD(7, nxB, nyB, nzB, fxB, fyB, fzB, 3, refsB.w)
-#undef PT_CHILD
-#define PT_CSWAP(i, j)                                                                                                     \
-    {                                                                                                                      \
-        const bool sw = key[j] < key[i];                                                                                   \
-        const float tk = sw ? key[j] : key[i];                                                                             \
-        key[j] = sw ? key[i] : key[j];                                                                                     \
-        key[i] = tk;                                                                                                       \
-        const int tr = sw ? r[j] : r[i];                                                                                   \
-        r[j] = sw ? r[i] : r[j];                                                                                           \
-        r[i] = tr;                                                                                                         \
-    }
-    PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(4, 5) PT_CSWAP(6, 7)
-    PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(4, 6) PT_CSWAP(5, 7)
-    PT_CSWAP(1, 2) PT_CSWAP(5, 6)
-    PT_CSWAP(0, 4) PT_CSWAP(1, 5) PT_CSWAP(2, 6) PT_CSWAP(3, 7)
-    PT_CSWAP(2, 4) PT_CSWAP(3, 5)
-    PT_CSWAP(1, 2) PT_CSWAP(3, 4) PT_CSWAP(5, 6)
-#undef PT_CSWAP
-    return hits;
-}
-#else
 PT_DEV int visitNode(const BvhNode *__restrict__ np, f3 o, f3 id, float tmin, float lim, int &r0, int &r1, int &r2, int &r3)
 {
     const float4 na = np->a;
@@ -1161,7 +1180,6 @@ PT_DEV int visitNode(const BvhNode *__restrict__ np, f3 o, f3 id, float tmin, fl
 #undef PT_CSWAP
     return (int)h0 + (int)h1 + (int)h2 + (int)h3;
 }
-#endif
 
 // Culling against the current best leaves room for the triangle test's own error in t (Moeller-Trumbore from a far
 // origin: ~1e-5 relative): two triangles in one plane can report the SAME t while the point o + t d lies a few 1e-5
@@ -1210,20 +1228,11 @@ PT_DEV bool traceRay(const TraceScene &sc, f3 o, f3 d, float tmin, float tmax, S
         {
             if (STATS)
                 (*nodeVisits)++;
-#if PT_WIDE8
-            int r[8];
-            const int h = visitNode(&sc.nodes[ref], o, id, tmin, ANY_HIT ? best.t : best.t * kCullSlack, r);
-#pragma unroll
-            for (int k = 7; k >= 1; k--)
-                if (h > k) st.push((uint32_t)r[k]);
-            const int r0 = r[0];
-#else
             int r0, r1, r2, r3;
             const int h = visitNode(&sc.nodes[ref], o, id, tmin, ANY_HIT ? best.t : best.t * kCullSlack, r0, r1, r2, r3);
             if (h > 3) st.push((uint32_t)r3);
             if (h > 2) st.push((uint32_t)r2);
             if (h > 1) st.push((uint32_t)r1);
-#endif
             if (h > 0)
                 ref = r0;
             else
@@ -1242,7 +1251,7 @@ PT_DEV bool traceRay(const TraceScene &sc, f3 o, f3 d, float tmin, float tmax, S
             const float4 ta = tp->a, tb = tp->b, tc = tp->c;
             float t, u, v;
             if (intersectTri(F3(ta.x, ta.y, ta.z), F3(ta.w, tb.x, tb.y), F3(tb.z, tb.w, tc.x), o, d, tmin, tmax, t, u, v) &&
-                (!ALPHA || __float_as_uint(tc.w) == 0u ||
+                (!ALPHA || !(__float_as_uint(tc.w) & kTriNonOpaque) ||
                  anyHitKeeps<ANY_HIT>(sc, __float_as_uint(tc.y), __float_as_uint(tc.z), (uint32_t)~leafRef, t, u, v, decal)))
             {
                 const uint32_t pair = __float_as_uint(tc.y), prim = __float_as_uint(tc.z);
@@ -1284,29 +1293,18 @@ PT_DEV bool traceRay(const TraceScene &sc, f3 o, f3 d, float tmin, float tmax, S
 // visits per lane, then one leaf phase for every lane that reached a leaf, then the
 // refill -- so the triangle code is issued once per round, not once per node visit.
 //
-// IO supplies the queue: bool load(item, o, d, tmin, tmax) (false = nothing to trace,
-// e.g. a dead slot) and void store(item, hit, anyHit, decal).
-#ifndef PT_TRACE_CHUNK
-#define PT_TRACE_CHUNK 128
-#endif
-#ifndef PT_NODE_STEPS
-#define PT_NODE_STEPS 2 // measured: 1 -> 1040, 2 -> 1064, 3 -> 1055, 4 -> 1034, 6 -> 975, 10 -> 872 Msamples/s
-#endif
-#ifndef PT_UNIFORM_NODE
-#define PT_UNIFORM_NODE 0 // wave-uniform node fetch through the scalar path (see persistentTrace); measured, DESIGN.md section 4
-#endif
-constexpr uint32_t kTraceChunk = PT_TRACE_CHUNK;
-constexpr int kNodeStepsPerRound = PT_NODE_STEPS;
+// IO supplies the queue: bool load(item, o, d, tmin, tmax) (false = nothing to trace, e.g. a dead slot), for closest-hit
+// queries void improve(item, t, u, v, triSlot) (a nearer hit was found: the IO keeps where) and uint32_t bestSlot(item)
+// (its triangle), and void store(item, hit, hitAny, anyHitQuery) when the ray is done (hit.t and hit.pair; u, v, slot are the IO's).
+constexpr uint32_t kTraceChunk = 128;   // measured: 64 -> 1327, 128 -> 1347, 256 -> 1310 Msamples/s
+constexpr int kNodeStepsPerRound = 2;   // measured: 1 -> 1040, 2 -> 1064, 3 -> 1055, 4 -> 1034, 6 -> 975, 10 -> 872 Msamples/s
 constexpr int kRefDone = 0x7fffffff;
 
-#ifdef PT_VISIT_STATS
-__device__ uint32_t g_visitStats[2][68]; // [closest | shadow][max, sum lo, rays, -, histogram of visits / 16]
-// [closest | shadow][rounds, refill phases run, lanes refilled, node steps run, lanes in them, leaf phases run, lanes in them, waves]
-__device__ unsigned long long g_roundStats[2][8];
-#endif
 
 // IO::kFixedTmin >= 0: every ray of the queue has this tmin (the wavefront queues: 1e-5) -> a literal, not a register
+// IO::kFixedTmax likewise (closest-hit queues: 1e4)
 #define PT_TMIN (IO::kFixedTmin >= 0.0f ? IO::kFixedTmin : tmin)
+#define PT_TMAX (IO::kFixedTmax >= 0.0f ? IO::kFixedTmax : tmax)
 template <bool ANY_HIT, bool ALPHA, typename IO>
 PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32_t *__restrict__ chunkCounter, Stack &st)
 {
@@ -1320,11 +1318,7 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
     // queue is handed out through the atomic counter, which keeps the load balance of the dynamic scheme.
     const uint32_t waves = gridDim.x * (blockDim.x >> 6), waveId = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t totalChunks = (count + kTraceChunk - 1) / kTraceChunk;
-#ifndef PT_STATIC_SHARE_NUM
-#define PT_STATIC_SHARE_NUM 7
-#define PT_STATIC_SHARE_DEN 8
-#endif
-    const uint32_t staticRounds = (uint32_t)(((uint64_t)totalChunks * PT_STATIC_SHARE_NUM / PT_STATIC_SHARE_DEN) / waves);
+    const uint32_t staticRounds = (uint32_t)(((uint64_t)totalChunks * 7 / 8) / waves);
     uint32_t round = 0;
     bool have = false;
     uint32_t item = 0;
@@ -1335,25 +1329,14 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
     int ref = kRefDone;
     st.sp = 0;
     st.overflow = false;
-#ifdef PT_VISIT_STATS
-    uint32_t visits = 0;
-    uint32_t rs[7] = { 0, 0, 0, 0, 0, 0, 0 }; // wave-uniform
-#endif
 
     for (;;)
     {
         // ---- refill idle lanes from the wave's chunk
         uint64_t idleMask = __ballot(!have);
-#if PT_REFILL_MIN > 1
         // postponed while only a few lanes are idle and the others have work (wave-uniform decision)
-        if ((uint32_t)__popcll(idleMask) < (uint32_t)PT_REFILL_MIN && idleMask != ~0ull && !(cursor == end && exhausted))
+        if ((uint32_t)__popcll(idleMask) < kRefillMin && idleMask != ~0ull && !(cursor == end && exhausted))
             idleMask = 0ull;
-#endif
-#ifdef PT_VISIT_STATS
-        rs[0]++;
-        if (idleMask)
-            rs[1]++;
-#endif
         if (idleMask)
         {
             if (cursor == end && !exhausted)
@@ -1387,17 +1370,13 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
                     {
                         have = true;
                         id = fastInverse(d);
-                        best.t = tmax;
-                        best.u = best.v = 0.0f;
+                        best.t = PT_TMAX; // an any-hit query ends at its first hit: its limit stays tmax and best.t is not kept
                         best.pair = 0xffffffffu;
                         st.sp = 0;
-                        ref = (sc.triCount && rayIsTraceable(o, d, PT_TMIN, tmax)) ? 0 : kRefDone;
+                        ref = (sc.triCount && rayIsTraceable(o, d, PT_TMIN, PT_TMAX)) ? 0 : kRefDone;
                     }
                 }
                 cursor += take;
-#ifdef PT_VISIT_STATS
-                rs[2] += take;
-#endif
             }
             else if (exhausted && __ballot(have) == 0)
                 break;
@@ -1406,56 +1385,18 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
         // ---- node phase: a few visits per lane; lanes at a leaf (ref < 0) wait for the leaf phase
         for (int step = 0; step < kNodeStepsPerRound; step++)
         {
-#ifdef PT_VISIT_STATS
-            {
-                const uint32_t nl = (uint32_t)__popcll(__ballot(have && ref >= 0 && ref != kRefDone));
-                rs[3] += nl ? 1u : 0u;
-                rs[4] += nl;
-            }
-#endif
             if (have && ref >= 0 && ref != kRefDone)
             {
-#if PT_WIDE8
-                int r[8];
-                const int h = visitNode(&sc.nodes[ref], o, id, PT_TMIN, ANY_HIT ? best.t : best.t * kCullSlack, r);
-#pragma unroll
-                for (int k = 7; k >= 1; k--)
-                    if (h > k) st.push((uint32_t)r[k]);
-                const int r0 = r[0];
-#else
                 int r0, r1, r2, r3;
-#if PT_UNIFORM_NODE
-                // Wave-uniform node fetch: when every lane that takes this step is at the SAME node (the 8x8-pixel wave of
-                // primary rays in the upper levels of the tree) the 64 bytes come once through the scalar path
-                // (s_load_dwordx16 into SGPRs) instead of as 64 x 4 dwordx4 through the vector memory pipeline.
-                const int uref = __builtin_amdgcn_readfirstlane(ref);
-                int h;
-                if (__ballot(ref != uref) == 0ull)
-                    h = visitNode(&sc.nodes[uref], o, id, PT_TMIN, ANY_HIT ? best.t : best.t * kCullSlack, r0, r1, r2, r3);
-                else
-                    h = visitNode(&sc.nodes[ref], o, id, PT_TMIN, ANY_HIT ? best.t : best.t * kCullSlack, r0, r1, r2, r3);
-#else
-                const int h = visitNode(&sc.nodes[ref], o, id, PT_TMIN, ANY_HIT ? best.t : best.t * kCullSlack, r0, r1, r2, r3);
-#endif
+                const int h = visitNode(&sc.nodes[ref], o, id, PT_TMIN, ANY_HIT ? PT_TMAX : best.t * kCullSlack, r0, r1, r2, r3);
                 if (h > 3) st.push((uint32_t)r3);
                 if (h > 2) st.push((uint32_t)r2);
                 if (h > 1) st.push((uint32_t)r1);
-#endif
                 ref = h > 0 ? r0 : (st.sp ? (int)st.pop() : kRefDone);
-#ifdef PT_VISIT_STATS
-                visits++;
-#endif
             }
         }
 
         // ---- leaf phase (single-triangle leaves: ref = ~slot)
-#ifdef PT_VISIT_STATS
-        {
-            const uint32_t ll = (uint32_t)__popcll(__ballot(have && ref < 0));
-            rs[5] += ll ? 1u : 0u;
-            rs[6] += ll;
-        }
-#endif
         if (have && ref < 0)
         {
             const int leafRef = ref;
@@ -1463,35 +1404,42 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
             const float4 ta = tp->a, tb = tp->b, tc = tp->c;
             float t, u, v;
             ref = st.sp ? (int)st.pop() : kRefDone;
-            bool candidate = intersectTri(F3(ta.x, ta.y, ta.z), F3(ta.w, tb.x, tb.y), F3(tb.z, tb.w, tc.x), o, d, PT_TMIN, tmax, t, u, v);
-            if (ALPHA && candidate && __float_as_uint(tc.w) != 0u)
+            bool candidate = intersectTri(F3(ta.x, ta.y, ta.z), F3(ta.w, tb.x, tb.y), F3(tb.z, tb.w, tc.x), o, d, PT_TMIN, PT_TMAX, t, u, v);
+            uint32_t pair = __float_as_uint(tc.y), prim = __float_as_uint(tc.z);
+            if (ALPHA && candidate && (__float_as_uint(tc.w) & kTriNonOpaque))
             {
-                // the any-hit stage; the nearest ignored candidate of a closest ray (the decal) is kept by the IO in the slot's
-                // record in memory -- a read-modify-write per ignored candidate, which is rare -- not in six registers of
-                // every lane: 78 -> 72 VGPRs = 7 instead of 6 waves per SIMD.  One behind the hit found so far cannot matter.
-                const float alpha = hitBaseColor(sc.sv, __float_as_uint(tc.y), (uint32_t)~leafRef, u, v).w;
+                // the any-hit stage; the nearest ignored candidate of a closest ray (the decal) is the IO's business: it keeps
+                // (distance, triangle) in the slot's record in memory, not in registers of every lane.  One behind the hit
+                // found so far cannot matter.
+                const float alpha = hitAlpha(sc, (uint32_t)~leafRef, u, v);
                 candidate = ANY_HIT ? !(alpha < 1.0f) : !(alpha < 0.5f);
                 if (!ANY_HIT && !candidate && t <= best.t)
-                    io.ignored(t, u, v, __float_as_uint(tc.y), __float_as_uint(tc.z), (uint32_t)~leafRef, sc);
+                    io.ignored(t, u, v, (uint32_t)~leafRef, sc);
+                if (candidate && (!ANY_HIT || IO::kNeedsPrim))
+                {
+                    // the ids are read again behind the alpha fetch instead of being held in registers across it
+                    const float4 again = sc.tris[fetchAgainAfter((uint32_t)~leafRef, alpha)].c;
+                    pair = __float_as_uint(again.y);
+                    prim = __float_as_uint(again.z);
+                }
             }
             if (candidate)
             {
-                const uint32_t pair = __float_as_uint(tc.y), prim = __float_as_uint(tc.z);
                 // the prim id of the best hit is not carried in a register: an exact tie inside one (instance, mesh) pair
                 // is rare enough to re-read it from the triangle record
                 if (ANY_HIT)
                 {
-                    best.pair = pair;
+                    best.pair = IO::kNeedsPrim ? pair : 0u; // a shadow query only asks whether
                     best.slot = (uint32_t)~leafRef;
                     ref = kRefDone;
                 }
-                else if (t < best.t || (t == best.t && (pair < best.pair || (pair == best.pair && prim < __float_as_uint(sc.tris[best.slot].c.z)))))
+                else if (t < best.t || (t == best.t && (pair < best.pair || (pair == best.pair && prim < __float_as_uint(sc.tris[io.bestSlot(item)].c.z)))))
                 {
+                    // where the best hit lies on its triangle goes to the IO's record at once (write-through: a ray improves
+                    // its hit two or three times): three registers less in every lane for the length of the walk
                     best.t = t;
-                    best.u = u;
-                    best.v = v;
                     best.pair = pair;
-                    best.slot = (uint32_t)~leafRef;
+                    io.improve(item, t, u, v, (uint32_t)~leafRef);
                 }
             }
         }
@@ -1500,28 +1448,14 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
         if (have && ref == kRefDone)
         {
             if (IO::kNeedsPrim)
-                best.prim = best.pair != 0xffffffffu ? __float_as_uint(sc.tris[best.slot].c.z) : 0xffffffffu;
-            io.store(item, best, best.pair != 0xffffffffu);
+                best.prim = best.pair != 0xffffffffu ? __float_as_uint(sc.tris[ANY_HIT ? best.slot : io.bestSlot(item)].c.z) : 0xffffffffu;
+            io.store(item, best, best.pair != 0xffffffffu, ANY_HIT);
             have = false;
-#ifdef PT_VISIT_STATS
-            atomicMax(&g_visitStats[ANY_HIT][0], visits);
-            atomicAdd(&g_visitStats[ANY_HIT][1], visits);
-            atomicAdd(&g_visitStats[ANY_HIT][2], 1u);
-            atomicAdd(&g_visitStats[ANY_HIT][4 + (visits / 16 < 63 ? visits / 16 : 63)], 1u);
-            visits = 0;
-#endif
         }
     }
-#ifdef PT_VISIT_STATS
-    if (lane == 0)
-    {
-        for (int k = 0; k < 7; k++)
-            atomicAdd(&g_roundStats[ANY_HIT][k], (unsigned long long)rs[k]);
-        atomicAdd(&g_roundStats[ANY_HIT][7], 1ull);
-    }
-#endif
 }
 
 #undef PT_TMIN
+#undef PT_TMAX
 
 } // namespace ptd

@@ -845,11 +845,11 @@ struct DevTexture
 
 struct TextureView
 {
-    const DevTexture *textures;
+    const DevTexture *textures; // render time: levelOffset indexes the decoded pool; upload time (k_blit_level): the pool of the format
     uint32_t textureCount;
-    const uint32_t *texels8; // RGBA8 pool
-    const float4 *texelsF;   // RGBA32F pool
-    const float *srgbLut;    // 256 entries, sRGB byte -> linear
+    const uint32_t *texels8; // upload time only: RGBA8 pool
+    const float4 *texelsF;   // render time: the decoded pool of every texture; upload time: the RGBA32F pool
+    const float *srgbLut;    // upload time only: 256 entries, sRGB byte -> linear
 };
 
 PT_DEV uint32_t levelDim(uint32_t d, uint32_t level) { const uint32_t v = d >> level; return v ? v : 1u; }
@@ -865,7 +865,9 @@ PT_DEV uint32_t quantize8(float x)
     return (uint32_t)__builtin_floorf(x * 255.0f + 0.5f);
 }
 
-PT_DEV f4 fetchTexel(const TextureView &tv, const DevTexture &t, uint32_t level, uint32_t x, uint32_t y)
+// Upload-time form of a texel (k_blit_level builds mip chains in the image's own format, Image.cpp:264-300): decode from
+// the pool of the texture's format.
+PT_DEV f4 fetchTexelEncoded(const TextureView &tv, const DevTexture &t, uint32_t level, uint32_t x, uint32_t y)
 {
     const size_t idx = (size_t)t.levelOffset[level] + (size_t)y * levelDim(t.width, level) + x;
     f4 r;
@@ -885,6 +887,19 @@ PT_DEV f4 fetchTexel(const TextureView &tv, const DevTexture &t, uint32_t level,
         r.x = (float)(p & 255u) / 255.0f; r.y = (float)((p >> 8) & 255u) / 255.0f; r.z = (float)((p >> 16) & 255u) / 255.0f;
     }
     r.w = (float)(p >> 24) / 255.0f;
+    return r;
+}
+
+// Render-time form: every level of every texture sits DECODED (four floats per texel, the values fetchTexelEncoded returns)
+// in one pool, written once at upload by k_decode_texels -- a texel is ONE dwordx4 load.  In the 8-bit pools a texel cost
+// a load, three dependent loads from the sRGB table (or three IEEE divisions by 255) and one more division for alpha, per
+// texel of every bilinear footprint of every anisotropic tap; 288 GB of HBM hold the 4x larger pool of any scene the
+// reference's 1 GiB texture budget (Config.h:63-64) admits.  The values are the same bits, so nothing downstream changes.
+PT_DEV f4 fetchTexel(const TextureView &tv, const DevTexture &t, uint32_t level, uint32_t x, uint32_t y)
+{
+    const float4 v = tv.texelsF[(size_t)t.levelOffset[level] + (size_t)y * levelDim(t.width, level) + x];
+    f4 r;
+    r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
     return r;
 }
 
@@ -1329,38 +1344,63 @@ PT_DEV MaterialSample unknownMaterial()
 template <bool TEX>
 PT_DEV MaterialSample sampleMaterial(const SceneView &sv, uint32_t materialId, f2 texCoords, f4 derivatives, bool isHitFromInside) // :144-171
 {
-#define sampleTexture(idx) sampleTexture<TEX>(sv.tex, (idx), texCoords, derivatives)
     const uint32_t materialType = materialId & 0xffu;
     const uint32_t materialIndex = materialId >> 8;
     MaterialSample ret;
-    MaterialTexels t;
-    if (materialType == PTX_MATERIAL_TYPE_METALLIC_ROUGHNESS) // :62-84
-    {
-        const PtxMetallicRoughnessMaterial *m = &sv.mr[materialIndex];
-        t.emissive = sampleTexture(m->EmissiveIdx); t.color = sampleTexture(m->ColorIdx); t.normal = sampleTexture(m->NormalIdx);
-        t.a = sampleTexture(m->RoughnessIdx); t.b = sampleTexture(m->MetallicIdx);
-        ret = sampleMaterial(m, t, isHitFromInside);
-    }
-    else if (materialType == PTX_MATERIAL_TYPE_SPECULAR_GLOSSINESS) // :86-113
-    {
-        const PtxSpecularGlossinessMaterial *m = &sv.sg[materialIndex];
-        t.emissive = sampleTexture(m->EmissiveIdx); t.color = sampleTexture(m->ColorIdx); t.normal = sampleTexture(m->NormalIdx);
-        t.a = sampleTexture(m->SpecularIdx); t.b = sampleTexture(m->GlossinessIdx);
-        ret = sampleMaterial(m, t, isHitFromInside);
-    }
-    else if (materialType == PTX_MATERIAL_TYPE_PHONG) // :115-142
-    {
-        const PtxPhongMaterial *m = &sv.phong[materialIndex];
-        t.emissive = sampleTexture(m->EmissiveIdx); t.color = sampleTexture(m->ColorIdx); t.normal = sampleTexture(m->NormalIdx);
-        t.a = sampleTexture(m->SpecularIdx); t.b = sampleTexture(m->ShininessIdx);
-        ret = sampleMaterial(m, t, isHitFromInside);
-    }
-    else // :163-166
+    if (materialType > PTX_MATERIAL_TYPE_PHONG) // :163-166
         ret = unknownMaterial();
+    else
+    {
+        // the five texture slots of the three material structs sit at the same offsets, in the order of MaterialTexels
+        const PtxMetallicRoughnessMaterial *mr = &sv.mr[materialIndex];
+        const PtxSpecularGlossinessMaterial *sg = &sv.sg[materialIndex];
+        const PtxPhongMaterial *ph = &sv.phong[materialIndex];
+        uint32_t i0, i1, i2, i3, i4;
+        if (materialType == PTX_MATERIAL_TYPE_METALLIC_ROUGHNESS) // :62-84
+        {
+            i0 = mr->EmissiveIdx; i1 = mr->ColorIdx; i2 = mr->NormalIdx; i3 = mr->RoughnessIdx; i4 = mr->MetallicIdx;
+        }
+        else if (materialType == PTX_MATERIAL_TYPE_SPECULAR_GLOSSINESS) // :86-113
+        {
+            i0 = sg->EmissiveIdx; i1 = sg->ColorIdx; i2 = sg->NormalIdx; i3 = sg->SpecularIdx; i4 = sg->GlossinessIdx;
+        }
+        else // :115-142
+        {
+            i0 = ph->EmissiveIdx; i1 = ph->ColorIdx; i2 = ph->NormalIdx; i3 = ph->SpecularIdx; i4 = ph->ShininessIdx;
+        }
+        MaterialTexels t;
+        if (TEX)
+        {
+            // ONE copy of the sampler in the kernel, run five times, instead of five (fifteen over the three branches) inlined
+            // copies: the textured shade kernel was 270 KB of code, several times the instruction cache, and its register
+            // peak was the sampler's live state times the calls the scheduler overlapped.  The fetches have no side
+            // effects, so running them before the branch's arithmetic changes nothing.
+#pragma nounroll
+            for (int k = 0; k < 5; k++)
+            {
+                const uint32_t idx = k == 0 ? i0 : k == 1 ? i1 : k == 2 ? i2 : k == 3 ? i3 : i4;
+                const f4 c = sampleTexture<true>(sv.tex, idx, texCoords, derivatives);
+                if (k == 0) t.emissive = c;
+                else if (k == 1) t.color = c;
+                else if (k == 2) t.normal = c;
+                else if (k == 3) t.a = c;
+                else t.b = c;
+            }
+        }
+        else
+        {
+            t.emissive = sampleTexture(i0); t.color = sampleTexture(i1); t.normal = sampleTexture(i2); t.a = sampleTexture(i3); t.b = sampleTexture(i4);
+        }
+        if (materialType == PTX_MATERIAL_TYPE_METALLIC_ROUGHNESS)
+            ret = sampleMaterial(mr, t, isHitFromInside);
+        else if (materialType == PTX_MATERIAL_TYPE_SPECULAR_GLOSSINESS)
+            ret = sampleMaterial(sg, t, isHitFromInside);
+        else
+            ret = sampleMaterial(ph, t, isHitFromInside);
+    }
     if (sv.dxNormalTextures)
         ret.Normal.y *= -1;
     return ret;
-#undef sampleTexture
 }
 
 // ---- closestHit.rchit ---------------------------------------------------------------------------

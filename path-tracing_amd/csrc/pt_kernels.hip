@@ -309,6 +309,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(LaunchParams p, Wavefront w
 struct ClosestIO
 {
     static constexpr float kFixedTmin = 0.00001f; // ray.glsl:79
+    static constexpr float kFixedTmax = 10000.0f; // ray.glsl:80
     static constexpr bool kNeedsPrim = false;    // the hit record carries (t, u, v, slot) and the pair
     const Wavefront &wf;
     const uint32_t *queue;
@@ -331,27 +332,29 @@ struct ClosestIO
             wf.decalT[slot] = -1.0f; // anyhit.rahit state of a fresh ray: nothing ignored yet
         return true;
     }
-    PT_DEV void store(uint32_t, const Hit &h, bool)
+    PT_DEV void improve(uint32_t, float t, float u, float v, uint32_t triSlot)
     {
-        wf.hit[slot] = make_float4(h.t, h.u, h.v, __uint_as_float(h.slot)); // w = triangle slot in leaf order
-        wf.hitPair[slot] = h.pair;
+        wf.hit[slot] = make_float4(t, u, v, __uint_as_float(triSlot)); // w = triangle slot in leaf order
     }
+    PT_DEV uint32_t bestSlot(uint32_t) const { return __float_as_uint(wf.hit[slot].w); }
+    PT_DEV void store(uint32_t, const Hit &h, bool, bool) { wf.hitPair[slot] = h.pair; }
     // anyhit.rahit:54-61: the nearest ignored candidate (ties: smaller (pair, prim)) is the decal.  It lives in the slot's
     // record -- (triangle slot, u, v, pair) + its distance -- and k_shade fetches its colour if the hit lies behind it.
-    PT_DEV void ignored(float t, float u, float v, uint32_t pair, uint32_t prim, uint32_t triSlot, const TraceScene &sc)
+    // The ids come from the triangle record when they are needed (the tie, the store), not as arguments held in registers.
+    PT_DEV void ignored(float t, float u, float v, uint32_t triSlot, const TraceScene &sc)
     {
         const float cur = wf.decalT[slot];
         bool nearer = cur == -1.0f || t < cur;
         if (!nearer && t == cur)
         {
-            const float4 dq = wf.decal[slot];
-            const uint32_t curPair = __float_as_uint(dq.w), curPrim = __float_as_uint(sc.tris[__float_as_uint(dq.x)].c.z);
-            nearer = pair < curPair || (pair == curPair && prim < curPrim);
+            const float4 mine = sc.tris[triSlot].c, other = sc.tris[__float_as_uint(wf.decal[slot].x)].c;
+            const uint32_t pair = __float_as_uint(mine.y), curPair = __float_as_uint(other.y);
+            nearer = pair < curPair || (pair == curPair && __float_as_uint(mine.z) < __float_as_uint(other.z));
         }
         if (nearer)
         {
             wf.decalT[slot] = t;
-            wf.decal[slot] = make_float4(__uint_as_float(triSlot), u, v, __uint_as_float(pair));
+            wf.decal[slot] = make_float4(__uint_as_float(triSlot), u, v, sc.tris[triSlot].c.y);
         }
     }
 };
@@ -368,7 +371,10 @@ struct ClosestIO
 #define PT_ALPHA_CLOSEST_WAVES 7 // the decal lives in memory (ClosestIO::ignored): 78 -> 72 registers
 #endif
 #define PT_ALPHA_CLOSEST_ATTR __attribute__((amdgpu_waves_per_eu(PT_ALPHA_CLOSEST_WAVES, PT_ALPHA_CLOSEST_WAVES)))
-#define PT_ALPHA_SHADOW_ATTR __attribute__((amdgpu_waves_per_eu(7, 7)))  // 8 waves would spill 11 registers with the two-pass triangle test
+#ifndef PT_ALPHA_SHADOW_WAVES
+#define PT_ALPHA_SHADOW_WAVES 7 // 8 waves would spill 11 registers with the two-pass triangle test
+#endif
+#define PT_ALPHA_SHADOW_ATTR __attribute__((amdgpu_waves_per_eu(PT_ALPHA_SHADOW_WAVES, PT_ALPHA_SHADOW_WAVES)))
 template <bool ALPHA>
 PT_DEV void traceClosestBody(const TraceScene &sc, const Wavefront &wf, int qin, const BounceCtl &ctl)
 {
@@ -456,8 +462,11 @@ __global__ void __launch_bounds__(kBlock) PT_SHADE_ATTR k_shade<false>(LaunchPar
 }
 // the sampler pushes the TEX variant a few registers past 256, i.e. to ONE wave per SIMD: hold it at two (4 registers
 // spill; texture_test k_shade 8.3 -> 5.5 ms per step, atrium_like 17.1 -> 11.6 ms)
+#ifndef PT_SHADE_TEX_ATTR
+#define PT_SHADE_TEX_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
 template <>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) k_shade<true>(LaunchParams p, SceneView sv, Wavefront wf, int qin, BounceCtl ctl)
+__global__ void __launch_bounds__(kBlock) PT_SHADE_TEX_ATTR k_shade<true>(LaunchParams p, SceneView sv, Wavefront wf, int qin, BounceCtl ctl)
 {
     shadeBody<true>(p, sv, wf, qin, ctl);
 }
@@ -716,6 +725,7 @@ PT_DEV void shadeBody(const LaunchParams &p, const SceneView &sv, const Wavefron
 struct ShadowIO
 {
     static constexpr float kFixedTmin = 0.00001f; // raygen.rgen:26
+    static constexpr float kFixedTmax = -1.0f;    // per ray: the distance to the light
     static constexpr bool kNeedsPrim = false;
     const Wavefront &wf;
     float finished;
@@ -730,11 +740,13 @@ struct ShadowIO
         finished = d4.w;
         return true;
     }
-    PT_DEV void ignored(float, float, float, uint32_t, uint32_t, uint32_t, const TraceScene &) {} // shadow rays keep no decal
+    PT_DEV void ignored(float, float, float, uint32_t, const TraceScene &) {} // shadow rays keep no decal
+    PT_DEV void improve(uint32_t, float, float, float, uint32_t) {}
+    PT_DEV uint32_t bestSlot(uint32_t) const { return 0u; }
     // The traversal only records the answer.  What follows from it -- the NEE add into rad[slot], finishing the sample of a
     // path that ended on this bounce -- is k_apply_shadow's: inside the traversal loop those dependent loads and stores
     // sat in the retire phase of nearly every round for a handful of lanes (shadow rounds took 1.8x a closest round).
-    PT_DEV void store(uint32_t item, const Hit &, bool occluded) { wf.shadowResult[item] = (uint8_t)((occluded ? 0u : 1u) | (finished != 0.0f ? 2u : 0u)); }
+    PT_DEV void store(uint32_t item, const Hit &, bool occluded, bool) { wf.shadowResult[item] = (uint8_t)((occluded ? 0u : 1u) | (finished != 0.0f ? 2u : 0u)); }
 };
 
 template <bool ALPHA>
@@ -1159,7 +1171,7 @@ __global__ void k_skin(const PtxAnimatedVertex *__restrict__ in, const uint32_t 
 // traceRayEXT stand-in over explicit rays (o.xyz, tmin, d.xyz, tmax): traversal parity tests
 struct RaysIO
 {
-    static constexpr float kFixedTmin = -1.0f; // per ray
+    static constexpr float kFixedTmin = -1.0f, kFixedTmax = -1.0f; // per ray
     static constexpr bool kNeedsPrim = true;     // ptx_trace_rays reports (pair, prim)
     const float4 *rays;
     float4 *outHit;
@@ -1173,10 +1185,15 @@ struct RaysIO
         tmax = d4.w;
         return true;
     }
-    PT_DEV void ignored(float, float, float, uint32_t, uint32_t, uint32_t, const TraceScene &) {}
-    PT_DEV void store(uint32_t item, const Hit &h, bool hitAny)
+    PT_DEV void ignored(float, float, float, uint32_t, const TraceScene &) {}
+    // closest-hit queries: (u, v) and the triangle of the best hit so far wait in the output record
+    PT_DEV void improve(uint32_t item, float t, float u, float v, uint32_t triSlot) { outHit[item] = make_float4(t, u, v, __uint_as_float(triSlot)); }
+    PT_DEV uint32_t bestSlot(uint32_t item) const { return __float_as_uint(outHit[item].w); }
+    PT_DEV void store(uint32_t item, const Hit &h, bool hitAny, bool anyHitQuery)
     {
-        outHit[item] = make_float4(h.t, h.u, h.v, hitAny ? 1.0f : 0.0f);
+        const float4 cur = outHit[item];
+        const bool kept = hitAny && !anyHitQuery; // improve() has written (u, v)
+        outHit[item] = make_float4(h.t, kept ? cur.y : 0.0f, kept ? cur.z : 0.0f, hitAny ? 1.0f : 0.0f);
         outIds[item] = make_uint2(h.pair, h.prim);
     }
 };
@@ -1249,8 +1266,8 @@ __global__ void k_blit_level(TextureView tv, uint32_t src, uint32_t srcLevel, ui
     const float x0 = __builtin_floorf(x), y0 = __builtin_floorf(y), ax = x - x0, ay = y - y0;
     const float cx0 = clamp_(x0, 0.0f, (float)(sw - 1)), cx1 = clamp_(x0 + 1.0f, 0.0f, (float)(sw - 1));
     const float cy0 = clamp_(y0, 0.0f, (float)(sh - 1)), cy1 = clamp_(y0 + 1.0f, 0.0f, (float)(sh - 1));
-    const f4 top = lerp4(fetchTexel(tv, ts, srcLevel, (uint32_t)cx0, (uint32_t)cy0), fetchTexel(tv, ts, srcLevel, (uint32_t)cx1, (uint32_t)cy0), ax);
-    const f4 bot = lerp4(fetchTexel(tv, ts, srcLevel, (uint32_t)cx0, (uint32_t)cy1), fetchTexel(tv, ts, srcLevel, (uint32_t)cx1, (uint32_t)cy1), ax);
+    const f4 top = lerp4(fetchTexelEncoded(tv, ts, srcLevel, (uint32_t)cx0, (uint32_t)cy0), fetchTexelEncoded(tv, ts, srcLevel, (uint32_t)cx1, (uint32_t)cy0), ax);
+    const f4 bot = lerp4(fetchTexelEncoded(tv, ts, srcLevel, (uint32_t)cx0, (uint32_t)cy1), fetchTexelEncoded(tv, ts, srcLevel, (uint32_t)cx1, (uint32_t)cy1), ax);
     const f4 c = lerp4(top, bot, ay);
     const size_t idx = (size_t)td.levelOffset[dstLevel] + (size_t)j * dw + i;
     if (td.format == PTX_TEXTURE_RGBA32F)
@@ -1259,6 +1276,27 @@ __global__ void k_blit_level(TextureView tv, uint32_t src, uint32_t srcLevel, ui
         texels8[idx] = quantize8(linearToSrgb(c.x)) | quantize8(linearToSrgb(c.y)) << 8 | quantize8(linearToSrgb(c.z)) << 16 | quantize8(c.w) << 24;
     else
         texels8[idx] = quantize8(c.x) | quantize8(c.y) << 8 | quantize8(c.z) << 16 | quantize8(c.w) << 24;
+}
+
+// All levels of one 8-bit texture (a contiguous run of its pool) into the decoded pool the render kernels sample.
+__global__ void k_decode_texels(const uint32_t *__restrict__ texels8, const float *__restrict__ srgbLut, uint32_t first, uint32_t count, uint32_t format,
+                                float4 *__restrict__ decoded)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count)
+        return;
+    const uint32_t p = texels8[first + k];
+    float4 r;
+    if (format == PTX_TEXTURE_RGBA8_SRGB)
+    {
+        r.x = srgbLut[p & 255u]; r.y = srgbLut[(p >> 8) & 255u]; r.z = srgbLut[(p >> 16) & 255u];
+    }
+    else
+    {
+        r.x = (float)(p & 255u) / 255.0f; r.y = (float)((p >> 8) & 255u) / 255.0f; r.z = (float)((p >> 16) & 255u) / 255.0f;
+    }
+    r.w = (float)(p >> 24) / 255.0f;
+    decoded[k] = r;
 }
 
 __global__ void k_test_texture(TextureView tv, const float *__restrict__ in, float *__restrict__ out, uint32_t n, int implicitLod)
@@ -1601,9 +1639,16 @@ struct PtxRenderer
     DevBuf<uint32_t> pairFirst;
     DevBuf<PtxLightsUbo> lights;
     DevBuf<DevTexture> textures;
-    DevBuf<uint32_t> texels8;
+    DevBuf<uint32_t> texels8; // upload time: the pools of the image formats, in which mip chains are built; released after
     DevBuf<float4> texelsF;
     DevBuf<float> srgbLut;
+    DevBuf<DevTexture> renderTextures; // what the render kernels sample: every texel decoded to four floats, one pool
+    DevBuf<float4> renderTexels;
+    // what the any-hit stages read (scenes with non-opaque geometry; pt_bvh.hpp, hitAlpha)
+    DevBuf<AlphaTex> alphaTex;     // per colour texture
+    DevBuf<uint32_t> alphaTexOf;   // scene texture -> entry of alphaTex
+    DevBuf<float4> alphaQuads;     // 2 x 2 alpha footprints of their base levels
+    DevBuf<AlphaTri> alphaTris;    // per triangle slot, written behind k_emit
     uint32_t textureCount = 0;
     uint32_t skyKind = PTX_SKYBOX_CLEAR_COLOR; // its images follow the scene textures in `textures`
     bool samplerNeeded = false; // some uploaded texture is not a 1x1 white placeholder
@@ -2024,6 +2069,8 @@ int ptx_share_scene(PtxRenderer *r, PtxRenderer *owner)
     // its own copies are not needed any more
     r->vertices.release(); r->indices.release(); r->mr.release(); r->sg.release(); r->phong.release(); r->pairs.release();
     r->pairFirst.release(); r->textures.release(); r->texels8.release(); r->texelsF.release(); r->srgbLut.release();
+    r->renderTextures.release(); r->renderTexels.release();
+    r->alphaTex.release(); r->alphaTexOf.release(); r->alphaQuads.release(); r->alphaTris.release();
     r->animatedVertices.release(); r->skinSource.release(); r->bones.release();
     r->nodes.release(); r->tris.release(); r->shadeTris.release();
     r->build.release();
@@ -2384,14 +2431,75 @@ int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *s)
             for (uint32_t l = 1; l < t.levels; l++)
                 blit(i, l - 1, i, l);
         }
+        // The pool the render kernels sample (pt_device.hpp, fetchTexel): every level of every texture decoded to four floats,
+        // the RGBA32F pool first, the 8-bit textures behind it; `renderTextures` is the table with offsets into that pool.
+        if ((uint64_t)nf + n8 > 0xffffffffull)
+            return fail(r, PTX_ERROR_INVALID_ARGUMENT, "texture pool exceeds 2^32 texels");
+        HIP_TRY(r, r->renderTexels.alloc(nf + n8));
+        HIP_TRY(r, r->renderTextures.alloc(total));
+        if (nf)
+            HIP_TRY(r, hipMemcpyAsync(r->renderTexels.p, r->texelsF.p, nf * sizeof(float4), hipMemcpyDeviceToDevice, r->stream));
+        std::vector<DevTexture> renderTable(table.begin(), table.begin() + total);
+        for (uint32_t i = 0; i < total; i++)
+        {
+            DevTexture &t = renderTable[i];
+            if (t.format == PTX_TEXTURE_RGBA32F)
+                continue;
+            size_t count = 0;
+            for (uint32_t l = 0; l < t.levels; l++)
+                count += (size_t)dim(t.width, l) * dim(t.height, l);
+            const uint32_t first = t.levelOffset[0];
+            k_decode_texels<<<(uint32_t)((count + 255) / 256), 256, 0, r->stream>>>(r->texels8.p, r->srgbLut.p, first, (uint32_t)count, t.format,
+                                                                                  r->renderTexels.p + nf + first);
+            for (uint32_t l = 0; l < t.levels; l++)
+                t.levelOffset[l] += (uint32_t)nf;
+        }
+        if (total)
+            HIP_TRY(r, hipMemcpyAsync(r->renderTextures.p, renderTable.data(), total * sizeof(DevTexture), hipMemcpyHostToDevice, r->stream));
+        // any-hit data: the alpha footprints of every texture some material names as its colour texture
+        std::vector<AlphaTex> alphaTex;
+        std::vector<uint32_t> alphaTexOf(r->textureCount ? r->textureCount : 1u, kNoAlphaTex);
+        if (anyNonOpaque)
+        {
+            size_t quads = 0;
+            auto mark = [&](uint32_t colorIdx) {
+                if (colorIdx < PTX_SCENE_TEXTURE_OFFSET || colorIdx - PTX_SCENE_TEXTURE_OFFSET >= r->textureCount)
+                    return;
+                const uint32_t ti = colorIdx - PTX_SCENE_TEXTURE_OFFSET;
+                if (alphaTexOf[ti] != kNoAlphaTex)
+                    return;
+                alphaTexOf[ti] = (uint32_t)alphaTex.size();
+                alphaTex.push_back({ renderTable[ti].width, renderTable[ti].height, (uint32_t)quads, 0u });
+                quads += (size_t)renderTable[ti].width * renderTable[ti].height;
+            };
+            for (uint32_t i = 0; i < s->metallicRoughnessMaterialCount; i++) mark(s->metallicRoughnessMaterials[i].ColorIdx);
+            for (uint32_t i = 0; i < s->specularGlossinessMaterialCount; i++) mark(s->specularGlossinessMaterials[i].ColorIdx);
+            for (uint32_t i = 0; i < s->phongMaterialCount; i++) mark(s->phongMaterials[i].ColorIdx);
+            if (quads > 0xffffffffull)
+                return fail(r, PTX_ERROR_INVALID_ARGUMENT, "alpha footprints exceed 2^32 texels");
+            HIP_TRY(r, r->alphaQuads.alloc(quads));
+            for (uint32_t ti = 0; ti < r->textureCount; ti++)
+                if (alphaTexOf[ti] != kNoAlphaTex)
+                {
+                    const AlphaTex &at = alphaTex[alphaTexOf[ti]];
+                    k_alpha_quads<<<(at.width * at.height + 255) / 256, 256, 0, r->stream>>>(at.width, at.height, r->renderTexels.p + renderTable[ti].levelOffset[0],
+                                                                                            r->alphaQuads.p + at.offset);
+                }
+        }
+        if ((rc = upload(r, r->alphaTex, alphaTex.data(), alphaTex.size())) != PTX_OK) return rc;
+        if ((rc = upload(r, r->alphaTexOf, alphaTexOf.data(), alphaTexOf.size())) != PTX_OK) return rc;
         HIP_TRY(r, hipStreamSynchronize(r->stream)); // `table` and the caller's texel arrays may go away
         HIP_TRY(r, hipGetLastError());
+        // the pools of the upload formats have done their work (mip chains, scaling)
+        r->texels8.release(); r->texelsF.release(); r->srgbLut.release(); r->textures.release();
     }
     HIP_TRY(r, hipStreamSynchronize(r->stream)); // the host vectors above go out of scope
     r->sceneReady = true;
     r->stats.triangles = tri;
     return PTX_OK;
 }
+
+static SceneView makeSceneView(const PtxRenderer *r);
 
 // Full build (refit = false) or refit: new triangle records and leaf boxes, then the bottom-up box pass and the
 // 4-wide emit over the KEPT Morton order and binary topology.  keepState leaves the temporaries allocated for
@@ -2567,6 +2675,11 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
         if (getenv("PTX_VERBOSE"))
             std::fprintf(stderr, "[ptx] relayout: %u of %u emitted nodes are live, %u levels\n", hi, nv - 1, levels);
     }
+    if (r->anyNonOpaque && nv) // the any-hit records of the slots k_emit has just written
+    {
+        BUILD_TRY(r->alphaTris.alloc(n));
+        k_alpha_tris<<<vblocks, 256, 0, r->stream>>>(nv, r->tris.p, r->shadeTris.p, makeSceneView(r), r->alphaTexOf.p, r->alphaTris.p);
+    }
     uint32_t revived = 0;
     if (refit)
         BUILD_TRY(hipMemcpyAsync(&revived, &B.sceneBounds.p[7], sizeof(revived), hipMemcpyDeviceToHost, r->stream));
@@ -2685,10 +2798,19 @@ static SceneView makeSceneView(const PtxRenderer *r)
     sv.vertices = s->vertices.p; sv.indices = s->indices.p; sv.mr = s->mr.p; sv.sg = s->sg.p; sv.phong = s->phong.p;
     sv.pairs = s->pairs.p; sv.dxNormalTextures = s->dxNormalTextures;
     sv.lights = r->lights.p; // the lights come with every launch: each frame in flight has its own
-    sv.tex.textures = s->textures.p; sv.tex.textureCount = s->textureCount; sv.tex.texels8 = s->texels8.p; sv.tex.texelsF = s->texelsF.p;
-    sv.tex.srgbLut = s->srgbLut.p;
+    sv.tex.textures = s->renderTextures.p; sv.tex.textureCount = s->textureCount; sv.tex.texels8 = nullptr; sv.tex.texelsF = s->renderTexels.p;
+    sv.tex.srgbLut = nullptr;
     sv.skyKind = s->skyKind;
     return sv;
+}
+
+static TraceScene makeTraceScene(const PtxRenderer *r)
+{
+    const PtxRenderer *s = sceneOf(r);
+    TraceScene sc;
+    sc.nodes = s->nodes.p; sc.tris = s->tris.p; sc.triCount = s->treeTris;
+    sc.alphaTris = s->alphaTris.p; sc.alphaTex = s->alphaTex.p; sc.alphaQuads = s->alphaQuads.p;
+    return sc;
 }
 
 static int ensureSlots(PtxRenderer *r, size_t slots)
@@ -2985,7 +3107,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
     pl.p = p;
     pl.sv = makeSceneView(r);
     pl.mode = kernelMode(r);
-    pl.sc.nodes = sceneOf(r)->nodes.p; pl.sc.tris = sceneOf(r)->tris.p; pl.sc.triCount = sceneOf(r)->treeTris; pl.sc.sv = pl.sv;
+    pl.sc = makeTraceScene(r);
     pl.bounces = uniform->BounceCount;
     const SceneView &sv = pl.sv;
     const TraceScene &sc = pl.sc;
@@ -3397,8 +3519,8 @@ int ptx_test_texture(PtxRenderer *r, const float *in, float *out, uint32_t n, in
     HIP_TRY(r, r->testOut.alloc((size_t)n * 4));
     HIP_TRY(r, hipMemcpyAsync(r->testIn.p, in, (size_t)n * 28, hipMemcpyHostToDevice, r->stream));
     TextureView tv;
-    tv.textures = r->textures.p; tv.textureCount = r->textureCount; tv.texels8 = r->texels8.p; tv.texelsF = r->texelsF.p;
-    tv.srgbLut = r->srgbLut.p;
+    tv.textures = r->renderTextures.p; tv.textureCount = r->textureCount; tv.texels8 = nullptr; tv.texelsF = r->renderTexels.p;
+    tv.srgbLut = nullptr;
     k_test_texture<<<(n + 63) / 64, 64, 0, r->stream>>>(tv, r->testIn.p, r->testOut.p, n, implicitLod);
     HIP_TRY(r, hipMemcpyAsync(out, r->testOut.p, (size_t)n * 16, hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(r, hipStreamSynchronize(r->stream));
@@ -3421,7 +3543,7 @@ int ptx_trace_rays(PtxRenderer *r, const float *rays, uint32_t n, int anyHit, fl
     HIP_TRY(r, dHits.alloc(n));
     HIP_TRY(r, dIds.alloc(n));
     TraceScene sc;
-    sc.nodes = sceneOf(r)->nodes.p; sc.tris = sceneOf(r)->tris.p; sc.triCount = sceneOf(r)->treeTris; sc.sv = makeSceneView(r);
+    sc = makeTraceScene(r);
     hipError_t e = hipMemcpyAsync(dRays.p, rays, (size_t)n * 32, hipMemcpyHostToDevice, r->stream);
     if (e == hipSuccess)
     {
@@ -3459,25 +3581,5 @@ int ptx_bind_accumulation(PtxRenderer *r, void *devPtr, size_t bytes)
     return PTX_OK;
 }
 
-#ifdef PT_VISIT_STATS
-// Instrumented builds only (tools/visit_histogram.py): node visits per ray of the queue traversal kernels,
-// out[2][68] = [closest | shadow][max, sum, rays, -, 64 bins of 16 visits]; rounds[2][8] = per kernel the wave-level loop
-// counts (rounds, refill phases run, lanes refilled, node steps run, lanes in them, leaf phases run, lanes in them, waves);
-// reset != 0 clears the counters afterwards.
-__attribute__((visibility("default"))) int ptx_debug_visit_stats(uint32_t *out, unsigned long long *rounds, int reset)
-{
-    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(out, HIP_SYMBOL(ptd::g_visitStats), sizeof(uint32_t) * 2 * 68) != hipSuccess ||
-        hipMemcpyFromSymbol(rounds, HIP_SYMBOL(ptd::g_roundStats), sizeof(unsigned long long) * 2 * 8) != hipSuccess)
-        return PTX_ERROR_DEVICE;
-    if (reset)
-    {
-        static const unsigned long long zero[2 * 68] = {};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(ptd::g_visitStats), zero, sizeof(uint32_t) * 2 * 68) != hipSuccess ||
-            hipMemcpyToSymbol(HIP_SYMBOL(ptd::g_roundStats), zero, sizeof(unsigned long long) * 2 * 8) != hipSuccess)
-            return PTX_ERROR_DEVICE;
-    }
-    return PTX_OK;
-}
-#endif
 
 } // extern "C"
