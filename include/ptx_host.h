@@ -20,12 +20,12 @@ typedef struct PthScene PthScene;
 PTX_API const char *pth_scene_names(void);
 /* detail in (0,1] scales tessellation of the procedural stand-ins; seed 0 = scene default.
  * Besides the registry names:
- *   "file:<path>"            one glTF 2.0 / GLB asset through SceneImporter::AddFile (a CombinedSceneLoader with one
- *                            component, ExampleScenes.cpp:41-66)
- *   "description:<json>"     a SceneDescription (SceneManager.h:48-57; the aggregates of ExampleScenes.cpp:87-236):
+ *   "file:<path>"            one glTF 2.0 / GLB / FBX / OBJ asset through SceneImporter::AddFile (the registry's
+ *                            one-component file scenes, ExampleScenes.cpp:41-66)
+ *   "description:<json>"     a SceneDescription (host/SceneDescription.h; the aggregates of ExampleScenes.cpp:87-236):
  *   "description:@<file>"    {"components": [...], "skybox": "x.hdr", "mapping": "orca" | "none",
  *                            "dxNormalTextures": bool, "forceFullTextureSize": bool}; components and skybox that do not
- *                            exist are dropped as SceneDescription::ToLoader does, none left = error */
+ *                            exist are dropped (the reference warns and carries on, SceneManager.cpp:66-94), none left = error */
 PTX_API PthScene *pth_scene_create(const char *name, float detail, uint32_t seed);
 PTX_API void pth_scene_destroy(PthScene *s);
 PTX_API const char *pth_last_error(void);

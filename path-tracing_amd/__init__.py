@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import atexit
 import ctypes as C
+import glob
 import os
 import subprocess
 import sys
@@ -173,8 +174,9 @@ def build(force: bool = False, verbose: bool = True) -> None:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
     host = os.path.join(PKG_DIR, "host")
-    host_src = [os.path.join(host, f) for f in ("Scene.cpp", "Camera.cpp", "ExampleScenes.cpp", "OutputSaver.cpp", "TextureImporter.cpp", "JpegDecoder.cpp", "SceneImporter.cpp", "SceneManager.cpp", "FbxReader.cpp", "ObjReader.cpp", "host_capi.cpp")]
-    host_dep = host_src + [os.path.join(host, f) for f in ("Scene.h", "Camera.h", "ExampleScenes.h", "OutputSaver.h", "TextureImporter.h", "SceneImporter.h", "SceneManager.h", "Json.h", "Math.h")] + [
+    host_src = [os.path.join(host, f) for f in ("Scene.cpp", "Camera.cpp", "ExampleScenes.cpp", "OutputSaver.cpp", "TextureImporter.cpp", "JpegDecoder.cpp", "SceneImporter.cpp", "SceneDescription.cpp", "FbxReader.cpp", "ObjReader.cpp", "host_capi.cpp")]
+    # every header and source of host/ (a stale library after an edit to a header that is not listed is a silent wrong test)
+    host_dep = sorted(glob.glob(os.path.join(host, "*.h")) + glob.glob(os.path.join(host, "*.cpp"))) + [
         os.path.join(REPO_DIR, "include", "ptx_host.h"), os.path.join(REPO_DIR, "include", "ptx.h")]
     if force or _newer(HOST_LIB, host_dep):
         cmd = ["g++"] + HOST_FLAGS + ["-o", HOST_LIB] + host_src

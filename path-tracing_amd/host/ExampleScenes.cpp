@@ -11,7 +11,7 @@
 //    and do not exist offline.
 #include "ExampleScenes.h"
 #include "SceneImporter.h"
-#include "SceneManager.h"
+#include "SceneDescription.h"
 
 #include <fstream>
 #include <sstream>
@@ -1613,7 +1613,7 @@ std::shared_ptr<Scene> CreateScene(const std::string &name, float detail, uint32
 {
     SceneBuilder sb;
     bool useSceneCamera = true;
-    if (name.rfind("file:", 0) == 0) // a glTF 2.0 asset through the importer (SceneManager's file scenes, ExampleScenes.cpp:41-66)
+    if (name.rfind("file:", 0) == 0) // a glTF 2.0 asset through the importer (the registry's file scenes, ExampleScenes.cpp:41-66)
         SceneImporter::AddFile(sb, name.substr(5));
     else if (name.rfind("description:", 0) == 0)
     {
@@ -1631,10 +1631,7 @@ std::shared_ptr<Scene> CreateScene(const std::string &name, float detail, uint32
             text = ss.str();
             base = file.parent_path();
         }
-        const auto loader = SceneDescription::FromJson(text, base).ToLoader();
-        if (!loader->HasContent())
-            throw error("Entire scene not found"); // AddSceneByDescription, ExampleScenes.cpp:76-85
-        loader->Load(sb);
+        SceneDescription::Parse(text, base).Build(sb);
     }
     else if (name == "default")
     {

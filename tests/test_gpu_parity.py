@@ -550,7 +550,7 @@ def test_cpp_host_adapter_end_to_end(pkg, tmp_path):
     host = pkg.PKG_DIR + "/host"
     exe = str(tmp_path / "render_scene")
     cmd = ["g++", "-std=c++20", "-O2", pkg.REPO_DIR + "/examples/render_scene.cpp"] + [f"{host}/{f}.cpp" for f in
-           ("Scene", "Camera", "ExampleScenes", "OutputSaver", "TextureImporter", "JpegDecoder", "SceneImporter", "SceneManager", "FbxReader", "ObjReader", "RendererHip")] + [f"-I{host}", f"-L{pkg.PKG_DIR}", "-lptx_hip",
+           ("Scene", "Camera", "ExampleScenes", "OutputSaver", "TextureImporter", "JpegDecoder", "SceneImporter", "SceneDescription", "FbxReader", "ObjReader", "RendererHip")] + [f"-I{host}", f"-L{pkg.PKG_DIR}", "-lptx_hip",
            f"-Wl,-rpath,{pkg.PKG_DIR}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
     subprocess.check_call(cmd)
     W, H, spp, depth = 160, 90, 4, 4

@@ -239,7 +239,7 @@ def test_imported_scene_renders_like_the_oracle(pkg, orc, tmp_path):
 
 
 # ---------------------------------------------------------------------------------------
-# scene descriptions (SceneManager.h:48-57, ExampleScenes.cpp:87-236): several components, a skybox file, flags
+# scene descriptions (the aggregates of ExampleScenes.cpp:87-236): several components, a skybox file, flags
 # ---------------------------------------------------------------------------------------
 def _component(pkg, tmp_path, name, build):
     w = GltfWriter()
