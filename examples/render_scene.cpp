@@ -4,7 +4,7 @@
 // samples, run the post-process chain (postprocess.comp -> bloom -> composition.comp -> toneMapping.comp) and
 // hand the output image to the OutputSaver (PNG / TGA / HDR by file extension).
 //
-//   g++ -std=c++20 -O2 examples/render_scene.cpp path-tracing_amd/host/{Scene,Camera,ExampleScenes,OutputSaver,TextureImporter,JpegDecoder,SceneImporter,RendererHip}.cpp \
+//   g++ -std=c++20 -O2 examples/render_scene.cpp path-tracing_amd/host/{Scene,Camera,ExampleScenes,OutputSaver,TextureImporter,JpegDecoder,SceneImporter,SceneDescription,FbxReader,ObjReader,RendererHip}.cpp \
 //       -Ipath-tracing_amd/host -Lpath-tracing_amd -lptx_hip -Wl,-rpath,'$ORIGIN/../path-tracing_amd' -o examples/render_scene
 //   examples/render_scene default 640 360 16 4 out.png
 #include <cmath>
@@ -24,6 +24,8 @@ int main(int argc, char **argv)
     const uint32_t width = argc > 2 ? std::atoi(argv[2]) : 640, height = argc > 3 ? std::atoi(argv[3]) : 360;
     const uint32_t spp = argc > 4 ? std::atoi(argv[4]) : 16, bounces = argc > 5 ? std::atoi(argv[5]) : 4;
     const char *out = argc > 6 ? argv[6] : "render.png";
+    // the host's job, before the process first uses HIP (INTEGRATION.md "Frames in flight"): one hardware queue per stream
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     try
     {
         std::shared_ptr<Scene> scene = ExampleScenes::CreateScene(name, 0.25f, 0);

@@ -37,6 +37,11 @@ extern "C" {
 #define PTX_API __attribute__((visibility("default")))
 #endif
 
+/* Bumped whenever a struct of this header changes size or layout or an entry point changes meaning; ptx_abi_version()
+ * returns the value the loaded library was built with.  3: PtxSceneDesc.textureMemoryBudget (round 2),
+ * PtxStats.hardwareQueues (round 3). */
+#define PTX_ABI_VERSION 3u
+
 /* ------------------------------------------------------------------------- */
 /* Data contract                                                             */
 /* ------------------------------------------------------------------------- */
@@ -355,18 +360,26 @@ typedef struct PtxStats {
     double lastTailMs;       /* ... spent in k_tail (fused late bounces)            */
     uint64_t tracedRays;     /* closest-hit queries carried by the k_trace_closest launches timed in lastTraceMs
                                 (segments also counts the ones k_tail traces itself) */
+    uint64_t hardwareQueues; /* hardware queues the environment grants the process's HIP streams (GPU_MAX_HW_QUEUES when
+                                the handle was created, 4 = the runtime's default when unset): below two per handle the
+                                frames in flight run one after the other */
 } PtxStats;
 
 typedef struct PtxRenderer PtxRenderer;
 
 /* Renderer::Init / Renderer::Shutdown (Renderer.cpp:77-218).  One handle = one frame in flight (the reference's per-frame
  * rendering resources, Renderer.cpp:1454-1460): two HIP streams each.  The HIP runtime maps a process's streams onto
- * GPU_MAX_HW_QUEUES hardware queues (4 by default, which serialises frames in flight); loading this library puts
- * GPU_MAX_HW_QUEUES=16 into the environment unless the host has set it -- effective when HIP has not been used yet. */
+ * GPU_MAX_HW_QUEUES hardware queues (4 by default, which serialises frames in flight): a host that keeps several handles
+ * exports GPU_MAX_HW_QUEUES=16 before its first HIP call.  The library does not touch the environment; it
+ * reports what it finds (PtxStats::hardwareQueues) and the first handle whose streams no longer fit leaves a note in
+ * ptx_last_error although ptx_create returned PTX_OK. */
 PTX_API int ptx_create(const PtxDeviceDesc *desc, PtxRenderer **out);
 PTX_API void ptx_destroy(PtxRenderer *r);
 PTX_API const char *ptx_last_error(const PtxRenderer *r);
 PTX_API int ptx_device_count(void);
+/* PTX_ABI_VERSION of the library that was loaded: the structs of this header carry no size fields, so a binding compares
+ * this with the header it was written against before the first call (the Python package and RendererHip do). */
+PTX_API uint32_t ptx_abi_version(void);
 
 /* Renderer::UpdateSceneData (Renderer.cpp:238-439): copy the scene to HBM. */
 PTX_API int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *scene);

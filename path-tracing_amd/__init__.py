@@ -28,8 +28,9 @@ import weakref
 import numpy as np
 
 # The runtime maps all HIP streams of the process onto GPU_MAX_HW_QUEUES hardware queues (default 4); frames in flight need
-# one per stream to overlap (csrc/pt_kernels.hip, defaultHardwareQueueCount).  It is read at the first HIP call, so it has
-# to be in the environment before torch initialises the device.
+# one per stream to overlap (csrc/pt_kernels.hip, hardwareQueuesGranted).  It is read at the first HIP call, so it has to
+# be in the environment before torch initialises the device -- and it is the host's to set, which for Python callers is
+# this package at import time (no thread of ours exists yet); the C library only reports what it finds.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
@@ -46,7 +47,7 @@ HOST_FLAGS = ["-std=c++20", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-fvi
 
 # every symbol include/ptx.h and include/ptx_host.h declare
 PTX_SYMBOLS = [
-    "ptx_create", "ptx_destroy", "ptx_last_error", "ptx_device_count", "ptx_scene_upload", "ptx_build_accel", "ptx_share_scene",
+    "ptx_create", "ptx_destroy", "ptx_last_error", "ptx_device_count", "ptx_abi_version", "ptx_scene_upload", "ptx_build_accel", "ptx_share_scene",
     "ptx_resize", "ptx_set_tile_shard", "ptx_set_backend", "ptx_reset_accumulation", "ptx_render",
     "ptx_render_frames", "ptx_synchronize", "ptx_readback", "ptx_readback_begin", "ptx_readback_end", "ptx_device_accum_ptr", "ptx_accum_bytes",
     "ptx_shard_bytes", "ptx_pack_shard", "ptx_unpack_shard", "ptx_get_stats", "ptx_bind_accumulation",
@@ -119,6 +120,7 @@ class PostProcessingUniformData(C.Structure):
 TONE_MAPPING_SDR, TONE_MAPPING_HDR = 0, 1
 ACCEL_REFIT, ACCEL_REBUILD = 0, 1
 OUTPUT_RGBA8_SRGB, OUTPUT_RGBA32F = 0, 1
+ABI_VERSION = 3  # PTX_ABI_VERSION of include/ptx.h
 
 
 class DeviceDesc(C.Structure):
@@ -134,7 +136,7 @@ class Stats(C.Structure):
         ("pathSamples", C.c_uint64), ("segments", C.c_uint64), ("shadowRays", C.c_uint64), ("retries", C.c_uint64),
         ("triangles", C.c_uint64), ("bvhNodes", C.c_uint64), ("lastRenderMs", C.c_double), ("lastTraceMs", C.c_double),
         ("lastBuildMs", C.c_double), ("traceLaunches", C.c_uint64), ("lastShadeMs", C.c_double), ("lastShadowMs", C.c_double), ("lastTailMs", C.c_double),
-        ("tracedRays", C.c_uint64),
+        ("tracedRays", C.c_uint64), ("hardwareQueues", C.c_uint64),
     ]
 
 
@@ -241,6 +243,12 @@ def load_hip() -> C.CDLL:
         if not os.path.exists(HIP_LIB):
             raise RuntimeError(f"{HIP_LIB} missing: the HIP extension is not built (run __graft_entry__.build())")
         lib = C.CDLL(HIP_LIB)
+        have = None
+        if hasattr(lib, "ptx_abi_version"):
+            lib.ptx_abi_version.restype = C.c_uint32
+            have = lib.ptx_abi_version()
+        if have != ABI_VERSION and not os.environ.get("PTX_ABI_UNCHECKED"):  # PTX_ABI_UNCHECKED: A/B runs against an older experimental build
+            raise RuntimeError(f"{HIP_LIB} has ABI {have}, this package was written against {ABI_VERSION} (include/ptx.h): rebuild")
         P = C.c_void_p
         lib.ptx_create.argtypes = [C.POINTER(DeviceDesc), C.POINTER(P)]
         lib.ptx_destroy.argtypes = [P]

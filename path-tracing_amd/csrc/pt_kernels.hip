@@ -23,6 +23,7 @@
 // No CPU fallback exists: without a HIP device ptx_create fails.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -1627,6 +1628,7 @@ struct PtxRenderer
     uint32_t backend = PTX_BACKEND_WAVEFRONT;
     hipStream_t stream = nullptr;
     bool ownStream = false;
+    bool counted = false; // in g_liveHandles
     std::string error;
 
     // scene (HBM copies of the Scene getters)
@@ -1746,10 +1748,14 @@ struct PtxRenderer
     // what the last launch left for ptx_get_stats / the next launch to pick up once the device is done
     bool statsPending = false;
     uint32_t pendingBounces = 0, pendingTailBelow = 0, pendingSlots = 0;
+    uint64_t pendingEpoch = 0;
     uint32_t pendingDeadSlots = 0; // slots of ragged edge tiles outside the image: in the first queue, not rays
     bool pendingVerbose = false;
     std::vector<uint32_t> hintActive; // queue length per bounce of the last canonical launch: sizes the grids of the next one
     uint32_t hintSlots = 0, hintBounces = 0;
+    uint64_t hintEpoch = 0;  // sceneEpoch of the scene the hint was learnt on
+    uint64_t sceneEpoch = 1; // bumped by every upload and full build of THIS handle's scene (a refit keeps it: the poses of
+                             // an animation differ little from frame to frame)
     PtxStats stats = {};
 };
 
@@ -1778,6 +1784,13 @@ static int fail(PtxRenderer *r, int code, const char *fmt, ...)
 static const PtxRenderer *sceneOf(const PtxRenderer *r)
 {
     return r->sceneOwner ? r->sceneOwner : r;
+}
+
+// May `r` trace and shade right now?  A borrower is only as ready as its owner: between the owner's ptx_scene_upload and
+// its ptx_build_accel the owner's tree describes the OLD triangles while pairs, vertices and textures are the new ones.
+static bool sceneUsable(const PtxRenderer *r)
+{
+    return r->accelReady && (!r->sceneOwner || (r->sceneOwner->sceneReady && r->sceneOwner->accelReady));
 }
 
 static void detachSharedScene(PtxRenderer *r)
@@ -1880,15 +1893,26 @@ static LaunchParams makeParams(const PtxRenderer *r, const PtxRaygenUniformData 
 // onto GPU_MAX_HW_QUEUES hardware queues -- 4 unless the environment says otherwise.  Streams that share a queue run
 // one after the other, which is exactly what frames in flight are meant to avoid: measured on chess_like with 2 / 4 /
 // 8 / 16 queues, whole frame (3 in flight) 10.7 / 8.50 / 8.17 / 8.16 ms per step, one rank's shard of 8 (12 in flight)
-// - / 1.73 / 1.68 / 1.54.  The variable is read when the runtime initialises (the first HIP call of the process), so the
-// default is put in place when this library is loaded; a value the host has set is left alone, and a host that
-// initialises HIP before loading the library sets it itself.
-__attribute__((constructor)) static void defaultHardwareQueueCount()
+// - / 1.73 / 1.68 / 1.54.  The variable is read when the runtime initialises (the first HIP call of the process) and is
+// the HOST's to set (the Python package and bench.py set it at import): a library that edits its host's
+// environment at load time races with getenv in the host's other threads and cannot know whether HIP is up already.  What
+// the library does instead is REPORT: PtxStats::hardwareQueues says how many queues the environment grants, and the
+// handle whose streams no longer fit says so once (ptx_last_error after a successful ptx_create, stderr under PTX_VERBOSE).
+static uint32_t hardwareQueuesGranted()
 {
-    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    const char *e = getenv("GPU_MAX_HW_QUEUES");
+    const unsigned long v = e ? strtoul(e, nullptr, 10) : 0ul;
+    return v ? (uint32_t)v : 4u; // the runtime's default
 }
+static std::atomic<uint32_t> g_liveHandles{0};
+static std::atomic<bool> g_queueWarningGiven{false};
 
 extern "C" {
+
+uint32_t ptx_abi_version(void)
+{
+    return PTX_ABI_VERSION;
+}
 
 int ptx_device_count(void)
 {
@@ -1951,6 +1975,17 @@ int ptx_create(const PtxDeviceDesc *desc, PtxRenderer **out)
         ptx_destroy(r);
         return PTX_ERROR_OUT_OF_MEMORY;
     }
+    r->stats.hardwareQueues = hardwareQueuesGranted();
+    r->counted = true;
+    const uint32_t live = ++g_liveHandles;
+    if (2u * live > r->stats.hardwareQueues && live > 1 && !g_queueWarningGiven.exchange(true))
+    {
+        // not an error: the handle works, its frames just run behind the other handles' instead of beside them
+        fail(r, PTX_OK, "%u handles (two streams each) share %u hardware queues: frames in flight will serialise; export GPU_MAX_HW_QUEUES=16 "
+                        "before the process first uses HIP", live, (uint32_t)r->stats.hardwareQueues);
+        if (getenv("PTX_VERBOSE"))
+            fprintf(stderr, "[ptx] %s\n", r->error.c_str());
+    }
     *out = r;
     return PTX_OK;
 }
@@ -1960,6 +1995,8 @@ void ptx_destroy(PtxRenderer *r)
     if (!r)
         return;
     (void)hipSetDevice(r->device);
+    if (r->counted)
+        --g_liveHandles;
     if (r->stream)
         (void)hipStreamSynchronize(r->stream);
     detachSharedScene(r);
@@ -2002,6 +2039,8 @@ int ptx_set_backend(PtxRenderer *r, uint32_t backend)
 {
     if (!r || backend > PTX_BACKEND_MEGAKERNEL)
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_set_backend: bad backend %u", backend);
+    if (r->backend != backend)
+        r->hintSlots = 0u; // the learnt bounce schedule is the wavefront backend's
     r->backend = backend;
     return PTX_OK;
 }
@@ -2078,6 +2117,7 @@ int ptx_share_scene(PtxRenderer *r, PtxRenderer *owner)
     r->sceneOwner = owner;
     owner->sceneSharers.push_back(r);
     r->accelReady = true;
+    r->hintSlots = 0u; // whatever this handle had learnt, it had learnt on another scene
     r->stats.triangles = owner->stats.triangles;
     r->stats.bvhNodes = owner->stats.bvhNodes;
     return PTX_OK;
@@ -2088,11 +2128,9 @@ int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *s)
     if (!r || !s)
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_scene_upload: null argument");
     HIP_TRY(r, hipSetDevice(r->device));
-    detachSharedScene(r); // a renderer that was borrowing a scene gets its own again
-    quiesceSharers(r);
-    r->sceneReady = r->accelReady = false;
 
-    // validate indices the kernels will dereference (the reference trusts its importer)
+    // validate indices the kernels will dereference (the reference trusts its importer); a description that is refused
+    // here leaves the handle as it was -- its own scene, or the one it borrows
     for (uint32_t i = 0; i < s->instanceCount; i++)
         if (s->instances[i].ModelIndex >= s->modelCount)
             return fail(r, PTX_ERROR_INVALID_ARGUMENT, "instance %u: model index out of range", i);
@@ -2125,6 +2163,12 @@ int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *s)
             if (idx[geo.IndexOffset + k] >= geo.VertexLength)
                 return fail(r, PTX_ERROR_INVALID_ARGUMENT, "geometry %u: index %u beyond its vertex range", g, k);
     }
+
+    // from here on the old scene is gone, whatever happens
+    detachSharedScene(r); // a renderer that was borrowing a scene gets its own again
+    quiesceSharers(r);
+    r->sceneReady = r->accelReady = false;
+    r->sceneEpoch++;
 
     // (instance, mesh) pairs in instance-then-mesh order; global triangle id = running prim count
     // Device vertex buffer = scene vertices, then one skinned copy per instanced animated mesh in pair order
@@ -2707,6 +2751,7 @@ int ptx_build_accel(PtxRenderer *r)
     if (!r || !r->sceneReady)
         return fail(r, PTX_ERROR_NOT_READY, "ptx_build_accel: no scene uploaded");
     quiesceSharers(r);
+    r->sceneEpoch++; // schedules learnt on the old tree's scene are not this one's (ptx_scene_upload without a build in between cannot render)
     return buildAccel(r, false, false);
 }
 
@@ -2921,8 +2966,12 @@ static int enqueueBounce(PtxRenderer *r, const RenderPlan &pl, uint32_t b, int q
     if (tail)
     {
         const BounceCtl tctl = { b, tail == 2 ? 0xffffffffu : pl.tailBelow, 0u };
-        const uint32_t most = est < pl.tailBelow ? est : pl.tailBelow;
-        const dim3 grid(gridFor(most, kBlock, kMaxPersistentThreads / kBlock)); // grid-stride loop; the spill region holds this many threads
+        // grid-stride loop; the spill region holds kMaxPersistentThreads.  A hinted schedule (tail == 2) hands the tail
+        // whatever is left, and the hint is last frame's: a view that keeps four times the paths alive still finds a thread
+        // per path (blocks beyond the queue return at once), anything beyond that strides.
+        const uint32_t room = tail == 2 ? 4u * pl.tailBelow : pl.tailBelow;
+        const uint32_t most = est < room ? est : room;
+        const dim3 grid(gridFor(most, kBlock, kMaxPersistentThreads / kBlock));
         if (pl.mode == 2)
             k_tail<2><<<grid, kBlock, 0, X>>>(pl.p, pl.sv, pl.sc, pl.wfAux, qout, tctl);
         else if (pl.mode == 1)
@@ -3073,6 +3122,7 @@ static int collectRender(PtxRenderer *r)
         r->hintActive[tailBounce + 1] = tailPaths;
     r->hintSlots = tailPaths > r->pendingTailBelow ? 0u : r->pendingSlots;
     r->hintBounces = r->pendingBounces;
+    r->hintEpoch = r->pendingEpoch;
     return PTX_OK;
 }
 
@@ -3080,7 +3130,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
 {
     if (!r || !uniform || !lights)
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_render: null argument");
-    if (!r->accelReady || !imagePtr(r) || (r->sceneOwner && !r->sceneOwner->accelReady))
+    if (!sceneUsable(r) || !imagePtr(r))
         return fail(r, PTX_ERROR_NOT_READY, "ptx_render: need ptx_scene_upload (or ptx_share_scene), ptx_build_accel and ptx_resize first");
     if (uniform->SampleCount == 0 || uniform->SampleCount > 0xffffu || uniform->BounceCount > 0xffffu || frames == 0)
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_render: SampleCount must be in [1, 65535], BounceCount <= 65535");
@@ -3205,7 +3255,10 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
     pl.wfAux.spill = r->spillAux.p;
 
     const bool canonical = uniform->SampleCount == 1;
-    const uint32_t *hint = (canonical && r->hintSlots == p.numSlots && r->hintBounces == pl.bounces && !r->hintActive.empty()) ? r->hintActive.data() : nullptr;
+    // the learnt schedule belongs to (shape of the launch, scene it was learnt on); a camera or light change inside one scene
+    // keeps it -- a hint that is off costs time, never results, and the tail's grid leaves room for that (enqueueBounce)
+    const uint32_t *hint = (canonical && r->hintSlots == p.numSlots && r->hintBounces == pl.bounces && r->hintEpoch == sceneOf(r)->sceneEpoch && !r->hintActive.empty())
+                               ? r->hintActive.data() : nullptr;
     k_generate<<<gridFor(p.numSlots), kBlock, 0, r->stream>>>(p, wf);
     HIP_TRY(r, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&r->counters.p[C_ACTIVE0]), (int)p.numSlots, 1, r->stream));
     int rcq = enqueueRound(r, pl, p.numSlots, hint);
@@ -3255,6 +3308,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
     r->pendingBounces = pl.bounces;
     r->pendingTailBelow = pl.tailBelow;
     r->pendingSlots = canonical ? p.numSlots : 0u;
+    r->pendingEpoch = sceneOf(r)->sceneEpoch;
     r->pendingDeadSlots = p.numSlots - p.ownedPixels * frames;
     r->pendingVerbose = getenv("PTX_VERBOSE") != nullptr;
     return PTX_OK;
@@ -3532,8 +3586,8 @@ int ptx_trace_rays(PtxRenderer *r, const float *rays, uint32_t n, int anyHit, fl
 {
     if (!r || !rays || !hits || !ids)
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_trace_rays: null argument");
-    if (!r->accelReady)
-        return fail(r, PTX_ERROR_NOT_READY, "ptx_trace_rays: no acceleration structure");
+    if (!sceneUsable(r))
+        return fail(r, PTX_ERROR_NOT_READY, "ptx_trace_rays: no acceleration structure (of a shared scene: the owner's is being replaced)");
     if (!n)
         return PTX_OK;
     HIP_TRY(r, hipSetDevice(r->device));

@@ -22,6 +22,9 @@ void RendererHip::Check(int status)
 void RendererHip::Init(int deviceIndex, void *stream)
 {
     PtxDeviceDesc desc = { deviceIndex, PTX_BACKEND_WAVEFRONT, stream };
+    if (ptx_abi_version() != PTX_ABI_VERSION)
+        throw error("RendererHip: libptx_hip.so was built against another ptx.h (ABI " + std::to_string(ptx_abi_version()) + ", expected " +
+                    std::to_string(PTX_ABI_VERSION) + ")");
     if (ptx_create(&desc, &s_Renderer) != PTX_OK)
         throw error("RendererHip: ptx_create failed (no HIP device?)");
 }

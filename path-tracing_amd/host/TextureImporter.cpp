@@ -8,8 +8,9 @@
 namespace PathTracing
 {
 
-// A decoded image is at most this many pixels (the reference keeps textures within 4096 x 4096, TextureUploader.h:74):
-// a corrupted header must not turn into a multi-gigabyte allocation.
+// A decoded image is at most this many pixels: 16x the 4096 x 4096 the reference keeps textures within AFTER its scaling
+// (TextureUploader.h:74) -- sources may be larger than what is uploaded (skies are), but a corrupted header must not turn
+// into a multi-gigabyte allocation, and every decoder checks the data that is really there before it sizes a buffer.
 constexpr uint64_t kMaxImagePixels = 16384ull * 16384ull;
 
 
@@ -285,6 +286,20 @@ DecodedImage TextureImporter::DecodePng(std::span<const uint8_t> f)
     img.Channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 4 ? 2 : ctype == 6 ? 4 : (trns.empty() ? 3 : 4);
     if ((ctype == 0 || ctype == 2) && !trns.empty())
         img.Channels++; // a colour key adds an alpha channel
+    {
+        // bounds before allocation: what the passes need must be in the inflated stream before w * h * 4 bytes are asked for
+        // (a 100-byte file can declare 16384 x 16384)
+        uint64_t needed = 0;
+        for (int pass = 0; pass < passCount; pass++)
+        {
+            const Pass &ps = passes[pass];
+            const uint64_t pw = w > ps.x0 ? (w - ps.x0 + ps.dx - 1) / ps.dx : 0, ph = h > ps.y0 ? (h - ps.y0 + ps.dy - 1) / ps.dy : 0;
+            if (pw && ph)
+                needed += ((pw * samples * depth + 7) / 8 + 1) * ph;
+        }
+        if (raw.size() < needed)
+            throw error("PNG: not enough image data");
+    }
     img.Pixels.resize(static_cast<size_t>(w) * h * 4);
     size_t at = 0; // position in the inflated stream
     for (int pass = 0; pass < passCount; pass++)

@@ -141,6 +141,17 @@ def test_inflate_and_png_variants(pkg):
     bw = rng.integers(0, 2, (11, 19)).astype(np.uint8)
     img, _ = pkg.decode_image(_adam7_png(19, 11, 0, 1, bw))
     assert (img[..., 0] == bw * 255).all()
+    # a header that declares 16384 x 16384 over a few bytes of data is refused BEFORE the 1 GiB pixel buffer is asked for
+    import resource
+    import time
+    tiny = _adam7_png(3, 3, 6, 8, rng.integers(0, 256, (3, 3, 4), dtype=np.uint8))
+    ihdr = struct.pack(">IIBBBBB", 16384, 16384, 8, 6, 0, 0, 1)
+    huge = tiny[:12] + b"IHDR" + ihdr + struct.pack(">I", zlib.crc32(b"IHDR" + ihdr) & 0xFFFFFFFF) + tiny[33:]
+    for lie in (huge, huge.replace(ihdr, ihdr[:-1] + b"\x00")):  # interlaced and not
+        before, t0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss, time.time()
+        with pytest.raises(pkg.PtxError):
+            pkg.decode_image(lie)
+        assert resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - before < 64 * 1024 and time.time() - t0 < 1.0  # KiB
     # errors: truncated stream, unknown interlace method, garbage
     good = _png(w, h, 6, 8, [rgba[y].tobytes() for y in range(h)])
     for bad in (good[:100], good.replace(b"IHDR" + good[16:28] + b"\x00", b"IHDR" + good[16:28] + b"\x02"), b"not an image at all" * 4):

@@ -34,21 +34,29 @@ def test_headers_and_libraries_agree(pkg):
         assert hasattr(host, name), name
 
 
-def test_library_sets_the_hardware_queue_default(pkg):
-    """Loading the HIP library puts GPU_MAX_HW_QUEUES=16 into the environment (frames in flight need a hardware queue per
-    stream; the runtime reads the variable at its first call) and leaves a value the host has chosen alone."""
+def test_hardware_queue_default_is_the_hosts_not_the_librarys(pkg):
+    """The HIP library leaves the process environment alone (a load-time setenv races with the host's threads and cannot
+    know whether HIP is up already); the Python package -- the host, for Python callers -- sets GPU_MAX_HW_QUEUES=16 at
+    import unless the caller has chosen a value; the library reports its ABI version."""
     import subprocess
     import sys
 
-    code = ("import ctypes, os, sys; ctypes.CDLL(sys.argv[1]); libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; "
-            "print(libc.getenv(b'GPU_MAX_HW_QUEUES').decode())")
-    for preset, expect in ((None, "16"), ("6", "6")):
+    lib_code = ("import ctypes, os, sys; lib = ctypes.CDLL(sys.argv[1]); libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; "
+                "v = libc.getenv(b'GPU_MAX_HW_QUEUES'); lib.ptx_abi_version.restype = ctypes.c_uint32; "
+                "print(v.decode() if v else 'unset', lib.ptx_abi_version())")
+    pkg_code = "import os, sys; sys.path.insert(0, sys.argv[1]); import __graft_entry__ as g; g.load_package(); print(os.environ['GPU_MAX_HW_QUEUES'])"
+    for preset in (None, "6"):
         env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
         if preset:
             env["GPU_MAX_HW_QUEUES"] = preset
-        out = subprocess.run([sys.executable, "-c", code, pkg.HIP_LIB], env=env, capture_output=True, text=True, timeout=120)
+        out = subprocess.run([sys.executable, "-c", lib_code, pkg.HIP_LIB], env=env, capture_output=True, text=True, timeout=120)
         assert out.returncode == 0, out.stderr
-        assert out.stdout.strip() == expect
+        assert out.stdout.split() == [preset or "unset", str(pkg.ABI_VERSION)]
+        out = subprocess.run([sys.executable, "-c", pkg_code, pkg.REPO_DIR], env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        assert out.stdout.strip() == (preset or "16")
+    header = open(os.path.join(pkg.REPO_DIR, "include", "ptx.h")).read()
+    assert f"#define PTX_ABI_VERSION {pkg.ABI_VERSION}u" in header
 
 
 def test_no_cpu_fallback(pkg):

@@ -1,5 +1,8 @@
 """ptx_share_scene: frames in flight render ONE scene and one tree (the reference keeps per-frame rendering resources over
 one set of scene buffers, Renderer.cpp:238-439, 1454-1460)."""
+import ctypes as C
+import os
+
 import numpy as np
 import pytest
 
@@ -79,6 +82,28 @@ def test_share_scene_lifetime_and_errors(pkg):
     c.resize(W, H)
     c.render_frames(uo, other.lights, 0, 1)
     assert (b.readback().view(np.uint32) == c.readback().view(np.uint32)).all()
+    # between the owner's upload and its build the owner's tree describes the OLD triangles: the borrower must not trace
+    owner._check(owner.lib.ptx_scene_upload(owner.handle, C.byref(scene.desc)))
+    rays = np.array([[0, 1, 5, 0, 0, 0, -1, 100]], np.float32)
+    with pytest.raises(pkg.PtxError):
+        b.render_frames(uo, other.lights, 0, 1)
+    with pytest.raises(pkg.PtxError):
+        b.trace_rays(rays)
+    owner._check(owner.lib.ptx_build_accel(owner.handle))
+    b.trace_rays(rays)
+    owner.upload(other)
+    # an upload the borrower's handle REFUSES (an instance names a model that does not exist) leaves it borrowing
+    bad = type(other.desc)()
+    C.memmove(C.byref(bad), C.byref(other.desc), C.sizeof(bad))
+    one = np.zeros(13, np.uint32)  # PtxModelInstance: ModelIndex + 3 x 4 floats
+    one[0] = 10 ** 6
+    bad.instances, bad.instanceCount = one.ctypes.data, 1
+    with pytest.raises(pkg.PtxError):
+        b._check(b.lib.ptx_scene_upload(b.handle, C.byref(bad)))
+    b.reset()
+    b.render_frames(uo, other.lights, 0, 1)
+    assert (b.readback().view(np.uint32) == c.readback().view(np.uint32)).all()
+    assert b.stats().hardwareQueues == int(os.environ["GPU_MAX_HW_QUEUES"])
     # a borrower that uploads gets its own scene back
     b.upload(scene)
     b.reset()
