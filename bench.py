@@ -275,9 +275,11 @@ class Job:
         self.finish()
         c = {"trace_ms": 0.0, "shade_ms": 0.0, "shadow_ms": 0.0, "tail_ms": 0.0, "launches": 0, "rays": 0, "segments": 0, "shadow": 0}
         self.collect = c
+        t0 = time.perf_counter()
         for _ in range(steps):
             self.step(job_spp, readback=False)
             self.rs[(self.k - 1) % self.F].synchronize()
+        c["wall_s"], c["steps"] = time.perf_counter() - t0, steps
         self.finish()
         self.collect = None
         return c
@@ -288,38 +290,96 @@ class Job:
         self.scene.close()
 
 
-def roofline(job, stats, digest):
-    """Dominant kernel k_trace_closest: algorithmic bytes (SURVEY.md 8d model) and counter-measured HBM bytes, both over
-    the kernel's live HIP-event time.  The kernel is latency-bound (dependent node fetches), not HBM-bound: `bound` says
-    so, `frac` prices the model bytes against the HBM peak as the contract asks, `frac_counter` the bytes that moved."""
-    bpr = algorithmic_bytes_per_closest_ray(job.n_tris)
+RENDER_KERNELS = ("k_generate", "k_prologue", "k_trace_closest", "k_shade", "k_shade_tex", "k_shade_split", "k_trace_shadow", "k_apply_shadow", "k_tail",
+                  "k_finish_restarts", "k_restart", "k_accumulate", "k_upload_lights", "__amd_rocclr_copyBuffer", "__amd_rocclr_fillBufferAligned")
+
+
+def segment_model_bytes(n_tris: int) -> int:
+    """B_segment(N) = 2 (32 L(N) + 36) + 796 bytes."""
+    L = max(1, math.ceil(math.log2(max(n_tris, 2))))
+    return 2 * (32 * L + 36) + 796
+
+
+def traffic_doc(job):
+    """Per-kernel HBM bytes per launch from separate rocprofv3 --pmc passes of this same command on this scene (PMC
+    counters cannot be read from inside the process): the newest committed summary of the scene, or --traffic-json."""
+    a = job.args
+    if (a.detail, job.W, job.H, a.spp, a.depth, job.world) != (1.0, 1920, 1080, 8, 8, 1):
+        return None, None
+    if a.traffic_json:
+        cands = [a.traffic_json]
+    else:
+        cands = sorted(glob.glob(os.path.join(REPO, "profiles", "r*traffic*.json")), key=os.path.getmtime, reverse=True)
+    for f in cands:
+        if not os.path.exists(f):
+            continue
+        doc = json.load(open(f))
+        if doc.get("scene", "chess_like") == job.scene.name:
+            return doc, f
+    return None, None
+
+
+def kernel_roofline(job, stats, bpr):
     trace_s = stats["trace_ms"] * 1e-3
     launches = max(stats["launches"], 1)
     achieved = stats["rays"] * bpr / trace_s / 1e9
+    return {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "avg_launch_ms": stats["trace_ms"] / launches, "launches": stats["launches"],
+            "rays_per_launch": stats["rays"] / launches, "model_bytes_per_launch": bpr * stats["rays"] / launches,
+            "grays_per_s": stats["rays"] / trace_s / 1e9}
+
+
+def roofline(job, stats, digest, stats_x=None, step_ms=None, segments_per_sample=None):
+    """Dominant kernel k_trace_closest: algorithmic bytes (SURVEY.md 8d model) and counter-measured HBM bytes per launch over
+    the kernel's launch duration from live HIP events.  The kernel is latency-bound (dependent node fetches), not HBM-bound:
+    `bound` says so, `frac` prices the model bytes against the HBM peak as the contract asks, `frac_counter` the bytes that moved.
+
+    Which duration: with frames in flight a launch's duration counts the time it shares the machine with the other frames'
+    launches -- six launches of 1.6 ms per 7.7 ms step are more than the step -- so the top-level figures use the launch ALONE on
+    the machine (`stats_x`: the same frames one at a time, measured live right after the timed region), and the timed region's
+    overlapped durations ride in `overlapped`.  `step` prices the WHOLE step instead of one kernel: model bytes per sample x samples
+    and the sum of every render kernel's counter bytes, over the step time of the timed region."""
+    bpr = algorithmic_bytes_per_closest_ray(job.n_tris)
+    over = kernel_roofline(job, stats, bpr)
+    top = kernel_roofline(job, stats_x, bpr) if stats_x and stats_x["trace_ms"] > 0 else over
     out = {
-        "bound": "latency", "priced_against": "hbm", "kernel": "k_trace_closest", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS, "traffic": None, "achieved_counter": None, "frac_counter": None,
-        "model_bytes_per_ray": bpr, "model_bytes_per_launch": bpr * stats["rays"] / launches,
-        "rays_per_launch": stats["rays"] / launches, "avg_launch_ms": stats["trace_ms"] / launches, "launches": stats["launches"],
-        "grays_per_s": stats["rays"] / trace_s / 1e9,
+        "bound": "latency", "priced_against": "hbm", "kernel": "k_trace_closest", "achieved": top["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": top["frac"], "traffic": None, "achieved_counter": None, "frac_counter": None,
+        "measured": ("launch alone on the machine (the same frames one at a time, live HIP events after the timed region)" if top is not over
+                     else "launches of the timed region (live HIP events)"),
+        "model_bytes_per_ray": bpr, "model_bytes_per_launch": top["model_bytes_per_launch"],
+        "rays_per_launch": top["rays_per_launch"], "avg_launch_ms": top["avg_launch_ms"], "launches": top["launches"],
+        "grays_per_s": top["grays_per_s"],
         "limiter": "dependent-fetch latency: SQ_WAIT_ANY / SQ_WAVE_CYCLES of this kernel in profiles/*_sq.txt",
     }
-    # HBM traffic comes from separate rocprofv3 --pmc passes of this same command (PMC counters cannot be read from
-    # inside the process): the newest committed summary is attached when it was collected on this workload, and marked
-    # stale when the kernels have changed since.
-    a = job.args
-    tj = a.traffic_json or (sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic.json")), key=os.path.getmtime) or [None])[-1]
-    default_workload = (job.scene.name, a.detail, job.W, job.H, a.spp, a.depth, job.world) == ("chess_like", 1.0, 1920, 1080, 8, 8, 1)
-    if tj and os.path.exists(tj) and default_workload:
-        doc = json.load(open(tj))
-        t = doc.get("k_trace_closest")
-        if t:
-            traffic = t["hbm_bytes_per_launch"]
-            out["traffic"] = traffic
-            out["achieved_counter"] = traffic / (out["avg_launch_ms"] * 1e-3) / 1e9
-            out["frac_counter"] = out["achieved_counter"] / HBM_PEAK_GBS
-            out["traffic_source"] = os.path.relpath(tj, REPO) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, (2*FETCH+WRITE)*1024)"
-            out["traffic_stale"] = doc.get("source_digest") != digest
+    if top is not over:
+        out["overlapped"] = dict(over, what=f"launches of the timed region, {job.F} frames in flight: a launch's duration counts the time it "
+                                            "shares the machine with the other frames' launches (falls as overlap and throughput rise)")
+    doc, tj = traffic_doc(job)
+    if doc and doc.get("k_trace_closest"):
+        traffic = doc["k_trace_closest"]["hbm_bytes_per_launch"]
+        out["traffic"] = traffic
+        out["achieved_counter"] = traffic / (out["avg_launch_ms"] * 1e-3) / 1e9
+        out["frac_counter"] = out["achieved_counter"] / HBM_PEAK_GBS
+        if "overlapped" in out:
+            out["overlapped"]["achieved_counter"] = traffic / (over["avg_launch_ms"] * 1e-3) / 1e9
+            out["overlapped"]["frac_counter"] = out["overlapped"]["achieved_counter"] / HBM_PEAK_GBS
+        out["traffic_source"] = os.path.relpath(tj, REPO) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, (2*FETCH+WRITE)*1024)"
+        out["traffic_stale"] = doc.get("source_digest") != digest
+    if step_ms and segments_per_sample:
+        samples = job.W * job.H * job.args.spp / job.world
+        model = (segments_per_sample * segment_model_bytes(job.n_tris) + 32) * samples
+        step = {"what": "the whole step (every kernel of one frame batch) over ms_per_step of the timed region",
+                "model_bytes": model, "frac_model": model / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "model": "SURVEY 8d: (segments_per_sample * B_segment(N) + 32) * samples; counts bytes the caches serve, so it can exceed what HBM delivers",
+                "counter_bytes": None, "frac_counter": None}
+        if doc and doc.get("k_generate", {}).get("launches"):
+            frames = doc["k_generate"]["launches"]  # one k_generate per step of the profiled command
+            total = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in doc.items() if isinstance(v, dict) and k in RENDER_KERNELS)
+            step["counter_bytes"] = total / frames
+            step["frac_counter"] = step["counter_bytes"] / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            step["counter_bytes_by_kernel"] = {k: v["hbm_bytes_per_launch"] * v["launches"] / frames for k, v in doc.items()
+                                               if isinstance(v, dict) and k in RENDER_KERNELS and v["hbm_bytes_per_launch"] * v["launches"] / frames > 1e6}
+        out["step"] = step
     return out
 
 
@@ -351,19 +411,11 @@ def scene_line(args, pkg, torch, dist, orc, name, rank, world, local_rank, steps
             },
         }
         if args.backend == "wavefront" and stats["trace_ms"] > 0:
-            line["roofline"] = roofline(job, stats, digest)
-            if stats_x and stats_x["trace_ms"] > 0:
-                x = roofline(job, stats_x, digest)
-                line["roofline"]["frac_exclusive"] = x["frac"]
-                line["roofline"]["note"] = (
-                    f"frac is taken over the timed region, where {job.F} frames are in flight and a launch's duration counts the time it shares "
-                    "the machine with the other frames' launches (it falls as overlap and throughput rise); frac_exclusive is the same launch "
-                    "alone on the machine -- the figure comparable with a one-frame-in-flight measurement and with "
-                    "profiles/*_kernel_stats_one_in_flight.csv")
-                line["roofline"]["exclusive"] = {
-                    "what": "the same frames one at a time, after the timed region: launch durations without other frames' kernels on the machine",
-                    "avg_launch_ms": x["avg_launch_ms"], "launches": x["launches"], "achieved": x["achieved"], "frac": x["frac"],
-                    "achieved_counter": x["achieved_counter"], "frac_counter": x["frac_counter"], "grays_per_s": x["grays_per_s"]}
+            line["roofline"] = roofline(job, stats, digest, stats_x, line["ms_per_step"], line["config"]["segments_per_sample"])
+        if stats_x:
+            # latency of ONE frame batch (reset -> 8 spp -> done, nothing else on the machine); `value` is the pipelined rate
+            line["one_in_flight_ms_per_step"] = stats_x["wall_s"] / stats_x["steps"] * 1e3
+            line["one_in_flight_value"] = W * H * spp / (stats_x["wall_s"] / stats_x["steps"]) / 1e6
         if with_cpu:
             line["cpu_baseline"] = cpu_baseline(orc, job.scene, W, H, args.depth, args.cpu_seconds)
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]

@@ -102,7 +102,7 @@ def _run_bench_two_ranks(tmp_path, backend, extra=()):
     import subprocess
 
     out = tmp_path / f"gathered_{backend}.npy"
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN")  # WARN: RCCL says WHY it refuses a communicator
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--single-device", "--dist-backend", backend,
            "--steps", "2", "--warmup", "1", "--repeats", "1", "--scene", "chess_like", "--detail", "0.05", "--width", "328", "--height", "200",
@@ -121,7 +121,12 @@ def test_bench_two_ranks_gather_the_single_rank_frame(pkg, tmp_path, backend):
 
     p, out = _run_bench_two_ranks(tmp_path, backend)
     if p.returncode != 0 and backend == "nccl":
-        pytest.skip("RCCL refuses two ranks on one device here: " + p.stderr.strip().splitlines()[-1][:200])
+        # RCCL refuses two ranks on ONE device at communicator init ("Duplicate GPU detected", ncclInvalidUsage): that, and only
+        # that, is a reason to skip -- any other failure of the RCCL branch is a failure of this test
+        import re
+        m = re.search(r"Duplicate GPU detected[^\n]*|ncclInvalidUsage[^\n]*|invalid usage[^\n]*", p.stderr + p.stdout)
+        if m:
+            pytest.skip("RCCL refuses two ranks on one device (runs wherever two GPUs exist): " + m.group(0)[:200])
     assert p.returncode == 0, p.stderr[-2000:]
     line = json.loads(p.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["weak"]["scaling"] == "weak" and line["value"] > 0

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/profile_set.sh TAG [bench.py args ...] -- run ON THE GPU BOX (through gpurun): the profile set of one build.
+# tools/profile_set.sh TAG [--scene NAME] [bench.py args ...] -- run ON THE GPU BOX (through gpurun): the profile set of one build.
 #   gpurun_out/TAG_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the default bench.py workload
 #   gpurun_out/TAG_kernel_stats_one_in_flight.csv   the same with --in-flight 1
 #   gpurun_out/TAG_traffic.json       per-kernel HBM bytes per launch from two PMC passes (FETCH_SIZE, WRITE_SIZE; separate
@@ -8,6 +8,7 @@
 #   gpurun_out/TAG_bench.json         the un-profiled bench.py line of the same build
 # Copy what is to be judged into profiles/ afterwards.
 TAG=${1:?tag}; shift
+SCENE=chess_like; prev=""; for a in "$@"; do [ "$prev" = "--scene" ] && SCENE=$a; prev=$a; done
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -25,7 +26,7 @@ cp "$(find gpurun_out/${TAG}_trace1 -name '*kernel_stats.csv' | head -1)" gpurun
 find gpurun_out/${TAG}_trace1 -name "*.csv" -size +1M -delete
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${TAG}_fetch -o $TAG -- $CMD > gpurun_out/${TAG}_fetch.log 2>&1; echo "fetch rc=$?"
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${TAG}_write -o $TAG -- $CMD > gpurun_out/${TAG}_write.log 2>&1; echo "write rc=$?"
-python3 tools/pmc_traffic.py gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write gpurun_out/${TAG}_traffic.json
+python3 tools/pmc_traffic.py gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write gpurun_out/${TAG}_traffic.json $SCENE
 python3 tools/trace_gaps.py gpurun_out/${TAG}_trace | grep step | tail -3
 CMD3="python3 bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-extra-scenes $*"
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/${TAG}_sq1 -o sq -- $CMD3 > gpurun_out/${TAG}_sq1.log 2>&1; echo "sq1 rc=$?"
