@@ -343,3 +343,89 @@ def test_isotropic_texture_grad_against_float64_formulas(pkg, orc):
                 want[sel] += bilinear(level, uf[sel], vf[sel]) * wgt[sel]
     err = np.abs(got - want) / np.maximum(1.0, np.abs(want))
     assert err.max() < 3e-5, float(err.max())
+
+
+def test_anisotropic_texture_grad_against_float64_formulas(pkg, orc):
+    """The anisotropic branch of the sampler (material.glsl:72-76 calls textureGrad on a sampler with anisotropy at the device
+    maximum, Renderer.cpp:103-110) against an independent float64 restatement of the Vulkan / EXT_texture_filter_anisotropic
+    formulas: rho_x, rho_y = lengths of the two gradients in texels, eta = min(rho_max / rho_min, 16), N = ceil(eta) taps at
+    lambda = log2(rho_max / eta), spaced along the longer gradient at i / (N + 1) - 1/2, each the linear blend of the two
+    nearest levels' bilinear lookups, averaged.  Float texture, no quantisation; footprints from 1:1.05 to 1:40 (clamped at
+    16), both axes as the major one.  Cases within 1e-3 of an integer eta are left out: there the float32 and float64 tap
+    counts may differ by one, which is a property of ceil, not of the sampler."""
+    rng = np.random.default_rng(9)
+    W, H = 64, 32
+    base = rng.uniform(0, 3, (H, W, 4)).astype(np.float32)
+    s = pkg.Scene("texture_test")
+    d, keep = _desc_with(pkg, s, [(W, H, F32, 1, base.reshape(-1))], budget=2**64 - 1)
+    osc = orc.OracleScene(d, build_bvh=False)
+    chain = [base.astype(np.float64)]
+    while max(chain[-1].shape[:2]) > 1:  # bilinear clamp-to-edge halving = the 2 x 2 mean while both extents are even, 2 x 1 after
+        c = chain[-1]
+        hh, ww = c.shape[:2]
+        if hh > 1 and ww > 1:
+            chain.append((c[0::2, 0::2] + c[1::2, 0::2] + c[0::2, 1::2] + c[1::2, 1::2]) / 4)
+        elif ww > 1:
+            chain.append((c[:, 0::2] + c[:, 1::2]) / 2)
+        else:
+            chain.append((c[0::2] + c[1::2]) / 2)
+
+    def bilinear(level, u, v):
+        img = chain[level]
+        h, w = img.shape[:2]
+        x, y = u * w - 0.5, v * h - 0.5
+        x0, y0 = np.floor(x), np.floor(y)
+        ax, ay = (x - x0)[:, None], (y - y0)[:, None]
+        i0, i1, j0, j1 = (x0.astype(int) % w), ((x0.astype(int) + 1) % w), (y0.astype(int) % h), ((y0.astype(int) + 1) % h)
+        return (img[j0, i0] * (1 - ax) + img[j0, i1] * ax) * (1 - ay) + (img[j1, i0] * (1 - ax) + img[j1, i1] * ax) * ay
+
+    def trilinear(lam, u, v):
+        lam = np.clip(lam, 0, len(chain) - 1)
+        l0 = np.floor(lam).astype(int)
+        l1 = np.minimum(l0 + 1, len(chain) - 1)
+        f = (lam - l0)[:, None]
+        out = np.zeros((len(u), 4))
+        for level in range(len(chain)):
+            for sel, wgt in ((l0 == level, 1 - f), (l1 == level, f)):
+                if sel.any():
+                    out[sel] += bilinear(level, u[sel], v[sel]) * wgt[sel]
+        return out
+
+    n = 6000
+    u, v = rng.uniform(-1.5, 2.5, n), rng.uniform(-1.5, 2.5, n)
+    major = 2.0 ** rng.uniform(0.0, 5.0, n)            # longer gradient, in texels
+    ratio = np.exp(rng.uniform(np.log(1.05), np.log(40.0), n))
+    minor = major / ratio
+    ang = rng.uniform(0, 2 * np.pi, n)
+    swap = rng.integers(0, 2, n).astype(bool)           # which of (d/dx, d/dy) is the longer one
+    skew = rng.uniform(-0.4, 0.4, n)                    # the two gradients need not be perpendicular
+    ax_, ay_ = np.cos(ang), np.sin(ang)
+    bx_, by_ = np.cos(ang + np.pi / 2 + skew), np.sin(ang + np.pi / 2 + skew)
+    gx = np.where(swap[:, None], np.stack([minor * bx_, minor * by_], 1), np.stack([major * ax_, major * ay_], 1))  # texels
+    gy = np.where(swap[:, None], np.stack([major * ax_, major * ay_], 1), np.stack([minor * bx_, minor * by_], 1))
+    dudx, dvdx, dudy, dvdy = (np.float32(gx[:, 0] / W), np.float32(gx[:, 1] / H), np.float32(gy[:, 0] / W), np.float32(gy[:, 1] / H))
+    got = osc.test_texture(_inputs(9, np.float32(u), np.float32(v), dudx, dvdx, dudy, dvdy)).view(np.float32)
+
+    uf, vf = np.float64(np.float32(u)), np.float64(np.float32(v))
+    mux, mvx, muy, mvy = np.float64(dudx) * W, np.float64(dvdx) * H, np.float64(dudy) * W, np.float64(dvdy) * H
+    rx, ry = np.hypot(mux, mvx), np.hypot(muy, mvy)
+    rmax, rmin = np.maximum(rx, ry), np.minimum(rx, ry)
+    eta = np.minimum(rmax / rmin, 16.0)
+    N = np.ceil(eta)
+    lam = np.log2(rmax / eta)
+    du = np.where(rx >= ry, np.float64(dudx), np.float64(dudy))
+    dv = np.where(rx >= ry, np.float64(dvdx), np.float64(dvdy))
+    want = np.zeros((n, 4))
+    for taps in range(1, 17):
+        sel = N == taps
+        if not sel.any():
+            continue
+        acc = np.zeros((int(sel.sum()), 4))
+        for i in range(1, taps + 1):
+            w = i / (taps + 1.0) - 0.5
+            acc += trilinear(lam[sel], uf[sel] + du[sel] * w, vf[sel] + dv[sel] * w)
+        want[sel] = acc / taps
+    ok = (np.abs(eta - np.round(eta)) > 1e-3) | (eta >= 16.0)
+    assert ok.sum() > 0.97 * n and (N[ok] >= 2).sum() > 0.9 * ok.sum() and (N[ok] == 16).sum() > 300
+    err = np.abs(got - want) / np.maximum(1.0, np.abs(want))
+    assert err[ok].max() < 5e-5, float(err[ok].max())
