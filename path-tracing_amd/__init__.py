@@ -42,6 +42,13 @@ HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off", "-fno-fast-math",  # arithmetic conventions of csrc/pt_device.hpp
     "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
+    # No SLP vectorisation: under plain -O3 the compiler packs adjacent scalar f32 multiplies and adds into v_pk_mul_f32 /
+    # v_pk_add_f32, whose operands must sit in aligned register PAIRS -- the shading kernels then spend a tenth of their VALU
+    # instructions on v_mov shuffling (731 -> 391 in k_shade<false>) and every kernel pays in registers: k_trace_closest 64 -> 54
+    # VGPRs, k_shade<false> 168 with 15 spilled -> 168 with none, k_shade<true> 238 -> 221, k_generate 57 -> 51 (8 waves).  Same
+    # IEEE operations, same bits.  Measured (1 MI355X, 1080p, 8 spp, two runs each in one call): chess_like 2,139 / 2,158 ->
+    # 2,265 / 2,290 Msamples/s, street_like 1,135 / 1,145 -> 1,176 / 1,174, temple_like 822 / 827 -> 843 / 846, atrium_like flat.
+    "-fno-slp-vectorize",
 ]
 HOST_FLAGS = ["-std=c++20", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-fvisibility=hidden"]
 
