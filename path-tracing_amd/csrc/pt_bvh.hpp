@@ -1293,7 +1293,9 @@ PT_DEV bool traceRay(const TraceScene &sc, f3 o, f3 d, float tmin, float tmax, S
 // visits per lane, then one leaf phase for every lane that reached a leaf, then the
 // refill -- so the triangle code is issued once per round, not once per node visit.
 //
-// IO supplies the queue: bool load(item, o, d, tmin, tmax) (false = nothing to trace, e.g. a dead slot), for closest-hit
+// IO supplies the queue: kHasQueue + queueEntry(item) / setEntry(entry) (what item `item` of the queue names -- a path slot --
+// read by the wave a chunk at a time and handed back to the lane that takes the item), bool load(item, o, d, tmin, tmax) (false =
+// nothing to trace, e.g. a dead slot), for closest-hit
 // queries void improve(item, t, u, v, triSlot) (a nearer hit was found: the IO keeps where) and uint32_t bestSlot(item)
 // (its triangle), and void store(item, hit, hitAny, anyHitQuery) when the ray is done (hit.t and hit.pair; u, v, slot are the IO's).
 constexpr uint32_t kTraceChunk = 128;   // measured: 64 -> 1327, 128 -> 1347, 256 -> 1310 Msamples/s
@@ -1322,6 +1324,14 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
     uint32_t round = 0;
     bool have = false;
     uint32_t item = 0;
+    // The wave's current chunk of the ray queue, staged in LDS (IO::kHasQueue): when the wave takes a chunk, two coalesced loads
+    // bring its 128 queue entries in, and a refilling lane takes its entry from there by the rank the refill ballot gives it --
+    // one dependent global load less at the head of the chain of every ray (queue entry -> ray -> root).  The first attempt
+    // (round 2) lost 3 % to seven spilled registers at the 64-VGPR budget; without the SLP vectoriser the kernels have the room
+    // (58 / 56 VGPRs): chess_like +0.9 %, street_like +1.8 %, atrium_like +0.6 % (two runs each, one call).
+    __shared__ uint32_t s_stagedQueue[4][kTraceChunk]; // per wave of the block (256 threads)
+    __attribute__((address_space(3))) uint32_t *stagedQueue = (__attribute__((address_space(3))) uint32_t *)&s_stagedQueue[threadIdx.x >> 6][0];
+    uint32_t chunkStart = 0; // wave-uniform
     f3 o = F3s(0.0f), d = F3s(0.0f), id = F3s(0.0f);
     float tmin = 0.0f, tmax = 0.0f;
     Hit best;
@@ -1357,6 +1367,16 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
                     cursor = c;
                     end = c + kTraceChunk < count ? c + kTraceChunk : count;
                 }
+                if (IO::kHasQueue && c < count)
+                {
+                    // (the wave's own LDS traffic is in order: no barrier, only the compiler must not move the reads up)
+                    const uint32_t e0 = c + lane, e1 = c + 64u + lane;
+                    const uint32_t q0 = e0 < count ? io.queueEntry(e0) : 0u, q1 = e1 < count ? io.queueEntry(e1) : 0u;
+                    stagedQueue[lane] = q0;
+                    stagedQueue[64u + lane] = q1;
+                    chunkStart = c;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                }
             }
             if (cursor < end)
             {
@@ -1366,6 +1386,8 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
                 if (!have && rank < take)
                 {
                     item = cursor + rank;
+                    if (IO::kHasQueue)
+                        io.setEntry(stagedQueue[item - chunkStart]);
                     if (io.load(item, o, d, tmin, tmax))
                     {
                         have = true;
@@ -1436,7 +1458,9 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
                 else if (t < best.t || (t == best.t && (pair < best.pair || (pair == best.pair && prim < __float_as_uint(sc.tris[io.bestSlot(item)].c.z)))))
                 {
                     // where the best hit lies on its triangle goes to the IO's record at once (write-through: a ray improves
-                    // its hit two or three times): three registers less in every lane for the length of the walk
+                    // its hit two or three times): three registers less in every lane for the length of the walk.  (Keeping
+                    // them in registers where the kernel has the room -- 57 instead of 54 VGPRs in the opaque closest kernel --
+                    // measured -0.8 % / +0.2 % / +0.3 % on chess_like / street_like / atrium_like: the stores are not what it waits for.)
                     best.t = t;
                     best.pair = pair;
                     io.improve(item, t, u, v, (uint32_t)~leafRef);

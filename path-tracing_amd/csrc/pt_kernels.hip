@@ -312,12 +312,14 @@ struct ClosestIO
     static constexpr float kFixedTmin = 0.00001f; // ray.glsl:79
     static constexpr float kFixedTmax = 10000.0f; // ray.glsl:80
     static constexpr bool kNeedsPrim = false;    // the hit record carries (t, u, v, slot) and the pair
+    static constexpr bool kHasQueue = true;
     const Wavefront &wf;
     const uint32_t *queue;
     uint32_t slot;
+    PT_DEV uint32_t queueEntry(uint32_t item) const { return queue[item]; }
+    PT_DEV void setEntry(uint32_t s) { slot = s; }
     PT_DEV bool load(uint32_t item, f3 &o, f3 &d, float &tmin, float &tmax)
     {
-        slot = queue[item];
         const float4 d4 = wf.rayD[slot];
         if (d4.w < 0.0f)
         {
@@ -728,11 +730,15 @@ struct ShadowIO
     static constexpr float kFixedTmin = 0.00001f; // raygen.rgen:26
     static constexpr float kFixedTmax = -1.0f;    // per ray: the distance to the light
     static constexpr bool kNeedsPrim = false;
+    static constexpr bool kHasQueue = true;
     const Wavefront &wf;
     float finished;
+    uint32_t staged;
+    PT_DEV uint32_t queueEntry(uint32_t item) const { return wf.shadowQueue[item]; }
+    PT_DEV void setEntry(uint32_t s) { staged = s; }
     PT_DEV bool load(uint32_t item, f3 &o, f3 &d, float &tmin, float &tmax)
     {
-        const uint32_t slot = wf.shadowQueue[item];
+        const uint32_t slot = staged;
         const float4 o4 = wf.shO[slot], d4 = wf.shD[slot];
         o = F3(o4.x, o4.y, o4.z);
         d = F3(d4.x, d4.y, d4.z);
@@ -757,7 +763,7 @@ PT_DEV void traceShadowBody(const LaunchParams &p, const TraceScene &sc, const W
     if (count == 0u)
         return;
     PT_DECLARE_STACK(st, kLdsStack, wf.spill)
-    ShadowIO io = { wf, 0.0f };
+    ShadowIO io = { wf, 0.0f, 0u };
     persistentTrace<true, ALPHA>(sc, io, count, &wf.counters[shadowChunkCounter(parity)], st);
     if (st.overflow)
         atomicAdd(&wf.counters[C_OVERFLOW], 1u);
@@ -1043,6 +1049,10 @@ PT_DEV void tailBody(const LaunchParams &p, const SceneView &sv, const TraceScen
     }
     PT_DECLARE_STACK(st, PT_TAIL_LDS, wf.spill)
     PathCounters pc;
+    // (Dealing the paths to every 2nd / 4th / 8th lane -- a wave runs each bounce for as long as its slowest path takes, so fewer
+    // paths per wave shorten every wave's chain and put more waves on a SIMD -- was measured: with frames in flight the lanes
+    // it wastes are not free.  chess_like whole frame 7.36 / 7.12 -> 7.39 / 7.26 ms per step, a rank's shard of 8 1.29 / 1.27 ->
+    // 1.35 / 1.34, of 4 2.07 -> 2.23, street_like's shard of 8 1.96 -> 2.04.)
     for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x)
     {
         const uint32_t i = base + threadIdx.x;
@@ -1174,6 +1184,9 @@ struct RaysIO
 {
     static constexpr float kFixedTmin = -1.0f, kFixedTmax = -1.0f; // per ray
     static constexpr bool kNeedsPrim = true;     // ptx_trace_rays reports (pair, prim)
+    static constexpr bool kHasQueue = false;
+    PT_DEV uint32_t queueEntry(uint32_t item) const { return item; }
+    PT_DEV void setEntry(uint32_t) {}
     const float4 *rays;
     float4 *outHit;
     uint2 *outIds;
@@ -2965,12 +2978,12 @@ static int enqueueBounce(PtxRenderer *r, const RenderPlan &pl, uint32_t b, int q
     HIP_TRY(r, hipEventRecord(ev.x1, X));
     if (tail)
     {
-        const BounceCtl tctl = { b, tail == 2 ? 0xffffffffu : pl.tailBelow, 0u };
         // grid-stride loop; the spill region holds kMaxPersistentThreads.  A hinted schedule (tail == 2) hands the tail
         // whatever is left, and the hint is last frame's: a view that keeps four times the paths alive still finds a thread
         // per path (blocks beyond the queue return at once), anything beyond that strides.
         const uint32_t room = tail == 2 ? 4u * pl.tailBelow : pl.tailBelow;
         const uint32_t most = est < room ? est : room;
+        const BounceCtl tctl = { b, tail == 2 ? 0xffffffffu : pl.tailBelow, 0u };
         const dim3 grid(gridFor(most, kBlock, kMaxPersistentThreads / kBlock));
         if (pl.mode == 2)
             k_tail<2><<<grid, kBlock, 0, X>>>(pl.p, pl.sv, pl.sc, pl.wfAux, qout, tctl);
