@@ -19,7 +19,8 @@
 //                   the traversal kernels were bound by the per-CU address/L1 pipeline (every
 //                   lane fetches its own node: 4 divergent dwordx4 per visit), not by HBM.
 //   Tri       48 B  v0, e1, e2 (Moeller-Trumbore form) + (pair, prim) ids, in leaf order
-// child ref >= 0: internal node index; < 0: leaf, triangle slot = ~ref; kEmptyRef: no child.
+// child ref >= 0: internal node index; < 0: leaf, ~ref = triangle slot (bits 0..29) | kLeafNonOpaque for a triangle of a
+// non-opaque geometry (so that its any-hit record can be fetched WITH the triangle, not after it); kEmptyRef: no child.
 #pragma once
 
 #include "pt_device.hpp"
@@ -42,11 +43,13 @@ struct Tri
 {
     float4 a; // v0.xyz, e1.x
     float4 b; // e1.yz, e2.xy
-    float4 c; // e2.z, pair (bits), prim (bits), w (bits): bit 31 = non-opaque geometry (any-hit stages run), bits 0..30 = the
-              // triangle's index in the flattened instance / mesh / primitive order -- the order of (pair, prim)
+    float4 c; // e2.z, pair (bits), prim (bits), w (bits): bit 31 = non-opaque geometry (any-hit stages run); for those, bits
+              // 0..14 / 15..29 = width - 1 / height - 1 of the base level of its alpha texture (k_alpha_tris)
 };
 static_assert(sizeof(Tri) == 48, "Tri is 48 B");
 constexpr uint32_t kTriNonOpaque = 0x80000000u; // Tri::c.w
+constexpr uint32_t kLeafNonOpaque = 0x40000000u, kLeafSlotMask = 0x3fffffffu; // ~ref of a leaf
+constexpr uint32_t kMaxTriangles = 0x3fffffffu;
 
 struct Hit
 {
@@ -119,7 +122,7 @@ __global__ void k_tri_setup(uint32_t n, uint32_t pairCount, const uint32_t *__re
     Tri t;
     t.a = make_float4(w[0].x, w[0].y, w[0].z, e1.x);
     t.b = make_float4(e1.y, e1.z, e2.x, e2.y);
-    t.c = make_float4(e2.z, __uint_as_float(p), __uint_as_float(prim), __uint_as_float((pr->nonOpaque ? kTriNonOpaque : 0u) | g));
+    t.c = make_float4(e2.z, __uint_as_float(p), __uint_as_float(prim), __uint_as_float(pr->nonOpaque ? kTriNonOpaque : 0u));
     triTmp[g] = t;
 
     // bounds from the same p0, p0+e1, p0+e2 the intersection test sees, padded so the slab test does not reject a
@@ -789,6 +792,10 @@ __global__ void k_emit(int n, const uint32_t *__restrict__ vals, const float4 *_
     }
     BvhNode nd;
     nd.a = make_float4(o[0], o[1], o[2], __uint_as_float(ebits[0] | (ebits[1] << 8) | (ebits[2] << 16)));
+    // a leaf of a non-opaque geometry says so in its ref: the traversal fetches its any-hit record beside the triangle
+    for (int k = 0; k < count; k++)
+        if (c[k].ref < 0 && (__float_as_uint(triTmp[vals[~c[k].ref]].c.w) & kTriNonOpaque))
+            c[k].ref = ~(int)((uint32_t)~c[k].ref | kLeafNonOpaque);
     nd.refs = make_int4(c[0].ref, c[1].ref, count > 2 ? c[2].ref : kEmptyRef, count > 3 ? c[3].ref : kEmptyRef);
     nd.q0 = make_uint4(qlo[0], qhi[0], qlo[1], qhi[1]);
     nd.q1 = make_uint4(qlo[2], qhi[2], 0u, 0u);
@@ -858,7 +865,7 @@ __global__ void k_single_leaf_root(const uint32_t *vals, const float4 *boxLo, co
         eb[a] = (uint32_t)e;
     }
     nd.a = make_float4(lo[0], lo[1], lo[2], __uint_as_float(eb[0] | (eb[1] << 8) | (eb[2] << 16)));
-    nd.refs = make_int4(~0, kEmptyRef, kEmptyRef, kEmptyRef);
+    nd.refs = make_int4((__float_as_uint(triTmp[g].c.w) & kTriNonOpaque) ? ~(int)kLeafNonOpaque : ~0, kEmptyRef, kEmptyRef, kEmptyRef);
     nd.q0 = make_uint4(0xffffff00u, 0x000000ffu, 0xffffff00u, 0x000000ffu);
     nd.q1 = make_uint4(0xffffff00u, 0x000000ffu, 0u, 0u);
     nodes[0] = nd;
@@ -879,16 +886,19 @@ constexpr uint32_t kMaxNodeVisits = 1u << 20;
 // occlusionAnyhit.rahit:37-50 need ONE number per candidate, texture(textures[colorIdx], uv).a * colorFactor.a.  Through the
 // general path (hitBaseColor: pair -> material -> texture table -> four texels, uv from five float4 of the 272-byte shading
 // record) that was four dependent fetches and enough live state to cost the traversal kernels their eighth wave per SIMD.
-//   AlphaTri   32 B per triangle slot: the three texture coordinates, the alpha texture and the material's alpha factor
-//   AlphaTex   16 B per colour texture: base-level extent and where its quads start
+//   AlphaTri   32 B per triangle slot: the three texture coordinates, the material's alpha factor and where the quads of its
+//              alpha texture start (kNoAlphaTex: no texture, the factor is the alpha); the texture's base-level extent rides in
+//              the free bits of Tri::c.w.  A leaf of a non-opaque geometry is marked in its ref (kLeafNonOpaque), so the record is
+//              fetched WITH the triangle: behind the intersection test one dependent load is left (the quad) instead of three
+//              (record -> texture table -> quad).
 //   quads      per base-level texel (x, y) the alphas of the 2 x 2 bilinear footprint whose top-left texel it is --
 //              (x, y), (x+1, y), (x, y+1), (x+1, y+1) with repeat addressing -- so the footprint is ONE dwordx4 load
 struct AlphaTri
 {
     float4 a; // u0, v0, u1, v1
-    float4 b; // u2, v2, alpha texture (bits; kNoAlphaTex: constant alpha), colour factor alpha (or the constant alpha itself)
+    float4 b; // u2, v2, colour factor alpha (or the constant alpha itself), first quad of the alpha texture (bits; kNoAlphaTex: none)
 };
-struct AlphaTex
+struct AlphaTex // build time only (k_alpha_tris): per colour texture, base-level extent and where its quads start
 {
     uint32_t width, height, offset, pad;
 };
@@ -900,7 +910,6 @@ struct TraceScene
     const Tri *tris;
     uint32_t triCount;
     const AlphaTri *alphaTris; // ALPHA variants only
-    const AlphaTex *alphaTex;
     const float4 *alphaQuads;
 };
 
@@ -914,19 +923,17 @@ PT_DEV uint32_t fetchAgainAfter(uint32_t index, float after)
 
 // texture(textures[colorIdx], uv).a * colorFactor.a at a candidate hit: the .w of hitBaseColor(), bit for bit -- the same
 // interpolation of the texture coordinates, the same bilinear weights and operation order as sampleLevel / lerp4 on the
-// alpha channel alone.
-PT_DEV float hitAlpha(const TraceScene &sc, uint32_t slot, float u, float v)
+// alpha channel alone.  (ta, tb) = the triangle's AlphaTri, triW = its Tri::c.w.
+PT_DEV float hitAlpha(const TraceScene &sc, float4 ta, float4 tb, uint32_t triW, float u, float v)
 {
-    const float4 ta = sc.alphaTris[slot].a, tb = sc.alphaTris[slot].b;
-    const uint32_t tex = __float_as_uint(tb.z);
-    if (tex == kNoAlphaTex)
-        return tb.w;
+    const uint32_t first = __float_as_uint(tb.w);
+    if (first == kNoAlphaTex)
+        return tb.z;
     const f3 bary = F3(1.0f - u - v, u, v);
     float tu = (ta.x * bary.x + ta.z * bary.y) + tb.x * bary.z;
     float tv = (ta.y * bary.x + ta.w * bary.y) + tb.y * bary.z;
-    const AlphaTex at = sc.alphaTex[tex];
-    const float4 *quads = sc.alphaQuads + at.offset;
-    const uint32_t w = at.width, h = at.height;
+    const float4 *quads = sc.alphaQuads + first;
+    const uint32_t w = (triW & 0x7fffu) + 1u, h = ((triW >> 15) & 0x7fffu) + 1u;
     float alpha;
     if (w == 1 && h == 1)
         alpha = quads[0].x;
@@ -962,21 +969,26 @@ PT_DEV float hitAlpha(const TraceScene &sc, uint32_t slot, float u, float v)
         const float top = a00 * (1.0f - ax) + a10 * ax, bot = a01 * (1.0f - ax) + a11 * ax;
         alpha = top * (1.0f - ay) + bot * ay;
     }
-    return alpha * tb.w;
+    return alpha * tb.z;
+}
+PT_DEV float hitAlpha(const TraceScene &sc, uint32_t slot, uint32_t triW, float u, float v)
+{
+    return hitAlpha(sc, sc.alphaTris[slot].a, sc.alphaTris[slot].b, triW, u, v);
 }
 
 // One thread per triangle slot of the tree: the any-hit record of a triangle of a non-opaque geometry.  The texture
 // coordinates come from the shading record k_emit wrote (floats 3..4, 17..18, 31..32), the colour texture and factor by
 // the rules of material.glsl:25-54 (getColorTextureIdx / getColorFactor; an unknown material type: texture 0, factor 1).
-__global__ void k_alpha_tris(uint32_t n, const Tri *__restrict__ tris, const ShadeTri *__restrict__ shadeTris, SceneView sv,
-                             const uint32_t *__restrict__ alphaTexOf, AlphaTri *__restrict__ out)
+// The extent of the alpha texture goes into the free bits of the triangle's own record (Tri::c.w).
+__global__ void k_alpha_tris(uint32_t n, Tri *__restrict__ tris, const ShadeTri *__restrict__ shadeTris, SceneView sv,
+                             const uint32_t *__restrict__ alphaTexOf, const AlphaTex *__restrict__ alphaTex, AlphaTri *__restrict__ out)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
         return;
     AlphaTri r;
     r.a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    r.b = make_float4(0.0f, 0.0f, __uint_as_float(kNoAlphaTex), 1.0f);
+    r.b = make_float4(0.0f, 0.0f, 1.0f, __uint_as_float(kNoAlphaTex));
     const float4 tc = tris[i].c;
     if (__float_as_uint(tc.w) & kTriNonOpaque)
     {
@@ -1002,12 +1014,17 @@ __global__ void k_alpha_tris(uint32_t n, const Tri *__restrict__ tris, const Sha
             idx = sv.phong[materialIndex].ColorIdx;
             factor = sv.phong[materialIndex].Color[3];
         }
-        uint32_t tex = kNoAlphaTex;
+        uint32_t first = kNoAlphaTex, extent = 0u;
         if (idx >= PTX_SCENE_TEXTURE_OFFSET && idx - PTX_SCENE_TEXTURE_OFFSET < sv.tex.textureCount)
-            tex = alphaTexOf[idx - PTX_SCENE_TEXTURE_OFFSET];
+        {
+            const AlphaTex at = alphaTex[alphaTexOf[idx - PTX_SCENE_TEXTURE_OFFSET]];
+            first = at.offset;
+            extent = (at.width - 1u) | (at.height - 1u) << 15; // both at most 32768 (checked at upload)
+        }
         else
             factor = sampleTexture(idx).w * factor; // a fixed 1x1 default (or the white placeholder past the table): constant alpha
-        r.b = make_float4(q7.w, q8.x, __uint_as_float(tex), factor);
+        r.b = make_float4(q7.w, q8.x, factor, __uint_as_float(first));
+        tris[i].c.w = __uint_as_float(kTriNonOpaque | extent);
     }
     out[i] = r;
 }
@@ -1026,9 +1043,9 @@ __global__ void k_alpha_quads(uint32_t w, uint32_t h, const float4 *__restrict__
 //   closest rays  anyhit.rahit:36-64: alpha < 0.5 -> remembered as the decal if it is the nearest so far, ignored
 //   shadow rays   occlusionAnyhit.rahit:35-53: alpha < 1 -> ignored
 template <bool ANY_HIT>
-PT_DEV bool anyHitKeeps(const TraceScene &sc, uint32_t pair, uint32_t prim, uint32_t slot, float t, float u, float v, Decal &decal)
+PT_DEV bool anyHitKeeps(const TraceScene &sc, uint32_t pair, uint32_t prim, uint32_t slot, uint32_t triW, float t, float u, float v, Decal &decal)
 {
-    const float alpha = hitAlpha(sc, slot, u, v);
+    const float alpha = hitAlpha(sc, slot, triW, u, v);
     if (ANY_HIT)
         return !(alpha < 1.0f);
     if (alpha < 0.5f)
@@ -1246,20 +1263,20 @@ PT_DEV bool traceRay(const TraceScene &sc, f3 o, f3 d, float tmin, float tmax, S
         {
             if (STATS)
                 (*triTests)++;
-            const int leafRef = ref;
-            const Tri *tp = &sc.tris[~ref];
+            const uint32_t leafSlot = ALPHA ? (uint32_t)~ref & kLeafSlotMask : (uint32_t)~ref;
+            const Tri *tp = &sc.tris[leafSlot];
             const float4 ta = tp->a, tb = tp->b, tc = tp->c;
             float t, u, v;
             if (intersectTri(F3(ta.x, ta.y, ta.z), F3(ta.w, tb.x, tb.y), F3(tb.z, tb.w, tc.x), o, d, tmin, tmax, t, u, v) &&
                 (!ALPHA || !(__float_as_uint(tc.w) & kTriNonOpaque) ||
-                 anyHitKeeps<ANY_HIT>(sc, __float_as_uint(tc.y), __float_as_uint(tc.z), (uint32_t)~leafRef, t, u, v, decal)))
+                 anyHitKeeps<ANY_HIT>(sc, __float_as_uint(tc.y), __float_as_uint(tc.z), leafSlot, __float_as_uint(tc.w), t, u, v, decal)))
             {
                 const uint32_t pair = __float_as_uint(tc.y), prim = __float_as_uint(tc.z);
                 if (ANY_HIT)
                 {
                     best.pair = pair;
                     best.prim = prim;
-                    best.slot = (uint32_t)~leafRef;
+                    best.slot = leafSlot;
                     return true;
                 }
                 if (t < best.t || (t == best.t && (pair < best.pair || (pair == best.pair && prim < best.prim))))
@@ -1269,7 +1286,7 @@ PT_DEV bool traceRay(const TraceScene &sc, f3 o, f3 d, float tmin, float tmax, S
                     best.v = v;
                     best.pair = pair;
                     best.prim = prim;
-                    best.slot = (uint32_t)~leafRef;
+                    best.slot = leafSlot;
                 }
             }
             if (st.sp == 0)
@@ -1418,29 +1435,38 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
             }
         }
 
-        // ---- leaf phase (single-triangle leaves: ref = ~slot)
+        // ---- leaf phase (single-triangle leaves: ~ref = slot, with kLeafNonOpaque where the any-hit stage runs)
         if (have && ref < 0)
         {
-            const int leafRef = ref;
-            const Tri *tp = &sc.tris[~ref];
+            const uint32_t leafBits = (uint32_t)~ref;
+            const uint32_t leafSlot = ALPHA ? leafBits & kLeafSlotMask : leafBits;
+            const Tri *tp = &sc.tris[leafSlot];
             const float4 ta = tp->a, tb = tp->b, tc = tp->c;
+            // the any-hit record of a non-opaque triangle travels with the triangle: five independent loads, one wait
+            float4 aa = make_float4(0.0f, 0.0f, 0.0f, 0.0f), ab = aa;
+            const bool nonOpaque = ALPHA && (leafBits & kLeafNonOpaque) != 0u;
+            if (nonOpaque)
+            {
+                aa = sc.alphaTris[leafSlot].a;
+                ab = sc.alphaTris[leafSlot].b;
+            }
             float t, u, v;
             ref = st.sp ? (int)st.pop() : kRefDone;
             bool candidate = intersectTri(F3(ta.x, ta.y, ta.z), F3(ta.w, tb.x, tb.y), F3(tb.z, tb.w, tc.x), o, d, PT_TMIN, PT_TMAX, t, u, v);
             uint32_t pair = __float_as_uint(tc.y), prim = __float_as_uint(tc.z);
-            if (ALPHA && candidate && (__float_as_uint(tc.w) & kTriNonOpaque))
+            if (ALPHA && candidate && nonOpaque)
             {
                 // the any-hit stage; the nearest ignored candidate of a closest ray (the decal) is the IO's business: it keeps
                 // (distance, triangle) in the slot's record in memory, not in registers of every lane.  One behind the hit
                 // found so far cannot matter.
-                const float alpha = hitAlpha(sc, (uint32_t)~leafRef, u, v);
+                const float alpha = hitAlpha(sc, aa, ab, __float_as_uint(tc.w), u, v);
                 candidate = ANY_HIT ? !(alpha < 1.0f) : !(alpha < 0.5f);
                 if (!ANY_HIT && !candidate && t <= best.t)
-                    io.ignored(t, u, v, (uint32_t)~leafRef, sc);
+                    io.ignored(t, u, v, leafSlot, sc);
                 if (candidate && (!ANY_HIT || IO::kNeedsPrim))
                 {
                     // the ids are read again behind the alpha fetch instead of being held in registers across it
-                    const float4 again = sc.tris[fetchAgainAfter((uint32_t)~leafRef, alpha)].c;
+                    const float4 again = sc.tris[fetchAgainAfter(leafSlot, alpha)].c;
                     pair = __float_as_uint(again.y);
                     prim = __float_as_uint(again.z);
                 }
@@ -1452,7 +1478,7 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
                 if (ANY_HIT)
                 {
                     best.pair = IO::kNeedsPrim ? pair : 0u; // a shadow query only asks whether
-                    best.slot = (uint32_t)~leafRef;
+                    best.slot = leafSlot;
                     ref = kRefDone;
                 }
                 else if (t < best.t || (t == best.t && (pair < best.pair || (pair == best.pair && prim < __float_as_uint(sc.tris[io.bestSlot(item)].c.z)))))
@@ -1463,7 +1489,7 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
                     // measured -0.8 % / +0.2 % / +0.3 % on chess_like / street_like / atrium_like: the stores are not what it waits for.)
                     best.t = t;
                     best.pair = pair;
-                    io.improve(item, t, u, v, (uint32_t)~leafRef);
+                    io.improve(item, t, u, v, leafSlot);
                 }
             }
         }

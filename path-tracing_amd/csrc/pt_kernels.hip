@@ -2226,8 +2226,8 @@ int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *s)
             tri += geo.IndexLength / 3;
         }
     }
-    if (tri >= 0x7fffffffull)
-        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "scene has %llu triangles; limit is 2^31-1", (unsigned long long)tri);
+    if (tri > kMaxTriangles)
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "scene has %llu triangles; limit is 2^30-1", (unsigned long long)tri);
     pairFirst.push_back(static_cast<uint32_t>(tri));
     {
         uint32_t typesSeen = 0; // bit per material type, unknown types share bit 3
@@ -2519,12 +2519,18 @@ int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *s)
         if (anyNonOpaque)
         {
             size_t quads = 0;
+            bool tooLarge = false; // the extent of an alpha texture rides in 15 + 15 bits of the triangle record
             auto mark = [&](uint32_t colorIdx) {
                 if (colorIdx < PTX_SCENE_TEXTURE_OFFSET || colorIdx - PTX_SCENE_TEXTURE_OFFSET >= r->textureCount)
                     return;
                 const uint32_t ti = colorIdx - PTX_SCENE_TEXTURE_OFFSET;
                 if (alphaTexOf[ti] != kNoAlphaTex)
                     return;
+                if (renderTable[ti].width > 32768u || renderTable[ti].height > 32768u)
+                {
+                    tooLarge = true;
+                    return;
+                }
                 alphaTexOf[ti] = (uint32_t)alphaTex.size();
                 alphaTex.push_back({ renderTable[ti].width, renderTable[ti].height, (uint32_t)quads, 0u });
                 quads += (size_t)renderTable[ti].width * renderTable[ti].height;
@@ -2532,7 +2538,9 @@ int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *s)
             for (uint32_t i = 0; i < s->metallicRoughnessMaterialCount; i++) mark(s->metallicRoughnessMaterials[i].ColorIdx);
             for (uint32_t i = 0; i < s->specularGlossinessMaterialCount; i++) mark(s->specularGlossinessMaterials[i].ColorIdx);
             for (uint32_t i = 0; i < s->phongMaterialCount; i++) mark(s->phongMaterials[i].ColorIdx);
-            if (quads > 0xffffffffull)
+            if (tooLarge)
+                return fail(r, PTX_ERROR_INVALID_ARGUMENT, "a colour texture of a non-opaque geometry is larger than 32768 texels across");
+            if (quads >= 0xffffffffull)
                 return fail(r, PTX_ERROR_INVALID_ARGUMENT, "alpha footprints exceed 2^32 texels");
             HIP_TRY(r, r->alphaQuads.alloc(quads));
             for (uint32_t ti = 0; ti < r->textureCount; ti++)
@@ -2735,7 +2743,7 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
     if (r->anyNonOpaque && nv) // the any-hit records of the slots k_emit has just written
     {
         BUILD_TRY(r->alphaTris.alloc(n));
-        k_alpha_tris<<<vblocks, 256, 0, r->stream>>>(nv, r->tris.p, r->shadeTris.p, makeSceneView(r), r->alphaTexOf.p, r->alphaTris.p);
+        k_alpha_tris<<<vblocks, 256, 0, r->stream>>>(nv, r->tris.p, r->shadeTris.p, makeSceneView(r), r->alphaTexOf.p, r->alphaTex.p, r->alphaTris.p);
     }
     uint32_t revived = 0;
     if (refit)
@@ -2867,7 +2875,7 @@ static TraceScene makeTraceScene(const PtxRenderer *r)
     const PtxRenderer *s = sceneOf(r);
     TraceScene sc;
     sc.nodes = s->nodes.p; sc.tris = s->tris.p; sc.triCount = s->treeTris;
-    sc.alphaTris = s->alphaTris.p; sc.alphaTex = s->alphaTex.p; sc.alphaQuads = s->alphaQuads.p;
+    sc.alphaTris = s->alphaTris.p; sc.alphaQuads = s->alphaQuads.p;
     return sc;
 }
 

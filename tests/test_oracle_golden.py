@@ -49,7 +49,7 @@ def test_oracle_raygen_loop_against_reference_main(orc):
     import os
 
     for mode in ("fixed", "libm"):
-        with open(os.path.join(util.GOLDEN_DIR, f"golden_stage_{mode}.json")) as f:
+        with util.open_golden(f"golden_stage_{mode}.json") as f:
             c = json.load(f)["raygenMain"]
         inp = np.array(c["in"], np.uint32).reshape(-1, c["nin"])
         exp = np.array(c["out"], np.uint32).reshape(-1, c["nout"])
@@ -140,7 +140,7 @@ def test_oracle_closest_hit_against_reference_main(orc, pkg):
     import os
 
     for mode in ("fixed", "libm"):
-        with open(os.path.join(util.GOLDEN_DIR, f"golden_stage_{mode}.json")) as f:
+        with util.open_golden(f"golden_stage_{mode}.json") as f:
             c = json.load(f)["closestHitMain"]
         inp = np.array(c["in"], np.uint32).reshape(-1, c["nin"])
         exp = np.array(c["out"], np.uint32).reshape(-1, c["nout"])
@@ -183,7 +183,7 @@ def test_oracle_closest_hit_with_transforms_within_stated_bound(orc, pkg):
     import json
     import os
 
-    with open(os.path.join(util.GOLDEN_DIR, "golden_stage_fixed.json")) as f:
+    with util.open_golden("golden_stage_fixed.json") as f:
         c = json.load(f)["closestHitMainTransformed"]
     inp = np.array(c["in"], np.uint32).reshape(-1, c["nin"])
     exp = np.array(c["out"], np.uint32).reshape(-1, c["nout"])
@@ -220,7 +220,7 @@ def test_oracle_any_hit_against_reference_mains(orc, pkg):
     import json
     import os
 
-    with open(os.path.join(util.GOLDEN_DIR, "golden_stage_fixed.json")) as f:
+    with util.open_golden("golden_stage_fixed.json") as f:
         c = json.load(f)["anyHitMain"]
     inp = np.array(c["in"], np.uint32).reshape(-1, c["nin"])
     exp = np.array(c["out"], np.uint32).reshape(-1, c["nout"])
@@ -253,7 +253,7 @@ def test_oracle_miss_against_reference_main(orc, pkg):
     class Tex(C.Structure):
         _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("format", C.c_uint32), ("levels", C.c_uint32), ("data", C.c_void_p)]
 
-    with open(os.path.join(util.GOLDEN_DIR, "golden_stage_fixed.json")) as f:
+    with util.open_golden("golden_stage_fixed.json") as f:
         c = json.load(f)["missMain"]
     inp = np.array(c["in"], np.uint32).reshape(-1, c["nin"])
     exp = np.array(c["out"], np.uint32).reshape(-1, c["nout"])

@@ -7,6 +7,13 @@ import numpy as np
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
+
+def open_golden(name):
+    """A golden-vector file (text mode): they are committed gzip-compressed (decimal uint32 bit patterns compress 4x)."""
+    import gzip
+
+    return gzip.open(os.path.join(GOLDEN_DIR, name + ".gz"), "rt")
+
 GEOMETRY_DT = np.dtype([("VertexOffset", "u4"), ("VertexLength", "u4"), ("IndexOffset", "u4"), ("IndexLength", "u4"),
                         ("IsOpaque", "u1"), ("IsAnimated", "u1"), ("pad", "u1", 2)])
 MESH_DT = np.dtype([("GeometryIndex", "u4"), ("MaterialId", "u4"), ("TransformIndex", "u4")])
@@ -49,7 +56,7 @@ def pair_first(desc):
 
 
 def load_golden(mode):
-    with open(os.path.join(GOLDEN_DIR, f"golden_{mode}.json")) as f:
+    with open_golden(f"golden_{mode}.json") as f:
         g = json.load(f)
     out = {}
     for name, c in g.items():

@@ -75,6 +75,14 @@ def extract_struct(path, name):
     return m.group(0)
 
 
+def write_gz(dst, data):
+    """gzip without a timestamp or file name in the header: the same vectors give the same bytes."""
+    import gzip
+
+    with open(dst, "wb") as raw, gzip.GzipFile(filename="", mode="wb", fileobj=raw, mtime=0) as f:
+        f.write(data)
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit("reference not present; golden vectors can only be regenerated in the build container")
@@ -173,12 +181,12 @@ def main():
             cmd = ["g++", "-std=c++20", "-O1", "-ffp-contract=off", "-fno-fast-math", "-w"] + flag + [cpp, "-o", exe, "-lm"]
             subprocess.check_call(cmd)
             data = subprocess.check_output([exe])
-            dst = os.path.join(OUT, "golden_%s.json" % mode)
-            open(dst, "wb").write(data)
+            dst = os.path.join(OUT, "golden_%s.json.gz" % mode)
+            write_gz(dst, data)
             print("wrote", os.path.relpath(dst), len(data), "bytes")
             data = subprocess.check_output([exe, "stage"])  # the stage-level cases go into their own file
-            dst = os.path.join(OUT, "golden_stage_%s.json" % mode)
-            open(dst, "wb").write(data)
+            dst = os.path.join(OUT, "golden_stage_%s.json.gz" % mode)
+            write_gz(dst, data)
             print("wrote", os.path.relpath(dst), len(data), "bytes")
 
 
