@@ -270,9 +270,6 @@ PT_DEV void blockAddCounter(uint32_t *__restrict__ counter, uint32_t v)
 #ifndef PT_SHADE_ITEMS
 #define PT_SHADE_ITEMS 4
 #endif
-#ifndef PT_SHADE_SORT
-#define PT_SHADE_SORT 1 // material-sorted shade queue compiled in (see shadeBody); used when the scene mixes material types
-#endif
 constexpr uint32_t kShadeItems = PT_SHADE_ITEMS; // queue entries per thread per block-wide append in k_shade
 constexpr uint32_t kDeadPair = 0xfffffffeu; // hitPair of a slot outside the image (ragged edge tiles)
 
@@ -362,20 +359,20 @@ struct ClosestIO
     }
 };
 
-// The traversal kernels are latency-bound: throughput follows the number of resident waves.  The opaque variants fit
-// the 64-VGPR budget of 8 waves per SIMD without spilling when asked to (74 -> 63 registers: closest 6.2 -> 4.6 ms per
-// chess_like step); the ALPHA closest variant carries the sampler and the decal and stops at 6 waves.
+// Occupancy of the traversal kernels (waves per SIMD; overridable for A/B builds through tools/kernel_resources.py -- -D...).
+// The opaque variants run at the hardware's 8: 58 / 56 VGPRs without a spill.  The ALPHA variants hold the any-hit record of a
+// non-opaque triangle beside the triangle (70 / 68 VGPRs) and run at 7; at 8 the shadow variant fits (63, no vector spill)
+// and the closest variant spills 11 registers -- measured: atrium_like 732 / 726 -> 727 / 720 (shadow at 8) and 711 / 713 (both).
 #ifndef PT_TRACE_WAVES
 #define PT_TRACE_WAVES 8
 #endif
 #define PT_FULL_OCCUPANCY __attribute__((amdgpu_waves_per_eu(PT_TRACE_WAVES, PT_TRACE_WAVES)))
-// (round 2: forcing 7 / 8 waves on the ALPHA variants costs 18 / 31 spilled registers and scratch: atrium_like 460 -> 414 / 389 Msamples/s)
 #ifndef PT_ALPHA_CLOSEST_WAVES
-#define PT_ALPHA_CLOSEST_WAVES 7 // the decal lives in memory (ClosestIO::ignored): 78 -> 72 registers
+#define PT_ALPHA_CLOSEST_WAVES 7
 #endif
 #define PT_ALPHA_CLOSEST_ATTR __attribute__((amdgpu_waves_per_eu(PT_ALPHA_CLOSEST_WAVES, PT_ALPHA_CLOSEST_WAVES)))
 #ifndef PT_ALPHA_SHADOW_WAVES
-#define PT_ALPHA_SHADOW_WAVES 7 // 8 waves would spill 11 registers with the two-pass triangle test
+#define PT_ALPHA_SHADOW_WAVES 7
 #endif
 #define PT_ALPHA_SHADOW_ATTR __attribute__((amdgpu_waves_per_eu(PT_ALPHA_SHADOW_WAVES, PT_ALPHA_SHADOW_WAVES)))
 template <bool ALPHA>
@@ -453,8 +450,8 @@ template <bool TEX>
 PT_DEV void shadeBody(const LaunchParams &p, const SceneView &sv, const Wavefront &wf, int qin, const BounceCtl &ctl);
 template <bool TEX>
 __global__ void __launch_bounds__(kBlock) k_shade(LaunchParams p, SceneView sv, Wavefront wf, int qin, BounceCtl ctl);
-// 190 VGPRs once the new-sample code is out of the kernel; held at 168 = three waves per SIMD for 15 spilled dwords
-// (k_shade 3.42 -> 3.18 ms per chess_like step; four waves would spill 90 and lose)
+// 178 VGPRs by itself (195 with the SLP vectoriser); held at 168 = three waves per SIMD, which costs nothing now (15 spilled
+// dwords before round 3).  Four waves (128 VGPRs, 49 spilled) lose: chess_like 2,290 / 2,324 -> 2,164 / 2,185 Msamples/s.
 #ifndef PT_SHADE_ATTR
 #define PT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
 #endif
@@ -463,8 +460,8 @@ __global__ void __launch_bounds__(kBlock) PT_SHADE_ATTR k_shade<false>(LaunchPar
 {
     shadeBody<false>(p, sv, wf, qin, ctl);
 }
-// the sampler pushes the TEX variant a few registers past 256, i.e. to ONE wave per SIMD: hold it at two (4 registers
-// spill; texture_test k_shade 8.3 -> 5.5 ms per step, atrium_like 17.1 -> 11.6 ms)
+// the textured variant: 221 VGPRs = two waves per SIMD (round 1: a few registers past 256, i.e. ONE wave, held at two for four
+// spilled registers).  Three waves (168 VGPRs, 54 spilled, 164 B scratch) measure flat: atrium_like 725 / 730 -> 723 / 724.
 #ifndef PT_SHADE_TEX_ATTR
 #define PT_SHADE_TEX_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
@@ -488,7 +485,6 @@ PT_DEV void shadeBody(const LaunchParams &p, const SceneView &sv, const Wavefron
     // queues of a 16.6 M-slot launch would keep the counter line busy for 1.4 ms of a 2 ms kernel.
     for (uint32_t base = blockIdx.x * blockDim.x * kShadeItems; base < count; base += gridDim.x * blockDim.x * kShadeItems)
     {
-#if PT_SHADE_SORT
       // Material-sorted shade queue: the block's kBlock x kShadeItems entries are put in the order
       //   sky (miss.rmiss) | MetallicRoughness | SpecularGlossiness | Phong | unknown type | dead slot
       // (ShaderTypes.incl:143-145, the dispatch of material.glsl:144-166) before they are shaded, so that a wave runs one
@@ -562,7 +558,6 @@ PT_DEV void shadeBody(const LaunchParams &p, const SceneView &sv, const Wavefron
             }
         __syncthreads();
       }
-#endif
       uint32_t slots[kShadeItems];
       uint32_t pushBits = 0; // bit 2k: entry k joins the shadow queue, bit 2k+1: the next queue
 #pragma nounroll
@@ -573,12 +568,8 @@ PT_DEV void shadeBody(const LaunchParams &p, const SceneView &sv, const Wavefron
         uint32_t slot = 0, pair = kDeadPair;
         if (i < count)
         {
-#if PT_SHADE_SORT
             // entries past the block's share of the queue were sorted last, as dead slots
             slot = ctl.sortShade ? s_sorted[item * blockDim.x + threadIdx.x] : wf.queue[qin][i];
-#else
-            slot = wf.queue[qin][i];
-#endif
             pair = wf.hitPair[slot];
         }
         if (pair != kDeadPair)
