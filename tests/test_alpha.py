@@ -135,3 +135,52 @@ def test_alpha_scene_tail_multi_sample_and_lens(pkg, orc, monkeypatch):
         imgs.append(r.readback())
         r.close()
     assert (imgs[0].view(np.uint32) == imgs[1].view(np.uint32)).all()
+
+
+@pytest.mark.gpu
+def test_alpha_textures_of_odd_shapes_match_oracle(pkg, orc):
+    """The any-hit record carries the alpha texture's extent in 15 + 15 bits beside the triangle and reads 2 x 2 footprints
+    ("quads") with repeat addressing: the same scene with its three colour textures replaced by a 37 x 21, a 1 x 1 (the
+    constant shortcut), and a 300 x 2 image of random alphas around both thresholds -- traversal decisions (closest and
+    shadow queries, ids and t, u, v bit for bit against brute force) and a rendered frame against the oracle."""
+    import torch  # noqa: F401
+
+    from test_textures import SRGB, _desc_with
+
+    scene = pkg.Scene("alpha_test")
+    rng = np.random.default_rng(77)
+    shapes = [(37, 21), (1, 1), (300, 2)]
+    texels = []
+    for w, h in shapes:
+        px = rng.integers(0, 256, (h, w, 4)).astype(np.uint8)
+        px[..., 3] = rng.choice([0, 90, 127, 128, 200, 254, 255], (h, w))  # 127 / 128 straddle 0.5; 254 / 255 straddle 1
+        texels.append(px.reshape(-1))
+    texels[1][3] = 255
+    d, keep = _desc_with(pkg, scene, [(w, h, SRGB, 1, t) for (w, h), t in zip(shapes, texels)], budget=2**64 - 1)
+    r = pkg.Renderer()
+    r.upload(d)
+    osc = orc.OracleScene(d, build_bvh=False)
+    rays = util.random_rays(rng, 30000, -4.0, 4.0)
+    rays[:, 1] = np.abs(rays[:, 1])
+    hits, ids = r.trace_rays(rays, any_hit=False)
+    ref = osc.trace_closest(rays, brute_force=True)
+    first = util.pair_first(d)
+    miss = ids[:, 0] == 0xFFFFFFFF
+    gid = np.where(miss, 0xFFFFFFFF, first[np.minimum(ids[:, 0], len(first) - 2)] + ids[:, 1]).astype(np.uint32)
+    assert (gid == ref["tri"]).all(), f"{int((gid != ref['tri']).sum())} rays hit a different triangle"
+    h = ~miss
+    for k, f in enumerate(("t", "u", "v")):
+        assert (hits[h, k].view(np.uint32) == ref[f][h].view(np.uint32)).all(), f
+    occ_hits, _ = r.trace_rays(rays, any_hit=True)
+    assert ((occ_hits[:, 3] != 0) == (osc.trace_any(rays, brute_force=True) != 0)).all()
+    W, H = 128, 72
+    u = scene.uniform(W, H, bounces=5)
+    r.resize(W, H)
+    r.render_frames(u, scene.lights, 0, 2)
+    img = r.readback()
+    osc2 = orc.OracleScene(d)
+    acc = np.zeros((H, W, 4), np.float32)
+    for f in range(2):
+        osc2.render(scene.uniform(W, H, bounces=5, total_samples=f), scene.lights, W, H, accum=acc)
+    assert (img.view(np.uint32) == acc.view(np.uint32)).all()
+    r.close()

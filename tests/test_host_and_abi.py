@@ -159,3 +159,17 @@ def test_shard_helpers(pkg):
     assert (total == 1).all()  # every pixel is owned exactly once
     hip = pkg.load_hip()
     assert sorted(sum((pkg.owned_tiles(W, H, r, world) for r in range(world)), [])) == list(range(7 * 4))
+
+
+def test_instrumentation_patch_applies_to_the_current_kernels(pkg):
+    """tools/experiments/visit_stats.patch (the instrumentation tools/visit_histogram.py builds with) is kept out of the kernels
+    but must keep applying to them."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    patch = os.path.join(pkg.REPO_DIR, "tools", "experiments", "visit_stats.patch")
+    with tempfile.TemporaryDirectory() as tmp:
+        shutil.copytree(os.path.join(pkg.PKG_DIR, "csrc"), os.path.join(tmp, "path-tracing_amd", "csrc"))
+        p = subprocess.run(["patch", "-p1", "-s", "--dry-run", "-i", patch], cwd=tmp, capture_output=True, text=True)
+        assert p.returncode == 0, p.stdout + p.stderr

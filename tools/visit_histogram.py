@@ -1,16 +1,29 @@
 #!/usr/bin/env python3
 """Node visits per ray of the two queue traversal kernels over whole frames (GPU, instrumented build).
 
-Usage: tools/visit_histogram.py [scene ...]   (builds tools/scratch/libptx_visits.so with -DPT_VISIT_STATS on first use)
+Usage: tools/visit_histogram.py [scene ...]   (builds tools/scratch/libptx_visits.so from a scratch copy of the sources with tools/experiments/visit_stats.patch applied)
 One frame of 1920x1080, 8 spp, depth 8 per scene; prints rays, mean / max visits and the histogram in bins of 16 visits,
 for k_trace_closest and k_trace_shadow, plus the depth-1 frame (primary rays and their shadow queries only).
 """
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "tools", "scratch", "libptx_visits.so")
-if not os.path.exists(LIB):
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), "k_trace", "-o", LIB, "--", "-DPT_VISIT_STATS"])
+PATCH = os.path.join(ROOT, "tools", "experiments", "visit_stats.patch")
+SRC = [os.path.join(ROOT, "path-tracing_amd", "csrc", f) for f in ("pt_kernels.hip", "pt_bvh.hpp", "pt_device.hpp", "pt_post.hpp")]
+if not os.path.exists(LIB) or any(os.path.getmtime(f) > os.path.getmtime(LIB) for f in SRC + [PATCH]):
+    # the instrumentation lives in a patch, not in the kernels: apply it to a scratch copy of the sources and build that
+    import shutil
+    import tempfile
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as _graft
+    _pkg = _graft.load_package()
+    with tempfile.TemporaryDirectory(prefix="ptvisits_") as tmp:
+        shutil.copytree(os.path.join(ROOT, "path-tracing_amd", "csrc"), os.path.join(tmp, "path-tracing_amd", "csrc"))
+        shutil.copytree(os.path.join(ROOT, "include"), os.path.join(tmp, "include"))
+        subprocess.check_call(["patch", "-p1", "-s", "-i", PATCH], cwd=tmp)
+        os.makedirs(os.path.dirname(LIB), exist_ok=True)
+        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + _pkg.HIPCC_FLAGS + ["-DPT_VISIT_STATS", "-o", LIB,
+                               os.path.join(tmp, "path-tracing_amd", "csrc", "pt_kernels.hip")])
 os.environ["PTX_HIP_LIB"] = LIB
 sys.path.insert(0, ROOT)
 import numpy as np
