@@ -919,20 +919,75 @@ PT_DEV uint32_t wrapRepeat(float x0, uint32_t n) // floor(x) mod n, in float: CP
     return i >= n ? n - 1 : i;
 }
 
-PT_DEV f4 sampleLevel(const TextureView &tv, const DevTexture &t, uint32_t level, float u, float v)
+// One level of a texture as the bilinear lookup needs it, computed once per textureGrad call (the anisotropic filter runs up to
+// sixteen taps on the same two levels).  iw / ih: the exact reciprocal of an extent that is a power of two, 0 otherwise.
+struct LevelView
 {
-    const uint32_t w = levelDim(t.width, level), h = levelDim(t.height, level);
-    if (w == 1 && h == 1) // exact for 1x1 (hardware weights are fixed point and sum to 1)
-        return fetchTexel(tv, t, level, 0, 0);
+    uint32_t w, h, offset;
+    float fw, fh, iw, ih;
+};
+PT_DEV float exactReciprocalOfPow2(uint32_t n, float fn) { return (n & (n - 1u)) == 0u ? __uint_as_float(0x7f000000u - __float_as_uint(fn)) : 0.0f; }
+PT_DEV LevelView levelView(const DevTexture &t, uint32_t level)
+{
+    LevelView lv;
+    lv.w = levelDim(t.width, level);
+    lv.h = levelDim(t.height, level);
+    lv.offset = t.levelOffset[level];
+    lv.fw = (float)lv.w;
+    lv.fh = (float)lv.h;
+    lv.iw = exactReciprocalOfPow2(lv.w, lv.fw);
+    lv.ih = exactReciprocalOfPow2(lv.h, lv.fh);
+    return lv;
+}
+
+// wrapRepeat(x0, n) for an integer-valued x0, bit for bit, without its IEEE division where that can be shown:
+// for |x0| < 2^22 every step of wrapRepeat is exact integer arithmetic in float (the quotient's rounding error, below
+// |x0| / n * 2^-24 < 1 / (2 n), cannot carry floor() across an integer, and x0 - k * n is exact below 2^24), so its result is the
+// mathematical floor(x0) mod n and its two guards never fire.  With n = 2^k the quotient x0 * 2^-k is exact as well: one multiply
+// for the ten instructions of a correctly rounded division, four times per bilinear lookup, two lookups per trilinear tap, up
+// to sixteen taps per textureGrad.
+constexpr float kExactWrapLimit = 4194304.0f; // 2^22
+PT_DEV uint32_t wrapRepeatInt(float x0, uint32_t n, float fn, float inv)
+{
+    if (inv != 0.0f && abs_(x0) < kExactWrapLimit)
+        return (uint32_t)(x0 - __builtin_floorf(x0 * inv) * fn);
+    return wrapRepeat(x0, n);
+}
+// wrapRepeat(x0 + 1, n) from i0 = wrapRepeat(x0, n): inside the exact range it is the next index
+PT_DEV uint32_t wrapRepeatNext(float x0, uint32_t i0, uint32_t n)
+{
+    if (abs_(x0) < kExactWrapLimit)
+        return i0 + 1u == n ? 0u : i0 + 1u;
+    return wrapRepeat(x0 + 1.0f, n);
+}
+
+PT_DEV f4 fetchLevelTexel(const TextureView &tv, const LevelView &lv, uint32_t x, uint32_t y)
+{
+    // the pool holds fewer than 2^32 texels (ptx_scene_upload) and an extent is at most 2^15: 32-bit index arithmetic
+    const float4 v = tv.texelsF[lv.offset + y * lv.w + x];
+    f4 r;
+    r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+    return r;
+}
+
+PT_DEV f4 sampleLevel(const TextureView &tv, const LevelView &lv, float u, float v)
+{
+    if (lv.w == 1 && lv.h == 1) // exact for 1x1 (hardware weights are fixed point and sum to 1)
+        return fetchLevelTexel(tv, lv, 0, 0);
     if (!(abs_(u) < 1e9f)) u = 0.0f;
     if (!(abs_(v) < 1e9f)) v = 0.0f;
-    const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    const float x = u * lv.fw - 0.5f, y = v * lv.fh - 0.5f;
     const float x0 = __builtin_floorf(x), y0 = __builtin_floorf(y);
     const float ax = x - x0, ay = y - y0;
-    const uint32_t ix0 = wrapRepeat(x0, w), ix1 = wrapRepeat(x0 + 1.0f, w), iy0 = wrapRepeat(y0, h), iy1 = wrapRepeat(y0 + 1.0f, h);
-    const f4 top = lerp4(fetchTexel(tv, t, level, ix0, iy0), fetchTexel(tv, t, level, ix1, iy0), ax);
-    const f4 bot = lerp4(fetchTexel(tv, t, level, ix0, iy1), fetchTexel(tv, t, level, ix1, iy1), ax);
+    const uint32_t ix0 = wrapRepeatInt(x0, lv.w, lv.fw, lv.iw), iy0 = wrapRepeatInt(y0, lv.h, lv.fh, lv.ih);
+    const uint32_t ix1 = wrapRepeatNext(x0, ix0, lv.w), iy1 = wrapRepeatNext(y0, iy0, lv.h);
+    const f4 top = lerp4(fetchLevelTexel(tv, lv, ix0, iy0), fetchLevelTexel(tv, lv, ix1, iy0), ax);
+    const f4 bot = lerp4(fetchLevelTexel(tv, lv, ix0, iy1), fetchLevelTexel(tv, lv, ix1, iy1), ax);
     return lerp4(top, bot, ay);
+}
+PT_DEV f4 sampleLevel(const TextureView &tv, const DevTexture &t, uint32_t level, float u, float v)
+{
+    return sampleLevel(tv, levelView(t, level), u, v);
 }
 
 // textureGrad with the reference's sampler (trilinear, anisotropy at the device maximum, Renderer.cpp:103-110), by the
@@ -941,17 +996,37 @@ PT_DEV f4 sampleLevel(const TextureView &tv, const DevTexture &t, uint32_t level
 // isotropic lookup.
 constexpr float kMaxAnisotropy = 16.0f;
 
-PT_DEV f4 trilinearSample(const TextureView &tv, const DevTexture &t, float lod, float u, float v)
+// The two levels of a trilinear lookup and the blend between them: the same for every tap of one textureGrad.
+struct TrilinearView
+{
+    LevelView l0, l1;
+    float f;
+    bool single; // f == 0 or no second level: the lookup is the first level's
+};
+PT_DEV TrilinearView trilinearView(const DevTexture &t, float lod)
 {
     const float q = (float)(t.levels - 1);
     if (!(lod >= 0.0f)) lod = 0.0f;
     if (lod > q) lod = q;
-    const float d0 = __builtin_floorf(lod), f = lod - d0;
+    const float d0 = __builtin_floorf(lod);
     const uint32_t l0 = (uint32_t)d0, l1 = l0 + 1 < t.levels ? l0 + 1 : t.levels - 1;
-    const f4 c0 = sampleLevel(tv, t, l0, u, v);
-    if (f == 0.0f || l1 == l0)
+    TrilinearView tv3;
+    tv3.f = lod - d0;
+    tv3.single = tv3.f == 0.0f || l1 == l0;
+    tv3.l0 = levelView(t, l0);
+    tv3.l1 = levelView(t, l1);
+    return tv3;
+}
+PT_DEV f4 trilinearSample(const TextureView &tv, const TrilinearView &tl, float u, float v)
+{
+    const f4 c0 = sampleLevel(tv, tl.l0, u, v);
+    if (tl.single)
         return c0;
-    return lerp4(c0, sampleLevel(tv, t, l1, u, v), f);
+    return lerp4(c0, sampleLevel(tv, tl.l1, u, v), tl.f);
+}
+PT_DEV f4 trilinearSample(const TextureView &tv, const DevTexture &t, float lod, float u, float v)
+{
+    return trilinearSample(tv, trilinearView(t, lod), u, v);
 }
 
 PT_DEV f4 textureGradSample(const TextureView &tv, const DevTexture &t, float u, float v, float dudx, float dvdx, float dudy, float dvdy)
@@ -969,8 +1044,9 @@ PT_DEV f4 textureGradSample(const TextureView &tv, const DevTexture &t, float u,
     const float n = __builtin_ceilf(eta);
     const float rho = rmax / eta;
     const float lod = rho > 0.0f ? (float)log2_((double)rho) : 0.0f;
+    const TrilinearView tl = trilinearView(t, lod);
     if (n <= 1.0f || lod >= (float)(t.levels - 1)) // every tap would read the 1x1 top level: one tap
-        return trilinearSample(tv, t, lod, u, v);
+        return trilinearSample(tv, tl, u, v);
     const float du = rx >= ry ? dudx : dudy, dv = rx >= ry ? dvdx : dvdy;
     f4 sum;
     sum.x = sum.y = sum.z = sum.w = 0.0f;
@@ -978,7 +1054,7 @@ PT_DEV f4 textureGradSample(const TextureView &tv, const DevTexture &t, float u,
     for (int i = 1; i <= taps; i++)
     {
         const float w = (float)i / (n + 1.0f) - 0.5f;
-        const f4 c = trilinearSample(tv, t, lod, u + du * w, v + dv * w);
+        const f4 c = trilinearSample(tv, tl, u + du * w, v + dv * w);
         sum.x += c.x; sum.y += c.y; sum.z += c.z; sum.w += c.w;
     }
     sum.x /= n; sum.y /= n; sum.z /= n; sum.w /= n;

@@ -429,3 +429,46 @@ def test_anisotropic_texture_grad_against_float64_formulas(pkg, orc):
     assert ok.sum() > 0.97 * n and (N[ok] >= 2).sum() > 0.9 * ok.sum() and (N[ok] == 16).sum() > 300
     err = np.abs(got - want) / np.maximum(1.0, np.abs(want))
     assert err[ok].max() < 5e-5, float(err[ok].max())
+
+
+def test_exact_wrap_fast_paths_equal_the_division_formula():
+    """The HIP sampler takes repeat addressing without its IEEE division where that is provably the same number
+    (pt_device.hpp, wrapRepeatInt / wrapRepeatNext): for an integer-valued x0 with |x0| < 2^22 the float formula
+    x0 - floor(x0 / n) * n is exact integer arithmetic -- the mathematical floor(x0) mod n -- so (a) for n = 2^k the quotient
+    may be taken as x0 * 2^-k, and (b) the index of x0 + 1 is the next index.  Emulated here in float32 (every numpy float32
+    operation rounds like the device's), against the formula of the oracle, for every extent up to 69, the powers of two and their
+    neighbours up to 32768, 200 random extents; outside the range both fall back to the formula itself."""
+    f = np.float32
+
+    def wrap_repeat(x0, n):
+        fn = f(n)
+        q = (x0 / fn).astype(np.float32)
+        m = (x0 - (np.floor(q) * fn).astype(np.float32)).astype(np.float32)
+        m = np.where(m >= 0, m, f(0))
+        i = m.astype(np.uint32)
+        return np.where(i >= n, n - 1, i)
+
+    def wrap_int(x0, n):
+        fn = f(n)
+        if n & (n - 1):
+            return wrap_repeat(x0, n)
+        inv = np.uint32(0x7F000000 - int(fn.view(np.uint32))).view(np.float32)
+        assert inv * fn == 1.0
+        fast = (x0 - (np.floor((x0 * inv).astype(np.float32)) * fn).astype(np.float32)).astype(np.float32).astype(np.uint32)
+        return np.where(np.abs(x0) < f(4194304.0), fast, wrap_repeat(x0, n))
+
+    def wrap_next(x0, i0, n):
+        nxt = np.where(i0 + 1 == n, 0, i0 + 1).astype(np.uint32)
+        return np.where(np.abs(x0) < f(4194304.0), nxt, wrap_repeat((x0 + f(1)).astype(np.float32), n))
+
+    rng = np.random.default_rng(0)
+    extents = list(range(1, 70)) + [127, 128, 129, 255, 256, 257, 300, 511, 512, 513, 1000, 1023, 1024, 1025, 2047, 2048, 4095, 4096, 4097,
+                                    8191, 8192, 16384, 16385, 32767, 32768] + [int(x) for x in rng.integers(2, 32768, 200)]
+    for n in extents:
+        xs = np.concatenate([rng.integers(-4194303, 4194304, 50000), np.arange(-3 * n - 2, 3 * n + 3), rng.integers(-2**31, 2**31, 5000),
+                             [-4194304, 4194303, 4194304, -4194305, 8388608, -8388608, 2**24, 2**30]]).astype(np.float32)
+        a, b = wrap_repeat(xs, n), wrap_int(xs, n)
+        assert (a == b).all(), n
+        assert (wrap_repeat((xs + f(1)).astype(np.float32), n) == wrap_next(xs, b, n)).all(), n
+        inside = np.abs(xs) < 4194304
+        assert (a[inside] == np.mod(xs[inside].astype(np.int64), n)).all(), n
