@@ -122,7 +122,7 @@ __global__ void k_tri_setup(uint32_t n, uint32_t pairCount, const uint32_t *__re
     Tri t;
     t.a = make_float4(w[0].x, w[0].y, w[0].z, e1.x);
     t.b = make_float4(e1.y, e1.z, e2.x, e2.y);
-    t.c = make_float4(e2.z, __uint_as_float(p), __uint_as_float(prim), __uint_as_float(pr->nonOpaque ? kTriNonOpaque : 0u));
+    t.c = make_float4(e2.z, __uint_as_float(p), __uint_as_float(prim), __uint_as_float((pr->flags & kPairNonOpaque) ? kTriNonOpaque : 0u));
     triTmp[g] = t;
 
     // bounds from the same p0, p0+e1, p0+e2 the intersection test sees, padded so the slab test does not reject a

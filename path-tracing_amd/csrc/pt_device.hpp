@@ -1136,8 +1136,10 @@ struct DevPair
     float M[12];
     float Rinv[9]; // columns c0, c1, c2
     uint32_t vertexOffset, indexOffset, materialId;
-    uint32_t nonOpaque; // geometry without VK_GEOMETRY_OPAQUE_BIT: the any-hit stages run (AccelerationStructure.cpp:94-97)
+    uint32_t flags; // kPairNonOpaque: geometry without VK_GEOMETRY_OPAQUE_BIT, the any-hit stages run (AccelerationStructure.cpp:94-97);
+                    // kPairTextured: its material samples at least one scene texture (k_shade's sort groups those hits)
 };
+constexpr uint32_t kPairNonOpaque = 1u, kPairTextured = 2u;
 
 // What anyhit.rahit leaves in the payload: the nearest ignored (alpha < 0.5) candidate.  The any-hit
 // invocation order is the driver's; nearest-with-id-tie-break is the order-independent reading of

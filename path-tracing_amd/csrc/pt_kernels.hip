@@ -486,18 +486,21 @@ PT_DEV void shadeBody(const LaunchParams &p, const SceneView &sv, const Wavefron
     for (uint32_t base = blockIdx.x * blockDim.x * kShadeItems; base < count; base += gridDim.x * blockDim.x * kShadeItems)
     {
       // Material-sorted shade queue: the block's kBlock x kShadeItems entries are put in the order
-      //   sky (miss.rmiss) | MetallicRoughness | SpecularGlossiness | Phong | unknown type | dead slot
+      //   sky (miss.rmiss) | MetallicRoughness | SpecularGlossiness | Phong | unknown type | the three types again for materials
+      //   that sample a scene texture | dead slot
       // (ShaderTypes.incl:143-145, the dispatch of material.glsl:144-166) before they are shaded, so that a wave runs one
-      // branch of sampleMaterial / the miss stage instead of all that its 64 entries happen to need.  A stable counting
-      // sort: per wave one ballot per (entry, key) gives the counts, a prefix over (key, wave) the bases, the same ballots
-      // the ranks; the sorted slots go through LDS.  Deterministic: the order inside a key is the queue order.
+      // branch of sampleMaterial / the miss stage instead of all that its 64 entries happen to need, and the software sampler
+      // -- up to sixteen anisotropic taps, a seventh of an atrium_like step -- runs in waves of textured hits only instead of in
+      // every wave that holds one.  A stable counting sort: per wave one ballot per (entry, key) gives the counts, a prefix
+      // over (key, wave) the bases, the same ballots the ranks; the sorted slots go through LDS.  Deterministic: the order
+      // inside a key is the queue order.
       // Measured (1 MI355X, 1080p, 8 spp, one frame in flight): materials_test (three material types + an unknown one side
       // by side) 1,313 -> 1,536 Msamples/s, k_shade 8.06 -> 6.29 ms; scenes of ONE material type pay for the sort and get
-      // nothing back (temple_like 614 -> 600, chess_like and atrium_like +-0.5 %), hence the switch.
+      // nothing back (temple_like 614 -> 600, chess_like +-0.5 %), hence the switch.
       __shared__ uint32_t s_sorted[kBlock * kShadeItems];
       if (ctl.sortShade)
       {
-        constexpr uint32_t kKeys = 6, kWaves = kBlock / 64;
+        constexpr uint32_t kKeys = 9, kWaves = kBlock / 64;
         __shared__ uint32_t s_keyCount[kWaves][kKeys], s_keyBase[kWaves][kKeys];
         const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
         const uint64_t lower = (1ull << lane) - 1ull;
@@ -508,7 +511,7 @@ PT_DEV void shadeBody(const LaunchParams &p, const SceneView &sv, const Wavefron
         for (uint32_t item = 0; item < kShadeItems; item++)
         {
             const uint32_t i = base + item * blockDim.x + threadIdx.x;
-            uint32_t sl = 0, key = 5u;
+            uint32_t sl = 0, key = kKeys - 1u; // dead, and the padding past the end of the queue: sorted last
             if (i < count)
             {
                 sl = wf.queue[qin][i];
@@ -518,7 +521,7 @@ PT_DEV void shadeBody(const LaunchParams &p, const SceneView &sv, const Wavefron
                 else if (pr != kDeadPair)
                 {
                     const uint32_t type = sv.pairs[pr].materialId & 0xffu;
-                    key = type <= PTX_MATERIAL_TYPE_PHONG ? 1u + type : 4u;
+                    key = type <= PTX_MATERIAL_TYPE_PHONG ? ((sv.pairs[pr].flags & kPairTextured) ? 5u : 1u) + type : 4u;
                 }
             }
             mySlot[item] = sl;
@@ -1690,6 +1693,7 @@ struct PtxRenderer
     } build;
     bool anyNonOpaque = false;  // some instanced geometry lacks the opaque flag: any-hit stages run
     bool mixedMaterialTypes = false; // the instanced meshes use more than one material type (ShaderTypes.incl:143-145): k_shade sorts its queue
+    bool mixedTextured = false;      // ... or materials with and without scene textures: the sampler runs for waves of textured hits only
     bool usePloc = true;        // PLOC topology instead of Karras (PTX_BUILDER=lbvh switches back)
     uint32_t plocRadius = kPlocRadius;
     uint32_t residentClosest[2] = { 0, 0 }, residentShadow[2] = { 0, 0 }; // blocks the chip holds at once, per [ALPHA] variant
@@ -2051,6 +2055,26 @@ int ptx_set_backend(PtxRenderer *r, uint32_t backend)
 
 } // extern "C"
 
+// Does the material's branch of material.glsl:62-142 fetch a scene texture (an index at or past PTX_SCENE_TEXTURE_OFFSET inside
+// the uploaded table) through any of its five slots?  The five indices sit at the same offsets in the three 96-byte structs.
+static bool materialSamplesSceneTexture(const PtxSceneDesc *s, uint32_t materialId)
+{
+    const uint32_t type = materialId & 0xffu, index = materialId >> 8;
+    const uint32_t *idx = nullptr;
+    if (type == PTX_MATERIAL_TYPE_METALLIC_ROUGHNESS && index < s->metallicRoughnessMaterialCount)
+        idx = &s->metallicRoughnessMaterials[index].EmissiveIdx;
+    else if (type == PTX_MATERIAL_TYPE_SPECULAR_GLOSSINESS && index < s->specularGlossinessMaterialCount)
+        idx = &s->specularGlossinessMaterials[index].EmissiveIdx;
+    else if (type == PTX_MATERIAL_TYPE_PHONG && index < s->phongMaterialCount)
+        idx = &s->phongMaterials[index].EmissiveIdx;
+    if (!idx)
+        return false;
+    for (int k = 0; k < 5; k++)
+        if (idx[k] >= PTX_SCENE_TEXTURE_OFFSET && idx[k] - PTX_SCENE_TEXTURE_OFFSET < s->textureCount)
+            return true;
+    return false;
+}
+
 // world = A_instance * A_mesh * x (sampling.glsl:7)
 static void composeTransform(const float *Ai, const float *Am, float *M)
 {
@@ -2209,8 +2233,8 @@ int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *s)
             r->pairInstance.push_back(i);
             r->pairMeshTransform.push_back(s->transforms[rec.TransformIndex]);
             pr.materialId = rec.MaterialId;
-            pr.nonOpaque = geo.IsOpaque ? 0u : 1u;
-            if (pr.nonOpaque)
+            pr.flags = (geo.IsOpaque ? 0u : kPairNonOpaque) | (materialSamplesSceneTexture(s, rec.MaterialId) ? kPairTextured : 0u);
+            if (pr.flags & kPairNonOpaque)
                 anyNonOpaque = true;
             pairs.push_back(pr);
             pairFirst.push_back(static_cast<uint32_t>(tri));
@@ -2225,6 +2249,10 @@ int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *s)
         for (const DevPair &pr : pairs)
             typesSeen |= 1u << ((pr.materialId & 0xffu) <= PTX_MATERIAL_TYPE_PHONG ? (pr.materialId & 0xffu) : 3u);
         r->mixedMaterialTypes = (typesSeen & (typesSeen - 1u)) != 0u;
+        bool textured = false, plain = false;
+        for (const DevPair &pr : pairs)
+            ((pr.flags & kPairTextured) ? textured : plain) = true;
+        r->mixedTextured = textured && plain;
     }
     r->pairCount = static_cast<uint32_t>(pairs.size());
     r->triCount = static_cast<uint32_t>(tri);
@@ -3242,7 +3270,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
         if (rcr != PTX_OK)
             return rcr;
     }
-    pl.sortShade = sceneOf(r)->mixedMaterialTypes ? 1u : 0u;
+    pl.sortShade = (sceneOf(r)->mixedMaterialTypes || sceneOf(r)->mixedTextured) ? 1u : 0u;
     if (const char *e = getenv("PTX_SHADE_SORT"))
         pl.sortShade = atoi(e) ? 1u : 0u;
     // measured with 16 hardware queues (chess_like, ms per step at 25 / 50 / 75 / 100 / 200 / 400 K live paths): whole frame 8.04 / 7.82 /
