@@ -416,10 +416,11 @@ __global__ void k_karras(int n, const uint64_t *__restrict__ keys, int2 *__restr
 // the prefix scan of the merge flags: deterministic, and the last merge (the root) gets id 0.
 // Search radius.  Round 1, chess_like alone: 4 -> 1265, 8 -> 1277, 16 -> 1270, 32 -> 1285, 64 -> 1297, 128 -> 1298 Msamples/s (build
 // 11.7 .. 21 ms) -> 32.  Round 3, all four stand-ins, Msamples/s at 8 / 16 / 32 / 64 / 128 (pairs = two runs): street_like 1274,
-// 1283 / 1270, 1261 / 1220, 1214 / 1191 / 1186 -- a wider search makes ITS tree worse, monotonically (a street canyon: a few
-// huge building triangles among a finely tessellated road; the widest neighbourhood pairs small clusters with the big boxes
-// early) --, chess_like 2270, 2274 / 2301, 2292 / 2302, 2295, temple_like 896, 892 / 896, 896 / 902, 907, atrium_like - / 777, 757 /
-// 783, 764 / 780 / 772.  16 costs the other three at most 1 % and gives street_like 4 %; the build is faster too.
+// 1283 / 1270, 1261 / 1220, 1214 / 1191 / 1186 -- a wider search makes ITS tree worse, monotonically: 15.7 node visits per
+// primary ray at 16, 18.7 at 32 --, chess_like 2270, 2274 / 2301, 2292 / 2302, 2295, temple_like 896, 892 / 896, 896 / 902, 907,
+// atrium_like - / 777, 757 / 783, 764 / 780 / 772.  No radius is best everywhere, so ptx_build_accel builds with 16 AND 32 and
+// keeps the tree that costs sampled rays less (k_sample_tree_cost; it picks 16 for street_like, chess_like and temple_like, 32 for
+// atrium_like -- what the frame times say).  This constant is the radius of builds that skip the comparison.
 constexpr int kPlocRadius = 16;
 
 __global__ void k_ploc_init(uint32_t n, const uint32_t *__restrict__ vals, const float4 *__restrict__ boxLo, const float4 *__restrict__ boxHi,

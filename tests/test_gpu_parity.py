@@ -579,3 +579,28 @@ def test_cpp_host_adapter_end_to_end(pkg, tmp_path):
     r.postprocess(spp)
     assert (png == r.read_output()).all()
     r.close()
+
+
+def test_tree_choice_does_not_change_images(pkg, monkeypatch):
+    """ptx_build_accel builds the tree with two PLOC search radii and keeps the one that costs sampled surface-to-surface
+    rays fewer node visits and triangle tests (k_sample_tree_cost); a radius given in the environment skips the comparison.
+    Closest hits are tree-independent by construction, so all three renders are the same bits."""
+    import torch  # noqa: F401
+
+    scene = pkg.Scene("street_like", 0.05)
+    W, H = 160, 90
+    u = scene.uniform(W, H, bounces=6)
+    images = []
+    for radius in (None, "16", "32"):
+        if radius is None:
+            monkeypatch.delenv("PTX_PLOC_RADIUS", raising=False)
+        else:
+            monkeypatch.setenv("PTX_PLOC_RADIUS", radius)
+        r = pkg.Renderer()
+        r.upload(scene)
+        assert r.stats().lastBuildMs > 0
+        r.resize(W, H)
+        r.render_frames(u, scene.lights, 0, 3)
+        images.append(r.readback())
+        r.close()
+    assert (images[0].view(np.uint32) == images[1].view(np.uint32)).all() and (images[0].view(np.uint32) == images[2].view(np.uint32)).all()
