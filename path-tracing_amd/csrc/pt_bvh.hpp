@@ -414,14 +414,16 @@ __global__ void k_karras(int n, const uint64_t *__restrict__ keys, int2 *__restr
 // in the SAME arrays (children / parentOfNode / parentOfLeaf, root = node 0, leaf ref = ~sorted position),
 // so k_refit / k_emit and the refit path are unchanged.  Node ids are handed out downwards from n - 2 by
 // the prefix scan of the merge flags: deterministic, and the last merge (the root) gets id 0.
-// Search radius.  Round 1, chess_like alone: 4 -> 1265, 8 -> 1277, 16 -> 1270, 32 -> 1285, 64 -> 1297, 128 -> 1298 Msamples/s (build
-// 11.7 .. 21 ms) -> 32.  Round 3, all four stand-ins, Msamples/s at 8 / 16 / 32 / 64 / 128 (pairs = two runs): street_like 1274,
-// 1283 / 1270, 1261 / 1220, 1214 / 1191 / 1186 -- a wider search makes ITS tree worse, monotonically: 15.7 node visits per
-// primary ray at 16, 18.7 at 32 --, chess_like 2270, 2274 / 2301, 2292 / 2302, 2295, temple_like 896, 892 / 896, 896 / 902, 907,
-// atrium_like - / 777, 757 / 783, 764 / 780 / 772.  No radius is best everywhere, so ptx_build_accel builds with 16 AND 32 and
-// keeps the tree that costs sampled rays less (k_sample_tree_cost; it picks 16 for street_like, chess_like and temple_like, 32 for
-// atrium_like -- what the frame times say).  This constant is the radius of builds that skip the comparison.
+// Search radius and shape weight.  Round 1, chess_like alone: radius 4 -> 1265, 8 -> 1277, 16 -> 1270, 32 -> 1285, 64 -> 1297, 128 -> 1298
+// Msamples/s (build 11.7 .. 21 ms) -> 32.  Round 3, all four stand-ins, Msamples/s at 8 / 16 / 32 / 64 / 128 (pairs = two runs):
+// street_like 1274, 1283 / 1270, 1261 / 1220, 1214 / 1191 / 1186 -- a wider search makes ITS tree worse, monotonically: 15.7 node
+// visits per primary ray at 16, 18.7 at 32 --, chess_like 2270, 2274 / 2301, 2292 / 2302, 2295, temple_like 896, 892 / 896, 896 / 902,
+// 907, atrium_like - / 777, 757 / 783, 764 / 780 / 772; and the cost of 65,536 sampled rays (k_sample_tree_cost) over radius {8, 16,
+// 32, 64} x shape {0, 0.25, 1} moves by 5-10 % per scene with no setting best everywhere (temple_like: 2.86 M at (64, 1), 3.18 M at
+// (16, 0); street_like: 3.96 M at (8, 0), 4.75 M at (64, 0)).  So ptx_build_accel builds a few candidates and keeps the tree that
+// costs the sampled rays least (kTreeCandidates).  These constants are the parameters of builds that skip the comparison.
 constexpr int kPlocRadius = 16;
+constexpr float kPlocShape = 0.0f;
 
 __global__ void k_ploc_init(uint32_t n, const uint32_t *__restrict__ vals, const float4 *__restrict__ boxLo, const float4 *__restrict__ boxHi,
                             int *__restrict__ cluster, float4 *__restrict__ cLo, float4 *__restrict__ cHi)
@@ -437,7 +439,9 @@ __global__ void k_ploc_init(uint32_t n, const uint32_t *__restrict__ vals, const
 
 // pairs are ordered by (union area, lower position, higher position): a strict total order, so the globally
 // smallest pair is always mutual and every iteration merges at least once
-__global__ void k_ploc_nearest(uint32_t count, uint32_t radius, const float4 *__restrict__ cLo, const float4 *__restrict__ cHi, uint32_t *__restrict__ nn)
+// `shape`: weight of a compactness term in the merge metric, area + shape * (longest extent)^2 -- the surface area of the union of
+// two flat boxes does not tell a square from a strip.  Symmetric in (i, j) like the area, so the order stays total.
+__global__ void k_ploc_nearest(uint32_t count, uint32_t radius, float shape, const float4 *__restrict__ cLo, const float4 *__restrict__ cHi, uint32_t *__restrict__ nn)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count)
@@ -453,7 +457,8 @@ __global__ void k_ploc_nearest(uint32_t count, uint32_t radius, const float4 *__
             continue;
         const float4 l = cLo[j], h = cHi[j];
         const float dx = fmaxf(hi.x, h.x) - fminf(lo.x, l.x), dy = fmaxf(hi.y, h.y) - fminf(lo.y, l.y), dz = fmaxf(hi.z, h.z) - fminf(lo.z, l.z);
-        const float area = dx * dy + dy * dz + dz * dx;
+        const float longest = fmaxf(dx, fmaxf(dy, dz));
+        const float area = (dx * dy + dy * dz + dz * dx) + shape * longest * longest;
         const uint32_t a = i < j ? i : j, b = i < j ? j : i;
         if (area < best || (area == best && (a < bestA || (a == bestA && b < bestB))) || bestA == 0xffffffffu)
         {

@@ -1657,6 +1657,11 @@ template <typename T> struct DevBuf
         p = nullptr;
         n = 0;
     }
+    void swap(DevBuf &o)
+    {
+        std::swap(p, o.p);
+        std::swap(n, o.n);
+    }
 };
 
 struct PtxRenderer
@@ -1726,6 +1731,7 @@ struct PtxRenderer
     bool mixedTextured = false;      // ... or materials with and without scene textures: the sampler runs for waves of textured hits only
     bool usePloc = true;        // PLOC topology instead of Karras (PTX_BUILDER=lbvh switches back)
     uint32_t plocRadius = kPlocRadius;
+    float plocShape = kPlocShape;
     uint32_t residentClosest[2] = { 0, 0 }, residentShadow[2] = { 0, 0 }; // blocks the chip holds at once, per [ALPHA] variant
     DevBuf<float4> decal;
     DevBuf<float> decalT;
@@ -1991,6 +1997,8 @@ int ptx_create(const PtxDeviceDesc *desc, PtxRenderer **out)
         r->usePloc = std::strcmp(e, "lbvh") != 0;
     if (const char *e = getenv("PTX_RAYS_PER_THREAD"))
         g_raysPerThread = std::max(1u, (uint32_t)strtoul(e, nullptr, 10));
+    if (const char *e = getenv("PTX_PLOC_SHAPE"))
+        r->plocShape = (float)atof(e);
     if (const char *e = getenv("PTX_PLOC_RADIUS"))
         r->plocRadius = std::max(1u, (uint32_t)strtoul(e, nullptr, 10));
     if (const char *e = getenv("PTX_RESIDENT_CAP"))
@@ -2730,7 +2738,7 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
             while (count > 1)
             {
                 const uint32_t cb = (count + 255) / 256, sb = (count + kScanBlock - 1) / kScanBlock;
-                k_ploc_nearest<<<cb, 256, 0, r->stream>>>(count, r->plocRadius, lIn, hIn, nn.p);
+                k_ploc_nearest<<<cb, 256, 0, r->stream>>>(count, r->plocRadius, r->plocShape, lIn, hIn, nn.p);
                 k_ploc_flags<<<cb, 256, 0, r->stream>>>(count, nn.p, flags.p);
                 k_scan64_sums<<<sb, 256, 0, r->stream>>>(count, flags.p, sums.p);
                 k_scan64_top<<<1, 1024, 0, r->stream>>>(sb, sums.p, total.p);
@@ -2842,37 +2850,50 @@ int ptx_build_accel(PtxRenderer *r)
         return fail(r, PTX_ERROR_NOT_READY, "ptx_build_accel: no scene uploaded");
     quiesceSharers(r);
     r->sceneEpoch++; // schedules learnt on the old tree's scene are not this one's (ptx_scene_upload without a build in between cannot render)
-    // Which search radius?  Build with each candidate, price the tree on sampled surface-to-surface rays, keep the cheaper one
-    // (the last build is the kept one; lastBuildMs is the time of everything).  A radius given in the environment, the Karras
-    // builder and small scenes skip the comparison; the per-frame rebuilds of an animation use the radius chosen here.
-    static const uint32_t candidates[] = { 16u, 32u };
-    constexpr uint32_t kCandidates = sizeof(candidates) / sizeof(candidates[0]);
-    if (!r->usePloc || getenv("PTX_PLOC_RADIUS") || r->triCount < 4096u)
+    // Which tree?  Build a few candidates, price each on sampled surface-to-surface rays, keep the cheapest (its buffers are swapped
+    // aside while the others are built; lastBuildMs is the time of everything).  Parameters given in the environment, the Karras
+    // builder and small scenes skip the comparison; the per-frame rebuilds of an animation use the parameters chosen here.
+    struct Candidate { uint32_t radius; float shape; };
+    static const Candidate kTreeCandidates[] = { { 8u, 0.0f }, { 16u, 0.0f }, { 16u, 0.25f }, { 32u, 1.0f } };
+    constexpr uint32_t kCandidates = sizeof(kTreeCandidates) / sizeof(kTreeCandidates[0]);
+    if (!r->usePloc || getenv("PTX_PLOC_RADIUS") || getenv("PTX_PLOC_SHAPE") || r->triCount < 4096u)
         return buildAccel(r, false, false);
+    DevBuf<BvhNode> bestNodes;
+    DevBuf<Tri> bestTris;
+    DevBuf<ShadeTri> bestShadeTris;
+    DevBuf<AlphaTri> bestAlphaTris;
+    auto swapTree = [&]() { r->nodes.swap(bestNodes); r->tris.swap(bestTris); r->shadeTris.swap(bestShadeTris); r->alphaTris.swap(bestAlphaTris); };
     unsigned long long cost[kCandidates] = {};
+    uint64_t bestNodeCount = 0;
     double totalMs = 0.0;
     uint32_t best = 0;
     for (uint32_t k = 0; k < kCandidates; k++)
     {
-        r->plocRadius = candidates[k];
+        r->plocRadius = kTreeCandidates[k].radius;
+        r->plocShape = kTreeCandidates[k].shape;
         int rc = buildAccel(r, false, false);
         totalMs += r->stats.lastBuildMs;
         if (rc != PTX_OK || (rc = sampleTreeCost(r, &cost[k])) != PTX_OK)
             return rc;
-        if (cost[k] < cost[best])
+        if (k == 0 || cost[k] < cost[best])
+        {
             best = k;
+            bestNodeCount = r->stats.bvhNodes;
+            swapTree(); // the renderer's buffers now hold the previous best (or nothing): the next candidate is built over them
+        }
     }
-    if (getenv("PTX_VERBOSE"))
-        std::fprintf(stderr, "[ptx] tree cost on sampled rays: radius 16 -> %llu, radius 32 -> %llu: %u kept\n", cost[0], cost[1], candidates[best]);
-    r->plocRadius = candidates[best];
-    if (best != kCandidates - 1)
-    {
-        const int rc = buildAccel(r, false, false);
-        totalMs += r->stats.lastBuildMs;
-        if (rc != PTX_OK)
-            return rc;
-    }
+    swapTree();
+    r->stats.bvhNodes = bestNodeCount;
+    r->plocRadius = kTreeCandidates[best].radius;
+    r->plocShape = kTreeCandidates[best].shape;
     r->stats.lastBuildMs = totalMs;
+    if (getenv("PTX_VERBOSE"))
+    {
+        std::fprintf(stderr, "[ptx] tree cost on sampled rays:");
+        for (uint32_t k = 0; k < kCandidates; k++)
+            std::fprintf(stderr, " (radius %u, shape %.2f) %llu%s", kTreeCandidates[k].radius, kTreeCandidates[k].shape, cost[k], k == best ? " <- kept" : "");
+        std::fprintf(stderr, "; %.1f ms\n", totalMs);
+    }
     return PTX_OK;
 }
 
