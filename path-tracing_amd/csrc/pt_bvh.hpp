@@ -166,9 +166,11 @@ PT_DEV uint64_t expandBits21(uint32_t v) // 21 bits -> every third bit of 63
 
 constexpr uint64_t kInertKey = ~0ull; // above every 63-bit Morton code: inert triangles end up behind the sorted rest
 
+// cubic: one scale for the three axes (cells of the curve are cubes) instead of each axis normalised to its own extent
+// (cells have the proportions of the scene: in a street 80 x 16 x 16 units they are five times longer than wide)
 __global__ void k_morton(uint32_t n, const float4 *__restrict__ boxLo, const float4 *__restrict__ boxHi,
                          const uint32_t *__restrict__ sceneBounds, const uint8_t *__restrict__ inert, uint64_t *__restrict__ keys,
-                         uint32_t *__restrict__ vals)
+                         uint32_t *__restrict__ vals, int cubic)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n)
@@ -182,10 +184,13 @@ __global__ void k_morton(uint32_t n, const float4 *__restrict__ boxLo, const flo
     const float4 lo = boxLo[g], hi = boxHi[g];
     const float c[3] = { 0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z) };
     uint32_t q[3];
+    float widest = 0.0f;
+    for (int a = 0; a < 3; a++)
+        widest = fmaxf(widest, unorderedFloat(sceneBounds[3 + a]) - unorderedFloat(sceneBounds[a]));
     for (int a = 0; a < 3; a++)
     {
         const float mn = unorderedFloat(sceneBounds[a]), mx = unorderedFloat(sceneBounds[3 + a]);
-        const float ext = mx - mn;
+        const float ext = cubic ? widest : mx - mn;
         float f = ext > 0.0f ? (c[a] - mn) / ext : 0.0f;
         f = f == f ? fminf(fmaxf(f, 0.0f), 1.0f) : 0.0f;
         const uint32_t v = (uint32_t)(f * 2097151.0f);
@@ -420,8 +425,9 @@ __global__ void k_karras(int n, const uint64_t *__restrict__ keys, int2 *__restr
 // visits per primary ray at 16, 18.7 at 32 --, chess_like 2270, 2274 / 2301, 2292 / 2302, 2295, temple_like 896, 892 / 896, 896 / 902,
 // 907, atrium_like - / 777, 757 / 783, 764 / 780 / 772; and the cost of 65,536 sampled rays (k_sample_tree_cost) over radius {8, 16,
 // 32, 64} x shape {0, 0.25, 1} moves by 5-10 % per scene with no setting best everywhere (temple_like: 2.86 M at (64, 1), 3.18 M at
-// (16, 0); street_like: 3.96 M at (8, 0), 4.75 M at (64, 0)).  So ptx_build_accel builds a few candidates and keeps the tree that
-// costs the sampled rays least (kTreeCandidates).  These constants are the parameters of builds that skip the comparison.
+// (16, 0); street_like: 3.96 M at (8, 0), 4.75 M at (64, 0), 3.78 M at (8, 1) over a Morton curve with cubic cells, which costs
+// chess_like and atrium_like 3-5 %).  So ptx_build_accel builds a few candidates and keeps the tree that costs the sampled rays
+// least (kTreeCandidates).  These constants are the parameters of builds that skip the comparison.
 constexpr int kPlocRadius = 16;
 constexpr float kPlocShape = 0.0f;
 

@@ -1732,6 +1732,7 @@ struct PtxRenderer
     bool usePloc = true;        // PLOC topology instead of Karras (PTX_BUILDER=lbvh switches back)
     uint32_t plocRadius = kPlocRadius;
     float plocShape = kPlocShape;
+    bool mortonCubic = false; // k_morton: cubic cells
     uint32_t residentClosest[2] = { 0, 0 }, residentShadow[2] = { 0, 0 }; // blocks the chip holds at once, per [ALPHA] variant
     DevBuf<float4> decal;
     DevBuf<float> decalT;
@@ -2696,7 +2697,7 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
     uint32_t nv = B.treeTris; // triangles in the tree: all but the zero-area ones, which sort to the end
     if (!refit)
     {
-        k_morton<<<blocks, 256, 0, r->stream>>>(n, B.boxLo.p, B.boxHi.p, B.sceneBounds.p, B.inert.p, B.keys0.p, B.vals0.p);
+        k_morton<<<blocks, 256, 0, r->stream>>>(n, B.boxLo.p, B.boxHi.p, B.sceneBounds.p, B.inert.p, B.keys0.p, B.vals0.p, r->mortonCubic ? 1 : 0);
         for (uint32_t shift = 0; shift < 64; shift += 8) // 63-bit keys + the all-ones sentinel of inert triangles: 8 passes
         {
             k_sort_hist<<<numTiles, 64, 0, r->stream>>>(n, kin, shift, numTiles, B.hist.p);
@@ -2853,8 +2854,8 @@ int ptx_build_accel(PtxRenderer *r)
     // Which tree?  Build a few candidates, price each on sampled surface-to-surface rays, keep the cheapest (its buffers are swapped
     // aside while the others are built; lastBuildMs is the time of everything).  Parameters given in the environment, the Karras
     // builder and small scenes skip the comparison; the per-frame rebuilds of an animation use the parameters chosen here.
-    struct Candidate { uint32_t radius; float shape; };
-    static const Candidate kTreeCandidates[] = { { 8u, 0.0f }, { 16u, 0.0f }, { 16u, 0.25f }, { 32u, 1.0f } };
+    struct Candidate { uint32_t radius; float shape; bool cubic; };
+    static const Candidate kTreeCandidates[] = { { 8u, 0.0f, false }, { 16u, 0.0f, false }, { 16u, 0.25f, false }, { 32u, 1.0f, false }, { 8u, 1.0f, true } };
     constexpr uint32_t kCandidates = sizeof(kTreeCandidates) / sizeof(kTreeCandidates[0]);
     if (!r->usePloc || getenv("PTX_PLOC_RADIUS") || getenv("PTX_PLOC_SHAPE") || r->triCount < 4096u)
         return buildAccel(r, false, false);
@@ -2871,6 +2872,7 @@ int ptx_build_accel(PtxRenderer *r)
     {
         r->plocRadius = kTreeCandidates[k].radius;
         r->plocShape = kTreeCandidates[k].shape;
+        r->mortonCubic = kTreeCandidates[k].cubic;
         int rc = buildAccel(r, false, false);
         totalMs += r->stats.lastBuildMs;
         if (rc != PTX_OK || (rc = sampleTreeCost(r, &cost[k])) != PTX_OK)
@@ -2886,12 +2888,14 @@ int ptx_build_accel(PtxRenderer *r)
     r->stats.bvhNodes = bestNodeCount;
     r->plocRadius = kTreeCandidates[best].radius;
     r->plocShape = kTreeCandidates[best].shape;
+    r->mortonCubic = kTreeCandidates[best].cubic;
     r->stats.lastBuildMs = totalMs;
     if (getenv("PTX_VERBOSE"))
     {
         std::fprintf(stderr, "[ptx] tree cost on sampled rays:");
         for (uint32_t k = 0; k < kCandidates; k++)
-            std::fprintf(stderr, " (radius %u, shape %.2f) %llu%s", kTreeCandidates[k].radius, kTreeCandidates[k].shape, cost[k], k == best ? " <- kept" : "");
+            std::fprintf(stderr, " (radius %u, shape %.2f%s) %llu%s", kTreeCandidates[k].radius, kTreeCandidates[k].shape, kTreeCandidates[k].cubic ? ", cubic cells" : "",
+                         cost[k], k == best ? " <- kept" : "");
         std::fprintf(stderr, "; %.1f ms\n", totalMs);
     }
     return PTX_OK;
