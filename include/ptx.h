@@ -353,7 +353,7 @@ typedef struct PtxStats {
     uint64_t bvhNodes;       /* nodes of the 4-wide tree (reachable from the root)  */
     double lastRenderMs;     /* device time of the last ptx_render (HIP events)     */
     double lastTraceMs;      /* ... spent in k_trace_closest (HIP events on the stream) */
-    double lastBuildMs;      /* device time of the last ptx_build_accel             */
+    double lastBuildMs;      /* device time of the last ptx_build_accel (every candidate tree it built) */
     uint64_t traceLaunches;  /* number of traversal kernel launches in last render  */
     double lastShadeMs;      /* ... spent in k_shade                                */
     double lastShadowMs;     /* ... spent in k_trace_shadow                         */
@@ -384,7 +384,12 @@ PTX_API uint32_t ptx_abi_version(void);
 /* Renderer::UpdateSceneData (Renderer.cpp:238-439): copy the scene to HBM. */
 PTX_API int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *scene);
 /* AccelerationStructure::Build (AccelerationStructure.cpp:26-46; BLAS :64-247, TLAS
- * :250-301), replaced by a software LBVH over the flattened world-space triangles. */
+ * :250-301), replaced by a software LBVH over the flattened world-space triangles.
+ * The call builds a handful of candidate trees (clustering radius, merge metric, Morton cells) and keeps the one that
+ * costs a sample of surface-to-surface rays the fewest node visits and triangle tests: results never depend on the tree,
+ * its quality moves frame times by several per cent, and no one setting is best for every scene.  PtxStats::lastBuildMs
+ * is the time of all of it (2M triangles: ~40 ms).  PTX_PLOC_RADIUS / PTX_PLOC_SHAPE in the environment build one tree
+ * with those parameters instead; the per-frame rebuilds of ptx_update_animation use the parameters chosen here. */
 PTX_API int ptx_build_accel(PtxRenderer *r);
 /* Frames in flight share ONE scene: the reference keeps GetInFlightCount() sets of per-frame rendering resources
  * (Renderer.cpp:1454-1460) over one set of scene buffers and one acceleration structure (s_StaticSceneData / s_SceneData,
