@@ -1255,7 +1255,7 @@ __global__ void k_unpack_shard(LaunchParams p, const float4 *__restrict__ src, f
 // builds the tree with more than one search radius and keeps the cheaper one: "lower surface-area cost" does not always mean
 // "fewer visits" (street_like: a wider PLOC search gives 13 % MORE visits per ray), and results never depend on the tree.
 template <bool ALPHA>
-__global__ void __launch_bounds__(kBlock) k_sample_tree_cost(TraceScene sc, uint32_t n, uint32_t *spill, unsigned long long *cost)
+__global__ void __launch_bounds__(kBlock) k_sample_tree_cost(TraceScene sc, uint32_t n, uint32_t *spill, uint32_t *cost)
 {
     PT_DECLARE_STACK(st, kLdsStack, spill)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1275,9 +1275,7 @@ __global__ void __launch_bounds__(kBlock) k_sample_tree_cost(TraceScene sc, uint
             traceRay<false, true, ALPHA>(sc, ca, d * (1.0f / len), 1e-4f * len, 1e4f, st, best, &visits, &tests);
         }
     }
-    const uint32_t c = visits + tests; // one dependent fetch each
-    if (c)
-        atomicAdd(cost, (unsigned long long)c);
+    waveAddCounter(cost, visits + tests); // one dependent fetch each; one atomic per wave (65,536 same-address atomics took 13 ms)
 }
 
 // ---- textures (row N1): sRGB table and the mip chain are produced on the device ------------------
@@ -2828,18 +2826,20 @@ static TraceScene makeTraceScene(const PtxRenderer *r);
 // node visits + triangle tests of 65,536 sampled rays through the tree just built (k_sample_tree_cost)
 static int sampleTreeCost(PtxRenderer *r, unsigned long long *cost)
 {
-    constexpr uint32_t kRays = 65536;
-    DevBuf<unsigned long long> d;
+    constexpr uint32_t kRays = 65536; // a few million visits and tests in all: 32 bits
+    DevBuf<uint32_t> d;
     HIP_TRY(r, d.alloc(1));
-    HIP_TRY(r, hipMemsetAsync(d.p, 0, sizeof(unsigned long long), r->stream));
+    HIP_TRY(r, hipMemsetAsync(d.p, 0, sizeof(uint32_t), r->stream));
     const TraceScene sc = makeTraceScene(r);
     if (r->anyNonOpaque)
         k_sample_tree_cost<true><<<kRays / kBlock, kBlock, 0, r->stream>>>(sc, kRays, r->spill.p, d.p);
     else
         k_sample_tree_cost<false><<<kRays / kBlock, kBlock, 0, r->stream>>>(sc, kRays, r->spill.p, d.p);
-    HIP_TRY(r, hipMemcpyAsync(cost, d.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, r->stream));
+    uint32_t total = 0;
+    HIP_TRY(r, hipMemcpyAsync(&total, d.p, sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(r, hipStreamSynchronize(r->stream));
     HIP_TRY(r, hipGetLastError());
+    *cost = total;
     return PTX_OK;
 }
 
