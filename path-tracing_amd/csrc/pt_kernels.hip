@@ -1272,7 +1272,9 @@ __global__ void __launch_bounds__(kBlock) k_sample_tree_cost(TraceScene sc, uint
         if (len > 0.0f)
         {
             Hit best;
-            traceRay<false, true, ALPHA>(sc, ca, d * (1.0f / len), 1e-4f * len, 1e4f, st, best, &visits, &tests);
+            // the segment between the two surfaces, not the line through them: a path segment ends where it lands, and a line
+            // that runs on inside a slab of alpha-tested cards costs a thousand visits that no path ray pays
+            traceRay<false, true, ALPHA>(sc, ca, d * (1.0f / len), 1e-4f * len, 1.001f * len, st, best, &visits, &tests);
         }
     }
     waveAddCounter(cost, visits + tests); // one dependent fetch each; one atomic per wave (65,536 same-address atomics took 13 ms)
