@@ -40,23 +40,58 @@ using namespace ptd;
 // Launch parameters
 // =====================================================================================
 
+// Per-slot path state is written by one kernel and read once by the next: a stream.  Its loads and stores carry the
+// non-temporal hint (global_load / global_store ... nt), so that the 4 MB of L2 an XCD has keep tree nodes and texels instead
+// of records nobody reads twice.  Measured (1 MI355X, 1080p, 8 spp, two runs each in one call, plain -> nt): atrium_like
+// 788 / 789 -> 811 / 823 Msamples/s, chess_like 2,248 / 2,229 -> 2,267 / 2,262, temple_like 898 / 883 -> 905 / 895, street_like
+// flat; the hint on the loads alone or on the stores alone gives half of it; on the ShadeTri reads it costs 4 % (the samples
+// of one pixel sit in neighbouring lanes and share them).
+template <typename T> struct StreamWord { typedef T type; };
+template <> struct StreamWord<float4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct StreamWord<uint4> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
+template <typename T> struct StreamRef
+{
+    T *p;
+    typedef typename StreamWord<T>::type W;
+    PT_DEV operator T() const
+    {
+        const W w = __builtin_nontemporal_load(reinterpret_cast<const W *>(p));
+        T v;
+        __builtin_memcpy(&v, &w, sizeof(T));
+        return v;
+    }
+    PT_DEV void operator=(const T &v) const
+    {
+        W w;
+        __builtin_memcpy(&w, &v, sizeof(T));
+        __builtin_nontemporal_store(w, reinterpret_cast<W *>(p));
+    }
+};
+template <typename T> struct Stream // wf.rayO[slot] reads and writes as before; wf.rayO.p[slot] is the plain access
+{
+    T *p;
+    PT_DEV StreamRef<T> operator[](size_t i) const { return StreamRef<T>{p + i}; }
+    __host__ __device__ Stream &operator=(T *q) { p = q; return *this; }
+    __host__ __device__ explicit operator bool() const { return p != nullptr; }
+};
+
 struct Wavefront // device pointers of the per-slot state (SoA)
 {
-    float4 *rayO;   // origin.xyz, w = MaxRoughness (payload.MaxRoughness)
-    float4 *rayD;   // direction.xyz
-    float4 *thr;    // throughput.rgb
-    float4 *rad;    // radiance.rgb accumulated over the samples of this launch
-    uint4 *meta;    // x = rngState, y = pixel (y*W+x) or 0xffffffff, z = bounce | smpl<<16, w = frame
-    float4 *hit;    // t, u, v, triangle slot in leaf order (bits)
-    uint32_t *hitPair;
-    float4 *shO;    // shadow origin.xyz, w = tmax (LightDistance)
-    float4 *shD;    // shadow direction.xyz, w = 1 if the path ends after this bounce
-    float4 *shC;    // NEE contribution throughput * DirectLight / DirectLightPdf
-    float4 *slotRad; // final radiance of the slot (consumed by k_accumulate)
-    float4 *decal;   // nearest ignored any-hit candidate: (triangle slot, u, v, pair) -- k_shade fetches its colour and alpha
-    float *decalT;   // (payload.LightDirection / LightDistance) if the hit lies behind it; null unless the scene has non-opaque
+    Stream<float4> rayO;   // origin.xyz, w = MaxRoughness (payload.MaxRoughness)
+    Stream<float4> rayD;   // direction.xyz
+    Stream<float4> thr;    // throughput.rgb
+    Stream<float4> rad;    // radiance.rgb accumulated over the samples of this launch
+    Stream<uint4> meta;    // x = rngState, y = pixel (y*W+x) or 0xffffffff, z = bounce | smpl<<16, w = frame
+    Stream<float4> hit;    // t, u, v, triangle slot in leaf order (bits)
+    Stream<uint32_t> hitPair;
+    Stream<float4> shO;    // shadow origin.xyz, w = tmax (LightDistance)
+    Stream<float4> shD;    // shadow direction.xyz, w = 1 if the path ends after this bounce
+    Stream<float4> shC;    // NEE contribution throughput * DirectLight / DirectLightPdf
+    Stream<float4> slotRad; // final radiance of the slot (consumed by k_accumulate)
+    Stream<float4> decal;   // nearest ignored any-hit candidate: (triangle slot, u, v, pair) -- k_shade fetches its colour and alpha
+    Stream<float> decalT;   // (payload.LightDirection / LightDistance) if the hit lies behind it; null unless the scene has non-opaque
                      // geometry.  decalT = its distance or -1 (payload.DirectLightPdf)
-    float4 *diff[3]; // payload.RayDifferentials0..2 (rx origin, rx dir, ry origin, ry dir); null unless the scene has textures
+    Stream<float4> diff[3]; // payload.RayDifferentials0..2 (rx origin, rx dir, ry origin, ry dir); null unless the scene has textures
     uint32_t *queue[2];
     uint32_t *shadowQueue;
     uint8_t *shadowResult; // per shadow queue entry: bit 0 = the light is visible, bit 1 = the path ends here (k_apply_shadow)
@@ -134,7 +169,27 @@ struct LaunchParams
     uint32_t frames, firstFrame;
     uint32_t numSlots;
     uint32_t ownedPixels; // slots of one frame that map to a pixel inside the image
+    uint32_t framesPerWave; // 1, 2, 4 or 8 (divides frames): a wave of 64 slots = 64 / framesPerWave pixels x framesPerWave frames
 };
+
+// slot <-> (frame of the batch, slot inside the frame).  The samples a batch adds to ONE pixel sit in neighbouring lanes: their
+// primary rays differ by the sub-pixel jitter only, they reach the same triangles and the same texels (a wave = 8 pixels of a
+// row x 8 frames instead of an 8x8 pixel block of one frame).  Measured, 1 / 2 / 4 / 8 frames per wave (PTX_FRAMES_PER_WAVE,
+// two runs each): atrium_like 770, 766 / 769, 777 / 779, 776 / 788, 782 Msamples/s (k_shade<true> 44.8 -> 39.5 ms of kernel time
+// per step), street_like +1 %, chess_like and temple_like flat; a 4x2 pixel footprint instead of the row: flat.
+PT_DEV void slotFrame(const LaunchParams &p, uint32_t slot, uint32_t &f, uint32_t &s)
+{
+    const uint32_t g = p.framesPerWave, pixelsPerWave = 64u / g, wave = slot >> 6, lane = slot & 63u;
+    const uint32_t chunks = p.slotsPerFrame / pixelsPerWave; // slotsPerFrame is a multiple of 64
+    f = (wave / chunks) * g + lane % g;
+    s = (wave % chunks) * pixelsPerWave + lane / g;
+}
+PT_DEV uint32_t slotOf(const LaunchParams &p, uint32_t f, uint32_t s)
+{
+    const uint32_t g = p.framesPerWave, pixelsPerWave = 64u / g;
+    const uint32_t chunks = p.slotsPerFrame / pixelsPerWave;
+    return (((f / g) * chunks + s / pixelsPerWave) << 6) + (s % pixelsPerWave) * g + f % g;
+}
 
 // slot -> pixel.  Owned tiles are rank, rank+world, ...; inside a tile pixels are laid
 // out in 8x8 blocks so that one wave64 = one 8x8 pixel block (coherent primary rays).
@@ -279,7 +334,8 @@ __global__ void __launch_bounds__(kBlock) k_generate(LaunchParams p, Wavefront w
 {
     for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < p.numSlots; slot += gridDim.x * blockDim.x)
     {
-        const uint32_t f = slot / p.slotsPerFrame, s = slot % p.slotsPerFrame;
+        uint32_t f, s;
+        slotFrame(p, slot, f, s);
         const uint32_t pixel = slotPixel(p, s);
         const uint32_t frame = p.firstFrame + f;
         uint4 meta = make_uint4(0u, pixel, 0u, frame);
@@ -336,7 +392,7 @@ struct ClosestIO
     {
         wf.hit[slot] = make_float4(t, u, v, __uint_as_float(triSlot)); // w = triangle slot in leaf order
     }
-    PT_DEV uint32_t bestSlot(uint32_t) const { return __float_as_uint(wf.hit[slot].w); }
+    PT_DEV uint32_t bestSlot(uint32_t) const { return __float_as_uint(wf.hit.p[slot].w); }
     PT_DEV void store(uint32_t, const Hit &h, bool, bool) { wf.hitPair[slot] = h.pair; }
     // anyhit.rahit:54-61: the nearest ignored candidate (ties: smaller (pair, prim)) is the decal.  It lives in the slot's
     // record -- (triangle slot, u, v, pair) + its distance -- and k_shade fetches its colour if the hit lies behind it.
@@ -347,7 +403,7 @@ struct ClosestIO
         bool nearer = cur == -1.0f || t < cur;
         if (!nearer && t == cur)
         {
-            const float4 mine = sc.tris[triSlot].c, other = sc.tris[__float_as_uint(wf.decal[slot].x)].c;
+            const float4 mine = sc.tris[triSlot].c, other = sc.tris[__float_as_uint(wf.decal.p[slot].x)].c;
             const uint32_t pair = __float_as_uint(mine.y), curPair = __float_as_uint(other.y);
             nearer = pair < curPair || (pair == curPair && __float_as_uint(mine.z) < __float_as_uint(other.z));
         }
@@ -796,7 +852,7 @@ __global__ void __launch_bounds__(kBlock) k_apply_shadow(LaunchParams p, Wavefro
                     f3 radiance = F3(r4.x, r4.y, r4.z);
                     restart = finishSample(p, wf, slot, meta, radiance, nSamples, nRetries);
                     if (restart)
-                        wf.meta[slot].z = meta.z;
+                        wf.meta.p[slot].z = meta.z;
                 }
                 else
                     wf.rad[slot] = r4; // the slot is already in the next queue (k_shade)
@@ -853,7 +909,7 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(LaunchParams p, const flo
         float4 acc = image[pixel];
         for (uint32_t f = 0; f < p.frames; f++)
         {
-            const float4 r = slotRad[f * p.slotsPerFrame + s];
+            const float4 r = slotRad[slotOf(p, f, s)];
             acc.x = r.x + acc.x;
             acc.y = r.y + acc.y;
             acc.z = r.z + acc.z;
@@ -967,7 +1023,9 @@ __global__ void __launch_bounds__(kBlock) k_megakernel(LaunchParams p, SceneView
 {
     PT_DECLARE_STACK(st, kLdsStackMega, (uint32_t *)nullptr)
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t f = slot / p.slotsPerFrame, s = slot % p.slotsPerFrame;
+    uint32_t f = 0, s = 0;
+    if (slot < p.numSlots)
+        slotFrame(p, slot, f, s);
     const uint32_t pixel = slot < p.numSlots ? slotPixel(p, s) : 0xffffffffu;
     PathCounters pc;
     f3 radiance = F3s(0.0f);
@@ -1924,6 +1982,10 @@ static LaunchParams makeParams(const PtxRenderer *r, const PtxRaygenUniformData 
     p.frames = frames;
     p.firstFrame = firstFrame;
     p.numSlots = p.slotsPerFrame * frames;
+    static const uint32_t maxPerWave = getenv("PTX_FRAMES_PER_WAVE") ? (uint32_t)atoi(getenv("PTX_FRAMES_PER_WAVE")) : 8u;
+    p.framesPerWave = 1;
+    while (p.framesPerWave < maxPerWave && p.framesPerWave < 8u && frames % (p.framesPerWave * 2u) == 0u)
+        p.framesPerWave *= 2u;
     for (uint32_t t = p.rank; t < p.numTiles; t += p.worldSize)
     {
         const uint32_t x0 = (t % p.tilesX) * p.tileSize, y0 = (t / p.tilesX) * p.tileSize;
