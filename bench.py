@@ -23,7 +23,8 @@ all_gather of the tile shards per step.  The reported metric is the NAMED frame 
 is the same frame at 8 N spp, which is how BASELINE configs[3] and [4] are posed) is measured in the same run and
 printed in `weak`.
 
-Frames in flight (`--in-flight`, default 4 on one GPU, 12 per rank on several -- a tile shard is a small frame): consecutive steps run on renderers that take turns, each on its own stream
+Frames in flight (`--in-flight`, default 8 per GPU: two streams each = the 16 hardware queues; more share queues and lose --
+a rank's 1/8 tile shard takes 1.15 / 1.24 / 1.19 ms per step with 8 / 12 / 16 in flight): consecutive steps run on renderers that take turns, each on its own stream
 with its own path state, as the reference keeps frames in flight (Renderer.cpp:1454-1460): ptx_render only enqueues a
 frame -- the bounce loop is driven from the device -- so the latency-bound end of one frame overlaps the head of the
 next.  Every step is still one complete frame: reset, 8 spp, gather, read-back.
@@ -136,7 +137,7 @@ class Job:
         self.scene = pkg.Scene(scene_name, args.detail)
         self.lights = self.scene.lights
         backend = pkg.BACKEND_WAVEFRONT if args.backend == "wavefront" else pkg.BACKEND_MEGAKERNEL
-        self.F = args.in_flight if args.in_flight > 0 else (4 if self.shard_world_hint(shard, world) == 1 else 12)
+        self.F = args.in_flight if args.in_flight > 0 else 8
         self.streams = [torch.cuda.Stream() for _ in range(self.F)]
         self.rs = [pkg.Renderer(device=local_rank, backend=backend, stream=s.cuda_stream) for s in self.streams]
         self.shard_rank, self.shard_world = shard if shard else (rank, world)
@@ -162,10 +163,6 @@ class Job:
             self.shard_floats = max(self.rs[0].shard_bytes(k) for k in range(world)) // 4
             self.send = [torch.zeros(self.shard_floats, dtype=torch.float32, device="cuda") for _ in range(self.F)]
             self.recv = [torch.zeros(world * self.shard_floats, dtype=torch.float32, device="cuda") for _ in range(self.F)]
-
-    @staticmethod
-    def shard_world_hint(shard, world):
-        return shard[1] if shard else world
 
     def _take_stats(self, i):
         if self.issued[i] and self.collect is not None:
@@ -438,10 +435,10 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--tile", type=int, default=32)
     ap.add_argument("--in-flight", type=int, default=0,
-                    help="frames in flight: renderers (own stream, own path state) taking the steps in turn; 0 = 4 on one GPU, 12 per "
-                         "rank on several (a rank's share of the frame shrinks with the world size and its kernels with it: measured on "
-                         "one GPU with 16 hardware queues, a 1/8 tile shard takes 1.39 ms per step with 12 frames in flight (6 do as well), the whole "
-                         "frame 8.40 / 7.93 / 7.88 / 7.94 with 2 / 3 / 4 / 6 before the tail threshold moved to 75 K, 7.85 with 4 after)")
+                    help="frames in flight: renderers (own stream, own path state) taking the steps in turn; 0 = 8 per GPU.  Measured on "
+                         "one GPU with 16 hardware queues since the read-back rides on the auxiliary stream (no third stream per frame) and "
+                         "leaves through a one-workgroup copy: whole frame 6.91 / 6.76 / 6.63 ms per step with 4 / 6 / 8 in flight "
+                         "(chess_like), 19.8 / 19.7 / 19.4 (atrium_like), 12.98 / 12.49 / 11.99 (street_like)")
     ap.add_argument("--backend", default="wavefront", choices=["wavefront", "megakernel"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -424,7 +424,9 @@ PTX_API int ptx_synchronize(PtxRenderer *r);
 /* imageLoad of the accumulation image: device -> host, W*H*4 floats (running SUM). */
 PTX_API int ptx_readback(PtxRenderer *r, float *rgba, size_t bytes);
 /* The same read-back, overlapped with whatever is launched next: _begin snapshots the image on the render stream and
- * starts the copy into `pinnedHost` (page-locked memory, width*height*16 bytes) on a second stream; _end waits for it.
+ * starts the copy into `pinnedHost` (page-locked memory, width*height*16 bytes) on the renderer's auxiliary stream -- a
+ * one-workgroup copy kernel when the device can address the buffer (hipHostMalloc / hipHostRegister memory; gentle on the
+ * PCIe link the other frames' dispatches share), the runtime's copy otherwise; _end waits for it.
  * A second _begin before _end queues behind the first.  (OutputSaver reads its output back a frame late in the same
  * way, OutputSaver.cpp:120-199.) */
 PTX_API int ptx_readback_begin(PtxRenderer *r, float *pinnedHost, size_t bytes);

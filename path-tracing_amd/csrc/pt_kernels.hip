@@ -184,12 +184,6 @@ PT_DEV void slotFrame(const LaunchParams &p, uint32_t slot, uint32_t &f, uint32_
     f = (wave / chunks) * g + lane % g;
     s = (wave % chunks) * pixelsPerWave + lane / g;
 }
-PT_DEV uint32_t slotOf(const LaunchParams &p, uint32_t f, uint32_t s)
-{
-    const uint32_t g = p.framesPerWave, pixelsPerWave = 64u / g;
-    const uint32_t chunks = p.slotsPerFrame / pixelsPerWave;
-    return (((f / g) * chunks + s / pixelsPerWave) << 6) + (s % pixelsPerWave) * g + f % g;
-}
 
 // slot -> pixel.  Owned tiles are rank, rank+world, ...; inside a tile pixels are laid
 // out in 8x8 blocks so that one wave64 = one 8x8 pixel block (coherent primary rays).
@@ -901,21 +895,33 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(LaunchParams p, const flo
 {
     if (pendingRestarts && *pendingRestarts != 0u)
         return;
-    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < p.slotsPerFrame; s += gridDim.x * blockDim.x)
+    // One thread per slot of a frame group: a wave reads the 64 slots of its wave-chunk with one coalesced load (8 pixels x 8
+    // frames when framesPerWave = 8), then the first lane of each pixel adds its frames in frame order through lane shuffles.
+    const uint32_t g = p.framesPerWave, pixelsPerWave = 64u / g, groups = p.frames / g;
+    const uint32_t chunks = p.slotsPerFrame / pixelsPerWave;
+    const uint32_t lane = threadIdx.x & 63u, sub = lane % g;
+    for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; base < chunks * 64u; base += gridDim.x * blockDim.x)
     {
+        const uint32_t chunk = base >> 6, s = chunk * pixelsPerWave + lane / g;
         const uint32_t pixel = slotPixel(p, s);
-        if (pixel == 0xffffffffu)
-            continue;
-        float4 acc = image[pixel];
-        for (uint32_t f = 0; f < p.frames; f++)
+        const bool owner = sub == 0u && pixel != 0xffffffffu;
+        float4 acc = owner ? image[pixel] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (uint32_t group = 0; group < groups; group++)
         {
-            const float4 r = slotRad[slotOf(p, f, s)];
-            acc.x = r.x + acc.x;
-            acc.y = r.y + acc.y;
-            acc.z = r.z + acc.z;
+            const float4 r = slotRad[((size_t)(group * chunks + chunk) << 6) + lane];
+            for (uint32_t k = 0; k < g; k++) // every lane runs the shuffles; only the owners' sums are kept
+            {
+                const float rx = __shfl(r.x, (int)(lane + k)), ry = __shfl(r.y, (int)(lane + k)), rz = __shfl(r.z, (int)(lane + k));
+                acc.x = rx + acc.x;
+                acc.y = ry + acc.y;
+                acc.z = rz + acc.z;
+            }
         }
-        acc.w = 1.0f;
-        image[pixel] = acc;
+        if (owner)
+        {
+            acc.w = 1.0f;
+            image[pixel] = acc;
+        }
     }
 }
 
@@ -1290,6 +1296,13 @@ __global__ void __launch_bounds__(kBlock) k_trace_rays(TraceScene sc, const floa
 }
 
 // shard pack / unpack: tile-major dense buffer [ownedTile][tileSize^2] of RGBA32F
+// the image to page-locked host memory with a few workgroups: posted writes over PCIe
+__global__ void __launch_bounds__(kBlock) k_copy_out(const float4 *__restrict__ src, float4 *__restrict__ dst, uint32_t n)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+
 __global__ void k_pack_shard(LaunchParams p, const float4 *__restrict__ image, float4 *__restrict__ dst)
 {
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < p.slotsPerFrame; s += gridDim.x * blockDim.x)
@@ -3391,7 +3404,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
         // raygen.rgen:62: the bounce loop never runs, every sample ends with radiance 0 -- nothing is generated, traced or
         // shaded (the wavefront kernels test the bounce limit only AFTER a bounce); the image still gets its alpha
         HIP_TRY(r, hipMemsetAsync(r->slotRad.p, 0, (size_t)p.numSlots * sizeof(float4), r->stream));
-        k_accumulate<<<gridFor(p.slotsPerFrame), kBlock, 0, r->stream>>>(p, r->slotRad.p, imagePtr(r), nullptr);
+        k_accumulate<<<gridFor((size_t)p.slotsPerFrame * p.framesPerWave), kBlock, 0, r->stream>>>(p, r->slotRad.p, imagePtr(r), nullptr);
         HIP_TRY(r, hipEventRecord(r->evB, r->stream));
         HIP_TRY(r, hipGetLastError());
         r->stats.pathSamples = (uint64_t)p.ownedPixels * frames * uniform->SampleCount;
@@ -3407,7 +3420,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
             k_megakernel<1><<<grid, kBlock, 0, r->stream>>>(p, sv, sc, r->slotRad.p, r->counters.p);
         else
             k_megakernel<0><<<grid, kBlock, 0, r->stream>>>(p, sv, sc, r->slotRad.p, r->counters.p);
-        k_accumulate<<<gridFor(p.slotsPerFrame), kBlock, 0, r->stream>>>(p, r->slotRad.p, imagePtr(r), nullptr);
+        k_accumulate<<<gridFor((size_t)p.slotsPerFrame * p.framesPerWave), kBlock, 0, r->stream>>>(p, r->slotRad.p, imagePtr(r), nullptr);
         HIP_TRY(r, hipMemcpyAsync(r->hostCounters, r->counters.p, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
         HIP_TRY(r, hipEventRecord(r->evB, r->stream));
         HIP_TRY(r, hipStreamSynchronize(r->stream));
@@ -3510,7 +3523,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
                 return rcq;
         }
     }
-    k_accumulate<<<gridFor(p.slotsPerFrame), kBlock, 0, r->stream>>>(p, r->slotRad.p, imagePtr(r), nullptr);
+    k_accumulate<<<gridFor((size_t)p.slotsPerFrame * p.framesPerWave), kBlock, 0, r->stream>>>(p, r->slotRad.p, imagePtr(r), nullptr);
     HIP_TRY(r, hipMemcpyAsync(r->hostCounters, r->counters.p, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(r, hipEventRecord(r->evB, r->stream));
     HIP_TRY(r, hipGetLastError());
@@ -3566,20 +3579,37 @@ int ptx_readback_begin(PtxRenderer *r, float *pinnedHost, size_t bytes)
     if (!r || !pinnedHost || !imagePtr(r) || bytes != (size_t)r->width * r->height * sizeof(float4))
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_readback_begin: buffer must be width*height*16 bytes");
     HIP_TRY(r, hipSetDevice(r->device));
-    if (!r->copyStream)
+    if (!r->evSnapshot)
     {
-        HIP_TRY(r, hipStreamCreateWithFlags(&r->copyStream, hipStreamNonBlocking));
         HIP_TRY(r, hipEventCreateWithFlags(&r->evSnapshot, hipEventDisableTiming));
         HIP_TRY(r, hipEventCreateWithFlags(&r->evCopied, hipEventDisableTiming));
     }
+    // The copy to the host rides on the renderer's auxiliary stream -- idle once the frame's shadow and tail kernels are done,
+    // and not needed again before this renderer's next frame -- instead of a third stream per frame in flight: the streams of a
+    // process share GPU_MAX_HW_QUEUES hardware queues, and streams on one queue run one after the other.
+    if (!r->auxStream && !r->copyStream)
+        HIP_TRY(r, hipStreamCreateWithFlags(&r->copyStream, hipStreamNonBlocking));
+    const hipStream_t copyOn = r->auxStream ? r->auxStream : r->copyStream;
     HIP_TRY(r, r->staging.alloc((size_t)r->width * r->height));
     if (r->copyInFlight) // the previous copy still reads the staging image
         HIP_TRY(r, hipStreamWaitEvent(r->stream, r->evCopied, 0));
     HIP_TRY(r, hipMemcpyAsync(r->staging.p, imagePtr(r), bytes, hipMemcpyDeviceToDevice, r->stream));
     HIP_TRY(r, hipEventRecord(r->evSnapshot, r->stream));
-    HIP_TRY(r, hipStreamWaitEvent(r->copyStream, r->evSnapshot, 0));
-    HIP_TRY(r, hipMemcpyAsync(pinnedHost, r->staging.p, bytes, hipMemcpyDeviceToHost, r->copyStream));
-    HIP_TRY(r, hipEventRecord(r->evCopied, r->copyStream));
+    HIP_TRY(r, hipStreamWaitEvent(copyOn, r->evSnapshot, 0));
+    // The snapshot leaves through ONE workgroup writing to the page-locked buffer (posted writes over PCIe, 33 MB in a few ms)
+    // rather than through hipMemcpyAsync: a DMA burst at the link's full rate delays the completion signals and packet fetches
+    // of every other frame in flight for its 1.2 ms -- measured on chess_like with 8 frames in flight: no read-back 2,600
+    // Msamples/s, hipMemcpyAsync (SDMA) 2,416 / 2,422, copy kernel with 256 / 64 / 8 / 4 / 2 / 1 workgroups 2,359 / 2,395 / 2,445
+    // / 2,441 / 2,465 / 2,483-2,494.  Host memory the device cannot address (not page-locked) takes the runtime's copy.
+    void *hostOnDevice = nullptr;
+    if (hipHostGetDevicePointer(&hostOnDevice, pinnedHost, 0) == hipSuccess && hostOnDevice)
+        k_copy_out<<<1, kBlock, 0, copyOn>>>(r->staging.p, static_cast<float4 *>(hostOnDevice), (uint32_t)(bytes / sizeof(float4)));
+    else
+    {
+        (void)hipGetLastError();
+        HIP_TRY(r, hipMemcpyAsync(pinnedHost, r->staging.p, bytes, hipMemcpyDeviceToHost, copyOn));
+    }
+    HIP_TRY(r, hipEventRecord(r->evCopied, copyOn));
     r->copyInFlight = true;
     return PTX_OK;
 }
@@ -3590,7 +3620,7 @@ int ptx_readback_end(PtxRenderer *r)
         return PTX_ERROR_INVALID_ARGUMENT;
     if (r->copyInFlight)
     {
-        HIP_TRY(r, hipStreamSynchronize(r->copyStream));
+        HIP_TRY(r, hipEventSynchronize(r->evCopied));
         r->copyInFlight = false;
     }
     return PTX_OK;
