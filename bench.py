@@ -130,7 +130,7 @@ class Job:
     resources per frame: Renderer.cpp:1454-1460,1617-1618).  ptx_render only ENQUEUES a frame (the bounce loop is driven
     from the device), so nothing in a step waits for the GPU; a renderer's statistics are read when its turn comes again."""
 
-    def __init__(self, args, pkg, torch, dist, scene_name, rank, world, local_rank, shard=None):
+    def __init__(self, args, pkg, torch, dist, scene_name, rank, world, local_rank, shard=None, alone_steps=0):
         self.args, self.pkg, self.torch, self.dist = args, pkg, torch, dist
         self.rank, self.world = rank, world
         self.W, self.H = args.width, args.height
@@ -138,19 +138,25 @@ class Job:
         self.lights = self.scene.lights
         backend = pkg.BACKEND_WAVEFRONT if args.backend == "wavefront" else pkg.BACKEND_MEGAKERNEL
         self.F = args.in_flight if args.in_flight > 0 else 8
-        self.streams = [torch.cuda.Stream() for _ in range(self.F)]
-        self.rs = [pkg.Renderer(device=local_rank, backend=backend, stream=s.cuda_stream) for s in self.streams]
         self.shard_rank, self.shard_world = shard if shard else (rank, world)
+        self.u = self.scene.uniform(self.W, self.H, bounces=args.depth)
+        self.streams = [torch.cuda.Stream()]
+        self.rs = [pkg.Renderer(device=local_rank, backend=backend, stream=self.streams[0].cuda_stream)]
         t0 = time.time()
         self.rs[0].upload(self.scene)
         self.rs[0].synchronize()
         self.upload_build_s = time.time() - t0
+        self.rs[0].resize(self.W, self.H)
+        self.rs[0].set_tile_shard(self.shard_rank, self.shard_world, args.tile)
+        # One frame at a time while this renderer's two streams are the only ones of the process (see alone())
+        self.alone_stats = self.alone(args.spp, alone_steps) if alone_steps > 0 else None
+        for _ in range(1, self.F):
+            self.streams.append(torch.cuda.Stream())
+            self.rs.append(pkg.Renderer(device=local_rank, backend=backend, stream=self.streams[-1].cuda_stream))
         for r in self.rs[1:]:  # the frames in flight share one scene and one tree, as the reference's per-frame resources do
             r.share_scene(self.rs[0])
-        for r in self.rs:
             r.resize(self.W, self.H)
             r.set_tile_shard(self.shard_rank, self.shard_world, args.tile)
-        self.u = self.scene.uniform(self.W, self.H, bounces=args.depth)
         self.build_ms = self.rs[0].stats().lastBuildMs
         self.n_tris = self.scene.triangle_count
         self.nbytes = self.W * self.H * 16
@@ -264,21 +270,35 @@ class Job:
                 break
         return float(np.median(regions)), regions, stats
 
-    def exclusive(self, job_spp, steps):
-        """The same frames ONE at a time (every step waits for its frame), outside the timed region: the kernels' durations
-        without other frames' kernels sharing the machine.  With frames in flight a launch's duration counts the time it
-        shares the CUs with the launches of the other frames, so the per-launch figure of the timed region falls as the
-        overlap (and the throughput) rises; this one is the kernel's own."""
-        self.finish()
+    def alone(self, job_spp, steps):
+        """The same frames ONE at a time on the first renderer, before the other frames in flight exist: the kernels' durations
+        without other frames' kernels sharing the machine, and the latency of one frame batch.  With frames in flight a launch's
+        duration counts the time it shares the CUs with the launches of the other frames, so the per-launch figure of the timed
+        region falls as the overlap (and the throughput) rises; this one is the kernel's own.  Measured BEFORE the other renderers
+        are created because the events that bracket a launch pass through the command processor, which takes longer once more
+        hardware queues are mapped, whether they have work or not (the same three steps right after a timed region with 2 / 4 / 8
+        frames in flight: 0.78 / 0.83 / 0.87 ms per closest-hit launch, 9.7 / 11.2 / 11.0-11.4 ms per frame; a process with ONE
+        frame in flight, which is what `rocprofv3 --kernel-trace` of `--in-flight 1` sees: 0.75-0.77 and 9.6-9.8)."""
+        r = self.rs[0]
+        for _ in range(2):  # buffers, the bounce schedule (the first launch of a shape is driven from the host)
+            r.reset()
+            r.render_frames(self.u, self.lights, 0, job_spp)
+            r.synchronize()
         c = {"trace_ms": 0.0, "shade_ms": 0.0, "shadow_ms": 0.0, "tail_ms": 0.0, "launches": 0, "rays": 0, "segments": 0, "shadow": 0}
-        self.collect = c
         t0 = time.perf_counter()
         for _ in range(steps):
-            self.step(job_spp, readback=False)
-            self.rs[(self.k - 1) % self.F].synchronize()
+            r.reset()
+            r.render_frames(self.u, self.lights, 0, job_spp)
+            r.synchronize()
+            st = r.stats()
+            c["trace_ms"] += st.lastTraceMs
+            c["shade_ms"] += st.lastShadeMs
+            c["shadow_ms"] += st.lastShadowMs
+            c["tail_ms"] += st.lastTailMs
+            c["launches"] += st.traceLaunches // 2
+            c["rays"] += st.tracedRays
+            c["segments"], c["shadow"] = st.segments, st.shadowRays
         c["wall_s"], c["steps"] = time.perf_counter() - t0, steps
-        self.finish()
-        self.collect = None
         return c
 
     def close(self):
@@ -332,7 +352,7 @@ def roofline(job, stats, digest, stats_x=None, step_ms=None, segments_per_sample
 
     Which duration: with frames in flight a launch's duration counts the time it shares the machine with the other frames'
     launches -- six launches of 1.6 ms per 7.7 ms step are more than the step -- so the top-level figures use the launch ALONE on
-    the machine (`stats_x`: the same frames one at a time, measured live right after the timed region), and the timed region's
+    the machine (`stats_x`: the same frames one at a time, measured live before the other frames in flight exist), and the timed region's
     overlapped durations ride in `overlapped`.  `step` prices the WHOLE step instead of one kernel: model bytes per sample x samples
     and the sum of every render kernel's counter bytes, over the step time of the timed region."""
     bpr = algorithmic_bytes_per_closest_ray(job.n_tris)
@@ -341,7 +361,7 @@ def roofline(job, stats, digest, stats_x=None, step_ms=None, segments_per_sample
     out = {
         "bound": "latency", "priced_against": "hbm", "kernel": "k_trace_closest", "achieved": top["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": top["frac"], "traffic": None, "achieved_counter": None, "frac_counter": None,
-        "measured": ("launch alone on the machine (the same frames one at a time, live HIP events after the timed region)" if top is not over
+        "measured": ("launch alone on the machine (the same frames one at a time on the first renderer, live HIP events, before the other frames in flight exist)" if top is not over
                      else "launches of the timed region (live HIP events)"),
         "model_bytes_per_ray": bpr, "model_bytes_per_launch": top["model_bytes_per_launch"],
         "rays_per_launch": top["rays_per_launch"], "avg_launch_ms": top["avg_launch_ms"], "launches": top["launches"],
@@ -382,12 +402,12 @@ def roofline(job, stats, digest, stats_x=None, step_ms=None, segments_per_sample
 
 def scene_line(args, pkg, torch, dist, orc, name, rank, world, local_rank, steps, warmup, min_seconds, with_cpu, digest):
     """Measure one scene: the read-back-inclusive rate (value), the rate without read-back, roofline, CPU baseline."""
-    job = Job(args, pkg, torch, dist, name, rank, world, local_rank)
+    job = Job(args, pkg, torch, dist, name, rank, world, local_rank, alone_steps=3 if world == 1 and args.backend == "wavefront" else 0)
     W, H = job.W, job.H
     spp = args.spp
     med, regions, stats = job.measure(spp, steps, warmup, args.repeats, min_seconds, readback=True)
     med_nr, regions_nr, _ = job.measure(spp, steps, 0, max(1, min(len(regions), 3)), 0.0, readback=False)
-    stats_x = job.exclusive(spp, 3) if world == 1 and args.backend == "wavefront" else None
+    stats_x = job.alone_stats
     line = None
     if rank == 0:
         samples = W * H * spp * steps
@@ -505,14 +525,24 @@ def main():
         out = dict(common, scaling="strong", **line)  # N = 1 of the strong-scaling series: the named 8-spp frame
         out["config"]["parallelism"] = "pixel-tile shard x1"
         if not args.no_extra_scenes and args.scene == "chess_like":
-            # the same measurement on the other stand-ins; fewer steps per region: their steps are longer
-            # (not too few: a region starts and ends with an empty ring of frames in flight)
+            # the same measurement on the other stand-ins: the same K steps per region (a region starts
+            # and ends with an empty ring of frames in flight, and with 8 of them half as many steps read 5-15 % lower), each in
+            # a process of its own, as `bench.py --scene NAME` runs it -- behind another scene's job in THIS process atrium_like
+            # reads 10 % lower (756 against 845 Msamples/s on one box: its 460 MB tree lands in memory the first job used and freed)
+            import subprocess
             out["configs"] = []
+            mine = set(common) | {"scaling"}
             for name in EXTRA_SCENES:
-                steps = max(3, args.steps // 2)
-                l = scene_line(args, pkg, torch, dist, orc, name, 0, 1, local_rank, steps, 2, min(args.min_seconds, 1.5),
-                               not args.no_cpu_baseline, digest)
-                out["configs"].append(l)
+                cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--scene", name, "--no-extra-scenes", "--steps", str(args.steps),
+                       "--warmup", "2", "--repeats", str(args.repeats), "--min-seconds", str(min(args.min_seconds, 1.5)),
+                       "--detail", str(args.detail), "--width", str(W), "--height", str(H), "--spp", str(args.spp), "--depth", str(args.depth),
+                       "--tile", str(args.tile), "--in-flight", str(args.in_flight), "--backend", args.backend,
+                       "--cpu-seconds", str(args.cpu_seconds)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+                p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+                if p.returncode != 0:
+                    raise SystemExit(f"[bench] the `configs` run of {name} failed (exit code {p.returncode})")
+                l = json.loads(p.stdout.strip().splitlines()[-1])
+                out["configs"].append({k: v for k, v in l.items() if k not in mine})
         print(json.dumps(out), flush=True)
         return
 

@@ -18,7 +18,7 @@ CMD="python3 bench.py --steps 5 --warmup 1 --repeats 1 --no-cpu-baseline --no-ex
 TRACE_CMD="python3 bench.py --repeats 1 --no-cpu-baseline --no-extra-scenes $*"
 for d in trace fetch write sq1 sq2; do rm -rf gpurun_out/${TAG}_$d; done
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace -o $TAG -- $TRACE_CMD > gpurun_out/${TAG}_trace.log 2>&1; echo "trace rc=$?"
-# the same workload with ONE frame in flight: what bench.py's roofline.exclusive measures live (launch durations without other
+# the same workload with ONE frame in flight: what bench.py's top-level roofline measures live (launch durations without other
 # frames' kernels on the machine; tracing perturbs the overlap of the default command, not this)
 rm -rf gpurun_out/${TAG}_trace1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace1 -o $TAG -- $TRACE_CMD --in-flight 1 > gpurun_out/${TAG}_trace1.log 2>&1; echo "trace1 rc=$?"
