@@ -308,7 +308,7 @@ class Job:
 
 
 RENDER_KERNELS = ("k_generate", "k_prologue", "k_trace_closest", "k_shade", "k_shade_tex", "k_shade_split", "k_trace_shadow", "k_apply_shadow", "k_tail",
-                  "k_finish_restarts", "k_restart", "k_accumulate", "k_upload_lights", "__amd_rocclr_copyBuffer", "__amd_rocclr_fillBufferAligned")
+                  "k_finish_restarts", "k_restart", "k_accumulate", "k_copy_out", "k_upload_lights", "__amd_rocclr_copyBuffer", "__amd_rocclr_fillBufferAligned")
 
 
 def segment_model_bytes(n_tris: int) -> int:
