@@ -196,6 +196,39 @@ def test_batched_frames_equal_sequential_launches(pkg):
     assert (seq.view(np.uint32) == batched.view(np.uint32)).all()
 
 
+@pytest.mark.parametrize("backend", ["wavefront", "megakernel"])
+def test_pipelined_readback_paths(pkg, backend):
+    """ptx_readback_begin / _end: the snapshot is the image at the time of _begin whatever is rendered next, through the
+    one-workgroup copy kernel (page-locked buffer, on the auxiliary stream -- or the copy stream of a backend without one) and
+    through the runtime's copy (pageable buffer the device cannot address)."""
+    import torch
+
+    scene = pkg.Scene("chess_like", 0.05)
+    W, H = 168, 104
+    r = pkg.Renderer(backend=pkg.BACKEND_WAVEFRONT if backend == "wavefront" else pkg.BACKEND_MEGAKERNEL)
+    r.upload(scene)
+    r.resize(W, H)
+    u = scene.uniform(W, H, bounces=5)
+    r.render_frames(u, scene.lights, 0, 8)
+    first = r.readback()
+    pinned = torch.empty(W * H * 4, dtype=torch.float32, pin_memory=True)
+    pinned.fill_(-1.0)
+    pageable = np.full((H, W, 4), -1.0, dtype=np.float32)
+    for ptr, view in ((pinned.data_ptr(), lambda: pinned.numpy().reshape(H, W, 4)), (pageable.ctypes.data, lambda: pageable)):
+        r.readback_begin(ptr, W * H * 16)
+        r.reset()  # the next frame starts at once: it must not show in the snapshot
+        r.render_frames(u, scene.lights, 8, 8)
+        r.readback_end()
+        assert (view().view(np.uint32) == first.view(np.uint32)).all()
+        second = r.readback()
+        r.reset()
+        r.render_frames(u, scene.lights, 0, 8)
+    assert not (second.view(np.uint32) == first.view(np.uint32)).all()
+    with pytest.raises(pkg.PtxError):
+        r.readback_begin(pinned.data_ptr(), W * H * 16 - 16)
+    r.close()
+
+
 def test_multi_sample_launch_matches_oracle(pkg, orc):
     # SampleCount > 1 in ONE launch: the RNG state is carried across samples (raygen.rgen:42-46)
     scene = pkg.Scene("default")
