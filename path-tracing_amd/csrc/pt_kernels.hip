@@ -1954,14 +1954,30 @@ static uint32_t gridFor(size_t n, uint32_t block = kBlock, uint32_t cap = 256 * 
 // Grid of a persistent traversal kernel.  A launch never finishes before its longest ray (hundreds of dependent node
 // fetches), which is many times an average ray: giving every thread several rays of a SMALL launch costs nothing, and
 // leaves compute units free for the kernel running beside it on the other stream.
-static uint32_t g_raysPerThread = 4; // PTX_RAYS_PER_THREAD; measured 1 / 2 / 4 / 8 / 16: 12.79 / 12.68 / 12.64 / 12.93 / 13.99 ms per step (3.72 / 3.67 / 3.64 / 3.65 / 4.01 on a 1/8 shard)
+// Rays per thread: PTX_RAYS_PER_THREAD fixes it; otherwise 4 while the process holds fewer than four renderers -- a frame alone
+// on the machine wants every launch spread over all of it (one frame in flight: 9.6 ms per frame with 4, 10.6 with 8 / 12) -- and,
+// with four or more (frames in flight share the machine), 8, or 12 for a launch below 3 M rays: a SMALL launch then does better
+// with fewer, longer-lived waves -- a wave that works through eight chunks drains its stragglers once, not once per two chunks,
+// and holds a quarter of the wave slots meanwhile.  Measured with eight frames in flight on 16 hardware queues, 4 / 6 / 8 / 12 rays
+// per thread: a rank's tile shard of 8 (2.07 M slots) 1.158 / 1.100 / 1.085 / 1.074 ms per step, of 4: 1.912 / 1.903 / 1.886 /
+// 1.846, of 2: 3.442 / 3.431 / 3.401 / 3.355; the whole frame, read-back included, three interleaved runs of 4 / this rule / 8:
+// chess_like 2,439 / 2,437 / 2,444 Msamples/s, atrium_like 816 / 812 / 820; 16 and 32 lose on both.
+static uint32_t g_raysPerThread = 0;
+static std::atomic<uint32_t> g_liveHandles{0};
+static uint32_t raysPerThreadFor(size_t n)
+{
+    if (g_raysPerThread)
+        return g_raysPerThread;
+    return g_liveHandles.load(std::memory_order_relaxed) < 4u ? 4u : (n < 3000000u ? 12u : 8u);
+}
 // A persistent kernel must not launch more blocks than the chip holds at once: with the static chunk schedule the chunks
 // of a block that is not resident yet wait until a resident block has drained the whole queue, and then run on a mostly
 // empty chip.  residentBlocks = occupancy (blocks per CU, from the kernel's VGPR / LDS use) x compute units.
 static uint32_t g_residentCap = 1; // PTX_RESIDENT_CAP=0: the old fixed cap of 2048 blocks
 static uint32_t traceGridFor(size_t n, uint32_t residentBlocks = 0)
 {
-    const uint32_t g = gridFor((n + g_raysPerThread - 1) / g_raysPerThread);
+    const uint32_t per = raysPerThreadFor(n);
+    const uint32_t g = gridFor((n + per - 1) / per);
     return g_residentCap && residentBlocks && g > residentBlocks ? residentBlocks : g;
 }
 
@@ -2024,7 +2040,6 @@ static uint32_t hardwareQueuesGranted()
     const unsigned long v = e ? strtoul(e, nullptr, 10) : 0ul;
     return v ? (uint32_t)v : 4u; // the runtime's default
 }
-static std::atomic<uint32_t> g_liveHandles{0};
 static std::atomic<bool> g_queueWarningGiven{false};
 
 extern "C" {
