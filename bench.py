@@ -6,8 +6,9 @@ readback / gather" (SURVEY.md 8d).
 A "step" is one pass of the hot path over one frame batch: reset the accumulation image, add `spp` samples per pixel
 (canonical schedule: one sample per launch, RNG frame = launch index), with N > 1 GPUs gather the
 pixel-tile shards to rank 0 (the single RCCL exchange of SURVEY.md 8e), and read the RGBA32F sum back to page-locked
-host memory.  The read-back of step k overlaps the rendering of step k + 1 (ptx_readback_begin: device-side snapshot,
-PCIe copy on a second stream -- the reference reads its output back a frame late too, OutputSaver.cpp:120-199); the
+host memory.  The read-back of step k overlaps the rendering of the steps behind it (ptx_readback_begin: device-side snapshot,
+then a one-workgroup copy to the page-locked buffer on the renderer's auxiliary stream -- the reference reads its output back
+a frame late too, OutputSaver.cpp:120-199); the
 timed region ends when the last image is on the host.  `value` is that read-back-inclusive rate; the rate without any
 read-back is reported beside it (`no_readback`).  Scene upload and the tree build are outside the timed region (the
 reference builds its acceleration structures in UpdateSceneData, not in Render).  Inputs are resident in HBM when the
@@ -15,7 +16,8 @@ timed region starts.
 
 Workload at N = 1: BASELINE configs[1] "ABeautifulGame, 1920x1080, 8 spp, depth 8" through its procedural stand-in
 `chess_like` (the glTF assets are downloaded at CMake time by the reference and do not exist offline).
-The same line for the stand-ins of configs[3] (north_star's target scene), [2] and [4] rides in `configs`.
+The same line for the stand-ins of configs[3] (north_star's target scene), [2] and [4] rides in `configs`, each measured
+as `bench.py --scene NAME` in a child process with the same K.
 
 N > 1: the frame is cut into 32x32 pixel tiles dealt round-robin to the ranks; no collective inside the data path, one
 all_gather of the tile shards per step.  The reported metric is the NAMED frame split over the GPUs (`"scaling":
@@ -24,14 +26,16 @@ is the same frame at 8 N spp, which is how BASELINE configs[3] and [4] are posed
 printed in `weak`.
 
 Frames in flight (`--in-flight`, default 8 per GPU: two streams each = the 16 hardware queues; more share queues and lose --
-a rank's 1/8 tile shard takes 1.15 / 1.24 / 1.19 ms per step with 8 / 12 / 16 in flight): consecutive steps run on renderers that take turns, each on its own stream
+a rank's 1/8 tile shard takes 1.15 / 1.24 / 1.19 ms per step with 8 / 12 / 16 in flight):
+consecutive steps run on renderers that take turns, each on its own stream
 with its own path state, as the reference keeps frames in flight (Renderer.cpp:1454-1460): ptx_render only enqueues a
 frame -- the bounce loop is driven from the device -- so the latency-bound end of one frame overlaps the head of the
 next.  Every step is still one complete frame: reset, 8 spp, gather, read-back.
 
-Order of a run: setup (scene, tree build, and one frame per renderer of the ring so that its buffers exist and its bounce
-schedule has been learnt -- preparation per renderer, like the build), W warm-up steps, then the timed region of exactly K
-steps.  The region is repeated (`--repeats`, default: until >= 2 s have been timed) and the line reports the MEDIAN
+Order of a run: scene and tree build on the first renderer; at N = 1 the launch-alone leg on it (Job.alone: the same frames one
+at a time before any other renderer exists -- the top level of `roofline`, `one_in_flight_*`); the other renderers of the ring
+and one frame on each so that its buffers exist and its bounce schedule has been learnt (preparation per renderer, like the
+build); W warm-up steps; then the timed region of exactly K steps.  The region is repeated (`--repeats`, default: until >= 2 s have been timed) and the line reports the MEDIAN
 region; min / max ride in `spread`.
 
 Launch:  python bench.py --gpus N --steps K --warmup W           (N = 1)
