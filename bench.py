@@ -92,8 +92,8 @@ def effective_cores() -> int:
 def source_digest(pkg) -> str:
     """Identity of the kernels being measured: the HIP sources the library is built from."""
     h = hashlib.sha256()
-    for f in ("pt_kernels.hip", "pt_bvh.hpp", "pt_device.hpp", "pt_post.hpp"):
-        h.update(open(os.path.join(pkg.PKG_DIR, "csrc", f), "rb").read())
+    for f in pkg.hip_sources():
+        h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -28,7 +28,7 @@ import weakref
 import numpy as np
 
 # The runtime maps all HIP streams of the process onto GPU_MAX_HW_QUEUES hardware queues (default 4); frames in flight need
-# one per stream to overlap (csrc/pt_kernels.hip, hardwareQueuesGranted).  It is read at the first HIP call, so it has to
+# one per stream to overlap (csrc/pt_runtime.hpp, hardwareQueuesGranted).  It is read at the first HIP call, so it has to
 # be in the environment before torch initialises the device -- and it is the host's to set, which for Python callers is
 # this package at import time (no thread of ours exists yet); the C library only reports what it finds.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
@@ -171,11 +171,19 @@ def _newer(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
+HIP_TRANSLATION_UNIT = "ptx_capi.hip"  # the one translation unit of libptx_hip.so; it includes every header of csrc/
+
+
+def hip_sources():
+    """Every source file of the HIP library, the translation unit first (build dependencies, source digests of the profiles)."""
+    csrc = os.path.join(PKG_DIR, "csrc")
+    return [os.path.join(csrc, HIP_TRANSLATION_UNIT)] + sorted(glob.glob(os.path.join(csrc, "*.hpp")))
+
+
 def build(force: bool = False, verbose: bool = True) -> None:
     """Compile the HIP extension for gfx950 and the C++ host mirror, in-tree."""
     csrc = os.path.join(PKG_DIR, "csrc")
-    hip_src = [os.path.join(csrc, f) for f in ("pt_kernels.hip", "pt_bvh.hpp", "pt_device.hpp", "pt_post.hpp")] + [
-        os.path.join(REPO_DIR, "include", "ptx.h")]
+    hip_src = [os.path.join(csrc, HIP_TRANSLATION_UNIT)] + hip_sources()[1:] + [os.path.join(REPO_DIR, "include", "ptx.h")]
     if force or _newer(HIP_LIB, hip_src):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         cmd = [hipcc] + HIPCC_FLAGS + ["-o", HIP_LIB, hip_src[0]]

@@ -1,27 +1,8 @@
-// pt_kernels.hip -- HIP kernels of the path-tracing pass for gfx950 (MI355X) and the
-// C-ABI of include/ptx.h.
-//
-// The reference runs ONE ray-tracing pipeline dispatch per frame,
-//   vkCmdTraceRaysKHR(W, H, 1)            (Renderer/Renderer.cpp:911-917)
-// whose raygen shader (Shaders/raygen.rgen:36-118) loops over samples and bounces and
-// calls traceRayEXT twice per bounce (closest hit :68, occlusion :31).  Recursion depth
-// is 1, i.e. the path is an iterative loop in raygen: that loop is cut here at the two
-// traceRayEXT calls into a queue-per-stage WAVEFRONT:
-//
-//   k_generate        raygen.rgen:38-60   RNG seed, primary ray
-//   k_trace_closest   raygen.rgen:68      closest-hit query over the active queue
-//   k_shade           closestHit.rchit / miss.rmiss + raygen.rgen:71-96 bookkeeping
-//   k_trace_shadow    raygen.rgen:22-34   occlusion query: one answer per shadow-queue entry
-//   k_apply_shadow    raygen.rgen:79-81   NEE add of the visible lights, finish of the paths that ended on this bounce
-//   k_accumulate      raygen.rgen:115-117  image += radiance, in frame order
-//
-// Every path slot is (frame, pixel); its state lives in SoA arrays in HBM; queues hold
-// slot indices and are compacted by wave-aggregated atomics.  A bring-up MEGAKERNEL
-// (one thread per slot running the loop 1:1) shares all device functions and is kept as
-// the in-tree A/B reference of the wavefront.
-//
-// No CPU fallback exists: without a HIP device ptx_create fails.
-#include <hip/hip_runtime.h>
+// pt_runtime.hpp -- host side of the HIP library: the renderer object behind a PtxRenderer handle, its device buffers, scene
+// upload, the tree build (kernels: pt_bvh_build.hpp), the bounce schedule of the wavefront backend, read-back, the output
+// stage.  Functions here take a valid handle; include/ptx.h's entry points (ptx_capi.hip) are thin wrappers around them.
+// No CPU fallback exists: without a HIP device createRenderer fails.
+#pragma once
 
 #include <atomic>
 #include <cstdarg>
@@ -31,1669 +12,9 @@
 #include <string>
 #include <vector>
 
-#include "pt_bvh.hpp"
+#include "pt_aux_kernels.hpp"
+#include "pt_bvh_build.hpp"
 #include "pt_post.hpp"
-
-using namespace ptd;
-
-// =====================================================================================
-// Launch parameters
-// =====================================================================================
-
-// Per-slot path state is written by one kernel and read once by the next: a stream.  Its loads and stores carry the
-// non-temporal hint (global_load / global_store ... nt), so that the 4 MB of L2 an XCD has keep tree nodes and texels instead
-// of records nobody reads twice.  Measured (1 MI355X, 1080p, 8 spp, two runs each in one call, plain -> nt): atrium_like
-// 788 / 789 -> 811 / 823 Msamples/s, chess_like 2,248 / 2,229 -> 2,267 / 2,262, temple_like 898 / 883 -> 905 / 895, street_like
-// flat; the hint on the loads alone or on the stores alone gives half of it; on the ShadeTri reads it costs 4 % (the samples
-// of one pixel sit in neighbouring lanes and share them).
-template <typename T> struct StreamWord { typedef T type; };
-template <> struct StreamWord<float4> { typedef float type __attribute__((ext_vector_type(4))); };
-template <> struct StreamWord<uint4> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
-template <typename T> struct StreamRef
-{
-    T *p;
-    typedef typename StreamWord<T>::type W;
-    PT_DEV operator T() const
-    {
-        const W w = __builtin_nontemporal_load(reinterpret_cast<const W *>(p));
-        T v;
-        __builtin_memcpy(&v, &w, sizeof(T));
-        return v;
-    }
-    PT_DEV void operator=(const T &v) const
-    {
-        W w;
-        __builtin_memcpy(&w, &v, sizeof(T));
-        __builtin_nontemporal_store(w, reinterpret_cast<W *>(p));
-    }
-};
-template <typename T> struct Stream // wf.rayO[slot] reads and writes as before; wf.rayO.p[slot] is the plain access
-{
-    T *p;
-    PT_DEV StreamRef<T> operator[](size_t i) const { return StreamRef<T>{p + i}; }
-    __host__ __device__ Stream &operator=(T *q) { p = q; return *this; }
-    __host__ __device__ explicit operator bool() const { return p != nullptr; }
-};
-
-struct Wavefront // device pointers of the per-slot state (SoA)
-{
-    Stream<float4> rayO;   // origin.xyz, w = MaxRoughness (payload.MaxRoughness)
-    Stream<float4> rayD;   // direction.xyz
-    Stream<float4> thr;    // throughput.rgb
-    Stream<float4> rad;    // radiance.rgb accumulated over the samples of this launch
-    Stream<uint4> meta;    // x = rngState, y = pixel (y*W+x) or 0xffffffff, z = bounce | smpl<<16, w = frame
-    Stream<float4> hit;    // t, u, v, triangle slot in leaf order (bits)
-    Stream<uint32_t> hitPair;
-    Stream<float4> shO;    // shadow origin.xyz, w = tmax (LightDistance)
-    Stream<float4> shD;    // shadow direction.xyz, w = 1 if the path ends after this bounce
-    Stream<float4> shC;    // NEE contribution throughput * DirectLight / DirectLightPdf
-    Stream<float4> slotRad; // final radiance of the slot (consumed by k_accumulate)
-    Stream<float4> decal;   // nearest ignored any-hit candidate: (triangle slot, u, v, pair) -- k_shade fetches its colour and alpha
-    Stream<float> decalT;   // (payload.LightDirection / LightDistance) if the hit lies behind it; null unless the scene has non-opaque
-                     // geometry.  decalT = its distance or -1 (payload.DirectLightPdf)
-    Stream<float4> diff[3]; // payload.RayDifferentials0..2 (rx origin, rx dir, ry origin, ry dir); null unless the scene has textures
-    uint32_t *queue[2];
-    uint32_t *shadowQueue;
-    uint8_t *shadowResult; // per shadow queue entry: bit 0 = the light is visible, bit 1 = the path ends here (k_apply_shadow)
-    uint32_t *restartQueue;
-    uint32_t *counters; // see enum Counter
-    uint32_t *spill;    // traversal stack overflow region [kGlobalSpill][kMaxPersistentThreads]
-};
-
-// Every counter sits on its own 128-byte line: atomics to one L2 line serialise (~11 ns each on MI355X) whatever
-// word they touch, and the queue, chunk and statistics counters are all hot in the same kernels.
-constexpr int kCounterStride = 32; // uint32 words
-constexpr int kMaxTimedBounces = 64; // per-bounce bookkeeping (live counts for the statistics, kernel timing events) up to this depth
-enum Counter
-{
-    C_ACTIVE0 = 0 * kCounterStride,
-    C_ACTIVE1 = 1 * kCounterStride,
-    C_SHADOW = 2 * kCounterStride,    // shadow queue of even bounces (the shadow kernel of bounce b runs beside bounce b + 1: two sets)
-    C_HITS = 3 * kCounterStride,      // closest-hit shader invocations (= occlusion queries of the reference)
-    C_SAMPLES = 4 * kCounterStride,   // completed pixel-samples incl. retries
-    C_RETRIES = 5 * kCounterStride,
-    C_SEGMENTS = 6 * kCounterStride,  // closest-hit queries traced inside k_tail / the megakernel
-    C_OVERFLOW = 7 * kCounterStride,
-    C_CHUNK = 8 * kCounterStride,        // next unclaimed queue entry of k_trace_closest
-    C_CHUNK_SHADOW = 9 * kCounterStride, // ... of k_trace_shadow, even bounces
-    C_RESTART = 10 * kCounterStride, // slots re-queued for their next sample (multi-sample launch, NaN restart), drained after the bounce loop
-    C_SHADOW1 = 11 * kCounterStride,       // odd bounces
-    C_CHUNK_SHADOW1 = 12 * kCounterStride,
-    C_WAVE_SEGMENTS = 13 * kCounterStride, // 64-bit: closest-hit queries traced by k_trace_closest (k_prologue adds each bounce's queue length)
-    C_TAIL_PATHS = 14 * kCounterStride,    // paths k_tail took over
-    C_BOUNCE_ACTIVE = 15 * kCounterStride, // [kMaxTimedBounces + 1]: queue length at the start of each bounce of the last round
-    C_COUNT = C_BOUNCE_ACTIVE + ((kMaxTimedBounces + 1 + kCounterStride - 1) / kCounterStride) * kCounterStride
-};
-PT_DEV int queueCounter(int q) { return q ? (int)C_ACTIVE1 : (int)C_ACTIVE0; }
-PT_DEV int shadowCounter(int parity) { return parity ? (int)C_SHADOW1 : (int)C_SHADOW; }
-PT_DEV int shadowChunkCounter(int parity) { return parity ? (int)C_CHUNK_SHADOW1 : (int)C_CHUNK_SHADOW; }
-
-// The bounce loop is driven from the device: every kernel of a bounce takes its queue length from the counter block, so
-// the host enqueues the whole schedule (BounceCount bounces) without a single read-back in between.
-//   * A queue at or below `tailBelow` paths (after the first bounce) belongs to k_tail, which runs them to the end of
-//     their sample in one launch: the wavefront kernels of the following bounces see that and return at once.
-//   * k_prologue, one thread ahead of each bounce, clears the counters that bounce appends to (the shadow queue has two
-//     sets: the shadow kernel of bounce b runs beside bounce b + 1) and keeps the statistics.
-struct BounceCtl
-{
-    uint32_t bounce;    // 1-based index inside the round
-    uint32_t tailBelow; // queues of at most this many paths go to k_tail (never the first bounce of a round)
-    uint32_t sortShade; // k_shade puts its block's queue entries in material-type order first (scenes that mix types)
-};
-PT_DEV bool bounceRuns(const BounceCtl &c, uint32_t count) { return count != 0u && (c.bounce <= 1u || count > c.tailBelow); }
-
-__global__ void k_prologue(Wavefront wf, int qin, BounceCtl ctl)
-{
-    const uint32_t count = wf.counters[queueCounter(qin)];
-    const int parity = (int)(ctl.bounce & 1u);
-    wf.counters[queueCounter(qin ^ 1)] = 0u;
-    wf.counters[shadowCounter(parity)] = 0u;
-    wf.counters[shadowChunkCounter(parity)] = 0u;
-    wf.counters[C_CHUNK] = 0u;
-    if (ctl.bounce <= (uint32_t)kMaxTimedBounces)
-        wf.counters[C_BOUNCE_ACTIVE + ctl.bounce] = count;
-    if (bounceRuns(ctl, count))
-    {
-        unsigned long long *seg = reinterpret_cast<unsigned long long *>(&wf.counters[C_WAVE_SEGMENTS]);
-        *seg += count;
-    }
-}
-
-
-struct LaunchParams
-{
-    PtxRaygenUniformData u;
-    uint32_t width, height;
-    uint32_t rank, worldSize, tileSize, tilesX, numTiles, ownedTiles;
-    uint32_t slotsPerFrame; // ownedTiles * tileSize^2
-    uint32_t frames, firstFrame;
-    uint32_t numSlots;
-    uint32_t ownedPixels; // slots of one frame that map to a pixel inside the image
-    uint32_t framesPerWave; // 1, 2, 4 or 8 (divides frames): a wave of 64 slots = 64 / framesPerWave pixels x framesPerWave frames
-};
-
-// slot <-> (frame of the batch, slot inside the frame).  The samples a batch adds to ONE pixel sit in neighbouring lanes: their
-// primary rays differ by the sub-pixel jitter only, they reach the same triangles and the same texels (a wave = 8 pixels of a
-// row x 8 frames instead of an 8x8 pixel block of one frame).  Measured, 1 / 2 / 4 / 8 frames per wave (PTX_FRAMES_PER_WAVE,
-// two runs each): atrium_like 770, 766 / 769, 777 / 779, 776 / 788, 782 Msamples/s (k_shade<true> 44.8 -> 39.5 ms of kernel time
-// per step), street_like +1 %, chess_like and temple_like flat; a 4x2 pixel footprint instead of the row: flat.
-PT_DEV void slotFrame(const LaunchParams &p, uint32_t slot, uint32_t &f, uint32_t &s)
-{
-    const uint32_t g = p.framesPerWave, pixelsPerWave = 64u / g, wave = slot >> 6, lane = slot & 63u;
-    const uint32_t chunks = p.slotsPerFrame / pixelsPerWave; // slotsPerFrame is a multiple of 64
-    f = (wave / chunks) * g + lane % g;
-    s = (wave % chunks) * pixelsPerWave + lane / g;
-}
-
-// slot -> pixel.  Owned tiles are rank, rank+world, ...; inside a tile pixels are laid
-// out in 8x8 blocks so that one wave64 = one 8x8 pixel block (coherent primary rays).
-PT_DEV uint32_t slotPixel(const LaunchParams &p, uint32_t slotInFrame)
-{
-    const uint32_t ts = p.tileSize, perTile = ts * ts;
-    const uint32_t k = slotInFrame / perTile, o = slotInFrame % perTile;
-    const uint32_t tile = p.rank + k * p.worldSize;
-    const uint32_t bpr = ts / 8, blk = o / 64, ib = o % 64;
-    const uint32_t x = (tile % p.tilesX) * ts + (blk % bpr) * 8 + (ib % 8);
-    const uint32_t y = (tile / p.tilesX) * ts + (blk / bpr) * 8 + (ib / 8);
-    if (tile >= p.numTiles || x >= p.width || y >= p.height)
-        return 0xffffffffu;
-    return y * p.width + x;
-}
-
-// raygen.rgen:44-60: start one sample of a slot (jitter draws, primary ray; with DIFF also the
-// offset rays of raygen.rgen:56-58)
-template <bool DIFF>
-PT_DEV void startSample(const LaunchParams &p, uint32_t pixel, uint32_t &rng, f3 &origin, f3 &direction, DiffRays &diff)
-{
-    f2 u;
-    u.x = rnd(rng);
-    u.y = rnd(rng);
-    const uint32_t px = pixel % p.width, py = pixel / p.width;
-    f3 rx = F3s(0.0f), ry = F3s(0.0f);
-    if (p.u.LensRadius > 0)
-    {
-        f2 u2;
-        u2.x = rnd(rng);
-        u2.y = rnd(rng);
-        constructPrimaryRayLens<DIFF>(px, py, p.width, p.height, p.u.ViewInverse, p.u.ProjInverse, u, u2, p.u.LensRadius, p.u.FocalDistance,
-                                      origin, direction, rx, ry);
-    }
-    else
-        constructPrimaryRay<DIFF>(px, py, p.width, p.height, p.u.ViewInverse, p.u.ProjInverse, u, origin, direction, rx, ry);
-    if (DIFF)
-    {
-        diff.rxOrigin = origin;
-        diff.rxDirection = rx;
-        diff.ryOrigin = origin;
-        diff.ryDirection = ry;
-    }
-}
-
-// the payload packing of raygen.rgen:56-58 / closestHit.rchit:157-159
-PT_DEV void storeDiff(const Wavefront &wf, uint32_t slot, const DiffRays &d)
-{
-    wf.diff[0][slot] = make_float4(d.rxOrigin.x, d.rxOrigin.y, d.rxOrigin.z, d.rxDirection.x);
-    wf.diff[1][slot] = make_float4(d.rxDirection.y, d.rxDirection.z, d.ryOrigin.x, d.ryOrigin.y);
-    wf.diff[2][slot] = make_float4(d.ryOrigin.z, d.ryDirection.x, d.ryDirection.y, d.ryDirection.z);
-}
-PT_DEV DiffRays loadDiff(const Wavefront &wf, uint32_t slot)
-{
-    const float4 a = wf.diff[0][slot], b = wf.diff[1][slot], c = wf.diff[2][slot];
-    DiffRays d;
-    d.rxOrigin = F3(a.x, a.y, a.z);
-    d.rxDirection = F3(a.w, b.x, b.y);
-    d.ryOrigin = F3(b.z, b.w, c.x);
-    d.ryDirection = F3(c.y, c.z, c.w);
-    return d;
-}
-
-// new primary ray of a slot; the differentials go straight to the slot state when the scene carries them
-PT_DEV void startSlotSample(const LaunchParams &p, const Wavefront &wf, uint32_t slot, uint32_t pixel, uint32_t &rng, f3 &o, f3 &d)
-{
-    DiffRays diff;
-    if (wf.diff[0])
-    {
-        startSample<true>(p, pixel, rng, o, d, diff);
-        storeDiff(wf, slot, diff);
-    }
-    else
-        startSample<false>(p, pixel, rng, o, d, diff);
-}
-
-PT_DEV bool badRadiance(f3 r) // raygen.rgen:101,107
-{
-    return __builtin_isnan(r.x) || __builtin_isnan(r.y) || __builtin_isnan(r.z) || __builtin_isinf(r.x) ||
-           __builtin_isinf(r.y) || __builtin_isinf(r.z);
-}
-
-// =====================================================================================
-// Wavefront kernels
-// =====================================================================================
-
-constexpr int kBlock = 256;
-
-// Queue append with ONE atomic per wave: ballot the pushing lanes, the first of them
-// reserves popcount slots, every lane takes base + its rank.  Must be reached by all lanes
-// of the wave that are still in the (wave-uniform) loop.
-PT_DEV void wavePush(uint32_t *__restrict__ queue, uint32_t *__restrict__ counter, bool push, uint32_t value)
-{
-    const uint64_t mask = __ballot(push);
-    if (mask == 0)
-        return;
-    const uint32_t lane = threadIdx.x & 63u;
-    const int leader = __ffsll((unsigned long long)mask) - 1;
-    uint32_t base = 0;
-    if ((int)lane == leader)
-        base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader);
-    if (push)
-        queue[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = value;
-}
-
-// statistics: lanes count in registers, one atomic per wave at kernel exit
-PT_DEV void waveAddCounter(uint32_t *__restrict__ counter, uint32_t v)
-{
-    for (int off = 32; off > 0; off >>= 1)
-        v += __shfl_down(v, off);
-    if ((threadIdx.x & 63u) == 0 && v)
-        atomicAdd(counter, v);
-}
-
-// the same per block (all threads of the block must call it): one global atomic per block instead of per wave
-PT_DEV void blockAddCounter(uint32_t *__restrict__ counter, uint32_t v)
-{
-    __shared__ uint32_t s_sum;
-    if (threadIdx.x == 0)
-        s_sum = 0;
-    __syncthreads();
-    for (int off = 32; off > 0; off >>= 1)
-        v += __shfl_down(v, off);
-    if ((threadIdx.x & 63u) == 0 && v)
-        atomicAdd(&s_sum, v);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_sum)
-        atomicAdd(counter, s_sum);
-    __syncthreads();
-}
-
-#ifndef PT_SHADE_ITEMS
-#define PT_SHADE_ITEMS 4
-#endif
-constexpr uint32_t kShadeItems = PT_SHADE_ITEMS; // queue entries per thread per block-wide append in k_shade
-constexpr uint32_t kDeadPair = 0xfffffffeu; // hitPair of a slot outside the image (ragged edge tiles)
-
-// No queue atomics here: queue 0 is the identity over all slots (the host sets its count);
-// slots of edge tiles that fall outside the image are flagged dead through rayD.w < 0.
-__global__ void __launch_bounds__(kBlock) k_generate(LaunchParams p, Wavefront wf)
-{
-    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < p.numSlots; slot += gridDim.x * blockDim.x)
-    {
-        uint32_t f, s;
-        slotFrame(p, slot, f, s);
-        const uint32_t pixel = slotPixel(p, s);
-        const uint32_t frame = p.firstFrame + f;
-        uint4 meta = make_uint4(0u, pixel, 0u, frame);
-        wf.queue[0][slot] = slot;
-        if (pixel != 0xffffffffu)
-        {
-            uint32_t rng = initRng(pixel % p.width, pixel / p.width, p.width, frame); // raygen.rgen:38
-            f3 o, d;
-            startSlotSample(p, wf, slot, pixel, rng, o, d);
-            meta.x = rng;
-            wf.rayO[slot] = make_float4(o.x, o.y, o.z, 0.0f); // MaxRoughness = 0, raygen.rgen:60
-            wf.rayD[slot] = make_float4(d.x, d.y, d.z, 0.0f);
-            // thr[slot] = 1 and rad[slot] = 0 are implied by meta.z == 0 (first bounce of the first sample): 32 bytes per
-            // slot neither written here nor read by the first k_shade
-        }
-        else
-        {
-            wf.rayD[slot] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
-            wf.slotRad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        }
-        wf.meta[slot] = meta;
-    }
-}
-
-struct ClosestIO
-{
-    static constexpr float kFixedTmin = 0.00001f; // ray.glsl:79
-    static constexpr float kFixedTmax = 10000.0f; // ray.glsl:80
-    static constexpr bool kNeedsPrim = false;    // the hit record carries (t, u, v, slot) and the pair
-    static constexpr bool kHasQueue = true;
-    const Wavefront &wf;
-    const uint32_t *queue;
-    uint32_t slot;
-    PT_DEV uint32_t queueEntry(uint32_t item) const { return queue[item]; }
-    PT_DEV void setEntry(uint32_t s) { slot = s; }
-    PT_DEV bool load(uint32_t item, f3 &o, f3 &d, float &tmin, float &tmax)
-    {
-        const float4 d4 = wf.rayD[slot];
-        if (d4.w < 0.0f)
-        {
-            wf.hitPair[slot] = kDeadPair;
-            return false;
-        }
-        const float4 o4 = wf.rayO[slot];
-        o = F3(o4.x, o4.y, o4.z);
-        d = F3(d4.x, d4.y, d4.z);
-        tmin = 0.00001f; // ray.glsl:79-80: tmin = 1e-5, tmax = 1e4 on every segment
-        tmax = 10000.0f;
-        if (wf.decalT)
-            wf.decalT[slot] = -1.0f; // anyhit.rahit state of a fresh ray: nothing ignored yet
-        return true;
-    }
-    PT_DEV void improve(uint32_t, float t, float u, float v, uint32_t triSlot)
-    {
-        wf.hit[slot] = make_float4(t, u, v, __uint_as_float(triSlot)); // w = triangle slot in leaf order
-    }
-    PT_DEV uint32_t bestSlot(uint32_t) const { return __float_as_uint(wf.hit.p[slot].w); }
-    PT_DEV void store(uint32_t, const Hit &h, bool, bool) { wf.hitPair[slot] = h.pair; }
-    // anyhit.rahit:54-61: the nearest ignored candidate (ties: smaller (pair, prim)) is the decal.  It lives in the slot's
-    // record -- (triangle slot, u, v, pair) + its distance -- and k_shade fetches its colour if the hit lies behind it.
-    // The ids come from the triangle record when they are needed (the tie, the store), not as arguments held in registers.
-    PT_DEV void ignored(float t, float u, float v, uint32_t triSlot, const TraceScene &sc)
-    {
-        const float cur = wf.decalT[slot];
-        bool nearer = cur == -1.0f || t < cur;
-        if (!nearer && t == cur)
-        {
-            const float4 mine = sc.tris[triSlot].c, other = sc.tris[__float_as_uint(wf.decal.p[slot].x)].c;
-            const uint32_t pair = __float_as_uint(mine.y), curPair = __float_as_uint(other.y);
-            nearer = pair < curPair || (pair == curPair && __float_as_uint(mine.z) < __float_as_uint(other.z));
-        }
-        if (nearer)
-        {
-            wf.decalT[slot] = t;
-            wf.decal[slot] = make_float4(__uint_as_float(triSlot), u, v, sc.tris[triSlot].c.y);
-        }
-    }
-};
-
-// Occupancy of the traversal kernels (waves per SIMD; overridable for A/B builds through tools/kernel_resources.py -- -D...).
-// The opaque variants run at the hardware's 8: 58 / 56 VGPRs without a spill.  The ALPHA variants hold the any-hit record of a
-// non-opaque triangle beside the triangle (70 / 68 VGPRs) and run at 7; at 8 the shadow variant fits (63, no vector spill)
-// and the closest variant spills 11 registers -- measured: atrium_like 732 / 726 -> 727 / 720 (shadow at 8) and 711 / 713 (both).
-#ifndef PT_TRACE_WAVES
-#define PT_TRACE_WAVES 8
-#endif
-#define PT_FULL_OCCUPANCY __attribute__((amdgpu_waves_per_eu(PT_TRACE_WAVES, PT_TRACE_WAVES)))
-#ifndef PT_ALPHA_CLOSEST_WAVES
-#define PT_ALPHA_CLOSEST_WAVES 7
-#endif
-#define PT_ALPHA_CLOSEST_ATTR __attribute__((amdgpu_waves_per_eu(PT_ALPHA_CLOSEST_WAVES, PT_ALPHA_CLOSEST_WAVES)))
-#ifndef PT_ALPHA_SHADOW_WAVES
-#define PT_ALPHA_SHADOW_WAVES 7
-#endif
-#define PT_ALPHA_SHADOW_ATTR __attribute__((amdgpu_waves_per_eu(PT_ALPHA_SHADOW_WAVES, PT_ALPHA_SHADOW_WAVES)))
-template <bool ALPHA>
-PT_DEV void traceClosestBody(const TraceScene &sc, const Wavefront &wf, int qin, const BounceCtl &ctl)
-{
-    const uint32_t count = wf.counters[queueCounter(qin)];
-    if (!bounceRuns(ctl, count))
-        return;
-    PT_DECLARE_STACK(st, kLdsStack, wf.spill)
-    ClosestIO io = { wf, wf.queue[qin], 0u };
-    persistentTrace<false, ALPHA>(sc, io, count, &wf.counters[C_CHUNK], st);
-    if (st.overflow)
-        atomicAdd(&wf.counters[C_OVERFLOW], 1u);
-}
-template <bool ALPHA>
-__global__ void __launch_bounds__(kBlock) k_trace_closest(TraceScene sc, Wavefront wf, int qin, BounceCtl ctl);
-template <>
-__global__ void __launch_bounds__(kBlock) PT_FULL_OCCUPANCY k_trace_closest<false>(TraceScene sc, Wavefront wf, int qin, BounceCtl ctl)
-{
-    traceClosestBody<false>(sc, wf, qin, ctl);
-}
-template <>
-__global__ void __launch_bounds__(kBlock) PT_ALPHA_CLOSEST_ATTR k_trace_closest<true>(TraceScene sc, Wavefront wf, int qin, BounceCtl ctl)
-{
-    traceClosestBody<true>(sc, wf, qin, ctl);
-}
-
-// raygen.rgen:99-112 + sample loop control for a slot whose path has ended.
-// Returns true if the slot has samples left in this launch (next sample of a multi-sample launch, NaN restart): the
-// caller appends it to the restart queue and k_restart draws its next primary ray before that queue is consumed.
-// The ray is NOT constructed here: the camera matrices, the lens and the differential code would sit in the register
-// and instruction-cache budget of the shading and traversal kernels for a path the canonical schedule
-// (SampleCount = 1) takes only after a NaN.
-PT_DEV bool finishSample(const LaunchParams &p, const Wavefront &wf, uint32_t slot, uint4 &meta, f3 &radiance,
-                         uint32_t &nSamples, uint32_t &nRetries)
-{
-    uint32_t smpl = meta.z >> 16;
-    nSamples++;
-    if (badRadiance(radiance))
-    {
-        radiance = F3s(0.0f);
-        smpl = 0; // "smpl = -1; continue" restarts ALL samples of the launch, RNG carried on
-        nRetries++;
-    }
-    else
-        smpl = smpl + 1;
-    if (smpl < p.u.SampleCount)
-    {
-        meta.z = smpl << 16; // bounce = 0
-        wf.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-        return true;
-    }
-    wf.slotRad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-    return false;
-}
-
-// Appends the slots of the calling lanes (restart == true) to the restart queue with one atomic per wave.  May be
-// called under divergent control flow: the ballot sees the active lanes only.
-PT_DEV void pushRestarts(const Wavefront &wf, bool restart, uint32_t slot)
-{
-    const uint64_t mask = __ballot(restart);
-    if (!mask)
-        return;
-    const uint32_t lane = threadIdx.x & 63u;
-    const int leader = __ffsll((unsigned long long)mask) - 1;
-    uint32_t base = 0;
-    if ((int)lane == leader)
-        base = atomicAdd(&wf.counters[C_RESTART], (uint32_t)__popcll(mask));
-    base = __shfl(base, leader);
-    if (restart)
-        wf.restartQueue[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = slot;
-}
-
-template <bool TEX>
-PT_DEV void shadeBody(const LaunchParams &p, const SceneView &sv, const Wavefront &wf, int qin, const BounceCtl &ctl);
-template <bool TEX>
-__global__ void __launch_bounds__(kBlock) k_shade(LaunchParams p, SceneView sv, Wavefront wf, int qin, BounceCtl ctl);
-// 178 VGPRs by itself (195 with the SLP vectoriser); held at 168 = three waves per SIMD, which costs nothing now (15 spilled
-// dwords before round 3).  Four waves (128 VGPRs, 49 spilled) lose: chess_like 2,290 / 2,324 -> 2,164 / 2,185 Msamples/s.
-#ifndef PT_SHADE_ATTR
-#define PT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
-#endif
-template <>
-__global__ void __launch_bounds__(kBlock) PT_SHADE_ATTR k_shade<false>(LaunchParams p, SceneView sv, Wavefront wf, int qin, BounceCtl ctl)
-{
-    shadeBody<false>(p, sv, wf, qin, ctl);
-}
-// the textured variant: 221 VGPRs = two waves per SIMD (round 1: a few registers past 256, i.e. ONE wave, held at two for four
-// spilled registers).  Three waves (168 VGPRs, 54 spilled, 164 B scratch) measure flat: atrium_like 725 / 730 -> 723 / 724.
-#ifndef PT_SHADE_TEX_ATTR
-#define PT_SHADE_TEX_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
-#endif
-template <>
-__global__ void __launch_bounds__(kBlock) PT_SHADE_TEX_ATTR k_shade<true>(LaunchParams p, SceneView sv, Wavefront wf, int qin, BounceCtl ctl)
-{
-    shadeBody<true>(p, sv, wf, qin, ctl);
-}
-template <bool TEX>
-PT_DEV void shadeBody(const LaunchParams &p, const SceneView &sv, const Wavefront &wf, int qin, const BounceCtl &ctl)
-{
-    __shared__ uint32_t s_cnt[2], s_base[2];
-    const int qout = qin ^ 1;
-    const uint32_t count = wf.counters[queueCounter(qin)];
-    if (!bounceRuns(ctl, count)) // empty, or k_tail's
-        return;
-    const int shadowSet = shadowCounter((int)(ctl.bounce & 1u));
-    uint32_t nHits = 0, nSamples = 0, nRetries = 0;
-    // kShadeItems queue entries per thread between two block-wide appends: the appends cost one global atomic per
-    // block and queue, and same-address atomics serialise at ~11 ns -- at one entry per thread the 65 K blocks x 2
-    // queues of a 16.6 M-slot launch would keep the counter line busy for 1.4 ms of a 2 ms kernel.
-    for (uint32_t base = blockIdx.x * blockDim.x * kShadeItems; base < count; base += gridDim.x * blockDim.x * kShadeItems)
-    {
-      // Material-sorted shade queue: the block's kBlock x kShadeItems entries are put in the order
-      //   sky (miss.rmiss) | MetallicRoughness | SpecularGlossiness | Phong | unknown type | the three types again for materials
-      //   that sample a scene texture | dead slot
-      // (ShaderTypes.incl:143-145, the dispatch of material.glsl:144-166) before they are shaded, so that a wave runs one
-      // branch of sampleMaterial / the miss stage instead of all that its 64 entries happen to need, and the software sampler
-      // -- up to sixteen anisotropic taps, a seventh of an atrium_like step -- runs in waves of textured hits only instead of in
-      // every wave that holds one.  A stable counting sort: per wave one ballot per (entry, key) gives the counts, a prefix
-      // over (key, wave) the bases, the same ballots the ranks; the sorted slots go through LDS.  Deterministic: the order
-      // inside a key is the queue order.
-      // Measured (1 MI355X, 1080p, 8 spp, one frame in flight): materials_test (three material types + an unknown one side
-      // by side) 1,313 -> 1,536 Msamples/s, k_shade 8.06 -> 6.29 ms; scenes of ONE material type pay for the sort and get
-      // nothing back (temple_like 614 -> 600, chess_like +-0.5 %), hence the switch.
-      __shared__ uint32_t s_sorted[kBlock * kShadeItems];
-      if (ctl.sortShade)
-      {
-        constexpr uint32_t kKeys = 9, kWaves = kBlock / 64;
-        __shared__ uint32_t s_keyCount[kWaves][kKeys], s_keyBase[kWaves][kKeys];
-        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-        const uint64_t lower = (1ull << lane) - 1ull;
-        uint32_t mySlot[kShadeItems], myKey[kShadeItems];
-        uint32_t cnt[kKeys];
-        for (uint32_t k = 0; k < kKeys; k++)
-            cnt[k] = 0;
-        for (uint32_t item = 0; item < kShadeItems; item++)
-        {
-            const uint32_t i = base + item * blockDim.x + threadIdx.x;
-            uint32_t sl = 0, key = kKeys - 1u; // dead, and the padding past the end of the queue: sorted last
-            if (i < count)
-            {
-                sl = wf.queue[qin][i];
-                const uint32_t pr = wf.hitPair[sl];
-                if (pr == 0xffffffffu)
-                    key = 0u;
-                else if (pr != kDeadPair)
-                {
-                    const uint32_t type = sv.pairs[pr].materialId & 0xffu;
-                    key = type <= PTX_MATERIAL_TYPE_PHONG ? ((sv.pairs[pr].flags & kPairTextured) ? 5u : 1u) + type : 4u;
-                }
-            }
-            mySlot[item] = sl;
-            myKey[item] = key;
-            for (uint32_t k = 0; k < kKeys; k++)
-                cnt[k] += (uint32_t)__popcll(__ballot(key == k));
-        }
-        if (lane < kKeys)
-        {
-            uint32_t c = 0;
-            for (uint32_t k = 0; k < kKeys; k++) // no dynamic register indexing
-                c = lane == k ? cnt[k] : c;
-            s_keyCount[wave][lane] = c;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0)
-        {
-            uint32_t run = 0;
-            for (uint32_t k = 0; k < kKeys; k++)
-                for (uint32_t w = 0; w < kWaves; w++)
-                {
-                    s_keyBase[w][k] = run;
-                    run += s_keyCount[w][k];
-                }
-        }
-        __syncthreads();
-        uint32_t done[kKeys];
-        for (uint32_t k = 0; k < kKeys; k++)
-            done[k] = s_keyBase[wave][k];
-        for (uint32_t item = 0; item < kShadeItems; item++)
-            for (uint32_t k = 0; k < kKeys; k++)
-            {
-                const uint64_t m = __ballot(myKey[item] == k);
-                if (myKey[item] == k)
-                    s_sorted[done[k] + (uint32_t)__popcll(m & lower)] = mySlot[item];
-                done[k] += (uint32_t)__popcll(m);
-            }
-        __syncthreads();
-      }
-      uint32_t slots[kShadeItems];
-      uint32_t pushBits = 0; // bit 2k: entry k joins the shadow queue, bit 2k+1: the next queue
-#pragma nounroll
-      for (uint32_t item = 0; item < kShadeItems; item++)
-      {
-        const uint32_t i = base + item * blockDim.x + threadIdx.x;
-        bool pushNext = false, pushShadow = false, restart = false;
-        uint32_t slot = 0, pair = kDeadPair;
-        if (i < count)
-        {
-            // entries past the block's share of the queue were sorted last, as dead slots
-            slot = ctl.sortShade ? s_sorted[item * blockDim.x + threadIdx.x] : wf.queue[qin][i];
-            pair = wf.hitPair[slot];
-        }
-        if (pair != kDeadPair)
-        {
-            uint4 meta = wf.meta[slot];
-            const float4 hit = wf.hit[slot];
-            // first bounce of a sample: throughput = 1 (raygen.rgen:52); and of the first sample: radiance = 0 (:42)
-            float4 r4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), t4 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-            if (meta.z != 0u)
-                r4 = wf.rad[slot];
-            if ((meta.z & 0xffffu) != 0u)
-                t4 = wf.thr[slot];
-            f3 radiance = F3(r4.x, r4.y, r4.z), throughput = F3(t4.x, t4.y, t4.z);
-
-            if (pair == 0xffffffffu)
-            {
-                // miss.rmiss:16-39: sky colour / skybox lookup, Pdf = -1 -> raygen.rgen:71-75
-                const float4 d4 = wf.rayD[slot];
-                radiance = radiance + throughput * missEmissive(sv, F3(d4.x, d4.y, d4.z));
-                restart = finishSample(p, wf, slot, meta, radiance, nSamples, nRetries);
-            }
-            else
-            {
-                const float4 o4 = wf.rayO[slot], d4 = wf.rayD[slot];
-                HitOut out;
-                DiffRays diff;
-                if (TEX)
-                    diff = loadDiff(wf, slot);
-                Decal decal = noDecal();
-                if (TEX && wf.decalT)
-                {
-                    decal.dist = wf.decalT[slot];
-                    if (decal.dist != -1.0f)
-                    {
-                        const float4 dq = wf.decal[slot];
-                        decal.slot = __float_as_uint(dq.x);
-                        decal.u = dq.y;
-                        decal.v = dq.z;
-                        decal.pair = __float_as_uint(dq.w);
-                    }
-                }
-                closestHit<TEX>(sv, F3(d4.x, d4.y, d4.z), hit.x, hit.y, hit.z, pair, __float_as_uint(hit.w), o4.w, meta.x, out, diff, decal);
-                nHits++;
-
-                radiance = radiance + throughput * out.Emissive; // raygen.rgen:77
-
-                // raygen.rgen:79-81, evaluated with the pre-update throughput
-                f3 contribution = F3s(0.0f);
-                if (out.DirectLightPdf > 0.0f)
-                {
-                    contribution = (throughput * out.DirectLight) / out.DirectLightPdf;
-                    // adding an exact zero cannot change radiance (it is never -0): skip the query
-                    pushShadow = !(contribution.x == 0.0f && contribution.y == 0.0f && contribution.z == 0.0f);
-                }
-
-                if (out.Pdf > 0.001f) // :83-84
-                    throughput = throughput * (out.Bsdf / out.Pdf);
-
-                bool finished = false;
-                const float prob = fmin_(maxComponent(throughput), 1.0f); // :86
-                uint32_t bounce = meta.z & 0xffffu;
-                if (prob < 0.001f)
-                    finished = true;
-                else if (prob < rnd(meta.x)) // :90
-                    finished = true;
-                else
-                {
-                    throughput = throughput / prob; // :93
-                    bounce = bounce + 1;
-                    if (bounce >= p.u.BounceCount)
-                        finished = true;
-                }
-                meta.z = (meta.z & 0xffff0000u) | bounce;
-
-                if (pushShadow)
-                {
-                    const f3 sd = -normalize(out.LightDirection); // raygen.rgen:24
-                    wf.shO[slot] = make_float4(out.Position.x, out.Position.y, out.Position.z, out.LightDistance);
-                    wf.shD[slot] = make_float4(sd.x, sd.y, sd.z, finished ? 1.0f : 0.0f);
-                    wf.shC[slot] = make_float4(contribution.x, contribution.y, contribution.z, 0.0f);
-                }
-                if (finished && !pushShadow)
-                    restart = finishSample(p, wf, slot, meta, radiance, nSamples, nRetries);
-                else
-                {
-                    wf.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-                    if (!finished)
-                    {
-                        wf.rayO[slot] = make_float4(out.Position.x, out.Position.y, out.Position.z, out.MaxRoughness);
-                        wf.rayD[slot] = make_float4(out.Direction.x, out.Direction.y, out.Direction.z, 0.0f);
-                        wf.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, 0.0f);
-                        if (TEX)
-                            storeDiff(wf, slot, diff);
-                        pushNext = true; // a pending shadow query only adds to rad[slot] before the next bounce
-                    }
-                }
-            }
-            wf.meta[slot] = meta;
-        }
-        pushRestarts(wf, restart, slot);
-        // queue appends with ONE global atomic per block and queue: same-address atomics
-        // serialise at ~11 ns each on MI355X, so per-wave appends would cost more than the shading
-        for (uint32_t k = 0; k < kShadeItems; k++) // no dynamic register indexing
-            if (k == item)
-                slots[k] = slot;
-        pushBits |= (pushShadow ? 1u : 0u) << (2 * item) | (pushNext ? 2u : 0u) << (2 * item);
-      }
-        // queue appends with ONE global atomic per block and queue for all kShadeItems x 256 entries
-        if (threadIdx.x < 2)
-            s_cnt[threadIdx.x] = 0;
-        __syncthreads();
-        const uint32_t lane = threadIdx.x & 63u;
-        uint32_t waveS[kShadeItems], waveN[kShadeItems];
-        for (uint32_t k = 0; k < kShadeItems; k++)
-        {
-            const uint64_t maskS = __ballot((pushBits >> (2 * k)) & 1u), maskN = __ballot((pushBits >> (2 * k)) & 2u);
-            uint32_t ws = 0, wn = 0;
-            if (lane == 0)
-            {
-                if (maskS)
-                    ws = atomicAdd(&s_cnt[0], (uint32_t)__popcll(maskS));
-                if (maskN)
-                    wn = atomicAdd(&s_cnt[1], (uint32_t)__popcll(maskN));
-            }
-            waveS[k] = __shfl(ws, 0);
-            waveN[k] = __shfl(wn, 0);
-        }
-        __syncthreads();
-        if (threadIdx.x < 2 && s_cnt[threadIdx.x])
-            s_base[threadIdx.x] = atomicAdd(&wf.counters[threadIdx.x == 0 ? shadowSet : queueCounter(qout)], s_cnt[threadIdx.x]);
-        __syncthreads();
-        const uint64_t below = (1ull << lane) - 1ull;
-        for (uint32_t k = 0; k < kShadeItems; k++)
-        {
-            const uint64_t maskS = __ballot((pushBits >> (2 * k)) & 1u), maskN = __ballot((pushBits >> (2 * k)) & 2u);
-            if ((pushBits >> (2 * k)) & 1u)
-                wf.shadowQueue[s_base[0] + waveS[k] + (uint32_t)__popcll(maskS & below)] = slots[k];
-            if ((pushBits >> (2 * k)) & 2u)
-                wf.queue[qout][s_base[1] + waveN[k] + (uint32_t)__popcll(maskN & below)] = slots[k];
-        }
-    }
-    blockAddCounter(&wf.counters[C_HITS], nHits);
-    blockAddCounter(&wf.counters[C_SAMPLES], nSamples);
-    blockAddCounter(&wf.counters[C_RETRIES], nRetries);
-}
-
-struct ShadowIO
-{
-    static constexpr float kFixedTmin = 0.00001f; // raygen.rgen:26
-    static constexpr float kFixedTmax = -1.0f;    // per ray: the distance to the light
-    static constexpr bool kNeedsPrim = false;
-    static constexpr bool kHasQueue = true;
-    const Wavefront &wf;
-    float finished;
-    uint32_t staged;
-    PT_DEV uint32_t queueEntry(uint32_t item) const { return wf.shadowQueue[item]; }
-    PT_DEV void setEntry(uint32_t s) { staged = s; }
-    PT_DEV bool load(uint32_t item, f3 &o, f3 &d, float &tmin, float &tmax)
-    {
-        const uint32_t slot = staged;
-        const float4 o4 = wf.shO[slot], d4 = wf.shD[slot];
-        o = F3(o4.x, o4.y, o4.z);
-        d = F3(d4.x, d4.y, d4.z);
-        tmin = 0.00001f; // raygen.rgen:26-31: tmin = 1e-5, tmax = LightDistance, terminate on first hit
-        tmax = o4.w;
-        finished = d4.w;
-        return true;
-    }
-    PT_DEV void ignored(float, float, float, uint32_t, const TraceScene &) {} // shadow rays keep no decal
-    PT_DEV void improve(uint32_t, float, float, float, uint32_t) {}
-    PT_DEV uint32_t bestSlot(uint32_t) const { return 0u; }
-    // The traversal only records the answer.  What follows from it -- the NEE add into rad[slot], finishing the sample of a
-    // path that ended on this bounce -- is k_apply_shadow's: inside the traversal loop those dependent loads and stores
-    // sat in the retire phase of nearly every round for a handful of lanes (shadow rounds took 1.8x a closest round).
-    PT_DEV void store(uint32_t item, const Hit &, bool occluded, bool) { wf.shadowResult[item] = (uint8_t)((occluded ? 0u : 1u) | (finished != 0.0f ? 2u : 0u)); }
-};
-
-template <bool ALPHA>
-PT_DEV void traceShadowBody(const LaunchParams &p, const TraceScene &sc, const Wavefront &wf, int qout, int parity)
-{
-    const uint32_t count = wf.counters[shadowCounter(parity)];
-    if (count == 0u)
-        return;
-    PT_DECLARE_STACK(st, kLdsStack, wf.spill)
-    ShadowIO io = { wf, 0.0f, 0u };
-    persistentTrace<true, ALPHA>(sc, io, count, &wf.counters[shadowChunkCounter(parity)], st);
-    if (st.overflow)
-        atomicAdd(&wf.counters[C_OVERFLOW], 1u);
-    (void)p;
-    (void)qout;
-}
-
-// raygen.rgen:79-81 after the occlusion query, one thread per shadow queue entry: a visible light adds the contribution
-// k_shade prepared; a path that ended on this bounce is finished (its slot may be due a new sample: restart queue).
-__global__ void __launch_bounds__(kBlock) k_apply_shadow(LaunchParams p, Wavefront wf, int parity)
-{
-    const uint32_t count = wf.counters[shadowCounter(parity)];
-    uint32_t nSamples = 0, nRetries = 0;
-    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x)
-    {
-        const uint32_t item = base + threadIdx.x;
-        bool restart = false;
-        uint32_t slot = 0;
-        if (item < count)
-        {
-            const uint32_t result = wf.shadowResult[item];
-            slot = wf.shadowQueue[item];
-            if (result)
-            {
-                float4 r4 = wf.rad[slot];
-                if (result & 1u)
-                {
-                    const float4 c = wf.shC[slot];
-                    r4.x = r4.x + c.x;
-                    r4.y = r4.y + c.y;
-                    r4.z = r4.z + c.z;
-                }
-                if (result & 2u)
-                {
-                    uint4 meta = wf.meta[slot];
-                    f3 radiance = F3(r4.x, r4.y, r4.z);
-                    restart = finishSample(p, wf, slot, meta, radiance, nSamples, nRetries);
-                    if (restart)
-                        wf.meta.p[slot].z = meta.z;
-                }
-                else
-                    wf.rad[slot] = r4; // the slot is already in the next queue (k_shade)
-            }
-        }
-        // the slot cannot join the next queue directly: k_trace_closest of the next bounce may already be consuming it
-        pushRestarts(wf, restart, slot);
-    }
-    blockAddCounter(&wf.counters[C_SAMPLES], nSamples);
-    blockAddCounter(&wf.counters[C_RETRIES], nRetries);
-}
-template <bool ALPHA>
-__global__ void __launch_bounds__(kBlock) k_trace_shadow(LaunchParams p, TraceScene sc, Wavefront wf, int qout, int parity);
-template <>
-__global__ void __launch_bounds__(kBlock) PT_FULL_OCCUPANCY k_trace_shadow<false>(LaunchParams p, TraceScene sc, Wavefront wf, int qout, int parity)
-{
-    traceShadowBody<false>(p, sc, wf, qout, parity);
-}
-template <>
-__global__ void __launch_bounds__(kBlock) PT_ALPHA_SHADOW_ATTR k_trace_shadow<true>(LaunchParams p, TraceScene sc, Wavefront wf, int qout, int parity)
-{
-    traceShadowBody<true>(p, sc, wf, qout, parity);
-}
-
-// The second half of finishSample for the slots the shadow kernel re-queued: next primary ray, RNG carried on.
-__global__ void __launch_bounds__(kBlock) k_restart(LaunchParams p, Wavefront wf, uint32_t count)
-{
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
-    {
-        const uint32_t slot = wf.restartQueue[i];
-        uint4 meta = wf.meta[slot];
-        f3 o, d;
-        startSlotSample(p, wf, slot, meta.y, meta.x, o, d);
-        wf.rayO[slot] = make_float4(o.x, o.y, o.z, 0.0f);
-        wf.rayD[slot] = make_float4(d.x, d.y, d.z, 0.0f);
-        wf.meta[slot] = meta; // bounce 0: thr[slot] = 1 is implied
-    }
-}
-
-// raygen.rgen:115-117 for `frames` launches in frame order: bit-identical to issuing the
-// launches one after another.
-// pendingRestarts: counter of slots still waiting for another sample (multi-sample launch, NaN restart): their slotRad is
-// not final, the host runs further rounds and accumulates afterwards
-__global__ void __launch_bounds__(kBlock) k_accumulate(LaunchParams p, const float4 *__restrict__ slotRad, float4 *__restrict__ image,
-                                                        const uint32_t *__restrict__ pendingRestarts)
-{
-    if (pendingRestarts && *pendingRestarts != 0u)
-        return;
-    // One thread per slot of a frame group: a wave reads the 64 slots of its wave-chunk with one coalesced load (8 pixels x 8
-    // frames when framesPerWave = 8), then the first lane of each pixel adds its frames in frame order through lane shuffles.
-    const uint32_t g = p.framesPerWave, pixelsPerWave = 64u / g, groups = p.frames / g;
-    const uint32_t chunks = p.slotsPerFrame / pixelsPerWave;
-    const uint32_t lane = threadIdx.x & 63u, sub = lane % g;
-    for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; base < chunks * 64u; base += gridDim.x * blockDim.x)
-    {
-        const uint32_t chunk = base >> 6, s = chunk * pixelsPerWave + lane / g;
-        const uint32_t pixel = slotPixel(p, s);
-        const bool owner = sub == 0u && pixel != 0xffffffffu;
-        float4 acc = owner ? image[pixel] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        for (uint32_t group = 0; group < groups; group++)
-        {
-            const float4 r = slotRad[((size_t)(group * chunks + chunk) << 6) + lane];
-            for (uint32_t k = 0; k < g; k++) // every lane runs the shuffles; only the owners' sums are kept
-            {
-                const float rx = __shfl(r.x, (int)(lane + k)), ry = __shfl(r.y, (int)(lane + k)), rz = __shfl(r.z, (int)(lane + k));
-                acc.x = rx + acc.x;
-                acc.y = ry + acc.y;
-                acc.z = rz + acc.z;
-            }
-        }
-        if (owner)
-        {
-            acc.w = 1.0f;
-            image[pixel] = acc;
-        }
-    }
-}
-
-// =====================================================================================
-// Fused path loop: raygen.rgen:36-118 as one device function.  Used by
-//   * k_megakernel  -- one thread per slot from the first sample (bring-up / A-B reference)
-//   * k_tail        -- finishes the paths still alive once the wavefront has thinned out:
-//                      late bounces have few rays and every per-bounce kernel then costs the
-//                      latency of its LONGEST ray (~0.4 ms measured) whatever the ray count
-// =====================================================================================
-
-struct PathCounters
-{
-    uint32_t nSeg = 0, nHit = 0, nSmp = 0, nRetry = 0;
-    bool stuck = false; // some path never produced a finite sample and was given up (kMaxSampleRetries)
-};
-// A slot whose samples keep coming out NaN / Inf would spin for ever (it hangs the GPU in the reference): after this many
-// restarts in a row it is given up with radiance 0 and the launch reports an error.
-constexpr uint32_t kMaxSampleRetries = 256;
-
-// Runs a slot to the end of its launch -- or, with ONE_SAMPLE, to the end of the sample it is in (smpl then tells
-// the caller whether samples remain).  `fresh` = start with a new sample (primary ray); otherwise continue the
-// current sample at `bounce` with the given ray / throughput.
-// MODE 0: opaque geometry, fixed 1x1 textures; 1: + ray differentials and the sampler (TEX); 2: + any-hit stages (ALPHA)
-template <int MODE, bool ONE_SAMPLE = false>
-PT_DEV f3 runPath(const LaunchParams &p, const SceneView &sv, const TraceScene &sc, Stack &st, uint32_t pixel, uint32_t &rng,
-                  f3 radiance, f3 throughput, f3 ro, f3 rd, DiffRays diff, float maxRoughness, uint32_t bounce, int &smpl, bool fresh,
-                  PathCounters &pc)
-{
-    constexpr bool TEX = MODE >= 1, ALPHA = MODE == 2;
-    uint32_t restartsInARow = 0;
-    for (;;)
-    {
-        if (fresh)
-        {
-            if (ONE_SAMPLE || smpl >= (int)p.u.SampleCount) // ONE_SAMPLE (k_tail): no sample is ever started here
-                break;
-            throughput = F3s(1.0f);
-            startSample<TEX>(p, pixel, rng, ro, rd, diff);
-            maxRoughness = 0.0f;
-            bounce = 0;
-            fresh = false;
-        }
-        for (; bounce < p.u.BounceCount; bounce++)
-        {
-            Hit h;
-            pc.nSeg++;
-            Decal decal = noDecal();
-            if (!traceRay<false, false, ALPHA>(sc, ro, rd, 0.00001f, 10000.0f, st, h, nullptr, nullptr, &decal))
-            {
-                radiance = radiance + throughput * missEmissive(sv, rd);
-                break;
-            }
-            HitOut out;
-            closestHit<TEX>(sv, rd, h.t, h.u, h.v, h.pair, h.slot, maxRoughness, rng, out, diff, decal);
-            pc.nHit++;
-            maxRoughness = out.MaxRoughness;
-            radiance = radiance + throughput * out.Emissive;
-            if (out.DirectLightPdf > 0.0f)
-            {
-                const f3 c = (throughput * out.DirectLight) / out.DirectLightPdf;
-                if (!(c.x == 0.0f && c.y == 0.0f && c.z == 0.0f))
-                {
-                    Hit sh;
-                    if (!traceRay<true, false, ALPHA>(sc, out.Position, -normalize(out.LightDirection), 0.00001f, out.LightDistance, st, sh))
-                        radiance = radiance + c;
-                }
-            }
-            if (out.Pdf > 0.001f)
-                throughput = throughput * (out.Bsdf / out.Pdf);
-            const float prob = fmin_(maxComponent(throughput), 1.0f);
-            if (prob < 0.001f)
-                break;
-            if (prob < rnd(rng))
-                break;
-            throughput = throughput / prob;
-            ro = out.Position;
-            rd = out.Direction;
-        }
-        pc.nSmp++;
-        if (badRadiance(radiance)) // raygen.rgen:99-112: restart ALL samples, RNG carried on
-        {
-            radiance = F3s(0.0f);
-            smpl = 0;
-            pc.nRetry++;
-            if (++restartsInARow >= kMaxSampleRetries)
-            {
-                pc.stuck = true;
-                smpl = (int)p.u.SampleCount;
-            }
-        }
-        else
-        {
-            smpl++;
-            restartsInARow = 0;
-        }
-        fresh = true;
-    }
-    return radiance;
-}
-
-template <int MODE>
-__global__ void __launch_bounds__(kBlock) k_megakernel(LaunchParams p, SceneView sv, TraceScene sc, float4 *__restrict__ slotRad,
-                                                        uint32_t *__restrict__ counters)
-{
-    PT_DECLARE_STACK(st, kLdsStackMega, (uint32_t *)nullptr)
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t f = 0, s = 0;
-    if (slot < p.numSlots)
-        slotFrame(p, slot, f, s);
-    const uint32_t pixel = slot < p.numSlots ? slotPixel(p, s) : 0xffffffffu;
-    PathCounters pc;
-    f3 radiance = F3s(0.0f);
-    if (pixel != 0xffffffffu)
-    {
-        uint32_t rng = initRng(pixel % p.width, pixel / p.width, p.width, p.firstFrame + f);
-        DiffRays diff;
-        diff.rxOrigin = diff.rxDirection = diff.ryOrigin = diff.ryDirection = F3s(0.0f);
-        int smpl = 0;
-        radiance = runPath<MODE>(p, sv, sc, st, pixel, rng, F3s(0.0f), F3s(1.0f), F3s(0.0f), F3s(0.0f), diff, 0.0f, 0u, smpl, true, pc);
-    }
-    if (slot < p.numSlots)
-        slotRad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-    if (st.overflow)
-        atomicAdd(&counters[C_OVERFLOW], 1u);
-    if (pc.stuck)
-        atomicAdd(&counters[C_OVERFLOW + 1], 1u);
-    waveAddCounter(&counters[C_SEGMENTS], pc.nSeg);
-    waveAddCounter(&counters[C_HITS], pc.nHit);
-    waveAddCounter(&counters[C_SAMPLES], pc.nSmp);
-    waveAddCounter(&counters[C_RETRIES], pc.nRetry);
-}
-
-// The slots of queue `qin` sit at a bounce boundary (ray, throughput, radiance, RNG and
-// bounce/sample counters in the SoA state, no shadow query pending): run each to the end of its sample.  A slot
-// with samples left (multi-sample launch, NaN restart) goes back through the restart queue and the wavefront
-// kernels: finishing ALL its samples here, one thread per path at 2 waves / SIMD, made a SampleCount = 8 launch six
-// times slower than eight one-sample launches.
-// k_tail is latency-bound at whatever occupancy it gets: a 32-entry LDS stack (overflow into the global region of the
-// traversal kernels) instead of 64 entries lifts the LDS limit of two blocks per CU, and 168 VGPRs (7 spilled dwords in
-// mode 0) make it three waves per SIMD: 1.50 -> 1.08 ms per chess_like step
-#ifndef PT_TAIL_ATTR
-#define PT_TAIL_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
-#endif
-#ifndef PT_TAIL_LDS
-#define PT_TAIL_LDS 32
-#endif
-#ifndef PT_TAIL_TEX_ATTR
-#define PT_TAIL_TEX_ATTR PT_TAIL_ATTR
-#endif
-template <int MODE>
-PT_DEV void tailBody(const LaunchParams &p, const SceneView &sv, const TraceScene &sc, const Wavefront &wf, int qin, const BounceCtl &ctl);
-template <int MODE>
-__global__ void __launch_bounds__(kBlock) k_tail(LaunchParams p, SceneView sv, TraceScene sc, Wavefront wf, int qin, BounceCtl ctl);
-template <>
-__global__ void __launch_bounds__(kBlock) PT_TAIL_ATTR k_tail<0>(LaunchParams p, SceneView sv, TraceScene sc, Wavefront wf, int qin, BounceCtl ctl)
-{
-    tailBody<0>(p, sv, sc, wf, qin, ctl);
-}
-template <>
-__global__ void __launch_bounds__(kBlock) PT_TAIL_TEX_ATTR k_tail<1>(LaunchParams p, SceneView sv, TraceScene sc, Wavefront wf, int qin, BounceCtl ctl)
-{
-    tailBody<1>(p, sv, sc, wf, qin, ctl);
-}
-template <>
-__global__ void __launch_bounds__(kBlock) PT_TAIL_TEX_ATTR k_tail<2>(LaunchParams p, SceneView sv, TraceScene sc, Wavefront wf, int qin, BounceCtl ctl)
-{
-    tailBody<2>(p, sv, sc, wf, qin, ctl);
-}
-// Launched after the shadow kernel of every bounce, on that kernel's stream (so the NEE adds of the bounce have landed
-// in rad[slot]): it takes the queue over once it is short enough -- the complement of bounceRuns() for the bounces that
-// follow, which then find the queue is not theirs and return.
-template <int MODE>
-PT_DEV void tailBody(const LaunchParams &p, const SceneView &sv, const TraceScene &sc, const Wavefront &wf, int qin, const BounceCtl &ctl)
-{
-    const uint32_t count = wf.counters[queueCounter(qin)];
-    if (count == 0u || count > ctl.tailBelow) // ctl.bounce = the bounce whose shade kernel filled the queue
-        return;
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-    {
-        wf.counters[C_TAIL_PATHS] = count;
-        wf.counters[C_TAIL_PATHS + 1] = ctl.bounce;
-    }
-    PT_DECLARE_STACK(st, PT_TAIL_LDS, wf.spill)
-    PathCounters pc;
-    // (Dealing the paths to every 2nd / 4th / 8th lane -- a wave runs each bounce for as long as its slowest path takes, so fewer
-    // paths per wave shorten every wave's chain and put more waves on a SIMD -- was measured: with frames in flight the lanes
-    // it wastes are not free.  chess_like whole frame 7.36 / 7.12 -> 7.39 / 7.26 ms per step, a rank's shard of 8 1.29 / 1.27 ->
-    // 1.35 / 1.34, of 4 2.07 -> 2.23, street_like's shard of 8 1.96 -> 2.04.)
-    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x)
-    {
-        const uint32_t i = base + threadIdx.x;
-        bool restart = false;
-        uint32_t restartSlot = 0;
-        if (i < count)
-        {
-            const uint32_t slot = wf.queue[qin][i];
-            const uint4 meta = wf.meta[slot];
-            const float4 o4 = wf.rayO[slot], d4 = wf.rayD[slot];
-            float4 r4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), t4 = make_float4(1.0f, 1.0f, 1.0f, 0.0f); // see k_shade
-            if (meta.z != 0u)
-                r4 = wf.rad[slot];
-            if ((meta.z & 0xffffu) != 0u)
-                t4 = wf.thr[slot];
-            uint32_t rng = meta.x;
-            DiffRays diff;
-            if (MODE >= 1)
-                diff = loadDiff(wf, slot);
-            else
-                diff.rxOrigin = diff.rxDirection = diff.ryOrigin = diff.ryDirection = F3s(0.0f);
-            int smpl = (int)(meta.z >> 16);
-            const f3 radiance = runPath<MODE, true>(p, sv, sc, st, meta.y, rng, F3(r4.x, r4.y, r4.z), F3(t4.x, t4.y, t4.z), F3(o4.x, o4.y, o4.z),
-                                                   F3(d4.x, d4.y, d4.z), diff, o4.w, meta.z & 0xffffu, smpl, false, pc);
-            if (smpl < (int)p.u.SampleCount)
-            {
-                wf.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-                wf.meta[slot] = make_uint4(rng, meta.y, (uint32_t)smpl << 16, meta.w);
-                restart = true;
-                restartSlot = slot;
-            }
-            else
-                wf.slotRad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-        }
-        pushRestarts(wf, restart, restartSlot); // k_restart draws the next primary ray before the queue is consumed
-    }
-    if (st.overflow)
-        atomicAdd(&wf.counters[C_OVERFLOW], 1u);
-    waveAddCounter(&wf.counters[C_SEGMENTS], pc.nSeg);
-    waveAddCounter(&wf.counters[C_HITS], pc.nHit);
-    waveAddCounter(&wf.counters[C_SAMPLES], pc.nSmp);
-    waveAddCounter(&wf.counters[C_RETRIES], pc.nRetry);
-}
-
-// The rare slots whose sample came out NaN / Inf in a canonical (SampleCount = 1) launch: raygen.rgen:99-112 restarts
-// the sample with the RNG carried on.  They sit in the restart queue with radiance 0 and smpl = 0; this kernel runs each
-// of them to the end of the launch the way the megakernel would (new primary ray, whole path, again if the radiance is
-// bad again), so that a launch completes on the device without the host looking at the queue.  Multi-sample launches do
-// NOT come here: their restart queue holds every slot once per extra sample, and goes through the wavefront kernels
-// round by round (renderImpl).
-template <int MODE>
-__global__ void __launch_bounds__(kBlock) PT_TAIL_TEX_ATTR k_finish_restarts(LaunchParams p, SceneView sv, TraceScene sc, Wavefront wf)
-{
-    const uint32_t count = wf.counters[C_RESTART];
-    if (count == 0u)
-        return;
-    PT_DECLARE_STACK(st, PT_TAIL_LDS, wf.spill)
-    PathCounters pc;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
-    {
-        const uint32_t slot = wf.restartQueue[i];
-        const uint4 meta = wf.meta[slot];
-        const float4 r4 = wf.rad[slot];
-        uint32_t rng = meta.x;
-        DiffRays diff;
-        diff.rxOrigin = diff.rxDirection = diff.ryOrigin = diff.ryDirection = F3s(0.0f);
-        int smpl = (int)(meta.z >> 16);
-        const f3 radiance = runPath<MODE>(p, sv, sc, st, meta.y, rng, F3(r4.x, r4.y, r4.z), F3s(1.0f), F3s(0.0f), F3s(0.0f), diff, 0.0f, 0u, smpl,
-                                          true, pc);
-        wf.slotRad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-    }
-    if (st.overflow)
-        atomicAdd(&wf.counters[C_OVERFLOW], 1u);
-    if (pc.stuck)
-        atomicAdd(&wf.counters[C_OVERFLOW + 1], 1u);
-    waveAddCounter(&wf.counters[C_SEGMENTS], pc.nSeg);
-    waveAddCounter(&wf.counters[C_HITS], pc.nHit);
-    waveAddCounter(&wf.counters[C_SAMPLES], pc.nSmp);
-    waveAddCounter(&wf.counters[C_RETRIES], pc.nRetry);
-}
-
-// =====================================================================================
-// Utility kernels
-// =====================================================================================
-
-// skinning.comp:21-50: 4-bone linear-blend skinning of one output vertex.  bones = mat3x4[]: "vec4 * mat3x4" is the
-// dot product with each stored row, i.e. a bone is the affine matrix in 3 rows x 4; the normal goes through the
-// inverse transpose of its linear part.
-__global__ void k_skin(const PtxAnimatedVertex *__restrict__ in, const uint32_t *__restrict__ source, uint32_t count,
-                       const PtxTransform *__restrict__ bones, uint32_t boneCount, PtxVertex *__restrict__ out)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count)
-        return;
-    const PtxAnimatedVertex a = in[source[i]];
-    f3 P = F3s(0.0f), N = F3s(0.0f), T = F3s(0.0f), B = F3s(0.0f);
-    float totalWeight = 0;
-    for (int k = 0; k < 4 && totalWeight < 1.0f; k++)
-    {
-        const uint32_t boneIndex = a.BoneIndices[k];
-        const float w = a.BoneWeights[k];
-        float M[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
-        if (boneIndex < boneCount)
-            for (int q = 0; q < 12; q++)
-                M[q] = bones[boneIndex].m[q];
-        P = P + xformPoint(M, ld3(a.Position)) * w;
-        T = T + normalize(xformVector(M, ld3(a.Tangent))) * w;
-        B = B + normalize(xformVector(M, ld3(a.Bitangent))) * w;
-        mat3 R;
-        R.c0 = F3(M[0], M[4], M[8]);
-        R.c1 = F3(M[1], M[5], M[9]);
-        R.c2 = F3(M[2], M[6], M[10]);
-        const mat3 Ri = inverse(R);
-        const f3 n = ld3(a.Normal);
-        N = N + normalize(F3(dot(n, Ri.c0), dot(n, Ri.c1), dot(n, Ri.c2))) * w;
-        totalWeight += w;
-    }
-    PtxVertex o;
-    o.Position[0] = P.x; o.Position[1] = P.y; o.Position[2] = P.z;
-    o.TexCoords[0] = a.TexCoords[0]; o.TexCoords[1] = a.TexCoords[1];
-    o.Normal[0] = N.x; o.Normal[1] = N.y; o.Normal[2] = N.z;
-    o.Tangent[0] = T.x; o.Tangent[1] = T.y; o.Tangent[2] = T.z;
-    o.Bitangent[0] = B.x; o.Bitangent[1] = B.y; o.Bitangent[2] = B.z;
-    out[i] = o;
-}
-
-// traceRayEXT stand-in over explicit rays (o.xyz, tmin, d.xyz, tmax): traversal parity tests
-struct RaysIO
-{
-    static constexpr float kFixedTmin = -1.0f, kFixedTmax = -1.0f; // per ray
-    static constexpr bool kNeedsPrim = true;     // ptx_trace_rays reports (pair, prim)
-    static constexpr bool kHasQueue = false;
-    PT_DEV uint32_t queueEntry(uint32_t item) const { return item; }
-    PT_DEV void setEntry(uint32_t) {}
-    const float4 *rays;
-    float4 *outHit;
-    uint2 *outIds;
-    PT_DEV bool load(uint32_t item, f3 &o, f3 &d, float &tmin, float &tmax)
-    {
-        const float4 o4 = rays[2 * item], d4 = rays[2 * item + 1];
-        o = F3(o4.x, o4.y, o4.z);
-        d = F3(d4.x, d4.y, d4.z);
-        tmin = o4.w;
-        tmax = d4.w;
-        return true;
-    }
-    PT_DEV void ignored(float, float, float, uint32_t, const TraceScene &) {}
-    // closest-hit queries: (u, v) and the triangle of the best hit so far wait in the output record
-    PT_DEV void improve(uint32_t item, float t, float u, float v, uint32_t triSlot) { outHit[item] = make_float4(t, u, v, __uint_as_float(triSlot)); }
-    PT_DEV uint32_t bestSlot(uint32_t item) const { return __float_as_uint(outHit[item].w); }
-    PT_DEV void store(uint32_t item, const Hit &h, bool hitAny, bool anyHitQuery)
-    {
-        const float4 cur = outHit[item];
-        const bool kept = hitAny && !anyHitQuery; // improve() has written (u, v)
-        outHit[item] = make_float4(h.t, kept ? cur.y : 0.0f, kept ? cur.z : 0.0f, hitAny ? 1.0f : 0.0f);
-        outIds[item] = make_uint2(h.pair, h.prim);
-    }
-};
-
-template <bool ALPHA>
-__global__ void __launch_bounds__(kBlock) k_trace_rays(TraceScene sc, const float4 *__restrict__ rays, uint32_t n, int anyHit,
-                                                        float4 *__restrict__ outHit, uint2 *__restrict__ outIds, uint32_t *chunkCounter, uint32_t *spill)
-{
-    PT_DECLARE_STACK(st, kLdsStack, spill)
-    if (anyHit == 2) // diagnostics: closest hit, returning (node visits, triangle tests) instead of ids
-    {
-        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        {
-            const float4 o = rays[2 * i], d = rays[2 * i + 1];
-            Hit h;
-            uint32_t nv = 0, nt = 0;
-            const bool hitAny = traceRay<false, true, ALPHA>(sc, F3(o.x, o.y, o.z), F3(d.x, d.y, d.z), o.w, d.w, st, h, &nv, &nt);
-            outHit[i] = make_float4(h.t, h.u, h.v, hitAny ? 1.0f : 0.0f);
-            outIds[i] = make_uint2(nv, nt);
-        }
-        return;
-    }
-    RaysIO io = { rays, outHit, outIds };
-    if (anyHit)
-        persistentTrace<true, ALPHA>(sc, io, n, chunkCounter, st);
-    else
-        persistentTrace<false, ALPHA>(sc, io, n, chunkCounter, st);
-}
-
-// shard pack / unpack: tile-major dense buffer [ownedTile][tileSize^2] of RGBA32F
-// the image to page-locked host memory with a few workgroups: posted writes over PCIe
-__global__ void __launch_bounds__(kBlock) k_copy_out(const float4 *__restrict__ src, float4 *__restrict__ dst, uint32_t n)
-{
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        dst[i] = src[i];
-}
-
-__global__ void k_pack_shard(LaunchParams p, const float4 *__restrict__ image, float4 *__restrict__ dst)
-{
-    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < p.slotsPerFrame; s += gridDim.x * blockDim.x)
-    {
-        const uint32_t pixel = slotPixel(p, s);
-        dst[s] = pixel == 0xffffffffu ? make_float4(0, 0, 0, 0) : image[pixel];
-    }
-}
-__global__ void k_unpack_shard(LaunchParams p, const float4 *__restrict__ src, float4 *__restrict__ image)
-{
-    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < p.slotsPerFrame; s += gridDim.x * blockDim.x)
-    {
-        const uint32_t pixel = slotPixel(p, s);
-        if (pixel != 0xffffffffu)
-            image[pixel] = src[s];
-    }
-}
-
-// What a tree costs the rays of a path tracer: node visits + triangle tests of `n` closest-hit queries between the centroids
-// of pseudo-random pairs of triangles -- segments from surface to surface, like the segments of a path.  ptx_build_accel
-// builds the tree with more than one search radius and keeps the cheaper one: "lower surface-area cost" does not always mean
-// "fewer visits" (street_like: a wider PLOC search gives 13 % MORE visits per ray), and results never depend on the tree.
-template <bool ALPHA>
-__global__ void __launch_bounds__(kBlock) k_sample_tree_cost(TraceScene sc, uint32_t n, uint32_t *spill, uint32_t *cost)
-{
-    PT_DECLARE_STACK(st, kLdsStack, spill)
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t visits = 0, tests = 0;
-    if (i < n && sc.triCount > 1u)
-    {
-        const uint32_t a = jenkinsHash(2u * i + 1u) % sc.triCount, b = jenkinsHash(jenkinsHash(2u * i + 2u)) % sc.triCount;
-        const Tri ta = sc.tris[a], tb = sc.tris[b];
-        const float third = 1.0f / 3.0f;
-        const f3 ca = F3(ta.a.x + (ta.a.w + ta.b.z) * third, ta.a.y + (ta.b.x + ta.b.w) * third, ta.a.z + (ta.b.y + ta.c.x) * third);
-        const f3 cb = F3(tb.a.x + (tb.a.w + tb.b.z) * third, tb.a.y + (tb.b.x + tb.b.w) * third, tb.a.z + (tb.b.y + tb.c.x) * third);
-        const f3 d = cb - ca;
-        const float len = __builtin_sqrtf(dot(d, d));
-        if (len > 0.0f)
-        {
-            Hit best;
-            // the segment between the two surfaces, not the line through them: a path segment ends where it lands, and a line
-            // that runs on inside a slab of alpha-tested cards costs a thousand visits that no path ray pays
-            traceRay<false, true, ALPHA>(sc, ca, d * (1.0f / len), 1e-4f * len, 1.001f * len, st, best, &visits, &tests);
-        }
-    }
-    waveAddCounter(cost, visits + tests); // one dependent fetch each; one atomic per wave (65,536 same-address atomics took 13 ms)
-}
-
-// ---- textures (row N1): sRGB table and the mip chain are produced on the device ------------------
-__global__ void k_build_srgb_lut(float *lut)
-{
-    const uint32_t c = threadIdx.x;
-    if (c < 256)
-        lut[c] = srgbToLinear((float)c / 255.0f);
-}
-
-// vkCmdBlitImage with a linear filter (Image.cpp:264-300, TextureUploader.cpp:479-490): every texel of level `dstLevel` of
-// texture `dst` = the source level decoded and filtered bilinearly at the destination texel centre with clamp-to-edge,
-// re-encoded in the image format.  One level of a mip chain is the blit from the level above it (src == dst).
-__global__ void k_blit_level(TextureView tv, uint32_t src, uint32_t srcLevel, uint32_t dst, uint32_t dstLevel, uint32_t *texels8, float4 *texelsF)
-{
-    const DevTexture ts = tv.textures[src], td = tv.textures[dst];
-    const uint32_t sw = levelDim(ts.width, srcLevel), sh = levelDim(ts.height, srcLevel);
-    const uint32_t dw = levelDim(td.width, dstLevel), dh = levelDim(td.height, dstLevel);
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= dw * dh)
-        return;
-    const uint32_t i = k % dw, j = k / dw;
-    const float x = ((float)i + 0.5f) * ((float)sw / (float)dw) - 0.5f, y = ((float)j + 0.5f) * ((float)sh / (float)dh) - 0.5f;
-    const float x0 = __builtin_floorf(x), y0 = __builtin_floorf(y), ax = x - x0, ay = y - y0;
-    const float cx0 = clamp_(x0, 0.0f, (float)(sw - 1)), cx1 = clamp_(x0 + 1.0f, 0.0f, (float)(sw - 1));
-    const float cy0 = clamp_(y0, 0.0f, (float)(sh - 1)), cy1 = clamp_(y0 + 1.0f, 0.0f, (float)(sh - 1));
-    const f4 top = lerp4(fetchTexelEncoded(tv, ts, srcLevel, (uint32_t)cx0, (uint32_t)cy0), fetchTexelEncoded(tv, ts, srcLevel, (uint32_t)cx1, (uint32_t)cy0), ax);
-    const f4 bot = lerp4(fetchTexelEncoded(tv, ts, srcLevel, (uint32_t)cx0, (uint32_t)cy1), fetchTexelEncoded(tv, ts, srcLevel, (uint32_t)cx1, (uint32_t)cy1), ax);
-    const f4 c = lerp4(top, bot, ay);
-    const size_t idx = (size_t)td.levelOffset[dstLevel] + (size_t)j * dw + i;
-    if (td.format == PTX_TEXTURE_RGBA32F)
-        texelsF[idx] = make_float4(c.x, c.y, c.z, c.w);
-    else if (td.format == PTX_TEXTURE_RGBA8_SRGB)
-        texels8[idx] = quantize8(linearToSrgb(c.x)) | quantize8(linearToSrgb(c.y)) << 8 | quantize8(linearToSrgb(c.z)) << 16 | quantize8(c.w) << 24;
-    else
-        texels8[idx] = quantize8(c.x) | quantize8(c.y) << 8 | quantize8(c.z) << 16 | quantize8(c.w) << 24;
-}
-
-// All levels of one 8-bit texture (a contiguous run of its pool) into the decoded pool the render kernels sample.
-__global__ void k_decode_texels(const uint32_t *__restrict__ texels8, const float *__restrict__ srgbLut, uint32_t first, uint32_t count, uint32_t format,
-                                float4 *__restrict__ decoded)
-{
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= count)
-        return;
-    const uint32_t p = texels8[first + k];
-    float4 r;
-    if (format == PTX_TEXTURE_RGBA8_SRGB)
-    {
-        r.x = srgbLut[p & 255u]; r.y = srgbLut[(p >> 8) & 255u]; r.z = srgbLut[(p >> 16) & 255u];
-    }
-    else
-    {
-        r.x = (float)(p & 255u) / 255.0f; r.y = (float)((p >> 8) & 255u) / 255.0f; r.z = (float)((p >> 16) & 255u) / 255.0f;
-    }
-    r.w = (float)(p >> 24) / 255.0f;
-    decoded[k] = r;
-}
-
-__global__ void k_test_texture(TextureView tv, const float *__restrict__ in, float *__restrict__ out, uint32_t n, int implicitLod)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n)
-        return;
-    const float *a = in + (size_t)i * 7;
-    const uint32_t idx = __float_as_uint(a[0]);
-    f4 r;
-    r.x = r.y = r.z = r.w = 1.0f;
-    if (idx >= PTX_SCENE_TEXTURE_OFFSET && idx - PTX_SCENE_TEXTURE_OFFSET < tv.textureCount)
-    {
-        const DevTexture t = tv.textures[idx - PTX_SCENE_TEXTURE_OFFSET];
-        r = implicitLod ? sampleLevel(tv, t, 0, a[1], a[2]) : textureGradSample(tv, t, a[1], a[2], a[3], a[4], a[5], a[6]);
-    }
-    out[i * 4] = r.x; out[i * 4 + 1] = r.y; out[i * 4 + 2] = r.z; out[i * 4 + 3] = r.w;
-}
-
-// function-level entry (Path-Tracing-Tests/TestRenderer.cpp:79-105 dispatches a compute
-// shader that calls the production functions; packing documented in include/ptx.h)
-__constant__ int c_inStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4, 3, 3, 2, 6, 7, 3, 47 };
-__constant__ int c_outStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1, 2, 3, 2, 6, 3, 3, 17 };
-static const int h_inStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4, 3, 3, 2, 6, 7, 3, 47 };
-static const int h_outStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1, 2, 3, 2, 6, 3, 3, 17 };
-
-PT_DEV MaterialSample unpackMaterial(const float *p)
-{
-    MaterialSample m;
-    m.EmissiveColor = m.Normal = m.AttenuationColor = F3s(0.0f);
-    m.AttenuationDistance = 0.0f;
-    m.Color = F3(p[0], p[1], p[2]);
-    m.Roughness = p[3];
-    m.Metalness = p[4];
-    m.Transmission = p[5];
-    m.Eta = p[6];
-    return m;
-}
-
-__global__ void k_test_eval(uint32_t fn, const float *__restrict__ in, float *__restrict__ out, uint32_t n, PtxLightsUbo *scratchUbo)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n)
-        return;
-    const float *a = in + (size_t)i * c_inStride[fn];
-    float *o = out + (size_t)i * c_outStride[fn];
-    switch (fn)
-    {
-    case PTX_FN_GGX_DISTRIBUTION: o[0] = GGXDistribution(F3(a[0], a[1], a[2]), a[3]); break;
-    case PTX_FN_LAMBDA: o[0] = Lambda(F3(a[0], a[1], a[2]), a[3]); break;
-    case PTX_FN_GGX_SMITH: o[0] = GGXSmith(F3(a[0], a[1], a[2]), a[3]); break;
-    case PTX_FN_DIELECTRIC_FRESNEL: o[0] = DielectricFresnel(a[0], a[1]); break;
-    case PTX_FN_SCHLICK_FRESNEL: o[0] = SchlickFresnel(a[0]); break;
-    case PTX_FN_EVALUATE_REFLECTION: {
-        float pdf;
-        const f3 r = EvaluateReflection(F3(a[0], a[1], a[2]), F3(a[3], a[4], a[5]), F3(a[6], a[7], a[8]), a[9], pdf);
-        o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = pdf;
-        break;
-    }
-    case PTX_FN_EVALUATE_REFRACTION: {
-        float pdf;
-        const f3 r = EvaluateRefraction(F3(a[0], a[1], a[2]), F3(a[3], a[4], a[5]), F3(a[6], a[7], a[8]), a[9], a[10], pdf);
-        o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = pdf;
-        break;
-    }
-    case PTX_FN_SAMPLE_GGX: {
-        f2 u; u.x = a[0]; u.y = a[1];
-        const f3 r = SampleGGX(u, F3(a[2], a[3], a[4]), a[5]);
-        o[0] = r.x; o[1] = r.y; o[2] = r.z;
-        break;
-    }
-    case PTX_FN_SAMPLE_LOBE_PDFS: { // bsdf.glsl:62-70
-        const float metal = a[0], trans = a[1], F = a[2];
-        o[0] = (1.0f - metal) * (1.0f - F) * (1.0f - trans);
-        o[1] = (1.0f - metal) * F;
-        o[2] = metal;
-        o[3] = (1.0f - metal) * (1.0f - F) * trans;
-        break;
-    }
-    case PTX_FN_EVALUATE_BSDF: {
-        const MaterialSample m = unpackMaterial(a);
-        float pdf;
-        const f3 r = evaluateBSDF(m, F3(a[8], a[9], a[10]), F3(a[11], a[12], a[13]), pdf);
-        o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = pdf;
-        break;
-    }
-    case PTX_FN_SAMPLE_BSDF: {
-        const MaterialSample m = unpackMaterial(a);
-        uint32_t rng = __float_as_uint(a[11]);
-        const BSDFSample r = sampleBSDF(m, F3(a[8], a[9], a[10]), rng);
-        o[0] = r.Direction.x; o[1] = r.Direction.y; o[2] = r.Direction.z; o[3] = r.Pdf;
-        o[4] = r.Color.x; o[5] = r.Color.y; o[6] = r.Color.z; o[7] = __uint_as_float(rng);
-        break;
-    }
-    case PTX_FN_RNG: {
-        uint32_t stt = initRng(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3]));
-        o[0] = __uint_as_float(stt);
-        for (int k = 0; k < 4; k++)
-            o[1 + k] = rnd(stt);
-        break;
-    }
-    case PTX_FN_DISK: {
-        f2 u; u.x = a[0]; u.y = a[1];
-        const f2 d = sampleUniformDiskConcentric(u);
-        o[0] = d.x; o[1] = d.y;
-        break;
-    }
-    case PTX_FN_COS_HEMISPHERE: {
-        f2 u; u.x = a[0]; u.y = a[1];
-        const f3 d = sampleCosineHemisphere(u);
-        o[0] = d.x; o[1] = d.y; o[2] = d.z;
-        break;
-    }
-    case PTX_FN_TANGENT_SPACE: {
-        const mat3 m = computeTangentSpace(F3(a[0], a[1], a[2]));
-        o[0] = m.c0.x; o[1] = m.c0.y; o[2] = m.c0.z;
-        o[3] = m.c1.x; o[4] = m.c1.y; o[5] = m.c1.z;
-        o[6] = m.c2.x; o[7] = m.c2.y; o[8] = m.c2.z;
-        break;
-    }
-    case PTX_FN_OFFSET_SELF_INTERSECTION: {
-        const f3 r = offsetRayOriginSelfIntersection(F3(a[0], a[1], a[2]), F3(a[3], a[4], a[5]));
-        o[0] = r.x; o[1] = r.y; o[2] = r.z;
-        break;
-    }
-    case PTX_FN_PRIMARY_RAY: {
-        f2 u; u.x = a[4]; u.y = a[5];
-        f3 ro, rd, rx, ry;
-        constructPrimaryRay<true>(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3]), &a[6], &a[22], u, ro, rd,
-                                  rx, ry);
-        const f3 v[6] = { ro, rd, ro, rx, ro, ry };
-        for (int k = 0; k < 6; k++) { o[3 * k] = v[k].x; o[3 * k + 1] = v[k].y; o[3 * k + 2] = v[k].z; }
-        break;
-    }
-    case PTX_FN_SINCOS: sincos_(a[0], o[0], o[1]); break;
-    case PTX_FN_POW: o[0] = pow_(a[0], a[1]); break;
-    case PTX_FN_SAMPLE_LIGHT: {
-        PtxLightsUbo *ubo = &scratchUbo[i];
-        ubo->LightCount = __float_as_uint(a[6]);
-        for (int k = 0; k < 3; k++)
-        {
-            ubo->Directional.Color[k] = a[7 + k];
-            ubo->Directional.Direction[k] = a[10 + k];
-        }
-        for (int l = 0; l < 2; l++)
-        {
-            for (int k = 0; k < 3; k++)
-            {
-                ubo->Lights[l].Color[k] = a[13 + 9 * l + k];
-                ubo->Lights[l].Position[k] = a[16 + 9 * l + k];
-            }
-            ubo->Lights[l].AttenuationConstant = a[19 + 9 * l];
-            ubo->Lights[l].AttenuationLinear = a[20 + 9 * l];
-            ubo->Lights[l].AttenuationQuadratic = a[21 + 9 * l];
-        }
-        float pdf;
-        const LightSample ls = sampleLight(ubo, F3(a[0], a[1], a[2]), F3(a[3], a[4], a[5]), pdf);
-        o[0] = ls.Direction.x; o[1] = ls.Direction.y; o[2] = ls.Direction.z; o[3] = ls.Distance;
-        o[4] = ls.Color.x; o[5] = ls.Color.y; o[6] = ls.Color.z; o[7] = ls.Attenuation; o[8] = pdf;
-        break;
-    }
-    case PTX_FN_SHADOW_TERMINATOR: {
-        const f3 r = offsetRayOriginShadowTerminator(F3(a[0], a[1], a[2]), F3(a[3], a[4], a[5]), F3(a[6], a[7], a[8]), F3(a[9], a[10], a[11]),
-                                                     F3(a[12], a[13], a[14]), F3(a[15], a[16], a[17]), F3(a[18], a[19], a[20]),
-                                                     F3(a[21], a[22], a[23]), a[24] != 0.0f);
-        o[0] = r.x; o[1] = r.y; o[2] = r.z;
-        break;
-    }
-    case PTX_FN_PRIMARY_RAY_LENS: {
-        f2 u, u2; u.x = a[4]; u.y = a[5]; u2.x = a[6]; u2.y = a[7];
-        f3 ro, rd, rx, ry;
-        constructPrimaryRayLens<true>(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3]), &a[10], &a[26],
-                                      u, u2, a[8], a[9], ro, rd, rx, ry);
-        const f3 v[6] = { ro, rd, ro, rx, ro, ry };
-        for (int k = 0; k < 6; k++) { o[3 * k] = v[k].x; o[3 * k + 1] = v[k].y; o[3 * k + 2] = v[k].z; }
-        break;
-    }
-    case PTX_FN_DPN_DUV: {
-        f3 P[3], N[3];
-        f2 UV[3];
-        for (int k = 0; k < 3; k++)
-        {
-            P[k] = F3(a[8 * k], a[8 * k + 1], a[8 * k + 2]);
-            N[k] = F3(a[8 * k + 3], a[8 * k + 4], a[8 * k + 5]);
-            UV[k].x = a[8 * k + 6];
-            UV[k].y = a[8 * k + 7];
-        }
-        f3 r0, r1, r2, r3;
-        computeDpnDuv(P, N, UV, F3(a[24], a[25], a[26]), F3(a[27], a[28], a[29]), r0, r1, r2, r3);
-        o[0] = r0.x; o[1] = r0.y; o[2] = r0.z; o[3] = r1.x; o[4] = r1.y; o[5] = r1.z;
-        o[6] = r2.x; o[7] = r2.y; o[8] = r2.z; o[9] = r3.x; o[10] = r3.y; o[11] = r3.z;
-        break;
-    }
-    case PTX_FN_DP_DXY: {
-        f3 dx, dy;
-        computeDpDxy(F3(a[0], a[1], a[2]), F3(a[9], a[10], a[11]), F3(a[12], a[13], a[14]), F3(a[15], a[16], a[17]), F3(a[18], a[19], a[20]),
-                     F3(a[21], a[22], a[23]), dx, dy);
-        o[0] = dx.x; o[1] = dx.y; o[2] = dx.z; o[3] = dy.x; o[4] = dy.y; o[5] = dy.z;
-        break;
-    }
-    case PTX_FN_DERIVATIVES: {
-        const f4 r = computeDerivatives(F3(a[0], a[1], a[2]), F3(a[3], a[4], a[5]), F3(a[6], a[7], a[8]), F3(a[9], a[10], a[11]));
-        o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w;
-        break;
-    }
-    case PTX_FN_REFLECTED_DIFFERENTIALS:
-    case PTX_FN_REFRACTED_DIFFERENTIALS: {
-        f4 dv; dv.x = a[0]; dv.y = a[1]; dv.z = a[2]; dv.w = a[3];
-        DiffRays r;
-        r.rxOrigin = F3(a[22], a[23], a[24]); r.rxDirection = F3(a[25], a[26], a[27]);
-        r.ryOrigin = F3(a[28], a[29], a[30]); r.ryDirection = F3(a[31], a[32], a[33]);
-        if (fn == PTX_FN_REFLECTED_DIFFERENTIALS)
-            computeReflectedDifferentialRays(dv, F3(a[4], a[5], a[6]), F3(a[7], a[8], a[9]), F3(a[10], a[11], a[12]), F3(a[13], a[14], a[15]),
-                                             F3(a[16], a[17], a[18]), F3(a[19], a[20], a[21]), r);
-        else
-            computeRefractedDifferentialRays(dv, F3(a[4], a[5], a[6]), F3(a[7], a[8], a[9]), F3(a[10], a[11], a[12]), F3(a[13], a[14], a[15]),
-                                             F3(a[16], a[17], a[18]), F3(a[19], a[20], a[21]), a[34], r);
-        o[0] = r.rxOrigin.x; o[1] = r.rxOrigin.y; o[2] = r.rxOrigin.z; o[3] = r.rxDirection.x; o[4] = r.rxDirection.y; o[5] = r.rxDirection.z;
-        o[6] = r.ryOrigin.x; o[7] = r.ryOrigin.y; o[8] = r.ryOrigin.z; o[9] = r.ryDirection.x; o[10] = r.ryDirection.y; o[11] = r.ryDirection.z;
-        break;
-    }
-    case PTX_FN_SKYBOX_TEXCOORDS: {
-        const f2 uv = missSkyboxTexCoords(F3(a[0], a[1], a[2]));
-        o[0] = uv.x; o[1] = uv.y;
-        break;
-    }
-    case PTX_FN_HDR_TO_LDR: {
-        const f3 r = hdrToLdr(F3(a[0], a[1], a[2]));
-        o[0] = r.x; o[1] = r.y; o[2] = r.z;
-        break;
-    }
-    case PTX_FN_ATAN_ASIN:
-        o[0] = atan2_(a[0], a[1]);
-        o[1] = asin_(a[0]);
-        break;
-    case PTX_FN_POSTPROCESS_PIXEL: {
-        PtxPostProcessingUniformData u;
-        u.TotalSamples = __float_as_uint(a[3]); u.Exposure = a[4]; u.BloomThreshold = a[5]; u.BloomIntensity = 0.0f;
-        f3 c, b;
-        postprocessPixel(F3(a[0], a[1], a[2]), u, c, b);
-        o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = b.x; o[4] = b.y; o[5] = b.z;
-        break;
-    }
-    case PTX_FN_COMPOSITION_PIXEL: {
-        PtxPostProcessingUniformData u;
-        u.TotalSamples = 1u; u.Exposure = u.BloomThreshold = 0.0f; u.BloomIntensity = a[6];
-        const f3 c = compositionPixel(F3(a[0], a[1], a[2]), F3(a[3], a[4], a[5]), u);
-        o[0] = c.x; o[1] = c.y; o[2] = c.z;
-        break;
-    }
-    case PTX_FN_TONEMAP_PIXEL: {
-        const f3 c = toneMapPixel(F3(a[0], a[1], a[2]), PTX_TONE_MAPPING_SDR);
-        o[0] = c.x; o[1] = c.y; o[2] = c.z;
-        break;
-    }
-    case PTX_FN_COMPUTE_LOD: {
-        f4 dv; dv.x = a[0]; dv.y = a[1]; dv.z = a[2]; dv.w = a[3];
-        o[0] = computeLod(dv);
-        break;
-    }
-    case PTX_FN_SAMPLE_MATERIAL: {
-        const uint32_t type = __float_as_uint(a[0]);
-        const bool inside = __float_as_uint(a[1]) != 0u, flip = __float_as_uint(a[2]) != 0u;
-        MaterialTexels t;
-        f4 *tx[5] = { &t.emissive, &t.color, &t.normal, &t.a, &t.b };
-        for (int k = 0; k < 5; k++)
-        {
-            tx[k]->x = a[27 + 4 * k]; tx[k]->y = a[28 + 4 * k]; tx[k]->z = a[29 + 4 * k]; tx[k]->w = a[30 + 4 * k];
-        }
-        MaterialSample m;
-        if (type == PTX_MATERIAL_TYPE_METALLIC_ROUGHNESS)
-            m = sampleMaterial(reinterpret_cast<const PtxMetallicRoughnessMaterial *>(a + 3), t, inside);
-        else if (type == PTX_MATERIAL_TYPE_SPECULAR_GLOSSINESS)
-            m = sampleMaterial(reinterpret_cast<const PtxSpecularGlossinessMaterial *>(a + 3), t, inside);
-        else if (type == PTX_MATERIAL_TYPE_PHONG)
-            m = sampleMaterial(reinterpret_cast<const PtxPhongMaterial *>(a + 3), t, inside);
-        else
-            m = unknownMaterial();
-        if (flip)
-            m.Normal.y *= -1;
-        o[0] = m.EmissiveColor.x; o[1] = m.EmissiveColor.y; o[2] = m.EmissiveColor.z; o[3] = m.Color.x; o[4] = m.Color.y; o[5] = m.Color.z;
-        o[6] = m.Normal.x; o[7] = m.Normal.y; o[8] = m.Normal.z; o[9] = m.Roughness; o[10] = m.Metalness; o[11] = m.Transmission; o[12] = m.Eta;
-        o[13] = m.AttenuationColor.x; o[14] = m.AttenuationColor.y; o[15] = m.AttenuationColor.z; o[16] = m.AttenuationDistance;
-        break;
-    }
-    default: break;
-    }
-}
 
 // =====================================================================================
 // Host side: the renderer object behind the C-ABI
@@ -1735,8 +56,53 @@ template <typename T> struct DevBuf
     }
 };
 
+// The environment switches of the library (INTEGRATION.md lists them): experiment and test knobs, read ONCE per handle when it
+// is created -- no entry point calls getenv afterwards, and a handle keeps the values it was created with.
+struct EnvSwitches
+{
+    bool verbose = false;        // PTX_VERBOSE: progress and statistics on stderr
+    bool karrasBuilder = false;  // PTX_BUILDER=lbvh: Karras topology instead of PLOC
+    bool plocFixed = false;      // PTX_PLOC_RADIUS / PTX_PLOC_SHAPE given: ONE tree with these parameters, no candidates
+    uint32_t plocRadius = 0;     // PTX_PLOC_RADIUS
+    float plocShape = 0.0f;      // PTX_PLOC_SHAPE
+    int shadeSort = -1;          // PTX_SHADE_SORT=0 / 1 overrides the scene's choice (-1: not given)
+    long tailThreshold = -1;     // PTX_TAIL_THRESHOLD: live paths at or below which k_tail takes over (-1: the default)
+    uint32_t framesPerWave = 8;  // PTX_FRAMES_PER_WAVE: samples of one pixel in neighbouring lanes, at most this many
+    uint32_t raysPerThread = 0;  // PTX_RAYS_PER_THREAD (process-wide: the last handle created sets it)
+    long residentCap = -1;       // PTX_RESIDENT_CAP=0: persistent grids are not capped at the resident block count
+    static EnvSwitches read()
+    {
+        EnvSwitches e;
+        e.verbose = getenv("PTX_VERBOSE") != nullptr;
+        if (const char *v = getenv("PTX_BUILDER"))
+            e.karrasBuilder = std::strcmp(v, "lbvh") == 0;
+        if (const char *v = getenv("PTX_PLOC_SHAPE"))
+        {
+            e.plocFixed = true;
+            e.plocShape = (float)atof(v);
+        }
+        if (const char *v = getenv("PTX_PLOC_RADIUS"))
+        {
+            e.plocFixed = true;
+            e.plocRadius = std::max(1u, (uint32_t)strtoul(v, nullptr, 10));
+        }
+        if (const char *v = getenv("PTX_SHADE_SORT"))
+            e.shadeSort = atoi(v) ? 1 : 0;
+        if (const char *v = getenv("PTX_TAIL_THRESHOLD"))
+            e.tailThreshold = (long)strtoul(v, nullptr, 10);
+        if (const char *v = getenv("PTX_FRAMES_PER_WAVE"))
+            e.framesPerWave = (uint32_t)atoi(v);
+        if (const char *v = getenv("PTX_RAYS_PER_THREAD"))
+            e.raysPerThread = std::max(1u, (uint32_t)strtoul(v, nullptr, 10));
+        if (const char *v = getenv("PTX_RESIDENT_CAP"))
+            e.residentCap = (long)strtoul(v, nullptr, 10);
+        return e;
+    }
+};
+
 struct PtxRenderer
 {
+    EnvSwitches env;
     int device = 0;
     uint32_t backend = PTX_BACKEND_WAVEFRONT;
     hipStream_t stream = nullptr;
@@ -2011,7 +377,7 @@ static LaunchParams makeParams(const PtxRenderer *r, const PtxRaygenUniformData 
     p.frames = frames;
     p.firstFrame = firstFrame;
     p.numSlots = p.slotsPerFrame * frames;
-    static const uint32_t maxPerWave = getenv("PTX_FRAMES_PER_WAVE") ? (uint32_t)atoi(getenv("PTX_FRAMES_PER_WAVE")) : 8u;
+    const uint32_t maxPerWave = r->env.framesPerWave;
     p.framesPerWave = 1;
     while (p.framesPerWave < maxPerWave && p.framesPerWave < 8u && frames % (p.framesPerWave * 2u) == 0u)
         p.framesPerWave *= 2u;
@@ -2042,22 +408,9 @@ static uint32_t hardwareQueuesGranted()
 }
 static std::atomic<bool> g_queueWarningGiven{false};
 
-extern "C" {
+static void destroyRenderer(PtxRenderer *r);
 
-uint32_t ptx_abi_version(void)
-{
-    return PTX_ABI_VERSION;
-}
-
-int ptx_device_count(void)
-{
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess)
-        return 0;
-    return n;
-}
-
-int ptx_create(const PtxDeviceDesc *desc, PtxRenderer **out)
+static int createRenderer(const PtxDeviceDesc *desc, PtxRenderer **out)
 {
     if (!out)
         return PTX_ERROR_INVALID_ARGUMENT;
@@ -2084,21 +437,23 @@ int ptx_create(const PtxDeviceDesc *desc, PtxRenderer **out)
         }
         r->ownStream = true;
     }
-    if (const char *e = getenv("PTX_BUILDER"))
-        r->usePloc = std::strcmp(e, "lbvh") != 0;
-    if (const char *e = getenv("PTX_RAYS_PER_THREAD"))
-        g_raysPerThread = std::max(1u, (uint32_t)strtoul(e, nullptr, 10));
-    if (const char *e = getenv("PTX_PLOC_SHAPE"))
-        r->plocShape = (float)atof(e);
-    if (const char *e = getenv("PTX_PLOC_RADIUS"))
-        r->plocRadius = std::max(1u, (uint32_t)strtoul(e, nullptr, 10));
-    if (const char *e = getenv("PTX_RESIDENT_CAP"))
-        g_residentCap = (uint32_t)strtoul(e, nullptr, 10);
+    r->env = EnvSwitches::read(); // the only place the library reads its switches
+    r->usePloc = !r->env.karrasBuilder;
+    if (r->env.plocFixed)
+    {
+        r->plocShape = r->env.plocShape;
+        if (r->env.plocRadius)
+            r->plocRadius = r->env.plocRadius;
+    }
+    if (r->env.raysPerThread)
+        g_raysPerThread = r->env.raysPerThread;
+    if (r->env.residentCap >= 0)
+        g_residentCap = (uint32_t)r->env.residentCap;
     r->residentClosest[0] = residentBlocksOf(k_trace_closest<false>, r->device);
     r->residentClosest[1] = residentBlocksOf(k_trace_closest<true>, r->device);
     r->residentShadow[0] = residentBlocksOf(k_trace_shadow<false>, r->device);
     r->residentShadow[1] = residentBlocksOf(k_trace_shadow<true>, r->device);
-    if (getenv("PTX_VERBOSE"))
+    if (r->env.verbose)
         fprintf(stderr, "[ptx] resident blocks: closest %u / %u, shadow %u / %u\n", r->residentClosest[0], r->residentClosest[1], r->residentShadow[0],
                 r->residentShadow[1]);
     (void)hipEventCreate(&r->evA);
@@ -2109,7 +464,7 @@ int ptx_create(const PtxDeviceDesc *desc, PtxRenderer **out)
     if (r->counters.alloc(C_COUNT) != hipSuccess || r->lights.alloc(1) != hipSuccess || !r->hostCounters ||
         r->spill.alloc((size_t)kGlobalSpill * kMaxPersistentThreads) != hipSuccess)
     {
-        ptx_destroy(r);
+        destroyRenderer(r);
         return PTX_ERROR_OUT_OF_MEMORY;
     }
     r->stats.hardwareQueues = hardwareQueuesGranted();
@@ -2120,14 +475,14 @@ int ptx_create(const PtxDeviceDesc *desc, PtxRenderer **out)
         // not an error: the handle works, its frames just run behind the other handles' instead of beside them
         fail(r, PTX_OK, "%u handles (two streams each) share %u hardware queues: frames in flight will serialise; export GPU_MAX_HW_QUEUES=16 "
                         "before the process first uses HIP", live, (uint32_t)r->stats.hardwareQueues);
-        if (getenv("PTX_VERBOSE"))
+        if (r->env.verbose)
             fprintf(stderr, "[ptx] %s\n", r->error.c_str());
     }
     *out = r;
     return PTX_OK;
 }
 
-void ptx_destroy(PtxRenderer *r)
+static void destroyRenderer(PtxRenderer *r)
 {
     if (!r)
         return;
@@ -2167,22 +522,6 @@ void ptx_destroy(PtxRenderer *r)
     delete r;
 }
 
-const char *ptx_last_error(const PtxRenderer *r)
-{
-    return r ? r->error.c_str() : "null renderer";
-}
-
-int ptx_set_backend(PtxRenderer *r, uint32_t backend)
-{
-    if (!r || backend > PTX_BACKEND_MEGAKERNEL)
-        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_set_backend: bad backend %u", backend);
-    if (r->backend != backend)
-        r->hintSlots = 0u; // the learnt bounce schedule is the wavefront backend's
-    r->backend = backend;
-    return PTX_OK;
-}
-
-} // extern "C"
 
 // Does the material's branch of material.glsl:62-142 fetch a scene texture (an index at or past PTX_SCENE_TEXTURE_OFFSET inside
 // the uploaded table) through any of its five slots?  The five indices sit at the same offsets in the three 96-byte structs.
@@ -2242,9 +581,7 @@ template <typename T> static int upload(PtxRenderer *r, DevBuf<T> &buf, const T 
     return PTX_OK;
 }
 
-extern "C" {
-
-int ptx_share_scene(PtxRenderer *r, PtxRenderer *owner)
+static int shareScene(PtxRenderer *r, PtxRenderer *owner)
 {
     if (!r || !owner || r == owner)
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_share_scene: need two different renderers");
@@ -2280,7 +617,7 @@ int ptx_share_scene(PtxRenderer *r, PtxRenderer *owner)
     return PTX_OK;
 }
 
-int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *s)
+static int sceneUpload(PtxRenderer *r, const PtxSceneDesc *s)
 {
     if (!r || !s)
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_scene_upload: null argument");
@@ -2852,7 +1189,7 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
                 std::swap(hIn, hOut);
                 iterations++;
             }
-            if (getenv("PTX_VERBOSE"))
+            if (r->env.verbose)
                 std::fprintf(stderr, "[ptx] PLOC: %u triangles (%u inert left out), %u iterations\n", nv, n - nv, iterations);
             boxesDone = true;
         }
@@ -2885,7 +1222,7 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
             levels++;
         }
         r->stats.bvhNodes = hi;
-        if (getenv("PTX_VERBOSE"))
+        if (r->env.verbose)
             std::fprintf(stderr, "[ptx] relayout: %u of %u emitted nodes are live, %u levels\n", hi, nv - 1, levels);
     }
     if (r->anyNonOpaque && nv) // the any-hit records of the slots k_emit has just written
@@ -2935,7 +1272,7 @@ static int sampleTreeCost(PtxRenderer *r, unsigned long long *cost)
     return PTX_OK;
 }
 
-int ptx_build_accel(PtxRenderer *r)
+static int buildBestTree(PtxRenderer *r)
 {
     if (r && r->sceneOwner)
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_build_accel: this renderer shares another renderer's scene (ptx_share_scene)");
@@ -2949,7 +1286,7 @@ int ptx_build_accel(PtxRenderer *r)
     struct Candidate { uint32_t radius; float shape; bool cubic; };
     static const Candidate kTreeCandidates[] = { { 8u, 0.0f, false }, { 16u, 0.0f, false }, { 16u, 0.25f, false }, { 32u, 1.0f, false }, { 8u, 1.0f, true } };
     constexpr uint32_t kCandidates = sizeof(kTreeCandidates) / sizeof(kTreeCandidates[0]);
-    if (!r->usePloc || getenv("PTX_PLOC_RADIUS") || getenv("PTX_PLOC_SHAPE") || r->triCount < 4096u)
+    if (!r->usePloc || r->env.plocFixed || r->triCount < 4096u)
         return buildAccel(r, false, false);
     DevBuf<BvhNode> bestNodes;
     DevBuf<Tri> bestTris;
@@ -2960,6 +1297,11 @@ int ptx_build_accel(PtxRenderer *r)
     uint64_t bestNodeCount = 0;
     double totalMs = 0.0;
     uint32_t best = 0;
+    // While candidates are built the renderer's buffers hold whichever tree was built last and the best one sits in the locals
+    // above: nothing may render (or borrow the scene) until the final swap.  A candidate that fails (out of memory, a device
+    // error) does not take the scene down with it when an earlier one succeeded: that tree, its parameters and its node count
+    // are put back and the build succeeds with it.
+    r->accelReady = false;
     for (uint32_t k = 0; k < kCandidates; k++)
     {
         r->plocRadius = kTreeCandidates[k].radius;
@@ -2968,7 +1310,14 @@ int ptx_build_accel(PtxRenderer *r)
         int rc = buildAccel(r, false, false);
         totalMs += r->stats.lastBuildMs;
         if (rc != PTX_OK || (rc = sampleTreeCost(r, &cost[k])) != PTX_OK)
-            return rc;
+        {
+            r->accelReady = false;
+            if (k == 0)
+                return rc; // no tree at all: the error stands (ptx_last_error has the text)
+            if (r->env.verbose)
+                std::fprintf(stderr, "[ptx] tree candidate %u failed (%s): keeping candidate %u\n", k, r->error.c_str(), best);
+            break;
+        }
         if (k == 0 || cost[k] < cost[best])
         {
             best = k;
@@ -2982,7 +1331,8 @@ int ptx_build_accel(PtxRenderer *r)
     r->plocShape = kTreeCandidates[best].shape;
     r->mortonCubic = kTreeCandidates[best].cubic;
     r->stats.lastBuildMs = totalMs;
-    if (getenv("PTX_VERBOSE"))
+    r->accelReady = true;
+    if (r->env.verbose)
     {
         std::fprintf(stderr, "[ptx] tree cost on sampled rays:");
         for (uint32_t k = 0; k < kCandidates; k++)
@@ -2994,8 +1344,7 @@ int ptx_build_accel(PtxRenderer *r)
 }
 
 // Renderer.cpp:1750-1754 (+ RecordSkinningCommands :854-890, AccelerationStructure::Update :48-57)
-int ptx_update_animation(PtxRenderer *r, const PtxTransform *instanceTransforms, uint32_t instanceCount, const PtxTransform *boneTransforms,
-                         uint32_t boneCount, uint32_t accelUpdate)
+static int updateAnimation(PtxRenderer *r, const PtxTransform *instanceTransforms, uint32_t instanceCount, const PtxTransform *boneTransforms, uint32_t boneCount, uint32_t accelUpdate)
 {
     if (!r || accelUpdate > PTX_ACCEL_REBUILD)
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_update_animation: bad argument");
@@ -3034,36 +1383,6 @@ int ptx_update_animation(PtxRenderer *r, const PtxTransform *instanceTransforms,
     return buildAccel(r, refit, true);
 }
 
-int ptx_resize(PtxRenderer *r, uint32_t width, uint32_t height)
-{
-    if (!r || !width || !height || (uint64_t)width * height > 0x7fffffffull)
-        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_resize: bad extent %ux%u", width, height);
-    HIP_TRY(r, hipSetDevice(r->device));
-    r->width = width;
-    r->height = height;
-    r->outputReady = false;
-    r->boundImage = nullptr;
-    HIP_TRY(r, r->image.alloc((size_t)width * height));
-    return ptx_reset_accumulation(r);
-}
-
-int ptx_set_tile_shard(PtxRenderer *r, const PtxTileShard *s)
-{
-    if (!r || !s || !s->worldSize || s->rank >= s->worldSize || !s->tileSize || (s->tileSize % 8) != 0 || s->tileSize > 1024)
-        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_set_tile_shard: need rank < worldSize and tileSize a multiple of 8");
-    r->shard = *s;
-    return PTX_OK;
-}
-
-int ptx_reset_accumulation(PtxRenderer *r)
-{
-    if (!r || !imagePtr(r))
-        return fail(r, PTX_ERROR_NOT_READY, "ptx_reset_accumulation: no accumulation image (call ptx_resize)");
-    HIP_TRY(r, hipMemsetAsync(imagePtr(r), 0, (size_t)r->width * r->height * sizeof(float4), r->stream));
-    return PTX_OK;
-}
-
-} // extern "C"
 
 // Kernel variant of the uploaded scene: 0 = opaque geometry with the fixed 1x1 textures only, 1 = ray
 // differentials + software sampler, 2 = 1 + the any-hit stages (alpha test, decals).
@@ -3469,14 +1788,14 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
             return rcr;
     }
     pl.sortShade = (sceneOf(r)->mixedMaterialTypes || sceneOf(r)->mixedTextured) ? 1u : 0u;
-    if (const char *e = getenv("PTX_SHADE_SORT"))
-        pl.sortShade = atoi(e) ? 1u : 0u;
+    if (r->env.shadeSort >= 0)
+        pl.sortShade = (uint32_t)r->env.shadeSort;
     // measured with 16 hardware queues (chess_like, ms per step at 25 / 50 / 75 / 100 / 200 / 400 K live paths): whole frame 8.04 / 7.82 /
     // 7.85 / 7.80 / 8.14 / 8.13, a rank's tile shard of 8: 1.44 / 1.44 / 1.39 / 1.39 / 1.54 / 1.55, of 4: 2.29 / 2.24 / 2.24 / 2.33 / 2.34 /
     // 2.77, of 2: 3.93 / 3.89 / 3.91 / 3.98 / 4.06 / 4.41; the other scenes are flat from 50 K to 200 K
     pl.tailBelow = 75000;
-    if (const char *e = getenv("PTX_TAIL_THRESHOLD"))
-        pl.tailBelow = (uint32_t)strtoul(e, nullptr, 10);
+    if (r->env.tailThreshold >= 0)
+        pl.tailBelow = (uint32_t)r->env.tailThreshold;
     Wavefront &wf = pl.wf;
     wf.rayO = r->rayO.p; wf.rayD = r->rayD.p; wf.thr = r->thr.p; wf.rad = r->rad.p;
     wf.meta = r->meta.p; wf.hit = r->hit.p; wf.hitPair = r->hitPair.p;
@@ -3548,48 +1867,14 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
     r->pendingSlots = canonical ? p.numSlots : 0u;
     r->pendingEpoch = sceneOf(r)->sceneEpoch;
     r->pendingDeadSlots = p.numSlots - p.ownedPixels * frames;
-    r->pendingVerbose = getenv("PTX_VERBOSE") != nullptr;
+    r->pendingVerbose = r->env.verbose;
     return PTX_OK;
-}
-
-extern "C" {
-
-int ptx_render(PtxRenderer *r, const PtxRaygenUniformData *uniform, const PtxLightsUbo *lights)
-{
-    return renderImpl(r, uniform, lights, uniform ? uniform->TotalSamples : 0, 1);
-}
-
-int ptx_render_frames(PtxRenderer *r, const PtxRaygenUniformData *uniform, const PtxLightsUbo *lights, uint32_t firstFrame, uint32_t frames)
-{
-    if (!uniform)
-        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_render_frames: null uniform");
-    PtxRaygenUniformData u = *uniform;
-    u.SampleCount = 1; // canonical schedule: one sample per launch, RNG frame = launch index
-    u.TotalSamples = firstFrame;
-    return renderImpl(r, &u, lights, firstFrame, frames);
-}
-
-int ptx_synchronize(PtxRenderer *r)
-{
-    if (!r)
-        return PTX_ERROR_INVALID_ARGUMENT;
-    HIP_TRY(r, hipStreamSynchronize(r->stream));
-    return collectRender(r); // errors of an asynchronous launch surface here
-}
-
-int ptx_readback(PtxRenderer *r, float *rgba, size_t bytes)
-{
-    if (!r || !rgba || !imagePtr(r) || bytes != (size_t)r->width * r->height * sizeof(float4))
-        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_readback: buffer must be width*height*16 bytes");
-    HIP_TRY(r, hipMemcpyAsync(rgba, imagePtr(r), bytes, hipMemcpyDeviceToHost, r->stream));
-    HIP_TRY(r, hipStreamSynchronize(r->stream));
-    return collectRender(r); // an error of the launch that produced the image surfaces with it
 }
 
 // Read-back that overlaps the next launches: a device-to-device snapshot of the image on the render stream (33 MB at
 // 1080p: ~20 us), then the PCIe copy on a second stream while the render stream goes on.  The reference reads its
 // output back the same way, a frame late (OutputSaver.cpp:120-199).
-int ptx_readback_begin(PtxRenderer *r, float *pinnedHost, size_t bytes)
+static int readbackBegin(PtxRenderer *r, float *pinnedHost, size_t bytes)
 {
     if (!r || !pinnedHost || !imagePtr(r) || bytes != (size_t)r->width * r->height * sizeof(float4))
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_readback_begin: buffer must be width*height*16 bytes");
@@ -3629,53 +1914,7 @@ int ptx_readback_begin(PtxRenderer *r, float *pinnedHost, size_t bytes)
     return PTX_OK;
 }
 
-int ptx_readback_end(PtxRenderer *r)
-{
-    if (!r)
-        return PTX_ERROR_INVALID_ARGUMENT;
-    if (r->copyInFlight)
-    {
-        HIP_TRY(r, hipEventSynchronize(r->evCopied));
-        r->copyInFlight = false;
-    }
-    return PTX_OK;
-}
-
-void *ptx_device_accum_ptr(PtxRenderer *r)
-{
-    return r ? imagePtr(r) : nullptr;
-}
-
-size_t ptx_accum_bytes(const PtxRenderer *r)
-{
-    return r ? (size_t)r->width * r->height * sizeof(float4) : 0;
-}
-
-size_t ptx_shard_bytes(const PtxRenderer *r, uint32_t rank)
-{
-    if (!r || !r->width || rank >= r->shard.worldSize)
-        return 0;
-    PtxRenderer tmp;
-    tmp.width = r->width;
-    tmp.height = r->height;
-    tmp.shard = r->shard;
-    tmp.shard.rank = rank;
-    const LaunchParams p = makeParams(&tmp, nullptr, 0, 1);
-    return (size_t)p.slotsPerFrame * sizeof(float4);
-}
-
-int ptx_pack_shard(PtxRenderer *r, void *devDst)
-{
-    if (!r || !devDst || !imagePtr(r))
-        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_pack_shard: null argument");
-    const LaunchParams p = makeParams(r, nullptr, 0, 1);
-    if (p.slotsPerFrame)
-        k_pack_shard<<<gridFor(p.slotsPerFrame), kBlock, 0, r->stream>>>(p, imagePtr(r), static_cast<float4 *>(devDst));
-    HIP_TRY(r, hipGetLastError());
-    return PTX_OK;
-}
-
-int ptx_unpack_shard(PtxRenderer *r, uint32_t rank, const void *devSrc)
+static int unpackShard(PtxRenderer *r, uint32_t rank, const void *devSrc)
 {
     if (!r || !devSrc || !imagePtr(r) || rank >= r->shard.worldSize)
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_unpack_shard: bad argument");
@@ -3692,7 +1931,7 @@ int ptx_unpack_shard(PtxRenderer *r, uint32_t rank, const void *devSrc)
 }
 
 // Renderer::RecordPostProcessCommands + RecordSaveOutputCommands (Renderer.cpp:928-1085, :1204-1246)
-int ptx_postprocess(PtxRenderer *r, const PtxPostProcessingUniformData *uniform, uint32_t toneMappingMode)
+static int postprocess(PtxRenderer *r, const PtxPostProcessingUniformData *uniform, uint32_t toneMappingMode)
 {
     if (!r || !uniform || toneMappingMode > PTX_TONE_MAPPING_HDR)
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_postprocess: bad argument");
@@ -3734,7 +1973,7 @@ int ptx_postprocess(PtxRenderer *r, const PtxPostProcessingUniformData *uniform,
 }
 
 // OutputSaver: blit of the tone-mapped image into its output image + readback (OutputSaver.cpp:64-86, :120-199)
-int ptx_read_output(PtxRenderer *r, uint32_t outputFormat, void *host, size_t bytes)
+static int readOutput(PtxRenderer *r, uint32_t outputFormat, void *host, size_t bytes)
 {
     if (!r || !host || outputFormat > PTX_OUTPUT_RGBA32F)
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_read_output: bad argument");
@@ -3758,16 +1997,7 @@ int ptx_read_output(PtxRenderer *r, uint32_t outputFormat, void *host, size_t by
     return PTX_OK;
 }
 
-int ptx_write_accumulation(PtxRenderer *r, const float *rgba, size_t bytes)
-{
-    if (!r || !rgba || !imagePtr(r) || bytes != (size_t)r->width * r->height * sizeof(float4))
-        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_write_accumulation: buffer must be width*height*16 bytes");
-    HIP_TRY(r, hipMemcpyAsync(imagePtr(r), rgba, bytes, hipMemcpyHostToDevice, r->stream));
-    HIP_TRY(r, hipStreamSynchronize(r->stream));
-    return PTX_OK;
-}
-
-int ptx_get_stats(PtxRenderer *r, PtxStats *stats)
+static int getStats(PtxRenderer *r, PtxStats *stats)
 {
     if (!r || !stats)
         return PTX_ERROR_INVALID_ARGUMENT;
@@ -3784,17 +2014,7 @@ int ptx_get_stats(PtxRenderer *r, PtxStats *stats)
     return PTX_OK;
 }
 
-int ptx_test_input_stride(uint32_t fn)
-{
-    return fn < PTX_FN_COUNT ? h_inStride[fn] : -1;
-}
-
-int ptx_test_output_stride(uint32_t fn)
-{
-    return fn < PTX_FN_COUNT ? h_outStride[fn] : -1;
-}
-
-int ptx_test_eval(PtxRenderer *r, uint32_t fn, const float *in, float *out, uint32_t n)
+static int testEval(PtxRenderer *r, uint32_t fn, const float *in, float *out, uint32_t n)
 {
     if (!r || fn >= PTX_FN_COUNT || !in || !out)
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_test_eval: bad argument");
@@ -3815,7 +2035,7 @@ int ptx_test_eval(PtxRenderer *r, uint32_t fn, const float *in, float *out, uint
     return PTX_OK;
 }
 
-int ptx_test_texture(PtxRenderer *r, const float *in, float *out, uint32_t n, int implicitLod)
+static int testTexture(PtxRenderer *r, const float *in, float *out, uint32_t n, int implicitLod)
 {
     if (!r || !in || !out)
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_test_texture: null argument");
@@ -3837,7 +2057,7 @@ int ptx_test_texture(PtxRenderer *r, const float *in, float *out, uint32_t n, in
     return PTX_OK;
 }
 
-int ptx_trace_rays(PtxRenderer *r, const float *rays, uint32_t n, int anyHit, float *hits, uint32_t *ids)
+static int traceRays(PtxRenderer *r, const float *rays, uint32_t n, int anyHit, float *hits, uint32_t *ids)
 {
     if (!r || !rays || !hits || !ids)
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_trace_rays: null argument");
@@ -3879,16 +2099,3 @@ int ptx_trace_rays(PtxRenderer *r, const float *rays, uint32_t n, int anyHit, fl
         return fail(r, PTX_ERROR_DEVICE, "ptx_trace_rays: %s", hipGetErrorString(e));
     return PTX_OK;
 }
-
-int ptx_bind_accumulation(PtxRenderer *r, void *devPtr, size_t bytes)
-{
-    if (!r || !r->width)
-        return fail(r, PTX_ERROR_NOT_READY, "ptx_bind_accumulation: call ptx_resize first");
-    if (devPtr && bytes != (size_t)r->width * r->height * sizeof(float4))
-        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_bind_accumulation: buffer must be width*height*16 bytes");
-    r->boundImage = static_cast<float4 *>(devPtr);
-    return PTX_OK;
-}
-
-
-} // extern "C"

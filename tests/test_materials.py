@@ -133,6 +133,19 @@ def test_material_sorted_shade_queue_changes_nothing(pkg, orc, monkeypatch, sort
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tile", [8, 24])
+def test_material_sorted_shade_queue_on_ragged_tiles(pkg, orc, monkeypatch, tile):
+    """The sorted queue pads a block's share of the queue to kBlock x kShadeItems entries; padding and the dead slots of ragged
+    edge tiles sort under the same (last) key.  An image whose size is not a multiple of the tile and a first-bounce queue that
+    is not a multiple of 1024 entries: no slot may be shaded twice (padding used to read as slot 0), so image and counters
+    still equal the oracle's."""
+    monkeypatch.setenv("PTX_SHADE_SORT", "1")
+    monkeypatch.setenv("PTX_TAIL_THRESHOLD", "0")
+    img, ref = util.render_pair(pkg, orc, "materials_test", 0.4, 203, 117, frames=2, depth=6, tile=tile)
+    assert (img.view(np.uint32) == ref.view(np.uint32)).all()
+
+
+@pytest.mark.gpu
 def test_materials_scene_multi_sample_and_lens(pkg, orc):
     img, ref = util.render_pair(pkg, orc, "materials_test", 0.3, 96, 54, frames=2, depth=5, lens=0.04, sample_count=3)
     assert (img.view(np.uint32) == ref.view(np.uint32)).all()

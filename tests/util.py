@@ -88,7 +88,7 @@ def random_rays(rng, n, lo, hi, tmax=1e4):
     return rays
 
 
-def render_pair(pkg, orc, name, detail, W, H, frames, depth, backend=0, brute=False, lens=0.0, sample_count=1):
+def render_pair(pkg, orc, name, detail, W, H, frames, depth, backend=0, brute=False, lens=0.0, sample_count=1, tile=None):
     """Render `frames` launches with the HIP path and with the oracle; returns both accumulation images
     after checking that segment / shadow-ray / sample / retry counts agree launch by launch."""
     scene = pkg.Scene(name, detail)
@@ -96,6 +96,8 @@ def render_pair(pkg, orc, name, detail, W, H, frames, depth, backend=0, brute=Fa
     r = pkg.Renderer(backend=backend)
     r.upload(scene)
     r.resize(W, H)
+    if tile:
+        r.set_tile_shard(0, 1, tile)
     osc = orc.OracleScene(scene.desc, build_bvh=not brute)
     ref = np.zeros((H, W, 4), np.float32)
     seg = shadow = 0

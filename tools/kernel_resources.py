@@ -26,7 +26,7 @@ def main():
         args = args[:k] + args[k + 2:]
     flt = args[0] if args else ""
     pkg = graft.load_package()
-    src = os.path.join(pkg.PKG_DIR, "csrc", "pt_kernels.hip")
+    src = pkg.hip_sources()[0]
     cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + pkg.HIPCC_FLAGS + extra + ["-Rpass-analysis=kernel-resource-usage", "-o", out or pkg.HIP_LIB, src]
     p = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
     cur, rows = None, []

@@ -26,8 +26,8 @@ def source_digest():
     """Same digest as bench.py's: which kernels these counters were collected on."""
     csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "path-tracing_amd", "csrc")
     h = hashlib.sha256()
-    for f in ("pt_kernels.hip", "pt_bvh.hpp", "pt_device.hpp", "pt_post.hpp"):
-        h.update(open(os.path.join(csrc, f), "rb").read())
+    for f in [os.path.join(csrc, "ptx_capi.hip")] + sorted(glob.glob(os.path.join(csrc, "*.hpp"))):  # = path-tracing_amd.hip_sources()
+        h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -9,7 +9,8 @@ import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "tools", "scratch", "libptx_visits.so")
 PATCH = os.path.join(ROOT, "tools", "experiments", "visit_stats.patch")
-SRC = [os.path.join(ROOT, "path-tracing_amd", "csrc", f) for f in ("pt_kernels.hip", "pt_bvh.hpp", "pt_device.hpp", "pt_post.hpp")]
+import glob
+SRC = [os.path.join(ROOT, "path-tracing_amd", "csrc", "ptx_capi.hip")] + sorted(glob.glob(os.path.join(ROOT, "path-tracing_amd", "csrc", "*.hpp")))
 os.environ["PTX_HIP_LIB"] = LIB  # before the package is imported: it reads the variable once
 if not os.path.exists(LIB) or any(os.path.getmtime(f) > os.path.getmtime(LIB) for f in SRC + [PATCH]):
     # the instrumentation lives in a patch, not in the kernels: apply it to a scratch copy of the sources and build that
@@ -24,7 +25,7 @@ if not os.path.exists(LIB) or any(os.path.getmtime(f) > os.path.getmtime(LIB) fo
         subprocess.check_call(["patch", "-p1", "-s", "-i", PATCH], cwd=tmp)
         os.makedirs(os.path.dirname(LIB), exist_ok=True)
         subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + _pkg.HIPCC_FLAGS + ["-DPT_VISIT_STATS", "-o", LIB,
-                               os.path.join(tmp, "path-tracing_amd", "csrc", "pt_kernels.hip")])
+                               os.path.join(tmp, "path-tracing_amd", "csrc", "ptx_capi.hip")])
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch  # noqa: F401  (device runtime)
