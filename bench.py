@@ -437,6 +437,8 @@ def scene_line(args, pkg, torch, dist, orc, name, rank, world, local_rank, steps
             # latency of ONE frame batch (reset -> 8 spp -> done, nothing else on the machine); `value` is the pipelined rate
             line["one_in_flight_ms_per_step"] = stats_x["wall_s"] / stats_x["steps"] * 1e3
             line["one_in_flight_value"] = W * H * spp / (stats_x["wall_s"] / stats_x["steps"]) / 1e6
+            line["one_in_flight_kernel_ms_per_step"] = {"k_trace_closest": stats_x["trace_ms"] / stats_x["steps"], "k_shade": stats_x["shade_ms"] / stats_x["steps"],
+                                                        "k_trace_shadow": stats_x["shadow_ms"] / stats_x["steps"], "k_tail": stats_x["tail_ms"] / stats_x["steps"]}
         if with_cpu:
             line["cpu_baseline"] = cpu_baseline(orc, job.scene, W, H, args.depth, args.cpu_seconds)
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]

@@ -39,8 +39,8 @@ extern "C" {
 
 /* Bumped whenever a struct of this header changes size or layout or an entry point changes meaning; ptx_abi_version()
  * returns the value the loaded library was built with.  3: PtxSceneDesc.textureMemoryBudget (round 2),
- * PtxStats.hardwareQueues (round 3). */
-#define PTX_ABI_VERSION 3u
+ * PtxStats.hardwareQueues (round 3).  4: PtxStats.treeTriangles / treeReferences (round 4). */
+#define PTX_ABI_VERSION 4u
 
 /* ------------------------------------------------------------------------- */
 /* Data contract                                                             */
@@ -363,6 +363,11 @@ typedef struct PtxStats {
     uint64_t hardwareQueues; /* hardware queues the environment grants the process's HIP streams (GPU_MAX_HW_QUEUES when
                                 the handle was created, 4 = the runtime's default when unset): below two per handle the
                                 frames in flight run one after the other */
+    uint64_t treeTriangles;  /* triangles in the tree: `triangles` minus the zero-area ones, which no ray can hit (a full
+                                build leaves them out; bvhNodes is no measure of this -- the collapse into 4-wide nodes is
+                                driven by the boxes' areas, so fewer triangles can make more nodes) */
+    uint64_t treeReferences; /* leaves of the tree: treeTriangles plus the extra references of triangles that were split before
+                                the build (a large triangle may hang from several leaves, each with a tighter box) */
 } PtxStats;
 
 typedef struct PtxRenderer PtxRenderer;

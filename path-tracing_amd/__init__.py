@@ -127,7 +127,7 @@ class PostProcessingUniformData(C.Structure):
 TONE_MAPPING_SDR, TONE_MAPPING_HDR = 0, 1
 ACCEL_REFIT, ACCEL_REBUILD = 0, 1
 OUTPUT_RGBA8_SRGB, OUTPUT_RGBA32F = 0, 1
-ABI_VERSION = 3  # PTX_ABI_VERSION of include/ptx.h
+ABI_VERSION = 4  # PTX_ABI_VERSION of include/ptx.h
 
 
 class DeviceDesc(C.Structure):
@@ -143,7 +143,7 @@ class Stats(C.Structure):
         ("pathSamples", C.c_uint64), ("segments", C.c_uint64), ("shadowRays", C.c_uint64), ("retries", C.c_uint64),
         ("triangles", C.c_uint64), ("bvhNodes", C.c_uint64), ("lastRenderMs", C.c_double), ("lastTraceMs", C.c_double),
         ("lastBuildMs", C.c_double), ("traceLaunches", C.c_uint64), ("lastShadeMs", C.c_double), ("lastShadowMs", C.c_double), ("lastTailMs", C.c_double),
-        ("tracedRays", C.c_uint64), ("hardwareQueues", C.c_uint64),
+        ("tracedRays", C.c_uint64), ("hardwareQueues", C.c_uint64), ("treeTriangles", C.c_uint64), ("treeReferences", C.c_uint64),
     ]
 
 

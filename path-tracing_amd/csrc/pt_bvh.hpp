@@ -37,6 +37,8 @@ struct BvhNode
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode is 64 B");
 constexpr int kEmptyRef = 0x7ffffffe;
+constexpr int kRefDone = 0x7fffffff; // traversal: the ray is finished
+constexpr int kRefNone = 0x7ffffffd; // traversal: a node visit that hit no child (neither a node index nor a leaf nor kEmptyRef)
 
 struct Tri
 {
@@ -264,6 +266,15 @@ PT_DEV bool slab(float lx, float ly, float lz, float hx, float hy, float hz, f3 
 // box o + q * scale contains the child, leaf boxes are padded by 1e-5 relative, and the
 // interval test keeps the (1 + 2^-21) slack.  NaNs (0 * inf for axis-parallel rays) drop out
 // of fminf / fmaxf, which only makes the test more permissive.
+//
+// ORDERED = false (occlusion queries, raygen.rgen:31 gl_RayFlagsTerminateOnFirstHitEXT: any hit ends the ray, so the order in
+// which the hit children are entered decides nothing): no sorting network; r0..r3 are the four refs in slot order and the
+// return value is the MASK of the children hit (bit k = slot k); PT_ENTER_UNORDERED below walks them from the last slot down.
+// Measured (round 4, launch alone, sorted -> unordered): k_trace_shadow -5 % on chess_like, -7 % on street_like, -17 % on
+// atrium_like (whole frame +1 % / +1.5 % / +5.5 %).  Storing a node's children by surface area so that the largest (likeliest to
+// hold an occluder) is entered first was measured too: street_like +1.5 %, chess_like flat, atrium_like -5 % (back to the
+// sorted walk's time) -- not done.
+template <bool ORDERED>
 PT_DEV int visitNode(const BvhNode *__restrict__ np, f3 o, f3 id, float tmin, float lim, int &r0, int &r1, int &r2, int &r3)
 {
     const float4 na = np->a;
@@ -298,6 +309,11 @@ PT_DEV int visitNode(const BvhNode *__restrict__ np, f3 o, f3 id, float tmin, fl
     h1 = h1 && refs.y != kEmptyRef;
     h2 = h2 && refs.z != kEmptyRef;
     h3 = h3 && refs.w != kEmptyRef;
+    if (!ORDERED)
+    {
+        r0 = refs.x; r1 = refs.y; r2 = refs.z; r3 = refs.w;
+        return (h0 ? 1 : 0) | (h1 ? 2 : 0) | (h2 ? 4 : 0) | (h3 ? 8 : 0);
+    }
     const float inf = __uint_as_float(0x7f800000u);
     float k0 = h0 ? t0 : inf, k1 = h1 ? t1 : inf, k2 = h2 ? t2 : inf, k3 = h3 ? t3 : inf;
     r0 = refs.x; r1 = refs.y; r2 = refs.z; r3 = refs.w;
@@ -320,6 +336,18 @@ PT_DEV int visitNode(const BvhNode *__restrict__ np, f3 o, f3 id, float tmin, fl
 #undef PT_CSWAP
     return (int)h0 + (int)h1 + (int)h2 + (int)h3;
 }
+
+// The walk of an occlusion query from a node: enter the hit child in the highest slot, keep the others on the stack.
+#define PT_ENTER_UNORDERED(mask, r0, r1, r2, r3, st, ref, none)                                                            \
+    {                                                                                                                      \
+        int next_ = (none);                                                                                                \
+        bool have_ = false;                                                                                                \
+        if ((mask) & 1) { next_ = r0; have_ = true; }                                                                      \
+        if ((mask) & 2) { if (have_) st.push((uint32_t)next_); next_ = r1; have_ = true; }                                 \
+        if ((mask) & 4) { if (have_) st.push((uint32_t)next_); next_ = r2; have_ = true; }                                 \
+        if ((mask) & 8) { if (have_) st.push((uint32_t)next_); next_ = r3; have_ = true; }                                 \
+        ref = next_;                                                                                                       \
+    }
 
 // Culling against the current best leaves room for the triangle test's own error in t (Moeller-Trumbore from a far
 // origin: ~1e-5 relative): two triangles in one plane can report the SAME t while the point o + t d lies a few 1e-5
@@ -369,13 +397,19 @@ PT_DEV bool traceRay(const TraceScene &sc, f3 o, f3 d, float tmin, float tmax, S
             if (STATS)
                 (*nodeVisits)++;
             int r0, r1, r2, r3;
-            const int h = visitNode(&sc.nodes[ref], o, id, tmin, ANY_HIT ? best.t : best.t * kCullSlack, r0, r1, r2, r3);
-            if (h > 3) st.push((uint32_t)r3);
-            if (h > 2) st.push((uint32_t)r2);
-            if (h > 1) st.push((uint32_t)r1);
-            if (h > 0)
-                ref = r0;
+            const int h = visitNode<!ANY_HIT>(&sc.nodes[ref], o, id, tmin, ANY_HIT ? best.t : best.t * kCullSlack, r0, r1, r2, r3);
+            if (ANY_HIT)
+            {
+                PT_ENTER_UNORDERED(h, r0, r1, r2, r3, st, ref, kRefNone)
+            }
             else
+            {
+                if (h > 3) st.push((uint32_t)r3);
+                if (h > 2) st.push((uint32_t)r2);
+                if (h > 1) st.push((uint32_t)r1);
+                ref = h > 0 ? r0 : kRefNone;
+            }
+            if (ref == kRefNone)
             {
                 if (st.sp == 0)
                     break;
@@ -440,7 +474,6 @@ PT_DEV bool traceRay(const TraceScene &sc, f3 o, f3 d, float tmin, float tmax, S
 // (its triangle), and void store(item, hit, hitAny, anyHitQuery) when the ray is done (hit.t and hit.pair; u, v, slot are the IO's).
 constexpr uint32_t kTraceChunk = 128;   // measured: 64 -> 1327, 128 -> 1347, 256 -> 1310 Msamples/s
 constexpr int kNodeStepsPerRound = 2;   // measured: 1 -> 1040, 2 -> 1064, 3 -> 1055, 4 -> 1034, 6 -> 975, 10 -> 872 Msamples/s
-constexpr int kRefDone = 0x7fffffff;
 
 
 // IO::kFixedTmin >= 0: every ray of the queue has this tmin (the wavefront queues: 1e-5) -> a literal, not a register
@@ -550,11 +583,20 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
             if (have && ref >= 0 && ref != kRefDone)
             {
                 int r0, r1, r2, r3;
-                const int h = visitNode(&sc.nodes[ref], o, id, PT_TMIN, ANY_HIT ? PT_TMAX : best.t * kCullSlack, r0, r1, r2, r3);
-                if (h > 3) st.push((uint32_t)r3);
-                if (h > 2) st.push((uint32_t)r2);
-                if (h > 1) st.push((uint32_t)r1);
-                ref = h > 0 ? r0 : (st.sp ? (int)st.pop() : kRefDone);
+                const int h = visitNode<!ANY_HIT>(&sc.nodes[ref], o, id, PT_TMIN, ANY_HIT ? PT_TMAX : best.t * kCullSlack, r0, r1, r2, r3);
+                if (ANY_HIT)
+                {
+                    PT_ENTER_UNORDERED(h, r0, r1, r2, r3, st, ref, kRefNone)
+                }
+                else
+                {
+                    if (h > 3) st.push((uint32_t)r3);
+                    if (h > 2) st.push((uint32_t)r2);
+                    if (h > 1) st.push((uint32_t)r1);
+                    ref = h > 0 ? r0 : kRefNone;
+                }
+                if (ref == kRefNone)
+                    ref = st.sp ? (int)st.pop() : kRefDone;
             }
         }
 

@@ -593,6 +593,70 @@ __global__ void k_refit(int n, const uint32_t *__restrict__ vals, const float4 *
     }
 }
 
+// ---- cost-driven collapse (round 4) -------------------------------------------------------------------------------
+// Which binary nodes become 4-wide nodes?  The greedy rule of round 1 -- start from a node's two children and, twice, replace
+// the internal child with the largest surface area by its two children -- looks one step ahead.  This pass finds, for the given
+// binary topology, the collapse that minimises the surface-area cost of the WIDE tree by dynamic programming over the binary
+// tree (Ylitie, Karras, Laine 2017, section 4.1, with single-triangle leaves): a ray pays one node visit -- one fetch of 64
+// bytes, four slab tests -- for every wide node whose box it enters, with probability proportional to that box's area, and the
+// triangle tests are the same whatever node a triangle hangs from, so the objective is the summed area of the wide nodes.
+//   T(x, j)   least cost of the subtree of binary node x when it may occupy at most j child slots of a wide node above it
+//   leaf      T = 0 for every j (its test is paid in every collapse alike)
+//   internal  T(x, 1) = area(x) + D(x, 4)                         x becomes a wide node: its children share four slots
+//             T(x, j) = min(T(x, 1), D(x, j))        j = 2, 3, 4   or x is dissolved into the slots it was given
+//             D(x, j) = min over k of T(left, k) + T(right, j - k)
+// One thread per leaf walks up; the second thread to arrive at a node owns it (as k_refit).  Per node: the four costs and one
+// byte of decisions -- keep_j (bit 2 + j: T(x, 1) <= D(x, j)), the best split of three slots (bit 0: left gets 2) and of four
+// (bits 1..2: slots of the left child minus one) -- which k_emit follows from every node downwards.
+struct CollapseCost
+{
+    float4 t; // T(x, 1..4)
+};
+
+PT_DEV float4 collapseCostOf(int ref, const float4 *cost) // a child's T(., 1..4)
+{
+    if (ref < 0)
+        return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    return loadUncached(&cost[ref]);
+}
+
+__global__ void k_collapse_cost(int n, const int2 *__restrict__ children, const int *__restrict__ parentOfNode, const int *__restrict__ parentOfLeaf,
+                                const float4 *__restrict__ nodeLo, const float4 *__restrict__ nodeHi, uint32_t *__restrict__ flags,
+                                float4 *__restrict__ cost, uint8_t *__restrict__ decide)
+{
+    const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (leaf >= n)
+        return;
+    int node = parentOfLeaf[leaf];
+    while (node >= 0)
+    {
+        __threadfence(); // release my child's costs / acquire the sibling's
+        if (atomicAdd(&flags[node], 1u) == 0u)
+            return;
+        __threadfence();
+        const int2 ch = children[node];
+        const float4 l = collapseCostOf(ch.x, cost), r = collapseCostOf(ch.y, cost);
+        const float4 lo = nodeLo[node], hi = nodeHi[node];
+        const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+        const float area = dx * dy + dy * dz + dz * dx;
+        const float d2 = l.x + r.x;
+        const float d3a = l.x + r.y, d3b = l.y + r.x; // left 1 + right 2, left 2 + right 1
+        const float d3 = fminf(d3a, d3b);
+        const float d4a = l.x + r.z, d4b = l.y + r.y, d4c = l.z + r.x; // left 1, 2, 3
+        const float d4 = fminf(d4a, fminf(d4b, d4c));
+        const float t1 = area + d4;
+        uint32_t bits = 0;
+        bits |= d3b < d3a ? 1u : 0u;
+        bits |= (d4b < d4a && d4b <= d4c) ? 2u : (d4c < d4a && d4c < d4b) ? 4u : 0u;
+        bits |= t1 <= d2 ? 8u : 0u;
+        bits |= t1 <= d3 ? 16u : 0u;
+        bits |= t1 <= d4 ? 32u : 0u;
+        decide[node] = (uint8_t)bits;
+        cost[node] = make_float4(t1, fminf(t1, d2), fminf(t1, d3), fminf(t1, d4));
+        node = parentOfNode[node];
+    }
+}
+
 // Final layout.  Every binary LBVH node i becomes one 4-wide node: start from its two
 // children and, twice, replace the internal child with the largest surface area by that
 // child's two children (greedy SAH-style collapse).  Nodes that end up inside another
@@ -665,7 +729,7 @@ __global__ void k_emit(int n, const uint32_t *__restrict__ vals, const float4 *_
                        const float4 *__restrict__ boxHi, const int2 *__restrict__ children, const float4 *__restrict__ nodeLo,
                        const float4 *__restrict__ nodeHi, const Tri *__restrict__ triTmp, BvhNode *__restrict__ nodes,
                        Tri *__restrict__ tris, const DevPair *__restrict__ pairs, const PtxVertex *__restrict__ vertices,
-                       const uint32_t *__restrict__ indices, ShadeTri *__restrict__ shadeTris)
+                       const uint32_t *__restrict__ indices, ShadeTri *__restrict__ shadeTris, const uint8_t *__restrict__ decide)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n)
@@ -678,12 +742,46 @@ __global__ void k_emit(int n, const uint32_t *__restrict__ vals, const float4 *_
         return;
     ChildBox c[kNodeWidth];
     int count = 2;
+    if (decide)
+    {
+        // the cost-driven collapse (k_collapse_cost): node i shares its four slots between its children as decided there; a child
+        // that was given j slots either stays one child (a leaf, j = 1, or keep_j) or hands its slots on to ITS children
+        int ref[kNodeWidth] = { 0, 0, 0, 0 }, slots[kNodeWidth] = { 0, 0, 0, 0 }, sp = 0, out[kNodeWidth] = { 0, 0, 0, 0 };
+        count = 0;
+        {
+            const int2 ch = children[i];
+            const int k = 1 + (int)((decide[i] >> 1) & 3u);
+            ref[0] = ch.y; slots[0] = 4 - k;
+            ref[1] = ch.x; slots[1] = k;
+            sp = 2;
+        }
+        while (sp > 0)
+        {
+            sp--;
+            const int x = ref[sp], j = slots[sp];
+            const uint32_t d = x >= 0 ? decide[x] : 0u;
+            if (x < 0 || j == 1 || ((d >> (1 + j)) & 1u))
+                out[count++] = x;
+            else
+            {
+                const int2 ch = children[x];
+                const int k = j == 2 ? 1 : j == 3 ? 1 + (int)(d & 1u) : 1 + (int)((d >> 1) & 3u);
+                ref[sp] = ch.y; slots[sp] = j - k;
+                ref[sp + 1] = ch.x; slots[sp + 1] = k;
+                sp += 2;
+            }
+        }
+        for (int k = 0; k < kNodeWidth; k++)
+            if (k < count)
+                fetchChild(out[k], vals, boxLo, boxHi, nodeLo, nodeHi, c[k]);
+    }
+    else
     {
         const int2 ch = children[i];
         fetchChild(ch.x, vals, boxLo, boxHi, nodeLo, nodeHi, c[0]);
         fetchChild(ch.y, vals, boxLo, boxHi, nodeLo, nodeHi, c[1]);
     }
-    for (int round = 0; round < kNodeWidth - 2; round++)
+    for (int round = 0; round < kNodeWidth - 2 && !decide; round++)
     {
         int pick = -1;
         float best = -1.0f;

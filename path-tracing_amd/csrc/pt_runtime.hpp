@@ -4,6 +4,7 @@
 // No CPU fallback exists: without a HIP device createRenderer fails.
 #pragma once
 
+#include <algorithm>
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
@@ -56,6 +57,16 @@ template <typename T> struct DevBuf
     }
 };
 
+// How ptx_build_accel builds the tree (the software stand-in for VkBuildAccelerationStructureFlags: the reference asks its driver
+// for ePreferFastTrace, AccelerationStructure.cpp:319-324).  buildBestTree tries a few settings and keeps the cheapest tree.
+struct TreeParams
+{
+    uint32_t plocRadius = kPlocRadius; // PLOC: clusters look for their merge partner this many positions to either side
+    float plocShape = kPlocShape;      // PLOC: weight of the compactness term in the merge metric
+    bool mortonCubic = false;          // Morton curve with cubic cells (one scale for the three axes)
+    uint32_t collapse = 1;             // 4-wide collapse: 0 greedy by surface area (round 1), 1 cost-driven (k_collapse_cost)
+};
+
 // The environment switches of the library (INTEGRATION.md lists them): experiment and test knobs, read ONCE per handle when it
 // is created -- no entry point calls getenv afterwards, and a handle keeps the values it was created with.
 struct EnvSwitches
@@ -65,6 +76,7 @@ struct EnvSwitches
     bool plocFixed = false;      // PTX_PLOC_RADIUS / PTX_PLOC_SHAPE given: ONE tree with these parameters, no candidates
     uint32_t plocRadius = 0;     // PTX_PLOC_RADIUS
     float plocShape = 0.0f;      // PTX_PLOC_SHAPE
+    int collapse = -1;           // PTX_COLLAPSE=0 / 1: greedy / cost-driven 4-wide collapse (-1: not given; does not fix the other parameters)
     int shadeSort = -1;          // PTX_SHADE_SORT=0 / 1 overrides the scene's choice (-1: not given)
     long tailThreshold = -1;     // PTX_TAIL_THRESHOLD: live paths at or below which k_tail takes over (-1: the default)
     uint32_t framesPerWave = 8;  // PTX_FRAMES_PER_WAVE: samples of one pixel in neighbouring lanes, at most this many
@@ -86,6 +98,8 @@ struct EnvSwitches
             e.plocFixed = true;
             e.plocRadius = std::max(1u, (uint32_t)strtoul(v, nullptr, 10));
         }
+        if (const char *v = getenv("PTX_COLLAPSE"))
+            e.collapse = atoi(v) ? 1 : 0;
         if (const char *v = getenv("PTX_SHADE_SORT"))
             e.shadeSort = atoi(v) ? 1 : 0;
         if (const char *v = getenv("PTX_TAIL_THRESHOLD"))
@@ -153,13 +167,15 @@ struct PtxRenderer
         DevBuf<int2> children;
         DevBuf<int> parentOfNode, parentOfLeaf;
         DevBuf<BvhNode> rawNodes; // k_emit's output, one slot per binary node; k_relayout_level compacts it into `nodes`
+        DevBuf<float4> collapseCost; // k_collapse_cost: T(x, 1..4) per binary node
+        DevBuf<uint8_t> collapseDecide;
         DevBuf<uint32_t> oldOf;   // [0] onwards: emitted index of every node of the compact array; the last entry is the level counter
         bool valid = false;
         void release()
         {
             triTmp.release(); boxLo.release(); boxHi.release(); nodeLo.release(); nodeHi.release(); sceneBounds.release();
             vals0.release(); vals1.release(); hist.release(); histSums.release(); flags.release(); inert.release(); keys0.release(); keys1.release();
-            children.release(); parentOfNode.release(); parentOfLeaf.release(); rawNodes.release(); oldOf.release();
+            children.release(); parentOfNode.release(); parentOfLeaf.release(); rawNodes.release(); oldOf.release(); collapseCost.release(); collapseDecide.release();
             valid = false;
         }
     } build;
@@ -167,9 +183,7 @@ struct PtxRenderer
     bool mixedMaterialTypes = false; // the instanced meshes use more than one material type (ShaderTypes.incl:143-145): k_shade sorts its queue
     bool mixedTextured = false;      // ... or materials with and without scene textures: the sampler runs for waves of textured hits only
     bool usePloc = true;        // PLOC topology instead of Karras (PTX_BUILDER=lbvh switches back)
-    uint32_t plocRadius = kPlocRadius;
-    float plocShape = kPlocShape;
-    bool mortonCubic = false; // k_morton: cubic cells
+    TreeParams tree;            // of the tree in use; the per-frame rebuilds of an animation build with them again
     uint32_t residentClosest[2] = { 0, 0 }, residentShadow[2] = { 0, 0 }; // blocks the chip holds at once, per [ALPHA] variant
     DevBuf<float4> decal;
     DevBuf<float> decalT;
@@ -439,11 +453,13 @@ static int createRenderer(const PtxDeviceDesc *desc, PtxRenderer **out)
     }
     r->env = EnvSwitches::read(); // the only place the library reads its switches
     r->usePloc = !r->env.karrasBuilder;
+    if (r->env.collapse >= 0)
+        r->tree.collapse = (uint32_t)r->env.collapse;
     if (r->env.plocFixed)
     {
-        r->plocShape = r->env.plocShape;
+        r->tree.plocShape = r->env.plocShape;
         if (r->env.plocRadius)
-            r->plocRadius = r->env.plocRadius;
+            r->tree.plocRadius = r->env.plocRadius;
     }
     if (r->env.raysPerThread)
         g_raysPerThread = r->env.raysPerThread;
@@ -614,6 +630,8 @@ static int shareScene(PtxRenderer *r, PtxRenderer *owner)
     r->hintSlots = 0u; // whatever this handle had learnt, it had learnt on another scene
     r->stats.triangles = owner->stats.triangles;
     r->stats.bvhNodes = owner->stats.bvhNodes;
+    r->stats.treeTriangles = owner->stats.treeTriangles;
+    r->stats.treeReferences = owner->stats.treeReferences;
     return PTX_OK;
 }
 
@@ -1069,6 +1087,7 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
         r->accelReady = true;
         r->treeTris = 0;
         r->stats.bvhNodes = 0;
+        r->stats.treeTriangles = r->stats.treeReferences = 0;
         r->stats.lastBuildMs = 0.0;
         return PTX_OK;
     }
@@ -1094,7 +1113,7 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
         BUILD_TRY(B.hist.alloc(histCount)); BUILD_TRY(B.histSums.alloc(histBlocks)); BUILD_TRY(B.flags.alloc(n)); BUILD_TRY(B.inert.alloc(n));
         BUILD_TRY(B.keys0.alloc(n)); BUILD_TRY(B.keys1.alloc(n));
         BUILD_TRY(B.children.alloc(n)); BUILD_TRY(B.parentOfNode.alloc(n)); BUILD_TRY(B.parentOfLeaf.alloc(n));
-        BUILD_TRY(B.rawNodes.alloc(n)); BUILD_TRY(B.oldOf.alloc((size_t)n + 1));
+        BUILD_TRY(B.rawNodes.alloc(n)); BUILD_TRY(B.oldOf.alloc((size_t)n + 1)); BUILD_TRY(B.collapseCost.alloc(n)); BUILD_TRY(B.collapseDecide.alloc(n));
     }
 
     // PLOC temporaries: two cluster sequences, neighbour indices, scan flags (sized for all n; freed when this returns)
@@ -1124,7 +1143,7 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
     uint32_t nv = B.treeTris; // triangles in the tree: all but the zero-area ones, which sort to the end
     if (!refit)
     {
-        k_morton<<<blocks, 256, 0, r->stream>>>(n, B.boxLo.p, B.boxHi.p, B.sceneBounds.p, B.inert.p, B.keys0.p, B.vals0.p, r->mortonCubic ? 1 : 0);
+        k_morton<<<blocks, 256, 0, r->stream>>>(n, B.boxLo.p, B.boxHi.p, B.sceneBounds.p, B.inert.p, B.keys0.p, B.vals0.p, r->tree.mortonCubic ? 1 : 0);
         for (uint32_t shift = 0; shift < 64; shift += 8) // 63-bit keys + the all-ones sentinel of inert triangles: 8 passes
         {
             k_sort_hist<<<numTiles, 64, 0, r->stream>>>(n, kin, shift, numTiles, B.hist.p);
@@ -1147,6 +1166,7 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
     }
     r->treeTris = nv;
     r->stats.bvhNodes = nv > 1 ? nv - 1 : (nv ? 1 : 0);
+    r->stats.treeTriangles = r->stats.treeReferences = nv;
     const uint32_t vblocks = (nv + 255) / 256;
     if (nv == 1)
         k_single_leaf_root<<<1, 1, 0, r->stream>>>(vin, B.boxLo.p, B.boxHi.p, B.triTmp.p, r->nodes.p, r->tris.p, r->pairs.p, r->vertices.p,
@@ -1166,7 +1186,7 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
             while (count > 1)
             {
                 const uint32_t cb = (count + 255) / 256, sb = (count + kScanBlock - 1) / kScanBlock;
-                k_ploc_nearest<<<cb, 256, 0, r->stream>>>(count, r->plocRadius, r->plocShape, lIn, hIn, nn.p);
+                k_ploc_nearest<<<cb, 256, 0, r->stream>>>(count, r->tree.plocRadius, r->tree.plocShape, lIn, hIn, nn.p);
                 k_ploc_flags<<<cb, 256, 0, r->stream>>>(count, nn.p, flags.p);
                 k_scan64_sums<<<sb, 256, 0, r->stream>>>(count, flags.p, sums.p);
                 k_scan64_top<<<1, 1024, 0, r->stream>>>(sb, sums.p, total.p);
@@ -1198,8 +1218,15 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
         if (!boxesDone)
             k_refit<<<vblocks, 256, 0, r->stream>>>((int)nv, vin, B.boxLo.p, B.boxHi.p, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p,
                                                B.nodeLo.p, B.nodeHi.p, B.flags.p);
+        if (r->tree.collapse)
+        {
+            BUILD_TRY(hipMemsetAsync(B.flags.p, 0, (size_t)nv * 4, r->stream)); // (the arrival flags of k_refit: done with)
+            k_collapse_cost<<<vblocks, 256, 0, r->stream>>>((int)nv, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p, B.nodeLo.p, B.nodeHi.p, B.flags.p,
+                                                       B.collapseCost.p, B.collapseDecide.p);
+        }
         k_emit<<<vblocks, 256, 0, r->stream>>>((int)nv, vin, B.boxLo.p, B.boxHi.p, B.children.p, B.nodeLo.p, B.nodeHi.p, B.triTmp.p,
-                                              B.rawNodes.p, r->tris.p, r->pairs.p, r->vertices.p, r->indices.p, r->shadeTris.p);
+                                              B.rawNodes.p, r->tris.p, r->pairs.p, r->vertices.p, r->indices.p, r->shadeTris.p,
+                                              r->tree.collapse ? B.collapseDecide.p : nullptr);
         // breadth-first relayout into the compact array (k_relayout_level): the host reads the level's end after each launch
         uint32_t *nextFree = B.oldOf.p + n;
         const uint32_t first[1] = { 0u }, one = 1u;
@@ -1252,23 +1279,43 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
 
 static TraceScene makeTraceScene(const PtxRenderer *r);
 
-// node visits + triangle tests of 65,536 sampled rays through the tree just built (k_sample_tree_cost)
-static int sampleTreeCost(PtxRenderer *r, unsigned long long *cost)
+// The price of the tree just built on the sampled segments (k_sample_tree_cost): mean visits + tests per ray, the tail, and
+// the figure the candidates are compared by.  The tail term: a persistent traversal launch ends with its longest ray, and in the
+// thin launches of late bounces and of small tile shards that ray IS the launch -- a tree that saves 1 % on the mean and grows
+// its longest walks by a third is not cheaper.
+struct TreeCost
 {
-    constexpr uint32_t kRays = 65536; // a few million visits and tests in all: 32 bits
+    double mean = 0.0;   // visits + tests per ray
+    uint32_t p999 = 0;   // 99.9th percentile
+    uint32_t worst = 0;
+    double figure() const { return mean + kTreeTailWeight * (double)p999; }
+    static constexpr double kTreeTailWeight = 0.02; // a p99.9 five times the mean adds 10 % to the figure
+};
+constexpr uint32_t kTreeSampleRays = 65536;
+
+static int sampleTreeCost(PtxRenderer *r, DevBuf<float4> &segments, bool drawSegments, TreeCost *cost)
+{
     DevBuf<uint32_t> d;
-    HIP_TRY(r, d.alloc(1));
-    HIP_TRY(r, hipMemsetAsync(d.p, 0, sizeof(uint32_t), r->stream));
+    HIP_TRY(r, d.alloc(kTreeSampleRays));
+    HIP_TRY(r, segments.alloc(2 * (size_t)kTreeSampleRays));
     const TraceScene sc = makeTraceScene(r);
+    if (drawSegments)
+        k_sample_segments<<<kTreeSampleRays / kBlock, kBlock, 0, r->stream>>>(sc, kTreeSampleRays, segments.p);
     if (r->anyNonOpaque)
-        k_sample_tree_cost<true><<<kRays / kBlock, kBlock, 0, r->stream>>>(sc, kRays, r->spill.p, d.p);
+        k_sample_tree_cost<true><<<kTreeSampleRays / kBlock, kBlock, 0, r->stream>>>(sc, segments.p, kTreeSampleRays, r->spill.p, d.p);
     else
-        k_sample_tree_cost<false><<<kRays / kBlock, kBlock, 0, r->stream>>>(sc, kRays, r->spill.p, d.p);
-    uint32_t total = 0;
-    HIP_TRY(r, hipMemcpyAsync(&total, d.p, sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
+        k_sample_tree_cost<false><<<kTreeSampleRays / kBlock, kBlock, 0, r->stream>>>(sc, segments.p, kTreeSampleRays, r->spill.p, d.p);
+    std::vector<uint32_t> h(kTreeSampleRays);
+    HIP_TRY(r, hipMemcpyAsync(h.data(), d.p, kTreeSampleRays * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(r, hipStreamSynchronize(r->stream));
     HIP_TRY(r, hipGetLastError());
-    *cost = total;
+    unsigned long long sum = 0;
+    for (uint32_t v : h)
+        sum += v;
+    std::sort(h.begin(), h.end());
+    cost->mean = (double)sum / kTreeSampleRays;
+    cost->p999 = h[kTreeSampleRays - 1 - kTreeSampleRays / 1000];
+    cost->worst = h.back();
     return PTX_OK;
 }
 
@@ -1280,9 +1327,10 @@ static int buildBestTree(PtxRenderer *r)
         return fail(r, PTX_ERROR_NOT_READY, "ptx_build_accel: no scene uploaded");
     quiesceSharers(r);
     r->sceneEpoch++; // schedules learnt on the old tree's scene are not this one's (ptx_scene_upload without a build in between cannot render)
-    // Which tree?  Build a few candidates, price each on sampled surface-to-surface rays, keep the cheapest (its buffers are swapped
-    // aside while the others are built; lastBuildMs is the time of everything).  Parameters given in the environment, the Karras
-    // builder and small scenes skip the comparison; the per-frame rebuilds of an animation use the parameters chosen here.
+    // Which tree?  Build a few candidates, price each on the same sampled surface-to-surface segments, keep the cheapest (its
+    // buffers are swapped aside while the others are built; lastBuildMs is the time of everything).  Parameters given in the
+    // environment, the Karras builder and small scenes skip the comparison; the per-frame rebuilds of an animation use the
+    // parameters chosen here.
     struct Candidate { uint32_t radius; float shape; bool cubic; };
     static const Candidate kTreeCandidates[] = { { 8u, 0.0f, false }, { 16u, 0.0f, false }, { 16u, 0.25f, false }, { 32u, 1.0f, false }, { 8u, 1.0f, true } };
     constexpr uint32_t kCandidates = sizeof(kTreeCandidates) / sizeof(kTreeCandidates[0]);
@@ -1292,11 +1340,13 @@ static int buildBestTree(PtxRenderer *r)
     DevBuf<Tri> bestTris;
     DevBuf<ShadeTri> bestShadeTris;
     DevBuf<AlphaTri> bestAlphaTris;
+    DevBuf<float4> segments;
     auto swapTree = [&]() { r->nodes.swap(bestNodes); r->tris.swap(bestTris); r->shadeTris.swap(bestShadeTris); r->alphaTris.swap(bestAlphaTris); };
-    unsigned long long cost[kCandidates] = {};
+    TreeCost cost[kCandidates];
     uint64_t bestNodeCount = 0;
     double totalMs = 0.0;
-    uint32_t best = 0;
+    uint32_t best = 0, built = 0;
+    const TreeParams given = r->tree; // what the candidates do not vary (the collapse)
     // While candidates are built the renderer's buffers hold whichever tree was built last and the best one sits in the locals
     // above: nothing may render (or borrow the scene) until the final swap.  A candidate that fails (out of memory, a device
     // error) does not take the scene down with it when an earlier one succeeded: that tree, its parameters and its node count
@@ -1304,12 +1354,13 @@ static int buildBestTree(PtxRenderer *r)
     r->accelReady = false;
     for (uint32_t k = 0; k < kCandidates; k++)
     {
-        r->plocRadius = kTreeCandidates[k].radius;
-        r->plocShape = kTreeCandidates[k].shape;
-        r->mortonCubic = kTreeCandidates[k].cubic;
+        r->tree = given;
+        r->tree.plocRadius = kTreeCandidates[k].radius;
+        r->tree.plocShape = kTreeCandidates[k].shape;
+        r->tree.mortonCubic = kTreeCandidates[k].cubic;
         int rc = buildAccel(r, false, false);
         totalMs += r->stats.lastBuildMs;
-        if (rc != PTX_OK || (rc = sampleTreeCost(r, &cost[k])) != PTX_OK)
+        if (rc != PTX_OK || (rc = sampleTreeCost(r, segments, k == 0, &cost[k])) != PTX_OK)
         {
             r->accelReady = false;
             if (k == 0)
@@ -1318,7 +1369,8 @@ static int buildBestTree(PtxRenderer *r)
                 std::fprintf(stderr, "[ptx] tree candidate %u failed (%s): keeping candidate %u\n", k, r->error.c_str(), best);
             break;
         }
-        if (k == 0 || cost[k] < cost[best])
+        built = k + 1;
+        if (k == 0 || cost[k].figure() < cost[best].figure())
         {
             best = k;
             bestNodeCount = r->stats.bvhNodes;
@@ -1327,18 +1379,19 @@ static int buildBestTree(PtxRenderer *r)
     }
     swapTree();
     r->stats.bvhNodes = bestNodeCount;
-    r->plocRadius = kTreeCandidates[best].radius;
-    r->plocShape = kTreeCandidates[best].shape;
-    r->mortonCubic = kTreeCandidates[best].cubic;
+    r->tree = given;
+    r->tree.plocRadius = kTreeCandidates[best].radius;
+    r->tree.plocShape = kTreeCandidates[best].shape;
+    r->tree.mortonCubic = kTreeCandidates[best].cubic;
     r->stats.lastBuildMs = totalMs;
     r->accelReady = true;
     if (r->env.verbose)
     {
-        std::fprintf(stderr, "[ptx] tree cost on sampled rays:");
-        for (uint32_t k = 0; k < kCandidates; k++)
-            std::fprintf(stderr, " (radius %u, shape %.2f%s) %llu%s", kTreeCandidates[k].radius, kTreeCandidates[k].shape, kTreeCandidates[k].cubic ? ", cubic cells" : "",
-                         cost[k], k == best ? " <- kept" : "");
-        std::fprintf(stderr, "; %.1f ms\n", totalMs);
+        std::fprintf(stderr, "[ptx] tree cost on %u sampled segments, mean / p99.9 / max visits + tests per ray:", kTreeSampleRays);
+        for (uint32_t k = 0; k < built; k++)
+            std::fprintf(stderr, " (radius %u, shape %.2f%s) %.2f / %u / %u%s", kTreeCandidates[k].radius, kTreeCandidates[k].shape,
+                         kTreeCandidates[k].cubic ? ", cubic cells" : "", cost[k].mean, cost[k].p999, cost[k].worst, k == best ? " <- kept" : "");
+        std::fprintf(stderr, "; collapse %s; %.1f ms\n", given.collapse ? "cost-driven" : "greedy", totalMs);
     }
     return PTX_OK;
 }

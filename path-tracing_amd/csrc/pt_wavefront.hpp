@@ -1321,33 +1321,56 @@ __global__ void k_unpack_shard(LaunchParams p, const float4 *__restrict__ src, f
     }
 }
 
-// What a tree costs the rays of a path tracer: node visits + triangle tests of `n` closest-hit queries between the centroids
-// of pseudo-random pairs of triangles -- segments from surface to surface, like the segments of a path.  ptx_build_accel
-// builds the tree with more than one search radius and keeps the cheaper one: "lower surface-area cost" does not always mean
-// "fewer visits" (street_like: a wider PLOC search gives 13 % MORE visits per ray), and results never depend on the tree.
-template <bool ALPHA>
-__global__ void __launch_bounds__(kBlock) k_sample_tree_cost(TraceScene sc, uint32_t n, uint32_t *spill, uint32_t *cost)
+// What a tree costs the rays of a path tracer: node visits + triangle tests of closest-hit queries along `n` segments between
+// the centroids of pseudo-random pairs of triangles -- from surface to surface, like the segments of a path.  ptx_build_accel
+// builds a few candidate trees and keeps the cheapest: "lower surface-area cost" does not always mean "fewer visits"
+// (street_like: a wider PLOC search gives 13 % MORE visits per ray), and results never depend on the tree.
+//   k_sample_segments   the segments, drawn ONCE per build from the first candidate's triangle array and kept: every candidate
+//                       is priced on the same rays (leaf order differs from tree to tree, so indices into it would name other
+//                       triangles -- sampling noise that could decide between candidates a per cent apart)
+//   k_sample_tree_cost  per segment visits + tests, one number per ray: the host adds them up and takes the tail (p99.9)
+__global__ void k_sample_segments(TraceScene sc, uint32_t n, float4 *__restrict__ rays)
 {
-    PT_DECLARE_STACK(st, kLdsStack, spill)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t visits = 0, tests = 0;
-    if (i < n && sc.triCount > 1u)
+    if (i >= n)
+        return;
+    float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d = o; // d.w = 0: no segment
+    if (sc.triCount > 1u)
     {
         const uint32_t a = jenkinsHash(2u * i + 1u) % sc.triCount, b = jenkinsHash(jenkinsHash(2u * i + 2u)) % sc.triCount;
         const Tri ta = sc.tris[a], tb = sc.tris[b];
         const float third = 1.0f / 3.0f;
         const f3 ca = F3(ta.a.x + (ta.a.w + ta.b.z) * third, ta.a.y + (ta.b.x + ta.b.w) * third, ta.a.z + (ta.b.y + ta.c.x) * third);
         const f3 cb = F3(tb.a.x + (tb.a.w + tb.b.z) * third, tb.a.y + (tb.b.x + tb.b.w) * third, tb.a.z + (tb.b.y + tb.c.x) * third);
-        const f3 d = cb - ca;
-        const float len = __builtin_sqrtf(dot(d, d));
+        const f3 dir = cb - ca;
+        const float len = __builtin_sqrtf(dot(dir, dir));
         if (len > 0.0f)
         {
-            Hit best;
             // the segment between the two surfaces, not the line through them: a path segment ends where it lands, and a line
             // that runs on inside a slab of alpha-tested cards costs a thousand visits that no path ray pays
-            traceRay<false, true, ALPHA>(sc, ca, d * (1.0f / len), 1e-4f * len, 1.001f * len, st, best, &visits, &tests);
+            o = make_float4(ca.x, ca.y, ca.z, 1e-4f * len);
+            d = make_float4(dir.x * (1.0f / len), dir.y * (1.0f / len), dir.z * (1.0f / len), 1.001f * len);
         }
     }
-    waveAddCounter(cost, visits + tests); // one dependent fetch each; one atomic per wave (65,536 same-address atomics took 13 ms)
+    rays[2 * i] = o;
+    rays[2 * i + 1] = d;
+}
+
+template <bool ALPHA>
+__global__ void __launch_bounds__(kBlock) k_sample_tree_cost(TraceScene sc, const float4 *__restrict__ rays, uint32_t n, uint32_t *spill,
+                                                              uint32_t *__restrict__ perRay)
+{
+    PT_DECLARE_STACK(st, kLdsStack, spill)
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    uint32_t visits = 0, tests = 0;
+    const float4 o = rays[2 * i], d = rays[2 * i + 1];
+    if (d.w > 0.0f)
+    {
+        Hit best;
+        traceRay<false, true, ALPHA>(sc, F3(o.x, o.y, o.z), F3(d.x, d.y, d.z), o.w, d.w, st, best, &visits, &tests);
+    }
+    perRay[i] = visits + tests; // one dependent fetch each
 }
 
