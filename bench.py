@@ -66,6 +66,23 @@ STAND_IN = {"chess_like": "configs[1] 'Khronos ABeautifulGame'", "temple_like": 
             "atrium_like": "configs[3] 'Intel Sponza (MAIN+CURTAINS+IVY)'", "street_like": "configs[4] 'Amazon Bistro night'",
             "attenuation_blob": "configs[0] 'Khronos DragonAttenuation'"}
 EXTRA_SCENES = ("atrium_like", "temple_like", "street_like")
+# BASELINE.json `configs` at their own definitions (child processes of the default run).  Samples per pixel of the multi-GPU
+# jobs are bounded (a rate: 64 of configs[3]'s 256, 128 of configs[4]'s 1024) so that the default run stays within minutes.
+BASELINE_CONFIGS = (
+    ("configs[0] Khronos DragonAttenuation, 512x512, 1 spp, depth 4 -- CPU reference path (stand-in attenuation_blob)",
+     ["--scene", "attenuation_blob", "--width", "512", "--height", "512", "--spp", "1", "--depth", "4", "--steps", "50", "--warmup", "5"]),
+    ("configs[0] the reference's own default scene at the same shape (CreateDefaultScene, ExampleScenes.cpp:320-545)",
+     ["--scene", "default", "--width", "512", "--height", "512", "--spp", "1", "--depth", "4", "--steps", "50", "--warmup", "5"]),
+    ("configs[2] UE4 Sun Temple, 1920x1080, 64 spp, depth 8 -- 1xMI355X: ONE renderer, 64-frame batches",
+     ["--scene", "temple_like", "--spp", "64", "--depth", "8", "--in-flight", "1", "--steps", "4", "--warmup", "1"]),
+    ("configs[2] the same with two 64-frame batches in flight",
+     ["--scene", "temple_like", "--spp", "64", "--depth", "8", "--in-flight", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]),
+    ("configs[3] Intel Sponza, 1920x1080, 256 spp, depth 12 -- 4xMI355X: rank 0's tiles, 64 of the 256 spp per step",
+     ["--scene", "atrium_like", "--spp", "64", "--depth", "12", "--shard", "0/4", "--in-flight", "2", "--steps", "4", "--warmup", "2"]),
+    ("configs[4] Amazon Bistro night, 3840x2160, 1024 spp, depth 16 -- 8xMI355X: rank 0's tiles, 128 of the 1024 spp per step",
+     ["--scene", "street_like", "--width", "3840", "--height", "2160", "--spp", "128", "--depth", "16", "--shard", "0/8", "--in-flight", "2", "--steps", "3",
+      "--warmup", "2"]),
+)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
@@ -139,6 +156,7 @@ class Job:
         self.rank, self.world = rank, world
         self.W, self.H = args.width, args.height
         self.scene = pkg.Scene(scene_name, args.detail)
+        self.scene_has_textures = self.scene.desc.textureCount > 0  # k_shade<true> / k_tail<1,2> run instead of the plain variants
         self.lights = self.scene.lights
         backend = pkg.BACKEND_WAVEFRONT if args.backend == "wavefront" else pkg.BACKEND_MEGAKERNEL
         self.F = args.in_flight if args.in_flight > 0 else 8
@@ -321,23 +339,61 @@ def segment_model_bytes(n_tris: int) -> int:
     return 2 * (32 * L + 36) + 796
 
 
-def traffic_doc(job):
-    """Per-kernel HBM bytes per launch from separate rocprofv3 --pmc passes of this same command on this scene (PMC
-    counters cannot be read from inside the process): the newest committed summary of the scene, or --traffic-json."""
+def shape_key(W, H, spp, depth, shard):
+    """What a counter summary was collected on, beside the scene: image size / samples per pixel / depth / tile shard."""
+    r, n = shard if shard else (0, 1)
+    return f"{W}x{H}/{spp}spp/d{depth}/shard{r}of{n}"
+
+
+def counter_doc(job, kind):
+    """Per-kernel counters per launch from separate rocprofv3 --pmc passes of this same command on this scene and shape (PMC
+    counters cannot be read from inside the process): the newest committed summary, profiles/r*_{traffic,sq}*.json, whose
+    `scene` and `shape` match the job (tools/pmc_traffic.py, tools/pmc_sq.py), or --traffic-json."""
     a = job.args
-    if (a.detail, job.W, job.H, a.spp, a.depth, job.world) != (1.0, 1920, 1080, 8, 8, 1):
+    if a.detail != 1.0 or job.world != 1:
         return None, None
-    if a.traffic_json:
+    want = shape_key(job.W, job.H, a.spp, a.depth, (job.shard_rank, job.shard_world))
+    if kind == "traffic" and a.traffic_json:
         cands = [a.traffic_json]
     else:
-        cands = sorted(glob.glob(os.path.join(REPO, "profiles", "r*traffic*.json")), key=os.path.getmtime, reverse=True)
+        cands = sorted(glob.glob(os.path.join(REPO, "profiles", f"r*{kind}*.json")), key=os.path.getmtime, reverse=True)
     for f in cands:
         if not os.path.exists(f):
             continue
         doc = json.load(open(f))
-        if doc.get("scene", "chess_like") == job.scene.name:
+        if doc.get("scene", "chess_like") == job.scene.name and doc.get("shape", shape_key(1920, 1080, 8, 8, None)) == want:
             return doc, f
     return None, None
+
+
+def traffic_doc(job):
+    return counter_doc(job, "traffic")
+
+
+VALU_ISSUE_PER_S = 256 * 4 * 2.4e9 / 2  # wave-instructions per second the chip's 1024 SIMDs can issue: a wave64 VALU instruction
+                                         # takes 2 cycles on a SIMD-32 (/opt/skills/guides/MI355X_MICROARCH.md) at 2.4 GHz
+
+
+def shade_roofline(job, stats_x):
+    """k_shade is the largest kernel of the shipped configuration (eight frames in flight) and is bound by instruction issue,
+    not by bytes: its figure is VALU wave-instructions per launch (SQ_INSTS_VALU of the committed SQ pass of this scene and
+    shape) over what the SIMDs can issue in the launch's own duration (launch alone on the machine, live HIP events)."""
+    doc, f = counter_doc(job, "sq")
+    if not doc or not stats_x or stats_x["launches"] <= 0:
+        return None
+    name = "k_shade<true>" if any(k.startswith("k_shade<true>") for k in doc) and job.scene_has_textures else "k_shade<false>"
+    k = doc.get(name) or doc.get("k_shade")
+    if not k or "SQ_INSTS_VALU" not in k:
+        return None
+    ms = stats_x["shade_ms"] / stats_x["launches"]
+    valu = k["SQ_INSTS_VALU"]
+    out = {"kernel": name, "bound": "valu-issue", "valu_wave_insts_per_launch": valu, "ms_alone": ms,
+           "issue_ms": valu / VALU_ISSUE_PER_S * 1e3, "frac_valu_issue": valu / VALU_ISSUE_PER_S / (ms * 1e-3),
+           "peak": VALU_ISSUE_PER_S / 1e9, "unit": "G wave-instructions/s", "source": os.path.relpath(f, REPO),
+           "stale": doc.get("source_digest") != source_digest(job.pkg)}
+    if "SQ_WAVE_CYCLES" in k and k["SQ_WAVE_CYCLES"]:
+        out["wave_cycles_waiting"] = k.get("SQ_WAIT_ANY", 0.0) / k["SQ_WAVE_CYCLES"]
+    return out
 
 
 def kernel_roofline(job, stats, bpr):
@@ -387,7 +443,7 @@ def roofline(job, stats, digest, stats_x=None, step_ms=None, segments_per_sample
         out["traffic_source"] = os.path.relpath(tj, REPO) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, (2*FETCH+WRITE)*1024)"
         out["traffic_stale"] = doc.get("source_digest") != digest
     if step_ms and segments_per_sample:
-        samples = job.W * job.H * job.args.spp / job.world
+        samples = job.W * job.H * job.args.spp / job.shard_world  # what THIS rank renders per step
         model = (segments_per_sample * segment_model_bytes(job.n_tris) + 32) * samples
         step = {"what": "the whole step (every kernel of one frame batch) over ms_per_step of the timed region",
                 "model_bytes": model, "frac_model": model / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -401,20 +457,30 @@ def roofline(job, stats, digest, stats_x=None, step_ms=None, segments_per_sample
             step["counter_bytes_by_kernel"] = {k: v["hbm_bytes_per_launch"] * v["launches"] / frames for k, v in doc.items()
                                                if isinstance(v, dict) and k in RENDER_KERNELS and v["hbm_bytes_per_launch"] * v["launches"] / frames > 1e6}
         out["step"] = step
+        # the whole-step figures a reader should see first: what HBM moved over the step time; the closed-form model counts
+        # bytes the caches serve and stops being a roofline once it exceeds the peak
+        out["frac_step_counter"] = step["frac_counter"]
+        out["frac_step_model"] = step["frac_model"]
+        out["model_valid"] = bool(step["frac_model"] <= 1.0)
+    shade = shade_roofline(job, stats_x)
+    if shade:
+        out["shade"] = shade
     return out
 
 
 def scene_line(args, pkg, torch, dist, orc, name, rank, world, local_rank, steps, warmup, min_seconds, with_cpu, digest):
     """Measure one scene: the read-back-inclusive rate (value), the rate without read-back, roofline, CPU baseline."""
-    job = Job(args, pkg, torch, dist, name, rank, world, local_rank, alone_steps=3 if world == 1 and args.backend == "wavefront" else 0)
+    shard = tuple(int(x) for x in args.shard.split("/")) if args.shard else None
+    job = Job(args, pkg, torch, dist, name, rank, world, local_rank, shard=shard, alone_steps=3 if world == 1 and args.backend == "wavefront" else 0)
     W, H = job.W, job.H
     spp = args.spp
+    share = shard[1] if shard else 1  # a rank's share of a tile-sharded job renders 1 / share of the pixels
     med, regions, stats = job.measure(spp, steps, warmup, args.repeats, min_seconds, readback=True)
     med_nr, regions_nr, _ = job.measure(spp, steps, 0, max(1, min(len(regions), 3)), 0.0, readback=False)
     stats_x = job.alone_stats
     line = None
     if rank == 0:
-        samples = W * H * spp * steps
+        samples = W * H * spp * steps / share
         img = job.last_image()
         line = {
             "value": samples / med / 1e6, "unit": "Msamples/s", "ms_per_step": med / steps * 1e3, "steps": steps,
@@ -422,9 +488,11 @@ def scene_line(args, pkg, torch, dist, orc, name, rank, world, local_rank, steps
             "spread": {"regions": len(regions), "timed_s": float(sum(regions)), "min_ms_per_step": min(regions) / steps * 1e3,
                        "max_ms_per_step": max(regions) / steps * 1e3},
             "config": {
-                "workload": f"{name} (procedural stand-in for BASELINE {STAND_IN.get(name, 'scenes')}), {W}x{H}, {spp} spp, depth {args.depth}",
+                "workload": f"{name} (procedural stand-in for BASELINE {STAND_IN.get(name, 'scenes')}), {W}x{H}, {spp} spp, depth {args.depth}"
+                            + (f"; rank {shard[0]}'s share of a {shard[1]}-GPU pixel-tile shard (value = this rank's samples / s; no gather)" if shard else ""),
+                "shape": shape_key(W, H, spp, args.depth, shard),
                 "triangles": job.n_tris, "backend": args.backend, "tile": args.tile, "frames_in_flight": job.F,
-                "segments_per_sample": stats["segments"] / (W * H * spp / world),
+                "segments_per_sample": stats["segments"] / (W * H * spp / world / share),
                 "tree_build_ms": job.build_ms, "upload_plus_build_s": job.upload_build_s,
                 "kernel_ms_per_step": {"k_trace_closest": stats["trace_ms"] / steps, "k_shade": stats["shade_ms"] / steps,
                                        "k_trace_shadow": stats["shadow_ms"] / steps, "k_tail": stats["tail_ms"] / steps},
@@ -436,7 +504,7 @@ def scene_line(args, pkg, torch, dist, orc, name, rank, world, local_rank, steps
         if stats_x:
             # latency of ONE frame batch (reset -> 8 spp -> done, nothing else on the machine); `value` is the pipelined rate
             line["one_in_flight_ms_per_step"] = stats_x["wall_s"] / stats_x["steps"] * 1e3
-            line["one_in_flight_value"] = W * H * spp / (stats_x["wall_s"] / stats_x["steps"]) / 1e6
+            line["one_in_flight_value"] = W * H * spp / share / (stats_x["wall_s"] / stats_x["steps"]) / 1e6
             line["one_in_flight_kernel_ms_per_step"] = {"k_trace_closest": stats_x["trace_ms"] / stats_x["steps"], "k_shade": stats_x["shade_ms"] / stats_x["steps"],
                                                         "k_trace_shadow": stats_x["shadow_ms"] / stats_x["steps"], "k_tail": stats_x["tail_ms"] / stats_x["steps"]}
         if with_cpu:
@@ -476,6 +544,9 @@ def main():
                     help="experiments only: one process renders the tile shard of rank R of N (no gather) to see what a rank of an "
                          "N-GPU run costs; the printed line is marked and is not a benchmark result")
     ap.add_argument("--emulate-scaling", default="strong", choices=["weak", "strong"])
+    ap.add_argument("--shard", default=None, metavar="R/N",
+                    help="N = 1 only: measure rank R's share of an N-GPU pixel-tile shard of the frame (BASELINE configs[3] and [4] are "
+                         "4- and 8-GPU jobs: one GPU renders one rank's tiles; the line says so and `value` is that rank's rate)")
     ap.add_argument("--traffic-json", default=None,
                     help="per-kernel HBM bytes per launch from tools/pmc_traffic.py (default: newest profiles/r*_traffic.json)")
     ap.add_argument("--dump-image", default=None, help="testing: rank 0 saves the last frame (npy)")
@@ -531,24 +602,36 @@ def main():
         out = dict(common, scaling="strong", **line)  # N = 1 of the strong-scaling series: the named 8-spp frame
         out["config"]["parallelism"] = "pixel-tile shard x1"
         if not args.no_extra_scenes and args.scene == "chess_like":
-            # the same measurement on the other stand-ins: the same K steps per region (a region starts
-            # and ends with an empty ring of frames in flight, and with 8 of them half as many steps read 5-15 % lower), each in
-            # a process of its own, as `bench.py --scene NAME` runs it -- behind another scene's job in THIS process atrium_like
-            # reads 10 % lower (756 against 845 Msamples/s on one box: its 460 MB tree lands in memory the first job used and freed)
+            # Every other line is measured in a process of its own, as `bench.py --scene NAME ...` runs it (behind another scene's
+            # job in THIS process atrium_like reads 10 % lower: its 460 MB tree lands in memory the first job used and freed).
+            #   stand_ins_8spp  the other stand-ins at the headline's shape (1080p, 8 spp, depth 8), the same
+            #                   K steps per region (a region starts and ends with an empty ring of frames in flight)
+            #   configs         BASELINE.json's five configs AS BASELINE STATES THEM -- resolution, samples per pixel and depth of
+            #                   each; configs[1] is this line itself.  The multi-GPU configs run as ONE rank's share of the job on
+            #                   this GPU (--shard), with a bounded number of the job's samples per pixel; configs[0] is the config
+            #                   BASELINE names "CPU reference path": its cpu_baseline is that path, the GPU figure rides beside it.
             import subprocess
-            out["configs"] = []
             mine = set(common) | {"scaling"}
-            for name in EXTRA_SCENES:
-                cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--scene", name, "--no-extra-scenes", "--steps", str(args.steps),
-                       "--warmup", "2", "--repeats", str(args.repeats), "--min-seconds", str(min(args.min_seconds, 1.5)),
-                       "--detail", str(args.detail), "--width", str(W), "--height", str(H), "--spp", str(args.spp), "--depth", str(args.depth),
-                       "--tile", str(args.tile), "--in-flight", str(args.in_flight), "--backend", args.backend,
-                       "--cpu-seconds", str(args.cpu_seconds)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+
+            def child(extra, what):
+                cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-extra-scenes", "--detail", str(args.detail), "--tile", str(args.tile),
+                       "--backend", args.backend, "--cpu-seconds", str(args.cpu_seconds)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + extra
                 p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
                 if p.returncode != 0:
-                    raise SystemExit(f"[bench] the `configs` run of {name} failed (exit code {p.returncode})")
+                    raise SystemExit(f"[bench] the {what} run failed (exit code {p.returncode}): {' '.join(cmd)}")
                 l = json.loads(p.stdout.strip().splitlines()[-1])
-                out["configs"].append({k: v for k, v in l.items() if k not in mine})
+                return {k: v for k, v in l.items() if k not in mine}
+
+            out["stand_ins_8spp"] = []
+            for name in EXTRA_SCENES:
+                out["stand_ins_8spp"].append(child(["--scene", name, "--steps", str(args.steps), "--warmup", "2", "--repeats", str(args.repeats),
+                                                    "--min-seconds", str(min(args.min_seconds, 1.5)), "--width", str(W), "--height", str(H), "--spp", str(args.spp),
+                                                    "--depth", str(args.depth), "--in-flight", str(args.in_flight)], f"stand-in {name}"))
+            out["configs"] = []
+            for key, extra in BASELINE_CONFIGS:
+                l = child(extra + ["--repeats", "2", "--min-seconds", "0"], key)
+                out["configs"].append(dict({"baseline_config": key}, **l))
+            out["configs"].insert(1, {"baseline_config": "configs[1] Khronos ABeautifulGame, 1920x1080, 8 spp, depth 8 -- 1xMI355X", "is": "this line (value, roofline, cpu_baseline at the top level)"})
         print(json.dumps(out), flush=True)
         return
 

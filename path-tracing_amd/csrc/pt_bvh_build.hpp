@@ -601,26 +601,34 @@ __global__ void k_refit(int n, const uint32_t *__restrict__ vals, const float4 *
 // bytes, four slab tests -- for every wide node whose box it enters, with probability proportional to that box's area, and the
 // triangle tests are the same whatever node a triangle hangs from, so the objective is the summed area of the wide nodes.
 //   T(x, j)   least cost of the subtree of binary node x when it may occupy at most j child slots of a wide node above it
-//   leaf      T = 0 for every j (its test is paid in every collapse alike)
+//   leaf      T = the area of its box as the node above will store it (collapseCostOf), for every j
 //   internal  T(x, 1) = area(x) + D(x, 4)                         x becomes a wide node: its children share four slots
 //             T(x, j) = min(T(x, 1), D(x, j))        j = 2, 3, 4   or x is dissolved into the slots it was given
 //             D(x, j) = min over k of T(left, k) + T(right, j - k)
 // One thread per leaf walks up; the second thread to arrive at a node owns it (as k_refit).  Per node: the four costs and one
 // byte of decisions -- keep_j (bit 2 + j: T(x, 1) <= D(x, j)), the best split of three slots (bit 0: left gets 2) and of four
 // (bits 1..2: slots of the left child minus one) -- which k_emit follows from every node downwards.
-struct CollapseCost
-{
-    float4 t; // T(x, 1..4)
-};
+constexpr float kCollapseTriCost = 1.0f; // a triangle test (three loads, the two-pass test) against a node visit (four loads, four slab tests)
 
-PT_DEV float4 collapseCostOf(int ref, const float4 *cost) // a child's T(., 1..4)
+// A child's T(., 1..4).  A leaf is not free after all: its box is stored in 8 bits per plane inside the box of the wide node it
+// hangs from, i.e. grown by up to 1/255 of that node's extent per side -- a 6 cm triangle under a 10 m node is tested by every ray
+// that passes within 4 cm of it.  The wide node is not known yet when the leaf's parent x is priced; x's own box is the smallest
+// it can be (x dissolved into a larger node makes it worse), so the leaf costs the area of its box grown by extent(x) / 255.
+PT_DEV float4 collapseCostOf(int ref, const float4 *cost, const uint32_t *vals, const float4 *boxLo, const float4 *boxHi, float gx, float gy, float gz)
 {
     if (ref < 0)
-        return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    {
+        const uint32_t g = vals[~ref];
+        const float4 lo = boxLo[g], hi = boxHi[g];
+        const float dx = (hi.x - lo.x) + 2.0f * gx, dy = (hi.y - lo.y) + 2.0f * gy, dz = (hi.z - lo.z) + 2.0f * gz;
+        const float a = kCollapseTriCost * (dx * dy + dy * dz + dz * dx);
+        return make_float4(a, a, a, a);
+    }
     return loadUncached(&cost[ref]);
 }
 
-__global__ void k_collapse_cost(int n, const int2 *__restrict__ children, const int *__restrict__ parentOfNode, const int *__restrict__ parentOfLeaf,
+__global__ void k_collapse_cost(int n, const uint32_t *__restrict__ vals, const float4 *__restrict__ boxLo, const float4 *__restrict__ boxHi,
+                                const int2 *__restrict__ children, const int *__restrict__ parentOfNode, const int *__restrict__ parentOfLeaf,
                                 const float4 *__restrict__ nodeLo, const float4 *__restrict__ nodeHi, uint32_t *__restrict__ flags,
                                 float4 *__restrict__ cost, uint8_t *__restrict__ decide)
 {
@@ -635,9 +643,11 @@ __global__ void k_collapse_cost(int n, const int2 *__restrict__ children, const 
             return;
         __threadfence();
         const int2 ch = children[node];
-        const float4 l = collapseCostOf(ch.x, cost), r = collapseCostOf(ch.y, cost);
         const float4 lo = nodeLo[node], hi = nodeHi[node];
         const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+        const float q = 1.0f / 255.0f;
+        const float4 l = collapseCostOf(ch.x, cost, vals, boxLo, boxHi, dx * q, dy * q, dz * q);
+        const float4 r = collapseCostOf(ch.y, cost, vals, boxLo, boxHi, dx * q, dy * q, dz * q);
         const float area = dx * dy + dy * dz + dz * dx;
         const float d2 = l.x + r.x;
         const float d3a = l.x + r.y, d3b = l.y + r.x; // left 1 + right 2, left 2 + right 1

@@ -1221,7 +1221,7 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
         if (r->tree.collapse)
         {
             BUILD_TRY(hipMemsetAsync(B.flags.p, 0, (size_t)nv * 4, r->stream)); // (the arrival flags of k_refit: done with)
-            k_collapse_cost<<<vblocks, 256, 0, r->stream>>>((int)nv, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p, B.nodeLo.p, B.nodeHi.p, B.flags.p,
+            k_collapse_cost<<<vblocks, 256, 0, r->stream>>>((int)nv, vin, B.boxLo.p, B.boxHi.p, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p, B.nodeLo.p, B.nodeHi.p, B.flags.p,
                                                        B.collapseCost.p, B.collapseDecide.p);
         }
         k_emit<<<vblocks, 256, 0, r->stream>>>((int)nv, vin, B.boxLo.p, B.boxHi.p, B.children.p, B.nodeLo.p, B.nodeHi.p, B.triTmp.p,

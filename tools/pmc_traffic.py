@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Turn rocprofv3 PMC passes into per-kernel HBM traffic per launch.
 
-Usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json> [scene]   (scene: bench.py --scene of the profiled command, default chess_like)
+Usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json> [scene [shape]]   (scene: bench.py --scene of the profiled command, default
+       chess_like; shape: bench.py's shape key of it, WxH/SPPspp/dDEPTH/shardRofN, default 1920x1080/8spp/d8/shard0of1)
 where the dirs hold the counter_collection.csv of two separate passes of the SAME command,
   rocprofv3 --kernel-trace --pmc FETCH_SIZE  --output-format csv -d <fetch_dir> -- python3 bench.py ...
   rocprofv3 --kernel-trace --pmc WRITE_SIZE  --output-format csv -d <write_dir> -- python3 bench.py ...
@@ -57,6 +58,7 @@ def main():
     ranked = sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])
     out["source_digest"] = source_digest()
     out["scene"] = sys.argv[4] if len(sys.argv) > 4 else "chess_like"
+    out["shape"] = sys.argv[5] if len(sys.argv) > 5 else "1920x1080/8spp/d8/shard0of1"
     json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
     for k, v in ranked[:8]:
         if not isinstance(v, dict):
