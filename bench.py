@@ -187,7 +187,8 @@ class Job:
         self.k = 0
         self.issued = [False] * self.F
         self.collect = None
-        if world > 1:  # gather plumbing: equal-size padded shard buffers per frame in flight, one all_gather per step
+        self.gather = world > 1 or args.force_gather
+        if self.gather:  # gather plumbing: equal-size padded shard buffers per frame in flight, one all_gather per step
             self.shard_floats = max(self.rs[0].shard_bytes(k) for k in range(world)) // 4
             self.send = [torch.zeros(self.shard_floats, dtype=torch.float32, device="cuda") for _ in range(self.F)]
             self.recv = [torch.zeros(world * self.shard_floats, dtype=torch.float32, device="cuda") for _ in range(self.F)]
@@ -214,7 +215,7 @@ class Job:
         r.reset()
         r.render_frames(self.u, self.lights, 0, job_spp)
         self.issued[i] = True
-        if self.world > 1:
+        if self.gather:
             send, recv = self.send[i], self.recv[i]
             r.pack_shard(send.data_ptr())
             with torch.cuda.stream(self.streams[i]):  # the renderer runs on this torch stream: the collective is ordered behind the pack
@@ -540,6 +541,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --single-device lets the N > 1 code path be exercised on a 1-GPU box (testing only)")
     ap.add_argument("--single-device", action="store_true", help="testing only: every rank uses cuda:0")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="testing only: with ONE rank, still create the process group and run the N > 1 step (pack, all_gather, unpack, "
+                         "read-back) -- the RCCL branch executes on a 1-GPU box, where a 2-rank communicator on one device is refused")
     ap.add_argument("--emulate-shard", default=None, metavar="R/N",
                     help="experiments only: one process renders the tile shard of rank R of N (no gather) to see what a rank of an "
                          "N-GPU run costs; the printed line is marked and is not a benchmark result")
@@ -567,8 +571,9 @@ def main():
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -596,7 +601,7 @@ def main():
         job.close()
         return
 
-    if world == 1:
+    if world == 1 and not args.force_gather:
         line = scene_line(args, pkg, torch, dist, orc, args.scene, 0, 1, local_rank, args.steps, args.warmup, args.min_seconds,
                           not args.no_cpu_baseline, digest)
         out = dict(common, scaling="strong", **line)  # N = 1 of the strong-scaling series: the named 8-spp frame

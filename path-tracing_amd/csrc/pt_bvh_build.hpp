@@ -107,6 +107,313 @@ __global__ void k_tri_setup(uint32_t n, uint32_t pairCount, const uint32_t *__re
     }
 }
 
+// ---- triangle pre-splitting (round 4) ------------------------------------------------------------------------------
+// A triangle that is large against the cells of the tree around it -- a floor or wall made of two triangles, a long curtain
+// strip, a diagonal beam -- has ONE box in a tree of single-triangle leaves: every ray that crosses that box pays a node visit
+// up the whole chain of ancestors it inflates, and the test.  Splitting REFERENCES (Karras and Aila 2013, section 5; Ernst and
+// Greiner 2007): before the Morton sort such a triangle is cut, along planes of the Morton grid, into up to kMaxSplitsPerTri
+// pieces; each piece becomes a leaf of its own with the tight box of the triangle clipped to its cell, and all of them name the
+// same triangle record.  What a ray hits does not change: a closest-hit walk that meets the triangle through two leaves finds the
+// same (t, u, v, id) twice -- the second is no improvement --, an occlusion walk ends at the first, and the "nearest ignored
+// candidate" of the any-hit stage is idempotent for a repeated candidate (tests/test_gpu_parity.py: brute force, oracle images).
+//   priority  p = cbrt(2^-depth * (area of the box - smallest area its pieces could have)): depth = level of the coarsest
+//             Morton plane that crosses the box (the earlier in the tree a plane, the more a straddling box costs), the ideal
+//             area |n.x| + |n.y| + |n.z| of the edge cross product n = the triangle's three projections
+//   budget    pieces(g) = 1 + floor(D p(g)), D chosen so that the extra references are `budget` x the triangle count
+//   cut       at the coarsest Morton plane crossing the piece's tight box (midpoint where none does), the piece's count shared
+//             between the halves by their widths; a piece's box = the triangle clipped to its cell, where the cell is widened by
+//             the leaf padding of that axis (any point the triangle test accepts has a point of the triangle within the padding,
+//             pt_bvh.hpp "Arithmetic"; that point lies in the widened cell of the side the accepted point is on), then padded
+//             like every leaf box
+// Static scenes only: a refit keeps topology and references, and the pieces of a moving triangle would have to be cut again.
+constexpr uint32_t kMaxSplitsPerTri = 64;
+constexpr double kSplitPriorityScale = 1048576.0; // priorities are summed as integers (order-independent: the build stays deterministic)
+
+struct SplitGrid // the Morton grid of k_morton
+{
+    float mn[3], cell[3]; // cell = extent / 2^21 per axis (one value for all three with cubic cells)
+};
+PT_DEV SplitGrid splitGrid(const uint32_t *sceneBounds, int cubic)
+{
+    SplitGrid g;
+    float widest = 0.0f;
+    for (int a = 0; a < 3; a++)
+        widest = fmaxf(widest, unorderedFloat(sceneBounds[3 + a]) - unorderedFloat(sceneBounds[a]));
+    for (int a = 0; a < 3; a++)
+    {
+        g.mn[a] = unorderedFloat(sceneBounds[a]);
+        const float ext = cubic ? widest : unorderedFloat(sceneBounds[3 + a]) - g.mn[a];
+        g.cell[a] = ext > 0.0f ? ext / 2097152.0f : 0.0f;
+    }
+    return g;
+}
+// the coarsest grid plane strictly inside (lo, hi) on axis a: its depth in the tree of spatial medians (3 * level + axis;
+// 1000 = none) and position
+PT_DEV int coarsestPlane(const SplitGrid &g, int a, float lo, float hi, float &plane)
+{
+    if (!(g.cell[a] > 0.0f) || !(hi > lo))
+        return 1000;
+    const float fl = (lo - g.mn[a]) / g.cell[a], fh = (hi - g.mn[a]) / g.cell[a];
+    const int cl = (int)fminf(fmaxf(fl, 0.0f), 2097151.0f), ch = (int)fminf(fmaxf(fh, 0.0f), 2097151.0f);
+    if (cl == ch)
+        return 1000;
+    const int b = 31 - __clz(cl ^ ch); // highest bit in which the two cells differ
+    const int first = (ch >> b) << b;  // first cell of the upper half
+    plane = g.mn[a] + (float)first * g.cell[a];
+    if (!(plane > lo && plane < hi))
+        return 1000;
+    return 3 * (20 - b) + a;
+}
+
+PT_DEV float boxArea(const float *lo, const float *hi)
+{
+    const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return 2.0f * (dx * dy + dy * dz + dz * dx);
+}
+
+// per triangle: its priority (0 for an inert one), summed over the scene as an integer
+__global__ void k_split_priority(uint32_t n, const Tri *__restrict__ triTmp, const float4 *__restrict__ boxLo, const float4 *__restrict__ boxHi,
+                                 const uint8_t *__restrict__ inert, const uint32_t *__restrict__ sceneBounds, int cubic, float *__restrict__ priority,
+                                 unsigned long long *__restrict__ sum)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    float p = 0.0f;
+    if (g < n && !inert[g])
+    {
+        const SplitGrid grid = splitGrid(sceneBounds, cubic);
+        const float4 l4 = boxLo[g], h4 = boxHi[g];
+        const float lo[3] = { l4.x, l4.y, l4.z }, hi[3] = { h4.x, h4.y, h4.z };
+        int depth = 1000;
+        for (int a = 0; a < 3; a++)
+        {
+            float plane;
+            const int d = coarsestPlane(grid, a, lo[a], hi[a], plane);
+            depth = d < depth ? d : depth;
+        }
+        if (depth < 1000)
+        {
+            const Tri t = triTmp[g];
+            const f3 nrm = cross(F3(t.a.w, t.b.x, t.b.y), F3(t.b.z, t.b.w, t.c.x));
+            const float ideal = fabsf(nrm.x) + fabsf(nrm.y) + fabsf(nrm.z);
+            const float excess = boxArea(lo, hi) - ideal;
+            if (excess > 0.0f)
+                p = cbrtf(exp2f(-(float)depth / 3.0f) * excess); // (depth counts the three axes of a level separately)
+        }
+        if (!(p == p) || p > 1.0e6f)
+            p = 0.0f;
+    }
+    if (g < n)
+        priority[g] = p;
+    // one atomic per wave
+    unsigned long long q = (unsigned long long)((double)p * kSplitPriorityScale);
+    for (int off = 32; off > 0; off >>= 1)
+        q += __shfl_down(q, off);
+    if ((threadIdx.x & 63u) == 0 && q)
+        atomicAdd(sum, q);
+}
+
+// pieces per triangle (as an array to be scanned): 1 + floor(D p), at most kMaxSplitsPerTri
+__global__ void k_split_count(uint32_t n, const float *__restrict__ priority, float perPriority, uint32_t *__restrict__ count)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n)
+        return;
+    const float extra = floorf(perPriority * priority[g]);
+    uint32_t c = 1u + (extra > 0.0f ? (uint32_t)fminf(extra, (float)(kMaxSplitsPerTri - 1)) : 0u);
+    count[g] = c;
+}
+
+// the triangle (v0, v0 + e1, v0 + e2) clipped to a box: Sutherland-Hodgman against its six planes; returns the vertex count
+// (0: nothing left) and the bounds of what is left
+PT_DEV int clipTriToBox(const Tri &t, const float *cLo, const float *cHi, float *outLo, float *outHi)
+{
+    float pa[12][3], pb[12][3];
+    int n = 3;
+    pa[0][0] = t.a.x; pa[0][1] = t.a.y; pa[0][2] = t.a.z;
+    pa[1][0] = t.a.x + t.a.w; pa[1][1] = t.a.y + t.b.x; pa[1][2] = t.a.z + t.b.y;
+    pa[2][0] = t.a.x + t.b.z; pa[2][1] = t.a.y + t.b.w; pa[2][2] = t.a.z + t.c.x;
+    for (int plane = 0; plane < 6 && n > 0; plane++)
+    {
+        const int a = plane >> 1;
+        const bool upper = plane & 1; // keep x[a] <= bound, else x[a] >= bound
+        const float bound = upper ? cHi[a] : cLo[a];
+        int m = 0;
+        for (int i = 0; i < n; i++)
+        {
+            const float *p = pa[i], *q = pa[i + 1 == n ? 0 : i + 1];
+            const bool pin = upper ? p[a] <= bound : p[a] >= bound, qin = upper ? q[a] <= bound : q[a] >= bound;
+            if (pin && m < 12)
+            {
+                pb[m][0] = p[0]; pb[m][1] = p[1]; pb[m][2] = p[2];
+                m++;
+            }
+            if (pin != qin && m < 12)
+            {
+                const float w = (bound - p[a]) / (q[a] - p[a]);
+                for (int k = 0; k < 3; k++)
+                    pb[m][k] = p[k] + (q[k] - p[k]) * w;
+                pb[m][a] = bound;
+                m++;
+            }
+        }
+        n = m;
+        for (int i = 0; i < n; i++)
+            for (int k = 0; k < 3; k++)
+                pa[i][k] = pb[i][k];
+    }
+    for (int k = 0; k < 3; k++)
+    {
+        outLo[k] = 3.0e38f;
+        outHi[k] = -3.0e38f;
+    }
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++)
+        {
+            outLo[k] = fminf(outLo[k], pa[i][k]);
+            outHi[k] = fmaxf(outHi[k], pa[i][k]);
+        }
+    return n;
+}
+
+// the references of triangle g from refBase[g] on: its pieces' boxes (or its own box, when it is not split)
+__global__ void k_split_write(uint32_t n, const Tri *__restrict__ triTmp, const float4 *__restrict__ boxLo, const float4 *__restrict__ boxHi,
+                              const uint8_t *__restrict__ inert, const uint32_t *__restrict__ sceneBounds, int cubic, const uint32_t *__restrict__ refBase,
+                              uint32_t total, float4 *__restrict__ refLo, float4 *__restrict__ refHi, uint32_t *__restrict__ refTri,
+                              uint8_t *__restrict__ refInert)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n)
+        return;
+    const uint32_t base = refBase[g], pieces = (g + 1 < n ? refBase[g + 1] : total) - base;
+    const float4 l4 = boxLo[g], h4 = boxHi[g];
+    if (pieces <= 1u)
+    {
+        refLo[base] = l4;
+        refHi[base] = h4;
+        refTri[base] = g;
+        refInert[base] = inert[g];
+        return;
+    }
+    const SplitGrid grid = splitGrid(sceneBounds, cubic);
+    const Tri t = triTmp[g];
+    // the triangle's own leaf padding per axis (k_tri_setup), recovered from its padded and its exact bounds
+    float pad[3], tLo[3], tHi[3];
+    {
+        const float p0[3] = { t.a.x, t.a.y, t.a.z }, a1[3] = { t.a.w, t.b.x, t.b.y }, a2[3] = { t.b.z, t.b.w, t.c.x };
+        const float bl[3] = { l4.x, l4.y, l4.z };
+        for (int a = 0; a < 3; a++)
+        {
+            const float q1 = p0[a] + a1[a], q2 = p0[a] + a2[a];
+            tLo[a] = fminf(p0[a], fminf(q1, q2));
+            tHi[a] = fmaxf(p0[a], fmaxf(q1, q2));
+            pad[a] = tLo[a] - bl[a];
+        }
+    }
+    // explicit stack of (cell, pieces): a cell is the triangle's exact bounds cut by the planes chosen so far
+    float sLo[kMaxSplitsPerTri][3], sHi[kMaxSplitsPerTri][3];
+    uint32_t sCount[kMaxSplitsPerTri];
+    int sp = 0;
+    for (int a = 0; a < 3; a++)
+    {
+        sLo[0][a] = tLo[a];
+        sHi[0][a] = tHi[a];
+    }
+    sCount[0] = pieces;
+    sp = 1;
+    uint32_t out = base;
+    const uint32_t end = base + pieces;
+    while (sp > 0 && out < end)
+    {
+        sp--;
+        float cLo[3], cHi[3], wLo[3], wHi[3], bLo[3], bHi[3];
+        const uint32_t s = sCount[sp];
+        for (int a = 0; a < 3; a++)
+        {
+            cLo[a] = sLo[sp][a];
+            cHi[a] = sHi[sp][a];
+            wLo[a] = cLo[a] - pad[a]; // the cell widened by the padding: see the header comment
+            wHi[a] = cHi[a] + pad[a];
+        }
+        const int verts = clipTriToBox(t, wLo, wHi, bLo, bHi);
+        if (verts == 0) // cannot happen for cells cut from tight bounds; keep the count with a box that is certainly conservative
+            for (int a = 0; a < 3; a++)
+            {
+                bLo[a] = cLo[a];
+                bHi[a] = cHi[a];
+            }
+        int axis = -1, bestDepth = 1000;
+        float plane = 0.0f;
+        if (s > 1u)
+        {
+            // cut inside the piece's tight bounds (within the cell): coarsest Morton plane, else the midpoint of the longest axis
+            float lo[3], hi[3], longest = 0.0f;
+            for (int a = 0; a < 3; a++)
+            {
+                lo[a] = fmaxf(bLo[a], cLo[a]);
+                hi[a] = fminf(bHi[a], cHi[a]);
+                longest = fmaxf(longest, hi[a] - lo[a]);
+            }
+            for (int a = 0; a < 3; a++)
+            {
+                float pl;
+                // (not along an axis the piece is thin in: the halves would be as large as the piece)
+                const int d = (hi[a] - lo[a]) >= 0.25f * longest ? coarsestPlane(grid, a, lo[a], hi[a], pl) : 1000;
+                if (d < bestDepth)
+                {
+                    bestDepth = d;
+                    axis = a;
+                    plane = pl;
+                }
+            }
+            if (axis < 0)
+                for (int a = 0; a < 3; a++)
+                    if (hi[a] - lo[a] == longest && longest > 0.0f)
+                    {
+                        const float mid = 0.5f * (lo[a] + hi[a]);
+                        if (mid > lo[a] && mid < hi[a])
+                        {
+                            axis = a;
+                            plane = mid;
+                        }
+                        break;
+                    }
+            if (axis >= 0 && sp + 2 <= (int)kMaxSplitsPerTri)
+            {
+                const float wl = plane - lo[axis], wr = hi[axis] - plane;
+                uint32_t sl = (uint32_t)floorf((float)s * wl / (wl + wr) + 0.5f);
+                sl = sl < 1u ? 1u : (sl > s - 1u ? s - 1u : sl);
+                for (int a = 0; a < 3; a++)
+                {
+                    sLo[sp][a] = lo[a]; sHi[sp][a] = hi[a];
+                    sLo[sp + 1][a] = lo[a]; sHi[sp + 1][a] = hi[a];
+                }
+                sHi[sp][axis] = plane; // lower half
+                sCount[sp] = sl;
+                sLo[sp + 1][axis] = plane; // upper half
+                sCount[sp + 1] = s - sl;
+                sp += 2;
+                continue;
+            }
+        }
+        // a leaf box: the clipped bounds, padded like every leaf box and kept inside the triangle's own padded box; a piece that
+        // could not be cut stands for all of its count (repeated references are harmless)
+        for (uint32_t k = 0; k < s && out < end; k++, out++)
+        {
+            refLo[out] = make_float4(fmaxf(bLo[0] - pad[0], l4.x), fmaxf(bLo[1] - pad[1], l4.y), fmaxf(bLo[2] - pad[2], l4.z), 0.0f);
+            refHi[out] = make_float4(fminf(bHi[0] + pad[0], h4.x), fminf(bHi[1] + pad[1], h4.y), fminf(bHi[2] + pad[2], h4.z), 0.0f);
+            refTri[out] = g;
+            refInert[out] = 0;
+        }
+    }
+    for (; out < end; out++) // (stack exhausted early: cannot happen; keep every slot defined)
+    {
+        refLo[out] = l4;
+        refHi[out] = h4;
+        refTri[out] = g;
+        refInert[out] = 0;
+    }
+}
+
 PT_DEV uint64_t expandBits21(uint32_t v) // 21 bits -> every third bit of 63
 {
     uint64_t x = v & 0x1fffffu;
@@ -739,12 +1046,15 @@ __global__ void k_emit(int n, const uint32_t *__restrict__ vals, const float4 *_
                        const float4 *__restrict__ boxHi, const int2 *__restrict__ children, const float4 *__restrict__ nodeLo,
                        const float4 *__restrict__ nodeHi, const Tri *__restrict__ triTmp, BvhNode *__restrict__ nodes,
                        Tri *__restrict__ tris, const DevPair *__restrict__ pairs, const PtxVertex *__restrict__ vertices,
-                       const uint32_t *__restrict__ indices, ShadeTri *__restrict__ shadeTris, const uint8_t *__restrict__ decide)
+                       const uint32_t *__restrict__ indices, ShadeTri *__restrict__ shadeTris, const uint8_t *__restrict__ decide,
+                       const uint32_t *__restrict__ refTri)
 {
+    // vals[i] = the leaf reference at sorted position i; refTri (null: the identity) names its triangle -- a triangle that was
+    // split stands in several slots, record and all
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n)
     {
-        const Tri t = triTmp[vals[i]];
+        const Tri t = triTmp[refTri ? refTri[vals[i]] : vals[i]];
         tris[i] = t;
         writeShadeTri(t, pairs, vertices, indices, &shadeTris[i]);
     }
@@ -874,7 +1184,7 @@ __global__ void k_emit(int n, const uint32_t *__restrict__ vals, const float4 *_
     nd.a = make_float4(o[0], o[1], o[2], __uint_as_float(ebits[0] | (ebits[1] << 8) | (ebits[2] << 16)));
     // a leaf of a non-opaque geometry says so in its ref: the traversal fetches its any-hit record beside the triangle
     for (int k = 0; k < count; k++)
-        if (c[k].ref < 0 && (__float_as_uint(triTmp[vals[~c[k].ref]].c.w) & kTriNonOpaque))
+        if (c[k].ref < 0 && (__float_as_uint(triTmp[refTri ? refTri[vals[~c[k].ref]] : vals[~c[k].ref]].c.w) & kTriNonOpaque))
             c[k].ref = ~(int)((uint32_t)~c[k].ref | kLeafNonOpaque);
     nd.refs = make_int4(c[0].ref, c[1].ref, count > 2 ? c[2].ref : kEmptyRef, count > 3 ? c[3].ref : kEmptyRef);
     nd.q0 = make_uint4(qlo[0], qhi[0], qlo[1], qhi[1]);
@@ -924,6 +1234,62 @@ __global__ void __launch_bounds__(256) k_relayout_level(uint32_t lo, uint32_t hi
         }
     nd.refs = make_int4(refs[0], refs[1], refs[2], refs[3]);
     out[i] = nd;
+}
+
+// ---- subtree-contiguous (depth-first) order of the relaid-out nodes (round 4) ---------------------------------------
+// The breadth-first array above keeps the top of the tree dense, but below it every level is an array of its own: a walk of
+// eleven levels touches eleven regions of memory, and the deep levels of a 4 M-triangle tree are tens of megabytes each -- a
+// 2 MB page or an L2 line brought in for one ray serves few others (atrium_like, 460 MB of tree against 256 MB of Infinity
+// Cache: L2 hit rate 44 %, 2.4 M per-CU TLB misses per closest-hit launch, profiles/r03_mem_counters_atrium_like.txt).
+// In depth-first pre-order every subtree is one contiguous range: the last six levels under a node (4,096 nodes, 256 KB) share
+// a page, and rays that work in one part of the scene work in one part of the array.  Three passes over the levels the
+// breadth-first pass found (their ranges are known on the host, so nothing is read back):
+//   k_subtree_size   deepest level first: size[i] = 1 + the sizes of i's internal children
+//   k_subtree_pos    root first: pos[child] = pos[i] + 1 + the sizes of the children in the slots before it
+//   k_place_nodes    node i goes to pos[i], its child refs to pos[child]
+// (refs of a breadth-first node: indices into the breadth-first array.)
+__global__ void k_subtree_size(uint32_t lo, uint32_t hi, const BvhNode *__restrict__ nodes, uint32_t *__restrict__ size)
+{
+    const uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hi)
+        return;
+    const int4 r4 = nodes[i].refs;
+    const int refs[kNodeWidth] = { r4.x, r4.y, r4.z, r4.w };
+    uint32_t s = 1;
+    for (int k = 0; k < kNodeWidth; k++)
+        if (refs[k] >= 0 && refs[k] != kEmptyRef)
+            s += size[refs[k]];
+    size[i] = s;
+}
+__global__ void k_subtree_pos(uint32_t lo, uint32_t hi, const BvhNode *__restrict__ nodes, const uint32_t *__restrict__ size, uint32_t *__restrict__ pos)
+{
+    const uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hi)
+        return;
+    const int4 r4 = nodes[i].refs;
+    const int refs[kNodeWidth] = { r4.x, r4.y, r4.z, r4.w };
+    uint32_t next = (i == 0 ? 0u : pos[i]) + 1u;
+    if (i == 0)
+        pos[0] = 0u;
+    for (int k = 0; k < kNodeWidth; k++)
+        if (refs[k] >= 0 && refs[k] != kEmptyRef)
+        {
+            pos[refs[k]] = next;
+            next += size[refs[k]];
+        }
+}
+__global__ void k_place_nodes(uint32_t count, const BvhNode *__restrict__ nodes, const uint32_t *__restrict__ pos, BvhNode *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count)
+        return;
+    BvhNode nd = nodes[i];
+    int refs[kNodeWidth] = { nd.refs.x, nd.refs.y, nd.refs.z, nd.refs.w };
+    for (int k = 0; k < kNodeWidth; k++)
+        if (refs[k] >= 0 && refs[k] != kEmptyRef)
+            refs[k] = (int)pos[refs[k]];
+    nd.refs = make_int4(refs[0], refs[1], refs[2], refs[3]);
+    out[pos[i]] = nd;
 }
 
 // a one-triangle scene has no internal node: give it a root with one leaf child

@@ -65,6 +65,8 @@ struct TreeParams
     float plocShape = kPlocShape;      // PLOC: weight of the compactness term in the merge metric
     bool mortonCubic = false;          // Morton curve with cubic cells (one scale for the three axes)
     uint32_t collapse = 1;             // 4-wide collapse: 0 greedy by surface area (round 1), 1 cost-driven (k_collapse_cost)
+    float splitBudget = 0.0f;          // pre-splitting: extra leaf references as a fraction of the triangle count (0: none)
+    uint32_t layout = 0;               // node order: 0 breadth-first levels, 1 depth-first (every subtree one contiguous range; measured flat)
 };
 
 // The environment switches of the library (INTEGRATION.md lists them): experiment and test knobs, read ONCE per handle when it
@@ -76,6 +78,8 @@ struct EnvSwitches
     bool plocFixed = false;      // PTX_PLOC_RADIUS / PTX_PLOC_SHAPE given: ONE tree with these parameters, no candidates
     uint32_t plocRadius = 0;     // PTX_PLOC_RADIUS
     float plocShape = 0.0f;      // PTX_PLOC_SHAPE
+    float splitBudget = -1.0f;   // PTX_SPLIT_BUDGET: extra leaf references as a fraction of the triangle count (< 0: not given)
+    int layout = -1;             // PTX_NODE_LAYOUT=0 / 1: breadth-first / depth-first node order (-1: not given)
     int collapse = -1;           // PTX_COLLAPSE=0 / 1: greedy / cost-driven 4-wide collapse (-1: not given; does not fix the other parameters)
     int shadeSort = -1;          // PTX_SHADE_SORT=0 / 1 overrides the scene's choice (-1: not given)
     long tailThreshold = -1;     // PTX_TAIL_THRESHOLD: live paths at or below which k_tail takes over (-1: the default)
@@ -98,6 +102,10 @@ struct EnvSwitches
             e.plocFixed = true;
             e.plocRadius = std::max(1u, (uint32_t)strtoul(v, nullptr, 10));
         }
+        if (const char *v = getenv("PTX_SPLIT_BUDGET"))
+            e.splitBudget = (float)atof(v);
+        if (const char *v = getenv("PTX_NODE_LAYOUT"))
+            e.layout = atoi(v) ? 1 : 0;
         if (const char *v = getenv("PTX_COLLAPSE"))
             e.collapse = atoi(v) ? 1 : 0;
         if (const char *v = getenv("PTX_SHADE_SORT"))
@@ -162,6 +170,11 @@ struct PtxRenderer
         DevBuf<float4> boxLo, boxHi, nodeLo, nodeHi;
         DevBuf<uint32_t> sceneBounds, vals0, vals1, hist, histSums, flags;
         DevBuf<uint8_t> inert; // per flattened triangle: left out of the tree (zero area) by the last full build
+        // leaf references of a build that splits triangles (k_split_*): boxes, triangle and zero-area flag per reference
+        DevBuf<float4> refLo, refHi;
+        DevBuf<uint32_t> refTri;
+        DevBuf<uint8_t> refInert;
+        uint32_t refCount = 0; // references of the last full build (= triangles unless it split some)
         uint32_t treeTris = 0; // triangles in the tree = the first treeTris entries of the sorted order
         DevBuf<uint64_t> keys0, keys1;
         DevBuf<int2> children;
@@ -176,6 +189,7 @@ struct PtxRenderer
             triTmp.release(); boxLo.release(); boxHi.release(); nodeLo.release(); nodeHi.release(); sceneBounds.release();
             vals0.release(); vals1.release(); hist.release(); histSums.release(); flags.release(); inert.release(); keys0.release(); keys1.release();
             children.release(); parentOfNode.release(); parentOfLeaf.release(); rawNodes.release(); oldOf.release(); collapseCost.release(); collapseDecide.release();
+            refLo.release(); refHi.release(); refTri.release(); refInert.release();
             valid = false;
         }
     } build;
@@ -455,6 +469,10 @@ static int createRenderer(const PtxDeviceDesc *desc, PtxRenderer **out)
     r->usePloc = !r->env.karrasBuilder;
     if (r->env.collapse >= 0)
         r->tree.collapse = (uint32_t)r->env.collapse;
+    if (r->env.layout >= 0)
+        r->tree.layout = (uint32_t)r->env.layout;
+    if (r->env.splitBudget >= 0.0f)
+        r->tree.splitBudget = r->env.splitBudget;
     if (r->env.plocFixed)
     {
         r->tree.plocShape = r->env.plocShape;
@@ -1075,15 +1093,15 @@ static SceneView makeSceneView(const PtxRenderer *r);
 static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
 {
     HIP_TRY(r, hipSetDevice(r->device));
-    const uint32_t n = r->triCount;
-    if (!refit)
+    const uint32_t nTri = r->triCount;
+    if (nTri == 0)
     {
-        HIP_TRY(r, r->nodes.alloc(n > 1 ? n - 1 : 1));
-        HIP_TRY(r, r->tris.alloc(n ? n : 1));
-        HIP_TRY(r, r->shadeTris.alloc(n ? n : 1));
-    }
-    if (n == 0)
-    {
+        if (!refit)
+        {
+            HIP_TRY(r, r->nodes.alloc(1));
+            HIP_TRY(r, r->tris.alloc(1));
+            HIP_TRY(r, r->shadeTris.alloc(1));
+        }
         r->accelReady = true;
         r->treeTris = 0;
         r->stats.bvhNodes = 0;
@@ -1092,8 +1110,6 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
         return PTX_OK;
     }
     PtxRenderer::BuildState &B = r->build;
-    const uint32_t numTiles = (n + kSortTile - 1) / kSortTile;
-    const uint32_t histCount = 256 * numTiles, histBlocks = (histCount + kScan32Block - 1) / kScan32Block;
 #define BUILD_TRY(expr)                                                                                                    \
     do                                                                                                                     \
     {                                                                                                                      \
@@ -1105,12 +1121,79 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
                         hipGetErrorString(e_));                                                                            \
         }                                                                                                                  \
     } while (0)
+    // ---- per triangle: world-space record, padded box, zero-area flag
     if (!refit)
     {
         B.valid = false;
-        BUILD_TRY(B.triTmp.alloc(n)); BUILD_TRY(B.boxLo.alloc(n)); BUILD_TRY(B.boxHi.alloc(n)); BUILD_TRY(B.nodeLo.alloc(n));
-        BUILD_TRY(B.nodeHi.alloc(n)); BUILD_TRY(B.sceneBounds.alloc(8)); BUILD_TRY(B.vals0.alloc(n)); BUILD_TRY(B.vals1.alloc(n));
-        BUILD_TRY(B.hist.alloc(histCount)); BUILD_TRY(B.histSums.alloc(histBlocks)); BUILD_TRY(B.flags.alloc(n)); BUILD_TRY(B.inert.alloc(n));
+        BUILD_TRY(B.triTmp.alloc(nTri)); BUILD_TRY(B.boxLo.alloc(nTri)); BUILD_TRY(B.boxHi.alloc(nTri)); BUILD_TRY(B.inert.alloc(nTri));
+        BUILD_TRY(B.sceneBounds.alloc(8));
+    }
+    // [0..5] centroid bounds (ordered floats), [6] references in the tree (k_count_valid), [7] a refit found a revived triangle
+    const uint32_t initBounds[8] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u };
+    BUILD_TRY(hipMemcpyAsync(B.sceneBounds.p, initBounds, sizeof(initBounds), hipMemcpyHostToDevice, r->stream));
+    BUILD_TRY(hipEventRecord(r->evA, r->stream));
+    k_tri_setup<<<(nTri + 255) / 256, 256, 0, r->stream>>>(nTri, r->pairCount, r->pairFirst.p, r->pairs.p, r->vertices.p, r->indices.p, B.triTmp.p,
+                                                          B.boxLo.p, B.boxHi.p, B.sceneBounds.p, B.inert.p, refit ? 1 : 0);
+
+    // ---- leaf references: one per triangle, or the pieces of the triangles worth splitting (static scenes, full builds: a
+    // refit keeps the references of the last full build, and a build that keeps its state for refits does not split)
+    uint32_t n = refit ? B.refCount : nTri;
+    const float4 *refLo = B.boxLo.p, *refHi = B.boxHi.p;
+    const uint8_t *refInert = B.inert.p;
+    const uint32_t *refTri = nullptr; // reference -> triangle (null: the identity)
+    if (!refit && !keepState && r->tree.splitBudget > 0.0f && nTri > 1)
+    {
+        DevBuf<float> priority;
+        DevBuf<uint32_t> count, sums;
+        DevBuf<unsigned long long> sum;
+        const uint32_t sb = (nTri + 1 + kScan32Block - 1) / kScan32Block;
+        BUILD_TRY(priority.alloc(nTri)); BUILD_TRY(count.alloc((size_t)nTri + 1)); BUILD_TRY(sums.alloc(sb)); BUILD_TRY(sum.alloc(1));
+        BUILD_TRY(hipMemsetAsync(sum.p, 0, sizeof(unsigned long long), r->stream));
+        k_split_priority<<<(nTri + 255) / 256, 256, 0, r->stream>>>(nTri, B.triTmp.p, B.boxLo.p, B.boxHi.p, B.inert.p, B.sceneBounds.p,
+                                                                   r->tree.mortonCubic ? 1 : 0, priority.p, sum.p);
+        unsigned long long total = 0;
+        BUILD_TRY(hipMemcpyAsync(&total, sum.p, sizeof(total), hipMemcpyDeviceToHost, r->stream));
+        BUILD_TRY(hipStreamSynchronize(r->stream));
+        if (total)
+        {
+            const float perPriority = (float)((double)r->tree.splitBudget * nTri / ((double)total / kSplitPriorityScale));
+            BUILD_TRY(hipMemsetAsync(count.p + nTri, 0, sizeof(uint32_t), r->stream));
+            k_split_count<<<(nTri + 255) / 256, 256, 0, r->stream>>>(nTri, priority.p, perPriority, count.p);
+            if (sb > 1)
+            {
+                k_scan32_sums<<<sb, 256, 0, r->stream>>>(nTri + 1, count.p, sums.p);
+                k_scan_exclusive<<<1, 1024, 0, r->stream>>>(sb, sums.p);
+                k_scan32_apply<<<sb, 256, 0, r->stream>>>(nTri + 1, count.p, sums.p);
+            }
+            else
+                k_scan_exclusive<<<1, 1024, 0, r->stream>>>(nTri + 1, count.p);
+            uint32_t refs = 0;
+            BUILD_TRY(hipMemcpyAsync(&refs, count.p + nTri, sizeof(refs), hipMemcpyDeviceToHost, r->stream));
+            BUILD_TRY(hipStreamSynchronize(r->stream));
+            if (refs > nTri && refs <= kMaxTriangles)
+            {
+                BUILD_TRY(B.refLo.alloc(refs)); BUILD_TRY(B.refHi.alloc(refs)); BUILD_TRY(B.refTri.alloc(refs)); BUILD_TRY(B.refInert.alloc(refs));
+                k_split_write<<<(nTri + 255) / 256, 256, 0, r->stream>>>(nTri, B.triTmp.p, B.boxLo.p, B.boxHi.p, B.inert.p, B.sceneBounds.p,
+                                                                        r->tree.mortonCubic ? 1 : 0, count.p, refs, B.refLo.p, B.refHi.p, B.refTri.p, B.refInert.p);
+                BUILD_TRY(hipStreamSynchronize(r->stream)); // (count and priority go out of scope)
+                n = refs;
+                refLo = B.refLo.p; refHi = B.refHi.p; refInert = B.refInert.p; refTri = B.refTri.p;
+            }
+        }
+    }
+    if (!refit)
+        B.refCount = n;
+
+    // ---- per reference: everything from the Morton sort on
+    const uint32_t numTiles = (n + kSortTile - 1) / kSortTile;
+    const uint32_t histCount = 256 * numTiles, histBlocks = (histCount + kScan32Block - 1) / kScan32Block;
+    if (!refit)
+    {
+        BUILD_TRY(r->nodes.alloc(n)); // (as many as the emitted array: the two change places in the depth-first relayout)
+        BUILD_TRY(r->tris.alloc(n));
+        BUILD_TRY(r->shadeTris.alloc(n));
+        BUILD_TRY(B.nodeLo.alloc(n)); BUILD_TRY(B.nodeHi.alloc(n)); BUILD_TRY(B.vals0.alloc(n)); BUILD_TRY(B.vals1.alloc(n));
+        BUILD_TRY(B.hist.alloc(histCount)); BUILD_TRY(B.histSums.alloc(histBlocks)); BUILD_TRY(B.flags.alloc(n));
         BUILD_TRY(B.keys0.alloc(n)); BUILD_TRY(B.keys1.alloc(n));
         BUILD_TRY(B.children.alloc(n)); BUILD_TRY(B.parentOfNode.alloc(n)); BUILD_TRY(B.parentOfLeaf.alloc(n));
         BUILD_TRY(B.rawNodes.alloc(n)); BUILD_TRY(B.oldOf.alloc((size_t)n + 1)); BUILD_TRY(B.collapseCost.alloc(n)); BUILD_TRY(B.collapseDecide.alloc(n));
@@ -1127,23 +1210,16 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
         BUILD_TRY(hi1.alloc(n)); BUILD_TRY(nn.alloc(n)); BUILD_TRY(flags.alloc(n)); BUILD_TRY(sums.alloc((n + kScanBlock - 1) / kScanBlock));
         BUILD_TRY(total.alloc(1));
     }
-
-    // [0..5] centroid bounds (ordered floats), [6] triangles in the tree (k_count_valid), [7] a refit found a revived triangle
-    const uint32_t initBounds[8] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u };
-    BUILD_TRY(hipMemcpyAsync(B.sceneBounds.p, initBounds, sizeof(initBounds), hipMemcpyHostToDevice, r->stream));
     BUILD_TRY(hipMemsetAsync(B.flags.p, 0, (size_t)n * 4, r->stream));
-    BUILD_TRY(hipEventRecord(r->evA, r->stream));
 
     const uint32_t blocks = (n + 255) / 256;
-    k_tri_setup<<<blocks, 256, 0, r->stream>>>(n, r->pairCount, r->pairFirst.p, r->pairs.p, r->vertices.p, r->indices.p, B.triTmp.p,
-                                               B.boxLo.p, B.boxHi.p, B.sceneBounds.p, B.inert.p, refit ? 1 : 0);
     // 8 radix passes ping-pong the buffers an even number of times: the sorted order ends in keys0 / vals0
     uint64_t *kin = B.keys0.p, *kout = B.keys1.p;
     uint32_t *vin = B.vals0.p, *vout = B.vals1.p;
     uint32_t nv = B.treeTris; // triangles in the tree: all but the zero-area ones, which sort to the end
     if (!refit)
     {
-        k_morton<<<blocks, 256, 0, r->stream>>>(n, B.boxLo.p, B.boxHi.p, B.sceneBounds.p, B.inert.p, B.keys0.p, B.vals0.p, r->tree.mortonCubic ? 1 : 0);
+        k_morton<<<blocks, 256, 0, r->stream>>>(n, refLo, refHi, B.sceneBounds.p, refInert, B.keys0.p, B.vals0.p, r->tree.mortonCubic ? 1 : 0);
         for (uint32_t shift = 0; shift < 64; shift += 8) // 63-bit keys + the all-ones sentinel of inert triangles: 8 passes
         {
             k_sort_hist<<<numTiles, 64, 0, r->stream>>>(n, kin, shift, numTiles, B.hist.p);
@@ -1166,10 +1242,11 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
     }
     r->treeTris = nv;
     r->stats.bvhNodes = nv > 1 ? nv - 1 : (nv ? 1 : 0);
-    r->stats.treeTriangles = r->stats.treeReferences = nv;
+    r->stats.treeReferences = nv;
+    r->stats.treeTriangles = nTri - (n - nv); // a zero-area triangle has exactly one reference, and they are the ones left out
     const uint32_t vblocks = (nv + 255) / 256;
     if (nv == 1)
-        k_single_leaf_root<<<1, 1, 0, r->stream>>>(vin, B.boxLo.p, B.boxHi.p, B.triTmp.p, r->nodes.p, r->tris.p, r->pairs.p, r->vertices.p,
+        k_single_leaf_root<<<1, 1, 0, r->stream>>>(vin, refLo, refHi, B.triTmp.p, r->nodes.p, r->tris.p, r->pairs.p, r->vertices.p,
                                                    r->indices.p, r->shadeTris.p);
     else if (nv > 1)
     {
@@ -1177,7 +1254,7 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
         if (!refit && r->usePloc)
         {
             // PLOC over the sorted leaves (temporaries allocated above, outside the timed span)
-            k_ploc_init<<<vblocks, 256, 0, r->stream>>>(nv, vin, B.boxLo.p, B.boxHi.p, cl0.p, lo0.p, hi0.p);
+            k_ploc_init<<<vblocks, 256, 0, r->stream>>>(nv, vin, refLo, refHi, cl0.p, lo0.p, hi0.p);
             int *cIn = cl0.p, *cOut = cl1.p;
             float4 *lIn = lo0.p, *hIn = hi0.p, *lOut = lo1.p, *hOut = hi1.p;
             uint32_t count = nv;
@@ -1216,25 +1293,27 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
         else if (!refit)
             k_karras<<<vblocks, 256, 0, r->stream>>>((int)nv, kin, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p);
         if (!boxesDone)
-            k_refit<<<vblocks, 256, 0, r->stream>>>((int)nv, vin, B.boxLo.p, B.boxHi.p, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p,
+            k_refit<<<vblocks, 256, 0, r->stream>>>((int)nv, vin, refLo, refHi, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p,
                                                B.nodeLo.p, B.nodeHi.p, B.flags.p);
         if (r->tree.collapse)
         {
             BUILD_TRY(hipMemsetAsync(B.flags.p, 0, (size_t)nv * 4, r->stream)); // (the arrival flags of k_refit: done with)
-            k_collapse_cost<<<vblocks, 256, 0, r->stream>>>((int)nv, vin, B.boxLo.p, B.boxHi.p, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p, B.nodeLo.p, B.nodeHi.p, B.flags.p,
+            k_collapse_cost<<<vblocks, 256, 0, r->stream>>>((int)nv, vin, refLo, refHi, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p, B.nodeLo.p, B.nodeHi.p, B.flags.p,
                                                        B.collapseCost.p, B.collapseDecide.p);
         }
-        k_emit<<<vblocks, 256, 0, r->stream>>>((int)nv, vin, B.boxLo.p, B.boxHi.p, B.children.p, B.nodeLo.p, B.nodeHi.p, B.triTmp.p,
+        k_emit<<<vblocks, 256, 0, r->stream>>>((int)nv, vin, refLo, refHi, B.children.p, B.nodeLo.p, B.nodeHi.p, B.triTmp.p,
                                               B.rawNodes.p, r->tris.p, r->pairs.p, r->vertices.p, r->indices.p, r->shadeTris.p,
-                                              r->tree.collapse ? B.collapseDecide.p : nullptr);
+                                              r->tree.collapse ? B.collapseDecide.p : nullptr, refTri);
         // breadth-first relayout into the compact array (k_relayout_level): the host reads the level's end after each launch
         uint32_t *nextFree = B.oldOf.p + n;
         const uint32_t first[1] = { 0u }, one = 1u;
         BUILD_TRY(hipMemcpyAsync(B.oldOf.p, first, sizeof(first), hipMemcpyHostToDevice, r->stream)); // the root stays node 0
         BUILD_TRY(hipMemcpyAsync(nextFree, &one, sizeof(one), hipMemcpyHostToDevice, r->stream));
         uint32_t lo = 0, hi = 1, levels = 0;
+        std::vector<uint32_t> levelStart; // of the breadth-first array, plus its end
         while (lo < hi)
         {
+            levelStart.push_back(lo);
             k_relayout_level<<<(hi - lo + 255) / 256, 256, 0, r->stream>>>(lo, hi, B.rawNodes.p, B.oldOf.p, nextFree, r->nodes.p);
             uint32_t end = 0;
             BUILD_TRY(hipMemcpyAsync(&end, nextFree, sizeof(end), hipMemcpyDeviceToHost, r->stream));
@@ -1249,6 +1328,18 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
             levels++;
         }
         r->stats.bvhNodes = hi;
+        if (r->tree.layout == 1 && hi > 1)
+        {
+            // depth-first order (k_subtree_size / _pos / k_place_nodes); scratch: the build's flag and neighbour arrays are done with
+            levelStart.push_back(hi);
+            uint32_t *size = B.flags.p, *pos = B.vals1.p == vin ? B.vals0.p : B.vals1.p; // (the sorted order sits in the other one)
+            for (uint32_t l = levels; l-- > 0;)
+                k_subtree_size<<<(levelStart[l + 1] - levelStart[l] + 255) / 256, 256, 0, r->stream>>>(levelStart[l], levelStart[l + 1], r->nodes.p, size);
+            for (uint32_t l = 0; l < levels; l++)
+                k_subtree_pos<<<(levelStart[l + 1] - levelStart[l] + 255) / 256, 256, 0, r->stream>>>(levelStart[l], levelStart[l + 1], r->nodes.p, size, pos);
+            k_place_nodes<<<(hi + 255) / 256, 256, 0, r->stream>>>(hi, r->nodes.p, pos, B.rawNodes.p);
+            r->nodes.swap(B.rawNodes); // the emitted nodes are not needed again before the next k_emit, which rewrites them all
+        }
         if (r->env.verbose)
             std::fprintf(stderr, "[ptx] relayout: %u of %u emitted nodes are live, %u levels\n", hi, nv - 1, levels);
     }
@@ -1285,7 +1376,7 @@ static TraceScene makeTraceScene(const PtxRenderer *r);
 // its longest walks by a third is not cheaper.
 struct TreeCost
 {
-    double mean = 0.0;   // visits + tests per ray
+    double mean = 0.0;   // visits + tests per ray, without the top 0.1 % of the rays (robust against the odd ray that skims a surface)
     uint32_t p999 = 0;   // 99.9th percentile
     uint32_t worst = 0;
     double figure() const { return mean + kTreeTailWeight * (double)p999; }
@@ -1309,12 +1400,13 @@ static int sampleTreeCost(PtxRenderer *r, DevBuf<float4> &segments, bool drawSeg
     HIP_TRY(r, hipMemcpyAsync(h.data(), d.p, kTreeSampleRays * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(r, hipStreamSynchronize(r->stream));
     HIP_TRY(r, hipGetLastError());
-    unsigned long long sum = 0;
-    for (uint32_t v : h)
-        sum += v;
     std::sort(h.begin(), h.end());
-    cost->mean = (double)sum / kTreeSampleRays;
-    cost->p999 = h[kTreeSampleRays - 1 - kTreeSampleRays / 1000];
+    const uint32_t kept = kTreeSampleRays - kTreeSampleRays / 1000;
+    unsigned long long sum = 0;
+    for (uint32_t k = 0; k < kept; k++)
+        sum += h[k];
+    cost->mean = (double)sum / kept;
+    cost->p999 = h[kept - 1];
     cost->worst = h.back();
     return PTX_OK;
 }
@@ -1387,7 +1479,7 @@ static int buildBestTree(PtxRenderer *r)
     r->accelReady = true;
     if (r->env.verbose)
     {
-        std::fprintf(stderr, "[ptx] tree cost on %u sampled segments, mean / p99.9 / max visits + tests per ray:", kTreeSampleRays);
+        std::fprintf(stderr, "[ptx] tree cost on %u sampled rays, mean (lowest 99.9 %%) / p99.9 / max visits + tests per ray:", kTreeSampleRays);
         for (uint32_t k = 0; k < built; k++)
             std::fprintf(stderr, " (radius %u, shape %.2f%s) %.2f / %u / %u%s", kTreeCandidates[k].radius, kTreeCandidates[k].shape,
                          kTreeCandidates[k].cubic ? ", cubic cells" : "", cost[k].mean, cost[k].p999, cost[k].worst, k == best ? " <- kept" : "");

@@ -1321,35 +1321,51 @@ __global__ void k_unpack_shard(LaunchParams p, const float4 *__restrict__ src, f
     }
 }
 
-// What a tree costs the rays of a path tracer: node visits + triangle tests of closest-hit queries along `n` segments between
-// the centroids of pseudo-random pairs of triangles -- from surface to surface, like the segments of a path.  ptx_build_accel
-// builds a few candidate trees and keeps the cheapest: "lower surface-area cost" does not always mean "fewer visits"
-// (street_like: a wider PLOC search gives 13 % MORE visits per ray), and results never depend on the tree.
-//   k_sample_segments   the segments, drawn ONCE per build from the first candidate's triangle array and kept: every candidate
-//                       is priced on the same rays (leaf order differs from tree to tree, so indices into it would name other
-//                       triangles -- sampling noise that could decide between candidates a per cent apart)
-//   k_sample_tree_cost  per segment visits + tests, one number per ray: the host adds them up and takes the tail (p99.9)
+// What a tree costs the rays of a path tracer: node visits + triangle tests of closest-hit queries along `n` sampled rays.
+// ptx_build_accel builds a few candidate trees and keeps the cheapest: "lower surface-area cost" does not always mean "fewer
+// visits" (street_like: a wider PLOC search gives 13 % MORE visits per ray), and results never depend on the tree.
+//   k_sample_segments   the rays, drawn ONCE per build from the first candidate's triangle array and kept: every candidate is
+//                       priced on the same rays (leaf order differs from tree to tree, so indices into it would name other
+//                       triangles -- sampling noise that could decide between candidates a per cent apart).  A ray leaves the
+//                       centroid of a pseudo-random triangle in a cosine-distributed direction about its normal (either side) and
+//                       runs until it lands -- a diffuse bounce, what most rays of a path are.  (Rounds 2-3 sampled the segment
+//                       between the centroids of two random triangles: two triangles of one floor or wall give a ray IN that
+//                       surface, which crosses every leaf box along it -- up to 265,000 visits for one street_like segment, 7 % of
+//                       the sum over all 65,536 -- and no path ray does that; the candidates were being told apart by a dozen
+//                       such outliers.)
+//   k_sample_tree_cost  per ray visits + tests, one number per ray: the host takes the mean without the top 0.1 % and the tail
 __global__ void k_sample_segments(TraceScene sc, uint32_t n, float4 *__restrict__ rays)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
         return;
-    float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d = o; // d.w = 0: no segment
+    float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d = o; // d.w = 0: no ray
     if (sc.triCount > 1u)
     {
-        const uint32_t a = jenkinsHash(2u * i + 1u) % sc.triCount, b = jenkinsHash(jenkinsHash(2u * i + 2u)) % sc.triCount;
-        const Tri ta = sc.tris[a], tb = sc.tris[b];
+        uint32_t h = jenkinsHash(2u * i + 1u);
+        const Tri t = sc.tris[h % sc.triCount];
+        const f3 e1 = F3(t.a.w, t.b.x, t.b.y), e2 = F3(t.b.z, t.b.w, t.c.x);
         const float third = 1.0f / 3.0f;
-        const f3 ca = F3(ta.a.x + (ta.a.w + ta.b.z) * third, ta.a.y + (ta.b.x + ta.b.w) * third, ta.a.z + (ta.b.y + ta.c.x) * third);
-        const f3 cb = F3(tb.a.x + (tb.a.w + tb.b.z) * third, tb.a.y + (tb.b.x + tb.b.w) * third, tb.a.z + (tb.b.y + tb.c.x) * third);
-        const f3 dir = cb - ca;
-        const float len = __builtin_sqrtf(dot(dir, dir));
+        const f3 c = F3(t.a.x + (e1.x + e2.x) * third, t.a.y + (e1.y + e2.y) * third, t.a.z + (e1.z + e2.z) * third);
+        f3 nrm = cross(e1, e2);
+        const float len = __builtin_sqrtf(dot(nrm, nrm));
         if (len > 0.0f)
         {
-            // the segment between the two surfaces, not the line through them: a path segment ends where it lands, and a line
-            // that runs on inside a slab of alpha-tested cards costs a thousand visits that no path ray pays
-            o = make_float4(ca.x, ca.y, ca.z, 1e-4f * len);
-            d = make_float4(dir.x * (1.0f / len), dir.y * (1.0f / len), dir.z * (1.0f / len), 1.001f * len);
+            h = jenkinsHash(h);
+            nrm = nrm * (((h & 1u) ? 1.0f : -1.0f) / len);
+            const mat3 frame = computeTangentSpace(nrm);
+            const f3 tx = frame.c0, ty = frame.c1;
+            h = jenkinsHash(h);
+            const float u1 = (float)(h >> 8) * (1.0f / 16777216.0f);
+            h = jenkinsHash(h);
+            const float u2 = (float)(h >> 8) * (1.0f / 16777216.0f);
+            const float rr = __builtin_sqrtf(u1), phi = 6.2831853f * u2;
+            const float lx = rr * __builtin_cosf(phi), ly = rr * __builtin_sinf(phi), lz = __builtin_sqrtf(fmaxf(0.0f, 1.0f - u1));
+            f3 dir = tx * lx + ty * ly + nrm * lz;
+            dir = dir * (1.0f / __builtin_sqrtf(dot(dir, dir)));
+            const float size = __builtin_sqrtf(len); // ~ the triangle's edge length
+            o = make_float4(c.x + nrm.x * 1e-3f * size, c.y + nrm.y * 1e-3f * size, c.z + nrm.z * 1e-3f * size, 1e-5f);
+            d = make_float4(dir.x, dir.y, dir.z, 1e4f);
         }
     }
     rays[2 * i] = o;

@@ -140,3 +140,35 @@ def test_bench_two_ranks_gather_the_single_rank_frame(pkg, tmp_path, backend):
     ref = r.readback()
     r.close()
     assert (got.view(np.uint32) == ref.view(np.uint32)).all()
+
+
+@pytest.mark.gpu
+def test_rccl_gather_branch_runs_with_one_rank(pkg, tmp_path):
+    """The RCCL branch of bench.py's step() on real hardware: a one-rank `nccl` process group (RCCL refuses two ranks on one
+    device, and the GPU box has one), ptx_pack_shard -> all_gather_into_tensor on the renderer's torch stream ->
+    ptx_unpack_shard -> pipelined read-back, frames in flight.  The gathered frame must be the plain frame bit for bit."""
+    import json
+    import subprocess
+
+    out = tmp_path / "gathered_rccl1.npy"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()))
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--force-gather", "--dist-backend", "nccl", "--steps", "3", "--warmup", "1",
+           "--repeats", "1", "--scene", "chess_like", "--detail", "0.05", "--width", "328", "--height", "200", "--spp", "4", "--depth", "6",
+           "--in-flight", "3", "--dump-image", str(out)]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    start = p.stdout.rfind('{"metric"')  # (RCCL's own warnings go to stdout too, not always newline-terminated)
+    assert start >= 0, p.stdout[-2000:] + p.stderr[-2000:]
+    line = json.loads(p.stdout[start:].splitlines()[0])
+    assert line["n_gpus"] == 1 and "all_gather" in line["config"]["parallelism"] and line["value"] > 0
+    got = np.load(out)
+    W, H = 328, 200
+    scene = pkg.Scene("chess_like", 0.05)
+    r = pkg.Renderer()
+    r.upload(scene)
+    r.resize(W, H)
+    r.render_frames(scene.uniform(W, H, bounces=6), scene.lights, 0, 4)
+    ref = r.readback()
+    r.close()
+    assert (got.view(np.uint32) == ref.view(np.uint32)).all()

@@ -637,3 +637,33 @@ def test_tree_choice_does_not_change_images(pkg, monkeypatch):
         images.append(r.readback())
         r.close()
     assert (images[0].view(np.uint32) == images[1].view(np.uint32)).all() and (images[0].view(np.uint32) == images[2].view(np.uint32)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene_name,detail", [("temple_like", 0.15), ("alpha_test", 1.0), ("chess_like", 0.05)])
+def test_presplit_triangles_change_nothing(pkg, orc, monkeypatch, scene_name, detail):
+    """Triangle pre-splitting (PTX_SPLIT_BUDGET, TreeParams::splitBudget; off by default): a large triangle hangs from several
+    leaves, each with the tight box of its piece.  A closest-hit walk that meets it twice finds the same (t, u, v, id) twice, an
+    occlusion walk ends at the first, the any-hit stage's nearest ignored candidate is idempotent -- so closest hits equal
+    brute force bit for bit (ids, t, u, v), images and counters equal the oracle's, and only the leaf count differs."""
+    import torch  # noqa: F401
+
+    monkeypatch.setenv("PTX_SPLIT_BUDGET", "0.5")
+    scene = pkg.Scene(scene_name, detail)
+    r = pkg.Renderer()
+    r.upload(scene)
+    st = r.stats()
+    assert st.treeReferences > st.treeTriangles, "the budget must have produced extra leaf references"
+    rng = np.random.default_rng(11)
+    a = util.desc_arrays(scene.desc)
+    lo, hi = a["vertices"][:, :3].min(axis=0) - 1.0, a["vertices"][:, :3].max(axis=0) + 1.0
+    rays = util.random_rays(rng, 20000, lo, hi)
+    hits, ids = r.trace_rays(rays)
+    want = orc.OracleScene(scene.desc, build_bvh=False).trace_closest(rays, brute_force=True)
+    first = util.pair_first(scene.desc)
+    miss = ids[:, 0] == 0xFFFFFFFF
+    gid = np.where(miss, 0xFFFFFFFF, first[np.minimum(ids[:, 0], len(first) - 2)] + ids[:, 1]).astype(np.uint32)
+    assert (gid == want["tri"]).all() and (hits[:, 0].view(np.uint32) == want["t"].view(np.uint32)).all()
+    r.close()
+    img, ref = util.render_pair(pkg, orc, scene_name, detail, 160, 96, frames=2, depth=6)
+    assert (img.view(np.uint32) == ref.view(np.uint32)).all()

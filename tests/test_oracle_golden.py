@@ -1,5 +1,7 @@
 """The oracle against the golden vectors generated from the REFERENCE's own GLSL
 (tools/gen_golden.py; inputs include the grids of Path-Tracing-Tests/TestData.h)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -346,3 +348,28 @@ def test_analytic_checks(orc, pkg):
     t = orc.test_eval(pkg.FN["computeTangentSpace"], nrm, 9).view(np.float32).reshape(-1, 3, 3)
     gram = np.einsum("nij,nkj->nik", t, t)
     assert np.abs(gram - np.eye(3)).max() < 1e-5
+
+
+def test_golden_fixtures_regenerate_byte_for_byte_from_the_reference(tmp_path):
+    """The committed fixtures ARE what tools/gen_golden.py makes of the reference's shader text today: wherever /root/reference
+    exists (this container; not the GPU box) the generator runs into a scratch directory and every archive must come out
+    byte-identical to tests/golden/.  A fixture edited by hand, a generator that drifted from the committed vectors, or a
+    reference that changed under them fails here."""
+    import gzip
+    import subprocess
+    import sys
+
+    ref = "/root/reference/Path-Tracing/Shaders"
+    if not os.path.isdir(ref):
+        pytest.skip("the reference tree is not present (GPU box)")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(repo, "tools", "gen_golden.py"), "--out", str(tmp_path)], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    made = sorted(f for f in os.listdir(tmp_path) if f.endswith(".json") or f.endswith(".json.gz"))
+    committed = sorted(f for f in os.listdir(util.GOLDEN_DIR) if f.endswith(".json.gz"))
+    assert committed and [m if m.endswith(".gz") else m + ".gz" for m in made] == committed, (made, committed)
+    for m in made:
+        new = open(os.path.join(tmp_path, m), "rb").read()
+        new = gzip.decompress(new) if m.endswith(".gz") else new
+        old = gzip.decompress(open(os.path.join(util.GOLDEN_DIR, m if m.endswith(".gz") else m + ".gz"), "rb").read())
+        assert new == old, f"{m}: regenerated vectors differ from the committed fixture"

@@ -29,6 +29,8 @@ import tempfile
 REF = "/root/reference/Path-Tracing/Shaders"
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "..", "tests", "golden")
+if "--out" in sys.argv:  # tests/test_oracle_golden.py regenerates into a scratch directory and compares with the committed archives
+    OUT = sys.argv[sys.argv.index("--out") + 1]
 
 # (file, [(first_line, last_line), ...])  1-based inclusive
 SOURCES = [
