@@ -225,6 +225,22 @@ struct Stack
             return spill[(size_t)(sp - ldsDepth) * spillStride];
         return 0xffffffffu; // overflow: a harmless leaf (the launch reports the overflow)
     }
+    // The same for a wave none of whose lanes leaves the LDS part in this step (the caller has asked: roomFor / allInLds, one
+    // ballot and a scalar branch).  The traversal kernels are bound by instruction issue (round 4: SQ_ACTIVE_INST_ANY = 78 % of a
+    // SIMD's cycles in k_trace_closest at 4.4 cycles per instruction), and the two-level test of push() / pop() -- LDS, overflow
+    // region, overflow flag -- cost 18 instructions per push site, six sites per round: a tenth of the loop.
+    PT_DEV void pushLds(uint32_t v)
+    {
+        lds[sp * stride] = v;
+        sp++;
+    }
+    PT_DEV uint32_t popLds()
+    {
+        sp--;
+        return lds[sp * stride];
+    }
+    PT_DEV bool roomFor(int entries) const { return __ballot(sp + entries > ldsDepth) == 0ull; } // of the lanes active here
+    PT_DEV bool allInLds() const { return __ballot(sp > ldsDepth) == 0ull; }
 };
 
 #define PT_DECLARE_STACK(st, DEPTH, spillPtr)                                                                              \
@@ -338,14 +354,14 @@ PT_DEV int visitNode(const BvhNode *__restrict__ np, f3 o, f3 id, float tmin, fl
 }
 
 // The walk of an occlusion query from a node: enter the hit child in the highest slot, keep the others on the stack.
-#define PT_ENTER_UNORDERED(mask, r0, r1, r2, r3, st, ref, none)                                                            \
+#define PT_ENTER_UNORDERED(mask, r0, r1, r2, r3, st, ref, none, PUSH)                                                            \
     {                                                                                                                      \
         int next_ = (none);                                                                                                \
         bool have_ = false;                                                                                                \
         if ((mask) & 1) { next_ = r0; have_ = true; }                                                                      \
-        if ((mask) & 2) { if (have_) st.push((uint32_t)next_); next_ = r1; have_ = true; }                                 \
-        if ((mask) & 4) { if (have_) st.push((uint32_t)next_); next_ = r2; have_ = true; }                                 \
-        if ((mask) & 8) { if (have_) st.push((uint32_t)next_); next_ = r3; have_ = true; }                                 \
+        if ((mask) & 2) { if (have_) st.PUSH((uint32_t)next_); next_ = r1; have_ = true; }                                 \
+        if ((mask) & 4) { if (have_) st.PUSH((uint32_t)next_); next_ = r2; have_ = true; }                                 \
+        if ((mask) & 8) { if (have_) st.PUSH((uint32_t)next_); next_ = r3; have_ = true; }                                 \
         ref = next_;                                                                                                       \
     }
 
@@ -400,7 +416,7 @@ PT_DEV bool traceRay(const TraceScene &sc, f3 o, f3 d, float tmin, float tmax, S
             const int h = visitNode<!ANY_HIT>(&sc.nodes[ref], o, id, tmin, ANY_HIT ? best.t : best.t * kCullSlack, r0, r1, r2, r3);
             if (ANY_HIT)
             {
-                PT_ENTER_UNORDERED(h, r0, r1, r2, r3, st, ref, kRefNone)
+                PT_ENTER_UNORDERED(h, r0, r1, r2, r3, st, ref, kRefNone, push)
             }
             else
             {
@@ -584,19 +600,38 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
             {
                 int r0, r1, r2, r3;
                 const int h = visitNode<!ANY_HIT>(&sc.nodes[ref], o, id, PT_TMIN, ANY_HIT ? PT_TMAX : best.t * kCullSlack, r0, r1, r2, r3);
-                if (ANY_HIT)
+                if (__builtin_expect(st.roomFor(kNodeWidth - 1), 1)) // every lane of this step stays in the LDS part of its stack
                 {
-                    PT_ENTER_UNORDERED(h, r0, r1, r2, r3, st, ref, kRefNone)
+                    if (ANY_HIT)
+                    {
+                        PT_ENTER_UNORDERED(h, r0, r1, r2, r3, st, ref, kRefNone, pushLds)
+                    }
+                    else
+                    {
+                        if (h > 3) st.pushLds((uint32_t)r3);
+                        if (h > 2) st.pushLds((uint32_t)r2);
+                        if (h > 1) st.pushLds((uint32_t)r1);
+                        ref = h > 0 ? r0 : kRefNone;
+                    }
+                    if (ref == kRefNone)
+                        ref = st.sp ? (int)st.popLds() : kRefDone;
                 }
                 else
                 {
-                    if (h > 3) st.push((uint32_t)r3);
-                    if (h > 2) st.push((uint32_t)r2);
-                    if (h > 1) st.push((uint32_t)r1);
-                    ref = h > 0 ? r0 : kRefNone;
+                    if (ANY_HIT)
+                    {
+                        PT_ENTER_UNORDERED(h, r0, r1, r2, r3, st, ref, kRefNone, push)
+                    }
+                    else
+                    {
+                        if (h > 3) st.push((uint32_t)r3);
+                        if (h > 2) st.push((uint32_t)r2);
+                        if (h > 1) st.push((uint32_t)r1);
+                        ref = h > 0 ? r0 : kRefNone;
+                    }
+                    if (ref == kRefNone)
+                        ref = st.sp ? (int)st.pop() : kRefDone;
                 }
-                if (ref == kRefNone)
-                    ref = st.sp ? (int)st.pop() : kRefDone;
             }
         }
 
@@ -616,7 +651,10 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
                 ab = sc.alphaTris[leafSlot].b;
             }
             float t, u, v;
-            ref = st.sp ? (int)st.pop() : kRefDone;
+            if (__builtin_expect(st.allInLds(), 1))
+                ref = st.sp ? (int)st.popLds() : kRefDone;
+            else
+                ref = st.sp ? (int)st.pop() : kRefDone;
             bool candidate = intersectTri(F3(ta.x, ta.y, ta.z), F3(ta.w, tb.x, tb.y), F3(tb.z, tb.w, tc.x), o, d, PT_TMIN, PT_TMAX, t, u, v);
             uint32_t pair = __float_as_uint(tc.y), prim = __float_as_uint(tc.z);
             if (ALPHA && candidate && nonOpaque)
