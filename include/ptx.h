@@ -306,7 +306,12 @@ typedef struct PtxSceneDesc {
     /* Config MaxTextureMemoryBudgetAbsolute / ...VramPercent (Config.h:63-64,162-163; TextureUploader.cpp:29-37): bytes the scene
      * textures may take together.  Each gets budget / textureCount; a larger one is scaled down by an integer factor on upload
      * (TextureUploader.cpp:409-415,479-501).  0 = the reference's default, min(80 % of the device memory, 1 GiB);
-     * ~0 = no limit.  Ignored with forceFullTextureSize. */
+     * ~0 = no limit.  Ignored with forceFullTextureSize.
+     * The budget prices the texels in the IMAGE format, as the reference does (4 B per texel for the 8-bit formats); what this
+     * library keeps resident is every level decoded to four floats (16 B per texel) plus, for the colour textures of non-opaque
+     * geometry, one more float4 per base-level texel (the alpha footprints of the any-hit stages): about 4x the budgeted bytes
+     * for 8-bit textures, and about 5x at the peak of the upload, while the encoded pools and the decoded pool coexist.  A host
+     * that passes its whole VRAM share here leaves too little for that; the default (at most 1 GiB) does not come near it. */
     uint64_t textureMemoryBudget;
 } PtxSceneDesc;
 

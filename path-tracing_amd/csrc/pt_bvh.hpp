@@ -489,7 +489,9 @@ PT_DEV bool traceRay(const TraceScene &sc, f3 o, f3 d, float tmin, float tmax, S
 // queries void improve(item, t, u, v, triSlot) (a nearer hit was found: the IO keeps where) and uint32_t bestSlot(item)
 // (its triangle), and void store(item, hit, hitAny, anyHitQuery) when the ray is done (hit.t and hit.pair; u, v, slot are the IO's).
 constexpr uint32_t kTraceChunk = 128;   // measured: 64 -> 1327, 128 -> 1347, 256 -> 1310 Msamples/s
-constexpr int kNodeStepsPerRound = 2;   // measured: 1 -> 1040, 2 -> 1064, 3 -> 1055, 4 -> 1034, 6 -> 975, 10 -> 872 Msamples/s
+constexpr int kNodeStepsPerRound = 2;   // measured: 1 -> 1040, 2 -> 1064, 3 -> 1055, 4 -> 1034, 6 -> 975, 10 -> 872 Msamples/s; round 4, for the
+                                        // (now unordered) occlusion walk alone, 1 / 2 / 3: chess_like 2,529 / 2,563 / 2,543, street_like 1,257 / 1,305 / 1,310,
+                                        // atrium_like 892 / 896 / 892; refill threshold 8 / 16 / 24 again: 2,510 / 2,563 / 2,554, 1,275 / 1,305 / 1,291
 
 
 // IO::kFixedTmin >= 0: every ray of the queue has this tmin (the wavefront queues: 1e-5) -> a literal, not a register

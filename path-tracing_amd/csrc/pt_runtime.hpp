@@ -2031,7 +2031,9 @@ static int readbackBegin(PtxRenderer *r, float *pinnedHost, size_t bytes)
     if (!r->evSnapshot)
     {
         HIP_TRY(r, hipEventCreateWithFlags(&r->evSnapshot, hipEventDisableTiming));
-        HIP_TRY(r, hipEventCreateWithFlags(&r->evCopied, hipEventDisableTiming));
+        // The copy may be a kernel storing to host memory (k_copy_out): the event the host waits on must release those stores to
+        // the system scope, also for page-locked memory that is not host-coherent.
+        HIP_TRY(r, hipEventCreateWithFlags(&r->evCopied, hipEventDisableTiming | hipEventReleaseToSystem));
     }
     // The copy to the host rides on the renderer's auxiliary stream -- idle once the frame's shadow and tail kernels are done,
     // and not needed again before this renderer's next frame -- instead of a third stream per frame in flight: the streams of a
