@@ -226,9 +226,9 @@ struct Stack
         return 0xffffffffu; // overflow: a harmless leaf (the launch reports the overflow)
     }
     // The same for a wave none of whose lanes leaves the LDS part in this step (the caller has asked: roomFor / allInLds, one
-    // ballot and a scalar branch).  The traversal kernels are bound by instruction issue (round 4: SQ_ACTIVE_INST_ANY = 78 % of a
-    // SIMD's cycles in k_trace_closest at 4.4 cycles per instruction), and the two-level test of push() / pop() -- LDS, overflow
-    // region, overflow flag -- cost 18 instructions per push site, six sites per round: a tenth of the loop.
+    // ballot and a scalar branch).  Instructions on a visit's dependent chain are what the traversal kernels pay for (round 4,
+    // docs/EXPERIMENTS.md), and the two-level test of push() / pop() -- LDS, overflow region, overflow flag -- cost 18
+    // instructions per push site, six sites per round: a tenth of the loop.
     PT_DEV void pushLds(uint32_t v)
     {
         lds[sp * stride] = v;

@@ -1439,7 +1439,8 @@ static int buildBestTree(PtxRenderer *r)
     DevBuf<float4> segments;
     auto swapTree = [&]() { r->nodes.swap(bestNodes); r->tris.swap(bestTris); r->shadeTris.swap(bestShadeTris); r->alphaTris.swap(bestAlphaTris); };
     TreeCost cost[kCandidates];
-    uint64_t bestNodeCount = 0;
+    uint64_t bestNodeCount = 0, bestReferences = 0;
+    uint32_t bestTreeTris = 0; // (leaf slots: with pre-splitting the candidates can differ -- cubic cells move the cut planes)
     double totalMs = 0.0;
     uint32_t best = 0, built = 0;
     const TreeParams given = r->tree; // what the candidates do not vary (the collapse)
@@ -1470,11 +1471,15 @@ static int buildBestTree(PtxRenderer *r)
         {
             best = k;
             bestNodeCount = r->stats.bvhNodes;
+            bestReferences = r->stats.treeReferences;
+            bestTreeTris = r->treeTris;
             swapTree(); // the renderer's buffers now hold the previous best (or nothing): the next candidate is built over them
         }
     }
     swapTree();
     r->stats.bvhNodes = bestNodeCount;
+    r->stats.treeReferences = bestReferences;
+    r->treeTris = bestTreeTris;
     r->tree = given;
     r->tree.plocRadius = kTreeCandidates[best].radius;
     r->tree.plocShape = kTreeCandidates[best].shape;
