@@ -900,6 +900,278 @@ __global__ void k_refit(int n, const uint32_t *__restrict__ vals, const float4 *
     }
 }
 
+// ---- reinsertion (round 4): the binary tree re-optimised before it is collapsed -----------------------------------
+// PLOC decides every merge once, among neighbours in the Morton order; what it got wrong stays.  Parallel reinsertion (Meister
+// and Bittner 2018) revisits it: every node x (a subtree or a leaf) looks for the place in the tree where it would cost least --
+// removing x deletes its parent p (x's sibling s takes p's place) and shrinks the ancestors that held x only through p;
+// inserting x beside a node t adds one node over (x, t) and grows t's ancestors below the common ancestor:
+//   gain(t) = area(p) + sum over the ancestors a below the common one of (area(a) - area(a without x))
+//             - area(x u t) - sum over t's ancestors u below the common one of (area(u u x) - area(u))
+// The search walks up from p, level by level, and down the sibling subtree of each level with a stack, pruned by the best gain
+// so far (the terms still to come are all losses).  Moves that gain are applied in parallel where they do not cross: a move
+// claims every node on the path x .. common ancestor .. t with a 64-bit atomic max of (gain, x), and is applied only if it holds
+// them all -- two moves that could knot the tree (each one's target inside the other's subtree) share a node of their paths.
+// Then the boxes are recomputed bottom-up (k_refit) and the pass repeats.  Node ids, the root (node 0) and the arrays the
+// collapse reads (children / parentOfNode / parentOfLeaf, leaf ref = ~sorted position) stay as PLOC made them.
+struct ReinsertTree
+{
+    int n; // leaves
+    int2 *children;
+    int *parentOfNode, *parentOfLeaf;
+    const float4 *nodeLo, *nodeHi;
+    const uint32_t *vals;
+    const float4 *leafLo, *leafHi;
+};
+PT_DEV int rtParent(const ReinsertTree &t, int ref) { return ref >= 0 ? t.parentOfNode[ref] : t.parentOfLeaf[~ref]; }
+PT_DEV void rtSetParent(const ReinsertTree &t, int ref, int parent)
+{
+    if (ref >= 0)
+        t.parentOfNode[ref] = parent;
+    else
+        t.parentOfLeaf[~ref] = parent;
+}
+PT_DEV void rtBox(const ReinsertTree &t, int ref, float *lo, float *hi)
+{
+    float4 l, h;
+    if (ref >= 0) { l = t.nodeLo[ref]; h = t.nodeHi[ref]; }
+    else { const uint32_t g = t.vals[~ref]; l = t.leafLo[g]; h = t.leafHi[g]; }
+    lo[0] = l.x; lo[1] = l.y; lo[2] = l.z;
+    hi[0] = h.x; hi[1] = h.y; hi[2] = h.z;
+}
+PT_DEV float rtArea(const float *lo, const float *hi)
+{
+    const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+PT_DEV float rtUnionArea(const float *lo, const float *hi, const float *lo2, const float *hi2)
+{
+    const float dx = fmaxf(hi[0], hi2[0]) - fminf(lo[0], lo2[0]), dy = fmaxf(hi[1], hi2[1]) - fminf(lo[1], lo2[1]),
+                dz = fmaxf(hi[2], hi2[2]) - fminf(lo[2], lo2[2]);
+    return dx * dy + dy * dz + dz * dx;
+}
+PT_DEV uint32_t rtIndex(const ReinsertTree &t, int ref) { return ref >= 0 ? (uint32_t)ref : (uint32_t)(t.n - 1) + (uint32_t)~ref; } // node or leaf -> lock slot
+PT_DEV int rtRefOf(const ReinsertTree &t, uint32_t index) { return index < (uint32_t)(t.n - 1) ? (int)index : ~(int)(index - (uint32_t)(t.n - 1)); }
+
+constexpr int kReinsertLevels = 16; // how far up the search goes
+constexpr int kReinsertStack = 48;
+
+// per x (every node but the root and the root's children, every leaf whose parent is not the root): best target, its gain, and
+// the top of the path the move has to hold (the parent of the common ancestor, or the root)
+__global__ void k_reinsert_find(ReinsertTree t, uint32_t stride, uint32_t phase, int *__restrict__ target, float *__restrict__ gain, int *__restrict__ top)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t index = k * stride + phase;
+    if (index >= (uint32_t)(2 * t.n - 1))
+        return;
+    target[index] = kEmptyRef;
+    gain[index] = 0.0f;
+    const int x = rtRefOf(t, index);
+    if (x == 0)
+        return;
+    const int p = rtParent(t, x);
+    if (p <= 0) // the root's children stay: p would be deleted, and the root is node 0 by convention
+        return;
+    float xl[3], xh[3];
+    rtBox(t, x, xl, xh);
+    const float ax = rtArea(xl, xh);
+    const int2 pc = t.children[p];
+    const int s = pc.x == x ? pc.y : pc.x;
+    float bl[3], bh[3]; // the box of what is left of the path's subtree once x is gone
+    rtBox(t, s, bl, bh);
+    float pl[3], ph[3];
+    rtBox(t, p, pl, ph);
+    float R = rtArea(pl, ph); // p is deleted
+    float best = 0.0f;
+    int bestT = kEmptyRef, bestTop = 0;
+    int cur = p;
+    int stRef[kReinsertStack];
+    float stG[kReinsertStack];
+    for (int level = 0; level < kReinsertLevels; level++)
+    {
+        // the sibling subtree of this level: at level 0 the subtree of s itself (x moves deeper into its sibling)
+        const int anc = level == 0 ? p : rtParent(t, cur);
+        if (anc < 0)
+            break;
+        int o;
+        if (level == 0)
+            o = s;
+        else
+        {
+            const int2 ac = t.children[anc];
+            o = ac.x == cur ? ac.y : ac.x;
+        }
+        int sp = 0;
+        stRef[sp] = o;
+        stG[sp] = 0.0f;
+        sp++;
+        while (sp > 0)
+        {
+            sp--;
+            const int u = stRef[sp];
+            const float g = stG[sp];
+            float ul[3], uh[3];
+            rtBox(t, u, ul, uh);
+            const float au = rtUnionArea(ul, uh, xl, xh);
+            const float d = R - g - au;
+            if (d > best && !(level == 0 && u == s)) // (beside s: where it is now)
+            {
+                best = d;
+                bestT = u;
+                bestTop = level == 0 ? rtParent(t, p) : anc; // (p's parent gets s for p: it is part of every move)
+            }
+            if (u >= 0)
+            {
+                const float g2 = g + (au - rtArea(ul, uh));
+                if (R - g2 - ax > best && sp + 2 <= kReinsertStack)
+                {
+                    const int2 uc = t.children[u];
+                    stRef[sp] = uc.x; stG[sp] = g2; sp++;
+                    stRef[sp] = uc.y; stG[sp] = g2; sp++;
+                }
+            }
+        }
+        if (level == 0)
+            continue; // (next: the sibling of p under its parent; R and the path box are those of level 0)
+        // one level up: `anc` loses x too and shrinks to (path box u o); beside the shrunken anc is a candidate as well
+        float ol[3], oh[3], al[3], ah[3];
+        rtBox(t, o, ol, oh);
+        rtBox(t, anc, al, ah);
+        for (int a = 0; a < 3; a++)
+        {
+            bl[a] = fminf(bl[a], ol[a]);
+            bh[a] = fmaxf(bh[a], oh[a]);
+        }
+        R += rtArea(al, ah) - rtArea(bl, bh);
+        cur = anc;
+        if (anc != 0) // (beside the root there is no place)
+        {
+            const float d = R - rtUnionArea(bl, bh, xl, xh);
+            if (d > best)
+            {
+                best = d;
+                bestT = anc;
+                const int up = rtParent(t, anc);
+                bestTop = up >= 0 ? up : anc;
+            }
+        }
+    }
+    // (a gain below a millionth of the parent's area is rounding)
+    if (bestT != kEmptyRef && best > 1e-6f * rtArea(pl, ph))
+    {
+        target[index] = bestT;
+        gain[index] = best;
+        top[index] = bestTop;
+    }
+}
+
+PT_DEV unsigned long long rtKey(float g, uint32_t index) { return (unsigned long long)__float_as_uint(g) << 32 | index; }
+
+// claim (mode 0) or check (mode 1) every node of the move's paths: x and its sibling, p and up to `top`, t and up to `top`
+template <int MODE>
+PT_DEV bool rtWalk(const ReinsertTree &t, uint32_t index, int target, int top, unsigned long long key, unsigned long long *lock)
+{
+    const int x = rtRefOf(t, index);
+    const int p = rtParent(t, x);
+    const int2 pc = t.children[p];
+    const int s = pc.x == x ? pc.y : pc.x;
+    bool ok = true;
+    auto visit = [&](int ref) {
+        if (MODE == 0)
+            atomicMax(&lock[rtIndex(t, ref)], key);
+        else
+            ok = ok && lock[rtIndex(t, ref)] == key;
+    };
+    visit(x);
+    visit(s);
+    int guard = 0;
+    for (int u = p; u >= 0 && guard < 4096; u = rtParent(t, u), guard++)
+    {
+        visit(u);
+        if (u == top)
+            break;
+    }
+    visit(target); // (a leaf's ref is negative: it is not a step of the loop below)
+    for (int u = rtParent(t, target); u >= 0 && guard < 8192; u = rtParent(t, u), guard++)
+    {
+        visit(u);
+        if (u == top)
+            break;
+    }
+    return ok;
+}
+
+__global__ void k_reinsert_claim(ReinsertTree t, const int *__restrict__ target, const float *__restrict__ gain, const int *__restrict__ top,
+                                 unsigned long long *__restrict__ lock)
+{
+    const uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= (uint32_t)(2 * t.n - 1) || target[index] == kEmptyRef)
+        return;
+    rtWalk<0>(t, index, target[index], top[index], rtKey(gain[index], index), lock);
+}
+
+// apply the moves that hold all their nodes; counts them
+__global__ void k_reinsert_apply(ReinsertTree t, const int *__restrict__ target, const float *__restrict__ gain, const int *__restrict__ top,
+                                 unsigned long long *__restrict__ lock, uint32_t *__restrict__ applied)
+{
+    const uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= (uint32_t)(2 * t.n - 1) || target[index] == kEmptyRef)
+        return;
+    const int tg = target[index];
+    if (!rtWalk<1>(t, index, tg, top[index], rtKey(gain[index], index), lock))
+        return;
+    const int x = rtRefOf(t, index);
+    const int p = rtParent(t, x);
+    const int2 pc = t.children[p];
+    const int s = pc.x == x ? pc.y : pc.x;
+    const int a1 = rtParent(t, p);
+    // remove: s takes p's place under a1
+    {
+        int2 c = t.children[a1];
+        if (c.x == p) c.x = s; else c.y = s;
+        t.children[a1] = c;
+        rtSetParent(t, s, a1);
+    }
+    // insert: p becomes the node over (target, x), where the target stood
+    const int tp = rtParent(t, tg);
+    {
+        int2 c = t.children[tp];
+        if (c.x == tg) c.x = p; else c.y = p;
+        t.children[tp] = c;
+    }
+    t.children[p] = make_int2(tg, x);
+    rtSetParent(t, p, tp);
+    rtSetParent(t, tg, p);
+    rtSetParent(t, x, p);
+    atomicAdd(applied, 1u);
+}
+
+// is this still a tree?  (verbose builds check after every reinsertion pass)  counts: [0] children whose parent pointer does not
+// point back, [1] leaves that do not reach the root within 512 steps, [2] the longest leaf-to-root path
+__global__ void k_tree_check(ReinsertTree t, uint32_t *__restrict__ counts)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < t.n - 1)
+    {
+        const int2 c = t.children[i];
+        if (rtParent(t, c.x) != i)
+            atomicAdd(&counts[0], 1u);
+        if (rtParent(t, c.y) != i)
+            atomicAdd(&counts[0], 1u);
+    }
+    if (i < t.n)
+    {
+        int u = t.parentOfLeaf[i], steps = 1;
+        while (u > 0 && steps < 512)
+        {
+            u = t.parentOfNode[u];
+            steps++;
+        }
+        if (u != 0)
+            atomicAdd(&counts[1], 1u);
+        atomicMax(&counts[2], (uint32_t)steps);
+    }
+}
+
 // ---- cost-driven collapse (round 4) -------------------------------------------------------------------------------
 // Which binary nodes become 4-wide nodes?  The greedy rule of round 1 -- start from a node's two children and, twice, replace
 // the internal child with the largest surface area by its two children -- looks one step ahead.  This pass finds, for the given

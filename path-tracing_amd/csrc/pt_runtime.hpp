@@ -65,6 +65,9 @@ struct TreeParams
     float plocShape = kPlocShape;      // PLOC: weight of the compactness term in the merge metric
     bool mortonCubic = false;          // Morton curve with cubic cells (one scale for the three axes)
     uint32_t collapse = 1;             // 4-wide collapse: 0 greedy by surface area (round 1), 1 cost-driven (k_collapse_cost)
+    uint32_t reinsertPasses = 2;       // passes of parallel reinsertion over the binary tree before the collapse (k_reinsert_*): every
+                                       // candidate tree gets these; a build that keeps its state for refits (animation) at most these
+    uint32_t reinsertFinal = 32;       // ... and the candidate that wins is built once more with this many (15 ms per pass at 2 M triangles)
     float splitBudget = 0.0f;          // pre-splitting: extra leaf references as a fraction of the triangle count (0: none)
     uint32_t layout = 0;               // node order: 0 breadth-first levels, 1 depth-first (every subtree one contiguous range; measured flat)
 };
@@ -78,6 +81,7 @@ struct EnvSwitches
     bool plocFixed = false;      // PTX_PLOC_RADIUS / PTX_PLOC_SHAPE given: ONE tree with these parameters, no candidates
     uint32_t plocRadius = 0;     // PTX_PLOC_RADIUS
     float plocShape = 0.0f;      // PTX_PLOC_SHAPE
+    int reinsertPasses = -1;     // PTX_REINSERT=N: N reinsertion passes for the winning tree, min(N, 2) for every candidate (-1: not given)
     float splitBudget = -1.0f;   // PTX_SPLIT_BUDGET: extra leaf references as a fraction of the triangle count (< 0: not given)
     int layout = -1;             // PTX_NODE_LAYOUT=0 / 1: breadth-first / depth-first node order (-1: not given)
     int collapse = -1;           // PTX_COLLAPSE=0 / 1: greedy / cost-driven 4-wide collapse (-1: not given; does not fix the other parameters)
@@ -102,6 +106,8 @@ struct EnvSwitches
             e.plocFixed = true;
             e.plocRadius = std::max(1u, (uint32_t)strtoul(v, nullptr, 10));
         }
+        if (const char *v = getenv("PTX_REINSERT"))
+            e.reinsertPasses = atoi(v);
         if (const char *v = getenv("PTX_SPLIT_BUDGET"))
             e.splitBudget = (float)atof(v);
         if (const char *v = getenv("PTX_NODE_LAYOUT"))
@@ -473,6 +479,11 @@ static int createRenderer(const PtxDeviceDesc *desc, PtxRenderer **out)
         r->tree.layout = (uint32_t)r->env.layout;
     if (r->env.splitBudget >= 0.0f)
         r->tree.splitBudget = r->env.splitBudget;
+    if (r->env.reinsertPasses >= 0)
+    {
+        r->tree.reinsertFinal = (uint32_t)r->env.reinsertPasses;
+        r->tree.reinsertPasses = std::min(r->tree.reinsertPasses, r->tree.reinsertFinal);
+    }
     if (r->env.plocFixed)
     {
         r->tree.plocShape = r->env.plocShape;
@@ -1295,6 +1306,49 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
         if (!boxesDone)
             k_refit<<<vblocks, 256, 0, r->stream>>>((int)nv, vin, refLo, refHi, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p,
                                                B.nodeLo.p, B.nodeHi.p, B.flags.p);
+        const uint32_t reinsertPasses = refit ? 0u : r->tree.reinsertPasses;
+        if (reinsertPasses && nv > 3)
+        {
+            // parallel reinsertion over the binary tree (k_reinsert_find / _claim / _apply), boxes recomputed after every pass
+            const uint32_t slots = 2 * nv - 1, sblocks = (slots + 255) / 256;
+            DevBuf<int> target, top;
+            DevBuf<float> gain;
+            DevBuf<unsigned long long> lock;
+            DevBuf<uint32_t> applied;
+            BUILD_TRY(target.alloc(slots)); BUILD_TRY(top.alloc(slots)); BUILD_TRY(gain.alloc(slots)); BUILD_TRY(lock.alloc(slots)); BUILD_TRY(applied.alloc(1));
+            const ReinsertTree rt = { (int)nv, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p, B.nodeLo.p, B.nodeHi.p, vin, refLo, refHi };
+            for (uint32_t pass = 0; pass < reinsertPasses; pass++)
+            {
+                BUILD_TRY(hipMemsetAsync(lock.p, 0, (size_t)slots * sizeof(unsigned long long), r->stream));
+                BUILD_TRY(hipMemsetAsync(applied.p, 0, sizeof(uint32_t), r->stream));
+                k_reinsert_find<<<sblocks, 256, 0, r->stream>>>(rt, 1u, 0u, target.p, gain.p, top.p);
+                k_reinsert_claim<<<sblocks, 256, 0, r->stream>>>(rt, target.p, gain.p, top.p, lock.p);
+                k_reinsert_apply<<<sblocks, 256, 0, r->stream>>>(rt, target.p, gain.p, top.p, lock.p, applied.p);
+                // still a tree?  (a knot would hang k_refit: checked BEFORE the boxes are recomputed)
+                uint32_t moved = 0, check[3] = { 0, 0, 0 };
+                {
+                    DevBuf<uint32_t> counts;
+                    BUILD_TRY(counts.alloc(3));
+                    BUILD_TRY(hipMemsetAsync(counts.p, 0, 3 * sizeof(uint32_t), r->stream));
+                    k_tree_check<<<vblocks, 256, 0, r->stream>>>(rt, counts.p);
+                    BUILD_TRY(hipMemcpyAsync(check, counts.p, sizeof(check), hipMemcpyDeviceToHost, r->stream));
+                    BUILD_TRY(hipMemcpyAsync(&moved, applied.p, sizeof(moved), hipMemcpyDeviceToHost, r->stream));
+                    BUILD_TRY(hipStreamSynchronize(r->stream));
+                }
+                if (r->env.verbose)
+                    std::fprintf(stderr, "[ptx] reinsertion pass %u: %u moves; check: %u bad parent links, %u leaves off the root, longest path %u\n", pass,
+                                 moved, check[0], check[1], check[2]);
+                if (check[0] || check[1])
+                {
+                    B.release();
+                    return fail(r, PTX_ERROR_DEVICE, "ptx_build_accel: reinsertion pass %u left %u bad parent links, %u leaves off the root", pass, check[0], check[1]);
+                }
+                BUILD_TRY(hipMemsetAsync(B.flags.p, 0, (size_t)nv * 4, r->stream));
+                k_refit<<<vblocks, 256, 0, r->stream>>>((int)nv, vin, refLo, refHi, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p, B.nodeLo.p, B.nodeHi.p,
+                                                   B.flags.p);
+            }
+            BUILD_TRY(hipStreamSynchronize(r->stream)); // (the pass's buffers go out of scope)
+        }
         if (r->tree.collapse)
         {
             BUILD_TRY(hipMemsetAsync(B.flags.p, 0, (size_t)nv * 4, r->stream)); // (the arrival flags of k_refit: done with)
@@ -1431,7 +1485,14 @@ static int buildBestTree(PtxRenderer *r)
                                                  { 64u, 0.25f, false }, { 4u, 0.25f, false } };
     constexpr uint32_t kCandidates = sizeof(kTreeCandidates) / sizeof(kTreeCandidates[0]);
     if (!r->usePloc || r->env.plocFixed || r->triCount < 4096u)
-        return buildAccel(r, false, false);
+    {
+        // ONE tree: it gets the full number of reinsertion passes at once
+        const TreeParams keep = r->tree;
+        r->tree.reinsertPasses = std::max(keep.reinsertPasses, keep.reinsertFinal);
+        const int rc = buildAccel(r, false, false);
+        r->tree = keep;
+        return rc;
+    }
     DevBuf<BvhNode> bestNodes;
     DevBuf<Tri> bestTris;
     DevBuf<ShadeTri> bestShadeTris;
@@ -1476,7 +1537,33 @@ static int buildBestTree(PtxRenderer *r)
             swapTree(); // the renderer's buffers now hold the previous best (or nothing): the next candidate is built over them
         }
     }
-    swapTree();
+    // The winner once more, with the full number of reinsertion passes (the candidates had a few: the ranking is the same with 2
+    // as with 64, the cost keeps falling for dozens of passes).  Built over the renderer's buffers -- they hold a loser --, priced
+    // on the same rays, and kept only if it is no worse; if it fails, the candidate stands.
+    TreeCost finalCost;
+    bool haveFinal = false;
+    if (given.reinsertFinal > given.reinsertPasses && built > 0)
+    {
+        r->tree = given;
+        r->tree.plocRadius = kTreeCandidates[best].radius;
+        r->tree.plocShape = kTreeCandidates[best].shape;
+        r->tree.mortonCubic = kTreeCandidates[best].cubic;
+        r->tree.reinsertPasses = given.reinsertFinal;
+        int rc = buildAccel(r, false, false);
+        totalMs += r->stats.lastBuildMs;
+        if (rc == PTX_OK && sampleTreeCost(r, segments, false, &finalCost) == PTX_OK && finalCost.figure() <= cost[best].figure())
+        {
+            haveFinal = true;
+            bestNodeCount = r->stats.bvhNodes;
+            bestReferences = r->stats.treeReferences;
+            bestTreeTris = r->treeTris;
+        }
+        else if (r->env.verbose)
+            std::fprintf(stderr, "[ptx] the fully re-optimised tree was not kept (%s)\n", rc == PTX_OK ? "no cheaper" : r->error.c_str());
+        r->accelReady = false;
+    }
+    if (!haveFinal)
+        swapTree();
     r->stats.bvhNodes = bestNodeCount;
     r->stats.treeReferences = bestReferences;
     r->treeTris = bestTreeTris;
@@ -1492,7 +1579,9 @@ static int buildBestTree(PtxRenderer *r)
         for (uint32_t k = 0; k < built; k++)
             std::fprintf(stderr, " (radius %u, shape %.2f%s) %.2f / %u / %u%s", kTreeCandidates[k].radius, kTreeCandidates[k].shape,
                          kTreeCandidates[k].cubic ? ", cubic cells" : "", cost[k].mean, cost[k].p999, cost[k].worst, k == best ? " <- kept" : "");
-        std::fprintf(stderr, "; collapse %s; %.1f ms\n", given.collapse ? "cost-driven" : "greedy", totalMs);
+        if (haveFinal)
+            std::fprintf(stderr, "; with %u reinsertion passes %.2f / %u / %u", given.reinsertFinal, finalCost.mean, finalCost.p999, finalCost.worst);
+        std::fprintf(stderr, "; collapse %s, %u reinsertion passes per candidate; %.1f ms\n", given.collapse ? "cost-driven" : "greedy", given.reinsertPasses, totalMs);
     }
     return PTX_OK;
 }
