@@ -395,11 +395,14 @@ PTX_API uint32_t ptx_abi_version(void);
 PTX_API int ptx_scene_upload(PtxRenderer *r, const PtxSceneDesc *scene);
 /* AccelerationStructure::Build (AccelerationStructure.cpp:26-46; BLAS :64-247, TLAS
  * :250-301), replaced by a software LBVH over the flattened world-space triangles.
- * The call builds a handful of candidate trees (clustering radius, merge metric, Morton cells) and keeps the one that
- * costs a sample of surface-to-surface rays the fewest node visits and triangle tests: results never depend on the tree,
- * its quality moves frame times by several per cent, and no one setting is best for every scene.  PtxStats::lastBuildMs
- * is the time of all of it (2M triangles: ~40 ms).  PTX_PLOC_RADIUS / PTX_PLOC_SHAPE in the environment build one tree
- * with those parameters instead; the per-frame rebuilds of ptx_update_animation use the parameters chosen here. */
+ * The reference asks its driver for ePreferFastTrace (AccelerationStructure.cpp:319-324); this build spends time the same way:
+ * seven candidate trees (clustering radius, merge metric, Morton cells), each re-optimised by two passes of parallel reinsertion
+ * and collapsed to 4-wide nodes by a cost-driven rule, are priced on a sample of path-like rays (node visits + triangle tests), and
+ * the cheapest is built once more with 32 reinsertion passes.  Results never depend on the tree; its quality moves frame times by
+ * several per cent, and no one setting is best for every scene.  PtxStats::lastBuildMs is the time of all of it (2 M triangles:
+ * ~0.8 s, 4 M: ~1.7 s; PTX_REINSERT=0 in the environment: 0.14 / 0.27 s).  PTX_PLOC_RADIUS / PTX_PLOC_SHAPE build one tree with
+ * those parameters instead; the per-frame rebuilds of ptx_update_animation use the parameters chosen here with two reinsertion
+ * passes. */
 PTX_API int ptx_build_accel(PtxRenderer *r);
 /* Frames in flight share ONE scene: the reference keeps GetInFlightCount() sets of per-frame rendering resources
  * (Renderer.cpp:1454-1460) over one set of scene buffers and one acceleration structure (s_StaticSceneData / s_SceneData,

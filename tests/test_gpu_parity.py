@@ -615,20 +615,24 @@ def test_cpp_host_adapter_end_to_end(pkg, tmp_path):
 
 
 def test_tree_choice_does_not_change_images(pkg, monkeypatch):
-    """ptx_build_accel builds the tree with two PLOC search radii and keeps the one that costs sampled surface-to-surface
-    rays fewer node visits and triangle tests (k_sample_tree_cost); a radius given in the environment skips the comparison.
-    Closest hits are tree-independent by construction, so all three renders are the same bits."""
+    """ptx_build_accel builds seven candidate trees (PLOC search radius, compactness weight, cubic Morton cells), re-optimises
+    them by parallel reinsertion, collapses them to 4-wide nodes by a cost-driven rule and keeps the one that costs sampled rays
+    least (k_sample_tree_cost); switches in the environment fix a radius, turn the reinsertion off or up, select the greedy
+    collapse of rounds 1-3 or the depth-first node order.  Closest hits are tree-independent by construction, so every render is
+    the same bits."""
     import torch  # noqa: F401
 
     scene = pkg.Scene("street_like", 0.05)
     W, H = 160, 90
     u = scene.uniform(W, H, bounces=6)
     images = []
-    for radius in (None, "16", "32"):
-        if radius is None:
-            monkeypatch.delenv("PTX_PLOC_RADIUS", raising=False)
-        else:
-            monkeypatch.setenv("PTX_PLOC_RADIUS", radius)
+    switches = ({}, {"PTX_PLOC_RADIUS": "16"}, {"PTX_PLOC_RADIUS": "32"}, {"PTX_REINSERT": "0"}, {"PTX_REINSERT": "12", "PTX_COLLAPSE": "0"},
+                {"PTX_NODE_LAYOUT": "1"}, {"PTX_BUILDER": "lbvh", "PTX_REINSERT": "4"})
+    for env in switches:
+        for k in ("PTX_PLOC_RADIUS", "PTX_REINSERT", "PTX_COLLAPSE", "PTX_NODE_LAYOUT", "PTX_BUILDER"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         r = pkg.Renderer()
         r.upload(scene)
         assert r.stats().lastBuildMs > 0
@@ -636,7 +640,8 @@ def test_tree_choice_does_not_change_images(pkg, monkeypatch):
         r.render_frames(u, scene.lights, 0, 3)
         images.append(r.readback())
         r.close()
-    assert (images[0].view(np.uint32) == images[1].view(np.uint32)).all() and (images[0].view(np.uint32) == images[2].view(np.uint32)).all()
+    for k in range(1, len(images)):
+        assert (images[0].view(np.uint32) == images[k].view(np.uint32)).all(), switches[k]
 
 
 @pytest.mark.gpu
