@@ -204,6 +204,7 @@ struct PtxRenderer
     bool mixedTextured = false;      // ... or materials with and without scene textures: the sampler runs for waves of textured hits only
     bool usePloc = true;        // PLOC topology instead of Karras (PTX_BUILDER=lbvh switches back)
     TreeParams tree;            // of the tree in use; the per-frame rebuilds of an animation build with them again
+    bool reinsertBroken = false; // a reinsertion pass once left something that was not a tree (k_tree_check): off for this handle
     uint32_t residentClosest[2] = { 0, 0 }, residentShadow[2] = { 0, 0 }; // blocks the chip holds at once, per [ALPHA] variant
     DevBuf<float4> decal;
     DevBuf<float> decalT;
@@ -1306,7 +1307,7 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
         if (!boxesDone)
             k_refit<<<vblocks, 256, 0, r->stream>>>((int)nv, vin, refLo, refHi, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p,
                                                B.nodeLo.p, B.nodeHi.p, B.flags.p);
-        const uint32_t reinsertPasses = refit ? 0u : r->tree.reinsertPasses;
+        const uint32_t reinsertPasses = (refit || r->reinsertBroken) ? 0u : r->tree.reinsertPasses;
         if (reinsertPasses && nv > 3)
         {
             // parallel reinsertion over the binary tree (k_reinsert_find / _claim / _apply), boxes recomputed after every pass
@@ -1340,8 +1341,15 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
                                  moved, check[0], check[1], check[2]);
                 if (check[0] || check[1])
                 {
-                    B.release();
-                    return fail(r, PTX_ERROR_DEVICE, "ptx_build_accel: reinsertion pass %u left %u bad parent links, %u leaves off the root", pass, check[0], check[1]);
+                    // Not a tree any more (never seen since the path locks were completed, but the moves of a pass race by design):
+                    // this handle builds without reinsertion from now on, starting with this tree again.
+                    r->reinsertBroken = true;
+                    fail(r, PTX_OK, "ptx_build_accel: reinsertion pass %u left %u bad parent links, %u leaves off the root: rebuilt without reinsertion",
+                         pass, check[0], check[1]);
+                    if (r->env.verbose)
+                        std::fprintf(stderr, "[ptx] %s\n", r->error.c_str());
+                    BUILD_TRY(hipStreamSynchronize(r->stream));
+                    return buildAccel(r, false, keepState);
                 }
                 BUILD_TRY(hipMemsetAsync(B.flags.p, 0, (size_t)nv * 4, r->stream));
                 k_refit<<<vblocks, 256, 0, r->stream>>>((int)nv, vin, refLo, refHi, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p, B.nodeLo.p, B.nodeHi.p,
