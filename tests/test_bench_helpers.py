@@ -1,0 +1,81 @@
+"""Host-side logic of bench.py that needs no GPU: the byte models of SURVEY.md 8(d), the shape key that ties a counter summary
+to a workload, and the lookup of committed summaries by scene and shape."""
+import json
+import os
+import subprocess
+import sys
+import types
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import bench  # noqa: E402
+
+
+def test_byte_models_of_the_survey():
+    # B_trace_closest = 32 L(N) + 36 with L = ceil(log2 N); + 56 B of queue entry, ray and hit record
+    assert bench.algorithmic_bytes_per_closest_ray(1_999_000) == 32 * 21 + 36 + 56 == 764
+    assert bench.algorithmic_bytes_per_closest_ray(4_119_368) == 32 * 22 + 36 + 56 == 796
+    # worked values of the survey: N = 4 M -> B_segment = 2 * 740 + 796 = 2,276; N = 36 (the default scene) -> 1,252
+    assert bench.segment_model_bytes(4_000_000) == 2276
+    assert bench.segment_model_bytes(36) == 1252
+
+
+def test_shape_key_is_what_profile_set_writes():
+    """tools/profile_set.sh derives the same string from the bench.py arguments it is given (SHAPE=...)."""
+    assert bench.shape_key(1920, 1080, 8, 8, None) == "1920x1080/8spp/d8/shard0of1"
+    assert bench.shape_key(3840, 2160, 128, 16, (0, 8)) == "3840x2160/128spp/d16/shard0of8"
+    script = open(os.path.join(REPO, "tools", "profile_set.sh")).read()
+    start = script.index("TAG=${1:?tag}; shift")
+    end = script.index("# bench.py shape_key()")
+    snippet = script[start:script.index("\n", end)] + '\necho "$SCENE $SHAPE"\n'
+    out = subprocess.run(["bash", "-c", snippet, "x", "tag", "--scene", "street_like", "--width", "3840", "--height", "2160", "--spp", "128", "--depth", "16",
+                          "--shard", "0/8", "--in-flight", "2"], capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["street_like", bench.shape_key(3840, 2160, 128, 16, (0, 8))]
+
+
+def test_counter_summaries_are_found_by_scene_and_shape(tmp_path, monkeypatch):
+    """bench.py attaches the NEWEST committed summary whose scene and shape match the job; a summary of another shape of the
+    same scene (BASELINE configs[2] is temple_like at 64 spp) is not the 8-spp line's."""
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    docs = {"r09a_traffic.json": {"scene": "temple_like", "shape": bench.shape_key(1920, 1080, 8, 8, None), "k_generate": {"launches": 1, "hbm_bytes_per_launch": 1.0}},
+            "r09a_cfg2_traffic.json": {"scene": "temple_like", "shape": bench.shape_key(1920, 1080, 64, 8, None)},
+            "r09a_sq.json": {"scene": "temple_like", "shape": bench.shape_key(1920, 1080, 8, 8, None), "k_shade<false>": {"SQ_INSTS_VALU": 2.0e8}}}
+    for k, (name, d) in enumerate(docs.items()):
+        p = prof / name
+        p.write_text(json.dumps(d))
+        os.utime(p, (1000 + k, 1000 + k))
+    monkeypatch.setattr(bench, "REPO", str(tmp_path))
+
+    def job(spp, shard=None):
+        j = types.SimpleNamespace()
+        j.args = types.SimpleNamespace(detail=1.0, spp=spp, depth=8, traffic_json=None)
+        j.world, j.W, j.H = 1, 1920, 1080
+        j.shard_rank, j.shard_world = shard if shard else (0, 1)
+        j.scene = types.SimpleNamespace(name="temple_like")
+        return j
+
+    doc, path = bench.counter_doc(job(8), "traffic")
+    assert os.path.basename(path) == "r09a_traffic.json" and doc["shape"].startswith("1920x1080/8spp")
+    doc, path = bench.counter_doc(job(64), "traffic")
+    assert os.path.basename(path) == "r09a_cfg2_traffic.json"
+    doc, path = bench.counter_doc(job(8), "sq")
+    assert os.path.basename(path) == "r09a_sq.json"
+    assert bench.counter_doc(job(8, (0, 4)), "traffic") == (None, None)  # a rank's share is another shape
+
+
+def test_baseline_configs_cover_baseline_json():
+    """Every config of BASELINE.json has its line(s) in bench.py's `configs` (configs[1] is the headline itself)."""
+    baseline = json.load(open(os.path.join(REPO, "BASELINE.json")))
+    keys = [k for k, _ in bench.BASELINE_CONFIGS]
+    for i in range(len(baseline["configs"])):
+        if i == 1:
+            continue
+        assert any(k.startswith(f"configs[{i}]") for k in keys), i
+    by_key = dict(bench.BASELINE_CONFIGS)
+    a = by_key[[k for k in keys if k.startswith("configs[4]")][0]]
+    assert a[a.index("--width") + 1] == "3840" and a[a.index("--depth") + 1] == "16" and a[a.index("--shard") + 1] == "0/8"
+    a = by_key[[k for k in keys if k.startswith("configs[3]")][0]]
+    assert a[a.index("--depth") + 1] == "12" and a[a.index("--shard") + 1] == "0/4"
