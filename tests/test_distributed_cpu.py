@@ -23,7 +23,7 @@ def _free_port():
 
 def _pack(img, mask_tiles, tile, W, H):
     """Dense tile-major shard buffer [ownedTile][tile*tile][4] in the slot order of
-    csrc/pt_kernels.hip slotPixel(): 8x8 pixel blocks inside a tile."""
+    csrc/pt_wavefront.hpp slotPixel(): 8x8 pixel blocks inside a tile."""
     tiles_x = (W + tile - 1) // tile
     out = np.zeros((len(mask_tiles), tile * tile, 4), np.float32)
     bpr = tile // 8
