@@ -40,7 +40,11 @@ region; min / max ride in `spread`.
 
 Launch:  python bench.py --gpus N --steps K --warmup W           (N = 1)
          python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
-Rank 0 prints ONE JSON line.
+Output: the LAST stdout line is ONE compact JSON object (< 4 KB: compact_line()) -- metric, value, ms_per_step, config, `roofline`,
+`cpu_baseline` and one flat entry per BASELINE config.  Everything else the run measured (overlapped launch durations, per-kernel
+counter bytes, one-frame-alone figures, spreads, the children's full records) is written to bench_detail.json (and to
+gpurun_out/bench_detail.json where that directory exists); nothing but that one line reaches stdout -- file descriptor 1 is pointed
+at stderr for the life of the process (RCCL and the HIP runtime print to stdout) and the line is written to the saved descriptor.
 """
 from __future__ import annotations
 
@@ -68,6 +72,7 @@ STAND_IN = {"chess_like": "configs[1] 'Khronos ABeautifulGame'", "temple_like": 
 EXTRA_SCENES = ("atrium_like", "temple_like", "street_like")
 # BASELINE.json `configs` at their own definitions (child processes of the default run).  Samples per pixel of the multi-GPU
 # jobs are bounded (a rate: 64 of configs[3]'s 256, 128 of configs[4]'s 1024) so that the default run stays within minutes.
+CHILD_CPU_SECONDS = 3.0  # CPU leg of a `configs` child (one frame at least); the headline's own leg is --cpu-seconds
 BASELINE_CONFIGS = (
     ("configs[0] Khronos DragonAttenuation, 512x512, 1 spp, depth 4 -- CPU reference path (stand-in attenuation_blob)",
      ["--scene", "attenuation_blob", "--width", "512", "--height", "512", "--spp", "1", "--depth", "4", "--steps", "50", "--warmup", "5"]),
@@ -420,14 +425,14 @@ def roofline(job, stats, digest, stats_x=None, step_ms=None, segments_per_sample
     over = kernel_roofline(job, stats, bpr)
     top = kernel_roofline(job, stats_x, bpr) if stats_x and stats_x["trace_ms"] > 0 else over
     out = {
-        "bound": "latency", "priced_against": "hbm", "kernel": "k_trace_closest", "achieved": top["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "bound": "hbm", "kernel": "k_trace_closest", "achieved": top["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": top["frac"], "traffic": None, "achieved_counter": None, "frac_counter": None,
         "measured": ("launch alone on the machine (the same frames one at a time on the first renderer, live HIP events, before the other frames in flight exist)" if top is not over
                      else "launches of the timed region (live HIP events)"),
         "model_bytes_per_ray": bpr, "model_bytes_per_launch": top["model_bytes_per_launch"],
         "rays_per_launch": top["rays_per_launch"], "avg_launch_ms": top["avg_launch_ms"], "launches": top["launches"],
         "grays_per_s": top["grays_per_s"],
-        "limiter": "dependent-fetch latency: SQ_WAIT_ANY / SQ_WAVE_CYCLES of this kernel in profiles/*_sq.txt",
+        "limiter": "dependent-fetch latency (SQ_WAIT_ANY / SQ_WAVE_CYCLES in profiles/*_sq.txt); priced against HBM as the contract asks",
     }
     if top is not over:
         out["overlapped"] = dict(over, what=f"launches of the timed region, {job.F} frames in flight: a launch's duration counts the time it "
@@ -467,6 +472,117 @@ def roofline(job, stats, digest, stats_x=None, step_ms=None, segments_per_sample
     if shade:
         out["shade"] = shade
     return out
+
+
+LINE_LIMIT = 4096  # bytes of the one stdout line (the driver keeps ~8 KB of stdout tail and parses the last line)
+
+
+def _r(x, digits=5):
+    """Numbers of the compact line: 5 significant digits are more than the run-to-run spread."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        if not math.isfinite(x):
+            return None
+        return float(f"{x:.{digits}g}")
+    return x
+
+
+def _pick(d, keys):
+    return {k: _r(d[k]) for k in keys if d is not None and k in d and d[k] is not None}
+
+
+def config_entry(rec):
+    """One flat entry per BASELINE config: {key, value, ms_per_step, frac_step_counter, cpu}."""
+    if "is" in rec:
+        return {"key": rec["baseline_config"].split(" ")[0] + " = this line"}
+    cfg = rec.get("config", {})
+    e = {"key": rec["baseline_config"].split(" ")[0] + " " + cfg.get("workload", "").split(" ")[0] + " " + cfg.get("shape", ""),
+         "value": _r(rec.get("value")), "ms_per_step": _r(rec.get("ms_per_step")),
+         "frac_step_counter": _r((rec.get("roofline") or {}).get("frac_step_counter")),
+         "frac": _r((rec.get("roofline") or {}).get("frac")),
+         "cpu": _r((rec.get("cpu_baseline") or {}).get("value"))}
+    if cfg.get("frames_in_flight") is not None:
+        e["frames_in_flight"] = cfg["frames_in_flight"]
+    return e
+
+
+def compact_line(full, detail_path=None):
+    """The line the driver parses: the contract's keys, `roofline`, `cpu_baseline`, one flat entry per BASELINE config -- under
+    LINE_LIMIT bytes whatever the full record holds (optional parts are dropped, last first, if a string ever grows)."""
+    out = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data",
+                       "source_digest", "gpu_over_cpu", "one_in_flight_ms_per_step", "one_in_flight_value"))
+    out["vs_baseline"] = full.get("vs_baseline")
+    cfg = full.get("config", {})
+    out["config"] = _pick(cfg, ("workload", "shape", "triangles", "frames_in_flight", "segments_per_sample", "parallelism", "backend", "tile",
+                                "tree_build_ms"))
+    if "workload" in out["config"]:
+        out["config"]["workload"] = out["config"]["workload"][:200]
+    if "no_readback" in full:
+        out["no_readback_value"] = _r(full["no_readback"]["value"])
+    if "weak" in full:
+        out["weak"] = _pick(full["weak"], ("scaling", "value", "ms_per_step", "workload"))
+    rf = full.get("roofline")
+    if rf:
+        o = _pick(rf, ("kernel", "bound", "limiter", "achieved", "peak", "unit", "frac", "traffic", "traffic_factor", "frac_counter", "frac_step_counter",
+                       "frac_step_model", "model_valid", "avg_launch_ms", "rays_per_launch", "model_bytes_per_ray", "traffic_stale", "measured_on"))
+        if rf.get("traffic_source"):
+            o["traffic_source"] = rf["traffic_source"].split(" ")[0]
+        if rf.get("shade"):
+            o["shade"] = _pick(rf["shade"], ("kernel", "frac_valu_issue", "ms_alone", "valu_wave_insts_per_launch"))
+        out["roofline"] = o
+    cb = full.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind"))
+        out["cpu_baseline"]["sample"] = cb.get("sample", "")[:160]
+    if full.get("configs"):
+        out["configs"] = [config_entry(c) for c in full["configs"]]
+    if full.get("stand_ins_8spp"):
+        out["stand_ins_8spp"] = [{"key": (c.get("config", {}).get("workload", "").split(" ")[0]), "value": _r(c.get("value")),
+                                  "ms_per_step": _r(c.get("ms_per_step")), "cpu": _r((c.get("cpu_baseline") or {}).get("value"))}
+                                 for c in full["stand_ins_8spp"]]
+    if detail_path:
+        out["detail"] = detail_path
+    for drop in (None, "stand_ins_8spp", "weak", "configs"):  # never reached with today's strings; the limit holds by construction
+        if drop:
+            out.pop(drop, None)
+        if len(json.dumps(out)) < LINE_LIMIT:
+            break
+    return out
+
+
+_REAL_STDOUT = None
+
+
+def claim_stdout():
+    """Point file descriptor 1 at stderr and keep the real stdout for the one JSON line: RCCL (NCCL_DEBUG), the HIP runtime and
+    rocprofv3's tool library print to stdout, not always newline-terminated, and the driver parses the LAST stdout line."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+    return _REAL_STDOUT
+
+
+def emit(full, compact=True):
+    """Write the full record to bench_detail.json, then the compact line as the last (and only) line of the real stdout."""
+    detail = None
+    if compact:
+        for path in (os.path.join(REPO, "bench_detail.json"), os.path.join(REPO, "gpurun_out", "bench_detail.json")):
+            if os.path.isdir(os.path.dirname(path)):
+                try:
+                    with open(path, "w") as f:
+                        json.dump(full, f, indent=1)
+                    detail = detail or os.path.relpath(path, REPO)
+                except OSError:
+                    pass
+    line = json.dumps(compact_line(full, detail) if compact else full)
+    if compact:
+        assert len(line) < LINE_LIMIT, len(line)
+    out = _REAL_STDOUT or sys.stdout
+    out.write("\n" + line + "\n")
+    out.flush()
 
 
 def scene_line(args, pkg, torch, dist, orc, name, rank, world, local_rank, steps, warmup, min_seconds, with_cpu, digest):
@@ -537,7 +653,11 @@ def main():
     ap.add_argument("--backend", default="wavefront", choices=["wavefront", "megakernel"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra-scenes", action="store_true", help="N = 1: skip the `configs` lines of the other stand-in scenes")
+    ap.add_argument("--no-extra-scenes", action="store_true", help="N = 1: skip the `configs` children (BASELINE's other configs)")
+    ap.add_argument("--detail-run", action="store_true",
+                    help="N = 1: also measure the other stand-ins at the headline's shape (`stand_ins_8spp`) and the reference's default "
+                         "scene at configs[0]'s shape -- minutes more; the default run keeps to one child per BASELINE config")
+    ap.add_argument("--child", action="store_true", help="internal: a `configs` child -- print the FULL record as the one line")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --single-device lets the N > 1 code path be exercised on a 1-GPU box (testing only)")
     ap.add_argument("--single-device", action="store_true", help="testing only: every rank uses cuda:0")
@@ -555,6 +675,7 @@ def main():
                     help="per-kernel HBM bytes per launch from tools/pmc_traffic.py (default: newest profiles/r*_traffic.json)")
     ap.add_argument("--dump-image", default=None, help="testing: rank 0 saves the last frame (npy)")
     args = ap.parse_args()
+    claim_stdout()
 
     import torch
     import torch.distributed as dist
@@ -580,7 +701,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     pkg = graft.load_package()  # after torch: one HIP runtime in the process
-    orc = graft.load_oracle() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    orc = graft.load_oracle() if (rank == 0 and not args.no_cpu_baseline) else None
     digest = source_digest(pkg)
     W, H = args.width, args.height
     metric = "Msamples/s (paths*spp/s) at 1920x1080, 8spp, depth 8"
@@ -597,7 +718,7 @@ def main():
                    value=W * H * job_spp * args.steps / med / 1e6 / ew, ms_per_step=med / args.steps * 1e3,
                    config={"workload": f"EMULATION of rank {er} of {ew} ({args.scene}, tile shard, no gather, {job_spp} spp)",
                            "kernel_ms_per_step": {k: stats[k] / args.steps for k in ("trace_ms", "shade_ms", "shadow_ms", "tail_ms")}})
-        print(json.dumps(out), flush=True)
+        emit(out, compact=False)
         job.close()
         return
 
@@ -618,26 +739,32 @@ def main():
             import subprocess
             mine = set(common) | {"scaling"}
 
-            def child(extra, what):
-                cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-extra-scenes", "--detail", str(args.detail), "--tile", str(args.tile),
-                       "--backend", args.backend, "--cpu-seconds", str(args.cpu_seconds)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + extra
+            def child(extra, what, cpu=True):
+                cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-extra-scenes", "--child", "--detail", str(args.detail),
+                       "--tile", str(args.tile), "--backend", args.backend, "--cpu-seconds", str(min(args.cpu_seconds, CHILD_CPU_SECONDS))]
+                cmd += (["--no-cpu-baseline"] if args.no_cpu_baseline or not cpu else []) + [a for a in extra if a != "--no-cpu-baseline"]
                 p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
                 if p.returncode != 0:
                     raise SystemExit(f"[bench] the {what} run failed (exit code {p.returncode}): {' '.join(cmd)}")
                 l = json.loads(p.stdout.strip().splitlines()[-1])
                 return {k: v for k, v in l.items() if k not in mine}
 
-            out["stand_ins_8spp"] = []
-            for name in EXTRA_SCENES:
-                out["stand_ins_8spp"].append(child(["--scene", name, "--steps", str(args.steps), "--warmup", "2", "--repeats", str(args.repeats),
-                                                    "--min-seconds", str(min(args.min_seconds, 1.5)), "--width", str(W), "--height", str(H), "--spp", str(args.spp),
-                                                    "--depth", str(args.depth), "--in-flight", str(args.in_flight)], f"stand-in {name}"))
+            if args.detail_run:
+                out["stand_ins_8spp"] = []
+                for name in EXTRA_SCENES:
+                    out["stand_ins_8spp"].append(child(["--scene", name, "--steps", str(args.steps), "--warmup", "2", "--repeats", str(args.repeats),
+                                                        "--min-seconds", str(min(args.min_seconds, 1.5)), "--width", str(W), "--height", str(H),
+                                                        "--spp", str(args.spp), "--depth", str(args.depth), "--in-flight", str(args.in_flight)],
+                                                       f"stand-in {name}"))
             out["configs"] = []
             for key, extra in BASELINE_CONFIGS:
-                l = child(extra + ["--repeats", "2", "--min-seconds", "0"], key)
+                if "default scene" in key and not args.detail_run:
+                    continue
+                l = child(extra + ["--repeats", "2", "--min-seconds", "0"], key, cpu="--no-cpu-baseline" not in extra)
                 out["configs"].append(dict({"baseline_config": key}, **l))
-            out["configs"].insert(1, {"baseline_config": "configs[1] Khronos ABeautifulGame, 1920x1080, 8 spp, depth 8 -- 1xMI355X", "is": "this line (value, roofline, cpu_baseline at the top level)"})
-        print(json.dumps(out), flush=True)
+            out["configs"].insert(1, {"baseline_config": "configs[1] Khronos ABeautifulGame, 1920x1080, 8 spp, depth 8 -- 1xMI355X",
+                                      "is": "this line (value, roofline, cpu_baseline at the top level)"})
+        emit(out, compact=not args.child)
         return
 
     # ---- N > 1: strong scaling of the named frame is the metric; weak scaling beside it
@@ -662,12 +789,17 @@ def main():
                            "frame_checksum": [float(img[..., :3].astype(np.float64).sum()), bool(np.isfinite(img).all()), bool((img[..., 3] == 1).all())]})
         if args.backend == "wavefront" and stats_w["trace_ms"] > 0:
             out["roofline"] = roofline(job, stats_w, digest)
-            out["roofline"]["measured_on"] = "rank 0 of the weak-scaling run (per-GPU work of the 1-GPU benchmark)"
+            out["roofline"]["measured_on"] = "rank 0, weak-scaling run (per-GPU work of the 1-GPU benchmark)"
         if args.dump_image:
             np.save(args.dump_image, img)
-        print(json.dumps(out), flush=True)
+        if orc is not None:  # the same CPU leg as at N = 1, on rank 0's host cores while the other ranks wait in the barrier below
+            out["cpu_baseline"] = cpu_baseline(orc, job.scene, W, H, args.depth, min(args.cpu_seconds, 5.0))
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     job.close()
+    dist.barrier()
     dist.destroy_process_group()
+    if rank == 0:  # after the process group is gone: nothing prints behind the line
+        emit(out)
 
 
 if __name__ == "__main__":

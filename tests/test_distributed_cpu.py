@@ -106,7 +106,7 @@ def _run_bench_two_ranks(tmp_path, backend, extra=()):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--single-device", "--dist-backend", backend,
            "--steps", "2", "--warmup", "1", "--repeats", "1", "--scene", "chess_like", "--detail", "0.05", "--width", "328", "--height", "200",
-           "--spp", "4", "--depth", "6", "--dump-image", str(out), *extra]
+           "--spp", "4", "--depth", "6", "--cpu-seconds", "1", "--dump-image", str(out), *extra]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     return p, out
 
@@ -128,8 +128,11 @@ def test_bench_two_ranks_gather_the_single_rank_frame(pkg, tmp_path, backend):
         if m:
             pytest.skip("RCCL refuses two ranks on one device (runs wherever two GPUs exist): " + m.group(0)[:200])
     assert p.returncode == 0, p.stderr[-2000:]
-    line = json.loads(p.stdout.strip().splitlines()[-1])
+    last = p.stdout.splitlines()[-1]  # the LAST stdout line parses on its own, under RCCL's stdout chatter too
+    line = json.loads(last)
+    assert len(last) < 4096
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["weak"]["scaling"] == "weak" and line["value"] > 0
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1  # the N > 1 line carries the CPU leg too
     got = np.load(out)
     W, H = 328, 200  # ragged: 328 is not a multiple of the 32-pixel tile
     scene = pkg.Scene("chess_like", 0.05)
@@ -155,12 +158,12 @@ def test_rccl_gather_branch_runs_with_one_rank(pkg, tmp_path):
                MASTER_PORT=str(_free_port()))
     cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--force-gather", "--dist-backend", "nccl", "--steps", "3", "--warmup", "1",
            "--repeats", "1", "--scene", "chess_like", "--detail", "0.05", "--width", "328", "--height", "200", "--spp", "4", "--depth", "6",
-           "--in-flight", "3", "--dump-image", str(out)]
+           "--in-flight", "3", "--cpu-seconds", "1", "--dump-image", str(out)]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
-    start = p.stdout.rfind('{"metric"')  # (RCCL's own warnings go to stdout too, not always newline-terminated)
-    assert start >= 0, p.stdout[-2000:] + p.stderr[-2000:]
-    line = json.loads(p.stdout[start:].splitlines()[0])
+    last = p.stdout.splitlines()[-1]  # RCCL's own warnings go to fd 1 too: bench.py keeps them off the real stdout
+    line = json.loads(last)
+    assert len(last) < 4096 and line["cpu_baseline"]["value"] > 0
     assert line["n_gpus"] == 1 and "all_gather" in line["config"]["parallelism"] and line["value"] > 0
     got = np.load(out)
     W, H = 328, 200
