@@ -566,7 +566,10 @@ typedef enum PtxTestFunction {
                                        material record of that type (24 dwords; its texture indices are ignored), the five textureGrad
                                        results in slot order (emissive, colour, normal, 4th, 5th; rgba each)
                                        out (17): EmissiveColor Color Normal Roughness Metalness Transmission Eta AttenuationColor AttenuationDistance */
-    PTX_FN_COUNT = 35
+    PTX_FN_DIVIDE = 35,             /* in: a, b (2)   out: rcp(b), a / b (2) -- the specified division every `/` of the shader path goes
+                                       through: a * rcp(b), rcp correctly rounded on [2^-126, 2^126], +-inf below, +-0 above */
+    PTX_FN_SQRT = 36,               /* in: x          out: sqrt(x), correctly rounded                                          */
+    PTX_FN_COUNT = 37
 } PtxTestFunction;
 
 /* Material block used by PTX_FN_EVALUATE_BSDF / PTX_FN_SAMPLE_BSDF:

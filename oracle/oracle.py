@@ -140,8 +140,8 @@ class OracleScene:
 
 
 # words per case of pto_test_eval's inputs / outputs, by function id (include/ptx.h PTX_FN_*)
-IN_STRIDE = (4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4, 3, 3, 2, 6, 7, 3, 47)
-OUT_STRIDE = (1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1, 2, 3, 2, 6, 3, 3, 17)
+IN_STRIDE = (4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4, 3, 3, 2, 6, 7, 3, 47, 2, 1)
+OUT_STRIDE = (1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1, 2, 3, 2, 6, 3, 3, 17, 2, 1)
 
 
 def test_eval(fn: int, inputs: np.ndarray, nout: int) -> np.ndarray:

@@ -64,14 +64,14 @@ static inline v2 sampleUniformDiskConcentric(v2 u)
     float s, c;
     if (fabsf(offset.x) > fabsf(offset.y))
     {
-        const float theta = (PTO_PI / 4) * (offset.y / offset.x);
+        const float theta = (pto_div(PTO_PI, 4)) * (pto_div(offset.y, offset.x));
         pto_sincosf(theta, &s, &c);
         r.x = offset.x * c;
         r.y = offset.x * s;
     }
     else
     {
-        const float theta = PTO_PI / 2 - (PTO_PI / 4) * (offset.x / offset.y);
+        const float theta = pto_div(PTO_PI, 2) - (pto_div(PTO_PI, 4)) * (pto_div(offset.x, offset.y));
         pto_sincosf(theta, &s, &c);
         r.x = offset.y * c;
         r.y = offset.y * s;
@@ -112,9 +112,9 @@ static inline float GGXDistribution(v3 H, float alpha)
     const float Hy2 = H.y * H.y;
     const float Hz2 = H.z * H.z;
     const float alpha2 = alpha * alpha;
-    const float b = Hx2 / alpha2 + Hy2 / alpha2 + Hz2;
+    const float b = pto_div(Hx2, alpha2) + pto_div(Hy2, alpha2) + Hz2;
     const float denom = PTO_PI * alpha2 * (b * b);
-    return 1.0f / f_max(denom, 1.0f);
+    return pto_div(1.0f, f_max(denom, 1.0f));
 }
 
 /* shading.glsl:16-27 */
@@ -124,12 +124,12 @@ static inline float Lambda(v3 V, float alpha)
     const float Vy2 = V.y * V.y;
     const float Vz2 = fabsf(V.z) * fabsf(V.z);
     const float alpha2 = alpha * alpha;
-    const float nom = sqrtf(1.0f + (alpha2 * Vx2 + alpha2 * Vy2) / Vz2) - 1.0f;
-    return nom / 2.0f;
+    const float nom = sqrtf(1.0f + pto_div(alpha2 * Vx2 + alpha2 * Vy2, Vz2)) - 1.0f;
+    return pto_div(nom, 2.0f);
 }
 
 /* shading.glsl:29-32 */
-static inline float GGXSmith(v3 V, float alpha) { return 1.0f / (1.0f + Lambda(V, alpha)); }
+static inline float GGXSmith(v3 V, float alpha) { return pto_div(1.0f, 1.0f + Lambda(V, alpha)); }
 
 /* shading.glsl:34-48 */
 static inline float DielectricFresnel(float VdotH, float eta)
@@ -139,9 +139,9 @@ static inline float DielectricFresnel(float VdotH, float eta)
     if (sinThetaT2 > 1.0f)
         return 1.0f;
     const float cosThetaT = sqrtf(f_max(1.0f - sinThetaT2, 0.0f));
-    const float rs = (eta * cosThetaT - cosThetaI) / (eta * cosThetaT + cosThetaI);
-    const float rp = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
-    return (rs * rs + rp * rp) / 2.0f;
+    const float rs = pto_div(eta * cosThetaT - cosThetaI, eta * cosThetaT + cosThetaI);
+    const float rp = pto_div(eta * cosThetaI - cosThetaT, eta * cosThetaI + cosThetaT);
+    return pto_div(rs * rs + rp * rp, 2.0f);
 }
 
 /* shading.glsl:50-53 -- pow(x, 5) = x2*x2*x */
@@ -166,8 +166,8 @@ static inline v3 EvaluateReflection(v3 V, v3 L, v3 F, float alpha, float *pdf)
     const float Gv = GGXSmith(V, alpha);
     const float Gl = GGXSmith(L, alpha);
     const float G = Gv * Gl;
-    const float Dv = (Gv * f_max(VdotH, 0.0f) * D) / V.z;
-    *pdf = Dv / (4.0f * VdotH);
+    const float Dv = pto_div(Gv * f_max(VdotH, 0.0f) * D, V.z);
+    *pdf = pto_div(Dv, 4.0f * VdotH);
     return v_div(v_scale(F, D * G), 4.0f * V.z);
 }
 
@@ -188,11 +188,11 @@ static inline v3 EvaluateRefraction(v3 V, v3 L, v3 F, float alpha, float eta, fl
     const float Gv = GGXSmith(V, alpha);
     const float Gl = GGXSmith(L, alpha);
     const float G = Gv * Gl;
-    const float Dv = (Gv * fabsf(VdotH) * D) / V.z;
+    const float Dv = pto_div(Gv * fabsf(VdotH) * D, V.z);
     const float denominator = LdotH + eta * VdotH;
-    const float jacobian = ((eta * eta) * fabsf(LdotH)) / (denominator * denominator);
+    const float jacobian = pto_div((eta * eta) * fabsf(LdotH), denominator * denominator);
     *pdf = Dv * jacobian;
-    return v_scale(v_scale(v_scale(F, D * G), fabsf(VdotH) / fabsf(V.z)), jacobian);
+    return v_scale(v_scale(v_scale(F, D * G), pto_div(fabsf(VdotH), fabsf(V.z))), jacobian);
 }
 
 /* shading.glsl:111-129 */
@@ -200,7 +200,7 @@ static inline v3 SampleGGX(v2 u, v3 V, float alpha)
 {
     const v3 Vh = v_normalize(V3(alpha * V.x, alpha * V.y, fabsf(V.z)));
     const float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
-    const v3 T1 = lensq > 0 ? v_scale(V3(-Vh.y, Vh.x, 0), 1.0f / sqrtf(lensq)) : V3(1, 0, 0);
+    const v3 T1 = lensq > 0 ? v_scale(V3(-Vh.y, Vh.x, 0), pto_div(1.0f, sqrtf(lensq))) : V3(1, 0, 0);
     const v3 T2 = v_cross(Vh, T1);
     const float r = sqrtf(u.x);
     const float phi = 2.0f * PTO_PI * u.y;
@@ -249,7 +249,7 @@ typedef struct LobePdfs
 static inline v3 evaluateDiffuseBRDF(const MaterialSample *m, v3 V, v3 L, float *pdf)
 {
     (void)V;
-    *pdf = L.z * 1.0f / PTO_PI;
+    *pdf = pto_div(L.z * 1.0f, PTO_PI);
     return v_div(v_scale(m->Color, L.z), PTO_PI);
 }
 
@@ -364,8 +364,8 @@ typedef struct Ray
 /* direction through pixel-centre coordinates (pcx, pcy): ray.glsl:64-65,72-73 */
 static inline v3 pinholeDirection(float pcx, float pcy, uint32_t resX, uint32_t resY, const float *ViewInverse, const float *ProjInverse)
 {
-    const float inUVx = pcx / (float)resX;
-    const float inUVy = pcy / (float)resY;
+    const float inUVx = pto_div(pcx, (float)resX);
+    const float inUVy = pto_div(pcy, (float)resY);
     const float dx = inUVx * 2.0f - 1.0f;
     const float dy = inUVy * 2.0f - 1.0f;
     const v4 target = m4_mul(ProjInverse, dx, dy, 1, 1);
@@ -405,12 +405,12 @@ static inline Ray constructPrimaryRay(uint32_t px, uint32_t py, uint32_t resX, u
 static inline v3 lensDirection(float pcx, float pcy, uint32_t resX, uint32_t resY, const float *ViewInverse, const float *ProjInverse,
                                v3 originCameraSpace, float focalDistance)
 {
-    const float inUVx = pcx / (float)resX;
-    const float inUVy = pcy / (float)resY;
+    const float inUVx = pto_div(pcx, (float)resX);
+    const float inUVy = pto_div(pcy, (float)resY);
     const float dx = inUVx * 2.0f - 1.0f;
     const float dy = inUVy * 2.0f - 1.0f;
     const v4 target = m4_mul(ProjInverse, dx, dy, 1, 1);
-    const float ft = focalDistance / target.z;
+    const float ft = pto_div(focalDistance, target.z);
     const v3 pFocus = v_scale(V3(target.x, target.y, target.z), ft);
     const v3 nd = v_normalize(v_sub(pFocus, originCameraSpace));
     const v4 direction = m4_mul(ViewInverse, nd.x, nd.y, nd.z, 0);
@@ -512,7 +512,7 @@ static inline LightSample sampleLight(const PtxLightsUbo *ubo, v3 u, v3 position
 {
     const uint32_t lightCount = ubo->LightCount;
     const uint32_t lightIndex = (uint32_t)(u.x * (float)(lightCount + 1));
-    *pdf = 1.0f / (float)(lightCount + 1);
+    *pdf = pto_div(1.0f, (float)(lightCount + 1));
     LightSample ret;
     v2 uyz = { u.y, u.z };
 
@@ -539,8 +539,8 @@ static inline LightSample sampleLight(const PtxLightsUbo *ubo, v3 u, v3 position
     ret.Distance = v_length(v_sub(position, newPosition));
     ret.Direction = v_normalize(v_sub(position, newPosition));
     ret.Color = V3(light->Color[0], light->Color[1], light->Color[2]);
-    const float attenuation = 1.0f / (light->AttenuationConstant + ret.Distance * light->AttenuationLinear +
-                                      ret.Distance * ret.Distance * light->AttenuationQuadratic);
+    const float attenuation = pto_div(1.0f, light->AttenuationConstant + ret.Distance * light->AttenuationLinear +
+                                            ret.Distance * ret.Distance * light->AttenuationQuadratic);
     ret.Attenuation = f_clamp(attenuation, 0.0f, 1.0f);
     return ret;
 }
@@ -568,7 +568,7 @@ static inline void computeDpnDuv(const v3 p[3], const v3 n[3], const v2 uv[3], v
     }
     else
     {
-        const float invDet = 1.0f / det;
+        const float invDet = pto_div(1.0f, det);
         *dpdu = v_scale(v_sub(v_scale(e1, duv2.y), v_scale(e2, duv1.y)), invDet);
         *dpdv = v_scale(v_add(v_scale(e1, -duv2.x), v_scale(e2, duv1.x)), invDet);
         *dndu = v_scale(v_sub(v_scale(en1, duv2.y), v_scale(en2, duv1.y)), invDet);
@@ -583,9 +583,9 @@ static inline void computeDpDxy(v3 p, v3 origin, v3 direction, v3 rxOrigin, v3 r
     (void)origin;
     (void)direction;
     const float d = -v_dot(n, p);
-    const float tx = (-v_dot(n, rxOrigin) - d) / v_dot(n, rxDirection);
+    const float tx = pto_div(-v_dot(n, rxOrigin) - d, v_dot(n, rxDirection));
     const v3 px = v_add(rxOrigin, v_scale(rxDirection, tx));
-    const float ty = (-v_dot(n, ryOrigin) - d) / v_dot(n, ryDirection);
+    const float ty = pto_div(-v_dot(n, ryOrigin) - d, v_dot(n, ryDirection));
     const v3 py = v_add(ryOrigin, v_scale(ryDirection, ty));
     *dpdx = v_sub(px, p);
     *dpdy = v_sub(py, p);
@@ -608,7 +608,7 @@ static inline v4 computeDerivatives(v3 dpdx, v3 dpdy, v3 dpdu, v3 dpdv)
     const float ata00 = v_dot(dpdu, dpdu);
     const float ata01 = v_dot(dpdu, dpdv);
     const float ata11 = v_dot(dpdv, dpdv);
-    float invDet = 1 / differenceOfProducts(ata00, ata11, ata01, ata01);
+    float invDet = pto_div(1, differenceOfProducts(ata00, ata11, ata01, ata01));
     invDet = isinf(invDet) ? 0.0f : invDet;
     const float atb0x = v_dot(dpdu, dpdx);
     const float atb1x = v_dot(dpdv, dpdx);
@@ -636,9 +636,9 @@ static inline void computeReflectedDifferentialRays(v4 derivatives, v3 n, v3 p, 
     const v3 dndx = v_add(v_scale(dndu, dudx), v_scale(dndv, dvdx));
     const v3 dndy = v_add(v_scale(dndu, dudy), v_scale(dndv, dvdy));
     const float d = -v_dot(n, p);
-    const float tx = (-v_dot(n, r->rxOrigin) - d) / v_dot(n, r->rxDirection);
+    const float tx = pto_div(-v_dot(n, r->rxOrigin) - d, v_dot(n, r->rxDirection));
     const v3 px = v_add(r->rxOrigin, v_scale(r->rxDirection, tx));
-    const float ty = (-v_dot(n, r->ryOrigin) - d) / v_dot(n, r->ryDirection);
+    const float ty = pto_div(-v_dot(n, r->ryOrigin) - d, v_dot(n, r->ryDirection));
     const v3 py = v_add(r->ryOrigin, v_scale(r->ryDirection, ty));
     const v3 dwodx = v_sub(v_neg(r->rxDirection), viewDir);
     const v3 dwody = v_sub(v_neg(r->ryDirection), viewDir);
@@ -659,9 +659,9 @@ static inline void computeRefractedDifferentialRays(v4 derivatives, v3 n, v3 p, 
     v3 dndx = v_add(v_scale(dndu, dudx), v_scale(dndv, dvdx));
     v3 dndy = v_add(v_scale(dndu, dudy), v_scale(dndv, dvdy));
     const float d = -v_dot(n, p);
-    const float tx = (-v_dot(n, r->rxOrigin) - d) / v_dot(n, r->rxDirection);
+    const float tx = pto_div(-v_dot(n, r->rxOrigin) - d, v_dot(n, r->rxDirection));
     const v3 px = v_add(r->rxOrigin, v_scale(r->rxDirection, tx));
-    const float ty = (-v_dot(n, r->ryOrigin) - d) / v_dot(n, r->ryDirection);
+    const float ty = pto_div(-v_dot(n, r->ryOrigin) - d, v_dot(n, r->ryDirection));
     const v3 py = v_add(r->ryOrigin, v_scale(r->ryDirection, ty));
     const v3 dwodx = v_sub(v_neg(r->rxDirection), viewDir);
     const v3 dwody = v_sub(v_neg(r->ryDirection), viewDir);
@@ -675,9 +675,9 @@ static inline void computeRefractedDifferentialRays(v4 derivatives, v3 n, v3 p, 
     }
     const float dwoDotn_dx = v_dot(dwodx, n) + v_dot(viewDir, dndx);
     const float dwoDotn_dy = v_dot(dwody, n) + v_dot(viewDir, dndy);
-    const float mu = v_dot(viewDir, n) / eta - fabsf(v_dot(refractedDir, n));
-    const float dmudx = dwoDotn_dx * (1.0f / eta + 1.0f / (eta * eta) * v_dot(viewDir, n) / v_dot(refractedDir, n));
-    const float dmudy = dwoDotn_dy * (1.0f / eta + 1.0f / (eta * eta) * v_dot(viewDir, n) / v_dot(refractedDir, n));
+    const float mu = pto_div(v_dot(viewDir, n), eta) - fabsf(v_dot(refractedDir, n));
+    const float dmudx = dwoDotn_dx * (pto_div(1.0f, eta) + pto_div(pto_div(1.0f, eta * eta) * v_dot(viewDir, n), v_dot(refractedDir, n)));
+    const float dmudy = dwoDotn_dy * (pto_div(1.0f, eta) + pto_div(pto_div(1.0f, eta * eta) * v_dot(viewDir, n), v_dot(refractedDir, n)));
     r->rxDirection = v_normalize(v_add(v_sub(refractedDir, v_scale(dwodx, eta)), v_add(v_scale(dndx, mu), v_scale(n, dmudx))));
     r->ryDirection = v_normalize(v_add(v_sub(refractedDir, v_scale(dwody, eta)), v_add(v_scale(dndy, mu), v_scale(n, dmudy))));
 }
@@ -982,7 +982,7 @@ static inline int intersectTri(const float *v0, const float *e1, const float *e2
     const float det = v_dot(E1, pvec);
     if (!(det != 0.0f))
         return 0;
-    const float inv = 1.0f / det;
+    const float inv = pto_div(1.0f, det);
     /* Two passes (see pt_device.hpp): plain Moeller-Trumbore from the ray origin loses (|o - v0| / size)^2 ulps in the
      * barycentrics but its t is good; pass 1 solves from o with loose bounds on (u, v), pass 2 again from o + t1 d. */
     v3 tvec = v_sub(o, V0);
@@ -1471,7 +1471,7 @@ static inline v4 v4_lerp(v4 a, v4 b, float t)
 static inline uint32_t wrapRepeat(float x0, uint32_t n)
 {
     const float fn = (float)n;
-    float m = x0 - floorf(x0 / fn) * fn;
+    float m = x0 - floorf(pto_div(x0, fn)) * fn;
     if (!(m >= 0.0f)) m = 0.0f;
     uint32_t i = (uint32_t)m;
     return i >= n ? n - 1 : i;
@@ -1523,10 +1523,10 @@ static v4 textureGradSample(const PtoScene *s, const OTexture *t, float u, float
     const float rmax = f_max(rx, ry), rmin = f_min(rx, ry);
     float eta = 1.0f;
     if (rmax > 0.0f && rmax < 3.0e38f) /* finite footprint: otherwise a single tap */
-        eta = rmin > 0.0f ? f_min(rmax / rmin, PTO_MAX_ANISOTROPY) : PTO_MAX_ANISOTROPY;
+        eta = rmin > 0.0f ? f_min(pto_div(rmax, rmin), PTO_MAX_ANISOTROPY) : PTO_MAX_ANISOTROPY;
     if (!(eta >= 1.0f)) eta = 1.0f;
     const float n = ceilf(eta);
-    const float rho = rmax / eta;
+    const float rho = pto_div(rmax, eta);
     const float lod = rho > 0.0f ? (float)pto_log2((double)rho) : 0.0f;
     if (n <= 1.0f || lod >= (float)(t->levels - 1)) /* every tap would read the 1x1 top level: one tap */
         return trilinearSample(s, t, lod, u, v);
@@ -1535,11 +1535,12 @@ static v4 textureGradSample(const PtoScene *s, const OTexture *t, float u, float
     const int taps = (int)n;
     for (int i = 1; i <= taps; i++)
     {
-        const float w = (float)i / (n + 1.0f) - 0.5f;
+        const float w = pto_div((float)i, n + 1.0f) - 0.5f;
         const v4 c = trilinearSample(s, t, lod, u + du * w, v + dv * w);
         sum.x += c.x; sum.y += c.y; sum.z += c.z; sum.w += c.w;
     }
-    sum.x /= n; sum.y /= n; sum.z /= n; sum.w /= n;
+    const float rn = pto_rcp(n);
+    sum.x *= rn; sum.y *= rn; sum.z *= rn; sum.w *= rn;
     return sum;
 }
 
@@ -1834,8 +1835,8 @@ typedef struct MaterialTexels
 
 static inline v3 specGlossMetalness(v3 specular, v3 color) /* material.glsl:109-110, :138-139 */
 {
-    return V3(f_max(specular.x - 0.04f, 0.0f) / ((color.x - 0.04f) + 0.00001f), f_max(specular.y - 0.04f, 0.0f) / ((color.y - 0.04f) + 0.00001f),
-              f_max(specular.z - 0.04f, 0.0f) / ((color.z - 0.04f) + 0.00001f));
+    return V3(pto_div(f_max(specular.x - 0.04f, 0.0f), (color.x - 0.04f) + 0.00001f), pto_div(f_max(specular.y - 0.04f, 0.0f), (color.y - 0.04f) + 0.00001f),
+              pto_div(f_max(specular.z - 0.04f, 0.0f), (color.z - 0.04f) + 0.00001f));
 }
 
 /* material.glsl:62-84 as a function of the texels its textureGrad calls return */
@@ -1851,7 +1852,7 @@ static MaterialSample sampleMaterialMR(const PtxMetallicRoughnessMaterial *m, co
     ret.Transmission = m->Transmission;
     ret.AttenuationColor = V3(m->AttenuationColor[0], m->AttenuationColor[1], m->AttenuationColor[2]);
     ret.AttenuationDistance = m->AttenuationDistance;
-    ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
+    ret.Eta = isHitFromInside ? m->Ior : (pto_div(1.0f, m->Ior));
     return ret;
 }
 
@@ -1866,12 +1867,12 @@ static MaterialSample sampleMaterialSG(const PtxSpecularGlossinessMaterial *m, c
     ret.Transmission = m->Transmission;
     ret.AttenuationColor = V3(m->AttenuationColor[0], m->AttenuationColor[1], m->AttenuationColor[2]);
     ret.AttenuationDistance = m->AttenuationDistance;
-    ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
+    ret.Eta = isHitFromInside ? m->Ior : (pto_div(1.0f, m->Ior));
     const v3 specular = v_mul(rgb(t->a), V3(m->Specular[0], m->Specular[1], m->Specular[2]));
     const float glossiness = t->b.w * m->Glossiness;
     ret.Roughness = 1.0f - glossiness;
     const v3 diff = specGlossMetalness(specular, ret.Color);
-    ret.Metalness = (diff.x + diff.y + diff.z) / 3.0f;
+    ret.Metalness = pto_div(diff.x + diff.y + diff.z, 3.0f);
     return ret;
 }
 
@@ -1886,12 +1887,12 @@ static MaterialSample sampleMaterialPhong(const PtxPhongMaterial *m, const Mater
     ret.Transmission = m->Transmission;
     ret.AttenuationColor = V3(m->AttenuationColor[0], m->AttenuationColor[1], m->AttenuationColor[2]);
     ret.AttenuationDistance = m->AttenuationDistance;
-    ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
+    ret.Eta = isHitFromInside ? m->Ior : (pto_div(1.0f, m->Ior));
     const v3 specular = v_mul(rgb(t->a), V3(m->Specular[0], m->Specular[1], m->Specular[2]));
     const float shininess = t->b.w * m->Shininess;
     ret.Roughness = 1.0f - shininess;
     const v3 diff = specGlossMetalness(specular, ret.Color);
-    ret.Metalness = (diff.x + diff.y + diff.z) / 3.0f;
+    ret.Metalness = pto_div(diff.x + diff.y + diff.z, 3.0f);
     return ret;
 }
 
@@ -2077,7 +2078,7 @@ static void closestHit(const PtoScene *s, const PtxLightsUbo *lights, v3 rayOrig
 
     if (isHitFromInside) /* :123-128 Beer-Lambert over this segment */
     {
-        const float e = hit->t / material.AttenuationDistance;
+        const float e = pto_div(hit->t, material.AttenuationDistance);
         bsdf.Color.x *= pto_powf(material.AttenuationColor.x, e);
         bsdf.Color.y *= pto_powf(material.AttenuationColor.y, e);
         bsdf.Color.z *= pto_powf(material.AttenuationColor.z, e);
@@ -2150,8 +2151,8 @@ static inline v2 missSkyboxTexCoords(v3 dir)
     const float longitude = pto_atan2f(dir.z, dir.x);
     const float latitude = pto_asinf(-dir.y);
     v2 uv;
-    uv.x = longitude / 2.0f / PI + 0.5f;
-    uv.y = latitude / PI + 0.5f;
+    uv.x = pto_div(pto_div(longitude, 2.0f), PI) + 0.5f;
+    uv.y = pto_div(latitude, PI) + 0.5f;
     return uv;
 }
 
@@ -2192,7 +2193,7 @@ static v4 cubeTexel(const PtoScene *s, const OTexture *faces, uint32_t face, int
     const int n = (int)faces[face].width;
     if (ix >= 0 && ix < n && iy >= 0 && iy < n)
         return fetchTexel(s, &faces[face], 0, (uint32_t)ix, (uint32_t)iy);
-    float sc = 2.0f * (((float)ix + 0.5f) / (float)n) - 1.0f, tc = 2.0f * (((float)iy + 0.5f) / (float)n) - 1.0f, ma = 1.0f;
+    float sc = 2.0f * (pto_div((float)ix + 0.5f, (float)n)) - 1.0f, tc = 2.0f * (pto_div((float)iy + 0.5f, (float)n)) - 1.0f, ma = 1.0f;
     if (ix < 0 || ix >= n)
     {
         ma = 1.0f - (fabsf(sc) - 1.0f);
@@ -2217,8 +2218,8 @@ static v4 cubeTexel(const PtoScene *s, const OTexture *faces, uint32_t face, int
     float s2, t2, m2;
     cubeFace(r, &f2, &s2, &t2, &m2);
     const float mx = (float)(n - 1);
-    const uint32_t jx = (uint32_t)f_clamp(floorf((0.5f * (s2 / m2) + 0.5f) * (float)n), 0.0f, mx);
-    const uint32_t jy = (uint32_t)f_clamp(floorf((0.5f * (t2 / m2) + 0.5f) * (float)n), 0.0f, mx);
+    const uint32_t jx = (uint32_t)f_clamp(floorf((0.5f * (pto_div(s2, m2)) + 0.5f) * (float)n), 0.0f, mx);
+    const uint32_t jy = (uint32_t)f_clamp(floorf((0.5f * (pto_div(t2, m2)) + 0.5f) * (float)n), 0.0f, mx);
     return fetchTexel(s, &faces[f2], 0, jx, jy);
 }
 
@@ -2264,7 +2265,7 @@ static v4 sampleCube(const PtoScene *s, const OTexture *faces, v3 r)
     uint32_t face;
     float sc, tc, ma;
     cubeFace(r, &face, &sc, &tc, &ma);
-    const float u = 0.5f * (sc / ma) + 0.5f, v = 0.5f * (tc / ma) + 0.5f;
+    const float u = 0.5f * (pto_div(sc, ma)) + 0.5f, v = 0.5f * (pto_div(tc, ma)) + 0.5f;
     return sampleFaceSeamless(s, faces, face, u, v);
 }
 
@@ -2514,8 +2515,8 @@ int pto_render(const PtoScene *s, const PtxRaygenUniformData *U, const PtxLights
 /* Function-level entry (packing documented in include/ptx.h)               */
 /* ======================================================================== */
 
-static const int kInStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4, 3, 3, 2, 6, 7, 3, 47 };
-static const int kOutStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1, 2, 3, 2, 6, 3, 3, 17 };
+static const int kInStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4, 3, 3, 2, 6, 7, 3, 47, 2, 1 };
+static const int kOutStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1, 2, 3, 2, 6, 3, 3, 17, 2, 1 };
 
 static MaterialSample unpackMaterial(const float *p)
 {
@@ -2733,6 +2734,11 @@ int pto_test_eval(uint32_t fn, const float *in, float *out, uint32_t n)
             o[0] = pto_atan2f(a[0], a[1]);
             o[1] = pto_asinf(a[0]);
             break;
+        case PTX_FN_DIVIDE:
+            o[0] = pto_rcp(a[1]);
+            o[1] = pto_div(a[0], a[1]);
+            break;
+        case PTX_FN_SQRT: o[0] = sqrtf(a[0]); break;
         case PTX_FN_COMPUTE_LOD: {
             v4 dv = { a[0], a[1], a[2], a[3] };
             o[0] = computeLod(dv);

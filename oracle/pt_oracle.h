@@ -30,11 +30,15 @@
  * Arithmetic conventions (GLSL leaves these implementation-defined; both this oracle
  * and the HIP kernels fix them identically so images can be compared bit-for-bit):
  *   - IEEE binary32, round-to-nearest, no contraction (-ffp-contract=off), fma only
- *     where the GLSL says fma();
+ *     where the GLSL says fma(); sqrt correctly rounded;
+ *   - every division of the shader path is a * rcp(b) with rcp the correctly rounded
+ *     reciprocal on [2^-126, 2^126] and flushed outside (pto_rcp, pt_oracle_math.h: inside
+ *     GLSL's 2.5-ULP latitude; round 5 -- it was the correctly rounded quotient before);
+ *     a vector / scalar is one reciprocal and three products;
  *   - dot(a,b) = (a.x*b.x + a.y*b.y) + a.z*b.z;  length = sqrt(dot);
- *     normalize(v) = v * (1/sqrt(dot(v,v)));  cross, reflect, refract, mix, clamp as
+ *     normalize(v) = v * rcp(sqrt(dot(v,v)));  cross, reflect, refract, mix, clamp as
  *     in the GLSL 4.60 spec 8.5; mat3*vec3 = (c0*x + c1*y) + c2*z; inverse(mat3) by
- *     cofactors * (1/det);
+ *     cofactors * rcp(det);
  *   - pow(x,2) = x*x, pow(x,5) = x2*x2*x; general pow/sin/cos by the fixed polynomial
  *     kernels pto_powf / pto_sincosf below.
  */

@@ -23,13 +23,35 @@ static inline float f_clamp(float x, float lo, float hi) { return f_min(f_max(x,
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
+/* ---- the specified division (arithmetic conventions, pt_oracle.h) ----
+ * GLSL leaves `/` to the implementation within 2.5 ULP for divisors in [2^-126, 2^126] and lets denormals be flushed
+ * (Vulkan 1.3 spec, "Precision and Operation of SPIR-V Instructions").  Every division of the shader path is
+ *     a / b  :=  a * rcp(b),      rcp(b) = the correctly rounded reciprocal RN(1 / b) for 2^-126 <= |b| <= 2^126,
+ *                                          +-inf for |b| < 2^-126 (zero and denormal divisors), +-0 for |b| > 2^126, NaN for NaN
+ * -- two roundings, <= 1.5 ULP.  On the device that is v_rcp_f32 + one FMA Newton step (5 VALU instead of the 11 of a
+ * correctly rounded quotient; a vector / scalar is ONE reciprocal and three multiplies); the step makes the result independent
+ * of the hardware seed: device == this definition on all 2^32 inputs (tools/experiments/rcp_sqrt_exhaustive.hip,
+ * profiles/r05_rcp_sqrt_exhaustive.txt; tests/test_gpu_parity.py::test_specified_reciprocal_on_all_inputs). */
+static inline float pto_rcp(float x)
+{
+    const float ax = fabsf(x);
+    if (x != x)
+        return x;
+    if (ax < 1.17549435e-38f) /* 2^-126 */
+        return copysignf(INFINITY, x);
+    if (ax > 8.50705917e37f) /* 2^126 */
+        return copysignf(0.0f, x);
+    return 1.0f / x;
+}
+static inline float pto_div(float a, float b) { return a * pto_rcp(b); }
+
 static inline v3 V3(float x, float y, float z) { v3 r = { x, y, z }; return r; }
 static inline v3 v3s(float s) { return V3(s, s, s); }
 static inline v3 v_add(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
 static inline v3 v_sub(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
 static inline v3 v_mul(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
 static inline v3 v_scale(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
-static inline v3 v_div(v3 a, float s) { return V3(a.x / s, a.y / s, a.z / s); }
+static inline v3 v_div(v3 a, float s) { const float r = pto_rcp(s); return V3(a.x * r, a.y * r, a.z * r); }
 static inline v3 v_neg(v3 a) { return V3(-a.x, -a.y, -a.z); }
 static inline float v_dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 static inline v3 v_cross(v3 a, v3 b)
@@ -37,7 +59,7 @@ static inline v3 v_cross(v3 a, v3 b)
     return V3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
 }
 static inline float v_length(v3 a) { return sqrtf(v_dot(a, a)); }
-static inline v3 v_normalize(v3 a) { return v_scale(a, 1.0f / sqrtf(v_dot(a, a))); }
+static inline v3 v_normalize(v3 a) { return v_scale(a, pto_rcp(sqrtf(v_dot(a, a)))); }
 /* reflect(I, N) = I - 2 * dot(N, I) * N */
 static inline v3 v_reflect(v3 I, v3 N) { return v_sub(I, v_scale(N, 2.0f * v_dot(N, I))); }
 /* refract(I, N, eta), GLSL 4.60 8.5 */
@@ -65,7 +87,7 @@ static inline m3 m3_inverse(m3 m)
     const float m10 = m.c1.x, m11 = m.c1.y, m12 = m.c1.z;
     const float m20 = m.c2.x, m21 = m.c2.y, m22 = m.c2.z;
     const float det = (m00 * (m11 * m22 - m21 * m12) - m10 * (m01 * m22 - m21 * m02)) + m20 * (m01 * m12 - m11 * m02);
-    const float id = 1.0f / det;
+    const float id = pto_rcp(det);
     m3 r;
     r.c0.x = (m11 * m22 - m21 * m12) * id;
     r.c1.x = -(m10 * m22 - m20 * m12) * id;

@@ -41,10 +41,10 @@ void pto_postprocess_pixel(v3 accColor, const PtxPostProcessingUniformData *u, v
     const float knee = 0.5f;
     const float threshold = u->BloomThreshold;
     const float br = f_max(color.x, f_max(color.y, color.z));
-    const v3 curve = V3(threshold - knee, knee * 2.0f, 0.25f / knee);
+    const v3 curve = V3(threshold - knee, knee * 2.0f, pto_div(0.25f, knee));
     float rq = f_clamp(br - curve.x, 0.0f, curve.y);
     rq = curve.z * rq * rq;
-    *bloomOut = v_scale(color, f_max(rq, br - threshold) / f_max(br, 0.0001f));
+    *bloomOut = v_scale(color, pto_div(f_max(rq, br - threshold), f_max(br, 0.0001f)));
     *colorOut = color;
 }
 
@@ -86,12 +86,12 @@ static inline v3 add4(v3 a, v3 b, v3 c, v3 d) { return v_add(v_add(v_add(a, b), 
 /* bloomDownsample.comp:18-62 */
 static void bloomDownsample(const Level *src, Level *dst)
 {
-    const float tx = 1.0f / (float)src->w, ty = 1.0f / (float)src->h;
+    const float tx = pto_div(1.0f, (float)src->w), ty = pto_div(1.0f, (float)src->h);
 #pragma omp parallel for schedule(static)
     for (int64_t yy = 0; yy < (int64_t)dst->h; yy++)
         for (uint32_t xx = 0; xx < dst->w; xx++)
         {
-            const float u = ((float)xx + 0.5f) / (float)dst->w, v = ((float)yy + 0.5f) / (float)dst->h;
+            const float u = pto_div((float)xx + 0.5f, (float)dst->w), v = pto_div((float)yy + 0.5f, (float)dst->h);
             const v3 a = bloomTap(src, u + -2.0f * tx, v + 2.0f * ty), b = bloomTap(src, u + 0.0f * tx, v + 2.0f * ty),
                      c = bloomTap(src, u + 2.0f * tx, v + 2.0f * ty);
             const v3 d = bloomTap(src, u + -2.0f * tx, v + 0.0f * ty), e = bloomTap(src, u + 0.0f * tx, v + 0.0f * ty),
@@ -113,12 +113,12 @@ static void bloomDownsample(const Level *src, Level *dst)
 /* bloomUpsample.comp:18-55: 3x3 tent of the smaller level added onto the larger one */
 static void bloomUpsample(const Level *src, Level *dst)
 {
-    const float x = 1.0f / (float)src->w, y = 1.0f / (float)src->h;
+    const float x = pto_div(1.0f, (float)src->w), y = pto_div(1.0f, (float)src->h);
 #pragma omp parallel for schedule(static)
     for (int64_t yy = 0; yy < (int64_t)dst->h; yy++)
         for (uint32_t xx = 0; xx < dst->w; xx++)
         {
-            const float u = ((float)xx + 0.5f) / (float)dst->w, v = ((float)yy + 0.5f) / (float)dst->h;
+            const float u = pto_div((float)xx + 0.5f, (float)dst->w), v = pto_div((float)yy + 0.5f, (float)dst->h);
             const v3 a = bloomTap(src, u + -x, v + y), b = bloomTap(src, u + 0.0f, v + y), c = bloomTap(src, u + x, v + y);
             const v3 d = bloomTap(src, u + -x, v + 0.0f), e = bloomTap(src, u + 0.0f, v + 0.0f), f = bloomTap(src, u + x, v + 0.0f);
             const v3 g = bloomTap(src, u + -x, v + -y), h = bloomTap(src, u + 0.0f, v + -y), i = bloomTap(src, u + x, v + -y);

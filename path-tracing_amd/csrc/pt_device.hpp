@@ -38,19 +38,50 @@ PT_DEV f3 operator+(f3 a, f3 b) { return F3(a.x + b.x, a.y + b.y, a.z + b.z); }
 PT_DEV f3 operator-(f3 a, f3 b) { return F3(a.x - b.x, a.y - b.y, a.z - b.z); }
 PT_DEV f3 operator*(f3 a, f3 b) { return F3(a.x * b.x, a.y * b.y, a.z * b.z); }
 PT_DEV f3 operator*(f3 a, float s) { return F3(a.x * s, a.y * s, a.z * s); }
-PT_DEV f3 operator/(f3 a, float s) { return F3(a.x / s, a.y / s, a.z / s); }
+// The specified division (arithmetic conventions): a / b := a * rcp_(b), rcp_ = the correctly rounded reciprocal
+// on [2^-126, 2^126], +-inf below (zero and denormal divisors), +-0 above.  v_rcp_f32 (1 ULP, flushes denormals both ways) + one FMA
+// Newton step = that definition on all 2^32 inputs (profiles/r05_rcp_sqrt_exhaustive.txt, test_specified_reciprocal_on_all_inputs);
+// the select keeps the seed where the step would produce NaN (x = 0, inf, denormal).  5 VALU; hipcc's IEEE quotient is 11.
+PT_DEV float rcp_(float x)
+{
+    const float r0 = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r0, 1.0f);
+    const float r1 = __builtin_fmaf(r0, e, r0);
+    return __builtin_fabsf(e) < 1.0f ? r1 : r0;
+}
+PT_DEV float div_(float a, float b) { return a * rcp_(b); }
+PT_DEV f3 operator/(f3 a, float s) { const float r = rcp_(s); return F3(a.x * r, a.y * r, a.z * r); }
 PT_DEV f3 operator-(f3 a) { return F3(-a.x, -a.y, -a.z); }
 
 PT_DEV float fmin_(float a, float b) { return (b < a) ? b : a; } // GLSL min
 PT_DEV float fmax_(float a, float b) { return (a < b) ? b : a; } // GLSL max
 PT_DEV float clamp_(float x, float lo, float hi) { return fmin_(fmax_(x, lo), hi); }
 PT_DEV float abs_(float x) { return __builtin_fabsf(x); }
-PT_DEV float sqrt_(float x) { return __builtin_sqrtf(x); } // correctly rounded (hipcc default)
+// Correctly rounded square root (IEEE; the oracle's sqrtf).  hipcc's expansion is 16 VALU, five of them a power-of-two scaling
+// that only matters for |x| < 2^-96, where the residuals below would underflow.  Here: v_sqrt_f32 (1 ULP) and the two-neighbour
+// residual test (exact FMAs), 10 VALU, behind ONE wave-uniform branch that sends a wave holding a tiny non-zero or zero argument
+// through hipcc's sequence instead (rare: the arguments are squared lengths and 1 - cos^2 terms).  Equal to __builtin_sqrtf on all
+// 2^32 inputs (tools/experiments/rcp_sqrt_exhaustive.hip).
+PT_DEV float sqrt_(float x)
+{
+#ifdef PTX_IEEE_SQRT_BUILTIN
+    return __builtin_sqrtf(x);
+#else
+    if (__builtin_amdgcn_ballot_w64(__builtin_fabsf(x) < 1.262177448e-29f) != 0) // 2^-96
+        return __builtin_sqrtf(x);
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
+    float r = rm <= 0.0f ? sm : s;
+    r = rp > 0.0f ? sp : r;
+    return r;
+#endif
+}
 
 PT_DEV float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 PT_DEV f3 cross(f3 a, f3 b) { return F3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
 PT_DEV float length(f3 a) { return sqrt_(dot(a, a)); }
-PT_DEV f3 normalize(f3 a) { return a * (1.0f / sqrt_(dot(a, a))); }
+PT_DEV f3 normalize(f3 a) { return a * rcp_(sqrt_(dot(a, a))); }
 PT_DEV f3 reflect(f3 I, f3 N) { return I - N * (2.0f * dot(N, I)); }
 PT_DEV f3 refract(f3 I, f3 N, float eta)
 {
@@ -74,7 +105,7 @@ PT_DEV mat3 inverse(const mat3 &m)
     const float m10 = m.c1.x, m11 = m.c1.y, m12 = m.c1.z;
     const float m20 = m.c2.x, m21 = m.c2.y, m22 = m.c2.z;
     const float det = (m00 * (m11 * m22 - m21 * m12) - m10 * (m01 * m22 - m21 * m02)) + m20 * (m01 * m12 - m11 * m02);
-    const float id = 1.0f / det;
+    const float id = rcp_(det);
     mat3 r;
     r.c0.x = (m11 * m22 - m21 * m12) * id;
     r.c1.x = -(m10 * m22 - m20 * m12) * id;
@@ -306,14 +337,14 @@ PT_DEV f2 sampleUniformDiskConcentric(f2 u) // :168-184
     float s, c;
     if (abs_(offset.x) > abs_(offset.y))
     {
-        const float theta = (PT_PI / 4) * (offset.y / offset.x);
+        const float theta = (div_(PT_PI, 4)) * (div_(offset.y, offset.x));
         sincos_(theta, s, c);
         r.x = offset.x * c;
         r.y = offset.x * s;
     }
     else
     {
-        const float theta = PT_PI / 2 - (PT_PI / 4) * (offset.x / offset.y);
+        const float theta = div_(PT_PI, 2) - (div_(PT_PI, 4)) * (div_(offset.x, offset.y));
         sincos_(theta, s, c);
         r.x = offset.y * c;
         r.y = offset.y * s;
@@ -349,9 +380,9 @@ PT_DEV float GGXDistribution(f3 H, float alpha) // :3-14 (D clamped to <= 1: kep
     const float Hy2 = H.y * H.y;
     const float Hz2 = H.z * H.z;
     const float alpha2 = alpha * alpha;
-    const float b = Hx2 / alpha2 + Hy2 / alpha2 + Hz2;
+    const float b = div_(Hx2, alpha2) + div_(Hy2, alpha2) + Hz2;
     const float denom = PT_PI * alpha2 * (b * b);
-    return 1.0f / fmax_(denom, 1.0f);
+    return div_(1.0f, fmax_(denom, 1.0f));
 }
 
 PT_DEV float Lambda(f3 V, float alpha) // :16-27
@@ -360,11 +391,11 @@ PT_DEV float Lambda(f3 V, float alpha) // :16-27
     const float Vy2 = V.y * V.y;
     const float Vz2 = abs_(V.z) * abs_(V.z);
     const float alpha2 = alpha * alpha;
-    const float nom = sqrt_(1.0f + (alpha2 * Vx2 + alpha2 * Vy2) / Vz2) - 1.0f;
-    return nom / 2.0f;
+    const float nom = sqrt_(1.0f + div_(alpha2 * Vx2 + alpha2 * Vy2, Vz2)) - 1.0f;
+    return div_(nom, 2.0f);
 }
 
-PT_DEV float GGXSmith(f3 V, float alpha) { return 1.0f / (1.0f + Lambda(V, alpha)); } // :29-32
+PT_DEV float GGXSmith(f3 V, float alpha) { return div_(1.0f, 1.0f + Lambda(V, alpha)); } // :29-32
 
 PT_DEV float DielectricFresnel(float VdotH, float eta) // :34-48
 {
@@ -373,9 +404,9 @@ PT_DEV float DielectricFresnel(float VdotH, float eta) // :34-48
     if (sinThetaT2 > 1.0f)
         return 1.0f;
     const float cosThetaT = sqrt_(fmax_(1.0f - sinThetaT2, 0.0f));
-    const float rs = (eta * cosThetaT - cosThetaI) / (eta * cosThetaT + cosThetaI);
-    const float rp = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
-    return (rs * rs + rp * rp) / 2.0f;
+    const float rs = div_(eta * cosThetaT - cosThetaI, eta * cosThetaT + cosThetaI);
+    const float rp = div_(eta * cosThetaI - cosThetaT, eta * cosThetaI + cosThetaT);
+    return div_(rs * rs + rp * rp, 2.0f);
 }
 
 PT_DEV float SchlickFresnel(float VdotH) // :50-53
@@ -398,8 +429,8 @@ PT_DEV f3 EvaluateReflection(f3 V, f3 L, f3 F, float alpha, float &pdf) // :56-7
     const float Gv = GGXSmith(V, alpha);
     const float Gl = GGXSmith(L, alpha);
     const float G = Gv * Gl;
-    const float Dv = (Gv * fmax_(VdotH, 0.0f) * D) / V.z;
-    pdf = Dv / (4.0f * VdotH);
+    const float Dv = div_(Gv * fmax_(VdotH, 0.0f) * D, V.z);
+    pdf = div_(Dv, 4.0f * VdotH);
     return (F * (D * G)) / (4.0f * V.z);
 }
 
@@ -419,18 +450,18 @@ PT_DEV f3 EvaluateRefraction(f3 V, f3 L, f3 F, float alpha, float eta, float &pd
     const float Gv = GGXSmith(V, alpha);
     const float Gl = GGXSmith(L, alpha);
     const float G = Gv * Gl;
-    const float Dv = (Gv * abs_(VdotH) * D) / V.z;
+    const float Dv = div_(Gv * abs_(VdotH) * D, V.z);
     const float denominator = LdotH + eta * VdotH;
-    const float jacobian = ((eta * eta) * abs_(LdotH)) / (denominator * denominator);
+    const float jacobian = div_((eta * eta) * abs_(LdotH), denominator * denominator);
     pdf = Dv * jacobian;
-    return ((F * (D * G)) * (abs_(VdotH) / abs_(V.z))) * jacobian;
+    return ((F * (D * G)) * (div_(abs_(VdotH), abs_(V.z)))) * jacobian;
 }
 
 PT_DEV f3 SampleGGX(f2 u, f3 V, float alpha) // :111-129
 {
     const f3 Vh = normalize(F3(alpha * V.x, alpha * V.y, abs_(V.z)));
     const float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
-    const f3 T1 = lensq > 0 ? F3(-Vh.y, Vh.x, 0) * (1.0f / sqrt_(lensq)) : F3(1, 0, 0);
+    const f3 T1 = lensq > 0 ? F3(-Vh.y, Vh.x, 0) * (div_(1.0f, sqrt_(lensq))) : F3(1, 0, 0);
     const f3 T2 = cross(Vh, T1);
     const float r = sqrt_(u.x);
     const float phi = 2.0f * PT_PI * u.y;
@@ -484,7 +515,7 @@ PT_DEV f3 evaluateBSDF(const MaterialSample &m, f3 V, f3 L, float &outPdf) // :7
     if (isReflection)
     {
         // evaluateDiffuseBRDF, :11-15
-        pdf = L.z * 1.0f / PT_PI;
+        pdf = div_(L.z * 1.0f, PT_PI);
         bsdf = bsdf + ((m.Color * L.z) / PT_PI) * pDiffuse;
         outPdf += pdf * pDiffuse;
         // evaluateGlossyBSDF, :22-25
@@ -544,8 +575,8 @@ PT_DEV BSDFSample sampleBSDF(const MaterialSample &m, f3 V, uint32_t &rngState) 
 
 PT_DEV f3 pinholeDirection(float pcx, float pcy, uint32_t resX, uint32_t resY, const float *ViewInverse, const float *ProjInverse) // :64-65,72-73
 {
-    const float inUVx = pcx / (float)resX;
-    const float inUVy = pcy / (float)resY;
+    const float inUVx = div_(pcx, (float)resX);
+    const float inUVy = div_(pcy, (float)resY);
     const float dx = inUVx * 2.0f - 1.0f;
     const float dy = inUVy * 2.0f - 1.0f;
     const f4 target = mul4(ProjInverse, dx, dy, 1, 1);
@@ -580,12 +611,12 @@ PT_DEV void constructPrimaryRay(uint32_t px, uint32_t py, uint32_t resX, uint32_
 PT_DEV f3 lensDirection(float pcx, float pcy, uint32_t resX, uint32_t resY, const float *ViewInverse, const float *ProjInverse,
                         f3 originCameraSpace, float focalDistance) // :24-25,35-38
 {
-    const float inUVx = pcx / (float)resX;
-    const float inUVy = pcy / (float)resY;
+    const float inUVx = div_(pcx, (float)resX);
+    const float inUVy = div_(pcy, (float)resY);
     const float dx = inUVx * 2.0f - 1.0f;
     const float dy = inUVy * 2.0f - 1.0f;
     const f4 target = mul4(ProjInverse, dx, dy, 1, 1);
-    const float ft = focalDistance / target.z;
+    const float ft = div_(focalDistance, target.z);
     const f3 pFocus = F3(target.x, target.y, target.z) * ft;
     const f3 nd = normalize(pFocus - originCameraSpace);
     const f4 d = mul4(ViewInverse, nd.x, nd.y, nd.z, 0);
@@ -668,7 +699,7 @@ PT_DEV LightSample sampleLight(const PtxLightsUbo *ubo, f3 u, f3 position, float
 {
     const uint32_t lightCount = ubo->LightCount;
     const uint32_t lightIndex = (uint32_t)(u.x * (float)(lightCount + 1));
-    pdf = 1.0f / (float)(lightCount + 1);
+    pdf = div_(1.0f, (float)(lightCount + 1));
     LightSample ret;
     f2 uyz;
     uyz.x = u.y;
@@ -693,8 +724,8 @@ PT_DEV LightSample sampleLight(const PtxLightsUbo *ubo, f3 u, f3 position, float
     ret.Distance = length(position - newPosition);
     ret.Direction = normalize(position - newPosition);
     ret.Color = F3(light->Color[0], light->Color[1], light->Color[2]);
-    const float attenuation = 1.0f / (light->AttenuationConstant + ret.Distance * light->AttenuationLinear +
-                                      ret.Distance * ret.Distance * light->AttenuationQuadratic);
+    const float attenuation = div_(1.0f, light->AttenuationConstant + ret.Distance * light->AttenuationLinear +
+                                         ret.Distance * ret.Distance * light->AttenuationQuadratic);
     ret.Attenuation = clamp_(attenuation, 0.0f, 1.0f);
     return ret;
 }
@@ -720,7 +751,7 @@ PT_DEV void computeDpnDuv(const f3 *p, const f3 *n, const f2 *uv, f3 vtxTangent,
     }
     else
     {
-        const float invDet = 1.0f / det;
+        const float invDet = div_(1.0f, det);
         dpdu = (e1 * dv2 - e2 * dv1) * invDet;
         dpdv = (e1 * (-du2) + e2 * du1) * invDet;
         dndu = (en1 * dv2 - en2 * dv1) * invDet;
@@ -731,9 +762,9 @@ PT_DEV void computeDpnDuv(const f3 *p, const f3 *n, const f2 *uv, f3 vtxTangent,
 PT_DEV void computeDpDxy(f3 p, f3 rxOrigin, f3 rxDirection, f3 ryOrigin, f3 ryDirection, f3 n, f3 &dpdx, f3 &dpdy) // :31-41
 {
     const float d = -dot(n, p);
-    const float tx = (-dot(n, rxOrigin) - d) / dot(n, rxDirection);
+    const float tx = div_(-dot(n, rxOrigin) - d, dot(n, rxDirection));
     const f3 px = rxOrigin + rxDirection * tx;
-    const float ty = (-dot(n, ryOrigin) - d) / dot(n, ryDirection);
+    const float ty = div_(-dot(n, ryOrigin) - d, dot(n, ryDirection));
     const f3 py = ryOrigin + ryDirection * ty;
     dpdx = px - p;
     dpdy = py - p;
@@ -754,7 +785,7 @@ PT_DEV f4 computeDerivatives(f3 dpdx, f3 dpdy, f3 dpdu, f3 dpdv) // :53-78
     const float ata00 = dot(dpdu, dpdu);
     const float ata01 = dot(dpdu, dpdv);
     const float ata11 = dot(dpdv, dpdv);
-    float invDet = 1 / differenceOfProducts(ata00, ata11, ata01, ata01);
+    float invDet = div_(1, differenceOfProducts(ata00, ata11, ata01, ata01));
     invDet = __builtin_isinf(invDet) ? 0.0f : invDet;
     const float atb0x = dot(dpdu, dpdx);
     const float atb1x = dot(dpdv, dpdx);
@@ -779,9 +810,9 @@ PT_DEV void computeReflectedDifferentialRays(f4 derivatives, f3 n, f3 p, f3 view
     const f3 dndx = dndu * dudx + dndv * dvdx;
     const f3 dndy = dndu * dudy + dndv * dvdy;
     const float d = -dot(n, p);
-    const float tx = (-dot(n, r.rxOrigin) - d) / dot(n, r.rxDirection);
+    const float tx = div_(-dot(n, r.rxOrigin) - d, dot(n, r.rxDirection));
     const f3 px = r.rxOrigin + r.rxDirection * tx;
-    const float ty = (-dot(n, r.ryOrigin) - d) / dot(n, r.ryDirection);
+    const float ty = div_(-dot(n, r.ryOrigin) - d, dot(n, r.ryDirection));
     const f3 py = r.ryOrigin + r.ryDirection * ty;
     const f3 dwodx = -r.rxDirection - viewDir;
     const f3 dwody = -r.ryDirection - viewDir;
@@ -801,9 +832,9 @@ PT_DEV void computeRefractedDifferentialRays(f4 derivatives, f3 n, f3 p, f3 view
     f3 dndx = dndu * dudx + dndv * dvdx;
     f3 dndy = dndu * dudy + dndv * dvdy;
     const float d = -dot(n, p);
-    const float tx = (-dot(n, r.rxOrigin) - d) / dot(n, r.rxDirection);
+    const float tx = div_(-dot(n, r.rxOrigin) - d, dot(n, r.rxDirection));
     const f3 px = r.rxOrigin + r.rxDirection * tx;
-    const float ty = (-dot(n, r.ryOrigin) - d) / dot(n, r.ryDirection);
+    const float ty = div_(-dot(n, r.ryOrigin) - d, dot(n, r.ryDirection));
     const f3 py = r.ryOrigin + r.ryDirection * ty;
     const f3 dwodx = -r.rxDirection - viewDir;
     const f3 dwody = -r.ryDirection - viewDir;
@@ -817,9 +848,9 @@ PT_DEV void computeRefractedDifferentialRays(f4 derivatives, f3 n, f3 p, f3 view
     }
     const float dwoDotn_dx = dot(dwodx, n) + dot(viewDir, dndx);
     const float dwoDotn_dy = dot(dwody, n) + dot(viewDir, dndy);
-    const float mu = dot(viewDir, n) / eta - abs_(dot(refractedDir, n));
-    const float dmudx = dwoDotn_dx * (1.0f / eta + 1.0f / (eta * eta) * dot(viewDir, n) / dot(refractedDir, n));
-    const float dmudy = dwoDotn_dy * (1.0f / eta + 1.0f / (eta * eta) * dot(viewDir, n) / dot(refractedDir, n));
+    const float mu = div_(dot(viewDir, n), eta) - abs_(dot(refractedDir, n));
+    const float dmudx = dwoDotn_dx * (div_(1.0f, eta) + div_(div_(1.0f, eta * eta) * dot(viewDir, n), dot(refractedDir, n)));
+    const float dmudy = dwoDotn_dy * (div_(1.0f, eta) + div_(div_(1.0f, eta * eta) * dot(viewDir, n), dot(refractedDir, n)));
     r.rxDirection = normalize((refractedDir - dwodx * eta) + (dndx * mu + n * dmudx));
     r.ryDirection = normalize((refractedDir - dwody * eta) + (dndy * mu + n * dmudy));
 }
@@ -913,7 +944,7 @@ PT_DEV f4 lerp4(f4 a, f4 b, float t)
 PT_DEV uint32_t wrapRepeat(float x0, uint32_t n) // floor(x) mod n, in float: CPU and GPU agree for any finite x
 {
     const float fn = (float)n;
-    float m = x0 - __builtin_floorf(x0 / fn) * fn;
+    float m = x0 - __builtin_floorf(div_(x0, fn)) * fn;
     if (!(m >= 0.0f)) m = 0.0f;
     const uint32_t i = (uint32_t)m;
     return i >= n ? n - 1 : i;
@@ -1039,10 +1070,10 @@ PT_DEV f4 textureGradSample(const TextureView &tv, const DevTexture &t, float u,
     const float rmax = fmax_(rx, ry), rmin = fmin_(rx, ry);
     float eta = 1.0f;
     if (rmax > 0.0f && rmax < 3.0e38f) // finite footprint: otherwise a single tap
-        eta = rmin > 0.0f ? fmin_(rmax / rmin, kMaxAnisotropy) : kMaxAnisotropy;
+        eta = rmin > 0.0f ? fmin_(div_(rmax, rmin), kMaxAnisotropy) : kMaxAnisotropy;
     if (!(eta >= 1.0f)) eta = 1.0f;
     const float n = __builtin_ceilf(eta);
-    const float rho = rmax / eta;
+    const float rho = div_(rmax, eta);
     const float lod = rho > 0.0f ? (float)log2_((double)rho) : 0.0f;
     const TrilinearView tl = trilinearView(t, lod);
     if (n <= 1.0f || lod >= (float)(t.levels - 1)) // every tap would read the 1x1 top level: one tap
@@ -1053,11 +1084,12 @@ PT_DEV f4 textureGradSample(const TextureView &tv, const DevTexture &t, float u,
     const int taps = (int)n;
     for (int i = 1; i <= taps; i++)
     {
-        const float w = (float)i / (n + 1.0f) - 0.5f;
+        const float w = div_((float)i, n + 1.0f) - 0.5f;
         const f4 c = trilinearSample(tv, tl, u + du * w, v + dv * w);
         sum.x += c.x; sum.y += c.y; sum.z += c.z; sum.w += c.w;
     }
-    sum.x /= n; sum.y /= n; sum.z /= n; sum.w /= n;
+    const float rn = rcp_(n);
+    sum.x *= rn; sum.y *= rn; sum.z *= rn; sum.w *= rn;
     return sum;
 }
 
@@ -1216,7 +1248,7 @@ PT_DEV f2 missSkyboxTexCoords(f3 dir) // miss.rmiss:20-25
     const float PI = 3.14159265359f; // common.glsl:3
     const float longitude = atan2_(dir.z, dir.x);
     const float latitude = asin_(-dir.y);
-    return F2(longitude / 2.0f / PI + 0.5f, latitude / PI + 0.5f);
+    return F2(div_(div_(longitude, 2.0f), PI) + 0.5f, div_(latitude, PI) + 0.5f);
 }
 
 // Cube map face selection of the Vulkan specification (largest magnitude, z before y before x on ties): face and the
@@ -1256,7 +1288,7 @@ PT_DEV f4 cubeTexel(const TextureView &tv, const DevTexture *faces, uint32_t fac
     const int n = (int)faces[face].width;
     if (ix >= 0 && ix < n && iy >= 0 && iy < n)
         return fetchTexel(tv, faces[face], 0, (uint32_t)ix, (uint32_t)iy);
-    float sc = 2.0f * (((float)ix + 0.5f) / (float)n) - 1.0f, tc = 2.0f * (((float)iy + 0.5f) / (float)n) - 1.0f, ma = 1.0f;
+    float sc = 2.0f * (div_((float)ix + 0.5f, (float)n)) - 1.0f, tc = 2.0f * (div_((float)iy + 0.5f, (float)n)) - 1.0f, ma = 1.0f;
     if (ix < 0 || ix >= n)
     {
         ma = 1.0f - (abs_(sc) - 1.0f);
@@ -1278,8 +1310,8 @@ PT_DEV f4 cubeTexel(const TextureView &tv, const DevTexture *faces, uint32_t fac
     float s2, t2, m2;
     cubeFace(r, f2, s2, t2, m2);
     const float mx = (float)(n - 1);
-    const uint32_t jx = (uint32_t)clamp_(__builtin_floorf((0.5f * (s2 / m2) + 0.5f) * (float)n), 0.0f, mx);
-    const uint32_t jy = (uint32_t)clamp_(__builtin_floorf((0.5f * (t2 / m2) + 0.5f) * (float)n), 0.0f, mx);
+    const uint32_t jx = (uint32_t)clamp_(__builtin_floorf((0.5f * (div_(s2, m2)) + 0.5f) * (float)n), 0.0f, mx);
+    const uint32_t jy = (uint32_t)clamp_(__builtin_floorf((0.5f * (div_(t2, m2)) + 0.5f) * (float)n), 0.0f, mx);
     return fetchTexel(tv, faces[f2], 0, jx, jy);
 }
 
@@ -1327,7 +1359,7 @@ PT_DEV f4 sampleCube(const TextureView &tv, const DevTexture *faces, f3 r)
     uint32_t face;
     float sc, tc, ma;
     cubeFace(r, face, sc, tc, ma);
-    const float u = 0.5f * (sc / ma) + 0.5f, v = 0.5f * (tc / ma) + 0.5f;
+    const float u = 0.5f * (div_(sc, ma)) + 0.5f, v = 0.5f * (div_(tc, ma)) + 0.5f;
     return sampleFaceSeamless(tv, faces, face, u, v);
 }
 
@@ -1346,9 +1378,9 @@ PT_DEV f3 missEmissive(const SceneView &sv, f3 rayDir)
 
 PT_DEV f3 specGlossMetalness(f3 specular, f3 color) // material.glsl:109-110, :138-139
 {
-    return F3(fmax_(specular.x - 0.04f, 0.0f) / ((color.x - 0.04f) + 0.00001f),
-              fmax_(specular.y - 0.04f, 0.0f) / ((color.y - 0.04f) + 0.00001f),
-              fmax_(specular.z - 0.04f, 0.0f) / ((color.z - 0.04f) + 0.00001f));
+    return F3(div_(fmax_(specular.x - 0.04f, 0.0f), (color.x - 0.04f) + 0.00001f),
+              div_(fmax_(specular.y - 0.04f, 0.0f), (color.y - 0.04f) + 0.00001f),
+              div_(fmax_(specular.z - 0.04f, 0.0f), (color.z - 0.04f) + 0.00001f));
 }
 
 // The five textureGrad results a material branch consumes, in the slot order of its struct: emissive, colour, normal,
@@ -1371,7 +1403,7 @@ PT_DEV MaterialSample sampleMaterial(const PtxMetallicRoughnessMaterial *m, cons
     ret.Transmission = m->Transmission;
     ret.AttenuationColor = ld3(m->AttenuationColor);
     ret.AttenuationDistance = m->AttenuationDistance;
-    ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
+    ret.Eta = isHitFromInside ? m->Ior : (div_(1.0f, m->Ior));
     return ret;
 }
 PT_DEV MaterialSample sampleMaterial(const PtxSpecularGlossinessMaterial *m, const MaterialTexels &t, bool isHitFromInside)
@@ -1383,12 +1415,12 @@ PT_DEV MaterialSample sampleMaterial(const PtxSpecularGlossinessMaterial *m, con
     ret.Transmission = m->Transmission;
     ret.AttenuationColor = ld3(m->AttenuationColor);
     ret.AttenuationDistance = m->AttenuationDistance;
-    ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
+    ret.Eta = isHitFromInside ? m->Ior : (div_(1.0f, m->Ior));
     const f3 specular = rgb(t.a) * ld3(m->Specular);
     const float glossiness = t.b.w * m->Glossiness;
     ret.Roughness = 1.0f - glossiness;
     const f3 diff = specGlossMetalness(specular, ret.Color);
-    ret.Metalness = (diff.x + diff.y + diff.z) / 3.0f;
+    ret.Metalness = div_(diff.x + diff.y + diff.z, 3.0f);
     return ret;
 }
 PT_DEV MaterialSample sampleMaterial(const PtxPhongMaterial *m, const MaterialTexels &t, bool isHitFromInside)
@@ -1400,12 +1432,12 @@ PT_DEV MaterialSample sampleMaterial(const PtxPhongMaterial *m, const MaterialTe
     ret.Transmission = m->Transmission;
     ret.AttenuationColor = ld3(m->AttenuationColor);
     ret.AttenuationDistance = m->AttenuationDistance;
-    ret.Eta = isHitFromInside ? m->Ior : (1.0f / m->Ior);
+    ret.Eta = isHitFromInside ? m->Ior : (div_(1.0f, m->Ior));
     const f3 specular = rgb(t.a) * ld3(m->Specular);
     const float shininess = t.b.w * m->Shininess;
     ret.Roughness = 1.0f - shininess;
     const f3 diff = specGlossMetalness(specular, ret.Color);
-    ret.Metalness = (diff.x + diff.y + diff.z) / 3.0f;
+    ret.Metalness = div_(diff.x + diff.y + diff.z, 3.0f);
     return ret;
 }
 // material.glsl:161-171: the unknown-type default (fields the GLSL leaves undefined are zero here) and flipNormalY
@@ -1661,7 +1693,7 @@ PT_DEV void closestHit(const SceneView &sv, f3 rayDirW, float t, float hu, float
 
     if (isHitFromInside) // :123-128
     {
-        const float e = t / material.AttenuationDistance;
+        const float e = div_(t, material.AttenuationDistance);
         bsdf.Color.x *= pow_(material.AttenuationColor.x, e);
         bsdf.Color.y *= pow_(material.AttenuationColor.y, e);
         bsdf.Color.z *= pow_(material.AttenuationColor.z, e);
@@ -1719,7 +1751,7 @@ PT_DEV bool intersectTri(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float tmin, float tmax
     const float det = dot(e1, pvec);
     if (!(det != 0.0f))
         return false;
-    const float inv = 1.0f / det;
+    const float inv = div_(1.0f, det);
     // pass 1 (plain, from the ray origin): good t, barycentrics off by (|o - v0| / size)^2 ulps -> loose bounds only
     f3 tvec = o - v0;
     float uu = dot(tvec, pvec) * inv;

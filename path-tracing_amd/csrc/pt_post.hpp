@@ -60,10 +60,10 @@ PT_DEV void postprocessPixel(f3 accColor, const PtxPostProcessingUniformData &u,
     const float knee = 0.5f;
     const float threshold = u.BloomThreshold;
     const float br = fmax_(color.x, fmax_(color.y, color.z));
-    const f3 curve = F3(threshold - knee, knee * 2.0f, 0.25f / knee);
+    const f3 curve = F3(threshold - knee, knee * 2.0f, div_(0.25f, knee));
     float rq = clamp_(br - curve.x, 0.0f, curve.y);
     rq = curve.z * rq * rq;
-    bloomOut = color * (fmax_(rq, br - threshold) / fmax_(br, 0.0001f));
+    bloomOut = color * (div_(fmax_(rq, br - threshold), fmax_(br, 0.0001f)));
     colorOut = color;
 }
 
@@ -124,11 +124,11 @@ __global__ void k_postprocess(const float4 *__restrict__ accum, uint32_t n, PtxP
 __global__ void k_bloom_downsample(BloomLevel src, BloomLevel dst)
 {
     const uint32_t n = dst.w * dst.h;
-    const float tx = 1.0f / (float)src.w, ty = 1.0f / (float)src.h;
+    const float tx = div_(1.0f, (float)src.w), ty = div_(1.0f, (float)src.h);
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x)
     {
         const uint32_t xx = p % dst.w, yy = p / dst.w;
-        const float u = ((float)xx + 0.5f) / (float)dst.w, v = ((float)yy + 0.5f) / (float)dst.h;
+        const float u = div_((float)xx + 0.5f, (float)dst.w), v = div_((float)yy + 0.5f, (float)dst.h);
         const f3 a = bloomTap(src, u + -2.0f * tx, v + 2.0f * ty), b = bloomTap(src, u + 0.0f * tx, v + 2.0f * ty),
                  c = bloomTap(src, u + 2.0f * tx, v + 2.0f * ty);
         const f3 d = bloomTap(src, u + -2.0f * tx, v + 0.0f * ty), e = bloomTap(src, u + 0.0f * tx, v + 0.0f * ty),
@@ -150,11 +150,11 @@ __global__ void k_bloom_downsample(BloomLevel src, BloomLevel dst)
 __global__ void k_bloom_upsample(BloomLevel src, BloomLevel dst)
 {
     const uint32_t n = dst.w * dst.h;
-    const float x = 1.0f / (float)src.w, y = 1.0f / (float)src.h;
+    const float x = div_(1.0f, (float)src.w), y = div_(1.0f, (float)src.h);
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x)
     {
         const uint32_t xx = p % dst.w, yy = p / dst.w;
-        const float u = ((float)xx + 0.5f) / (float)dst.w, v = ((float)yy + 0.5f) / (float)dst.h;
+        const float u = div_((float)xx + 0.5f, (float)dst.w), v = div_((float)yy + 0.5f, (float)dst.h);
         const f3 a = bloomTap(src, u + -x, v + y), b = bloomTap(src, u + 0.0f, v + y), c = bloomTap(src, u + x, v + y);
         const f3 d = bloomTap(src, u + -x, v + 0.0f), e = bloomTap(src, u + 0.0f, v + 0.0f), f = bloomTap(src, u + x, v + 0.0f);
         const f3 g = bloomTap(src, u + -x, v + -y), h = bloomTap(src, u + 0.0f, v + -y), i = bloomTap(src, u + x, v + -y);

@@ -136,3 +136,31 @@ def known_answer_ray_array(scene_name):
             ob, db = np.array(o, np.uint32).view(np.float32), np.array(d, np.uint32).view(np.float32)
             rays.append([ob[0], ob[1], ob[2], 1e-5, db[0], db[1], db[2], 1e4])
     return np.array(rays, np.float32)
+
+
+def reciprocal_inputs():
+    """Bit patterns for the specified reciprocal (PTX_FN_DIVIDE): all 2^23 mantissas of [1, 2) with both signs (the Newton step is
+    exact-scaling invariant inside the normal range), every exponent with 4,096 mantissas each (the flush boundaries 2^-126 and
+    2^126 lie in there), zero, denormals, infinities, NaNs and the patterns either side of both boundaries."""
+    m = np.arange(1 << 23, dtype=np.uint32)
+    parts = [np.uint32(0x3f800000) | m, np.uint32(0xbf800000) | m]
+    rng = np.random.default_rng(11)
+    mant = np.concatenate([np.uint32([0, 1, 0x7fffff, 0x7ffffe, 0x400000]), rng.integers(0, 1 << 23, 4091, dtype=np.uint32)])
+    for e in range(256):
+        parts.append((np.uint32(e << 23) | mant))
+        parts.append((np.uint32(0x80000000 | (e << 23)) | mant))
+    parts.append(np.uint32([0, 0x80000000, 1, 0x007fffff, 0x00800000, 0x00800001, 0x7e800000, 0x7e800001, 0x7e7fffff, 0x7f7fffff, 0x7f800000,
+                            0xff800000, 0x7fc00000, 0xffc00001, 0x7f800001]))
+    return np.concatenate(parts)
+
+
+def reciprocal_spec(b):
+    """The definition (oracle/pt_oracle_math.h pto_rcp) in numpy: RN(1 / b) on [2^-126, 2^126], +-inf below, +-0 above."""
+    b = b.astype(np.float32)
+    with np.errstate(all="ignore"):
+        r = (np.float32(1.0) / b).astype(np.float32)
+        ab = np.abs(b)
+        r = np.where(ab < np.float32(1.17549435e-38), np.copysign(np.float32(np.inf), b), r)
+        r = np.where(ab > np.float32(8.50705917e37), np.copysign(np.float32(0.0), b), r)
+        r = np.where(np.isnan(b), b, r)
+    return r.astype(np.float32)

@@ -49,11 +49,15 @@ STRUCTS = [
 FLOAT_LIT = re.compile(r"(?<![A-Za-z_0-9.])((?:\d+\.\d*|\.\d+)(?:[eE][+-]?\d+)?|\d+[eE][+-]?\d+)(?![fF0-9A-Za-z_.])")
 
 
+FLOAT_LIT_F = re.compile(r"(?<![A-Za-z_0-9.])((?:\d+\.\d*|\.\d+)(?:[eE][+-]?\d+)?|\d+[eE][+-]?\d+)[fF](?![0-9A-Za-z_.])")
+
+
 def rewrite(text: str) -> str:
     text = re.sub(r"^\s*#(include|version|extension).*$", "", text, flags=re.M)
     text = re.sub(r"\binout\s+(\w+)\s+(\w+)", r"\1& \2", text)
     text = re.sub(r"\bout\s+(\w+)\s+(\w+)", r"\1& \2", text)
-    text = FLOAT_LIT.sub(r"\1f", text)
+    text = FLOAT_LIT_F.sub(r"float(\1F)", text)  # literals the shader text already suffixes
+    text = FLOAT_LIT.sub(r"float(\1f)", text)  # `float` is glsl::Float (glsl_shim.hpp): a literal and a variable have ONE type in ?:
     text = re.sub(r"\.(xyz|yzw|xy|yz|zw|rgb)\b", r".\1()", text)
     # GLSL evaluates call arguments left to right (GLSL 4.60 6.1.1); C++ only does so
     # for braced initialisers, and the draw order of rand() is part of the contract.
@@ -178,6 +182,8 @@ def main():
         parts.append('#include "%s/golden_main.inc"' % HERE)
         cpp = os.path.join(tmp, "golden.cpp")
         open(cpp, "w").write("\n".join(parts))
+        if os.environ.get("PT_GOLDEN_KEEP"):  # debugging the shim: a copy of the generated file OUTSIDE the repository
+            open(os.environ["PT_GOLDEN_KEEP"], "w").write("\n".join(parts))
         for mode, flag in (("libm", []), ("fixed", ["-DSHIM_FIXED"])):
             exe = os.path.join(tmp, "golden_" + mode)
             cmd = ["g++", "-std=c++20", "-O1", "-ffp-contract=off", "-fno-fast-math", "-w"] + flag + [cpp, "-o", exe, "-lm"]

@@ -6,15 +6,70 @@
 // it is applied to stays in /tmp (reference sources are not copied into this repo).
 //
 // Builtins follow the arithmetic conventions written in oracle/pt_oracle.h.  With
-// -DSHIM_FIXED the transcendental builtins use the fixed polynomial kernels
-// (bit-exact structure check); without it they use glibc's libm (independent check of
-// those kernels, compared within a few ULP).
+// -DSHIM_FIXED the transcendental builtins use the fixed polynomial kernels and `/` is
+// the specified division a * rcp(b) (bit-exact structure check); without it they use
+// glibc's libm and IEEE division (independent check of those kernels and of the division
+// convention, compared within a few ULP).
+//
+// GLSL's `float` is the class glsl::Float here (every later `float` token -- the shim's own
+// types, the reference's shader text, tools/golden_main.inc -- is that class through the macro
+// at the end of this prologue), so that a scalar `a / b` of the shader text goes through an
+// operator this file defines; +, -, * and the comparisons are plain IEEE binary32.
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
+#include <string>
+#include <type_traits>
+#include <vector>
 
 #include "../oracle/pt_oracle_math.h"
+
+namespace glsl
+{
+typedef float f32; // the machine type, for the few places that need it
+template <class T> concept Arith = std::is_arithmetic_v<T>;
+
+struct Float
+{
+    f32 v;
+    Float() = default;
+    constexpr Float(f32 x) : v(x) {}
+    constexpr Float(double x) : v((f32)x) {}
+    constexpr Float(int x) : v((f32)x) {}
+    constexpr Float(unsigned x) : v((f32)x) {}
+    constexpr Float(long x) : v((f32)x) {}
+    constexpr Float(unsigned long x) : v((f32)x) {}
+    constexpr operator f32() const { return v; }
+    Float &operator+=(Float o) { v = v + o.v; return *this; }
+    Float &operator-=(Float o) { v = v - o.v; return *this; }
+    Float &operator*=(Float o) { v = v * o.v; return *this; }
+    Float &operator/=(Float o);
+};
+inline f32 shimDiv(f32 a, f32 b)
+{
+#ifdef SHIM_FIXED
+    return a * pto_rcp(b); // the specified division (oracle/pt_oracle_math.h)
+#else
+    return a / b; // IEEE: the independent check
+#endif
+}
+inline Float &Float::operator/=(Float o) { v = shimDiv(v, o.v); return *this; }
+inline Float operator-(Float a) { return Float(-a.v); }
+inline Float operator+(Float a) { return a; }
+#define SHIM_BINOP(op, expr)                                                                          \
+    inline Float operator op(Float a, Float b) { const f32 x = a.v, y = b.v; return Float(expr); }    \
+    template <Arith T> inline Float operator op(Float a, T b) { const f32 x = a.v, y = (f32)b; return Float(expr); } \
+    template <Arith T> inline Float operator op(T a, Float b) { const f32 x = (f32)a, y = b.v; return Float(expr); }
+SHIM_BINOP(+, x + y)
+SHIM_BINOP(-, x - y)
+SHIM_BINOP(*, x * y)
+SHIM_BINOP(/, shimDiv(x, y))
+#undef SHIM_BINOP
+} // namespace glsl
+
+#define float ::glsl::Float // from here on (all standard headers are in)
 
 namespace glsl
 {
@@ -35,7 +90,7 @@ struct ivec2
 };
 struct vec2
 {
-    union { struct { float x, y; }; struct { float r, g; }; };
+    union { float x; float r; }; union { float y; float g; };
     vec2() {}
     explicit vec2(float s) : x(s), y(s) {}
     vec2(float a, float b) : x(a), y(b) {}
@@ -44,7 +99,7 @@ struct vec2
 };
 struct vec3
 {
-    union { struct { float x, y, z; }; struct { float r, g, b; }; };
+    union { float x; float r; }; union { float y; float g; }; union { float z; float b; };
     vec3() {}
     explicit vec3(float s) : x(s), y(s), z(s) {}
     vec3(float a, float b_, float c) : x(a), y(b_), z(c) {}
@@ -68,7 +123,7 @@ struct ivec3
 };
 struct vec4
 {
-    union { struct { float x, y, z, w; }; struct { float r, g, b, a; }; };
+    union { float x; float r; }; union { float y; float g; }; union { float z; float b; }; union { float w; float a; };
     vec4() {}
     explicit vec4(float s) : x(s), y(s), z(s), w(s) {}
     vec4(float a_, float b_, float c, float d) : x(a_), y(b_), z(c), w(d) {}
@@ -136,7 +191,7 @@ inline vec3 operator*(const mat3 &m, vec3 v)
 }
 inline vec4 operator*(const mat4 &m, vec4 v)
 {
-    const v4 r = m4_mul(m.m, v.x, v.y, v.z, v.w);
+    const v4 r = m4_mul(reinterpret_cast<const f32 *>(m.m), v.x, v.y, v.z, v.w);
     return vec4(r.x, r.y, r.z, r.w);
 }
 
@@ -199,21 +254,21 @@ inline mat4 inverse(const mat4 &a) // cofactor expansion
 // ---- builtins --------------------------------------------------------------
 inline float abs(float x) { return fabsf(x); }
 inline float sqrt(float x) { return sqrtf(x); }
-inline float inversesqrt(float x) { return 1.0f / sqrtf(x); }
+inline float inversesqrt(float x) { return 1.0f / sqrt(x); } // the specified division of the correctly rounded root
 inline float min(float a, float b) { return f_min(a, b); }
 inline float max(float a, float b) { return f_max(a, b); }
 inline vec3 max(vec3 a, float b) { return vec3(f_max(a.x, b), f_max(a.y, b), f_max(a.z, b)); }
 inline float clamp(float x, float lo, float hi) { return f_clamp(x, lo, hi); }
-inline bool isinf(float x) { return std::isinf(x); }
-inline bool isnan(float x) { return std::isnan(x); }
+inline bool isinf(float x) { return std::isinf(x.v); }
+inline bool isnan(float x) { return std::isnan(x.v); }
 inline float fma(float a, float b, float c) { return fmaf(a, b, c); }
 inline int floatBitsToInt(float f) { int i; memcpy(&i, &f, 4); return i; }
 inline float intBitsToFloat(int i) { float f; memcpy(&f, &i, 4); return f; }
 inline float uintBitsToFloat(uint u) { float f; memcpy(&f, &u, 4); return f; }
 
 #ifdef SHIM_FIXED
-inline float cos(float x) { float s, c; pto_sincosf(x, &s, &c); return c; }
-inline float sin(float x) { float s, c; pto_sincosf(x, &s, &c); return s; }
+inline float cos(float x) { f32 s, c; pto_sincosf(x, &s, &c); return c; }
+inline float sin(float x) { f32 s, c; pto_sincosf(x, &s, &c); return s; }
 inline float pow(float x, float y)
 {
     if (y == 2.0f) return x * x;
@@ -225,7 +280,7 @@ inline float cos(float x) { return cosf(x); }
 inline float sin(float x) { return sinf(x); }
 inline float pow(float x, float y) { return powf(x, y); }
 #endif
-inline float pow(float x, int y) { return pow(x, (float)y); }
+template <class T> requires std::is_integral_v<T> inline float pow(float x, T y) { return pow(x, (float)y); }
 #ifdef SHIM_FIXED
 inline float exp(float x) { return pto_expf(x); }
 #else
@@ -249,7 +304,7 @@ inline float dot(uvec2 a, uvec2 b) { return (float)a.x * (float)b.x + (float)a.y
 inline vec3 cross(vec3 a, vec3 b) { return vec3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
 inline float length(vec3 a) { return sqrtf(dot(a, a)); }
 inline float distance(vec3 a, vec3 b) { return length(a - b); }
-inline vec3 normalize(vec3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+inline vec3 normalize(vec3 a) { return a * (1.0f / sqrt(dot(a, a))); }
 inline vec3 reflect(vec3 I, vec3 N) { return I - N * (2.0f * dot(N, I)); }
 inline vec3 refract(vec3 I, vec3 N, float eta)
 {
