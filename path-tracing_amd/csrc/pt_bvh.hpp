@@ -601,26 +601,42 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
             if (have && ref >= 0 && ref != kRefDone)
             {
                 int r0, r1, r2, r3;
-                const int h = visitNode<!ANY_HIT>(&sc.nodes[ref], o, id, PT_TMIN, ANY_HIT ? PT_TMAX : best.t * kCullSlack, r0, r1, r2, r3);
+#ifdef PTX_EXP_UNORDERED_CLOSEST
+                constexpr bool kUnordered = true; // experiment: closest-hit rays enter the hit children in slot order too
+#else
+                constexpr bool kUnordered = ANY_HIT;
+#endif
+                const int h = visitNode<!kUnordered>(&sc.nodes[ref], o, id, PT_TMIN, ANY_HIT ? PT_TMAX : best.t * kCullSlack, r0, r1, r2, r3);
                 if (__builtin_expect(st.roomFor(kNodeWidth - 1), 1)) // every lane of this step stays in the LDS part of its stack
                 {
-                    if (ANY_HIT)
+                    if (kUnordered)
                     {
                         PT_ENTER_UNORDERED(h, r0, r1, r2, r3, st, ref, kRefNone, pushLds)
                     }
                     else
                     {
+#ifdef PTX_EXP_BRANCHFREE_PUSH
+                        // three unconditional LDS stores at computed depths (what lies above sp is never read) instead of three
+                        // predicated regions
+                        const int p3 = st.sp, p2 = p3 + (h > 3 ? 1 : 0), p1 = p2 + (h > 2 ? 1 : 0);
+                        st.lds[p3 * st.stride] = (uint32_t)r3;
+                        st.lds[p2 * st.stride] = (uint32_t)r2;
+                        st.lds[p1 * st.stride] = (uint32_t)r1;
+                        st.sp = p1 + (h > 1 ? 1 : 0);
+                        ref = h > 0 ? r0 : kRefNone;
+#else
                         if (h > 3) st.pushLds((uint32_t)r3);
                         if (h > 2) st.pushLds((uint32_t)r2);
                         if (h > 1) st.pushLds((uint32_t)r1);
                         ref = h > 0 ? r0 : kRefNone;
+#endif
                     }
                     if (ref == kRefNone)
                         ref = st.sp ? (int)st.popLds() : kRefDone;
                 }
                 else
                 {
-                    if (ANY_HIT)
+                    if (kUnordered)
                     {
                         PT_ENTER_UNORDERED(h, r0, r1, r2, r3, st, ref, kRefNone, push)
                     }

@@ -96,13 +96,28 @@ __global__ void k_tri_setup(uint32_t n, uint32_t pairCount, const uint32_t *__re
     }
     boxLo[g] = make_float4(l[0], l[1], l[2], 0.0f);
     boxHi[g] = make_float4(h[0], h[1], h[2], 0.0f);
-    for (int a = 0; a < 3 && !isInert; a++)
+    // centroid bounds of the scene for the Morton grid (a refit keeps the sorted order and does not need them): reduced over the
+    // wave first -- six same-address atomics per TRIANGLE were most of this kernel's 4.4 ms at 4 M triangles
+    if (refit)
+        return;
+    for (int a = 0; a < 3; a++)
     {
         const float c = 0.5f * (l[a] + h[a]);
-        if (c == c && fabsf(c) < 3.0e38f)
+        const bool ok = !isInert && c == c && fabsf(c) < 3.0e38f;
+        uint32_t mn = ok ? orderedFloat(c) : 0xffffffffu, mx = ok ? orderedFloat(c) : 0u;
+        const bool fullWave = __ballot(1) == ~0ull; // (the last wave of the launch may be partial: its lanes go one by one)
+        if (fullWave)
+            for (int o = 32; o > 0; o >>= 1)
+            {
+                mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
+                mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+            }
+        if (!fullWave || (threadIdx.x & 63u) == 0u)
         {
-            atomicMin(&sceneBounds[a], orderedFloat(c));
-            atomicMax(&sceneBounds[3 + a], orderedFloat(c));
+            if (mn != 0xffffffffu)
+                atomicMin(&sceneBounds[a], mn);
+            if (mx != 0u)
+                atomicMax(&sceneBounds[3 + a], mx);
         }
     }
 }
@@ -900,6 +915,95 @@ __global__ void k_refit(int n, const uint32_t *__restrict__ vals, const float4 *
     }
 }
 
+// ---- level lists of the binary tree (round 5): bottom-up passes without fences ---------------------------------------
+// k_refit above climbs from every leaf and hands a node to the second thread that arrives: two agent-scope fences and one
+// atomic per node.  On this chip an agent-scope release writes the XCD's L2 back (eight L2s, not coherent with one another), so
+// the pass cost 11 ms at 2 M triangles and 25 ms at 4 M -- more than a rendered frame -- and the reinsertion passes, the
+// collapse's pricing and every animated frame's refit pay it.  Instead: the DEPTH of every node by pointer jumping over the parent
+// links (log2(depth) gather passes: d[i] += d[anc[i]], anc[i] = anc[anc[i]]), the nodes sorted by depth with one or two passes of the
+// radix sort above (stable, deterministic), and one launch per level from the deepest up -- a kernel boundary is all the ordering a
+// level needs.  The lists follow the topology: recomputed after PLOC and after every reinsertion pass, kept for the refits of an
+// animation (ptx_update_animation keeps topology and order).
+constexpr uint32_t kMaxTreeLevels = 4096; // deeper trees (never seen: PLOC trees of 2-4 M triangles are 40-70 deep) take k_refit
+
+__global__ void k_depth_init(int nodes, const int *__restrict__ parentOfNode, uint32_t *__restrict__ depth, int *__restrict__ anc)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nodes)
+        return;
+    const int p = parentOfNode[i];
+    depth[i] = p >= 0 ? 1u : 0u;
+    anc[i] = p;
+}
+
+// one pointer-jumping pass (ping-pong buffers); *pending becomes non-zero while some node has not reached the root
+__global__ void k_depth_jump(int nodes, const uint32_t *__restrict__ dIn, const int *__restrict__ aIn, uint32_t *__restrict__ dOut,
+                             int *__restrict__ aOut, uint32_t *__restrict__ pending)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nodes)
+        return;
+    int a = aIn[i];
+    uint32_t d = dIn[i];
+    if (a >= 0)
+    {
+        d += dIn[a];
+        a = aIn[a];
+    }
+    dOut[i] = d;
+    aOut[i] = a;
+    if (__ballot(a >= 0) != 0ull && (threadIdx.x & 63u) == 0u)
+        *pending = 1u;
+}
+
+__global__ void k_depth_keys(int nodes, const uint32_t *__restrict__ depth, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                             uint32_t *__restrict__ maxDepth)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t d = 0;
+    if (i < nodes)
+    {
+        d = depth[i];
+        keys[i] = d;
+        vals[i] = (uint32_t)i;
+    }
+    // wave maximum, one atomic per wave
+    for (int o = 32; o > 0; o >>= 1)
+        d = max(d, (uint32_t)__shfl_xor((int)d, o));
+    if ((threadIdx.x & 63u) == 0u)
+        atomicMax(maxDepth, d);
+}
+
+// first sorted position of every depth (levelStart[d]; the caller sets levelStart[maxDepth + 1] = nodes)
+__global__ void k_level_starts(int nodes, const uint64_t *__restrict__ sortedKeys, uint32_t *__restrict__ levelStart)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nodes)
+        return;
+    const uint32_t d = (uint32_t)sortedKeys[i];
+    if (i == 0 || (uint32_t)sortedKeys[i - 1] != d)
+        levelStart[d] = (uint32_t)i;
+}
+
+// the boxes of one level: every child is a leaf or a node of the level below, written by the launch before this one
+__global__ void k_refit_level(uint32_t first, uint32_t count, const uint32_t *__restrict__ order, const uint32_t *__restrict__ vals,
+                              const float4 *__restrict__ boxLo, const float4 *__restrict__ boxHi, const int2 *__restrict__ children,
+                              float4 *__restrict__ nodeLo, float4 *__restrict__ nodeHi)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count)
+        return;
+    const int node = (int)order[first + i];
+    const int2 ch = children[node];
+    float4 l0, h0, l1, h1;
+    if (ch.x < 0) { const uint32_t g = vals[~ch.x]; l0 = boxLo[g]; h0 = boxHi[g]; }
+    else { l0 = nodeLo[ch.x]; h0 = nodeHi[ch.x]; }
+    if (ch.y < 0) { const uint32_t g = vals[~ch.y]; l1 = boxLo[g]; h1 = boxHi[g]; }
+    else { l1 = nodeLo[ch.y]; h1 = nodeHi[ch.y]; }
+    nodeLo[node] = make_float4(fminf(l0.x, l1.x), fminf(l0.y, l1.y), fminf(l0.z, l1.z), 0.0f);
+    nodeHi[node] = make_float4(fmaxf(h0.x, h1.x), fmaxf(h0.y, h1.y), fmaxf(h0.z, h1.z), 0.0f);
+}
+
 // ---- reinsertion (round 4): the binary tree re-optimised before it is collapsed -----------------------------------
 // PLOC decides every merge once, among neighbours in the Morton order; what it got wrong stays.  Parallel reinsertion (Meister
 // and Bittner 2018) revisits it: every node x (a subtree or a leaf) looks for the place in the tree where it would cost least --
@@ -1206,6 +1310,36 @@ PT_DEV float4 collapseCostOf(int ref, const float4 *cost, const uint32_t *vals, 
     return loadUncached(&cost[ref]);
 }
 
+// T(node, 1..4) and the decision byte of one node from its children's (see above); UNCACHED: the children's costs come from other
+// CUs of the same launch (k_collapse_cost) or from the launch before (k_collapse_cost_level)
+template <bool UNCACHED>
+PT_DEV void collapseNode(int node, const uint32_t *vals, const float4 *boxLo, const float4 *boxHi, const int2 *children, const float4 *nodeLo,
+                         const float4 *nodeHi, float4 *cost, uint8_t *decide)
+{
+    const int2 ch = children[node];
+    const float4 lo = nodeLo[node], hi = nodeHi[node];
+    const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+    const float q = 1.0f / 255.0f;
+    const float4 l = ch.x >= 0 && !UNCACHED ? cost[ch.x] : collapseCostOf(ch.x, cost, vals, boxLo, boxHi, dx * q, dy * q, dz * q);
+    const float4 r = ch.y >= 0 && !UNCACHED ? cost[ch.y] : collapseCostOf(ch.y, cost, vals, boxLo, boxHi, dx * q, dy * q, dz * q);
+    const float area = dx * dy + dy * dz + dz * dx;
+    const float d2 = l.x + r.x;
+    const float d3a = l.x + r.y, d3b = l.y + r.x; // left 1 + right 2, left 2 + right 1
+    const float d3 = fminf(d3a, d3b);
+    const float d4a = l.x + r.z, d4b = l.y + r.y, d4c = l.z + r.x; // left 1, 2, 3
+    const float d4 = fminf(d4a, fminf(d4b, d4c));
+    const float t1 = area + d4;
+    uint32_t bits = 0;
+    bits |= d3b < d3a ? 1u : 0u;
+    bits |= (d4b < d4a && d4b <= d4c) ? 2u : (d4c < d4a && d4c < d4b) ? 4u : 0u;
+    bits |= t1 <= d2 ? 8u : 0u;
+    bits |= t1 <= d3 ? 16u : 0u;
+    bits |= t1 <= d4 ? 32u : 0u;
+    decide[node] = (uint8_t)bits;
+    cost[node] = make_float4(t1, fminf(t1, d2), fminf(t1, d3), fminf(t1, d4));
+}
+
+// the fence-and-atomic climb (kept for trees deeper than kMaxTreeLevels)
 __global__ void k_collapse_cost(int n, const uint32_t *__restrict__ vals, const float4 *__restrict__ boxLo, const float4 *__restrict__ boxHi,
                                 const int2 *__restrict__ children, const int *__restrict__ parentOfNode, const int *__restrict__ parentOfLeaf,
                                 const float4 *__restrict__ nodeLo, const float4 *__restrict__ nodeHi, uint32_t *__restrict__ flags,
@@ -1221,29 +1355,20 @@ __global__ void k_collapse_cost(int n, const uint32_t *__restrict__ vals, const 
         if (atomicAdd(&flags[node], 1u) == 0u)
             return;
         __threadfence();
-        const int2 ch = children[node];
-        const float4 lo = nodeLo[node], hi = nodeHi[node];
-        const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
-        const float q = 1.0f / 255.0f;
-        const float4 l = collapseCostOf(ch.x, cost, vals, boxLo, boxHi, dx * q, dy * q, dz * q);
-        const float4 r = collapseCostOf(ch.y, cost, vals, boxLo, boxHi, dx * q, dy * q, dz * q);
-        const float area = dx * dy + dy * dz + dz * dx;
-        const float d2 = l.x + r.x;
-        const float d3a = l.x + r.y, d3b = l.y + r.x; // left 1 + right 2, left 2 + right 1
-        const float d3 = fminf(d3a, d3b);
-        const float d4a = l.x + r.z, d4b = l.y + r.y, d4c = l.z + r.x; // left 1, 2, 3
-        const float d4 = fminf(d4a, fminf(d4b, d4c));
-        const float t1 = area + d4;
-        uint32_t bits = 0;
-        bits |= d3b < d3a ? 1u : 0u;
-        bits |= (d4b < d4a && d4b <= d4c) ? 2u : (d4c < d4a && d4c < d4b) ? 4u : 0u;
-        bits |= t1 <= d2 ? 8u : 0u;
-        bits |= t1 <= d3 ? 16u : 0u;
-        bits |= t1 <= d4 ? 32u : 0u;
-        decide[node] = (uint8_t)bits;
-        cost[node] = make_float4(t1, fminf(t1, d2), fminf(t1, d3), fminf(t1, d4));
+        collapseNode<true>(node, vals, boxLo, boxHi, children, nodeLo, nodeHi, cost, decide);
         node = parentOfNode[node];
     }
+}
+
+// one level of the same pass over the level lists (k_refit_level's order): no fences
+__global__ void k_collapse_cost_level(uint32_t first, uint32_t count, const uint32_t *__restrict__ order, const uint32_t *__restrict__ vals,
+                                      const float4 *__restrict__ boxLo, const float4 *__restrict__ boxHi, const int2 *__restrict__ children,
+                                      const float4 *__restrict__ nodeLo, const float4 *__restrict__ nodeHi, float4 *__restrict__ cost,
+                                      uint8_t *__restrict__ decide)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count)
+        collapseNode<false>((int)order[first + i], vals, boxLo, boxHi, children, nodeLo, nodeHi, cost, decide);
 }
 
 // Final layout.  Every binary LBVH node i becomes one 4-wide node: start from its two

@@ -57,14 +57,14 @@ PT_DEV float fmin_(float a, float b) { return (b < a) ? b : a; } // GLSL min
 PT_DEV float fmax_(float a, float b) { return (a < b) ? b : a; } // GLSL max
 PT_DEV float clamp_(float x, float lo, float hi) { return fmin_(fmax_(x, lo), hi); }
 PT_DEV float abs_(float x) { return __builtin_fabsf(x); }
-// Correctly rounded square root (IEEE; the oracle's sqrtf).  hipcc's expansion is 16 VALU, five of them a power-of-two scaling
-// that only matters for |x| < 2^-96, where the residuals below would underflow.  Here: v_sqrt_f32 (1 ULP) and the two-neighbour
-// residual test (exact FMAs), 10 VALU, behind ONE wave-uniform branch that sends a wave holding a tiny non-zero or zero argument
-// through hipcc's sequence instead (rare: the arguments are squared lengths and 1 - cos^2 terms).  Equal to __builtin_sqrtf on all
-// 2^32 inputs (tools/experiments/rcp_sqrt_exhaustive.hip).
+// Correctly rounded square root (IEEE): hipcc's expansion, 16 VALU -- v_sqrt_f32, the two-neighbour residual test, and a
+// power-of-two scaling for |x| < 2^-96 where the residuals would underflow.  A hand-written form without the scaling behind a
+// wave-uniform branch (10 VALU on the fast path; equal on all 2^32 inputs: tools/experiments/rcp_sqrt_exhaustive.hip) was measured
+// and is NOT used: k_shade alone 0.555 -> 0.586 ms, chess_like 2,656 -> 2,636 Msamples/s on one box (profiles/r05_ab_sqrt.txt) --
+// 62 extra branch sites cost the scheduler more than the six instructions they save.  -DPTX_HANDWRITTEN_SQRT builds it.
 PT_DEV float sqrt_(float x)
 {
-#ifdef PTX_IEEE_SQRT_BUILTIN
+#ifndef PTX_HANDWRITTEN_SQRT
     return __builtin_sqrtf(x);
 #else
     if (__builtin_amdgcn_ballot_w64(__builtin_fabsf(x) < 1.262177448e-29f) != 0) // 2^-96

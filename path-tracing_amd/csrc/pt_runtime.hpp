@@ -90,10 +90,12 @@ struct EnvSwitches
     uint32_t framesPerWave = 8;  // PTX_FRAMES_PER_WAVE: samples of one pixel in neighbouring lanes, at most this many
     uint32_t raysPerThread = 0;  // PTX_RAYS_PER_THREAD (process-wide: the last handle created sets it)
     long residentCap = -1;       // PTX_RESIDENT_CAP=0: persistent grids are not capped at the resident block count
+    bool fenceRefit = false;     // PTX_FENCE_REFIT=1: the round-4 bottom-up kernels (fence and atomic per node) instead of the level lists
     static EnvSwitches read()
     {
         EnvSwitches e;
         e.verbose = getenv("PTX_VERBOSE") != nullptr;
+        e.fenceRefit = getenv("PTX_FENCE_REFIT") != nullptr && std::strcmp(getenv("PTX_FENCE_REFIT"), "0") != 0;
         if (const char *v = getenv("PTX_BUILDER"))
             e.karrasBuilder = std::strcmp(v, "lbvh") == 0;
         if (const char *v = getenv("PTX_PLOC_SHAPE"))
@@ -189,6 +191,12 @@ struct PtxRenderer
         DevBuf<float4> collapseCost; // k_collapse_cost: T(x, 1..4) per binary node
         DevBuf<uint8_t> collapseDecide;
         DevBuf<uint32_t> oldOf;   // [0] onwards: emitted index of every node of the compact array; the last entry is the level counter
+        // level lists of the binary topology (pt_bvh_build.hpp, round 5): the nodes sorted by depth, for the bottom-up passes
+        DevBuf<uint32_t> lvDepth0, lvDepth1, lvVals0, lvVals1, lvStartDev;
+        DevBuf<int> lvAnc0, lvAnc1;
+        const uint32_t *levelOrder = nullptr; // lvVals0 or lvVals1
+        std::vector<uint32_t> levelStart;     // [d] first position of depth d in levelOrder, [maxDepth + 1] = nodes
+        bool levelsValid = false;
         bool valid = false;
         void release()
         {
@@ -196,6 +204,8 @@ struct PtxRenderer
             vals0.release(); vals1.release(); hist.release(); histSums.release(); flags.release(); inert.release(); keys0.release(); keys1.release();
             children.release(); parentOfNode.release(); parentOfLeaf.release(); rawNodes.release(); oldOf.release(); collapseCost.release(); collapseDecide.release();
             refLo.release(); refHi.release(); refTri.release(); refInert.release();
+            lvDepth0.release(); lvDepth1.release(); lvVals0.release(); lvVals1.release(); lvStartDev.release(); lvAnc0.release(); lvAnc1.release();
+            levelOrder = nullptr; levelStart.clear(); levelsValid = false;
             valid = false;
         }
     } build;
@@ -1099,6 +1109,99 @@ static int sceneUpload(PtxRenderer *r, const PtxSceneDesc *s)
 
 static SceneView makeSceneView(const PtxRenderer *r);
 
+// One 8-bit pass of the LSD radix sort of pt_bvh_build.hpp over `count` (key, value) pairs; hist / histSums sized by the caller.
+static void radixPass(PtxRenderer *r, uint32_t count, const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout, uint32_t shift,
+                      uint32_t *hist, uint32_t *histSums)
+{
+    const uint32_t numTiles = (count + kSortTile - 1) / kSortTile;
+    const uint32_t histCount = 256 * numTiles, histBlocks = (histCount + kScan32Block - 1) / kScan32Block;
+    k_sort_hist<<<numTiles, 64, 0, r->stream>>>(count, kin, shift, numTiles, hist);
+    if (histBlocks > 1)
+    {
+        k_scan32_sums<<<histBlocks, 256, 0, r->stream>>>(histCount, hist, histSums);
+        k_scan_exclusive<<<1, 1024, 0, r->stream>>>(histBlocks, histSums);
+        k_scan32_apply<<<histBlocks, 256, 0, r->stream>>>(histCount, hist, histSums);
+    }
+    else
+        k_scan_exclusive<<<1, 1024, 0, r->stream>>>(histCount, hist);
+    k_sort_scatter<<<numTiles, 64, 0, r->stream>>>(count, kin, vin, kout, vout, shift, numTiles, hist);
+}
+
+// Level lists of the CURRENT binary topology over nv leaves (B.children / B.parentOfNode): B.levelOrder, B.levelStart.
+// *usable = false: the tree is deeper than kMaxTreeLevels (or is not a tree) and the caller takes the fence-and-atomic kernels.
+// Scratch: B.keys0 / keys1 (the Morton keys are done with), B.hist / histSums.
+static hipError_t treeLevels(PtxRenderer *r, uint32_t nv, bool *usable)
+{
+    PtxRenderer::BuildState &B = r->build;
+    B.levelsValid = false;
+    *usable = false;
+    if (nv < 2)
+        return hipSuccess;
+    const uint32_t nodes = nv - 1, blocks = (nodes + 255) / 256;
+#define LV_TRY(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
+    LV_TRY(B.lvDepth0.alloc(nodes)); LV_TRY(B.lvDepth1.alloc(nodes)); LV_TRY(B.lvAnc0.alloc(nodes)); LV_TRY(B.lvAnc1.alloc(nodes));
+    LV_TRY(B.lvVals0.alloc(nodes)); LV_TRY(B.lvVals1.alloc(nodes)); LV_TRY(B.lvStartDev.alloc(kMaxTreeLevels + 2));
+    uint32_t *d0 = B.lvDepth0.p, *d1 = B.lvDepth1.p, *flag = B.lvStartDev.p; // (flag: the first word, before the starts are written)
+    int *a0 = B.lvAnc0.p, *a1 = B.lvAnc1.p;
+    k_depth_init<<<blocks, 256, 0, r->stream>>>((int)nodes, B.parentOfNode.p, d0, a0);
+    bool done = false;
+    for (uint32_t pass = 0; pass < 24 && !done; pass++) // pass k covers paths of 2^(k + 1) links
+    {
+        LV_TRY(hipMemsetAsync(flag, 0, sizeof(uint32_t), r->stream));
+        k_depth_jump<<<blocks, 256, 0, r->stream>>>((int)nodes, d0, a0, d1, a1, flag);
+        std::swap(d0, d1);
+        std::swap(a0, a1);
+        if (pass >= 4) // (a tree of 64 or more leaves is at least six deep: no point in asking earlier)
+        {
+            uint32_t pending = 0;
+            LV_TRY(hipMemcpyAsync(&pending, flag, sizeof(pending), hipMemcpyDeviceToHost, r->stream));
+            LV_TRY(hipStreamSynchronize(r->stream));
+            done = pending == 0;
+        }
+    }
+    if (!done)
+        return hipSuccess; // a parent chain longer than 2^24: not a tree the level passes can take
+    uint32_t maxDepth = 0;
+    LV_TRY(hipMemsetAsync(flag, 0, sizeof(uint32_t), r->stream));
+    k_depth_keys<<<blocks, 256, 0, r->stream>>>((int)nodes, d0, B.keys0.p, B.lvVals0.p, flag);
+    LV_TRY(hipMemcpyAsync(&maxDepth, flag, sizeof(maxDepth), hipMemcpyDeviceToHost, r->stream));
+    LV_TRY(hipStreamSynchronize(r->stream));
+    if (maxDepth >= kMaxTreeLevels)
+        return hipSuccess;
+    const uint64_t *sortedKeys = B.keys1.p;
+    radixPass(r, nodes, B.keys0.p, B.lvVals0.p, B.keys1.p, B.lvVals1.p, 0, B.hist.p, B.histSums.p);
+    B.levelOrder = B.lvVals1.p;
+    if (maxDepth > 255)
+    {
+        radixPass(r, nodes, B.keys1.p, B.lvVals1.p, B.keys0.p, B.lvVals0.p, 8, B.hist.p, B.histSums.p);
+        B.levelOrder = B.lvVals0.p;
+        sortedKeys = B.keys0.p;
+    }
+    k_level_starts<<<blocks, 256, 0, r->stream>>>((int)nodes, sortedKeys, B.lvStartDev.p);
+    B.levelStart.assign(maxDepth + 2, 0u);
+    LV_TRY(hipMemcpyAsync(B.levelStart.data(), B.lvStartDev.p, (maxDepth + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
+    LV_TRY(hipStreamSynchronize(r->stream));
+    B.levelStart[maxDepth + 1] = nodes;
+    for (uint32_t d = 0; d <= maxDepth; d++) // every depth up to the deepest holds a node, in order
+        if (B.levelStart[d] >= B.levelStart[d + 1])
+            return hipSuccess;
+#undef LV_TRY
+    B.levelsValid = true;
+    *usable = true;
+    return hipSuccess;
+}
+
+// Bottom-up boxes of the binary tree over the level lists: one launch per level, deepest first.
+static void refitLevels(PtxRenderer *r, const uint32_t *vin, const float4 *refLo, const float4 *refHi)
+{
+    PtxRenderer::BuildState &B = r->build;
+    for (size_t d = B.levelStart.size() - 1; d-- > 0;)
+    {
+        const uint32_t first = B.levelStart[d], count = B.levelStart[d + 1] - first;
+        k_refit_level<<<(count + 255) / 256, 256, 0, r->stream>>>(first, count, B.levelOrder, vin, refLo, refHi, B.children.p, B.nodeLo.p, B.nodeHi.p);
+    }
+}
+
 // Full build (refit = false) or refit: new triangle records and leaf boxes, then the bottom-up box pass and the
 // 4-wide emit over the KEPT Morton order and binary topology.  keepState leaves the temporaries allocated for
 // later refits; a static scene frees them.
@@ -1304,9 +1407,22 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
         }
         else if (!refit)
             k_karras<<<vblocks, 256, 0, r->stream>>>((int)nv, kin, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p);
+        // bottom-up boxes: over the level lists (kept from the last full build for a refit); the fence-and-atomic climb only for a
+        // tree the lists cannot take
+        const bool fenceKernels = r->env.fenceRefit;
+        bool haveLevels = false;
         if (!boxesDone)
-            k_refit<<<vblocks, 256, 0, r->stream>>>((int)nv, vin, refLo, refHi, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p,
-                                               B.nodeLo.p, B.nodeHi.p, B.flags.p);
+        {
+            if (refit)
+                haveLevels = B.levelsValid && !fenceKernels;
+            else if (!fenceKernels)
+                BUILD_TRY(treeLevels(r, nv, &haveLevels));
+            if (haveLevels)
+                refitLevels(r, vin, refLo, refHi);
+            else
+                k_refit<<<vblocks, 256, 0, r->stream>>>((int)nv, vin, refLo, refHi, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p,
+                                                   B.nodeLo.p, B.nodeHi.p, B.flags.p);
+        }
         const uint32_t reinsertPasses = (refit || r->reinsertBroken) ? 0u : r->tree.reinsertPasses;
         if (reinsertPasses && nv > 3)
         {
@@ -1351,17 +1467,37 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
                     BUILD_TRY(hipStreamSynchronize(r->stream));
                     return buildAccel(r, false, keepState);
                 }
-                BUILD_TRY(hipMemsetAsync(B.flags.p, 0, (size_t)nv * 4, r->stream));
-                k_refit<<<vblocks, 256, 0, r->stream>>>((int)nv, vin, refLo, refHi, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p, B.nodeLo.p, B.nodeHi.p,
-                                                   B.flags.p);
+                haveLevels = false;
+                if (!fenceKernels)
+                    BUILD_TRY(treeLevels(r, nv, &haveLevels)); // the pass changed the topology
+                if (haveLevels)
+                    refitLevels(r, vin, refLo, refHi);
+                else
+                {
+                    BUILD_TRY(hipMemsetAsync(B.flags.p, 0, (size_t)nv * 4, r->stream));
+                    k_refit<<<vblocks, 256, 0, r->stream>>>((int)nv, vin, refLo, refHi, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p, B.nodeLo.p, B.nodeHi.p,
+                                                       B.flags.p);
+                }
             }
             BUILD_TRY(hipStreamSynchronize(r->stream)); // (the pass's buffers go out of scope)
         }
         if (r->tree.collapse)
         {
-            BUILD_TRY(hipMemsetAsync(B.flags.p, 0, (size_t)nv * 4, r->stream)); // (the arrival flags of k_refit: done with)
-            k_collapse_cost<<<vblocks, 256, 0, r->stream>>>((int)nv, vin, refLo, refHi, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p, B.nodeLo.p, B.nodeHi.p, B.flags.p,
-                                                       B.collapseCost.p, B.collapseDecide.p);
+            if (!refit && !B.levelsValid && !fenceKernels) // (PLOC computes its boxes itself: no pass above has asked for the lists yet)
+                BUILD_TRY(treeLevels(r, nv, &haveLevels));
+            if (B.levelsValid && !fenceKernels)
+                for (size_t d = B.levelStart.size() - 1; d-- > 0;)
+                {
+                    const uint32_t first = B.levelStart[d], count = B.levelStart[d + 1] - first;
+                    k_collapse_cost_level<<<(count + 255) / 256, 256, 0, r->stream>>>(first, count, B.levelOrder, vin, refLo, refHi, B.children.p, B.nodeLo.p,
+                                                                                     B.nodeHi.p, B.collapseCost.p, B.collapseDecide.p);
+                }
+            else
+            {
+                BUILD_TRY(hipMemsetAsync(B.flags.p, 0, (size_t)nv * 4, r->stream)); // (the arrival flags of k_refit: done with)
+                k_collapse_cost<<<vblocks, 256, 0, r->stream>>>((int)nv, vin, refLo, refHi, B.children.p, B.parentOfNode.p, B.parentOfLeaf.p, B.nodeLo.p, B.nodeHi.p,
+                                                           B.flags.p, B.collapseCost.p, B.collapseDecide.p);
+            }
         }
         k_emit<<<vblocks, 256, 0, r->stream>>>((int)nv, vin, refLo, refHi, B.children.p, B.nodeLo.p, B.nodeHi.p, B.triTmp.p,
                                               B.rawNodes.p, r->tris.p, r->pairs.p, r->vertices.p, r->indices.p, r->shadeTris.p,
