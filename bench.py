@@ -190,13 +190,18 @@ class Job:
         # page-locked host images for the pipelined read-back, one per renderer
         self.host = [torch.empty(self.W * self.H * 4, dtype=torch.float32, pin_memory=True) for _ in range(self.F)] if rank == 0 else []
         self.k = 0
+        self.host_issue_s = 0.0
         self.issued = [False] * self.F
         self.collect = None
         self.gather = world > 1 or args.force_gather
+        # --emulate-shard R/N with --force-gather: rank 0's whole duty of an N-GPU step on ONE GPU -- pack, the collective call (one
+        # rank: RCCL's launch and a local copy; the N - 1 pieces that would arrive over xGMI are one device copy), N unpacks,
+        # read-back.  The link time itself is the model of tools/scaling_emulation.py; everything else is timed.
+        self.pieces = self.shard_world if (args.emulate_shard and args.force_gather) else world
         if self.gather:  # gather plumbing: equal-size padded shard buffers per frame in flight, one all_gather per step
-            self.shard_floats = max(self.rs[0].shard_bytes(k) for k in range(world)) // 4
+            self.shard_floats = max(self.rs[0].shard_bytes(k) for k in range(self.pieces)) // 4
             self.send = [torch.zeros(self.shard_floats, dtype=torch.float32, device="cuda") for _ in range(self.F)]
-            self.recv = [torch.zeros(world * self.shard_floats, dtype=torch.float32, device="cuda") for _ in range(self.F)]
+            self.recv = [torch.zeros(self.pieces * self.shard_floats, dtype=torch.float32, device="cuda") for _ in range(self.F)]
 
     def _take_stats(self, i):
         if self.issued[i] and self.collect is not None:
@@ -217,6 +222,7 @@ class Job:
         self.k += 1
         r = self.rs[i]
         self._take_stats(i)
+        t_host = time.perf_counter()  # from here on nothing waits for the GPU: what the host spends enqueueing one step
         r.reset()
         r.render_frames(self.u, self.lights, 0, job_spp)
         self.issued[i] = True
@@ -224,17 +230,21 @@ class Job:
             send, recv = self.send[i], self.recv[i]
             r.pack_shard(send.data_ptr())
             with torch.cuda.stream(self.streams[i]):  # the renderer runs on this torch stream: the collective is ordered behind the pack
-                if self.args.dist_backend == "nccl":
+                if self.pieces != self.world:  # emulation (see __init__)
+                    dist.all_gather_into_tensor(recv[:self.shard_floats], send)
+                    recv[self.shard_floats:].view(self.pieces - 1, self.shard_floats).copy_(send.expand(self.pieces - 1, self.shard_floats))
+                elif self.args.dist_backend == "nccl":
                     dist.all_gather_into_tensor(recv, send)  # RCCL: every shard straight over its own xGMI link
                 else:  # gloo (testing): staged through the host
                     parts = [torch.empty(self.shard_floats) for _ in range(self.world)]
                     dist.all_gather(parts, send.cpu())
                     recv.copy_(torch.cat(parts))
             if self.rank == 0:
-                for k in range(self.world):
+                for k in range(self.pieces):
                     r.unpack_shard(k, recv.data_ptr() + k * self.shard_floats * 4)
         if readback and self.rank == 0:
             r.readback_begin(self.host[i].data_ptr(), self.nbytes)
+        self.host_issue_s += time.perf_counter() - t_host
 
     def finish(self):
         for i, r in enumerate(self.rs):
@@ -257,8 +267,10 @@ class Job:
         self.barrier()
         self.collect = collect
         t0 = time.perf_counter()
+        self.host_issue_s = 0.0
         for _ in range(steps):
             self.step(job_spp, readback)
+        self.host_enqueue_s = self.host_issue_s  # the host's own share of the region: enqueueing, without the waits for statistics
         self.finish()
         self.barrier()
         elapsed = time.perf_counter() - t0
@@ -446,7 +458,9 @@ def roofline(job, stats, digest, stats_x=None, step_ms=None, segments_per_sample
         if "overlapped" in out:
             out["overlapped"]["achieved_counter"] = traffic / (over["avg_launch_ms"] * 1e-3) / 1e9
             out["overlapped"]["frac_counter"] = out["overlapped"]["achieved_counter"] / HBM_PEAK_GBS
-        out["traffic_source"] = os.path.relpath(tj, REPO) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, (2*FETCH+WRITE)*1024)"
+        out["traffic_factor"] = doc["k_trace_closest"].get("fetch_factor", 2.0)  # FETCH_SIZE -> bytes, measured per access pattern
+        out["traffic_source"] = (os.path.relpath(tj, REPO) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, (factor*FETCH+WRITE)*1024; factor 1 for "
+                                 "per-lane 64-B records, 2 for coalesced streams: profiles/r05_fetch_size_calibration.txt)")
         out["traffic_stale"] = doc.get("source_digest") != digest
     if step_ms and segments_per_sample:
         samples = job.W * job.H * job.args.spp / job.shard_world  # what THIS rank renders per step
@@ -460,6 +474,9 @@ def roofline(job, stats, digest, stats_x=None, step_ms=None, segments_per_sample
             total = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in doc.items() if isinstance(v, dict) and k in RENDER_KERNELS)
             step["counter_bytes"] = total / frames
             step["frac_counter"] = step["counter_bytes"] / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            upper = sum(v.get("hbm_bytes_per_launch_upper", v["hbm_bytes_per_launch"]) * v["launches"] for k, v in doc.items()
+                        if isinstance(v, dict) and k in RENDER_KERNELS)
+            step["frac_counter_upper"] = upper / frames / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS  # FETCH_SIZE doubled for every kernel (rounds 1-4)
             step["counter_bytes_by_kernel"] = {k: v["hbm_bytes_per_launch"] * v["launches"] / frames for k, v in doc.items()
                                                if isinstance(v, dict) and k in RENDER_KERNELS and v["hbm_bytes_per_launch"] * v["launches"] / frames > 1e6}
         out["step"] = step
@@ -668,6 +685,8 @@ def main():
                     help="experiments only: one process renders the tile shard of rank R of N (no gather) to see what a rank of an "
                          "N-GPU run costs; the printed line is marked and is not a benchmark result")
     ap.add_argument("--emulate-scaling", default="strong", choices=["weak", "strong"])
+    ap.add_argument("--emulate-readback", default="auto", choices=["auto", "on", "off"],
+                    help="experiments only: --emulate-shard steps end with the pipelined read-back (auto: with --force-gather)")
     ap.add_argument("--shard", default=None, metavar="R/N",
                     help="N = 1 only: measure rank R's share of an N-GPU pixel-tile shard of the frame (BASELINE configs[3] and [4] are "
                          "4- and 8-GPU jobs: one GPU renders one rank's tiles; the line says so and `value` is that rank's rate)")
@@ -709,12 +728,13 @@ def main():
               "vs_baseline": None,  # the reference publishes no number for this metric
               "dtype": "f32", "data": "synthetic", "source_digest": digest}
 
-    if args.emulate_shard:  # experiments: what one rank of an N-GPU job costs, on one GPU, no gather
+    if args.emulate_shard:  # experiments: what one rank of an N-GPU job costs, on one GPU (--force-gather: with rank 0's gather duty)
         er, ew = (int(x) for x in args.emulate_shard.split("/"))
         job = Job(args, pkg, torch, dist, args.scene, 0, 1, local_rank, shard=(er, ew))
         job_spp = args.spp * (ew if args.emulate_scaling == "weak" else 1)
-        med, regions, stats = job.measure(job_spp, args.steps, args.warmup, args.repeats, args.min_seconds, readback=False)
-        out = dict(common, emulated_shard=args.emulate_shard, scaling=args.emulate_scaling, steps=args.steps,
+        med, regions, stats = job.measure(job_spp, args.steps, args.warmup, args.repeats, args.min_seconds, readback=(args.emulate_readback == "on" or (args.emulate_readback == "auto" and args.force_gather)))
+        out = dict(common, emulated_shard=args.emulate_shard, scaling=args.emulate_scaling, steps=args.steps, gather_in_loop=bool(args.force_gather),
+                   host_enqueue_ms_per_step=job.host_enqueue_s / args.steps * 1e3,  # of the last region: the host's enqueue calls alone (no waits)
                    value=W * H * job_spp * args.steps / med / 1e6 / ew, ms_per_step=med / args.steps * 1e3,
                    config={"workload": f"EMULATION of rank {er} of {ew} ({args.scene}, tile shard, no gather, {job_spp} spp)",
                            "kernel_ms_per_step": {k: stats[k] / args.steps for k in ("trace_ms", "shade_ms", "shadow_ms", "tail_ms")}})

@@ -90,11 +90,16 @@ struct EnvSwitches
     uint32_t framesPerWave = 8;  // PTX_FRAMES_PER_WAVE: samples of one pixel in neighbouring lanes, at most this many
     uint32_t raysPerThread = 0;  // PTX_RAYS_PER_THREAD (process-wide: the last handle created sets it)
     long residentCap = -1;       // PTX_RESIDENT_CAP=0: persistent grids are not capped at the resident block count
+    uint32_t copyGroups = 0;     // PTX_COPY_GROUPS: workgroups of the read-back copy kernel (0: one, or 2 per rank of a tile shard, at most 16)
+    bool snapshotMemcpy = false; // PTX_SNAPSHOT_MEMCPY=1: the read-back's device-side snapshot by hipMemcpyAsync (rounds 1-4) instead of a kernel
     bool fenceRefit = false;     // PTX_FENCE_REFIT=1: the round-4 bottom-up kernels (fence and atomic per node) instead of the level lists
     static EnvSwitches read()
     {
         EnvSwitches e;
         e.verbose = getenv("PTX_VERBOSE") != nullptr;
+        if (const char *v = getenv("PTX_COPY_GROUPS"))
+            e.copyGroups = (uint32_t)strtoul(v, nullptr, 10);
+        e.snapshotMemcpy = getenv("PTX_SNAPSHOT_MEMCPY") != nullptr && std::strcmp(getenv("PTX_SNAPSHOT_MEMCPY"), "0") != 0;
         e.fenceRefit = getenv("PTX_FENCE_REFIT") != nullptr && std::strcmp(getenv("PTX_FENCE_REFIT"), "0") != 0;
         if (const char *v = getenv("PTX_BUILDER"))
             e.karrasBuilder = std::strcmp(v, "lbvh") == 0;
@@ -2282,7 +2287,13 @@ static int readbackBegin(PtxRenderer *r, float *pinnedHost, size_t bytes)
     HIP_TRY(r, r->staging.alloc((size_t)r->width * r->height));
     if (r->copyInFlight) // the previous copy still reads the staging image
         HIP_TRY(r, hipStreamWaitEvent(r->stream, r->evCopied, 0));
-    HIP_TRY(r, hipMemcpyAsync(r->staging.p, imagePtr(r), bytes, hipMemcpyDeviceToDevice, r->stream));
+    // the snapshot by a copy KERNEL (33 MB at the memory's rate: ~20 us), not hipMemcpyAsync: the runtime's device-to-device copy
+    // took 0.5 ms per 1080p image and the copies of the frames in flight queue behind one another -- a floor of 0.5 ms per step
+    // under every renderer that reads back, half the step of a 1 / 8 tile shard (tools/experiments/gather_cost.sh, round 5)
+    if (r->env.snapshotMemcpy)
+        HIP_TRY(r, hipMemcpyAsync(r->staging.p, imagePtr(r), bytes, hipMemcpyDeviceToDevice, r->stream));
+    else
+        k_copy_out<<<1024, kBlock, 0, r->stream>>>(imagePtr(r), r->staging.p, (uint32_t)(bytes / sizeof(float4)));
     HIP_TRY(r, hipEventRecord(r->evSnapshot, r->stream));
     HIP_TRY(r, hipStreamWaitEvent(copyOn, r->evSnapshot, 0));
     // The snapshot leaves through ONE workgroup writing to the page-locked buffer (posted writes over PCIe, 33 MB in a few ms)
@@ -2292,7 +2303,13 @@ static int readbackBegin(PtxRenderer *r, float *pinnedHost, size_t bytes)
     // / 2,441 / 2,465 / 2,483-2,494.  Host memory the device cannot address (not page-locked) takes the runtime's copy.
     void *hostOnDevice = nullptr;
     if (hipHostGetDevicePointer(&hostOnDevice, pinnedHost, 0) == hipSuccess && hostOnDevice)
-        k_copy_out<<<1, kBlock, 0, copyOn>>>(r->staging.p, static_cast<float4 *>(hostOnDevice), (uint32_t)(bytes / sizeof(float4)));
+    {
+        // ... for a whole frame on one GPU.  Rank 0 of an N-GPU job renders 1 / N of the frame per step and still reads ALL of it
+        // back: there the link, not the rendering, sets the pace, and one workgroup's 8 GB/s (4.1 ms per 1080p image) made a 1 / 8
+        // step of chess_like 2.2 ms instead of 0.96 (tools/experiments/gather_cost.sh) -- more workgroups with more ranks.
+        const uint32_t groups = r->env.copyGroups ? r->env.copyGroups : (r->shard.worldSize > 1 ? std::min(16u, 2u * r->shard.worldSize) : 1u);
+        k_copy_out<<<groups, kBlock, 0, copyOn>>>(r->staging.p, static_cast<float4 *>(hostOnDevice), (uint32_t)(bytes / sizeof(float4)));
+    }
     else
     {
         (void)hipGetLastError();
