@@ -615,21 +615,10 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
                     }
                     else
                     {
-#ifdef PTX_EXP_BRANCHFREE_PUSH
-                        // three unconditional LDS stores at computed depths (what lies above sp is never read) instead of three
-                        // predicated regions
-                        const int p3 = st.sp, p2 = p3 + (h > 3 ? 1 : 0), p1 = p2 + (h > 2 ? 1 : 0);
-                        st.lds[p3 * st.stride] = (uint32_t)r3;
-                        st.lds[p2 * st.stride] = (uint32_t)r2;
-                        st.lds[p1 * st.stride] = (uint32_t)r1;
-                        st.sp = p1 + (h > 1 ? 1 : 0);
-                        ref = h > 0 ? r0 : kRefNone;
-#else
                         if (h > 3) st.pushLds((uint32_t)r3);
                         if (h > 2) st.pushLds((uint32_t)r2);
                         if (h > 1) st.pushLds((uint32_t)r1);
                         ref = h > 0 ? r0 : kRefNone;
-#endif
                     }
                     if (ref == kRefNone)
                         ref = st.sp ? (int)st.popLds() : kRefDone;

@@ -1025,7 +1025,10 @@ PT_DEV f4 sampleLevel(const TextureView &tv, const DevTexture &t, uint32_t level
 // scheme of the Vulkan / EXT_texture_filter_anisotropic specifications: eta = min(rho_max / rho_min, 16), N = ceil(eta)
 // trilinear taps at LOD log2(rho_max / eta) along the longer gradient at (i / (N + 1) - 1/2), averaged; N = 1 is the
 // isotropic lookup.
-constexpr float kMaxAnisotropy = 16.0f;
+#ifndef PTX_EXP_MAX_ANISOTROPY
+#define PTX_EXP_MAX_ANISOTROPY 16.0f // (experiments only: what the anisotropic taps cost; the oracle's PTO_MAX_ANISOTROPY is 16)
+#endif
+constexpr float kMaxAnisotropy = PTX_EXP_MAX_ANISOTROPY;
 
 // The two levels of a trilinear lookup and the blend between them: the same for every tap of one textureGrad.
 struct TrilinearView
