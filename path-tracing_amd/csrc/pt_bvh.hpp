@@ -330,6 +330,18 @@ PT_DEV int visitNode(const BvhNode *__restrict__ np, f3 o, f3 id, float tmin, fl
         r0 = refs.x; r1 = refs.y; r2 = refs.z; r3 = refs.w;
         return (h0 ? 1 : 0) | (h1 ? 2 : 0) | (h2 ? 4 : 0) | (h3 ? 8 : 0);
     }
+#ifdef PTX_EXP_AXIS_ORDER
+    {
+        // experiment: k_emit stored the children in descending centroid order along the node's axis (bits 24..25 of the exponent
+        // word); PT_ENTER_UNORDERED enters the highest hit slot first, which is the near end for a ray that travels up the axis --
+        // one that travels down it sees the slots reversed
+        const uint32_t axis = (eb >> 24) & 3u;
+        const bool down = axis == 0u ? ngx : (axis == 1u ? ngy : ngz);
+        r0 = down ? refs.w : refs.x; r1 = down ? refs.z : refs.y; r2 = down ? refs.y : refs.z; r3 = down ? refs.x : refs.w;
+        const int fwd = (h0 ? 1 : 0) | (h1 ? 2 : 0) | (h2 ? 4 : 0) | (h3 ? 8 : 0), bwd = (h3 ? 1 : 0) | (h2 ? 2 : 0) | (h1 ? 4 : 0) | (h0 ? 8 : 0);
+        return down ? bwd : fwd;
+    }
+#endif
     const float inf = __uint_as_float(0x7f800000u);
     float k0 = h0 ? t0 : inf, k1 = h1 ? t1 : inf, k2 = h2 ? t2 : inf, k3 = h3 ? t3 : inf;
     r0 = refs.x; r1 = refs.y; r2 = refs.z; r3 = refs.w;
@@ -414,7 +426,12 @@ PT_DEV bool traceRay(const TraceScene &sc, f3 o, f3 d, float tmin, float tmax, S
                 (*nodeVisits)++;
             int r0, r1, r2, r3;
             const int h = visitNode<!ANY_HIT>(&sc.nodes[ref], o, id, tmin, ANY_HIT ? best.t : best.t * kCullSlack, r0, r1, r2, r3);
-            if (ANY_HIT)
+#ifdef PTX_EXP_AXIS_ORDER
+            constexpr bool kMaskWalk = true; // (experiment: the ordered visit returns a mask in the node's build-time order)
+#else
+            constexpr bool kMaskWalk = ANY_HIT;
+#endif
+            if (kMaskWalk)
             {
                 PT_ENTER_UNORDERED(h, r0, r1, r2, r3, st, ref, kRefNone, push)
             }
@@ -601,12 +618,14 @@ PT_DEV void persistentTrace(const TraceScene &sc, IO &io, uint32_t count, uint32
             if (have && ref >= 0 && ref != kRefDone)
             {
                 int r0, r1, r2, r3;
-#ifdef PTX_EXP_UNORDERED_CLOSEST
-                constexpr bool kUnordered = true; // experiment: closest-hit rays enter the hit children in slot order too
+#if defined(PTX_EXP_UNORDERED_CLOSEST)
+                constexpr bool kUnordered = true, kVisitOrdered = false; // experiment: closest-hit rays enter the hit children in slot order too
+#elif defined(PTX_EXP_AXIS_ORDER)
+                constexpr bool kUnordered = true, kVisitOrdered = !ANY_HIT; // experiment: ... in the build-time order along the node's axis (a mask, not a count)
 #else
-                constexpr bool kUnordered = ANY_HIT;
+                constexpr bool kUnordered = ANY_HIT, kVisitOrdered = !ANY_HIT;
 #endif
-                const int h = visitNode<!kUnordered>(&sc.nodes[ref], o, id, PT_TMIN, ANY_HIT ? PT_TMAX : best.t * kCullSlack, r0, r1, r2, r3);
+                const int h = visitNode<kVisitOrdered>(&sc.nodes[ref], o, id, PT_TMIN, ANY_HIT ? PT_TMAX : best.t * kCullSlack, r0, r1, r2, r3);
                 if (__builtin_expect(st.roomFor(kNodeWidth - 1), 1)) // every lane of this step stays in the LDS part of its stack
                 {
                     if (kUnordered)

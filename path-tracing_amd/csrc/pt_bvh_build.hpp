@@ -1525,6 +1525,36 @@ __global__ void k_emit(int n, const uint32_t *__restrict__ vals, const float4 *_
         count++;
     }
 
+    uint32_t orderAxis = 0;
+#ifdef PTX_EXP_AXIS_ORDER
+    // experiment (docs/EXPERIMENTS.md, round 5): the children stored in DESCENDING order of their centroids along the axis on which
+    // the centroids spread most; the closest-hit walk then enters the highest hit slot first for a ray that travels up that axis and
+    // the lowest for one that travels down it -- a fixed build-time order instead of the sorting network
+    {
+        float lo3[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi3[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+        for (int k = 0; k < kNodeWidth; k++)
+            if (k < count)
+                for (int a = 0; a < 3; a++)
+                {
+                    const float m = c[k].lo[a] + c[k].hi[a];
+                    lo3[a] = fminf(lo3[a], m);
+                    hi3[a] = fmaxf(hi3[a], m);
+                }
+        const float sx = hi3[0] - lo3[0], sy = hi3[1] - lo3[1], sz = hi3[2] - lo3[2];
+        orderAxis = sx >= sy && sx >= sz ? 0u : (sy >= sz ? 1u : 2u);
+        float key[kNodeWidth];
+        for (int k = 0; k < kNodeWidth; k++)
+            key[k] = k < count ? (orderAxis == 0 ? c[k].lo[0] + c[k].hi[0] : orderAxis == 1 ? c[k].lo[1] + c[k].hi[1] : c[k].lo[2] + c[k].hi[2]) : -3.0e38f;
+#define PT_ORDER_SWAP(a, b)                                                                                                \
+        if (key[a] < key[b])                                                                                               \
+        {                                                                                                                  \
+            const float tk = key[a]; key[a] = key[b]; key[b] = tk;                                                         \
+            const ChildBox tc = c[a]; c[a] = c[b]; c[b] = tc;                                                              \
+        }
+        PT_ORDER_SWAP(0, 1) PT_ORDER_SWAP(2, 3) PT_ORDER_SWAP(0, 2) PT_ORDER_SWAP(1, 3) PT_ORDER_SWAP(1, 2)
+#undef PT_ORDER_SWAP
+    }
+#endif
     const float4 nl = nodeLo[i], nh = nodeHi[i];
     const float o[3] = { nl.x, nl.y, nl.z }, top[3] = { nh.x, nh.y, nh.z };
     uint32_t ebits[3], qlo[3] = { 0, 0, 0 }, qhi[3] = { 0, 0, 0 };
@@ -1580,7 +1610,7 @@ __global__ void k_emit(int n, const uint32_t *__restrict__ vals, const float4 *_
         }
     }
     BvhNode nd;
-    nd.a = make_float4(o[0], o[1], o[2], __uint_as_float(ebits[0] | (ebits[1] << 8) | (ebits[2] << 16)));
+    nd.a = make_float4(o[0], o[1], o[2], __uint_as_float(ebits[0] | (ebits[1] << 8) | (ebits[2] << 16) | (orderAxis << 24)));
     // a leaf of a non-opaque geometry says so in its ref: the traversal fetches its any-hit record beside the triangle
     for (int k = 0; k < count; k++)
         if (c[k].ref < 0 && (__float_as_uint(triTmp[refTri ? refTri[vals[~c[k].ref]] : vals[~c[k].ref]].c.w) & kTriNonOpaque))
