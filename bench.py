@@ -411,6 +411,11 @@ def shade_roofline(job, stats_x):
            "stale": doc.get("source_digest") != source_digest(job.pkg)}
     if "SQ_WAVE_CYCLES" in k and k["SQ_WAVE_CYCLES"]:
         out["wave_cycles_waiting"] = k.get("SQ_WAIT_ANY", 0.0) / k["SQ_WAVE_CYCLES"]
+    if k.get("rocprof_ms_alone"):
+        # the kernel's own duration (rocprofv3 --kernel-trace of this command with one frame in flight, committed beside the counters):
+        # the live HIP-event bracket (ms_alone) also holds the wait for the previous bounce's k_apply_shadow on the auxiliary stream
+        out["ms_alone_rocprof"] = k["rocprof_ms_alone"]
+        out["frac_valu_issue_rocprof"] = valu / VALU_ISSUE_PER_S / (k["rocprof_ms_alone"] * 1e-3)
     return out
 
 
@@ -488,6 +493,12 @@ def roofline(job, stats, digest, stats_x=None, step_ms=None, segments_per_sample
     shade = shade_roofline(job, stats_x)
     if shade:
         out["shade"] = shade
+    sq, _ = counter_doc(job, "sq")
+    if sq:  # rocprofv3's own average of the same launch alone (committed kernel trace, one frame in flight): must agree with avg_launch_ms
+        alone = [v for k, v in sq.items() if isinstance(v, dict) and k.startswith("k_trace_closest") and v.get("rocprof_ms_alone")]
+        if alone:
+            best = max(alone, key=lambda v: v.get("rocprof_calls_alone", 0))
+            out["avg_launch_ms_rocprof"] = best["rocprof_ms_alone"]
     return out
 
 
@@ -542,11 +553,11 @@ def compact_line(full, detail_path=None):
     rf = full.get("roofline")
     if rf:
         o = _pick(rf, ("kernel", "bound", "limiter", "achieved", "peak", "unit", "frac", "traffic", "traffic_factor", "frac_counter", "frac_step_counter",
-                       "frac_step_model", "model_valid", "avg_launch_ms", "rays_per_launch", "model_bytes_per_ray", "traffic_stale", "measured_on"))
+                       "frac_step_model", "model_valid", "avg_launch_ms", "avg_launch_ms_rocprof", "rays_per_launch", "model_bytes_per_ray", "traffic_stale", "measured_on"))
         if rf.get("traffic_source"):
             o["traffic_source"] = rf["traffic_source"].split(" ")[0]
         if rf.get("shade"):
-            o["shade"] = _pick(rf["shade"], ("kernel", "frac_valu_issue", "ms_alone", "valu_wave_insts_per_launch"))
+            o["shade"] = _pick(rf["shade"], ("kernel", "frac_valu_issue", "ms_alone", "ms_alone_rocprof", "valu_wave_insts_per_launch"))
         out["roofline"] = o
     cb = full.get("cpu_baseline")
     if cb:

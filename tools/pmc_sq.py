@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """Per-kernel sums of SQ counters from rocprofv3 --pmc passes (counter_collection.csv), per launch.
-Usage: pmc_sq.py [--json out.json --scene NAME --shape KEY] <dir> [<dir> ...]
+Usage: pmc_sq.py [--json out.json --scene NAME --shape KEY --stats-alone kernel_stats_one_in_flight.csv] <dir> [<dir> ...]
 Each dir = one pass; counters of all passes are merged by kernel name (template variants kept apart).  The text summary goes to
 stdout; --json also writes {kernel: {counter: value per launch, "launches": n}, "scene", "shape", "source_digest"}, which
-bench.py reads for roofline.shade (VALU wave-instructions per launch of k_shade against the chip's issue rate)."""
+bench.py reads for roofline.shade (VALU wave-instructions per launch of k_shade against the chip's issue rate).  --stats-alone: the
+rocprofv3 --kernel-trace --stats summary of the same command with ONE frame in flight; every kernel's average duration there goes
+into the JSON as "rocprof_ms_alone" (the kernel's own duration: bench.py's HIP-event bracket of k_shade also holds the wait for the
+previous bounce's k_apply_shadow on the other stream)."""
 import collections
 import csv
 import glob
@@ -23,7 +26,7 @@ def source_digest():
 
 def main():
     args = sys.argv[1:]
-    opts = {"--json": None, "--scene": "chess_like", "--shape": "1920x1080/8spp/d8/shard0of1"}
+    opts = {"--json": None, "--scene": "chess_like", "--shape": "1920x1080/8spp/d8/shard0of1", "--stats-alone": None}
     while args and args[0] in opts:
         opts[args[0]] = args[1]
         args = args[2:]
@@ -46,6 +49,12 @@ def main():
             entry[name] = v / n
             entry["launches"] = n
         doc[k.replace("void ", "")] = entry
+    if opts["--stats-alone"] and os.path.exists(opts["--stats-alone"]):
+        for r in csv.DictReader(open(opts["--stats-alone"])):
+            k = r["Name"].split("(")[0].replace("void ", "")
+            if k in doc:
+                doc[k]["rocprof_ms_alone"] = float(r["AverageNs"]) * 1e-6
+                doc[k]["rocprof_calls_alone"] = int(r["Calls"])
     if opts["--json"]:
         doc["scene"], doc["shape"], doc["source_digest"] = opts["--scene"], opts["--shape"], source_digest()
         json.dump(doc, open(opts["--json"], "w"), indent=1, sort_keys=True)

@@ -36,7 +36,7 @@ python3 tools/trace_gaps.py gpurun_out/${TAG}_trace | grep step | tail -3
 CMD3="python3 bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-extra-scenes $*"
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/${TAG}_sq1 -o sq -- $CMD3 > gpurun_out/${TAG}_sq1.log 2>&1; echo "sq1 rc=$?"
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU --output-format csv -d gpurun_out/${TAG}_sq2 -o sq -- $CMD3 > gpurun_out/${TAG}_sq2.log 2>&1; echo "sq2 rc=$?"
-python3 tools/pmc_sq.py --json gpurun_out/${TAG}_sq.json --scene $SCENE --shape $SHAPE gpurun_out/${TAG}_sq1 gpurun_out/${TAG}_sq2 > gpurun_out/${TAG}_sq.txt 2>&1
+python3 tools/pmc_sq.py --json gpurun_out/${TAG}_sq.json --scene $SCENE --shape $SHAPE --stats-alone gpurun_out/${TAG}_kernel_stats_one_in_flight.csv gpurun_out/${TAG}_sq1 gpurun_out/${TAG}_sq2 > gpurun_out/${TAG}_sq.txt 2>&1
 cp "$(find gpurun_out/${TAG}_trace -name '*kernel_stats.csv' | head -1)" gpurun_out/${TAG}_kernel_stats.csv 2>/dev/null
 find gpurun_out/${TAG}_trace gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write gpurun_out/${TAG}_sq1 gpurun_out/${TAG}_sq2 -name "*.csv" -size +1M -delete
 # the un-profiled line quotes the traffic of THIS build: it looks for the newest profiles/r*_traffic.json
