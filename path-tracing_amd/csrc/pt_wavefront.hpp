@@ -1069,8 +1069,11 @@ __global__ void __launch_bounds__(kBlock) k_megakernel(LaunchParams p, SceneView
 #ifndef PT_TAIL_LDS
 #define PT_TAIL_LDS 32
 #endif
+// the textured tails (k_tail<1>, <2>, k_finish_restarts) at TWO waves per SIMD: at three they spilled 63-105 VGPRs into 148-188
+// bytes of scratch per lane, and both settings measure the same (round 4: atrium_like's 1 / 8 shard 2.88-2.91 ms per step, configs[3]
+// 827-835 Msamples/s either way) -- no scratch, then
 #ifndef PT_TAIL_TEX_ATTR
-#define PT_TAIL_TEX_ATTR PT_TAIL_ATTR
+#define PT_TAIL_TEX_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
 template <int MODE>
 PT_DEV void tailBody(const LaunchParams &p, const SceneView &sv, const TraceScene &sc, const Wavefront &wf, int qin, const BounceCtl &ctl);
