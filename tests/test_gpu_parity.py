@@ -672,6 +672,31 @@ def test_tree_choice_does_not_change_images(pkg, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scene_name,detail", [("street_like", 0.2), ("atrium_like", 0.1)])
+def test_level_lists_build_the_same_tree_as_the_fence_kernels(pkg, monkeypatch, scene_name, detail):
+    """The bottom-up passes of the build (boxes after every reinsertion pass, the collapse's pricing) run over level lists -- depths
+    by pointer jumping, nodes sorted by depth, one launch per level -- instead of the round-4 kernels that climbed from every leaf
+    with two fences and one atomic per node (PTX_FENCE_REFIT=1).  Both compute the same floats in a different order of nodes, so
+    the chosen tree is the same: the same number of wide nodes after the cost-driven collapse (a different box anywhere would move
+    the candidates' sampled costs and the collapse's decisions), and the same closest hits."""
+    import torch  # noqa: F401
+
+    scene = pkg.Scene(scene_name, detail)
+    rays = util.random_rays(np.random.default_rng(3), 20000, -8.0, 8.0)
+    got = []
+    for fence in ("0", "1"):
+        monkeypatch.setenv("PTX_FENCE_REFIT", fence)
+        r = pkg.Renderer()
+        r.upload(scene)
+        st = r.stats()
+        hits, ids = r.trace_rays(rays)
+        got.append((st.bvhNodes, st.treeTriangles, hits.view(np.uint32).copy(), ids.copy()))
+        r.close()
+    assert got[0][0] == got[1][0] and got[0][1] == got[1][1], (got[0][:2], got[1][:2])
+    assert (got[0][2] == got[1][2]).all() and (got[0][3] == got[1][3]).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("scene_name,detail", [("temple_like", 0.15), ("alpha_test", 1.0), ("chess_like", 0.05)])
 def test_presplit_triangles_change_nothing(pkg, orc, monkeypatch, scene_name, detail):
     """Triangle pre-splitting (PTX_SPLIT_BUDGET, TreeParams::splitBudget; off by default): a large triangle hangs from several
