@@ -89,6 +89,10 @@ BASELINE_CONFIGS = (
       "--warmup", "2"]),
 )
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+# What the chip delivers for THIS path's access pattern when nothing depends on anything: every lane fetching its own 64-byte record
+# (four dwordx4) at a permuted index of a 1 GiB buffer -- tools/experiments/fetch_size_calibration.hip, profiles/r05_fetch_size_calibration.txt:
+# 3.14 TB/s (the coalesced float4 stream of the same run: 6.74 TB/s).  The traversal's counter bytes are priced against it as well.
+GATHER_PEAK_GBS = 3140.0
 
 
 def algorithmic_bytes_per_closest_ray(n_tris: int) -> int:
@@ -460,6 +464,7 @@ def roofline(job, stats, digest, stats_x=None, step_ms=None, segments_per_sample
         out["traffic"] = traffic
         out["achieved_counter"] = traffic / (out["avg_launch_ms"] * 1e-3) / 1e9
         out["frac_counter"] = out["achieved_counter"] / HBM_PEAK_GBS
+        out["frac_counter_of_gather_rate"] = out["achieved_counter"] / GATHER_PEAK_GBS  # against the measured rate of independent 64-B gathers
         if "overlapped" in out:
             out["overlapped"]["achieved_counter"] = traffic / (over["avg_launch_ms"] * 1e-3) / 1e9
             out["overlapped"]["frac_counter"] = out["overlapped"]["achieved_counter"] / HBM_PEAK_GBS
@@ -552,7 +557,7 @@ def compact_line(full, detail_path=None):
         out["weak"] = _pick(full["weak"], ("scaling", "value", "ms_per_step", "workload"))
     rf = full.get("roofline")
     if rf:
-        o = _pick(rf, ("kernel", "bound", "limiter", "achieved", "peak", "unit", "frac", "traffic", "traffic_factor", "frac_counter", "frac_step_counter",
+        o = _pick(rf, ("kernel", "bound", "limiter", "achieved", "peak", "unit", "frac", "traffic", "traffic_factor", "frac_counter", "frac_counter_of_gather_rate", "frac_step_counter",
                        "frac_step_model", "model_valid", "avg_launch_ms", "avg_launch_ms_rocprof", "rays_per_launch", "model_bytes_per_ray", "traffic_stale", "measured_on"))
         if rf.get("traffic_source"):
             o["traffic_source"] = rf["traffic_source"].split(" ")[0]
