@@ -148,3 +148,29 @@ def test_the_json_line_ends_stdout_whatever_else_prints(tmp_path):
     assert "NCCL WARN" in p.stderr and "late chatter" in p.stderr
     detail = json.load(open(tmp_path / "bench_detail.json"))
     assert "overlapped" in detail["roofline"] and len(detail["configs"]) >= 5  # the full record is in the file
+
+
+def test_fetch_size_factor_follows_the_measured_calibration(tmp_path):
+    """tools/pmc_traffic.py: FETCH_SIZE counts half the bytes of a coalesced 16-B-per-lane stream and all the bytes of per-lane
+    64-byte records (profiles/r05_fetch_size_calibration.txt), so the factor is per kernel; the all-doubled figure of rounds 1-4
+    rides beside it."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import pmc_traffic
+
+    assert pmc_traffic.fetch_factor("k_generate") == 2.0 and pmc_traffic.fetch_factor("k_accumulate") == 2.0
+    assert pmc_traffic.fetch_factor("k_trace_closest") == 1.0 and pmc_traffic.fetch_factor("k_trace_shadow") == 1.0 and pmc_traffic.fetch_factor("k_shade") == 1.0
+    cal = open(os.path.join(REPO, "profiles", "r05_fetch_size_calibration.txt")).read()
+    assert "k_stream" in cal and "counter / known = 0.500" in cal and "k_gather64" in cal and "counter / known = 1.000" in cal
+    for d, counter, rows in (("fetch", "FETCH_SIZE", (("void k_trace_closest<false>(ptd::TraceScene)", 1000.0), ("k_generate(LaunchParams, Wavefront)", 10.0))),
+                             ("write", "WRITE_SIZE", (("void k_trace_closest<false>(ptd::TraceScene)", 100.0), ("k_generate(LaunchParams, Wavefront)", 2000.0)))):
+        (tmp_path / d).mkdir()
+        with open(tmp_path / d / "x_counter_collection.csv", "w") as f:
+            f.write("Kernel_Name,Counter_Name,Counter_Value\n")
+            for name, v in rows:
+                f.write(f'"{name}",{counter},{v}\n')
+    out = tmp_path / "t.json"
+    subprocess.run([sys.executable, os.path.join(REPO, "tools", "pmc_traffic.py"), str(tmp_path / "fetch"), str(tmp_path / "write"), str(out), "chess_like"],
+                   check=True, capture_output=True)
+    doc = json.load(open(out))
+    assert doc["k_trace_closest"]["hbm_bytes_per_launch"] == (1000.0 + 100.0) * 1024 and doc["k_trace_closest"]["hbm_bytes_per_launch_upper"] == 2100.0 * 1024
+    assert doc["k_generate"]["hbm_bytes_per_launch"] == (2 * 10.0 + 2000.0) * 1024 and doc["k_generate"]["fetch_factor"] == 2.0
