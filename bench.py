@@ -244,8 +244,13 @@ class Job:
                     dist.all_gather(parts, send.cpu())
                     recv.copy_(torch.cat(parts))
             if self.rank == 0:
+                # the owner of the frame hands it to the host WHILE it unpacks it (ptx_unpack_shard_host): no snapshot and no second
+                # pass over the image -- with N ranks rendering, the read-back of the whole frame is what bounds rank 0's step
+                fused = readback and self.args.gather_readback == "fused"
                 for k in range(self.pieces):
-                    r.unpack_shard(k, recv.data_ptr() + k * self.shard_floats * 4)
+                    r.unpack_shard(k, recv.data_ptr() + k * self.shard_floats * 4, self.host[i].data_ptr() if fused else 0, self.nbytes)
+                if fused:
+                    readback = False
         if readback and self.rank == 0:
             r.readback_begin(self.host[i].data_ptr(), self.nbytes)
         self.host_issue_s += time.perf_counter() - t_host
@@ -700,6 +705,9 @@ def main():
     ap.add_argument("--emulate-shard", default=None, metavar="R/N",
                     help="experiments only: one process renders the tile shard of rank R of N (no gather) to see what a rank of an "
                          "N-GPU run costs; the printed line is marked and is not a benchmark result")
+    ap.add_argument("--gather-readback", default="fused", choices=["fused", "separate"],
+                    help="N > 1, rank 0: the gathered frame goes to the host inside the unpack kernels (ptx_unpack_shard_host) / through "
+                         "ptx_unpack_shard + ptx_readback_begin as a whole-frame renderer's does (rounds 1-4)")
     ap.add_argument("--emulate-scaling", default="strong", choices=["weak", "strong"])
     ap.add_argument("--emulate-readback", default="auto", choices=["auto", "on", "off"],
                     help="experiments only: --emulate-shard steps end with the pipelined read-back (auto: with --force-gather)")

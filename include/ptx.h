@@ -452,6 +452,12 @@ PTX_API size_t ptx_accum_bytes(const PtxRenderer *r);
 PTX_API size_t ptx_shard_bytes(const PtxRenderer *r, uint32_t rank);
 PTX_API int ptx_pack_shard(PtxRenderer *r, void *devDst);
 PTX_API int ptx_unpack_shard(PtxRenderer *r, uint32_t rank, const void *devSrc);
+/* The same, and the shard's pixels also go straight into `pinnedHost` (page-locked, device-addressable, width*height*16 bytes):
+ * the rank that owns the gathered frame hands it to the host while it unpacks it -- no snapshot and no second pass over the image,
+ * which is what bounds a step once the ranks render faster than the PCIe link reads back.  Asynchronous on
+ * the render stream; the buffer is complete once every rank's shard has been unpacked into it and ptx_readback_end() has returned
+ * (it waits for the last such call). */
+PTX_API int ptx_unpack_shard_host(PtxRenderer *r, uint32_t rank, const void *devSrc, float *pinnedHost, size_t bytes);
 
 PTX_API int ptx_get_stats(PtxRenderer *r, PtxStats *stats);
 

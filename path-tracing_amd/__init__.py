@@ -57,7 +57,7 @@ PTX_SYMBOLS = [
     "ptx_create", "ptx_destroy", "ptx_last_error", "ptx_device_count", "ptx_abi_version", "ptx_scene_upload", "ptx_build_accel", "ptx_share_scene",
     "ptx_resize", "ptx_set_tile_shard", "ptx_set_backend", "ptx_reset_accumulation", "ptx_render",
     "ptx_render_frames", "ptx_synchronize", "ptx_readback", "ptx_readback_begin", "ptx_readback_end", "ptx_device_accum_ptr", "ptx_accum_bytes",
-    "ptx_shard_bytes", "ptx_pack_shard", "ptx_unpack_shard", "ptx_get_stats", "ptx_bind_accumulation",
+    "ptx_shard_bytes", "ptx_pack_shard", "ptx_unpack_shard", "ptx_unpack_shard_host", "ptx_get_stats", "ptx_bind_accumulation",
     "ptx_trace_rays", "ptx_test_input_stride", "ptx_test_output_stride", "ptx_test_eval", "ptx_test_texture",
     "ptx_postprocess", "ptx_read_output", "ptx_write_accumulation", "ptx_update_animation",
 ]
@@ -292,6 +292,7 @@ def load_hip() -> C.CDLL:
         lib.ptx_shard_bytes.restype = C.c_size_t
         lib.ptx_pack_shard.argtypes = [P, P]
         lib.ptx_unpack_shard.argtypes = [P, C.c_uint32, P]
+        lib.ptx_unpack_shard_host.argtypes = [P, C.c_uint32, P, P, C.c_size_t]
         lib.ptx_get_stats.argtypes = [P, C.POINTER(Stats)]
         lib.ptx_postprocess.argtypes = [P, C.POINTER(PostProcessingUniformData), C.c_uint32]
         lib.ptx_read_output.argtypes = [P, C.c_uint32, P, C.c_size_t]
@@ -501,8 +502,13 @@ class Renderer:
     def pack_shard(self, dev_dst: int):
         self._check(self.lib.ptx_pack_shard(self.handle, dev_dst))
 
-    def unpack_shard(self, rank: int, dev_src: int):
-        self._check(self.lib.ptx_unpack_shard(self.handle, rank, dev_src))
+    def unpack_shard(self, rank: int, dev_src: int, pinned_host: int = 0, nbytes: int = 0):
+        """ptx_unpack_shard; with `pinned_host` (address of a page-locked width*height*16-byte buffer) ptx_unpack_shard_host: the
+        shard's pixels also go straight to the host's frame (complete after every rank's shard and readback_end())."""
+        if pinned_host:
+            self._check(self.lib.ptx_unpack_shard_host(self.handle, rank, dev_src, pinned_host, nbytes))
+        else:
+            self._check(self.lib.ptx_unpack_shard(self.handle, rank, dev_src))
 
     def trace_rays(self, rays: np.ndarray, any_hit: bool = False):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)

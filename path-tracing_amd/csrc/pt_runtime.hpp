@@ -2320,10 +2320,29 @@ static int readbackBegin(PtxRenderer *r, float *pinnedHost, size_t bytes)
     return PTX_OK;
 }
 
-static int unpackShard(PtxRenderer *r, uint32_t rank, const void *devSrc)
+static int unpackShard(PtxRenderer *r, uint32_t rank, const void *devSrc, float *pinnedHost = nullptr, size_t hostBytes = 0)
 {
     if (!r || !devSrc || !imagePtr(r) || rank >= r->shard.worldSize)
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_unpack_shard: bad argument");
+    float4 *hostOnDevice = nullptr;
+    if (pinnedHost)
+    {
+        if (hostBytes != (size_t)r->width * r->height * sizeof(float4))
+            return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_unpack_shard_host: buffer must be width*height*16 bytes");
+        HIP_TRY(r, hipSetDevice(r->device));
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, pinnedHost, 0) != hipSuccess || !dp)
+        {
+            (void)hipGetLastError();
+            return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_unpack_shard_host: the buffer is not page-locked memory the device can address");
+        }
+        hostOnDevice = static_cast<float4 *>(dp);
+        if (!r->evSnapshot)
+        {
+            HIP_TRY(r, hipEventCreateWithFlags(&r->evSnapshot, hipEventDisableTiming));
+            HIP_TRY(r, hipEventCreateWithFlags(&r->evCopied, hipEventDisableTiming | hipEventReleaseToSystem));
+        }
+    }
     PtxRenderer tmp;
     tmp.width = r->width;
     tmp.height = r->height;
@@ -2331,8 +2350,13 @@ static int unpackShard(PtxRenderer *r, uint32_t rank, const void *devSrc)
     tmp.shard.rank = rank;
     const LaunchParams p = makeParams(&tmp, nullptr, 0, 1);
     if (p.slotsPerFrame)
-        k_unpack_shard<<<gridFor(p.slotsPerFrame), kBlock, 0, r->stream>>>(p, static_cast<const float4 *>(devSrc), imagePtr(r));
+        k_unpack_shard<<<gridFor(p.slotsPerFrame), kBlock, 0, r->stream>>>(p, static_cast<const float4 *>(devSrc), imagePtr(r), hostOnDevice);
     HIP_TRY(r, hipGetLastError());
+    if (hostOnDevice) // ptx_readback_end waits for the LAST of these: the stores of every unpack before it are released with it
+    {
+        HIP_TRY(r, hipEventRecord(r->evCopied, r->stream));
+        r->copyInFlight = true;
+    }
     return PTX_OK;
 }
 

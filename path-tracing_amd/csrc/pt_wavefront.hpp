@@ -1314,13 +1314,20 @@ __global__ void k_pack_shard(LaunchParams p, const float4 *__restrict__ image, f
         dst[s] = pixel == 0xffffffffu ? make_float4(0, 0, 0, 0) : image[pixel];
     }
 }
-__global__ void k_unpack_shard(LaunchParams p, const float4 *__restrict__ src, float4 *__restrict__ image)
+// host != nullptr: the same pixels also go straight to the page-locked frame of the host (ptx_unpack_shard_host: rank 0 of an
+// N-GPU step hands the gathered frame to the host while it unpacks it -- no snapshot, no second pass over the image)
+__global__ void k_unpack_shard(LaunchParams p, const float4 *__restrict__ src, float4 *__restrict__ image, float4 *__restrict__ host)
 {
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < p.slotsPerFrame; s += gridDim.x * blockDim.x)
     {
         const uint32_t pixel = slotPixel(p, s);
         if (pixel != 0xffffffffu)
-            image[pixel] = src[s];
+        {
+            const float4 v = src[s];
+            image[pixel] = v;
+            if (host)
+                host[pixel] = v;
+        }
     }
 }
 

@@ -180,6 +180,13 @@ int ptx_unpack_shard(PtxRenderer *r, uint32_t rank, const void *devSrc)
     return unpackShard(r, rank, devSrc);
 }
 
+int ptx_unpack_shard_host(PtxRenderer *r, uint32_t rank, const void *devSrc, float *pinnedHost, size_t bytes)
+{
+    if (!pinnedHost)
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_unpack_shard_host: null host buffer");
+    return unpackShard(r, rank, devSrc, pinnedHost, bytes);
+}
+
 int ptx_postprocess(PtxRenderer *r, const PtxPostProcessingUniformData *uniform, uint32_t toneMappingMode)
 {
     return postprocess(r, uniform, toneMappingMode);

@@ -6,11 +6,7 @@ run() { python3 bench.py --scene ${SCENE:-chess_like} --emulate-shard 0/8 --no-c
 echo "shard alone";                          run
 echo "shard + read-back";                    run --emulate-readback on
 echo "shard + gather duty, no read-back";    run --force-gather --dist-backend nccl --emulate-readback off
-echo "shard + gather duty + read-back";      run --force-gather --dist-backend nccl
+echo "shard + gather duty + read-back (ptx_unpack_shard + ptx_readback_begin, rounds 1-4)"; run --force-gather --dist-backend nccl --gather-readback separate
+echo "shard + gather duty + read-back (ptx_unpack_shard_host: the frame goes to the host inside the unpack kernels)"; run --force-gather --dist-backend nccl --gather-readback fused
 echo "whole frame (N = 1), read-back, PTX_COPY_GROUPS=1 / 4"; 
 for g in 1 4; do PTX_COPY_GROUPS=$g python3 bench.py --scene chess_like --emulate-shard 0/1 --emulate-readback on --no-cpu-baseline --steps 20 --warmup 4 2>/dev/null | tail -1 | python3 tools/experiments/print_step.py; done
-echo "-- with the round-4 snapshot (hipMemcpyAsync) --"
-export PTX_SNAPSHOT_MEMCPY=1
-echo "shard + read-back";                    run --emulate-readback on
-echo "shard + gather duty + read-back";      run --force-gather --dist-backend nccl
-python3 bench.py --scene chess_like --emulate-shard 0/1 --emulate-readback on --no-cpu-baseline --steps 20 --warmup 4 2>/dev/null | tail -1 | python3 tools/experiments/print_step.py
