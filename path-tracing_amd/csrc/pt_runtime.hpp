@@ -2350,7 +2350,15 @@ static int unpackShard(PtxRenderer *r, uint32_t rank, const void *devSrc, float 
     tmp.shard.rank = rank;
     const LaunchParams p = makeParams(&tmp, nullptr, 0, 1);
     if (p.slotsPerFrame)
-        k_unpack_shard<<<gridFor(p.slotsPerFrame), kBlock, 0, r->stream>>>(p, static_cast<const float4 *>(devSrc), imagePtr(r), hostOnDevice);
+    {
+        // towards the host a FEW workgroups (PTX_COPY_GROUPS; default 4 per shard): what the link carries in a burst, the command
+        // processor's own traffic over it waits behind -- 2 / 4 / 8 / 16 / 64 / 2,048 workgroups: 1.45 / 1.38 / 1.42 / 1.47 / 1.50 /
+        // 1.51 ms per 1 / 8 step of chess_like (profiles/r05_unpack_groups.txt)
+        uint32_t grid = gridFor(p.slotsPerFrame);
+        if (hostOnDevice)
+            grid = std::min(grid, r->env.copyGroups ? r->env.copyGroups : 4u);
+        k_unpack_shard<<<grid, kBlock, 0, r->stream>>>(p, static_cast<const float4 *>(devSrc), imagePtr(r), hostOnDevice);
+    }
     HIP_TRY(r, hipGetLastError());
     if (hostOnDevice) // ptx_readback_end waits for the LAST of these: the stores of every unpack before it are released with it
     {
