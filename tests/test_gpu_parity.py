@@ -313,6 +313,10 @@ def test_tile_shards_compose_to_full_frame(pkg):
     gathered.upload(scene)
     gathered.resize(W, H)
     gathered.set_tile_shard(0, world, 32)
+    # ptx_unpack_shard_host: the owner of the frame writes every shard into the host's page-locked frame while it unpacks it
+    host = torch.full((H * W * 4,), -1.0, dtype=torch.float32).pin_memory()
+    with pytest.raises(pkg.PtxError):
+        gathered.unpack_shard(0, 4096, host.data_ptr(), 16)  # the host buffer must be the whole frame
     for rank in range(world):
         part = pkg.Renderer()
         part.upload(scene)
@@ -327,9 +331,15 @@ def test_tile_shards_compose_to_full_frame(pkg):
         buf = torch.empty(nbytes // 4, dtype=torch.float32, device="cuda")
         part.pack_shard(buf.data_ptr())
         part.synchronize()
-        gathered.unpack_shard(rank, buf.data_ptr())
+        if rank == 1:
+            gathered.unpack_shard(rank, buf.data_ptr())  # the plain form and ...
+            gathered.unpack_shard(rank, buf.data_ptr(), host.data_ptr(), host.numel() * 4)  # ... the form that also writes the host's frame
+        else:
+            gathered.unpack_shard(rank, buf.data_ptr(), host.data_ptr(), host.numel() * 4)
         gathered.synchronize()
         part.close()
+    gathered.readback_end()  # waits for the last unpack's stores to the host
+    assert (host.numpy().reshape(H, W, 4).view(np.uint32) == ref.view(np.uint32)).all()
     out = gathered.readback()
     assert (out.view(np.uint32) == ref.view(np.uint32)).all()
     full.close()
