@@ -34,14 +34,14 @@ static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
  * profiles/r05_rcp_sqrt_exhaustive.txt; tests/test_gpu_parity.py::test_specified_reciprocal_on_all_inputs). */
 static inline float pto_rcp(float x)
 {
-    const float ax = fabsf(x);
+    uint32_t ab;
+    memcpy(&ab, &x, 4);
+    ab &= 0x7fffffffu;
+    if (ab - 0x00800000u <= 0x7e800000u - 0x00800000u) /* 2^-126 <= |x| <= 2^126: one range test on the bits */
+        return 1.0f / x;
     if (x != x)
         return x;
-    if (ax < 1.17549435e-38f) /* 2^-126 */
-        return copysignf(INFINITY, x);
-    if (ax > 8.50705917e37f) /* 2^126 */
-        return copysignf(0.0f, x);
-    return 1.0f / x;
+    return ab < 0x00800000u ? copysignf(INFINITY, x) : copysignf(0.0f, x); /* zero / denormal divisor; |x| > 2^126 incl. infinity */
 }
 static inline float pto_div(float a, float b) { return a * pto_rcp(b); }
 
