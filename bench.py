@@ -70,6 +70,7 @@ STAND_IN = {"chess_like": "configs[1] 'Khronos ABeautifulGame'", "temple_like": 
             "atrium_like": "configs[3] 'Intel Sponza (MAIN+CURTAINS+IVY)'", "street_like": "configs[4] 'Amazon Bistro night'",
             "attenuation_blob": "configs[0] 'Khronos DragonAttenuation'"}
 EXTRA_SCENES = ("atrium_like", "temple_like", "street_like")
+NORTH_STAR_SCENE = "atrium_like"  # BASELINE.json north_star: "Intel Sponza at 1080p / 8 spp on 1 MI355X" through its stand-in
 # BASELINE.json `configs` at their own definitions (child processes of the default run).  Samples per pixel of the multi-GPU
 # jobs are bounded (a rate: 64 of configs[3]'s 256, 128 of configs[4]'s 1024) so that the default run stays within minutes.
 CHILD_CPU_SECONDS = 3.0  # CPU leg of a `configs` child (one frame at least); the headline's own leg is --cpu-seconds
@@ -80,7 +81,7 @@ BASELINE_CONFIGS = (
      ["--scene", "default", "--width", "512", "--height", "512", "--spp", "1", "--depth", "4", "--steps", "50", "--warmup", "5"]),
     ("configs[2] UE4 Sun Temple, 1920x1080, 64 spp, depth 8 -- 1xMI355X: ONE renderer, 64-frame batches",
      ["--scene", "temple_like", "--spp", "64", "--depth", "8", "--in-flight", "1", "--steps", "4", "--warmup", "1"]),
-    ("configs[2] the same with two 64-frame batches in flight",
+    ("configs[2] the same with two 64-frame batches in flight (--detail-run only)",
      ["--scene", "temple_like", "--spp", "64", "--depth", "8", "--in-flight", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]),
     ("configs[3] Intel Sponza, 1920x1080, 256 spp, depth 12 -- 4xMI355X: rank 0's tiles, 64 of the 256 spp per step",
      ["--scene", "atrium_like", "--spp", "64", "--depth", "12", "--shard", "0/4", "--in-flight", "2", "--steps", "4", "--warmup", "2"]),
@@ -95,11 +96,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 GATHER_PEAK_GBS = 3140.0
 
 
+CLOSEST_STATE_BYTES = 4 + 32 + 20  # what k_trace_closest must move besides the tree: queue index 4 B + ray 32 B read + hit record 20 B written
+
+
 def algorithmic_bytes_per_closest_ray(n_tris: int) -> int:
-    """DESIGN.md 'Roofline': k_trace_closest per ray = L(N)*B_node + B_tri + the
-    state the kernel must move: queue index 4 B + ray 32 B read + hit record 20 B written."""
+    """SURVEY.md 8(d), the contract figure `roofline.frac` is priced on: B_trace_closest = L(N) * B_node + B_tri = 32 L(N) + 36
+    bytes per ray, L = ceil(log2 N).  (`frac_with_state` adds CLOSEST_STATE_BYTES: the kernel's own queue / ray / hit records.)"""
     L = max(1, math.ceil(math.log2(max(n_tris, 2))))
-    return 32 * L + 36 + 4 + 32 + 20
+    return 32 * L + 36
 
 
 def effective_cores() -> int:
@@ -151,6 +155,61 @@ def cpu_baseline(orc, scene, width, height, depth, seconds):
     }
 
 
+class FrameStore:
+    """The host frames of a job: `count` page-locked RGBA32F frames, frame j at ptr(j).
+
+    One process (N = 1, emulations): torch's page-locked allocator.  N > 1: ONE POSIX shared-memory segment that every rank of the
+    node maps; a rank registers with the HIP runtime (hipHostRegister) the frames it OWNS -- its gather kernel stores straight into
+    them -- and any process of the node (rank 0 here; an OutputSaver thread in a host application, OutputSaver.cpp:120-199) reads
+    every frame whichever rank composed it.  The name is unlinked as soon as every rank has mapped the segment: nothing stays in
+    /dev/shm behind a job, however it ends."""
+
+    def __init__(self, torch, dist, count, nbytes, rank, world, owned):
+        self.torch, self.count, self.nbytes, self.shared = torch, count, nbytes, world > 1
+        self.stride = (nbytes + 4095) // 4096 * 4096
+        self.registered = []
+        if not self.shared:
+            self.tensors = [torch.empty(nbytes // 4, dtype=torch.float32, pin_memory=True) for _ in range(count)]
+            return
+        import ctypes
+        import mmap
+        path = f"/dev/shm/ptx_frames_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}"
+        size = self.stride * count
+        if rank == 0:
+            fd = os.open(path, os.O_CREAT | os.O_RDWR | os.O_TRUNC, 0o600)
+            os.ftruncate(fd, size)
+        dist.barrier()
+        if rank != 0:
+            fd = os.open(path, os.O_RDWR)
+        self.mm = mmap.mmap(fd, size)
+        os.close(fd)
+        dist.barrier()
+        if rank == 0:
+            os.unlink(path)
+        self.base = ctypes.addressof(ctypes.c_char.from_buffer(self.mm))
+        rt = torch.cuda.cudart()
+        for j in owned:
+            err = rt.cudaHostRegister(self.base + j * self.stride, self.stride, 0)
+            if int(err) != 0:
+                raise RuntimeError(f"hipHostRegister of host frame {j} failed: {err}")
+            self.registered.append(self.base + j * self.stride)
+
+    def ptr(self, j):
+        return self.base + j * self.stride if self.shared else self.tensors[j].data_ptr()
+
+    def image(self, j, H, W):
+        if not self.shared:
+            return self.tensors[j].numpy().reshape(H, W, 4)
+        return np.frombuffer(self.mm, dtype=np.float32, count=H * W * 4, offset=j * self.stride).reshape(H, W, 4)
+
+    def close(self):
+        if self.shared:
+            rt = self.torch.cuda.cudart()
+            for a in self.registered:
+                rt.cudaHostUnregister(a)
+            self.registered = []
+
+
 class Job:
     """The scene, `in_flight` renderers on one GPU and the step() of the metric, for any (rank, world).
 
@@ -191,21 +250,42 @@ class Job:
         self.build_ms = self.rs[0].stats().lastBuildMs
         self.n_tris = self.scene.triangle_count
         self.nbytes = self.W * self.H * 16
-        # page-locked host images for the pipelined read-back, one per renderer
-        self.host = [torch.empty(self.W * self.H * 4, dtype=torch.float32, pin_memory=True) for _ in range(self.F)] if rank == 0 else []
         self.k = 0
         self.host_issue_s = 0.0
         self.issued = [False] * self.F
         self.collect = None
         self.gather = world > 1 or args.force_gather
-        # --emulate-shard R/N with --force-gather: rank 0's whole duty of an N-GPU step on ONE GPU -- pack, the collective call (one
-        # rank: RCCL's launch and a local copy; the N - 1 pieces that would arrive over xGMI are one device copy), N unpacks,
-        # read-back.  The link time itself is the model of tools/scaling_emulation.py; everything else is timed.
+        # --emulate-shard R/N with --force-gather: one rank's whole share of an N-GPU step on ONE GPU -- the collective call (one
+        # rank: RCCL's launch and a local copy) every step and, on the steps whose frame this rank OWNS, the N - 1 pieces that would
+        # arrive over xGMI (one device copy), the one gather launch and the frame's way to the host.  The link time itself is the
+        # model of tools/scaling_emulation.py; everything else is timed.
         self.pieces = self.shard_world if (args.emulate_shard and args.force_gather) else world
-        if self.gather:  # gather plumbing: equal-size padded shard buffers per frame in flight, one all_gather per step
+        # The OWNER of step k's frame: the rank that composes it from the gathered shards and hands it to the host.  Rotating
+        # (k % N): the RNG is a pure function of (pixel, width, frame) (common.glsl:143-147) and every frame in flight has its own
+        # resources (Renderer.cpp:1454-1460), so any rank may own any frame -- no rank carries the read-back of every step.
+        self.rotate = args.root == "rotate"
+        # host frames: step k lands in frame k % L, L = lcm(ranks, frames in flight) -- (k % N, k % F) name the owner and the ring
+        # slot, and a frame is reused only after the step that wrote it has left the ring
+        self.L = self.F * self.pieces // math.gcd(self.F, self.pieces) if self.gather else self.F
+        me = self.shard_rank if self.pieces != world else rank
+        owned = [j for j in range(self.L) if (j % self.pieces if self.rotate else 0) == me] if self.gather else list(range(self.L))
+        self.frames = FrameStore(torch, dist, self.L, self.nbytes, rank, world, owned)
+        if self.gather:  # gather plumbing: equal-size padded shard buffers per frame in flight, one collective per step
             self.shard_floats = max(self.rs[0].shard_bytes(k) for k in range(self.pieces)) // 4
             self.send = [torch.zeros(self.shard_floats, dtype=torch.float32, device="cuda") for _ in range(self.F)]
             self.recv = [torch.zeros(self.pieces * self.shard_floats, dtype=torch.float32, device="cuda") for _ in range(self.F)]
+            if args.shard_accumulation == "bound":
+                # raygen.rgen:115-117's accumulation goes straight into the message of the gather: no ptx_pack_shard pass
+                torch.cuda.synchronize()
+                for r, send in zip(self.rs, self.send):
+                    r.bind_shard_accumulation(send.data_ptr(), self.shard_floats * 4)
+
+    def owner(self, k):
+        """The rank that owns the frame of step k (`me` of an emulation is the emulated rank)."""
+        return k % self.pieces if self.rotate else 0
+
+    def i_own(self, k):
+        return self.owner(k) == (self.shard_rank if self.pieces != self.world else self.rank)
 
     def _take_stats(self, i):
         if self.issued[i] and self.collect is not None:
@@ -222,37 +302,55 @@ class Job:
 
     def step(self, job_spp, readback=True):
         torch, dist = self.torch, self.dist
-        i = self.k % self.F
+        k = self.k
+        i = k % self.F
         self.k += 1
         r = self.rs[i]
         self._take_stats(i)
         t_host = time.perf_counter()  # from here on nothing waits for the GPU: what the host spends enqueueing one step
         r.reset()
-        r.render_frames(self.u, self.lights, 0, job_spp)
+        r.render_frames(self.u, self.lights, 0, job_spp)  # (bound shard accumulation: k_accumulate writes the message itself)
         self.issued[i] = True
+        frame = self.frames.ptr(k % self.L)
         if self.gather:
             send, recv = self.send[i], self.recv[i]
-            r.pack_shard(send.data_ptr())
-            with torch.cuda.stream(self.streams[i]):  # the renderer runs on this torch stream: the collective is ordered behind the pack
-                if self.pieces != self.world:  # emulation (see __init__)
+            mine, root = self.i_own(k), self.owner(k)
+            if self.args.shard_accumulation != "bound":
+                r.pack_shard(send.data_ptr())
+            with torch.cuda.stream(self.streams[i]):  # the renderer runs on this torch stream: the collective is ordered behind the frame
+                if self.pieces != self.world:  # emulation (see __init__): the call every rank makes, the pieces only the owner receives
                     dist.all_gather_into_tensor(recv[:self.shard_floats], send)
-                    recv[self.shard_floats:].view(self.pieces - 1, self.shard_floats).copy_(send.expand(self.pieces - 1, self.shard_floats))
+                    if mine:
+                        recv[self.shard_floats:].view(self.pieces - 1, self.shard_floats).copy_(send.expand(self.pieces - 1, self.shard_floats))
+                elif self.args.dist_backend == "nccl" and self.args.collective == "gather":
+                    # the single gather of SURVEY.md 8(e): grouped ncclSend / ncclRecv, every piece over its own xGMI link to the owner
+                    dist.gather(send, list(recv.view(self.world, self.shard_floats).unbind(0)) if mine else None, dst=root)
                 elif self.args.dist_backend == "nccl":
-                    dist.all_gather_into_tensor(recv, send)  # RCCL: every shard straight over its own xGMI link
+                    dist.all_gather_into_tensor(recv, send)  # every shard to every rank: N x the bytes, one ring kernel
                 else:  # gloo (testing): staged through the host
-                    parts = [torch.empty(self.shard_floats) for _ in range(self.world)]
-                    dist.all_gather(parts, send.cpu())
-                    recv.copy_(torch.cat(parts))
-            if self.rank == 0:
-                # the owner of the frame hands it to the host WHILE it unpacks it (ptx_unpack_shard_host): no snapshot and no second
-                # pass over the image -- with N ranks rendering, the read-back of the whole frame is what bounds rank 0's step
-                fused = readback and self.args.gather_readback == "fused"
-                for k in range(self.pieces):
-                    r.unpack_shard(k, recv.data_ptr() + k * self.shard_floats * 4, self.host[i].data_ptr() if fused else 0, self.nbytes)
-                if fused:
+                    parts = [torch.empty(self.shard_floats) for _ in range(self.world)] if mine else None
+                    dist.gather(send.cpu(), parts, dst=root)
+                    if mine:
+                        recv.copy_(torch.cat(parts))
+            if mine:
+                if self.args.gather_unpack == "one":
+                    # ONE launch composes the frame from all N pieces; with a read-back it stores to the host's frame ONLY -- the
+                    # owner hands the frame on (OutputSaver's role) and has no use for a device copy of it
+                    if readback:
+                        r.unpack_shards(recv.data_ptr(), self.shard_floats * 4, False, frame, self.nbytes)
+                    else:
+                        r.unpack_shards(recv.data_ptr(), self.shard_floats * 4, True)
                     readback = False
-        if readback and self.rank == 0:
-            r.readback_begin(self.host[i].data_ptr(), self.nbytes)
+                else:  # rounds 1-5: N launches, device image and (fused) the host's frame
+                    fused = readback and self.args.gather_readback == "fused"
+                    for q in range(self.pieces):
+                        r.unpack_shard(q, recv.data_ptr() + q * self.shard_floats * 4, frame if fused else 0, self.nbytes)
+                    if fused:
+                        readback = False
+            else:
+                readback = False
+        if readback:
+            r.readback_begin(frame, self.nbytes)
         self.host_issue_s += time.perf_counter() - t_host
 
     def finish(self):
@@ -262,7 +360,8 @@ class Job:
             self._take_stats(i)
 
     def last_image(self):
-        return self.host[(self.k - 1) % self.F].numpy().reshape(self.H, self.W, 4)
+        """The frame of the last step, from the job's frame store (after finish() + barrier(): whichever rank composed it)."""
+        return self.frames.image((self.k - 1) % self.L, self.H, self.W)
 
     def barrier(self):
         if self.world > 1:
@@ -353,6 +452,7 @@ class Job:
     def close(self):
         for r in self.rs:
             r.close()
+        self.frames.close()
         self.scene.close()
 
 
@@ -452,7 +552,9 @@ def roofline(job, stats, digest, stats_x=None, step_ms=None, segments_per_sample
     top = kernel_roofline(job, stats_x, bpr) if stats_x and stats_x["trace_ms"] > 0 else over
     out = {
         "bound": "hbm", "kernel": "k_trace_closest", "achieved": top["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": top["frac"], "traffic": None, "achieved_counter": None, "frac_counter": None,
+        "frac": top["frac"],  # (32 L(N) + 36) B per ray
+        "frac_with_state": top["frac"] * (bpr + CLOSEST_STATE_BYTES) / bpr,  # + the kernel's own queue / ray / hit records (rounds 1-5's figure)
+        "traffic": None, "achieved_counter": None, "frac_counter": None,
         "measured": ("launch alone on the machine (the same frames one at a time on the first renderer, live HIP events, before the other frames in flight exist)" if top is not over
                      else "launches of the timed region (live HIP events)"),
         "model_bytes_per_ray": bpr, "model_bytes_per_launch": top["model_bytes_per_launch"],
@@ -549,7 +651,7 @@ def compact_line(full, detail_path=None):
     """The line the driver parses: the contract's keys, `roofline`, `cpu_baseline`, one flat entry per BASELINE config -- under
     LINE_LIMIT bytes whatever the full record holds (optional parts are dropped, last first, if a string ever grows)."""
     out = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data",
-                       "source_digest", "gpu_over_cpu", "one_in_flight_ms_per_step", "one_in_flight_value"))
+                       "source_digest", "gpu_over_cpu", "one_in_flight_ms_per_step", "one_in_flight_value", "n_ranks_seen"))
     out["vs_baseline"] = full.get("vs_baseline")
     cfg = full.get("config", {})
     out["config"] = _pick(cfg, ("workload", "shape", "triangles", "frames_in_flight", "segments_per_sample", "parallelism", "backend", "tile",
@@ -562,7 +664,7 @@ def compact_line(full, detail_path=None):
         out["weak"] = _pick(full["weak"], ("scaling", "value", "ms_per_step", "workload"))
     rf = full.get("roofline")
     if rf:
-        o = _pick(rf, ("kernel", "bound", "limiter", "achieved", "peak", "unit", "frac", "traffic", "traffic_factor", "frac_counter", "frac_counter_of_gather_rate", "frac_step_counter",
+        o = _pick(rf, ("kernel", "bound", "limiter", "achieved", "peak", "unit", "frac", "frac_with_state", "traffic", "traffic_factor", "frac_counter", "frac_counter_of_gather_rate", "frac_step_counter",
                        "frac_step_model", "model_valid", "avg_launch_ms", "avg_launch_ms_rocprof", "rays_per_launch", "model_bytes_per_ray", "traffic_stale", "measured_on"))
         if rf.get("traffic_source"):
             o["traffic_source"] = rf["traffic_source"].split(" ")[0]
@@ -575,13 +677,19 @@ def compact_line(full, detail_path=None):
         out["cpu_baseline"]["sample"] = cb.get("sample", "")[:160]
     if full.get("configs"):
         out["configs"] = [config_entry(c) for c in full["configs"]]
+    ns = full.get("north_star")
+    if ns:  # BASELINE.json north_star's own target: its scene at 1080p / 8 spp / depth 8, whole frame on one GPU, GPU over host CPU >= 10
+        out["north_star"] = {"key": ns.get("config", {}).get("workload", "").split(" ")[0] + " " + ns.get("config", {}).get("shape", ""),
+                             "value": _r(ns.get("value")), "ms_per_step": _r(ns.get("ms_per_step")),
+                             "cpu": _r((ns.get("cpu_baseline") or {}).get("value")), "gpu_over_cpu": _r(ns.get("gpu_over_cpu")),
+                             "frac": _r((ns.get("roofline") or {}).get("frac")), "target_gpu_over_cpu": 10}
     if full.get("stand_ins_8spp"):
         out["stand_ins_8spp"] = [{"key": (c.get("config", {}).get("workload", "").split(" ")[0]), "value": _r(c.get("value")),
                                   "ms_per_step": _r(c.get("ms_per_step")), "cpu": _r((c.get("cpu_baseline") or {}).get("value"))}
                                  for c in full["stand_ins_8spp"]]
     if detail_path:
         out["detail"] = detail_path
-    for drop in (None, "stand_ins_8spp", "weak", "configs"):  # never reached with today's strings; the limit holds by construction
+    for drop in (None, "stand_ins_8spp", "weak", "configs", "north_star"):  # never reached with today's strings; the limit holds by construction
         if drop:
             out.pop(drop, None)
         if len(json.dumps(out)) < LINE_LIMIT:
@@ -621,6 +729,29 @@ def emit(full, compact=True):
     out = _REAL_STDOUT or sys.stdout
     out.write("\n" + line + "\n")
     out.flush()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it: start `python -m torch.distributed.run --nproc-per-node N bench.py <the same
+    arguments>` as a CHILD process (this process has not touched the GPU and never will), relay the LAST line of its stdout -- the one
+    JSON line rank 0 printed -- and hand back its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this host driver
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    for l in lines[:-1]:
+        print(l, file=sys.stderr)
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    return p.returncode
 
 
 def scene_line(args, pkg, torch, dist, orc, name, rank, world, local_rank, steps, warmup, min_seconds, with_cpu, digest):
@@ -708,6 +839,19 @@ def main():
     ap.add_argument("--gather-readback", default="fused", choices=["fused", "separate"],
                     help="N > 1, rank 0: the gathered frame goes to the host inside the unpack kernels (ptx_unpack_shard_host) / through "
                          "ptx_unpack_shard + ptx_readback_begin as a whole-frame renderer's does (rounds 1-4)")
+    ap.add_argument("--root", default="rotate", choices=["rotate", "rank0"],
+                    help="N > 1: the owner of step k's frame (composes it from the gathered shards, hands it to the host) is rank k %% N / "
+                         "always rank 0 (rounds 1-5)")
+    ap.add_argument("--collective", default="gather", choices=["gather", "all_gather"],
+                    help="N > 1, RCCL: one gather to the frame's owner (grouped send / recv: 1 / N of the bytes) / all_gather_into_tensor "
+                         "(every shard to every rank, rounds 1-5)")
+    ap.add_argument("--gather-unpack", default="one", choices=["one", "per-rank"],
+                    help="the owner composes the frame with ONE launch over all N pieces, host-only stores when it reads back "
+                         "(ptx_unpack_shards) / N ptx_unpack_shard[_host] launches (rounds 1-5)")
+    ap.add_argument("--shard-accumulation", default="bound", choices=["bound", "packed"],
+                    help="N > 1: k_accumulate writes the gather's message itself (ptx_bind_shard_accumulation) / row-major image + ptx_pack_shard")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="testing: the ranks only join the process group and count themselves (no GPU work); rank 0 prints one JSON line")
     ap.add_argument("--emulate-scaling", default="strong", choices=["weak", "strong"])
     ap.add_argument("--emulate-readback", default="auto", choices=["auto", "on", "off"],
                     help="experiments only: --emulate-shard steps end with the pipelined read-back (auto: with --force-gather)")
@@ -717,7 +861,12 @@ def main():
     ap.add_argument("--traffic-json", default=None,
                     help="per-kernel HBM bytes per launch from tools/pmc_traffic.py (default: newest profiles/r*_traffic.json)")
     ap.add_argument("--dump-image", default=None, help="testing: rank 0 saves the last frame (npy)")
+    ap.add_argument("--dump-frames", default=None,
+                    help="testing, N > 1: rank 0 saves EVERY host frame of the job's frame store after the strong-scaling run (npy, [L, H, W, 4]): "
+                         "frame j was composed by rank j %% N")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))  # before anything touches the GPU: the ranks are CHILD processes, never an exec
     claim_stdout()
 
     import torch
@@ -728,20 +877,31 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch through torch.distributed.run",
-                  file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: the launcher and the flag disagree", file=sys.stderr)
+        sys.exit(2)
     if args.single_device:
         local_rank = 0
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if args.launch_check:  # the launch path alone: rendezvous, one collective, the one line -- runs without a GPU
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t)
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank == 0:
+            emit({"launch_check": True, "n_gpus": world, "n_ranks_seen": int(t.item())}, compact=False)
+        return
     torch.cuda.set_device(local_rank)
+    n_ranks_seen = 1
     if world > 1 or args.force_gather:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.ones(1, dtype=torch.int64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(t)  # every rank counts itself through the collective the job will use
+        n_ranks_seen = int(t.item())
 
     pkg = graft.load_package()  # after torch: one HIP runtime in the process
     orc = graft.load_oracle() if (rank == 0 and not args.no_cpu_baseline) else None
@@ -802,19 +962,25 @@ def main():
                                                        f"stand-in {name}"))
             out["configs"] = []
             for key, extra in BASELINE_CONFIGS:
-                if "default scene" in key and not args.detail_run:
+                if ("default scene" in key or "--detail-run only" in key) and not args.detail_run:
                     continue
                 l = child(extra + ["--repeats", "2", "--min-seconds", "0"], key, cpu="--no-cpu-baseline" not in extra)
                 out["configs"].append(dict({"baseline_config": key}, **l))
             out["configs"].insert(1, {"baseline_config": "configs[1] Khronos ABeautifulGame, 1920x1080, 8 spp, depth 8 -- 1xMI355X",
                                       "is": "this line (value, roofline, cpu_baseline at the top level)"})
+            # north_star's own target: ">= 10x the host-CPU Msamples/s on Intel Sponza at 1080p / 8 spp on 1 MI355X" -- its stand-in,
+            # the WHOLE frame on this GPU at the headline's shape
+            out["north_star"] = child(["--scene", NORTH_STAR_SCENE, "--steps", "10", "--warmup", "2", "--repeats", "2", "--min-seconds", "0",
+                                       "--width", "1920", "--height", "1080", "--spp", "8", "--depth", "8"], "north_star")
         emit(out, compact=not args.child)
         return
 
     # ---- N > 1: strong scaling of the named frame is the metric; weak scaling beside it
-    job = Job(args, pkg, torch, dist, args.scene, rank, world, local_rank)
+    job = Job(args, pkg, torch, dist, args.scene, rank, world, local_rank, alone_steps=3 if args.backend == "wavefront" else 0)
     med_s, regions_s, stats_s = job.measure(args.spp, args.steps, args.warmup, args.repeats, args.min_seconds, readback=True)
-    img = job.last_image().copy() if rank == 0 else None
+    img = job.last_image().copy() if rank == 0 else None  # from the job's frame store: composed by the rank that owned the last step
+    if rank == 0 and args.dump_frames:
+        np.save(args.dump_frames, np.stack([job.frames.image(j, H, W) for j in range(job.L)]))
     weak_spp = args.spp * world
     med_w, regions_w, stats_w = job.measure(weak_spp, args.steps, 1, args.repeats, args.min_seconds, readback=True)
     if rank == 0:
@@ -827,13 +993,17 @@ def main():
                    config={"workload": f"{args.scene} (procedural stand-in for BASELINE {STAND_IN.get(args.scene, 'scenes')}), {W}x{H}, "
                                        f"{args.spp} spp, depth {args.depth}",
                            "triangles": job.n_tris, "backend": args.backend, "tile": args.tile, "frames_in_flight": job.F,
-                           "parallelism": f"pixel-tile shard x{world}, 1 RCCL all_gather + read-back on rank 0 per step",
+                           "parallelism": (f"pixel-tile shard x{world}, 1 {args.collective if args.dist_backend == 'nccl' else 'gloo gather'} per step to the frame's owner "
+                                           f"({'rank k % N' if job.rotate else 'rank 0'}), {'one' if args.gather_unpack == 'one' else 'N'} unpack launch(es), "
+                                           f"host frames in shared memory"),
                            "rank0_kernel_ms_per_step": {"k_trace_closest": stats_s["trace_ms"] / args.steps, "k_shade": stats_s["shade_ms"] / args.steps,
                                                         "k_trace_shadow": stats_s["shadow_ms"] / args.steps, "k_tail": stats_s["tail_ms"] / args.steps},
                            "frame_checksum": [float(img[..., :3].astype(np.float64).sum()), bool(np.isfinite(img).all()), bool((img[..., 3] == 1).all())]})
-        if args.backend == "wavefront" and stats_w["trace_ms"] > 0:
-            out["roofline"] = roofline(job, stats_w, digest)
-            out["roofline"]["measured_on"] = "rank 0, weak-scaling run (per-GPU work of the 1-GPU benchmark)"
+        out["n_ranks_seen"] = n_ranks_seen
+        if args.backend == "wavefront" and stats_s["trace_ms"] > 0:
+            # as at N = 1: the launch ALONE on rank 0's GPU (its tile shard of the frame, before the other frames in flight exist)
+            out["roofline"] = roofline(job, stats_s, digest, job.alone_stats)
+            out["roofline"]["measured_on"] = f"rank 0's 1 / {world} tile shard of the frame, launch alone on its GPU"
         if args.dump_image:
             np.save(args.dump_image, img)
         if orc is not None:  # the same CPU leg as at N = 1, on rank 0's host cores while the other ranks wait in the barrier below

@@ -39,8 +39,11 @@ extern "C" {
 
 /* Bumped whenever a struct of this header changes size or layout or an entry point changes meaning; ptx_abi_version()
  * returns the value the loaded library was built with.  3: PtxSceneDesc.textureMemoryBudget (round 2),
- * PtxStats.hardwareQueues (round 3).  4: PtxStats.treeTriangles / treeReferences (round 4). */
-#define PTX_ABI_VERSION 4u
+ * PtxStats.hardwareQueues (round 3).  4: PtxStats.treeTriangles / treeReferences (round 4).  5: every `/` of the shader path
+ * became a * rcp(b) (round 5: ptx_test_eval and rendered images changed meaning in the last bits) and ptx_unpack_shard_host was
+ * added; ptx_unpack_shards, ptx_bind_shard_accumulation; repeat addressing of the sampler takes the exact floor(x) mod n for extents
+ * that are not powers of two (round 6). */
+#define PTX_ABI_VERSION 5u
 
 /* ------------------------------------------------------------------------- */
 /* Data contract                                                             */
@@ -458,6 +461,22 @@ PTX_API int ptx_unpack_shard(PtxRenderer *r, uint32_t rank, const void *devSrc);
  * the render stream; the buffer is complete once every rank's shard has been unpacked into it and ptx_readback_end() has returned
  * (it waits for the last such call). */
 PTX_API int ptx_unpack_shard_host(PtxRenderer *r, uint32_t rank, const void *devSrc, float *pinnedHost, size_t bytes);
+/* The whole gathered frame in ONE launch: `devSrc` holds the shards of ranks 0 .. worldSize-1 (ptx_pack_shard's layout each),
+ * `strideBytes` apart (a multiple of 16, at least the largest ptx_shard_bytes) -- the receive buffer of the gather as it is.
+ * Targets: this renderer's device image (toDeviceImage != 0), the host's page-locked frame (pinnedHost != NULL, width*height*16
+ * bytes; complete after ptx_readback_end), or both.  A rank that only hands the frame to the host -- OutputSaver's role
+ * (OutputSaver.cpp:120-199) -- passes toDeviceImage = 0 and never rewrites its device image.  One thread per pixel in row-major
+ * order: the stores are one contiguous stream over the frame.  Because the RNG is a pure function of (pixel, width, frame)
+ * (common.glsl:143-147) ANY rank may own any frame: a job rotates the owner over the ranks with its frames in flight
+ * (bench.py), so that no rank carries the read-back of every step. */
+PTX_API int ptx_unpack_shards(PtxRenderer *r, const void *devSrc, size_t strideBytes, int toDeviceImage, float *pinnedHost, size_t bytes);
+/* Accumulate the samples of this renderer's tile shard IN `devShard` (at least ptx_shard_bytes(r, own rank) bytes of device memory,
+ * e.g. the send buffer of the gather) in ptx_pack_shard's layout, instead of in the row-major accumulation image:
+ * raygen.rgen:115-117's imageLoad / imageStore go to entry = slot inside the frame.  ptx_reset_accumulation clears it,
+ * ptx_pack_shard becomes a no-op (or a device copy if asked for another buffer); the calls that need the row-major frame
+ * (ptx_readback*, ptx_postprocess, ptx_write_accumulation) return PTX_ERROR_NOT_READY until NULL is bound again.  ptx_resize and a
+ * ptx_set_tile_shard that changes the shard unbind it. */
+PTX_API int ptx_bind_shard_accumulation(PtxRenderer *r, void *devShard, size_t bytes);
 
 PTX_API int ptx_get_stats(PtxRenderer *r, PtxStats *stats);
 

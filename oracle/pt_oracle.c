@@ -1467,11 +1467,17 @@ static inline v4 v4_lerp(v4 a, v4 b, float t)
     return r;
 }
 
-/* repeat addressing: floor(x) mod n, in float so that CPU and GPU agree for any finite x */
+/* repeat addressing: floor(x) mod n for an integer-valued x0, in float so that CPU and GPU agree for any finite x.  Sampler
+ * addressing, not a shader `/`: x0 * rcp(n) carries two roundings, so for an n that is not a power of two floor() may be one
+ * off either way (x0 = n = 41: 41 * RN(1/41) < 1); the remainder is corrected by one period, not clamped.  For |x0| < 2^22
+ * every step is exact integer arithmetic and the result is the mathematical floor(x0) mod n (tests/test_textures.py, against
+ * np.mod); beyond it the guards only keep the index inside the level. */
 static inline uint32_t wrapRepeat(float x0, uint32_t n)
 {
     const float fn = (float)n;
     float m = x0 - floorf(pto_div(x0, fn)) * fn;
+    if (m < 0.0f) m += fn;
+    else if (m >= fn) m -= fn;
     if (!(m >= 0.0f)) m = 0.0f;
     uint32_t i = (uint32_t)m;
     return i >= n ? n - 1 : i;

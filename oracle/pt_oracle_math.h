@@ -28,7 +28,11 @@ static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
  * (Vulkan 1.3 spec, "Precision and Operation of SPIR-V Instructions").  Every division of the shader path is
  *     a / b  :=  a * rcp(b),      rcp(b) = the correctly rounded reciprocal RN(1 / b) for 2^-126 <= |b| <= 2^126,
  *                                          +-inf for |b| < 2^-126 (zero and denormal divisors), +-0 for |b| > 2^126, NaN for NaN
- * -- two roundings, <= 1.5 ULP.  On the device that is v_rcp_f32 + one FMA Newton step (5 VALU instead of the 11 of a
+ * -- two roundings, <= 1.5 ULP.  Where the product's value is NOT the IEEE quotient's (all stated, all tested on both sides:
+ * tests/test_oracle_golden.py::test_specified_division_corner_cases_are_the_stated_ones): 0 / (zero or denormal) = 0 * inf = NaN
+ * (under the denormal flush GLSL grants, 0 / denormal IS 0 / 0), inf / (|b| > 2^126) = NaN, x / x = 0 for |x| > 2^126 and inf
+ * for denormal x.  A NaN or infinity that reaches a sample is rejected by the shader itself (raygen.rgen:99-112: the launch's
+ * samples restart), so none of these can stay in the accumulation image.  On the device that is v_rcp_f32 + one FMA Newton step (5 VALU instead of the 11 of a
  * correctly rounded quotient; a vector / scalar is ONE reciprocal and three multiplies); the step makes the result independent
  * of the hardware seed: device == this definition on all 2^32 inputs (tools/experiments/rcp_sqrt_exhaustive.hip,
  * profiles/r05_rcp_sqrt_exhaustive.txt; tests/test_gpu_parity.py::test_specified_reciprocal_on_all_inputs). */

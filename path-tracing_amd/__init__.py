@@ -57,7 +57,7 @@ PTX_SYMBOLS = [
     "ptx_create", "ptx_destroy", "ptx_last_error", "ptx_device_count", "ptx_abi_version", "ptx_scene_upload", "ptx_build_accel", "ptx_share_scene",
     "ptx_resize", "ptx_set_tile_shard", "ptx_set_backend", "ptx_reset_accumulation", "ptx_render",
     "ptx_render_frames", "ptx_synchronize", "ptx_readback", "ptx_readback_begin", "ptx_readback_end", "ptx_device_accum_ptr", "ptx_accum_bytes",
-    "ptx_shard_bytes", "ptx_pack_shard", "ptx_unpack_shard", "ptx_unpack_shard_host", "ptx_get_stats", "ptx_bind_accumulation",
+    "ptx_shard_bytes", "ptx_pack_shard", "ptx_unpack_shard", "ptx_unpack_shard_host", "ptx_unpack_shards", "ptx_bind_shard_accumulation", "ptx_get_stats", "ptx_bind_accumulation",
     "ptx_trace_rays", "ptx_test_input_stride", "ptx_test_output_stride", "ptx_test_eval", "ptx_test_texture",
     "ptx_postprocess", "ptx_read_output", "ptx_write_accumulation", "ptx_update_animation",
 ]
@@ -127,7 +127,7 @@ class PostProcessingUniformData(C.Structure):
 TONE_MAPPING_SDR, TONE_MAPPING_HDR = 0, 1
 ACCEL_REFIT, ACCEL_REBUILD = 0, 1
 OUTPUT_RGBA8_SRGB, OUTPUT_RGBA32F = 0, 1
-ABI_VERSION = 4  # PTX_ABI_VERSION of include/ptx.h
+ABI_VERSION = 5  # PTX_ABI_VERSION of include/ptx.h
 
 
 class DeviceDesc(C.Structure):
@@ -293,6 +293,8 @@ def load_hip() -> C.CDLL:
         lib.ptx_pack_shard.argtypes = [P, P]
         lib.ptx_unpack_shard.argtypes = [P, C.c_uint32, P]
         lib.ptx_unpack_shard_host.argtypes = [P, C.c_uint32, P, P, C.c_size_t]
+        lib.ptx_unpack_shards.argtypes = [P, P, C.c_size_t, C.c_int, P, C.c_size_t]
+        lib.ptx_bind_shard_accumulation.argtypes = [P, P, C.c_size_t]
         lib.ptx_get_stats.argtypes = [P, C.POINTER(Stats)]
         lib.ptx_postprocess.argtypes = [P, C.POINTER(PostProcessingUniformData), C.c_uint32]
         lib.ptx_read_output.argtypes = [P, C.c_uint32, P, C.c_size_t]
@@ -509,6 +511,15 @@ class Renderer:
             self._check(self.lib.ptx_unpack_shard_host(self.handle, rank, dev_src, pinned_host, nbytes))
         else:
             self._check(self.lib.ptx_unpack_shard(self.handle, rank, dev_src))
+
+    def unpack_shards(self, dev_src: int, stride_bytes: int, to_device_image: bool = True, pinned_host: int = 0, nbytes: int = 0):
+        """ptx_unpack_shards: the whole gathered frame (every rank's shard, `stride_bytes` apart in `dev_src`) in one launch, to
+        the device image and / or the host's page-locked frame (complete after readback_end())."""
+        self._check(self.lib.ptx_unpack_shards(self.handle, dev_src, stride_bytes, 1 if to_device_image else 0, pinned_host or None, nbytes))
+
+    def bind_shard_accumulation(self, dev_shard: int, nbytes: int = 0):
+        """ptx_bind_shard_accumulation: accumulate this rank's samples in the dense tile-major shard buffer (0 unbinds)."""
+        self._check(self.lib.ptx_bind_shard_accumulation(self.handle, dev_shard or None, nbytes))
 
     def trace_rays(self, rays: np.ndarray, any_hit: bool = False):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)

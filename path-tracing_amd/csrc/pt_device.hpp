@@ -941,10 +941,19 @@ PT_DEV f4 lerp4(f4 a, f4 b, float t)
     return r;
 }
 
-PT_DEV uint32_t wrapRepeat(float x0, uint32_t n) // floor(x) mod n, in float: CPU and GPU agree for any finite x
+// Repeat addressing: floor(x) mod n for an integer-valued x0, in float so that CPU and GPU agree for any finite x.  This is
+// sampler addressing, not a shader `/`: the quotient x0 * rcp(n) carries two roundings, so for an n that is not a power of two
+// floor() may land one below or above the true k (x0 = n = 41: 41 * RN(1/41) < 1) -- the remainder is therefore CORRECTED by one
+// period, not clamped.  For |x0| < 2^22 the quotient's error is below |x0| / n * 2^-23 < 1/2, k is off by at most one, k * n and
+// x0 - k * n are exact integers below 2^24, and the result is the mathematical floor(x0) mod n (tests/test_textures.py checks it
+// against np.mod for every extent the sampler can meet); beyond that range a float no longer names one texel and the two guards
+// only keep the index inside the level.
+PT_DEV uint32_t wrapRepeat(float x0, uint32_t n)
 {
     const float fn = (float)n;
     float m = x0 - __builtin_floorf(div_(x0, fn)) * fn;
+    if (m < 0.0f) m += fn;
+    else if (m >= fn) m -= fn;
     if (!(m >= 0.0f)) m = 0.0f;
     const uint32_t i = (uint32_t)m;
     return i >= n ? n - 1 : i;
@@ -971,12 +980,10 @@ PT_DEV LevelView levelView(const DevTexture &t, uint32_t level)
     return lv;
 }
 
-// wrapRepeat(x0, n) for an integer-valued x0, bit for bit, without its IEEE division where that can be shown:
-// for |x0| < 2^22 every step of wrapRepeat is exact integer arithmetic in float (the quotient's rounding error, below
-// |x0| / n * 2^-24 < 1 / (2 n), cannot carry floor() across an integer, and x0 - k * n is exact below 2^24), so its result is the
-// mathematical floor(x0) mod n and its two guards never fire.  With n = 2^k the quotient x0 * 2^-k is exact as well: one multiply
-// for the ten instructions of a correctly rounded division, four times per bilinear lookup, two lookups per trilinear tap, up
-// to sixteen taps per textureGrad.
+// wrapRepeat(x0, n) for an integer-valued x0, bit for bit, without its reciprocal where that can be shown: for |x0| < 2^22
+// wrapRepeat returns the mathematical floor(x0) mod n (above) and its two guards never fire.  With n = 2^k the quotient x0 * 2^-k
+// is exact, so floor() is the true k and no correction is needed: one multiply for the reciprocal, the product and the two
+// corrections, four times per bilinear lookup, two lookups per trilinear tap, up to sixteen taps per textureGrad.
 constexpr float kExactWrapLimit = 4194304.0f; // 2^22
 PT_DEV uint32_t wrapRepeatInt(float x0, uint32_t n, float fn, float inv)
 {

@@ -247,6 +247,12 @@ struct PtxRenderer
     DevBuf<uint32_t> outSrgb8;
     bool outputReady = false;
     float4 *boundImage = nullptr; // external accumulation buffer, if bound
+    float4 *boundShard = nullptr; // ... or the dense tile-major shard buffer the samples are accumulated in (ptx_bind_shard_accumulation)
+    size_t boundShardBytes = 0;
+    // device alias of the page-locked host frame last used by a read-back / unpack (hipHostGetDevicePointer once per buffer)
+    const void *hostAliasOf = nullptr;
+    size_t hostAliasBytes = 0;
+    float4 *hostAlias = nullptr;
     // pipelined read-back (ptx_readback_begin / _end): snapshot of the image, copied out on its own stream
     DevBuf<float4> staging;
     hipStream_t copyStream = nullptr;
@@ -355,6 +361,16 @@ static void quiesceSharers(PtxRenderer *r)
 static float4 *imagePtr(PtxRenderer *r)
 {
     return r->boundImage ? r->boundImage : r->image.p;
+}
+// where k_accumulate adds the samples: the row-major frame, or this rank's dense tile-major shard (ptx_bind_shard_accumulation)
+static float4 *accumTarget(PtxRenderer *r)
+{
+    return r->boundShard ? r->boundShard : imagePtr(r);
+}
+static int frameIsElsewhere(PtxRenderer *r, const char *who)
+{
+    return fail(r, PTX_ERROR_NOT_READY, "%s: the accumulation of this renderer lives in a shard buffer (ptx_bind_shard_accumulation); the frame "
+                                         "is composed by ptx_unpack_shards on the rank that gathers it", who);
 }
 
 static uint32_t gridFor(size_t n, uint32_t block = kBlock, uint32_t cap = 256 * 8)
@@ -1245,6 +1261,12 @@ static int buildAccel(PtxRenderer *r, bool refit, bool keepState)
     if (!refit)
     {
         B.valid = false;
+        // the level lists describe the topology of the LAST build: a full build starts without them (a build whose reinsertion
+        // passes do not run -- PTX_REINSERT=0, a broken pass, the rebuild after a revived triangle -- would otherwise price its
+        // collapse in the order and over the node count of an older tree)
+        B.levelsValid = false;
+        B.levelOrder = nullptr;
+        B.levelStart.clear();
         BUILD_TRY(B.triTmp.alloc(nTri)); BUILD_TRY(B.boxLo.alloc(nTri)); BUILD_TRY(B.boxHi.alloc(nTri)); BUILD_TRY(B.inert.alloc(nTri));
         BUILD_TRY(B.sceneBounds.alloc(8));
     }
@@ -2130,7 +2152,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
         // raygen.rgen:62: the bounce loop never runs, every sample ends with radiance 0 -- nothing is generated, traced or
         // shaded (the wavefront kernels test the bounce limit only AFTER a bounce); the image still gets its alpha
         HIP_TRY(r, hipMemsetAsync(r->slotRad.p, 0, (size_t)p.numSlots * sizeof(float4), r->stream));
-        k_accumulate<<<gridFor((size_t)p.slotsPerFrame * p.framesPerWave), kBlock, 0, r->stream>>>(p, r->slotRad.p, imagePtr(r), nullptr);
+        k_accumulate<<<gridFor((size_t)p.slotsPerFrame * p.framesPerWave), kBlock, 0, r->stream>>>(p, r->slotRad.p, accumTarget(r), nullptr, r->boundShard ? 1u : 0u);
         HIP_TRY(r, hipEventRecord(r->evB, r->stream));
         HIP_TRY(r, hipGetLastError());
         r->stats.pathSamples = (uint64_t)p.ownedPixels * frames * uniform->SampleCount;
@@ -2146,7 +2168,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
             k_megakernel<1><<<grid, kBlock, 0, r->stream>>>(p, sv, sc, r->slotRad.p, r->counters.p);
         else
             k_megakernel<0><<<grid, kBlock, 0, r->stream>>>(p, sv, sc, r->slotRad.p, r->counters.p);
-        k_accumulate<<<gridFor((size_t)p.slotsPerFrame * p.framesPerWave), kBlock, 0, r->stream>>>(p, r->slotRad.p, imagePtr(r), nullptr);
+        k_accumulate<<<gridFor((size_t)p.slotsPerFrame * p.framesPerWave), kBlock, 0, r->stream>>>(p, r->slotRad.p, accumTarget(r), nullptr, r->boundShard ? 1u : 0u);
         HIP_TRY(r, hipMemcpyAsync(r->hostCounters, r->counters.p, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
         HIP_TRY(r, hipEventRecord(r->evB, r->stream));
         HIP_TRY(r, hipStreamSynchronize(r->stream));
@@ -2249,7 +2271,7 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
                 return rcq;
         }
     }
-    k_accumulate<<<gridFor((size_t)p.slotsPerFrame * p.framesPerWave), kBlock, 0, r->stream>>>(p, r->slotRad.p, imagePtr(r), nullptr);
+    k_accumulate<<<gridFor((size_t)p.slotsPerFrame * p.framesPerWave), kBlock, 0, r->stream>>>(p, r->slotRad.p, accumTarget(r), nullptr, r->boundShard ? 1u : 0u);
     HIP_TRY(r, hipMemcpyAsync(r->hostCounters, r->counters.p, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(r, hipEventRecord(r->evB, r->stream));
     HIP_TRY(r, hipGetLastError());
@@ -2263,6 +2285,24 @@ static int renderImpl(PtxRenderer *r, const PtxRaygenUniformData *uniform, const
     return PTX_OK;
 }
 
+// Device alias of a page-locked host frame (hipHostMalloc / hipHostRegister memory), looked up once per (pointer, size): the
+// owner of a gathered frame passes the same few buffers step after step.  nullptr: the device cannot address the buffer.
+static float4 *hostFrameAlias(PtxRenderer *r, const void *pinnedHost, size_t bytes)
+{
+    if (r->hostAlias && r->hostAliasOf == pinnedHost && r->hostAliasBytes == bytes)
+        return r->hostAlias;
+    void *dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, const_cast<void *>(pinnedHost), 0) != hipSuccess || !dp)
+    {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    r->hostAliasOf = pinnedHost;
+    r->hostAliasBytes = bytes;
+    r->hostAlias = static_cast<float4 *>(dp);
+    return r->hostAlias;
+}
+
 // Read-back that overlaps the next launches: a device-to-device snapshot of the image on the render stream (33 MB at
 // 1080p: ~20 us), then the PCIe copy on a second stream while the render stream goes on.  The reference reads its
 // output back the same way, a frame late (OutputSaver.cpp:120-199).
@@ -2270,6 +2310,8 @@ static int readbackBegin(PtxRenderer *r, float *pinnedHost, size_t bytes)
 {
     if (!r || !pinnedHost || !imagePtr(r) || bytes != (size_t)r->width * r->height * sizeof(float4))
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_readback_begin: buffer must be width*height*16 bytes");
+    if (r->boundShard)
+        return frameIsElsewhere(r, "ptx_readback_begin");
     HIP_TRY(r, hipSetDevice(r->device));
     if (!r->evSnapshot)
     {
@@ -2293,7 +2335,10 @@ static int readbackBegin(PtxRenderer *r, float *pinnedHost, size_t bytes)
     if (r->env.snapshotMemcpy)
         HIP_TRY(r, hipMemcpyAsync(r->staging.p, imagePtr(r), bytes, hipMemcpyDeviceToDevice, r->stream));
     else
+    {
         k_copy_out<<<1024, kBlock, 0, r->stream>>>(imagePtr(r), r->staging.p, (uint32_t)(bytes / sizeof(float4)));
+        HIP_TRY(r, hipGetLastError()); // (a failed launch would hand the host a stale staging image)
+    }
     HIP_TRY(r, hipEventRecord(r->evSnapshot, r->stream));
     HIP_TRY(r, hipStreamWaitEvent(copyOn, r->evSnapshot, 0));
     // The snapshot leaves through ONE workgroup writing to the page-locked buffer (posted writes over PCIe, 33 MB in a few ms)
@@ -2301,20 +2346,18 @@ static int readbackBegin(PtxRenderer *r, float *pinnedHost, size_t bytes)
     // of every other frame in flight for its 1.2 ms -- measured on chess_like with 8 frames in flight: no read-back 2,600
     // Msamples/s, hipMemcpyAsync (SDMA) 2,416 / 2,422, copy kernel with 256 / 64 / 8 / 4 / 2 / 1 workgroups 2,359 / 2,395 / 2,445
     // / 2,441 / 2,465 / 2,483-2,494.  Host memory the device cannot address (not page-locked) takes the runtime's copy.
-    void *hostOnDevice = nullptr;
-    if (hipHostGetDevicePointer(&hostOnDevice, pinnedHost, 0) == hipSuccess && hostOnDevice)
+    float4 *const hostOnDevice = hostFrameAlias(r, pinnedHost, bytes);
+    if (hostOnDevice)
     {
         // ... for a whole frame on one GPU.  Rank 0 of an N-GPU job renders 1 / N of the frame per step and still reads ALL of it
         // back: there the link, not the rendering, sets the pace, and one workgroup's 8 GB/s (4.1 ms per 1080p image) made a 1 / 8
         // step of chess_like 2.2 ms instead of 0.96 (tools/experiments/gather_cost.sh) -- more workgroups with more ranks.
         const uint32_t groups = r->env.copyGroups ? r->env.copyGroups : (r->shard.worldSize > 1 ? std::min(16u, 2u * r->shard.worldSize) : 1u);
-        k_copy_out<<<groups, kBlock, 0, copyOn>>>(r->staging.p, static_cast<float4 *>(hostOnDevice), (uint32_t)(bytes / sizeof(float4)));
+        k_copy_out<<<groups, kBlock, 0, copyOn>>>(r->staging.p, hostOnDevice, (uint32_t)(bytes / sizeof(float4)));
+        HIP_TRY(r, hipGetLastError());
     }
     else
-    {
-        (void)hipGetLastError();
         HIP_TRY(r, hipMemcpyAsync(pinnedHost, r->staging.p, bytes, hipMemcpyDeviceToHost, copyOn));
-    }
     HIP_TRY(r, hipEventRecord(r->evCopied, copyOn));
     r->copyInFlight = true;
     return PTX_OK;
@@ -2330,13 +2373,9 @@ static int unpackShard(PtxRenderer *r, uint32_t rank, const void *devSrc, float 
         if (hostBytes != (size_t)r->width * r->height * sizeof(float4))
             return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_unpack_shard_host: buffer must be width*height*16 bytes");
         HIP_TRY(r, hipSetDevice(r->device));
-        void *dp = nullptr;
-        if (hipHostGetDevicePointer(&dp, pinnedHost, 0) != hipSuccess || !dp)
-        {
-            (void)hipGetLastError();
+        hostOnDevice = hostFrameAlias(r, pinnedHost, hostBytes);
+        if (!hostOnDevice)
             return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_unpack_shard_host: the buffer is not page-locked memory the device can address");
-        }
-        hostOnDevice = static_cast<float4 *>(dp);
         if (!r->evSnapshot)
         {
             HIP_TRY(r, hipEventCreateWithFlags(&r->evSnapshot, hipEventDisableTiming));
@@ -2368,6 +2407,71 @@ static int unpackShard(PtxRenderer *r, uint32_t rank, const void *devSrc, float 
     return PTX_OK;
 }
 
+// The whole gathered frame in ONE launch (k_gather_frame): `devSrc` holds the shards of ranks 0 .. worldSize-1, `strideBytes`
+// apart, each in ptx_pack_shard's layout.  Targets: the device image (toDeviceImage), the host's page-locked frame, or both --
+// a rank that only hands the frame to the host (OutputSaver's role, OutputSaver.cpp:120-199) never rewrites its device image.
+static int unpackShards(PtxRenderer *r, const void *devSrc, size_t strideBytes, int toDeviceImage, float *pinnedHost, size_t hostBytes)
+{
+    if (!r || !devSrc || !r->width || (!toDeviceImage && !pinnedHost))
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_unpack_shards: need the gathered shards and at least one target");
+    if (toDeviceImage && !imagePtr(r))
+        return fail(r, PTX_ERROR_NOT_READY, "ptx_unpack_shards: no accumulation image (call ptx_resize)");
+    size_t largest = 0;
+    for (uint32_t k = 0; k < r->shard.worldSize; k++)
+        largest = std::max(largest, ptx_shard_bytes(r, k));
+    if (strideBytes < largest || strideBytes % sizeof(float4) != 0 || strideBytes / sizeof(float4) > 0xffffffffull)
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_unpack_shards: the stride must be a multiple of 16 bytes and at least the largest shard (%zu bytes)", largest);
+    HIP_TRY(r, hipSetDevice(r->device));
+    float4 *hostOnDevice = nullptr;
+    if (pinnedHost)
+    {
+        if (hostBytes != (size_t)r->width * r->height * sizeof(float4))
+            return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_unpack_shards: the host buffer must be width*height*16 bytes");
+        hostOnDevice = hostFrameAlias(r, pinnedHost, hostBytes);
+        if (!hostOnDevice)
+            return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_unpack_shards: the host buffer is not page-locked memory the device can address");
+        if (!r->evSnapshot)
+        {
+            HIP_TRY(r, hipEventCreateWithFlags(&r->evSnapshot, hipEventDisableTiming));
+            HIP_TRY(r, hipEventCreateWithFlags(&r->evCopied, hipEventDisableTiming | hipEventReleaseToSystem));
+        }
+    }
+    GatherParams g;
+    g.width = r->width;
+    g.height = r->height;
+    g.tileSize = r->shard.tileSize;
+    g.tilesX = (r->width + g.tileSize - 1) / g.tileSize;
+    g.worldSize = r->shard.worldSize;
+    g.strideSlots = (uint32_t)(strideBytes / sizeof(float4));
+    // towards the host a FEW workgroups (PTX_COPY_GROUPS): what the link carries in a burst, the command processor's own traffic
+    // over it waits behind (profiles/r05_unpack_groups.txt); device-only: the memory's rate
+    uint32_t grid = gridFor((size_t)r->width * r->height);
+    if (hostOnDevice)
+        grid = std::min(grid, r->env.copyGroups ? r->env.copyGroups : 16u);
+    k_gather_frame<<<grid, kBlock, 0, r->stream>>>(g, static_cast<const float4 *>(devSrc), toDeviceImage ? imagePtr(r) : nullptr, hostOnDevice);
+    HIP_TRY(r, hipGetLastError());
+    if (hostOnDevice) // ptx_readback_end waits for it
+    {
+        HIP_TRY(r, hipEventRecord(r->evCopied, r->stream));
+        r->copyInFlight = true;
+    }
+    return PTX_OK;
+}
+
+// ptx_bind_shard_accumulation: the samples of a tile-sharded renderer are accumulated IN the dense tile-major buffer that is the
+// message of the gather (k_accumulate's shard-major target) -- no ptx_pack_shard pass, no row-major frame on a rank that is not
+// the frame's owner.  The buffer must hold this rank's shard (ptx_shard_bytes); entries of ragged tiles outside the image stay 0.
+static int bindShardAccumulation(PtxRenderer *r, void *devShard, size_t bytes)
+{
+    if (!r || !r->width)
+        return fail(r, PTX_ERROR_NOT_READY, "ptx_bind_shard_accumulation: call ptx_resize and ptx_set_tile_shard first");
+    if (devShard && bytes < ptx_shard_bytes(r, r->shard.rank))
+        return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_bind_shard_accumulation: the buffer must hold ptx_shard_bytes() = %zu bytes", ptx_shard_bytes(r, r->shard.rank));
+    r->boundShard = static_cast<float4 *>(devShard);
+    r->boundShardBytes = devShard ? ptx_shard_bytes(r, r->shard.rank) : 0;
+    return PTX_OK;
+}
+
 // Renderer::RecordPostProcessCommands + RecordSaveOutputCommands (Renderer.cpp:928-1085, :1204-1246)
 static int postprocess(PtxRenderer *r, const PtxPostProcessingUniformData *uniform, uint32_t toneMappingMode)
 {
@@ -2375,6 +2479,8 @@ static int postprocess(PtxRenderer *r, const PtxPostProcessingUniformData *unifo
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_postprocess: bad argument");
     if (!imagePtr(r))
         return fail(r, PTX_ERROR_NOT_READY, "ptx_postprocess: no accumulation image (call ptx_resize)");
+    if (r->boundShard)
+        return frameIsElsewhere(r, "ptx_postprocess");
     HIP_TRY(r, hipSetDevice(r->device));
     const uint32_t W = r->width, H = r->height, n = W * H;
     uint32_t levels = 1;

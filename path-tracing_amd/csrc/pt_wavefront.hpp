@@ -890,8 +890,10 @@ __global__ void __launch_bounds__(kBlock) k_restart(LaunchParams p, Wavefront wf
 // launches one after another.
 // pendingRestarts: counter of slots still waiting for another sample (multi-sample launch, NaN restart): their slotRad is
 // not final, the host runs further rounds and accumulates afterwards
+// shardMajor: `image` is the dense tile-major shard buffer of this rank (ptx_bind_shard_accumulation: the message of the gather is
+// accumulated in place, entry = slot inside the frame, k_pack_shard's layout) instead of the row-major frame.
 __global__ void __launch_bounds__(kBlock) k_accumulate(LaunchParams p, const float4 *__restrict__ slotRad, float4 *__restrict__ image,
-                                                        const uint32_t *__restrict__ pendingRestarts)
+                                                        const uint32_t *__restrict__ pendingRestarts, uint32_t shardMajor)
 {
     if (pendingRestarts && *pendingRestarts != 0u)
         return;
@@ -905,7 +907,8 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(LaunchParams p, const flo
         const uint32_t chunk = base >> 6, s = chunk * pixelsPerWave + lane / g;
         const uint32_t pixel = slotPixel(p, s);
         const bool owner = sub == 0u && pixel != 0xffffffffu;
-        float4 acc = owner ? image[pixel] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const uint32_t at = shardMajor ? s : pixel;
+        float4 acc = owner ? image[at] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         for (uint32_t group = 0; group < groups; group++)
         {
             const float4 r = slotRad[((size_t)(group * chunks + chunk) << 6) + lane];
@@ -920,7 +923,7 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(LaunchParams p, const flo
         if (owner)
         {
             acc.w = 1.0f;
-            image[pixel] = acc;
+            image[at] = acc;
         }
     }
 }
@@ -1328,6 +1331,34 @@ __global__ void k_unpack_shard(LaunchParams p, const float4 *__restrict__ src, f
             if (host)
                 host[pixel] = v;
         }
+    }
+}
+
+// The owner of a gathered frame composes it from ALL the ranks' shards in ONE launch (ptx_unpack_shards; round 6: eight thin
+// k_unpack_shard launches per step sat on the rank that was already the slowest).  One thread per PIXEL in row-major order, the
+// source entry by the inverse of slotPixel: tile -> (rank = tile % world, position among that rank's tiles = tile / world), 8x8
+// block and lane inside the tile.  The stores -- to the device image, to the host's page-locked frame, or both -- are one
+// contiguous stream over the whole frame (a wave writes 1 KB); the loads are the 128-byte rows of the 8x8 blocks.
+struct GatherParams
+{
+    uint32_t width, height, tileSize, tilesX, worldSize;
+    uint32_t strideSlots; // float4 entries between the pieces of consecutive ranks in `src`
+};
+__global__ void __launch_bounds__(kBlock) k_gather_frame(GatherParams g, const float4 *__restrict__ src, float4 *__restrict__ image, float4 *__restrict__ host)
+{
+    const uint32_t n = g.width * g.height, ts = g.tileSize, bpr = ts / 8u, perTile = ts * ts;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    {
+        const uint32_t y = i / g.width, x = i - y * g.width;
+        const uint32_t tyq = y / ts, txq = x / ts, ty = y - tyq * ts, tx = x - txq * ts;
+        const uint32_t tile = tyq * g.tilesX + txq;
+        const uint32_t k = tile % g.worldSize, kt = tile / g.worldSize;
+        const uint32_t o = ((ty >> 3) * bpr + (tx >> 3)) * 64u + (ty & 7u) * 8u + (tx & 7u);
+        const float4 v = src[(size_t)k * g.strideSlots + kt * perTile + o];
+        if (image)
+            image[i] = v;
+        if (host)
+            host[i] = v;
     }
 }
 

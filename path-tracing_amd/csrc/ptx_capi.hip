@@ -72,6 +72,9 @@ int ptx_resize(PtxRenderer *r, uint32_t width, uint32_t height)
     r->height = height;
     r->outputReady = false;
     r->boundImage = nullptr;
+    r->boundShard = nullptr;
+    r->boundShardBytes = 0;
+    r->hostAlias = nullptr; // (a frame buffer of the new size is another registration)
     HIP_TRY(r, r->image.alloc((size_t)width * height));
     return ptx_reset_accumulation(r);
 }
@@ -80,6 +83,11 @@ int ptx_set_tile_shard(PtxRenderer *r, const PtxTileShard *s)
 {
     if (!r || !s || !s->worldSize || s->rank >= s->worldSize || !s->tileSize || (s->tileSize % 8) != 0 || s->tileSize > 1024)
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_set_tile_shard: need rank < worldSize and tileSize a multiple of 8");
+    if (r->boundShard && (r->shard.rank != s->rank || r->shard.worldSize != s->worldSize || r->shard.tileSize != s->tileSize))
+    {
+        r->boundShard = nullptr; // the bound buffer was laid out for the previous shard
+        r->boundShardBytes = 0;
+    }
     r->shard = *s;
     return PTX_OK;
 }
@@ -88,7 +96,10 @@ int ptx_reset_accumulation(PtxRenderer *r)
 {
     if (!r || !imagePtr(r))
         return fail(r, PTX_ERROR_NOT_READY, "ptx_reset_accumulation: no accumulation image (call ptx_resize)");
-    HIP_TRY(r, hipMemsetAsync(imagePtr(r), 0, (size_t)r->width * r->height * sizeof(float4), r->stream));
+    if (r->boundShard)
+        HIP_TRY(r, hipMemsetAsync(r->boundShard, 0, r->boundShardBytes, r->stream));
+    else
+        HIP_TRY(r, hipMemsetAsync(imagePtr(r), 0, (size_t)r->width * r->height * sizeof(float4), r->stream));
     return PTX_OK;
 }
 
@@ -119,6 +130,8 @@ int ptx_readback(PtxRenderer *r, float *rgba, size_t bytes)
 {
     if (!r || !rgba || !imagePtr(r) || bytes != (size_t)r->width * r->height * sizeof(float4))
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_readback: buffer must be width*height*16 bytes");
+    if (r->boundShard)
+        return frameIsElsewhere(r, "ptx_readback");
     HIP_TRY(r, hipMemcpyAsync(rgba, imagePtr(r), bytes, hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(r, hipStreamSynchronize(r->stream));
     return collectRender(r); // an error of the launch that produced the image surfaces with it
@@ -169,6 +182,12 @@ int ptx_pack_shard(PtxRenderer *r, void *devDst)
     if (!r || !devDst || !imagePtr(r))
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_pack_shard: null argument");
     const LaunchParams p = makeParams(r, nullptr, 0, 1);
+    if (r->boundShard) // the accumulation already IS the packed shard (ptx_bind_shard_accumulation)
+    {
+        if (devDst != r->boundShard && p.slotsPerFrame)
+            HIP_TRY(r, hipMemcpyAsync(devDst, r->boundShard, (size_t)p.slotsPerFrame * sizeof(float4), hipMemcpyDeviceToDevice, r->stream));
+        return PTX_OK;
+    }
     if (p.slotsPerFrame)
         k_pack_shard<<<gridFor(p.slotsPerFrame), kBlock, 0, r->stream>>>(p, imagePtr(r), static_cast<float4 *>(devDst));
     HIP_TRY(r, hipGetLastError());
@@ -187,6 +206,16 @@ int ptx_unpack_shard_host(PtxRenderer *r, uint32_t rank, const void *devSrc, flo
     return unpackShard(r, rank, devSrc, pinnedHost, bytes);
 }
 
+int ptx_unpack_shards(PtxRenderer *r, const void *devSrc, size_t strideBytes, int toDeviceImage, float *pinnedHost, size_t bytes)
+{
+    return unpackShards(r, devSrc, strideBytes, toDeviceImage, pinnedHost, bytes);
+}
+
+int ptx_bind_shard_accumulation(PtxRenderer *r, void *devShard, size_t bytes)
+{
+    return bindShardAccumulation(r, devShard, bytes);
+}
+
 int ptx_postprocess(PtxRenderer *r, const PtxPostProcessingUniformData *uniform, uint32_t toneMappingMode)
 {
     return postprocess(r, uniform, toneMappingMode);
@@ -201,6 +230,8 @@ int ptx_write_accumulation(PtxRenderer *r, const float *rgba, size_t bytes)
 {
     if (!r || !rgba || !imagePtr(r) || bytes != (size_t)r->width * r->height * sizeof(float4))
         return fail(r, PTX_ERROR_INVALID_ARGUMENT, "ptx_write_accumulation: buffer must be width*height*16 bytes");
+    if (r->boundShard)
+        return frameIsElsewhere(r, "ptx_write_accumulation");
     HIP_TRY(r, hipMemcpyAsync(imagePtr(r), rgba, bytes, hipMemcpyHostToDevice, r->stream));
     HIP_TRY(r, hipStreamSynchronize(r->stream));
     return PTX_OK;

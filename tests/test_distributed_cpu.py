@@ -97,29 +97,47 @@ def test_two_rank_tile_shard_gather(tmp_path, pkg, orc):
 # ---------------------------------------------------------------------------------------
 # the real N > 1 path: bench.py under torch.distributed.run, two ranks sharing GPU 0
 # ---------------------------------------------------------------------------------------
-def _run_bench_two_ranks(tmp_path, backend, extra=()):
+def _run_bench_two_ranks(tmp_path, backend, extra=(), launcher=True):
     import json
     import subprocess
 
     out = tmp_path / f"gathered_{backend}.npy"
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN")  # WARN: RCCL says WHY it refuses a communicator
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--single-device", "--dist-backend", backend,
-           "--steps", "2", "--warmup", "1", "--repeats", "1", "--scene", "chess_like", "--detail", "0.05", "--width", "328", "--height", "200",
-           "--spp", "4", "--depth", "6", "--cpu-seconds", "1", "--dump-image", str(out), *extra]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable]
+    if launcher:  # as the driver starts an N > 1 run
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port())]
+    cmd += [os.path.join(REPO, "bench.py"), "--gpus", "2", "--single-device", "--dist-backend", backend,
+            "--steps", "2", "--warmup", "1", "--repeats", "1", "--scene", "chess_like", "--detail", "0.05", "--width", "328", "--height", "200",
+            "--spp", "4", "--depth", "6", "--cpu-seconds", "1", "--dump-image", str(out), "--dump-frames", str(tmp_path / f"frames_{backend}.npy"), *extra]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     return p, out
+
+
+def _single_rank_frame(pkg, W=328, H=200):
+    scene = pkg.Scene("chess_like", 0.05)
+    r = pkg.Renderer()
+    r.upload(scene)
+    r.resize(W, H)
+    r.render_frames(scene.uniform(W, H, bounces=6), scene.lights, 0, 4)
+    ref = r.readback()
+    r.close()
+    return ref
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("backend", ["gloo", "nccl"])
 def test_bench_two_ranks_gather_the_single_rank_frame(pkg, tmp_path, backend):
-    """bench.py's own step() -- ptx_pack_shard, all_gather, ptx_unpack_shard, pipelined read-back, two frames in flight --
-    with two ranks on one GPU: rank 0's gathered frame must be the single-rank frame bit for bit, and the JSON line must
-    carry the strong-scaling metric with the weak one beside it."""
+    """bench.py's own step() with two ranks on one GPU -- samples accumulated straight in the gather's message
+    (ptx_bind_shard_accumulation), ONE gather per step to the frame's owner, the owner ROTATING over the ranks (step k: rank k % 2),
+    one ptx_unpack_shards launch that stores only to the host's frame, host frames in one shared-memory segment: EVERY frame of the
+    job's store, whichever rank composed it, must be the single-rank frame bit for bit, and the JSON line must carry the
+    strong-scaling metric with the weak one beside it, roofline.frac and the number of ranks the collective saw.
+    The gloo variant starts WITHOUT a launcher: bench.py spawns its own ranks."""
     import json
 
-    p, out = _run_bench_two_ranks(tmp_path, backend)
+    p, out = _run_bench_two_ranks(tmp_path, backend, launcher=(backend == "nccl"))
     if p.returncode != 0 and backend == "nccl":
         # RCCL refuses two ranks on ONE device at communicator init ("Duplicate GPU detected", ncclInvalidUsage): that, and only
         # that, is a reason to skip -- any other failure of the RCCL branch is a failure of this test
@@ -131,25 +149,37 @@ def test_bench_two_ranks_gather_the_single_rank_frame(pkg, tmp_path, backend):
     last = p.stdout.splitlines()[-1]  # the LAST stdout line parses on its own, under RCCL's stdout chatter too
     line = json.loads(last)
     assert len(last) < 4096
-    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["weak"]["scaling"] == "weak" and line["value"] > 0
+    assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["scaling"] == "strong" and line["weak"]["scaling"] == "weak" and line["value"] > 0
     assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1  # the N > 1 line carries the CPU leg too
+    assert 0 < line["roofline"]["frac"] < 1 and "rank k % N" in line["config"]["parallelism"]
+    ref = _single_rank_frame(pkg)  # W, H = 328, 200: ragged, 328 is not a multiple of the 32-pixel tile
     got = np.load(out)
-    W, H = 328, 200  # ragged: 328 is not a multiple of the 32-pixel tile
-    scene = pkg.Scene("chess_like", 0.05)
-    r = pkg.Renderer()
-    r.upload(scene)
-    r.resize(W, H)
-    r.render_frames(scene.uniform(W, H, bounces=6), scene.lights, 0, 4)
-    ref = r.readback()
-    r.close()
     assert (got.view(np.uint32) == ref.view(np.uint32)).all()
+    frames = np.load(tmp_path / f"frames_{backend}.npy")
+    assert frames.shape[0] == 8  # lcm(2 ranks, 8 frames in flight); frame j composed by rank j % 2
+    for j in range(frames.shape[0]):
+        assert (frames[j].view(np.uint32) == ref.view(np.uint32)).all(), f"frame {j} (owner: rank {j % 2}) differs from the single-rank frame"
 
 
 @pytest.mark.gpu
-def test_rccl_gather_branch_runs_with_one_rank(pkg, tmp_path):
+@pytest.mark.parametrize("variant", [("--root", "rank0"), ("--gather-unpack", "per-rank"), ("--shard-accumulation", "packed"),
+                                     ("--root", "rank0", "--gather-unpack", "per-rank", "--shard-accumulation", "packed", "--gather-readback", "separate")])
+def test_bench_two_ranks_older_gather_paths_give_the_same_frame(pkg, tmp_path, variant):
+    """The step's round-1-5 forms stay selectable (rank 0 owns every frame; N unpack launches; row-major accumulation +
+    ptx_pack_shard; separate read-back) and compose the same frame."""
+    p, out = _run_bench_two_ranks(tmp_path, "gloo", extra=variant)
+    assert p.returncode == 0, p.stderr[-2000:]
+    ref = _single_rank_frame(pkg)
+    assert (np.load(out).view(np.uint32) == ref.view(np.uint32)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("collective", ["gather", "all_gather"])
+def test_rccl_gather_branch_runs_with_one_rank(pkg, tmp_path, collective):
     """The RCCL branch of bench.py's step() on real hardware: a one-rank `nccl` process group (RCCL refuses two ranks on one
-    device, and the GPU box has one), ptx_pack_shard -> all_gather_into_tensor on the renderer's torch stream ->
-    ptx_unpack_shard -> pipelined read-back, frames in flight.  The gathered frame must be the plain frame bit for bit."""
+    device, and the GPU box has one), accumulation in the bound shard buffer -> dist.gather (grouped send / recv) on the renderer's
+    torch stream -> one ptx_unpack_shards launch into the host's frame, frames in flight.  The gathered frame must be the plain frame bit
+    for bit; the all_gather_into_tensor form of rounds 1-5 stays selectable and gives the same."""
     import json
     import subprocess
 
@@ -158,13 +188,13 @@ def test_rccl_gather_branch_runs_with_one_rank(pkg, tmp_path):
                MASTER_PORT=str(_free_port()))
     cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--force-gather", "--dist-backend", "nccl", "--steps", "3", "--warmup", "1",
            "--repeats", "1", "--scene", "chess_like", "--detail", "0.05", "--width", "328", "--height", "200", "--spp", "4", "--depth", "6",
-           "--in-flight", "3", "--cpu-seconds", "1", "--dump-image", str(out)]
+           "--in-flight", "3", "--cpu-seconds", "1", "--dump-image", str(out), "--collective", collective]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     last = p.stdout.splitlines()[-1]  # RCCL's own warnings go to fd 1 too: bench.py keeps them off the real stdout
     line = json.loads(last)
     assert len(last) < 4096 and line["cpu_baseline"]["value"] > 0
-    assert line["n_gpus"] == 1 and "all_gather" in line["config"]["parallelism"] and line["value"] > 0
+    assert line["n_gpus"] == 1 and line["n_ranks_seen"] == 1 and "gather" in line["config"]["parallelism"] and line["value"] > 0
     got = np.load(out)
     W, H = 328, 200
     scene = pkg.Scene("chess_like", 0.05)

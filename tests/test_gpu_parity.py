@@ -89,6 +89,14 @@ def test_specified_reciprocal_on_all_inputs(pkg, orc, gpu_renderer):
         ref = orc.test_eval(pkg.FN["divide"], pairs[sl], 2)
         assert util.bits_equal_or_both_nan(out, ref).all(), f"device != oracle in chunk {lo}"
         assert util.bits_equal_or_both_nan(out[:, 0], spec[sl].view(np.uint32)).all(), f"device != numpy definition in chunk {lo}"
+    # the corner cases the convention answers differently from IEEE `/` (stated in oracle/pt_oracle_math.h): zero numerators over
+    # zero / denormal divisors, infinite numerators over |b| > 2^126, x / x outside the range -- the same bits on the device
+    from test_oracle_golden import _division_corner_pairs
+    ca, cb = _division_corner_pairs()
+    corner = np.stack([ca.view(np.uint32), cb.view(np.uint32)], axis=1)
+    assert util.bits_equal_or_both_nan(gpu_renderer.test_eval(pkg.FN["divide"], corner), orc.test_eval(pkg.FN["divide"], corner, 2)).all()
+    zeros = np.stack([np.where(rng.integers(0, 2, len(b)) == 1, np.uint32(0x80000000), np.uint32(0)).astype(np.uint32), b], axis=1)[: 1 << 22]
+    assert util.bits_equal_or_both_nan(gpu_renderer.test_eval(pkg.FN["divide"], zeros), orc.test_eval(pkg.FN["divide"], zeros, 2)).all()
     x = np.concatenate([np.uint32(0x3f800000) | np.arange(1 << 23, dtype=np.uint32), np.uint32(0x40000000) | np.arange(1 << 23, dtype=np.uint32),
                         rng.integers(0, 1 << 32, 1 << 20, dtype=np.uint64).astype(np.uint32)]).reshape(-1, 1)
     for lo in range(0, len(x), 1 << 22):
@@ -679,6 +687,36 @@ def test_tree_choice_does_not_change_images(pkg, monkeypatch):
         r.close()
     for k in range(1, len(images)):
         assert (images[0].view(np.uint32) == images[k].view(np.uint32)).all(), switches[k]
+
+
+@pytest.mark.gpu
+def test_second_full_build_on_a_handle_does_not_reuse_the_level_lists_of_the_first(pkg, orc, monkeypatch):
+    """A handle keeps its build state between ptx_build_accel calls.  With no reinsertion pass (PTX_REINSERT=0) nothing recomputes
+    the level lists before the collapse prices the tree, so a second full build -- another scene, another node count -- must start
+    without the lists of the first (round-5 advice: stale lists gave the collapse a stale order over a stale node count).  Two
+    uploads of different scenes on one handle, each checked against a fresh handle's tree (same wide-node count) and image."""
+    import torch  # noqa: F401
+
+    monkeypatch.setenv("PTX_REINSERT", "0")
+    monkeypatch.setenv("PTX_PLOC_RADIUS", "16")
+    W, H = 128, 72
+    sa, sb = pkg.Scene("temple_like", 0.08), pkg.Scene("street_like", 0.05)
+    kept = pkg.Renderer()
+    kept.upload(sa)
+    kept.resize(W, H)
+    for scene in (sb, sa, sb):
+        kept.upload(scene)              # second, third, fourth full build on the kept state
+        fresh = pkg.Renderer()
+        fresh.upload(scene)
+        fresh.resize(W, H)
+        u = scene.uniform(W, H, bounces=6)
+        kept.reset(); kept.render_frames(u, scene.lights, 0, 2)
+        fresh.render_frames(u, scene.lights, 0, 2)
+        a, b = kept.readback(), fresh.readback()
+        assert kept.stats().bvhNodes == fresh.stats().bvhNodes, "the kept handle collapsed its tree differently"
+        assert (a.view(np.uint32) == b.view(np.uint32)).all()
+        fresh.close()
+    kept.close()
 
 
 @pytest.mark.gpu

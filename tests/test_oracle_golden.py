@@ -409,3 +409,28 @@ def test_specified_division_is_what_the_header_says(orc, pkg):
     outside = ~inside & ~np.isnan(bf)
     assert (np.isinf(out[:, 0].view(np.float32)[outside & (np.abs(bf) < 1)])).all()
     assert (out[:, 0].view(np.float32)[outside & (np.abs(bf) > 1)] == 0).all()
+
+
+def _division_corner_pairs():
+    """(a, b) pairs where a * rcp(b) is NOT the IEEE quotient's value (stated in pt_oracle_math.h): a zero numerator over a zero or
+    denormal divisor (0 * inf = NaN; IEEE: 0 / denormal = 0), an infinite numerator over |b| > 2^126 (inf * 0 = NaN; IEEE: inf),
+    x / x for |x| > 2^126 (x * 0 = 0; IEEE: 1) and for denormal x (inf; IEEE: 1)."""
+    f = np.float32
+    den = f(1e-40)
+    big = f(1.5e38)
+    a = np.array([0.0, -0.0, 0.0, 0.0, np.inf, -np.inf, big, -big, den, 1.0, 3.0, 0.0], np.float32)
+    b = np.array([den, den, 0.0, -den, big, big, big, big, den, den, big, 2.0], np.float32)
+    return a, b
+
+
+def test_specified_division_corner_cases_are_the_stated_ones(orc, pkg):
+    """The corner cases the a * rcp(b) convention answers differently from IEEE `/` are part of the specification (round-5
+    advice): NaN for 0 / (zero or denormal) and inf / (|b| > 2^126), 0 for x / x beyond 2^126, inf for finite / denormal.  GLSL
+    lets an implementation flush denormal operands, under which 0 / denormal IS 0 / 0; a NaN that reaches a pixel is what
+    raygen.rgen:99-112 rejects (the launch's samples restart), so it cannot stay in the accumulation image."""
+    a, b = _division_corner_pairs()
+    out = orc.test_eval(pkg.FN["divide"], np.stack([a.view(np.uint32), b.view(np.uint32)], axis=1), 2)[:, 1].view(np.float32)
+    assert np.isnan(out[:6]).all()                  # 0 / denormal, -0 / denormal, 0 / 0, 0 / -denormal, +-inf / big
+    assert (out[6:8] == 0).all()                    # x / x, |x| > 2^126
+    assert np.isinf(out[8]) and np.isinf(out[9])    # denormal / denormal, 1 / denormal
+    assert out[10] == 0 and out[11] == 0            # 3 / big flushes to zero; 0 / 2 = 0 as ever

@@ -432,18 +432,22 @@ def test_anisotropic_texture_grad_against_float64_formulas(pkg, orc):
 
 
 def test_exact_wrap_fast_paths_equal_the_division_formula():
-    """The HIP sampler takes repeat addressing without its IEEE division where that is provably the same number
-    (pt_device.hpp, wrapRepeatInt / wrapRepeatNext): for an integer-valued x0 with |x0| < 2^22 the float formula
-    x0 - floor(x0 / n) * n is exact integer arithmetic -- the mathematical floor(x0) mod n -- so (a) for n = 2^k the quotient
-    may be taken as x0 * 2^-k, and (b) the index of x0 + 1 is the next index.  Emulated here in float32 (every numpy float32
-    operation rounds like the device's), against the formula of the oracle, for every extent up to 69, the powers of two and their
-    neighbours up to 32768, 200 random extents; outside the range both fall back to the formula itself."""
+    """Repeat addressing (pt_device.hpp wrapRepeat / wrapRepeatInt / wrapRepeatNext, oracle/pt_oracle.c wrapRepeat): the
+    quotient is x0 * rcp(n) -- the specified division, two roundings -- so for an n that is not a power of two floor() can be one
+    off either way (x0 = n = 41); the remainder is corrected by one period.  For an integer-valued x0 with |x0| < 2^22 the result
+    is the mathematical floor(x0) mod n, so (a) for n = 2^k the quotient may be taken as x0 * 2^-k without a correction, and
+    (b) the index of x0 + 1 is the next index.  Emulated here in float32 (every numpy float32 operation rounds like the
+    device's), against np.mod, for every extent up to 69, the seams the round-5 review named (41, 47, 55, 61, 82, 83 at x0 = n;
+    15 ... 1920 further out), the powers of two and their neighbours up to 32768, 200 random extents; outside the range both
+    fall back to the formula itself."""
     f = np.float32
 
     def wrap_repeat(x0, n):
         fn = f(n)
-        q = (x0 / fn).astype(np.float32)
+        rcp = f(np.float64(1.0) / np.float64(fn))     # correctly rounded reciprocal (double rounding cannot occur for 1 / integer < 2^15)
+        q = (x0 * rcp).astype(np.float32)
         m = (x0 - (np.floor(q) * fn).astype(np.float32)).astype(np.float32)
+        m = np.where(m < 0, (m + fn).astype(np.float32), np.where(m >= fn, (m - fn).astype(np.float32), m)).astype(np.float32)
         m = np.where(m >= 0, m, f(0))
         i = m.astype(np.uint32)
         return np.where(i >= n, n - 1, i)
@@ -462,13 +466,128 @@ def test_exact_wrap_fast_paths_equal_the_division_formula():
         return np.where(np.abs(x0) < f(4194304.0), nxt, wrap_repeat((x0 + f(1)).astype(np.float32), n))
 
     rng = np.random.default_rng(0)
-    extents = list(range(1, 70)) + [127, 128, 129, 255, 256, 257, 300, 511, 512, 513, 1000, 1023, 1024, 1025, 2047, 2048, 4095, 4096, 4097,
-                                    8191, 8192, 16384, 16385, 32767, 32768] + [int(x) for x in rng.integers(2, 32768, 200)]
+    extents = list(range(1, 70)) + [82, 83, 120, 125, 250, 500, 1920, 127, 128, 129, 255, 256, 257, 300, 511, 512, 513, 1000, 1023, 1024,
+                                    1025, 2047, 2048, 4095, 4096, 4097, 8191, 8192, 16384, 16385, 32767, 32768] \
+        + [int(x) for x in rng.integers(2, 32768, 200)]
     for n in extents:
-        xs = np.concatenate([rng.integers(-4194303, 4194304, 50000), np.arange(-3 * n - 2, 3 * n + 3), rng.integers(-2**31, 2**31, 5000),
+        xs = np.concatenate([rng.integers(-4194303, 4194304, 50000), np.arange(-9 * n - 2, 9 * n + 3), rng.integers(-2**31, 2**31, 5000),
+                             n * np.arange(-4194303 // n, 4194303 // n + 1, max(1, (8388606 // n) // 20000)),   # the seams themselves
                              [-4194304, 4194303, 4194304, -4194305, 8388608, -8388608, 2**24, 2**30]]).astype(np.float32)
         a, b = wrap_repeat(xs, n), wrap_int(xs, n)
         assert (a == b).all(), n
         assert (wrap_repeat((xs + f(1)).astype(np.float32), n) == wrap_next(xs, b, n)).all(), n
         inside = np.abs(xs) < 4194304
         assert (a[inside] == np.mod(xs[inside].astype(np.int64), n)).all(), n
+
+
+# ---------------------------------------------------------------------------------------
+# repeat seams of extents that are not a power of two (round-5 review: x0 * rcp(n) floors one off at x0 = k * n)
+# ---------------------------------------------------------------------------------------
+_SEAM_EXTENTS = [(41, 47), (61, 55), (125, 83), (1000, 3), (82, 15), (1920, 30), (120, 250), (500, 60)]
+
+
+class _SeamScene:
+    """texture_test's PtxSceneDesc with its texture table replaced by RGBA32F images whose texel (x, y) holds
+    (x, y, x + 1000 y, 1): a lookup at a texel centre names the texel it fetched."""
+
+    def __init__(self, pkg):
+        import ctypes as C
+
+        class TextureDesc(C.Structure):
+            _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("format", C.c_uint32), ("levels", C.c_uint32), ("data", C.c_void_p)]
+
+        self.base = pkg.Scene("texture_test")
+        self.desc = self.base.desc
+        self.images = []
+        self.table = (TextureDesc * len(_SEAM_EXTENTS))()
+        for i, (w, h) in enumerate(_SEAM_EXTENTS):
+            x, y = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32))
+            img = np.ascontiguousarray(np.stack([x, y, x + 1000 * y, np.ones_like(x)], -1), np.float32)
+            self.images.append(img)
+            self.table[i] = TextureDesc(w, h, 2, 1, img.ctypes.data)
+        self.desc.textures = C.addressof(self.table)
+        self.desc.textureCount = len(_SEAM_EXTENTS)
+        self.desc.forceFullTextureSize = 1
+
+
+def _seam_inputs():
+    """Texel centres displaced by whole periods: u = (i + 1/2) / w + k (k = 0, +-1 ... +-8 and a few thousand), plus the
+    seams themselves u = k - 1/(2w) (x0 = k w - 1, next texel 0) and u = k + 1/(2w) (x0 = k w)."""
+    rows, want = [], []
+    rng = np.random.default_rng(11)
+    for t, (w, h) in enumerate(_SEAM_EXTENTS):
+        ks = np.concatenate([np.arange(-8, 9), rng.integers(-3000, 3000, 40)])
+        for k in ks:
+            for i in (0, 1, w // 2, w - 2, w - 1):
+                for j in (0, h - 1):
+                    u, v = np.float64(i + 0.5) / w + k, np.float64(j + 0.5) / h - k
+                    rows.append((9 + t, u, v))
+                    want.append((t, i % w, j % h))
+    a = np.zeros((len(rows), 7), np.float32)
+    a.view(np.uint32)[:, 0] = [r[0] for r in rows]
+    a[:, 1] = [r[1] for r in rows]
+    a[:, 2] = [r[2] for r in rows]
+    return a, np.array(want)
+
+
+def _expected_texels(inputs):
+    """The four texels and weights of the bilinear footprint in exact integer arithmetic (np.mod), from the float32 inputs as
+    the sampler sees them."""
+    f = np.float32
+    out = np.zeros((len(inputs), 4), np.float64)
+    for r, a in enumerate(inputs):
+        t = int(a.view(np.uint32)[0]) - 9
+        w, h = _SEAM_EXTENTS[t]
+        x, y = f(a[1] * f(w)) - f(0.5), f(a[2] * f(h)) - f(0.5)
+        x0, y0 = np.floor(x), np.floor(y)
+        ax, ay = np.float64(f(x - x0)), np.float64(f(y - y0))
+        i0, j0 = int(np.mod(np.int64(x0), w)), int(np.mod(np.int64(y0), h))
+        i1, j1 = (i0 + 1) % w, (j0 + 1) % h
+        tex = lambda i, j: np.array([i, j, i + 1000 * j, 1.0])
+        out[r] = (tex(i0, j0) * (1 - ax) + tex(i1, j0) * ax) * (1 - ay) + (tex(i0, j1) * (1 - ax) + tex(i1, j1) * ax) * ay
+    return out
+
+
+def test_oracle_repeat_seams_of_non_power_of_two_extents(pkg, orc):
+    ss = _SeamScene(pkg)
+    osc = orc.OracleScene(ss.desc, build_bvh=False)
+    inp, _ = _seam_inputs()
+    got = osc.test_texture(inp, implicit_lod=True).view(np.float32)
+    want = _expected_texels(inp)
+    err = np.abs(got - want) / np.maximum(1.0, np.abs(want))
+    assert err.max() < 1e-5, (float(err.max()), inp[int(err.max(axis=1).argmax())])
+    # the review's own cases: x0 = n exactly (u = 1 + 1/(2n)) must fetch texel 0 and its neighbour 1, not n - 1
+    for t, (w, h) in enumerate(_SEAM_EXTENTS[:3]):
+        u = np.float32(1.0 + 0.5 / w)
+        one = _inputs(9 + t, np.float32([u]), np.float32([0.5 / h]))
+        x = np.float32(u * np.float32(w)) - np.float32(0.5)
+        if np.floor(x) == w:
+            r = osc.test_texture(one, implicit_lod=True).view(np.float32)[0]
+            assert 0.0 <= r[0] <= 1.0, (w, r)
+
+
+@pytest.mark.gpu
+def test_sampler_repeat_seams_match_oracle_bitexact(pkg, orc):
+    import torch  # noqa: F401
+
+    ss = _SeamScene(pkg)
+    r = pkg.Renderer(device=0)
+    r.upload(ss.desc)
+    osc = orc.OracleScene(ss.desc, build_bvh=False)
+    inp, _ = _seam_inputs()
+    rng = np.random.default_rng(12)
+    n = 20000
+    rnd = np.zeros((n, 7), np.float32)
+    rnd.view(np.uint32)[:, 0] = rng.integers(9, 9 + len(_SEAM_EXTENTS), n)
+    rnd[:, 1:3] = rng.uniform(-40, 40, (n, 2))
+    rnd[:, 3:7] = (10.0 ** rng.uniform(-5, 0.0, (n, 4)) * rng.choice([-1, 1], (n, 4)))
+    rnd[:2000, 3:7] = 0
+    for batch in (inp, rnd):
+        for implicit in (True, False):
+            a = r.test_texture(batch, implicit)
+            b = osc.test_texture(batch, implicit)
+            assert (a == b).all(), f"{int((a != b).any(axis=1).sum())} samples differ (implicit={implicit})"
+    want = _expected_texels(inp)
+    got = r.test_texture(inp, True).view(np.float32)
+    assert (np.abs(got - want) / np.maximum(1.0, np.abs(want))).max() < 1e-5
+    r.close()
