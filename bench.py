@@ -57,8 +57,14 @@ import os
 import sys
 import time
 
-# before anything initialises HIP: one hardware queue per stream of the frames in flight (path-tracing_amd/__init__.py)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# Before anything initialises HIP: one hardware queue per stream of the process.  The frames in flight take two streams each (16
+# for the default 8); a job that gathers also runs torch's default stream (the gather's buffers, the staging copies) and the
+# collective library's own stream -- 17+ streams on 16 queues make two of them take turns, which cost a 1 / 8 shard step of
+# chess_like 0.14 ms of its 0.95 (profiles/r06_rccl_presence.txt: 16 queues 1.09 ms, 20 / 24 / 32 queues 0.98 / 0.97 / 0.99).
+# The HOST owns this variable: the library only reports what it finds.
+_GATHERS = "--force-gather" in sys.argv or any(a == "--gpus" and sys.argv[i + 1:i + 2] not in ([], ["1"]) for i, a in enumerate(sys.argv)) \
+    or int(os.environ.get("WORLD_SIZE", "1")) > 1
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24" if _GATHERS else "16")
 
 import numpy as np
 
@@ -319,7 +325,8 @@ class Job:
                 r.pack_shard(send.data_ptr())
             with torch.cuda.stream(self.streams[i]):  # the renderer runs on this torch stream: the collective is ordered behind the frame
                 if self.pieces != self.world:  # emulation (see __init__): the call every rank makes, the pieces only the owner receives
-                    dist.all_gather_into_tensor(recv[:self.shard_floats], send)
+                    if self.args.emulate_collective == "on":
+                        dist.all_gather_into_tensor(recv[:self.shard_floats], send)
                     if mine:
                         recv[self.shard_floats:].view(self.pieces - 1, self.shard_floats).copy_(send.expand(self.pieces - 1, self.shard_floats))
                 elif self.args.dist_backend == "nccl" and self.args.collective == "gather":
@@ -852,6 +859,8 @@ def main():
                     help="N > 1: k_accumulate writes the gather's message itself (ptx_bind_shard_accumulation) / row-major image + ptx_pack_shard")
     ap.add_argument("--launch-check", action="store_true",
                     help="testing: the ranks only join the process group and count themselves (no GPU work); rank 0 prints one JSON line")
+    ap.add_argument("--emulate-collective", default="on", choices=["on", "off"],
+                    help="experiments only: leave the collective call out of an emulated shard step (what the call itself costs)")
     ap.add_argument("--emulate-scaling", default="strong", choices=["weak", "strong"])
     ap.add_argument("--emulate-readback", default="auto", choices=["auto", "on", "off"],
                     help="experiments only: --emulate-shard steps end with the pipelined read-back (auto: with --force-gather)")

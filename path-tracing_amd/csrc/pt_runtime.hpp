@@ -76,6 +76,12 @@ struct TreeParams
 // is created -- no entry point calls getenv afterwards, and a handle keeps the values it was created with.
 struct EnvSwitches
 {
+    // Who runs where (round 6; docs/EXPERIMENTS.md): the handle's streams are created with a CU mask (hipExtStreamCreateWithCUMask)
+    //   0 none (any CU)   1 one XCD per handle (handle h -> XCD h % 8)   2 two groups of four XCDs (h % 2)
+    //   3 main stream (closest + shade) on XCDs 0-5, auxiliary stream (shadow, tail) on XCDs 6-7   4 two XCDs per handle (h % 4)
+    //   5 main stream on XCD h % 8, auxiliary stream on XCD (h + 4) % 8
+    // With a mask the library creates the main stream itself even if the host passed one (the host's stream cannot be masked).
+    uint32_t cuPartition = 0;
     bool verbose = false;        // PTX_VERBOSE: progress and statistics on stderr
     bool karrasBuilder = false;  // PTX_BUILDER=lbvh: Karras topology instead of PLOC
     bool plocFixed = false;      // PTX_PLOC_RADIUS / PTX_PLOC_SHAPE given: ONE tree with these parameters, no candidates
@@ -131,6 +137,8 @@ struct EnvSwitches
             e.raysPerThread = std::max(1u, (uint32_t)strtoul(v, nullptr, 10));
         if (const char *v = getenv("PTX_RESIDENT_CAP"))
             e.residentCap = (long)strtoul(v, nullptr, 10);
+        if (const char *v = getenv("PTX_CU_PARTITION"))
+            e.cuPartition = (uint32_t)strtoul(v, nullptr, 10);
         return e;
     }
 };
@@ -276,6 +284,7 @@ struct PtxRenderer
 
     // bounce schedule of the wavefront backend (renderImpl): closest + shade on `stream`, shadow + tail on `auxStream`
     hipStream_t auxStream = nullptr;
+    uint32_t handleSeq = 0, mainXcds = 0xffu, auxXcds = 0xffu; // PTX_CU_PARTITION: the XCDs this handle's streams may use
     DevBuf<uint32_t> spillAux; // traversal-stack overflow region of the kernels on auxStream
     struct BounceEvents
     {
@@ -476,6 +485,43 @@ static std::atomic<bool> g_queueWarningGiven{false};
 
 static void destroyRenderer(PtxRenderer *r);
 
+// CU masks of PTX_CU_PARTITION.  Bit i of the mask is compute unit i in the driver's numbering, which deals the CUs of a
+// multi-XCD device round-robin over the XCDs (bit i -> XCD i % 8, the amdgpu driver's mqd_symmetrically_map_cu_mask walks the mask
+// with a stride of the XCD count): XCD x = bits x, x + 8, x + 16 ...
+static std::atomic<uint32_t> g_handleSeq{0};
+static void xcdMask(uint32_t xcdBits, uint32_t cus, std::vector<uint32_t> &mask)
+{
+    mask.assign((cus + 31) / 32, 0u);
+    for (uint32_t i = 0; i < cus; i++)
+        if (xcdBits & (1u << (i % 8u)))
+            mask[i / 32] |= 1u << (i % 32);
+}
+// the XCDs of the handle's main / auxiliary stream under partition `mode`; 0xff = no mask
+static void partitionOf(uint32_t mode, uint32_t h, uint32_t &mainXcds, uint32_t &auxXcds)
+{
+    mainXcds = auxXcds = 0xffu;
+    switch (mode)
+    {
+    case 1: mainXcds = auxXcds = 1u << (h % 8u); break;
+    case 2: mainXcds = auxXcds = (h % 2u) ? 0xf0u : 0x0fu; break;
+    case 3: mainXcds = 0x3fu; auxXcds = 0xc0u; break;
+    case 4: mainXcds = auxXcds = 0x3u << (2u * (h % 4u)); break;
+    case 5: mainXcds = 1u << (h % 8u); auxXcds = 1u << ((h + 4u) % 8u); break;
+    case 6: mainXcds = auxXcds = 0x1ffu; break; // control: hipExtStreamCreateWithCUMask with EVERY CU enabled
+    case 7: mainXcds = auxXcds = 0x2ffu; break; // control: the library's own plain streams instead of the host's
+    default: break;
+    }
+}
+static hipError_t createStreamOn(hipStream_t *s, uint32_t xcds, int device)
+{
+    int cus = 0;
+    if (xcds == 0xffu || xcds == 0x2ffu || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 8)
+        return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    std::vector<uint32_t> mask;
+    xcdMask(xcds & 0xffu, (uint32_t)cus, mask);
+    return hipExtStreamCreateWithCUMask(s, (uint32_t)mask.size(), mask.data());
+}
+
 static int createRenderer(const PtxDeviceDesc *desc, PtxRenderer **out)
 {
     if (!out)
@@ -492,18 +538,20 @@ static int createRenderer(const PtxDeviceDesc *desc, PtxRenderer **out)
         delete r;
         return PTX_ERROR_NO_DEVICE;
     }
-    if (desc && desc->stream)
+    r->env = EnvSwitches::read(); // the only place the library reads its switches
+    r->handleSeq = g_handleSeq++;
+    partitionOf(r->env.cuPartition, r->handleSeq, r->mainXcds, r->auxXcds);
+    if (desc && desc->stream && r->mainXcds == 0xffu)
         r->stream = static_cast<hipStream_t>(desc->stream);
     else
     {
-        if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess)
+        if (createStreamOn(&r->stream, r->mainXcds, r->device) != hipSuccess)
         {
             delete r;
             return PTX_ERROR_DEVICE;
         }
         r->ownStream = true;
     }
-    r->env = EnvSwitches::read(); // the only place the library reads its switches
     r->usePloc = !r->env.karrasBuilder;
     if (r->env.collapse >= 0)
         r->tree.collapse = (uint32_t)r->env.collapse;
@@ -526,10 +574,12 @@ static int createRenderer(const PtxDeviceDesc *desc, PtxRenderer **out)
         g_raysPerThread = r->env.raysPerThread;
     if (r->env.residentCap >= 0)
         g_residentCap = (uint32_t)r->env.residentCap;
-    r->residentClosest[0] = residentBlocksOf(k_trace_closest<false>, r->device);
-    r->residentClosest[1] = residentBlocksOf(k_trace_closest<true>, r->device);
-    r->residentShadow[0] = residentBlocksOf(k_trace_shadow<false>, r->device);
-    r->residentShadow[1] = residentBlocksOf(k_trace_shadow<true>, r->device);
+    // (a masked stream holds fewer blocks at once: the persistent grids are sized to the XCDs the stream may use)
+    const uint32_t mainShare = (uint32_t)__builtin_popcount(r->mainXcds & 0xffu), auxShare = (uint32_t)__builtin_popcount(r->auxXcds & 0xffu);
+    r->residentClosest[0] = residentBlocksOf(k_trace_closest<false>, r->device) * mainShare / 8u;
+    r->residentClosest[1] = residentBlocksOf(k_trace_closest<true>, r->device) * mainShare / 8u;
+    r->residentShadow[0] = residentBlocksOf(k_trace_shadow<false>, r->device) * auxShare / 8u;
+    r->residentShadow[1] = residentBlocksOf(k_trace_shadow<true>, r->device) * auxShare / 8u;
     if (r->env.verbose)
         fprintf(stderr, "[ptx] resident blocks: closest %u / %u, shadow %u / %u\n", r->residentClosest[0], r->residentClosest[1], r->residentShadow[0],
                 r->residentShadow[1]);
@@ -1866,7 +1916,7 @@ static int ensureRenderResources(PtxRenderer *r, uint32_t bounces)
 {
     if (!r->auxStream)
     {
-        HIP_TRY(r, hipStreamCreateWithFlags(&r->auxStream, hipStreamNonBlocking));
+        HIP_TRY(r, createStreamOn(&r->auxStream, r->auxXcds, r->device));
         HIP_TRY(r, r->spillAux.alloc((size_t)kGlobalSpill * kMaxPersistentThreads));
     }
     const size_t want = bounces < (uint32_t)kMaxTimedBounces ? bounces : (uint32_t)kMaxTimedBounces;

@@ -56,31 +56,25 @@ void Scene::UpdateTransforms()
     }
 }
 
-// SceneGraph.cpp:8-34.  glm::transpose(scale(translate(I, p) * mat4(r), s)) in the reference's transposed
-// storage is the math matrix T * R * S here.
+// One step of an animation clip (behaviour of SceneGraph.cpp:8-34): the clock advances by timeStep * TickPerSecond and loops at
+// Duration; a loop sends every track's cursor back to its first key (cursors only move forward); every animated node's local
+// transform becomes T * R * S of the three sampled tracks -- glm::transpose(scale(translate(I, p) * mat4(r), s)) in the
+// reference's transposed storage is this math matrix.
 void Animation::Update(float timeStep, std::span<SceneNode> nodes)
 {
-    CurrentTick += timeStep * TickPerSecond;
-    if (CurrentTick >= Duration)
+    float tick = CurrentTick + timeStep * TickPerSecond;
+    const bool looped = tick >= Duration;
+    while (tick >= Duration) // (repeated subtraction, not fmod: the float the clock lands on is part of the behaviour)
+        tick -= Duration;
+    CurrentTick = tick;
+
+    for (AnimationNode &track : Nodes)
     {
-        for (AnimationNode &node : Nodes)
-        {
-            node.Positions.Index = 0;
-            node.Rotations.Index = 0;
-            node.Scales.Index = 0;
-        }
-    }
-
-    while (CurrentTick >= Duration)
-        CurrentTick -= Duration;
-
-    for (AnimationNode &node : Nodes)
-    {
-        const Vec3 position = node.Positions.Update(CurrentTick);
-        const Quat rotation = node.Rotations.Update(CurrentTick);
-        const Vec3 scale = node.Scales.Update(CurrentTick);
-
-        nodes[node.SceneNodeIndex].Transform = Scale(Translate(Mat4::Identity(), position) * ToMat4(rotation), scale);
+        if (looped)
+            track.Positions.Index = track.Rotations.Index = track.Scales.Index = 0;
+        const Mat4 translation = Translate(Mat4::Identity(), track.Positions.Update(tick));
+        const Mat4 rotation = ToMat4(track.Rotations.Update(tick));
+        nodes[track.SceneNodeIndex].Transform = Scale(translation * rotation, track.Scales.Update(tick));
     }
 }
 

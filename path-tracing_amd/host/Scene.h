@@ -162,33 +162,31 @@ struct AnimationNode
     Sequence<Vec3> Scales;
 };
 
-// SceneGraph.h:51-66
-template<typename T> inline T AnimationNode::Sequence<T>::Update(float currentTick)
-{
-    if (currentTick < Keys[0].Tick)
-        return Keys[0].Value;
+// Keyframe evaluation (behaviour of SceneGraph.h:51-76, written for this mirror; tests/test_animation.py pins it).
+// A track is sampled at non-decreasing ticks between two wraps of its animation, so `Index` is a cursor that only moves forward:
+// it rests on the last key whose SUCCESSOR is not strictly behind the tick (a tick exactly on a key still blends the segment that
+// ends there, with ratio 1).  Before the first key and from the last key on the track is constant.
+inline Vec3 BlendKeys(const Vec3 &from, const Vec3 &to, float ratio) { return Mix(from, to, ratio); }
+inline Quat BlendKeys(const Quat &from, const Quat &to, float ratio) { return Slerp(from, to, ratio); } // rotations: along the arc
 
-    while (Index + 1 < Keys.size() && currentTick > Keys[Index + 1].Tick)
-        Index++;
-
-    if (Index + 1 == Keys.size())
-        return Keys.back().Value;
-
-    const float total = Keys[Index + 1].Tick - Keys[Index].Tick;
-    const float current = currentTick - Keys[Index].Tick;
-
-    return Interpolate(current / total);
-}
-
-// SceneGraph.h:68-76
 template<typename T> inline T AnimationNode::Sequence<T>::Interpolate(float ratio)
 {
-    return Mix(Keys[Index].Value, Keys[Index + 1].Value, ratio);
+    return BlendKeys(Keys[Index].Value, Keys[Index + 1].Value, ratio);
 }
 
-template<> inline Quat AnimationNode::Sequence<Quat>::Interpolate(float ratio)
+template<typename T> inline T AnimationNode::Sequence<T>::Update(float currentTick)
 {
-    return Slerp(Keys[Index].Value, Keys[Index + 1].Value, ratio);
+    const Key &first = Keys.front();
+    if (currentTick < first.Tick)
+        return first.Value;
+    const uint32_t lastKey = static_cast<uint32_t>(Keys.size()) - 1u;
+    for (; Index < lastKey && Keys[Index + 1].Tick < currentTick; ++Index)
+    {
+    }
+    if (Index == lastKey)
+        return Keys[lastKey].Value;
+    const Key &from = Keys[Index], &to = Keys[Index + 1];
+    return Interpolate((currentTick - from.Tick) / (to.Tick - from.Tick));
 }
 
 // SceneGraph.h:78-86

@@ -48,6 +48,30 @@ def test_scene_graph_animation(pkg):
     assert abs(x0 - (-1.0)) < 1e-6 and abs(s2.lights.Lights[0].Position[0] - 2.5) < 1e-5
 
 
+def test_keyframe_cursors_do_not_depend_on_the_step_size(pkg):
+    """A track's key cursor only moves forward between two loops of its clip (Scene.h, AnimationNode::Sequence::Update): many
+    small steps, one large step, steps that land exactly on keys (whole seconds: every 30 ticks) and steps across the loop (4 s)
+    must all sample the same pose for the same clock."""
+    def state(steps):
+        sc = pkg.Scene("animated_test", 0.25)
+        sc.update(0.0)
+        for dt in steps:
+            sc.update(float(dt))
+        it, bn = sc.animation_state()
+        lp = [sc.lights.Lights[0].Position[k] for k in range(3)]
+        return np.concatenate([it.ravel(), bn.ravel(), lp])
+
+    rng = np.random.default_rng(4)
+    small = rng.uniform(0.01, 0.12, 40)
+    small *= 2.35 / small.sum()
+    assert np.allclose(state(small), state([2.35]), atol=3e-5)
+    assert np.allclose(state([1.0, 1.0, 1.0]), state([3.0]), atol=3e-5)            # every step ends ON a key
+    assert np.allclose(state([0.5] * 6), state([1.0, 1.0, 0.25, 0.75]), atol=3e-5)
+    assert np.allclose(state([1.7, 1.7, 1.7]), state([1.1]), atol=5e-5)            # 5.1 s = one loop + 1.1 s
+    assert np.allclose(state([9.3]), state([1.3]), atol=1e-4)                       # two loops in one step
+    assert not np.allclose(state([1.3]), state([1.1]), atol=1e-3)
+
+
 def test_oracle_skinning_and_posed_scene(pkg, orc):
     s = pkg.Scene("animated_test", 0.2)
     s.update(0.0)
