@@ -42,7 +42,7 @@ extern "C" {
  * PtxStats.hardwareQueues (round 3).  4: PtxStats.treeTriangles / treeReferences (round 4).  5: every `/` of the shader path
  * became a * rcp(b) (round 5: ptx_test_eval and rendered images changed meaning in the last bits) and ptx_unpack_shard_host was
  * added; ptx_unpack_shards, ptx_bind_shard_accumulation; repeat addressing of the sampler takes the exact floor(x) mod n for extents
- * that are not powers of two (round 6). */
+ * that are not powers of two; normalize() / inversesqrt() go through the specified rsq (PTX_FN_RSQ) instead of rcp(sqrt()) (round 6). */
 #define PTX_ABI_VERSION 5u
 
 /* ------------------------------------------------------------------------- */
@@ -594,7 +594,9 @@ typedef enum PtxTestFunction {
     PTX_FN_DIVIDE = 35,             /* in: a, b (2)   out: rcp(b), a / b (2) -- the specified division every `/` of the shader path goes
                                        through: a * rcp(b), rcp correctly rounded on [2^-126, 2^126], +-inf below, +-0 above */
     PTX_FN_SQRT = 36,               /* in: x          out: sqrt(x), correctly rounded                                          */
-    PTX_FN_COUNT = 37
+    PTX_FN_RSQ = 37,                /* in: x          out: rsq(x) -- the specified reciprocal square root of normalize() and inversesqrt():
+                                       RN(1 / sqrt(x)) for positive normal x, +-inf for +-0 / denormals, +0 for +inf, NaN otherwise  */
+    PTX_FN_COUNT = 38
 } PtxTestFunction;
 
 /* Material block used by PTX_FN_EVALUATE_BSDF / PTX_FN_SAMPLE_BSDF:

@@ -49,6 +49,8 @@ def load() -> C.CDLL:
         lib.pto_trace_closest.argtypes = [P, P, C.c_uint32, P, C.c_int]
         lib.pto_trace_any.argtypes = [P, P, C.c_uint32, P, C.c_int]
         lib.pto_test_eval.argtypes = [C.c_uint32, P, P, C.c_uint32]
+        lib.pto_rsq_selfcheck.argtypes = [C.POINTER(C.c_uint64)]
+        lib.pto_rsq_selfcheck.restype = C.c_uint64
         lib.pto_test_raygen.argtypes = [P, P, C.c_uint32]
         lib.pto_test_closest_hit.argtypes = [P, P, P, P, C.c_uint32]
         lib.pto_test_any_hit.argtypes = [P, P, P, C.c_uint32]
@@ -140,8 +142,15 @@ class OracleScene:
 
 
 # words per case of pto_test_eval's inputs / outputs, by function id (include/ptx.h PTX_FN_*)
-IN_STRIDE = (4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4, 3, 3, 2, 6, 7, 3, 47, 2, 1)
-OUT_STRIDE = (1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1, 2, 3, 2, 6, 3, 3, 17, 2, 1)
+IN_STRIDE = (4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4, 3, 3, 2, 6, 7, 3, 47, 2, 1, 1)
+OUT_STRIDE = (1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1, 2, 3, 2, 6, 3, 3, 17, 2, 1, 1)
+
+
+def rsq_selfcheck():
+    """(classes where pto_rsq or the device's float sequence differs from the exact RN(1 / sqrt(x)), classes where the seed matters)"""
+    dep = C.c_uint64(0)
+    wrong = load().pto_rsq_selfcheck(C.byref(dep))
+    return int(wrong), int(dep.value)
 
 
 def test_eval(fn: int, inputs: np.ndarray, nout: int) -> np.ndarray:

@@ -200,7 +200,7 @@ static inline v3 SampleGGX(v2 u, v3 V, float alpha)
 {
     const v3 Vh = v_normalize(V3(alpha * V.x, alpha * V.y, fabsf(V.z)));
     const float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
-    const v3 T1 = lensq > 0 ? v_scale(V3(-Vh.y, Vh.x, 0), pto_div(1.0f, sqrtf(lensq))) : V3(1, 0, 0);
+    const v3 T1 = lensq > 0 ? v_scale(V3(-Vh.y, Vh.x, 0), pto_rsq(lensq)) : V3(1, 0, 0); /* inversesqrt */
     const v3 T2 = v_cross(Vh, T1);
     const float r = sqrtf(u.x);
     const float phi = 2.0f * PTO_PI * u.y;
@@ -2521,8 +2521,8 @@ int pto_render(const PtoScene *s, const PtxRaygenUniformData *U, const PtxLights
 /* Function-level entry (packing documented in include/ptx.h)               */
 /* ======================================================================== */
 
-static const int kInStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4, 3, 3, 2, 6, 7, 3, 47, 2, 1 };
-static const int kOutStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1, 2, 3, 2, 6, 3, 3, 17, 2, 1 };
+static const int kInStride[PTX_FN_COUNT] = { 4, 4, 4, 2, 1, 10, 11, 6, 3, 14, 12, 4, 2, 2, 3, 6, 38, 1, 2, 31, 25, 42, 30, 24, 12, 34, 35, 4, 3, 3, 2, 6, 7, 3, 47, 2, 1, 1 };
+static const int kOutStride[PTX_FN_COUNT] = { 1, 1, 1, 1, 1, 4, 4, 3, 4, 4, 8, 5, 2, 3, 9, 3, 18, 2, 1, 9, 3, 18, 12, 6, 4, 12, 12, 1, 2, 3, 2, 6, 3, 3, 17, 2, 1, 1 };
 
 static MaterialSample unpackMaterial(const float *p)
 {
@@ -2534,6 +2534,61 @@ static MaterialSample unpackMaterial(const float *p)
     m.Transmission = p[5];
     m.Eta = p[6];
     return m;
+}
+
+/* r == RN(1 / sqrt(x)) exactly?  x = X 2^ex, r = R 2^er (24-bit integers): 1 / sqrt(x) lies between the midpoints m_lo < r < m_hi
+ * iff x m_hi^2 >= 1 >= x m_lo^2 (equality only where 1 / sqrt(x) is a float itself). */
+static int rsqExactlyRounded(float x, float r)
+{
+    int ex = 0, er = 0;
+    const float fx = frexpf(x, &ex), fr = frexpf(r, &er);
+    const uint64_t X = (uint64_t)ldexpf(fx, 24), R = (uint64_t)ldexpf(fr, 24);
+    ex -= 24;
+    er -= 24;
+    const unsigned __int128 mhi = 2 * R + 1; /* m_hi = (2 R + 1) 2^(er - 1) */
+    const int ehi = er - 1;
+    unsigned __int128 mlo;                   /* below a power of two the spacing halves */
+    int elo;
+    if (R == (1u << 23)) { mlo = 4 * R - 1; elo = er - 2; } else { mlo = 2 * R - 1; elo = er - 1; }
+    const unsigned __int128 phi = (unsigned __int128)X * mhi * mhi, plo = (unsigned __int128)X * mlo * mlo;
+    const int shi = -(ex + 2 * ehi), slo = -(ex + 2 * elo); /* X m^2 against 2^s */
+    const int okhi = shi < 0 ? 1 : (shi > 126 ? 0 : phi >= ((unsigned __int128)1 << shi));
+    const int oklo = slo < 0 ? 0 : (slo > 126 ? 1 : plo <= ((unsigned __int128)1 << slo));
+    return okhi && oklo;
+}
+
+uint64_t pto_rsq_selfcheck(uint64_t *seedDependent)
+{
+    uint64_t wrong = 0, dep = 0;
+    for (uint32_t parity = 0; parity < 2; parity++)
+        for (uint32_t m = 0; m < (1u << 23); m++)
+        {
+            const float x = u2f(((127u + parity) << 23) | m);
+            const float want = pto_rsq(x);
+            int bad = !rsqExactlyRounded(x, want), differs = 0;
+            float first = 0.0f;
+            for (int d = -1; d <= 1; d++) /* the device's sequence (pt_device.hpp rsq_) from every seed v_rsq_f32's 1 ULP allows */
+            {
+                const float y0 = u2f(f2u(want) + (uint32_t)d);
+                const float h = x * y0;
+                const float l = fmaf(x, y0, -h);
+                float e = fmaf(-h, y0, 1.0f);
+                e = fmaf(-l, y0, e);
+                const float p = fmaf(0.375f, e, 0.5f);
+                const float y1 = fmaf(y0 * e, p, y0);
+                if (d == -1)
+                    first = y1;
+                else if (y1 != first)
+                    differs = 1;
+                if (y1 != want)
+                    bad = 1;
+            }
+            wrong += (uint64_t)bad;
+            dep += (uint64_t)differs;
+        }
+    if (seedDependent)
+        *seedDependent = dep;
+    return wrong;
 }
 
 int pto_test_eval(uint32_t fn, const float *in, float *out, uint32_t n)
@@ -2745,6 +2800,7 @@ int pto_test_eval(uint32_t fn, const float *in, float *out, uint32_t n)
             o[1] = pto_div(a[0], a[1]);
             break;
         case PTX_FN_SQRT: o[0] = sqrtf(a[0]); break;
+        case PTX_FN_RSQ: o[0] = pto_rsq(a[0]); break;
         case PTX_FN_COMPUTE_LOD: {
             v4 dv = { a[0], a[1], a[2], a[3] };
             o[0] = computeLod(dv);

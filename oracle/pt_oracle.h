@@ -98,6 +98,11 @@ PTX_API int pto_postprocess(const float *accum, uint32_t W, uint32_t H, const Pt
 PTX_API int pto_encode_output(const float *linear, uint32_t W, uint32_t H, uint32_t format, void *out);
 PTX_API int pto_test_post(uint32_t which, const float *in, float *out, uint32_t n);
 
+/* pto_rsq on the positive normal range against the EXACT correctly rounded 1 / sqrt(x): all 2^24 (mantissa, exponent parity)
+ * classes, x * m^2 compared with 1 at the two midpoints m next to the result in 128-bit integer arithmetic; and the device's
+ * algorithm (pt_device.hpp rsq_) run in float on the CPU from the seeds RN - 1 ULP, RN, RN + 1 ULP.  Returns the number of classes
+ * where either differs from the exact answer (0), *seedDependent = classes where the three seeds disagree. */
+PTX_API uint64_t pto_rsq_selfcheck(uint64_t *seedDependent);
 /* Function-level entry, same packing as ptx_test_eval (include/ptx.h). */
 PTX_API int pto_test_eval(uint32_t fn, const float *in, float *out, uint32_t n);
 /* Stage level: raygen.rgen main() for one pixel with scripted trace calls (layout at the definition); checked against

@@ -49,6 +49,30 @@ static inline float pto_rcp(float x)
 }
 static inline float pto_div(float a, float b) { return a * pto_rcp(b); }
 
+/* ---- the specified reciprocal square root (round 6) ----
+ * GLSL grants inversesqrt 2 ULP and normalize() the precision of its expansion; both are
+ *     normalize(v) := v * rsq(dot(v, v)),   inversesqrt(x) := rsq(x),
+ *     rsq(x) = the correctly rounded RN(1 / sqrt(x)) for positive normal x (2^-126 <= x <= FLT_MAX),
+ *              +-inf for +-0 and +-denormal inputs (flushed), +0 for +inf, NaN for negative normal numbers, -inf and NaN.
+ * On the positive normal range (float)(1.0 / sqrt((double)x)) IS the correctly rounded value: 1 / sqrt(x * 4^k) = 2^-k / sqrt(x), so
+ * 2^24 (mantissa, exponent parity) classes decide it for every input, and pto_rsq_selfcheck() compares all of them with the exact
+ * answer in 128-bit integer arithmetic (x * m^2 against 1 at both neighbouring midpoints m; tests/test_oracle_golden.py).
+ * On the device: v_rsq_f32 (1 ULP) + ONE compensated Newton step with the second-order term, 8 VALU + 2 for the range select instead
+ * of the 21 of rcp(sqrt(x)) -- equal to this definition for every seed within 1 ULP (shown on the CPU for all 2^24 classes x 3
+ * seeds) and on all 2^32 inputs on the hardware (tools/experiments/rcp_sqrt_exhaustive.hip, profiles/r06_rsq_exhaustive.txt). */
+static inline float pto_rsq(float x)
+{
+    uint32_t b;
+    memcpy(&b, &x, 4);
+    if (b - 0x00800000u < 0x7f800000u - 0x00800000u) /* positive normal */
+        return (float)(1.0 / sqrt((double)x));
+    if (x != x)
+        return x;
+    if ((b & 0x7fffffffu) < 0x00800000u) /* +-0, +-denormal */
+        return copysignf(INFINITY, x);
+    return b == 0x7f800000u ? 0.0f : NAN; /* +inf; negative normal numbers and -inf */
+}
+
 static inline v3 V3(float x, float y, float z) { v3 r = { x, y, z }; return r; }
 static inline v3 v3s(float s) { return V3(s, s, s); }
 static inline v3 v_add(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -63,7 +87,7 @@ static inline v3 v_cross(v3 a, v3 b)
     return V3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
 }
 static inline float v_length(v3 a) { return sqrtf(v_dot(a, a)); }
-static inline v3 v_normalize(v3 a) { return v_scale(a, pto_rcp(sqrtf(v_dot(a, a)))); }
+static inline v3 v_normalize(v3 a) { return v_scale(a, pto_rsq(v_dot(a, a))); }
 /* reflect(I, N) = I - 2 * dot(N, I) * N */
 static inline v3 v_reflect(v3 I, v3 N) { return v_sub(I, v_scale(N, 2.0f * v_dot(N, I))); }
 /* refract(I, N, eta), GLSL 4.60 8.5 */

@@ -158,7 +158,7 @@ FN = {
     "computeDpnDuv": 22, "computeDpDxy": 23, "computeDerivatives": 24, "computeReflectedDifferentialRays": 25,
     "computeRefractedDifferentialRays": 26, "computeLod": 27, "missSkyboxTexCoords": 28, "hdrToLdr": 29, "atanAsin": 30,
     "postprocessPixel": 31, "compositionPixel": 32, "toneMapPixel": 33, "sampleMaterial": 34,
-    "divide": 35, "sqrt": 36,
+    "divide": 35, "sqrt": 36, "rsq": 37,
 }
 
 

@@ -8,7 +8,7 @@
 // Arithmetic conventions (fixed so results are reproducible bit for bit; GLSL leaves
 // them implementation-defined): IEEE binary32 round-to-nearest, no contraction
 // (compiled with -ffp-contract=off), fma only where the GLSL writes fma();
-// dot = (x*x' + y*y') + z*z'; normalize(v) = v * (1/sqrt(dot(v,v))); mat3*vec3 =
+// dot = (x*x' + y*y') + z*z'; normalize(v) = v * rsq(dot(v,v)), rsq the correctly rounded 1/sqrt; mat3*vec3 =
 // (c0*x + c1*y) + c2*z; inverse(mat3) by cofactors * (1/det); min/max as the GLSL
 // select forms (NaN behaviour of "y < x ? y : x"); pow(x,2) = x*x, pow(x,5) = x2*x2*x;
 // sin/cos/pow by the fixed polynomial kernels below (no ocml calls: their results are
@@ -78,10 +78,29 @@ PT_DEV float sqrt_(float x)
 #endif
 }
 
+// The specified reciprocal square root (arithmetic conventions): RN(1 / sqrt(x)) for positive normal x,
+// the hardware's own answer elsewhere (+-inf for +-0 and denormals, which v_rsq_f32 flushes; +0 for +inf; NaN for negative numbers).
+// v_rsq_f32 (1 ULP) + ONE Newton step whose residual 1 - x y^2 is taken in two pieces (h + l = x y exactly) and whose correction
+// carries the second-order term: y (1 + e / 2 + 3 e^2 / 8).  For every seed within 1 ULP of the true value this rounds to the
+// correctly rounded result on all 2^24 (mantissa, exponent parity) classes (proof by enumeration on the CPU, in the tests) and it equals the
+// definition on all 2^32 inputs on the hardware (tools/experiments/rcp_sqrt_exhaustive.hip).  8 VALU + the class test and select;
+// rcp_(sqrt_(x)), which normalize() was until round 6, is 21.
+PT_DEV float rsq_(float x)
+{
+    const float y0 = __builtin_amdgcn_rsqf(x);
+    const float h = x * y0;
+    float e = __builtin_fmaf(-h, y0, 1.0f);
+    const float nl = __builtin_fmaf(-x, y0, h); // -(x y0 - h): the low half of the product, negated (fma(a, b, c) = -fma(-a, b, -c) exactly)
+    e = __builtin_fmaf(nl, y0, e);
+    const float p = __builtin_fmaf(0.375f, e, 0.5f);
+    const float y1 = __builtin_fmaf(y0 * e, p, y0);
+    return __builtin_amdgcn_classf(x, 0x100) ? y1 : y0; // 0x100: positive normal
+}
+
 PT_DEV float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 PT_DEV f3 cross(f3 a, f3 b) { return F3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
 PT_DEV float length(f3 a) { return sqrt_(dot(a, a)); }
-PT_DEV f3 normalize(f3 a) { return a * rcp_(sqrt_(dot(a, a))); }
+PT_DEV f3 normalize(f3 a) { return a * rsq_(dot(a, a)); }
 PT_DEV f3 reflect(f3 I, f3 N) { return I - N * (2.0f * dot(N, I)); }
 PT_DEV f3 refract(f3 I, f3 N, float eta)
 {
@@ -461,7 +480,7 @@ PT_DEV f3 SampleGGX(f2 u, f3 V, float alpha) // :111-129
 {
     const f3 Vh = normalize(F3(alpha * V.x, alpha * V.y, abs_(V.z)));
     const float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
-    const f3 T1 = lensq > 0 ? F3(-Vh.y, Vh.x, 0) * (div_(1.0f, sqrt_(lensq))) : F3(1, 0, 0);
+    const f3 T1 = lensq > 0 ? F3(-Vh.y, Vh.x, 0) * rsq_(lensq) : F3(1, 0, 0); // inversesqrt
     const f3 T2 = cross(Vh, T1);
     const float r = sqrt_(u.x);
     const float phi = 2.0f * PT_PI * u.y;

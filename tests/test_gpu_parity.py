@@ -97,6 +97,21 @@ def test_specified_reciprocal_on_all_inputs(pkg, orc, gpu_renderer):
     assert util.bits_equal_or_both_nan(gpu_renderer.test_eval(pkg.FN["divide"], corner), orc.test_eval(pkg.FN["divide"], corner, 2)).all()
     zeros = np.stack([np.where(rng.integers(0, 2, len(b)) == 1, np.uint32(0x80000000), np.uint32(0)).astype(np.uint32), b], axis=1)[: 1 << 22]
     assert util.bits_equal_or_both_nan(gpu_renderer.test_eval(pkg.FN["divide"], zeros), orc.test_eval(pkg.FN["divide"], zeros, 2)).all()
+    # round 6: the specified reciprocal square root of normalize() / inversesqrt() -- both exponent parities x all 2^23 mantissas
+    # (1 / sqrt(4^k x) = 2^-k / sqrt(x): these 2^24 classes decide every positive normal input), every exponent with random
+    # mantissas, denormals, zeros, infinities, negative numbers, NaNs: device == oracle == (float)(1 / sqrt((double)x))
+    rs = np.concatenate([np.uint32(0x3f800000) | np.arange(1 << 23, dtype=np.uint32), np.uint32(0x40000000) | np.arange(1 << 23, dtype=np.uint32),
+                         rng.integers(0, 1 << 32, 1 << 21, dtype=np.uint64).astype(np.uint32),
+                         np.array([0, 0x80000000, 1, 0x007fffff, 0x80000001, 0x00800000, 0x7f7fffff, 0x7f800000, 0xff800000, 0x7fc00000, 0xbf800000], np.uint32)]).reshape(-1, 1)
+    for lo in range(0, len(rs), 1 << 22):
+        out = gpu_renderer.test_eval(pkg.FN["rsq"], rs[lo:lo + (1 << 22)])
+        ref = orc.test_eval(pkg.FN["rsq"], rs[lo:lo + (1 << 22)], 1)
+        assert util.bits_equal_or_both_nan(out, ref).all(), f"rsq chunk {lo}: device != oracle"
+        xf = rs[lo:lo + (1 << 22), 0].view(np.float32)
+        normal = (xf >= np.float32(1.17549435e-38)) & np.isfinite(xf)
+        with np.errstate(all="ignore"):
+            want = (1.0 / np.sqrt(xf[normal].astype(np.float64))).astype(np.float32)
+        assert (out[normal, 0].view(np.float32) == want).all(), f"rsq chunk {lo}: device != float64 definition"
     x = np.concatenate([np.uint32(0x3f800000) | np.arange(1 << 23, dtype=np.uint32), np.uint32(0x40000000) | np.arange(1 << 23, dtype=np.uint32),
                         rng.integers(0, 1 << 32, 1 << 20, dtype=np.uint64).astype(np.uint32)]).reshape(-1, 1)
     for lo in range(0, len(x), 1 << 22):

@@ -19,8 +19,11 @@ TOLERANCE = {"SchlickFresnel": 1e-6, "SampleGGX": 2e-6, "evaluateBSDF": 1e-6, "s
              # division only (exact until round 5, when `/` became a * rcp(b)):
              "GGXDistribution": 5e-7, "Lambda": 5e-7, "GGXSmith": 5e-7, "DielectricFresnel": 5e-7, "EvaluateReflection": 5e-7,
              "EvaluateRefraction": 5e-7, "constructPrimaryRay": 1e-6, "computeDpDxy": 3e-6, "computeReflectedDifferentialRays": 1e-6,
-             "computeRefractedDifferentialRays": 1e-6, "hdrToLdr": 5e-7, "postprocessPixel": 1e-6, "sampleMaterial": 1e-6}
-EXACT_WITH_LIBM = {"sampleLobePdfs", "rng", "computeTangentSpace", "offsetRayOriginSelfIntersection", "offsetRayOriginShadowTerminator",
+             "computeRefractedDifferentialRays": 1e-6, "hdrToLdr": 5e-7, "postprocessPixel": 1e-6, "sampleMaterial": 1e-6,
+             # normalize only (exact until round 6, when normalize(v) became v * rsq(dot): ONE rounding of 1 / sqrt where the libm
+             # build rounds the root and then the reciprocal)
+             "computeTangentSpace": 2e-7}
+EXACT_WITH_LIBM = {"sampleLobePdfs", "rng", "offsetRayOriginSelfIntersection", "offsetRayOriginShadowTerminator",
                    "computeDpnDuv", "computeDerivatives", "computeLod", "compositionPixel"}
 
 
@@ -159,7 +162,7 @@ def test_oracle_closest_hit_against_reference_main(orc, pkg):
         inp = np.array(c["in"], np.uint32).reshape(-1, c["nin"])
         exp = np.array(c["out"], np.uint32).reshape(-1, c["nout"])
         assert inp.shape[1] == 150 and exp.shape[1] == 35 and len(inp) >= 300
-        bad = 0
+        bad = loose = 0
         inside = refracted = decals = 0
         for row, want in zip(inp, exp):
             d, L, keep = _one_triangle_scene(pkg, row)
@@ -176,8 +179,13 @@ def test_oracle_closest_hit_against_reference_main(orc, pkg):
                 assert (np.isfinite(wf) == np.isfinite(gf)).all()
                 err = np.abs(gf[fin].astype(np.float64) - wf[fin]) / np.maximum(1.0, np.abs(wf[fin]))
                 err[14] = 0.0
-                assert err.max() < 2e-4, float(err.max())
+                # one case of the 360 is ill-conditioned (a sampled refraction at the edge of its domain: Bsdf and Pdf come out
+                # NEGATIVE, differences of nearly equal terms): there the last bit of a normalize() -- one rounding in rsq, two in
+                # the libm build's 1 / sqrt -- shows as 4e-3; every other case stays inside the tolerance of the transcendentals
+                loose += int(err.max() >= 2e-4)
+                assert err.max() < 5e-3, float(err.max())
         assert bad == 0, f"{bad} of {len(inp)} payloads differ"
+        assert loose <= 1
         assert decals >= 20
 
 
@@ -434,3 +442,32 @@ def test_specified_division_corner_cases_are_the_stated_ones(orc, pkg):
     assert (out[6:8] == 0).all()                    # x / x, |x| > 2^126
     assert np.isinf(out[8]) and np.isinf(out[9])    # denormal / denormal, 1 / denormal
     assert out[10] == 0 and out[11] == 0            # 3 / big flushes to zero; 0 / 2 = 0 as ever
+
+
+def test_specified_rsq_is_the_correctly_rounded_reciprocal_square_root(orc, pkg):
+    """oracle/pt_oracle_math.h pto_rsq -- normalize(v) = v * rsq(dot(v, v)), inversesqrt = rsq (round 6): on the positive normal range
+    it is the correctly rounded 1 / sqrt(x), checked against EXACT 128-bit integer arithmetic on all 2^24 (mantissa, exponent parity)
+    classes (1 / sqrt(4^k x) = 2^-k / sqrt(x)); the device's float sequence (v_rsq_f32 seed + one compensated Newton step with the
+    second-order term) run on the CPU from every seed the hardware's 1 ULP allows lands on the same float, so the definition does not
+    depend on the seed.  Outside: +-inf for +-0 and denormals, +0 for +inf, NaN for negative numbers and NaN.  Inside GLSL's 2 ULP."""
+    wrong, seed_dependent = orc.rsq_selfcheck()
+    assert wrong == 0 and seed_dependent == 0
+    f = np.float32
+    x = np.array([0.0, -0.0, 1e-40, -1e-40, np.inf, -np.inf, -1.0, np.nan, 1.0, 4.0, 0.25, 2.0, 3.4028235e38, 1.17549435e-38], np.float32)
+    out = orc.test_eval(pkg.FN["rsq"], x.view(np.uint32).reshape(-1, 1), 1)[:, 0].view(np.float32)
+    assert out[0] == np.inf and out[1] == -np.inf and out[2] == np.inf and out[3] == -np.inf and out[4] == 0 and not np.signbit(out[4])
+    assert np.isnan(out[5:8]).all()
+    assert (out[8:11] == f([1.0, 0.5, 2.0])).all() and out[11] == f(0.70710678118654752) and out[12] == f(1.0 / np.sqrt(np.float64(f(3.4028235e38))))
+    assert out[13] == f(2.0 ** 63)
+    # every exponent, random mantissas: against float64 (1 / sqrt in double, rounded once -- exactly what the definition says)
+    rng = np.random.default_rng(9)
+    bits = ((np.arange(1, 255, dtype=np.uint32).repeat(4000) << 23) | rng.integers(0, 1 << 23, 254 * 4000, dtype=np.uint32)).astype(np.uint32)
+    got = orc.test_eval(pkg.FN["rsq"], bits.reshape(-1, 1), 1)[:, 0].view(np.float32)
+    want = (1.0 / np.sqrt(bits.view(np.float32).astype(np.float64))).astype(np.float32)
+    assert (got == want).all()
+    # normalize keeps unit length to 1 ULP-ish and agrees with the IEEE-divided form to 1.5 ULP
+    v = rng.normal(size=(20000, 3)).astype(np.float32) * np.float32(10.0) ** rng.integers(-15, 15, (20000, 1)).astype(np.float32)
+    d = ((v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1]).astype(np.float32) + v[:, 2] * v[:, 2]).astype(np.float32)
+    r = orc.test_eval(pkg.FN["rsq"], d.view(np.uint32).reshape(-1, 1), 1)[:, 0].view(np.float32)
+    n = v * r[:, None]
+    assert np.abs(np.linalg.norm(n.astype(np.float64), axis=1) - 1.0).max() < 3e-7

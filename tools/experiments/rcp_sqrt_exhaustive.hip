@@ -54,7 +54,30 @@ __device__ __forceinline__ float sqrt_fast_only(float x)
 }
 __device__ __forceinline__ float sqrt_spec(float x) { return __builtin_sqrtf(x); } // IEEE, hipcc's 16-instruction expansion
 
-struct Report { unsigned long long bad[3][5]; uint32_t first[3][5][8]; uint32_t firstGot[3][5][8]; uint32_t firstWant[3][5][8]; };
+// round 6: rsq_(x) of pt_device.hpp -- v_rsq_f32 + one compensated Newton step with the second-order term (8 VALU + class test + select)
+// against the SPECIFICATION: RN(1 / sqrt(x)) for positive normal x = (float)(1.0 / sqrt((double)x)) (shown exact on the CPU for all 2^24
+// mantissa / exponent-parity classes), +-inf for +-0 and denormals, +0 for +inf, NaN for negative numbers and NaN
+__device__ __forceinline__ float rsq_dev(float x)
+{
+    const float y0 = __builtin_amdgcn_rsqf(x);
+    const float h = x * y0;
+    const float l = __builtin_fmaf(x, y0, -h);
+    float e = __builtin_fmaf(-h, y0, 1.0f);
+    e = __builtin_fmaf(-l, y0, e);
+    const float p = __builtin_fmaf(0.375f, e, 0.5f);
+    const float y1 = __builtin_fmaf(y0 * e, p, y0);
+    return __builtin_amdgcn_classf(x, 0x100) ? y1 : y0;
+}
+__device__ __forceinline__ float rsq_spec(float x)
+{
+    const uint32_t b = asu(x);
+    if (b - 0x00800000u < 0x7f800000u - 0x00800000u) return (float)(1.0 / __builtin_sqrt((double)x));
+    if (x != x) return x;
+    if ((b & 0x7fffffffu) < 0x00800000u) return __builtin_copysignf(__builtin_inff(), x);
+    return b == 0x7f800000u ? 0.0f : __builtin_nanf("");
+}
+
+struct Report { unsigned long long bad[4][5]; uint32_t first[4][5][8]; uint32_t firstGot[4][5][8]; uint32_t firstWant[4][5][8]; };
 
 __device__ int classOf(float x)
 {
@@ -71,9 +94,10 @@ __global__ void k_check(Report *rep, uint32_t base)
     const uint32_t bits = base + blockIdx.x * blockDim.x + threadIdx.x;
     const float x = asf(bits);
     const int c = classOf(x);
-    for (int f = 0; f < 3; f++)
+    for (int f = 0; f < 4; f++)
     {
-        const float got = f == 0 ? rcp_dev(x) : f == 1 ? sqrt_dev(x) : sqrt_fast_only(x), want = f == 0 ? rcp_spec(x) : sqrt_spec(x);
+        const float got = f == 0 ? rcp_dev(x) : f == 1 ? sqrt_dev(x) : f == 2 ? sqrt_fast_only(x) : rsq_dev(x);
+        const float want = f == 0 ? rcp_spec(x) : f == 3 ? rsq_spec(x) : sqrt_spec(x);
         const bool same = asu(got) == asu(want) || (got != got && want != want);  // any NaN equals any NaN
         if (!same)
         {
@@ -87,7 +111,7 @@ __global__ void k_check(Report *rep, uint32_t base)
 __global__ void k_probe(const uint32_t *in, uint32_t *out, int n)
 {
     const int i = threadIdx.x;
-    if (i < n) { out[2 * i] = asu(__builtin_amdgcn_rcpf(asf(in[i]))); out[2 * i + 1] = asu(__builtin_amdgcn_sqrtf(asf(in[i]))); }
+    if (i < n) { out[3 * i] = asu(__builtin_amdgcn_rcpf(asf(in[i]))); out[3 * i + 1] = asu(__builtin_amdgcn_sqrtf(asf(in[i]))); out[3 * i + 2] = asu(__builtin_amdgcn_rsqf(asf(in[i]))); }
 }
 
 int main()
@@ -98,9 +122,9 @@ int main()
         hipLaunchKernelGGL(k_check, dim3(1u << 16), dim3(256), 0, 0, rep, hi << 24);
     hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b);
     Report h; hipMemcpy(&h, rep, sizeof(h), hipMemcpyDeviceToHost);
-    const char *fn[3] = {"rcp_", "sqrt_", "sqrt fast path alone"}, *cl[5] = {"normal range", "zero/denormal", "> 2^126 / inf", "NaN", "[2^-126, 2^-96)"};
+    const char *fn[4] = {"rcp_", "sqrt_", "sqrt fast path alone", "rsq_"}, *cl[5] = {"normal range", "zero/denormal", "> 2^126 / inf", "NaN", "[2^-126, 2^-96)"};
     printf("all 2^32 inputs in %.1f ms\n", ms);
-    for (int f = 0; f < 3; f++)
+    for (int f = 0; f < 4; f++)
         for (int c = 0; c < 5; c++)
         {
             printf("%-20s %-16s mismatches %llu\n", fn[f], cl[c], h.bad[f][c]);
@@ -110,10 +134,10 @@ int main()
     const uint32_t probes[] = {0x00000000u, 0x80000000u, 0x00000001u, 0x00400000u, 0x007fffffu, 0x80400000u, 0x00800000u, 0x7e800000u, 0x7e800001u,
                                0x7f000000u, 0x7f7fffffu, 0x7f800000u, 0xff800000u, 0x7fc00000u, 0x3f800000u, 0x3fffffffu};
     const int n = sizeof(probes) / 4;
-    uint32_t *din, *dout; hipMalloc(&din, sizeof(probes)); hipMalloc(&dout, sizeof(probes) * 2);
+    uint32_t *din, *dout; hipMalloc(&din, sizeof(probes)); hipMalloc(&dout, sizeof(probes) * 3);
     hipMemcpy(din, probes, sizeof(probes), hipMemcpyHostToDevice);
     hipLaunchKernelGGL(k_probe, dim3(1), dim3(64), 0, 0, din, dout, n);
-    uint32_t out[2 * 16]; hipMemcpy(out, dout, sizeof(out), hipMemcpyDeviceToHost);
-    for (int i = 0; i < n; i++) printf("probe x %08x  v_rcp %08x  v_sqrt %08x\n", probes[i], out[2 * i], out[2 * i + 1]);
+    uint32_t out[3 * 16]; hipMemcpy(out, dout, sizeof(out), hipMemcpyDeviceToHost);
+    for (int i = 0; i < n; i++) printf("probe x %08x  v_rcp %08x  v_sqrt %08x  v_rsq %08x\n", probes[i], out[3 * i], out[3 * i + 1], out[3 * i + 2]);
     return 0;
 }

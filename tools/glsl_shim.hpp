@@ -254,7 +254,15 @@ inline mat4 inverse(const mat4 &a) // cofactor expansion
 // ---- builtins --------------------------------------------------------------
 inline float abs(float x) { return fabsf(x); }
 inline float sqrt(float x) { return sqrtf(x); }
-inline float inversesqrt(float x) { return 1.0f / sqrt(x); } // the specified division of the correctly rounded root
+inline glsl::f32 shimRsq(glsl::f32 x)
+{
+#ifdef SHIM_FIXED
+    return pto_rsq(x); // the specified reciprocal square root (oracle/pt_oracle_math.h)
+#else
+    return 1.0f / sqrtf(x); // IEEE: the independent check
+#endif
+}
+inline float inversesqrt(float x) { return float(shimRsq(x.v)); }
 inline float min(float a, float b) { return f_min(a, b); }
 inline float max(float a, float b) { return f_max(a, b); }
 inline vec3 max(vec3 a, float b) { return vec3(f_max(a.x, b), f_max(a.y, b), f_max(a.z, b)); }
@@ -304,7 +312,7 @@ inline float dot(uvec2 a, uvec2 b) { return (float)a.x * (float)b.x + (float)a.y
 inline vec3 cross(vec3 a, vec3 b) { return vec3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
 inline float length(vec3 a) { return sqrtf(dot(a, a)); }
 inline float distance(vec3 a, vec3 b) { return length(a - b); }
-inline vec3 normalize(vec3 a) { return a * (1.0f / sqrt(dot(a, a))); }
+inline vec3 normalize(vec3 a) { return a * float(shimRsq(dot(a, a).v)); }
 inline vec3 reflect(vec3 I, vec3 N) { return I - N * (2.0f * dot(N, I)); }
 inline vec3 refract(vec3 I, vec3 N, float eta)
 {
