@@ -7,15 +7,20 @@ Renders the whole frame (bench.py --emulate-shard 0/1) and then every rank's pix
 
   scaling_emulated = {frame_ms, shard_ms[WORLD], gather_ms_model, speedup_model = frame_ms / (max(shard_ms) + gather_ms_model)}
 
---gather (round 5): every shard run does RANK 0's whole gather duty inside the timed loop (bench.py --force-gather --dist-backend
-nccl: ptx_pack_shard, the RCCL all_gather_into_tensor call on a one-rank group, one device copy standing in for the WORLD - 1 pieces
-that arrive over xGMI, WORLD x ptx_unpack_shard, the pipelined read-back), and the whole frame reads back too; only the link time
-itself stays the model below.
+--gather: every shard run does ITS RANK's whole share of the job inside the timed loop (bench.py --force-gather --dist-backend nccl).
+Round 6 (the default): the owner of step k's frame is rank k % WORLD -- every step the rank accumulates straight into the gather's
+message and makes the collective call (RCCL on a one-rank group: its launch and a local copy); on the steps it OWNS (one in
+WORLD) it also takes the WORLD - 1 pieces that would arrive over xGMI (one device copy), composes the frame with ONE
+ptx_unpack_shards launch and stores it to the host's page-locked frame.  `--root rank0 --gather-unpack per-rank
+--shard-accumulation packed` (passed through to bench.py) gives round 5's step: rank 0 owns every frame.  The whole frame (0/1)
+reads back too.  Only the link time itself stays the model below.
 
-gather_ms_model: the one all_gather of the step.  Every rank contributes W*H*16/WORLD bytes (plus the padding of ragged tiles);
-RCCL's ring all-gather over point-to-point xGMI moves (WORLD - 1) such pieces over each link, one after the other, at the per-link
-rate of /opt/skills/guides (153 GB/s) -- per-link bound, the pessimistic schedule (each peer writing straight to rank 0 over its own
-link would take one piece's time).  Ranks render different tiles, so the slowest shard sets the step.
+gather_ms_model: the one gather of the step.  Every rank contributes W*H*16/WORLD bytes (plus the padding of ragged tiles) and
+sends them to the owner over ITS OWN xGMI link (point-to-point: the WORLD - 1 sends proceed in parallel), so the owner has the frame
+after one piece's time at the per-link rate of /opt/skills/guides (153 GB/s); `--collective all_gather` (rounds 1-5: RCCL's ring
+all_gather, WORLD - 1 pieces over each link one after the other) is priced as that.  The streams of the frames in flight are
+asynchronous, so on hardware this time overlaps the next frame's rendering; the model ADDS it to the step (pessimistic).  Ranks
+render different tiles, so the slowest shard sets the step.
 What the emulation cannot show: the ranks' launch overheads overlap on real hardware exactly as here (one process per GPU), but the
 gather's interaction with the frames in flight is modelled, not measured."""
 import json
@@ -64,9 +69,13 @@ def main():
     shards = [run(f"{r}/{world}") for r in range(world)]
     piece = W * H * 16 / world
     gather_in_loop = gather
-    gather = (world - 1) * piece / (XGMI_LINK_GBS * 1e9) * 1e3
+    ring = "all_gather" in " ".join(rest)
+    pieces_per_link = (world - 1) if ring else 1
+    gather = pieces_per_link * piece / (XGMI_LINK_GBS * 1e9) * 1e3
     out = {"scene": scene, "world": world, "frame_ms": frame, "shard_ms": shards, "gather_ms_model": gather, "gather_in_loop": gather_in_loop,
-           "gather_model": f"ring all-gather, {world - 1} pieces of {piece / 1e6:.2f} MB per link at {XGMI_LINK_GBS:.0f} GB/s",
+           "owner": "rank0" if "rank0" in rest else "rotating (k % world)",
+           "gather_model": (f"ring all-gather, {world - 1} pieces of {piece / 1e6:.2f} MB per link at {XGMI_LINK_GBS:.0f} GB/s" if ring else
+                            f"gather to the owner, one piece of {piece / 1e6:.2f} MB per link at {XGMI_LINK_GBS:.0f} GB/s, {world - 1} links in parallel"),
            "speedup_model": frame / (max(shards) + gather), "speedup_without_gather": frame / max(shards)}
     print(json.dumps({"scaling_emulated": out}))
 
