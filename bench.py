@@ -170,7 +170,7 @@ class FrameStore:
     every frame whichever rank composed it.  The name is unlinked as soon as every rank has mapped the segment: nothing stays in
     /dev/shm behind a job, however it ends."""
 
-    def __init__(self, torch, dist, count, nbytes, rank, world, owned):
+    def __init__(self, torch, dist, count, nbytes, rank, world, owned, register=True):
         self.torch, self.count, self.nbytes, self.shared = torch, count, nbytes, world > 1
         self.stride = (nbytes + 4095) // 4096 * 4096
         self.registered = []
@@ -193,6 +193,8 @@ class FrameStore:
         if rank == 0:
             os.unlink(path)
         self.base = ctypes.addressof(ctypes.c_char.from_buffer(self.mm))
+        if not register:  # (CPU tests of the segment itself: no HIP runtime to register with)
+            return
         rt = torch.cuda.cudart()
         for j in owned:
             err = rt.cudaHostRegister(self.base + j * self.stride, self.stride, 0)
@@ -209,7 +211,7 @@ class FrameStore:
         return np.frombuffer(self.mm, dtype=np.float32, count=H * W * 4, offset=j * self.stride).reshape(H, W, 4)
 
     def close(self):
-        if self.shared:
+        if self.shared and self.registered:
             rt = self.torch.cuda.cudart()
             for a in self.registered:
                 rt.cudaHostUnregister(a)

@@ -1,6 +1,7 @@
 """N > 1 path on CPU: two gloo ranks render their pixel-tile shards (with the oracle standing in
 for the GPU renderer, which is absent here), exchange them with the same pack -> all_gather ->
 unpack sequence bench.py uses, and rank 0 must hold the exact single-process frame."""
+import math
 import os
 import socket
 import sys
@@ -92,6 +93,44 @@ def test_two_rank_tile_shard_gather(tmp_path, pkg, orc):
     for f in range(2):
         osc.render(s.uniform(W, H, bounces=4, total_samples=f), s.lights, W, H, accum=ref)
     assert (got.view(np.uint32) == ref.view(np.uint32)).all()
+
+
+def _frame_store_worker(rank, world, port, outdir):
+    sys.path.insert(0, REPO)
+    import bench
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    F, H, W = 3, 5, 7
+    L = F * world // math.gcd(F, world)
+    owned = [j for j in range(L) if j % world == rank]
+    store = bench.FrameStore(torch, dist, L, H * W * 16, rank, world, owned, register=False)
+    dist.barrier()  # (rank 0 unlinks the name right after the constructor's last barrier)
+    assert store.shared and not os.path.exists(f"/dev/shm/ptx_frames_{port}_{os.getuid()}")  # unlinked once every rank has mapped it
+    for j in owned:  # what a rank's gather launch does through the registered alias: it writes the frames it owns
+        store.image(j, H, W)[...] = np.float32(100 * rank + j)
+    dist.barrier()
+    got = np.stack([store.image(j, H, W).copy() for j in range(L)])  # every rank sees every frame, whoever wrote it
+    want = np.stack([np.full((H, W, 4), 100 * (j % world) + j, np.float32) for j in range(L)])
+    assert (got == want).all()
+    assert store.ptr(1) - store.ptr(0) == store.stride and store.stride % 4096 == 0
+    dist.barrier()
+    store.close()
+    if rank == 0:
+        np.save(os.path.join(outdir, "frames_seen_by_rank0.npy"), got)
+    dist.destroy_process_group()
+
+
+def test_host_frames_in_shared_memory_are_seen_by_every_rank(tmp_path):
+    """bench.py's FrameStore for N > 1: ONE POSIX shared-memory segment of lcm(ranks, frames in flight) host
+    frames that every rank maps; step k's frame lives at index k % L and is written by its owner, rank k % N; any process of the
+    node reads every frame.  Two gloo ranks, no GPU (the hipHostRegister of the owned frames is the GPU tests' business): each
+    writes the frames it owns, both read all six; the segment's name is gone from /dev/shm as soon as both have mapped it."""
+    world = 2
+    mp.spawn(_frame_store_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "frames_seen_by_rank0.npy")
+    assert got.shape == (6, 5, 7, 4) and [float(got[j, 0, 0, 0]) for j in range(6)] == [0.0, 101.0, 2.0, 103.0, 4.0, 105.0]
 
 
 # ---------------------------------------------------------------------------------------
