@@ -282,6 +282,23 @@ class Job:
             self.shard_floats = max(self.rs[0].shard_bytes(k) for k in range(self.pieces)) // 4
             self.send = [torch.zeros(self.shard_floats, dtype=torch.float32, device="cuda") for _ in range(self.F)]
             self.recv = [torch.zeros(self.pieces * self.shard_floats, dtype=torch.float32, device="cuda") for _ in range(self.F)]
+            if world > 1 and args.dist_backend == "nccl" and args.collective == "gather":
+                # one trial gather on a few bytes before anything is timed: a collective library that refuses the grouped send / recv
+                # form raises here on every rank alike, and the job falls back to all_gather_into_tensor (rounds 1-5) instead of dying
+                try:
+                    probe = torch.full((4,), float(rank), device="cuda")
+                    parts = [torch.empty(4, device="cuda") for _ in range(world)] if rank == 0 else None
+                    dist.gather(probe, parts, dst=0)
+                    torch.cuda.synchronize()
+                    if rank == 0 and [float(p[0]) for p in parts] != [float(q) for q in range(world)]:
+                        raise RuntimeError("dist.gather delivered the wrong pieces")
+                except Exception as e:  # noqa: BLE001  (whatever the backend raises: the fallback is the point)
+                    print(f"[bench] rank {rank}: dist.gather failed ({e}); using all_gather_into_tensor", file=sys.stderr)
+                    args.collective = "all_gather"
+                flag = torch.tensor([1 if args.collective == "gather" else 0], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # every rank takes the same decision
+                if int(flag.item()) == 0:
+                    args.collective = "all_gather"
             if args.shard_accumulation == "bound":
                 # raygen.rgen:115-117's accumulation goes straight into the message of the gather: no ptx_pack_shard pass
                 torch.cuda.synchronize()
