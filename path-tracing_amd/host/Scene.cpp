@@ -44,12 +44,12 @@ Vec3 TransformVector(const Mat4 &t, Vec3 p)
 // parent.CurrentTransform * node.Transform.
 void Scene::UpdateTransforms()
 {
-    m_SceneNodes[0].CurrentTransform = m_SceneNodes[0].Transform;
-    for (size_t i = 1; i < m_SceneNodes.size(); i++)
+    m_Graph.Nodes[0].CurrentTransform = m_Graph.Nodes[0].Transform;
+    for (size_t i = 1; i < m_Graph.Nodes.size(); i++)
     {
-        SceneNode &node = m_SceneNodes[i];
-        const SceneNode &parent = m_SceneNodes[node.Parent];
-        if (m_IsRelativeTransform[i])
+        SceneNode &node = m_Graph.Nodes[i];
+        const SceneNode &parent = m_Graph.Nodes[node.Parent];
+        if (m_Graph.IsRelative[i])
             node.CurrentTransform = parent.CurrentTransform * node.Transform;
         else
             node.CurrentTransform = node.Transform;
@@ -82,31 +82,31 @@ void Animation::Update(float timeStep, std::span<SceneNode> nodes)
 bool Scene::Update(float timeStep)
 {
     bool updated = GetActiveCamera().OnUpdate(timeStep);
-    if (m_IsAnimationPaused)
+    if (m_Graph.Paused)
         return updated;
-    updated |= m_HasAnimatedInstances;
+    updated |= m_Graph.MovesInstances;
 
-    for (Animation &animation : m_Animations)
-        animation.Update(timeStep, m_SceneNodes);
+    for (Animation &animation : m_Graph.Animations)
+        animation.Update(timeStep, m_Graph.Nodes);
     UpdateTransforms();
     for (auto &instance : m_ModelInstances)
-        instance.Transform = m_SceneNodes[instance.SceneNodeIndex].CurrentTransform;
-    for (size_t i = 0; i < m_Bones.size(); i++) // "Offset * node" of the transposed glm form = node * Offset
+        instance.Transform = m_Graph.Nodes[instance.SceneNodeIndex].CurrentTransform;
+    for (size_t i = 0; i < m_Graph.Bones.size(); i++) // "Offset * node" of the transposed glm form = node * Offset
     {
-        const Mat4 t = m_SceneNodes[m_Bones[i].SceneNodeIndex].CurrentTransform * m_Bones[i].Offset;
-        std::memcpy(m_BoneTransforms[i].m, &t.m[0][0], sizeof(float) * 12);
+        const Mat4 t = m_Graph.Nodes[m_Graph.Bones[i].SceneNodeIndex].CurrentTransform * m_Graph.Bones[i].Offset;
+        std::memcpy(m_Graph.BoneTransforms[i].m, &t.m[0][0], sizeof(float) * 12);
     }
-    for (size_t i = 0; i < m_LightInfos.size(); i++)
+    for (size_t i = 0; i < m_Lights.PointRest.size(); i++)
     {
-        const Vec3 p = TransformPoint(m_SceneNodes[m_LightInfos[i].SceneNodeIndex].CurrentTransform, m_LightInfos[i].Position);
-        m_PointLights[i].Position[0] = p.x;
-        m_PointLights[i].Position[1] = p.y;
-        m_PointLights[i].Position[2] = p.z;
+        const Vec3 p = TransformPoint(m_Graph.Nodes[m_Lights.PointRest[i].SceneNodeIndex].CurrentTransform, m_Lights.PointRest[i].Position);
+        m_Lights.Point[i].Position[0] = p.x;
+        m_Lights.Point[i].Position[1] = p.y;
+        m_Lights.Point[i].Position[2] = p.z;
     }
-    const Vec3 d = TransformVector(m_SceneNodes[m_DirectionalLightInfo.SceneNodeIndex].CurrentTransform, m_DirectionalLightInfo.Direction);
-    m_DirectionalLight.Direction[0] = d.x;
-    m_DirectionalLight.Direction[1] = d.y;
-    m_DirectionalLight.Direction[2] = d.z;
+    const Vec3 d = TransformVector(m_Graph.Nodes[m_Lights.DirectionalRest.SceneNodeIndex].CurrentTransform, m_Lights.DirectionalRest.Direction);
+    m_Lights.Directional.Direction[0] = d.x;
+    m_Lights.Directional.Direction[1] = d.y;
+    m_Lights.Directional.Direction[2] = d.z;
     return updated;
 }
 
@@ -167,12 +167,12 @@ PtxSceneDesc Scene::GetDesc() const
     d.transformCount = static_cast<uint32_t>(m_Transforms.size());
     d.geometries = m_Geometries.data();
     d.geometryCount = static_cast<uint32_t>(m_Geometries.size());
-    d.metallicRoughnessMaterials = m_MetallicRoughnessMaterials.data();
-    d.metallicRoughnessMaterialCount = static_cast<uint32_t>(m_MetallicRoughnessMaterials.size());
-    d.specularGlossinessMaterials = m_SpecularGlossinessMaterials.data();
-    d.specularGlossinessMaterialCount = static_cast<uint32_t>(m_SpecularGlossinessMaterials.size());
-    d.phongMaterials = m_PhongMaterials.data();
-    d.phongMaterialCount = static_cast<uint32_t>(m_PhongMaterials.size());
+    d.metallicRoughnessMaterials = m_Materials.MetallicRoughness.data();
+    d.metallicRoughnessMaterialCount = static_cast<uint32_t>(m_Materials.MetallicRoughness.size());
+    d.specularGlossinessMaterials = m_Materials.SpecularGlossiness.data();
+    d.specularGlossinessMaterialCount = static_cast<uint32_t>(m_Materials.SpecularGlossiness.size());
+    d.phongMaterials = m_Materials.Phong.data();
+    d.phongMaterialCount = static_cast<uint32_t>(m_Materials.Phong.size());
     d.meshes = m_MeshRecords.data();
     d.meshCount = static_cast<uint32_t>(m_MeshRecords.size());
     d.models = m_ModelRanges.data();
@@ -234,10 +234,10 @@ PtxLightsUbo Scene::GetLightsUbo() const
 {
     PtxLightsUbo ubo;
     std::memset(&ubo, 0, sizeof(ubo));
-    ubo.LightCount = static_cast<uint32_t>(m_PointLights.size());
-    ubo.Directional = m_DirectionalLight;
-    for (size_t i = 0; i < m_PointLights.size(); i++)
-        ubo.Lights[i] = m_PointLights[i];
+    ubo.LightCount = static_cast<uint32_t>(m_Lights.Point.size());
+    ubo.Directional = m_Lights.Directional;
+    for (size_t i = 0; i < m_Lights.Point.size(); i++)
+        ubo.Lights[i] = m_Lights.Point[i];
     return ubo;
 }
 
@@ -250,228 +250,192 @@ SceneBuilder::SceneBuilder()
     Reset();
 }
 
+// A fresh scene under construction: transform slot 0 is the identity every untransformed mesh shares (Scene.h:312), node 0 is the
+// root of the graph (Scene.h:336), the light is the reference's default.
 void SceneBuilder::Reset()
 {
-    m_MeshOffset = 0;
-    m_Vertices.clear();
-    m_Indices.clear();
-    m_Transforms = { IdentityTransform() }; // Scene.h:312
-    m_Geometries.clear();
-    m_MetallicRoughnessMaterials.clear();
-    m_MetallicRoughnessMaterialIds.clear();
-    m_SpecularGlossinessMaterials.clear();
-    m_SpecularGlossinessMaterialIds.clear();
-    m_PhongMaterials.clear();
-    m_PhongMaterialIds.clear();
-    m_Textures.clear();
-    m_TextureIndices.clear();
-    m_Models.clear();
-    m_ModelInstanceInfos.clear();
-    m_SceneNodes.clear();
-    m_SceneNodes.push_back(SceneNode { RootNodeIndex, Mat4::Identity(), Mat4::Identity() }); // Scene.h:336
-    m_IsRelativeTransform.clear();
-    m_IsRelativeTransform.push_back(true);
-    m_Animations.clear();
-    m_AnimatedVertices.clear();
-    m_AnimatedIndices.clear();
-    m_Bones.clear();
-    m_LightInfos.clear();
-    m_PointLights.clear();
-    m_DirectionalLight = g_DefaultLight;
-    m_Skybox = SkyboxClearColor {};
-    m_DirectionalLightInfo = { RootNodeIndex, Vec3(-0.4f, -1.0f, -0.2f) };
-    m_CameraInfos.clear();
-    m_HasDxNormalTextures = false;
-    m_ForceFullTextureSize = false;
+    m_Scene = std::make_shared<Scene>();
+    Scene &s = *m_Scene;
+    s.m_Transforms.push_back(IdentityTransform());
+    s.m_Graph.Nodes.push_back(SceneNode { RootNodeIndex, Mat4::Identity(), Mat4::Identity() });
+    s.m_Graph.IsRelative.push_back(true);
+    s.m_Lights.Directional = g_DefaultLight;
+    s.m_Lights.DirectionalRest = { RootNodeIndex, Vec3(-0.4f, -1.0f, -0.2f) };
+    m_Ids = IdsByName();
+    m_PendingInstances.clear();
+    m_PendingCameras.clear();
+    m_NextMeshRecord = 0;
 }
 
 uint32_t SceneBuilder::AddSceneNode(SceneNode &&node)
 {
-    m_SceneNodes.push_back(node);
-    m_IsRelativeTransform.push_back(true);
-    return static_cast<uint32_t>(m_SceneNodes.size() - 1);
+    m_Scene->m_Graph.Nodes.push_back(node);
+    m_Scene->m_Graph.IsRelative.push_back(true);
+    return static_cast<uint32_t>(m_Scene->m_Graph.Nodes.size() - 1);
 }
 
 uint32_t SceneBuilder::AddGeometry(Geometry &&geometry)
 {
-    m_Geometries.push_back(geometry);
-    return static_cast<uint32_t>(m_Geometries.size() - 1);
+    m_Scene->m_Geometries.push_back(geometry);
+    return static_cast<uint32_t>(m_Scene->m_Geometries.size() - 1);
 }
 
 uint32_t SceneBuilder::AddModel(std::span<const MeshInfo> meshInfos)
 {
-    m_Models.push_back(CreateModel(meshInfos));
-    return static_cast<uint32_t>(m_Models.size() - 1);
+    m_Scene->m_Models.push_back(CreateModel(meshInfos));
+    return static_cast<uint32_t>(m_Scene->m_Models.size() - 1);
 }
 
 uint32_t SceneBuilder::AddModelInstance(uint32_t modelIndex, uint32_t sceneNodeIndex)
 {
-    m_ModelInstanceInfos.emplace_back(modelIndex, sceneNodeIndex);
-    return static_cast<uint32_t>(m_ModelInstanceInfos.size() - 1);
+    m_PendingInstances.emplace_back(modelIndex, sceneNodeIndex);
+    return static_cast<uint32_t>(m_PendingInstances.size() - 1);
 }
 
-// Scene.cpp:125-141: deduplicated by name
+namespace
+{
+// One entry per distinct name (the reference deduplicates textures and materials by name, Scene.cpp:125-194): the id the first
+// caller was given, or `make()`'s for a new name.
+template<typename Make> uint32_t IdForName(std::unordered_map<std::string, uint32_t> &ids, const std::string &name, Make make)
+{
+    const auto known = ids.find(name);
+    if (known != ids.end())
+        return known->second;
+    const uint32_t id = make();
+    ids.emplace(name, id);
+    return id;
+}
+}
+
 uint32_t SceneBuilder::AddTexture(TextureInfo &&texture)
 {
-    auto it = m_TextureIndices.find(texture.Name);
-    if (it != m_TextureIndices.end())
-        return it->second;
-    assert(m_Textures.size() < Shaders::MaxTextureCount);
-    m_Textures.push_back(std::move(texture));
-    const uint32_t textureIndex = Shaders::GetSceneTextureIndex(static_cast<uint32_t>(m_Textures.size() - 1));
-    m_TextureIndices[m_Textures.back().Name] = textureIndex;
-    return textureIndex;
+    const std::string name = texture.Name;
+    return IdForName(m_Ids.Textures, name, [&] {
+        std::vector<TextureInfo> &textures = m_Scene->m_Textures;
+        assert(textures.size() < Shaders::MaxTextureCount);
+        textures.push_back(std::move(texture));
+        return Shaders::GetSceneTextureIndex(static_cast<uint32_t>(textures.size() - 1));
+    });
 }
 
-// Scene.cpp:143-160
 Shaders::MaterialId SceneBuilder::AddMaterial(std::string name, Shaders::MetallicRoughnessMaterial material)
 {
-    auto it = m_MetallicRoughnessMaterialIds.find(name);
-    if (it != m_MetallicRoughnessMaterialIds.end())
-        return it->second;
-    assert(material.Ior >= 1.0f);
-    assert(m_MetallicRoughnessMaterials.size() < Shaders::MaxMaterialCount);
-    m_MetallicRoughnessMaterials.push_back(material);
-    const Shaders::MaterialId materialId = Shaders::CreateMaterialId(
-        static_cast<uint32_t>(m_MetallicRoughnessMaterials.size() - 1), Shaders::MaterialTypeMetallicRoughness);
-    m_MetallicRoughnessMaterialIds[std::move(name)] = materialId;
-    return materialId;
+    return IdForName(m_Ids.MetallicRoughness, name, [&] {
+        auto &materials = m_Scene->m_Materials.MetallicRoughness;
+        assert(material.Ior >= 1.0f); // Scene.cpp:147
+        assert(materials.size() < Shaders::MaxMaterialCount);
+        materials.push_back(material);
+        return Shaders::CreateMaterialId(static_cast<uint32_t>(materials.size() - 1), Shaders::MaterialTypeMetallicRoughness);
+    });
 }
 
-// Scene.cpp:162-177
 Shaders::MaterialId SceneBuilder::AddMaterial(std::string name, Shaders::SpecularGlossinessMaterial material)
 {
-    auto it = m_SpecularGlossinessMaterialIds.find(name);
-    if (it != m_SpecularGlossinessMaterialIds.end())
-        return it->second;
-    m_SpecularGlossinessMaterials.push_back(material);
-    const Shaders::MaterialId materialId = Shaders::CreateMaterialId(
-        static_cast<uint32_t>(m_SpecularGlossinessMaterials.size() - 1), Shaders::MaterialTypeSpecularGlossiness);
-    m_SpecularGlossinessMaterialIds[std::move(name)] = materialId;
-    return materialId;
+    return IdForName(m_Ids.SpecularGlossiness, name, [&] {
+        auto &materials = m_Scene->m_Materials.SpecularGlossiness;
+        materials.push_back(material);
+        return Shaders::CreateMaterialId(static_cast<uint32_t>(materials.size() - 1), Shaders::MaterialTypeSpecularGlossiness);
+    });
 }
 
-// Scene.cpp:179-194
 Shaders::MaterialId SceneBuilder::AddMaterial(std::string name, Shaders::PhongMaterial material)
 {
-    auto it = m_PhongMaterialIds.find(name);
-    if (it != m_PhongMaterialIds.end())
-        return it->second;
-    m_PhongMaterials.push_back(material);
-    const Shaders::MaterialId materialId =
-        Shaders::CreateMaterialId(static_cast<uint32_t>(m_PhongMaterials.size() - 1), Shaders::MaterialTypePhong);
-    m_PhongMaterialIds[std::move(name)] = materialId;
-    return materialId;
+    return IdForName(m_Ids.Phong, name, [&] {
+        auto &materials = m_Scene->m_Materials.Phong;
+        materials.push_back(material);
+        return Shaders::CreateMaterialId(static_cast<uint32_t>(materials.size() - 1), Shaders::MaterialTypePhong);
+    });
 }
 
 void SceneBuilder::SetAbsoluteTransform(uint32_t sceneNodeIndex)
 {
-    m_IsRelativeTransform[sceneNodeIndex] = false;
+    m_Scene->m_Graph.IsRelative[sceneNodeIndex] = false;
 }
 
-// Scene.cpp:229-234
+// a point light follows its scene node (Scene.cpp:229-234, :73-75): its rest position is kept beside the UBO record
 void SceneBuilder::AddLight(Shaders::PointLight &&light, uint32_t sceneNodeIndex)
 {
-    assert(m_LightInfos.size() < Shaders::MaxLightCount);
-    m_LightInfos.push_back({ sceneNodeIndex, Vec3(light.Position[0], light.Position[1], light.Position[2]) });
-    m_PointLights.push_back(light);
+    assert(m_Scene->m_Lights.PointRest.size() < Shaders::MaxLightCount);
+    m_Scene->m_Lights.PointRest.push_back({ sceneNodeIndex, Vec3(light.Position[0], light.Position[1], light.Position[2]) });
+    m_Scene->m_Lights.Point.push_back(light);
 }
 
-// Scene.cpp:236-240
 void SceneBuilder::SetDirectionalLight(Shaders::DirectionalLight &&light, uint32_t sceneNodeIndex)
 {
-    m_DirectionalLightInfo = { sceneNodeIndex, Vec3(light.Direction[0], light.Direction[1], light.Direction[2]) };
-    m_DirectionalLight = light;
+    m_Scene->m_Lights.DirectionalRest = { sceneNodeIndex, Vec3(light.Direction[0], light.Direction[1], light.Direction[2]) };
+    m_Scene->m_Lights.Directional = light;
 }
 
 void SceneBuilder::AddCamera(CameraInfo &&camera)
 {
-    m_CameraInfos.push_back(camera);
+    m_PendingCameras.push_back(camera);
 }
 
-// Scene.cpp:337-355: identity mesh transforms share slot 0; MeshOffset is the running
-// record index that becomes instanceShaderBindingTableRecordOffset.
+// Scene.cpp:337-355: meshes without a transform of their own share transform slot 0; MeshOffset is the running index of the
+// model's first mesh record, which becomes instanceShaderBindingTableRecordOffset.
 Model SceneBuilder::CreateModel(std::span<const MeshInfo> meshInfos)
 {
-    Model model = { {}, m_MeshOffset };
-    for (const MeshInfo &meshInfo : meshInfos)
+    std::vector<PtxTransform> &transforms = m_Scene->m_Transforms;
+    Model model = { {}, m_NextMeshRecord };
+    model.Meshes.reserve(meshInfos.size());
+    for (const MeshInfo &info : meshInfos)
     {
-        const bool isIdentity = IsIdentity(meshInfo.Transform);
-        model.Meshes.push_back({ meshInfo.GeometryIndex, meshInfo.MaterialIndex, meshInfo.ShaderMaterialType,
-                                 isIdentity ? IdentityTransformIndex : static_cast<uint32_t>(m_Transforms.size()) });
-        if (!isIdentity)
-            m_Transforms.push_back(meshInfo.Transform);
+        uint32_t slot = IdentityTransformIndex;
+        if (!IsIdentity(info.Transform))
+        {
+            slot = static_cast<uint32_t>(transforms.size());
+            transforms.push_back(info.Transform);
+        }
+        model.Meshes.push_back({ info.GeometryIndex, info.MaterialIndex, info.ShaderMaterialType, slot });
     }
-    m_MeshOffset += static_cast<uint32_t>(meshInfos.size());
+    m_NextMeshRecord += static_cast<uint32_t>(meshInfos.size());
     return model;
 }
 
-// Scene.cpp:267-335
+// Finish the scene in place (behaviour of Scene.cpp:267-335) and start a fresh one.
 std::shared_ptr<Scene> SceneBuilder::CreateSceneShared(const std::string &name)
 {
-    // Scene.cpp:269-288: anything below an animated node moves
-    std::vector<bool> isAnimated(m_SceneNodes.size(), false);
-    for (const Animation &animation : m_Animations)
-        for (const AnimationNode &node : animation.Nodes)
-            isAnimated[node.SceneNodeIndex] = true;
-    for (size_t i = 0; i < m_SceneNodes.size(); i++)
-        if (isAnimated[m_SceneNodes[i].Parent])
-            isAnimated[i] = true;
-    bool hasAnimatedInstances = !m_Bones.empty();
-    for (const LightInfo &light : m_LightInfos)
-        hasAnimatedInstances |= isAnimated[light.SceneNodeIndex];
-    for (auto [modelIndex, sceneNodeIndex] : m_ModelInstanceInfos)
-        hasAnimatedInstances |= isAnimated[sceneNodeIndex];
+    std::shared_ptr<Scene> scene = std::move(m_Scene);
+    Scene &s = *scene;
+    s.m_Name = name;
 
-    auto scene = std::make_shared<Scene>();
-    scene->m_Name = name;
-    scene->m_HasAnimatedInstances = hasAnimatedInstances;
-    scene->m_Vertices = std::move(m_Vertices);
-    scene->m_Indices = std::move(m_Indices);
-    scene->m_Transforms = std::move(m_Transforms);
-    scene->m_Geometries = std::move(m_Geometries);
-    scene->m_MetallicRoughnessMaterials = std::move(m_MetallicRoughnessMaterials);
-    scene->m_SpecularGlossinessMaterials = std::move(m_SpecularGlossinessMaterials);
-    scene->m_PhongMaterials = std::move(m_PhongMaterials);
-    scene->m_Textures = std::move(m_Textures);
-    scene->m_HasDxNormalTextures = m_HasDxNormalTextures;
-    scene->m_ForceFullTextureSize = m_ForceFullTextureSize;
-    scene->m_Models = std::move(m_Models);
-    scene->m_SceneNodes = std::move(m_SceneNodes);
-    scene->m_IsRelativeTransform = std::move(m_IsRelativeTransform);
-    scene->m_Animations = std::move(m_Animations);
-    scene->m_AnimatedVertices = std::move(m_AnimatedVertices);
-    scene->m_AnimatedIndices = std::move(m_AnimatedIndices);
-    scene->m_Bones = std::move(m_Bones);
-    scene->m_BoneTransforms.assign(scene->m_Bones.size(), IdentityTransform());
-    scene->m_HasSkeletalAnimations = false;
-    for (const Geometry &g : scene->m_Geometries)
-        scene->m_HasSkeletalAnimations |= g.IsAnimated != 0; // Scene.cpp:47-48
-    scene->m_LightInfos = std::move(m_LightInfos);
-    scene->m_PointLights = std::move(m_PointLights);
-    scene->m_DirectionalLightInfo = m_DirectionalLightInfo;
-    scene->m_DirectionalLight = m_DirectionalLight;
-    scene->m_Skybox = std::move(m_Skybox);
+    // what moves: every node an animation drives, and everything below such a node (nodes are stored in pre-order, so one pass)
+    std::vector<bool> moves(s.m_Graph.Nodes.size(), false);
+    for (const Animation &animation : s.m_Graph.Animations)
+        for (const AnimationNode &track : animation.Nodes)
+            moves[track.SceneNodeIndex] = true;
+    for (size_t i = 0; i < s.m_Graph.Nodes.size(); i++)
+        moves[i] = moves[i] || moves[s.m_Graph.Nodes[i].Parent];
+    s.m_Graph.MovesInstances = !s.m_Graph.Bones.empty();
+    for (const LightInfo &light : s.m_Lights.PointRest)
+        s.m_Graph.MovesInstances = s.m_Graph.MovesInstances || moves[light.SceneNodeIndex];
+    for (const auto &[modelIndex, sceneNodeIndex] : m_PendingInstances)
+        s.m_Graph.MovesInstances = s.m_Graph.MovesInstances || moves[sceneNodeIndex];
 
-    for (auto [modelIndex, sceneNodeIndex] : m_ModelInstanceInfos)
-        scene->m_ModelInstances.push_back({ modelIndex, sceneNodeIndex, scene->m_SceneNodes[sceneNodeIndex].Transform });
+    s.m_Graph.BoneTransforms.assign(s.m_Graph.Bones.size(), IdentityTransform());
+    s.m_Graph.HasSkinnedGeometry = false;
+    for (const Geometry &g : s.m_Geometries)
+        s.m_Graph.HasSkinnedGeometry = s.m_Graph.HasSkinnedGeometry || g.IsAnimated != 0; // Scene.cpp:47-48
 
-    // flattened SBT-record table in model-then-mesh order (Renderer.cpp:378-399; static
-    // scenes: geometryIndexMap is the identity, Renderer.cpp:333-350)
-    for (const Model &model : scene->m_Models)
+    for (const auto &[modelIndex, sceneNodeIndex] : m_PendingInstances)
+        s.m_ModelInstances.push_back({ modelIndex, sceneNodeIndex, s.m_Graph.Nodes[sceneNodeIndex].Transform });
+
+    // flattened SBT-record table in model-then-mesh order (Renderer.cpp:378-399; static scenes: geometryIndexMap is the identity,
+    // Renderer.cpp:333-350)
+    for (const Model &model : s.m_Models)
     {
-        scene->m_ModelRanges.push_back({ model.MeshOffset, static_cast<uint32_t>(model.Meshes.size()) });
+        s.m_ModelRanges.push_back({ model.MeshOffset, static_cast<uint32_t>(model.Meshes.size()) });
         for (const Mesh &mesh : model.Meshes)
-            scene->m_MeshRecords.push_back({ mesh.GeometryIndex, mesh.MaterialIndex, mesh.TransformBufferOffset });
+            s.m_MeshRecords.push_back({ mesh.GeometryIndex, mesh.MaterialIndex, mesh.TransformBufferOffset });
     }
 
-    scene->UpdateTransforms();
-    for (const auto &info : m_CameraInfos)
-        scene->m_SceneCameras.emplace_back(info.VerticalFOV, info.NearClip, info.FarClip, info.Position, info.Direction,
-                                           info.UpDirection, scene->m_SceneNodes[info.SceneNodeIndex].CurrentTransform);
-    // the application's frame loop runs Scene::Update before the first upload
-    // (Application.cpp:328-351): do the same so the Scene is consumable right away
-    scene->Update(0.0f);
+    s.UpdateTransforms();
+    for (const CameraInfo &info : m_PendingCameras)
+        s.m_SceneCameras.emplace_back(info.VerticalFOV, info.NearClip, info.FarClip, info.Position, info.Direction, info.UpDirection,
+                                      s.m_Graph.Nodes[info.SceneNodeIndex].CurrentTransform);
+    // the application's frame loop runs Scene::Update before the first upload (Application.cpp:328-351): do the same so that the
+    // Scene is consumable right away
+    s.Update(0.0f);
 
     Reset();
     return scene;

@@ -274,15 +274,15 @@ public:
     [[nodiscard]] std::span<const uint32_t> GetIndices() const { return m_Indices; }
     [[nodiscard]] std::span<const Shaders::AnimatedVertex> GetAnimatedVertices() const { return m_AnimatedVertices; }
     [[nodiscard]] std::span<const uint32_t> GetAnimatedIndices() const { return m_AnimatedIndices; }
-    [[nodiscard]] std::span<const PtxTransform> GetBoneTransforms() const { return m_BoneTransforms; } // glm::mat3x4 each
-    [[nodiscard]] bool HasAnimations() const { return !m_Animations.empty(); }
-    [[nodiscard]] bool HasSkeletalAnimations() const { return m_HasSkeletalAnimations; }
-    void SetAnimationPaused(bool paused) { m_IsAnimationPaused = paused; }
+    [[nodiscard]] std::span<const PtxTransform> GetBoneTransforms() const { return m_Graph.BoneTransforms; } // glm::mat3x4 each
+    [[nodiscard]] bool HasAnimations() const { return !m_Graph.Animations.empty(); }
+    [[nodiscard]] bool HasSkeletalAnimations() const { return m_Graph.HasSkinnedGeometry; }
+    void SetAnimationPaused(bool paused) { m_Graph.Paused = paused; }
     [[nodiscard]] std::span<const PtxTransform> GetTransforms() const { return m_Transforms; }
     [[nodiscard]] std::span<const Geometry> GetGeometries() const { return m_Geometries; }
-    [[nodiscard]] std::span<const Shaders::MetallicRoughnessMaterial> GetMetallicRoughnessMaterials() const { return m_MetallicRoughnessMaterials; }
-    [[nodiscard]] std::span<const Shaders::SpecularGlossinessMaterial> GetSpecularGlossinessMaterials() const { return m_SpecularGlossinessMaterials; }
-    [[nodiscard]] std::span<const Shaders::PhongMaterial> GetPhongMaterials() const { return m_PhongMaterials; }
+    [[nodiscard]] std::span<const Shaders::MetallicRoughnessMaterial> GetMetallicRoughnessMaterials() const { return m_Materials.MetallicRoughness; }
+    [[nodiscard]] std::span<const Shaders::SpecularGlossinessMaterial> GetSpecularGlossinessMaterials() const { return m_Materials.SpecularGlossiness; }
+    [[nodiscard]] std::span<const Shaders::PhongMaterial> GetPhongMaterials() const { return m_Materials.Phong; }
     [[nodiscard]] std::span<const TextureInfo> GetTextures() const { return m_Textures; }
     [[nodiscard]] std::span<const Model> GetModels() const { return m_Models; }
     [[nodiscard]] std::span<const ModelInstance> GetModelInstances() const { return m_ModelInstances; }
@@ -292,8 +292,8 @@ public:
     // backend: 0 = the reference's default (min(80 % of the device memory, 1 GiB)), ~0 = no limit
     void SetTextureMemoryBudget(uint64_t bytes) { m_TextureMemoryBudget = bytes; }
     [[nodiscard]] uint64_t GetTextureMemoryBudget() const { return m_TextureMemoryBudget; }
-    [[nodiscard]] std::span<const Shaders::PointLight> GetPointLights() const { return m_PointLights; }
-    [[nodiscard]] const Shaders::DirectionalLight &GetDirectionalLight() const { return m_DirectionalLight; }
+    [[nodiscard]] std::span<const Shaders::PointLight> GetPointLights() const { return m_Lights.Point; }
+    [[nodiscard]] const Shaders::DirectionalLight &GetDirectionalLight() const { return m_Lights.Directional; }
     [[nodiscard]] const SkyboxVariant &GetSkybox() const { return m_Skybox; }
 
     [[nodiscard]] uint32_t GetSceneCamerasCount() const { return static_cast<uint32_t>(m_SceneCameras.size()); }
@@ -315,33 +315,46 @@ private:
     friend class SceneBuilder;
 
     std::string m_Name;
+    // geometry pools and what indexes them
     std::vector<Shaders::Vertex> m_Vertices;
     std::vector<uint32_t> m_Indices;
+    std::vector<Shaders::AnimatedVertex> m_AnimatedVertices;
+    std::vector<uint32_t> m_AnimatedIndices;
     std::vector<PtxTransform> m_Transforms;
     std::vector<Geometry> m_Geometries;
-    std::vector<Shaders::MetallicRoughnessMaterial> m_MetallicRoughnessMaterials;
-    std::vector<Shaders::SpecularGlossinessMaterial> m_SpecularGlossinessMaterials;
-    std::vector<Shaders::PhongMaterial> m_PhongMaterials;
+    std::vector<Model> m_Models;
+    std::vector<ModelInstance> m_ModelInstances;
+    struct MaterialTables // one table per shading model; a MaterialId is (index << 8) | type
+    {
+        std::vector<Shaders::MetallicRoughnessMaterial> MetallicRoughness;
+        std::vector<Shaders::SpecularGlossinessMaterial> SpecularGlossiness;
+        std::vector<Shaders::PhongMaterial> Phong;
+    } m_Materials;
     std::vector<TextureInfo> m_Textures;
     bool m_HasDxNormalTextures = false;
     bool m_ForceFullTextureSize = false;
     uint64_t m_TextureMemoryBudget = 0;
-    std::vector<Model> m_Models;
-    std::vector<ModelInstance> m_ModelInstances;
-    std::vector<SceneNode> m_SceneNodes;
-    std::vector<bool> m_IsRelativeTransform;
-    std::vector<Animation> m_Animations;
-    std::vector<Shaders::AnimatedVertex> m_AnimatedVertices;
-    std::vector<uint32_t> m_AnimatedIndices;
-    std::vector<Bone> m_Bones;
-    std::vector<PtxTransform> m_BoneTransforms;
-    bool m_HasAnimatedInstances = false;
-    bool m_HasSkeletalAnimations = false;
-    bool m_IsAnimationPaused = false;
-    std::vector<LightInfo> m_LightInfos;
-    std::vector<Shaders::PointLight> m_PointLights;
-    DirectionalLightInfo m_DirectionalLightInfo;
-    Shaders::DirectionalLight m_DirectionalLight;
+    // The scene graph (the reference's SceneGraph class, SceneGraph.h:88-110, as a part of the scene): nodes in pre-order, which
+    // of them compose with their parent, the clips that drive them, and the skeleton's bones with the matrices skinning.comp reads.
+    struct Graph
+    {
+        std::vector<SceneNode> Nodes;
+        std::vector<bool> IsRelative;
+        std::vector<Animation> Animations;
+        std::vector<Bone> Bones;
+        std::vector<PtxTransform> BoneTransforms;
+        bool MovesInstances = false;     // an instance, light or bone hangs below an animated node: Update() reports a change
+        bool HasSkinnedGeometry = false; // some geometry is skinned (Scene.cpp:47-48)
+        bool Paused = false;
+    } m_Graph;
+    // lights as the UBO holds them, and where each rests in its node's frame (they follow their nodes, Scene.cpp:73-80)
+    struct Lights
+    {
+        std::vector<LightInfo> PointRest;
+        std::vector<Shaders::PointLight> Point;
+        DirectionalLightInfo DirectionalRest;
+        Shaders::DirectionalLight Directional;
+    } m_Lights;
     SkyboxVariant m_Skybox = SkyboxClearColor {};
     mutable std::vector<PtxTextureDesc> m_SkyboxRecords;
 
@@ -374,16 +387,16 @@ public:
     Shaders::MaterialId AddMaterial(std::string name, Shaders::SpecularGlossinessMaterial material);
     Shaders::MaterialId AddMaterial(std::string name, Shaders::PhongMaterial material);
 
-    std::vector<Shaders::Vertex> &GetVertices() { return m_Vertices; }
-    std::vector<uint32_t> &GetIndices() { return m_Indices; }
-    std::vector<Shaders::AnimatedVertex> &GetAnimatedVertices() { return m_AnimatedVertices; }
-    std::vector<uint32_t> &GetAnimatedIndices() { return m_AnimatedIndices; }
+    std::vector<Shaders::Vertex> &GetVertices() { return m_Scene->m_Vertices; }
+    std::vector<uint32_t> &GetIndices() { return m_Scene->m_Indices; }
+    std::vector<Shaders::AnimatedVertex> &GetAnimatedVertices() { return m_Scene->m_AnimatedVertices; }
+    std::vector<uint32_t> &GetAnimatedIndices() { return m_Scene->m_AnimatedIndices; }
 
-    void AddAnimation(Animation &&animation) { m_Animations.push_back(std::move(animation)); }
+    void AddAnimation(Animation &&animation) { m_Scene->m_Graph.Animations.push_back(std::move(animation)); }
     uint32_t AddBone(Bone &&bone)
     {
-        m_Bones.push_back(std::move(bone));
-        return static_cast<uint32_t>(m_Bones.size() - 1);
+        m_Scene->m_Graph.Bones.emplace_back(std::move(bone));
+        return static_cast<uint32_t>(m_Scene->m_Graph.Bones.size() - 1);
     }
 
     void SetAbsoluteTransform(uint32_t sceneNodeIndex);
@@ -391,13 +404,13 @@ public:
     void AddLight(Shaders::PointLight &&light, uint32_t sceneNodeIndex);
     void SetDirectionalLight(Shaders::DirectionalLight &&light, uint32_t sceneNodeIndex);
 
-    void SetSkybox(Skybox2D &&skybox) { m_Skybox = std::move(skybox); }
-    void SetSkybox(SkyboxCube &&skybox) { m_Skybox = std::move(skybox); }
+    void SetSkybox(Skybox2D &&skybox) { m_Scene->m_Skybox = std::move(skybox); }
+    void SetSkybox(SkyboxCube &&skybox) { m_Scene->m_Skybox = std::move(skybox); }
 
     void AddCamera(CameraInfo &&camera);
 
-    void SetDxNormalTextures() { m_HasDxNormalTextures = true; }
-    void ForceFullTextureSize() { m_ForceFullTextureSize = true; }
+    void SetDxNormalTextures() { m_Scene->m_HasDxNormalTextures = true; }
+    void ForceFullTextureSize() { m_Scene->m_ForceFullTextureSize = true; }
     [[nodiscard]] std::shared_ptr<Scene> CreateSceneShared(const std::string &name);
 
 public:
@@ -407,42 +420,19 @@ public:
     SceneBuilder();
 
 private:
-    std::vector<Shaders::Vertex> m_Vertices;
-    std::vector<uint32_t> m_Indices;
-    std::vector<PtxTransform> m_Transforms;
-    std::vector<Geometry> m_Geometries;
-
-    std::vector<Shaders::MetallicRoughnessMaterial> m_MetallicRoughnessMaterials;
-    std::unordered_map<std::string, uint32_t> m_MetallicRoughnessMaterialIds;
-    std::vector<Shaders::SpecularGlossinessMaterial> m_SpecularGlossinessMaterials;
-    std::unordered_map<std::string, uint32_t> m_SpecularGlossinessMaterialIds;
-    std::vector<Shaders::PhongMaterial> m_PhongMaterials;
-    std::unordered_map<std::string, uint32_t> m_PhongMaterialIds;
-
-    std::vector<TextureInfo> m_Textures;
-    std::unordered_map<std::string, uint32_t> m_TextureIndices;
-    bool m_HasDxNormalTextures = false;
-    bool m_ForceFullTextureSize = false;
-
-    std::vector<Model> m_Models;
-    std::vector<std::pair<uint32_t, uint32_t>> m_ModelInstanceInfos;
-
-    std::vector<SceneNode> m_SceneNodes;
-    std::vector<bool> m_IsRelativeTransform;
-    std::vector<Animation> m_Animations;
-    std::vector<Shaders::AnimatedVertex> m_AnimatedVertices;
-    std::vector<uint32_t> m_AnimatedIndices;
-    std::vector<Bone> m_Bones;
-
-    std::vector<LightInfo> m_LightInfos;
-    std::vector<Shaders::PointLight> m_PointLights;
-    DirectionalLightInfo m_DirectionalLightInfo;
-    Shaders::DirectionalLight m_DirectionalLight;
-    SkyboxVariant m_Skybox = SkyboxClearColor {};
-
-    std::vector<CameraInfo> m_CameraInfos;
-
-    uint32_t m_MeshOffset = 0;
+    // The builder fills the Scene it will hand out IN PLACE (it is a friend of Scene): geometry, materials, textures, the scene
+    // graph, lights and the skybox go straight into `m_Scene`'s members, so nothing is copied or cleared member by member when the
+    // scene is finished.  What is the builder's own is only what a finished Scene has no use for: the name -> id tables that
+    // deduplicate textures and materials, the (model, node) pairs and camera descriptions that become instances and cameras once
+    // the graph's transforms are known, and the running mesh-record offset.
+    std::shared_ptr<Scene> m_Scene;
+    struct IdsByName
+    {
+        std::unordered_map<std::string, uint32_t> Textures, MetallicRoughness, SpecularGlossiness, Phong;
+    } m_Ids;
+    std::vector<std::pair<uint32_t, uint32_t>> m_PendingInstances; // (model index, scene node index)
+    std::vector<CameraInfo> m_PendingCameras;
+    uint32_t m_NextMeshRecord = 0;
 
     void Reset();
     Model CreateModel(std::span<const MeshInfo> meshInfos);
