@@ -235,11 +235,18 @@ class Job:
         self.scene_has_textures = self.scene.desc.textureCount > 0  # k_shade<true> / k_tail<1,2> run instead of the plain variants
         self.lights = self.scene.lights
         backend = pkg.BACKEND_WAVEFRONT if args.backend == "wavefront" else pkg.BACKEND_MEGAKERNEL
-        self.F = args.in_flight if args.in_flight > 0 else 8
+        # A rank of an N-GPU job renders THIN frames (1 / N of the pixels): it keeps 16 of them in flight on ONE stream each, where
+        # a whole-frame renderer keeps 8 on two streams each (its shadow and tail kernels beside the next bounce) -- the same 16
+        # hardware queues either way.  1 / 8 shard step with the owner's duty in the loop, two streams x 8 -> one stream x 16:
+        # chess_like 1.05 -> 0.95 ms, street_like 1.61 -> 1.60, atrium_like 2.69 -> 2.60, temple_like 2.29 -> 2.20; 20 in flight
+        # fall off a cliff (3.4 ms); a whole frame loses 2 % with one stream (profiles/r06_single_stream*.txt).
+        gathers = world > 1 or args.force_gather
+        self.single_stream = (args.streams_per_frame == 1) if args.streams_per_frame else gathers
+        self.F = args.in_flight if args.in_flight > 0 else (16 if self.single_stream else 8)
         self.shard_rank, self.shard_world = shard if shard else (rank, world)
         self.u = self.scene.uniform(self.W, self.H, bounces=args.depth)
         self.streams = [torch.cuda.Stream()]
-        self.rs = [pkg.Renderer(device=local_rank, backend=backend, stream=self.streams[0].cuda_stream)]
+        self.rs = [pkg.Renderer(device=local_rank, backend=backend, stream=self.streams[0].cuda_stream, single_stream=self.single_stream)]
         t0 = time.time()
         self.rs[0].upload(self.scene)
         self.rs[0].synchronize()
@@ -250,7 +257,7 @@ class Job:
         self.alone_stats = self.alone(args.spp, alone_steps) if alone_steps > 0 else None
         for _ in range(1, self.F):
             self.streams.append(torch.cuda.Stream())
-            self.rs.append(pkg.Renderer(device=local_rank, backend=backend, stream=self.streams[-1].cuda_stream))
+            self.rs.append(pkg.Renderer(device=local_rank, backend=backend, stream=self.streams[-1].cuda_stream, single_stream=self.single_stream))
         for r in self.rs[1:]:  # the frames in flight share one scene and one tree, as the reference's per-frame resources do
             r.share_scene(self.rs[0])
             r.resize(self.W, self.H)
@@ -841,10 +848,13 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--tile", type=int, default=32)
     ap.add_argument("--in-flight", type=int, default=0,
-                    help="frames in flight: renderers (own stream, own path state) taking the steps in turn; 0 = 8 per GPU.  Measured on "
+                    help="frames in flight: renderers (own stream, own path state) taking the steps in turn; 0 = 8 per GPU (16 single-stream ones for a rank of an N-GPU job).  Measured on "
                          "one GPU with 16 hardware queues since the read-back rides on the auxiliary stream (no third stream per frame) and "
                          "leaves through a one-workgroup copy: whole frame 6.91 / 6.76 / 6.63 ms per step with 4 / 6 / 8 in flight "
                          "(chess_like), 19.8 / 19.7 / 19.4 (atrium_like), 12.98 / 12.49 / 11.99 (street_like)")
+    ap.add_argument("--streams-per-frame", type=int, default=0, choices=[0, 1, 2],
+                    help="HIP streams of a frame in flight: 2 = main + auxiliary (shadow and tail kernels beside the next bounce), 1 = one "
+                         "(PTX_DEVICE_SINGLE_STREAM); 0 = 2 for a whole frame on one GPU, 1 for a rank's tile shard of an N-GPU job")
     ap.add_argument("--backend", default="wavefront", choices=["wavefront", "megakernel"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -1023,7 +1033,7 @@ def main():
                            "triangles": job.n_tris, "backend": args.backend, "tile": args.tile, "frames_in_flight": job.F,
                            "parallelism": (f"pixel-tile shard x{world}, 1 {args.collective if args.dist_backend == 'nccl' else 'gloo gather'} per step to the frame's owner "
                                            f"({'rank k % N' if job.rotate else 'rank 0'}), {'one' if args.gather_unpack == 'one' else 'N'} unpack launch(es), "
-                                           f"host frames in shared memory"),
+                                           f"host frames in shared memory; {job.F} frames in flight on {'one stream' if job.single_stream else 'two streams'} each"),
                            "rank0_kernel_ms_per_step": {"k_trace_closest": stats_s["trace_ms"] / args.steps, "k_shade": stats_s["shade_ms"] / args.steps,
                                                         "k_trace_shadow": stats_s["shadow_ms"] / args.steps, "k_tail": stats_s["tail_ms"] / args.steps},
                            "frame_checksum": [float(img[..., :3].astype(np.float64).sum()), bool(np.isfinite(img).all()), bool((img[..., 3] == 1).all())]})

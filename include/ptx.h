@@ -42,7 +42,8 @@ extern "C" {
  * PtxStats.hardwareQueues (round 3).  4: PtxStats.treeTriangles / treeReferences (round 4).  5: every `/` of the shader path
  * became a * rcp(b) (round 5: ptx_test_eval and rendered images changed meaning in the last bits) and ptx_unpack_shard_host was
  * added; ptx_unpack_shards, ptx_bind_shard_accumulation; repeat addressing of the sampler takes the exact floor(x) mod n for extents
- * that are not powers of two; normalize() / inversesqrt() go through the specified rsq (PTX_FN_RSQ) instead of rcp(sqrt()) (round 6). */
+ * that are not powers of two; normalize() / inversesqrt() go through the specified rsq (PTX_FN_RSQ) instead of rcp(sqrt());
+ * PtxDeviceDesc.flags (round 6). */
 #define PTX_ABI_VERSION 5u
 
 /* ------------------------------------------------------------------------- */
@@ -336,10 +337,21 @@ typedef enum PtxBackend {
     PTX_BACKEND_MEGAKERNEL = 1  /* one thread per pixel running raygen.rgen's loop 1:1  */
 } PtxBackend;
 
+enum {
+    /* ONE stream per handle: the shadow and tail kernels of a frame ride on its main stream instead of an auxiliary one -- no overlap
+     * inside a frame, but a frame in flight then takes one hardware queue, not two, and twice as many frames fit the queues.  Pays
+     * for THIN frames (a rank's tile shard of an N-GPU job: 16 single-stream frames in flight against 8 two-stream ones, a 1 / 8
+     * shard step of chess_like 1.05 -> 0.95 ms, the heavier stand-ins -1 ... -4 %); a whole frame on one GPU does better with two
+     * streams (profiles/r06_single_stream*.txt). */
+    PTX_DEVICE_SINGLE_STREAM = 1u
+};
+
 typedef struct PtxDeviceDesc {
     int32_t deviceIndex;  /* HIP device ordinal                                        */
     uint32_t backend;     /* PtxBackend                                                */
     void *stream;         /* hipStream_t to launch on, or NULL for an internal stream  */
+    uint32_t flags;       /* PTX_DEVICE_*                                              */
+    uint32_t reserved;    /* 0                                                         */
 } PtxDeviceDesc;
 
 /* Pixel-tile shard of a frame: the image is cut into tileSize x tileSize

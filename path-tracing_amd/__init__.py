@@ -130,8 +130,11 @@ OUTPUT_RGBA8_SRGB, OUTPUT_RGBA32F = 0, 1
 ABI_VERSION = 5  # PTX_ABI_VERSION of include/ptx.h
 
 
+DEVICE_SINGLE_STREAM = 1  # PTX_DEVICE_SINGLE_STREAM
+
+
 class DeviceDesc(C.Structure):
-    _fields_ = [("deviceIndex", C.c_int32), ("backend", C.c_uint32), ("stream", C.c_void_p)]
+    _fields_ = [("deviceIndex", C.c_int32), ("backend", C.c_uint32), ("stream", C.c_void_p), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class TileShard(C.Structure):
@@ -399,10 +402,10 @@ def _close_renderers():
 class Renderer:
     """include/ptx.h as an object.  Raises PtxError (with ptx_last_error) on any failure."""
 
-    def __init__(self, device: int = 0, backend: int = BACKEND_WAVEFRONT, stream: int | None = None):
+    def __init__(self, device: int = 0, backend: int = BACKEND_WAVEFRONT, stream: int | None = None, single_stream: bool = False):
         self.lib = load_hip()
         self.handle = C.c_void_p()
-        desc = DeviceDesc(device, backend, stream)
+        desc = DeviceDesc(device, backend, stream, DEVICE_SINGLE_STREAM if single_stream else 0, 0)
         rc = self.lib.ptx_create(C.byref(desc), C.byref(self.handle))
         if rc:
             self.handle = None

@@ -82,6 +82,7 @@ struct EnvSwitches
     //   5 main stream on XCD h % 8, auxiliary stream on XCD (h + 4) % 8
     // With a mask the library creates the main stream itself even if the host passed one (the host's stream cannot be masked).
     uint32_t cuPartition = 0;
+    bool singleStream = false; // PTX_SINGLE_STREAM=1: every handle as if created with PTX_DEVICE_SINGLE_STREAM
     bool verbose = false;        // PTX_VERBOSE: progress and statistics on stderr
     bool karrasBuilder = false;  // PTX_BUILDER=lbvh: Karras topology instead of PLOC
     bool plocFixed = false;      // PTX_PLOC_RADIUS / PTX_PLOC_SHAPE given: ONE tree with these parameters, no candidates
@@ -137,6 +138,7 @@ struct EnvSwitches
             e.raysPerThread = std::max(1u, (uint32_t)strtoul(v, nullptr, 10));
         if (const char *v = getenv("PTX_RESIDENT_CAP"))
             e.residentCap = (long)strtoul(v, nullptr, 10);
+        e.singleStream = getenv("PTX_SINGLE_STREAM") != nullptr && std::strcmp(getenv("PTX_SINGLE_STREAM"), "0") != 0;
         if (const char *v = getenv("PTX_CU_PARTITION"))
             e.cuPartition = (uint32_t)strtoul(v, nullptr, 10);
         return e;
@@ -284,6 +286,8 @@ struct PtxRenderer
 
     // bounce schedule of the wavefront backend (renderImpl): closest + shade on `stream`, shadow + tail on `auxStream`
     hipStream_t auxStream = nullptr;
+    bool auxIsMain = false; // single-stream handle: auxStream is `stream` itself
+    bool singleStream = false; // PtxDeviceDesc.flags & PTX_DEVICE_SINGLE_STREAM
     uint32_t handleSeq = 0, mainXcds = 0xffu, auxXcds = 0xffu; // PTX_CU_PARTITION: the XCDs this handle's streams may use
     DevBuf<uint32_t> spillAux; // traversal-stack overflow region of the kernels on auxStream
     struct BounceEvents
@@ -533,6 +537,7 @@ static int createRenderer(const PtxDeviceDesc *desc, PtxRenderer **out)
     PtxRenderer *r = new PtxRenderer;
     r->device = desc ? desc->deviceIndex : 0;
     r->backend = desc ? desc->backend : PTX_BACKEND_WAVEFRONT;
+    r->singleStream = desc && (desc->flags & PTX_DEVICE_SINGLE_STREAM) != 0u;
     if (r->device < 0 || r->device >= n || hipSetDevice(r->device) != hipSuccess)
     {
         delete r;
@@ -597,11 +602,12 @@ static int createRenderer(const PtxDeviceDesc *desc, PtxRenderer **out)
     r->stats.hardwareQueues = hardwareQueuesGranted();
     r->counted = true;
     const uint32_t live = ++g_liveHandles;
-    if (2u * live > r->stats.hardwareQueues && live > 1 && !g_queueWarningGiven.exchange(true))
+    const uint32_t streamsPerHandle = (r->singleStream || r->env.singleStream) ? 1u : 2u;
+    if (streamsPerHandle * live > r->stats.hardwareQueues && live > 1 && !g_queueWarningGiven.exchange(true))
     {
         // not an error: the handle works, its frames just run behind the other handles' instead of beside them
-        fail(r, PTX_OK, "%u handles (two streams each) share %u hardware queues: frames in flight will serialise; export GPU_MAX_HW_QUEUES=16 "
-                        "before the process first uses HIP", live, (uint32_t)r->stats.hardwareQueues);
+        fail(r, PTX_OK, "%u handles (%u stream(s) each) share %u hardware queues: frames in flight will serialise; export GPU_MAX_HW_QUEUES=16 "
+                        "(24 for a process that also gathers) before the process first uses HIP", live, streamsPerHandle, (uint32_t)r->stats.hardwareQueues);
         if (r->env.verbose)
             fprintf(stderr, "[ptx] %s\n", r->error.c_str());
     }
@@ -630,7 +636,7 @@ static void destroyRenderer(PtxRenderer *r)
     }
     r->sceneSharers.clear();
     // every DevBuf member (scene, tree, build state, wavefront state, animation, output stage) frees itself in `delete r`
-    if (r->auxStream) { (void)hipStreamSynchronize(r->auxStream); (void)hipStreamDestroy(r->auxStream); }
+    if (r->auxStream && !r->auxIsMain) { (void)hipStreamSynchronize(r->auxStream); (void)hipStreamDestroy(r->auxStream); }
     for (PtxRenderer::BounceEvents &e : r->bounceEvents)
         for (hipEvent_t ev : { e.t0, e.t1, e.t2, e.x0, e.x1, e.x2 })
             if (ev)
@@ -1916,7 +1922,18 @@ static int ensureRenderResources(PtxRenderer *r, uint32_t bounces)
 {
     if (!r->auxStream)
     {
-        HIP_TRY(r, createStreamOn(&r->auxStream, r->auxXcds, r->device));
+    {
+        // PTX_DEVICE_SINGLE_STREAM (or PTX_SINGLE_STREAM=1 in the environment): the shadow and tail kernels ride on the main stream
+        // too -- no overlap inside a frame, one hardware queue per frame in flight instead of two (twice the frames on the same
+        // queues; what a rank's thin tile shard of an N-GPU job wants, include/ptx.h)
+        if (r->env.singleStream || r->singleStream)
+        {
+            r->auxStream = r->stream;
+            r->auxIsMain = true;
+        }
+        else
+            HIP_TRY(r, createStreamOn(&r->auxStream, r->auxXcds, r->device));
+    }
         HIP_TRY(r, r->spillAux.alloc((size_t)kGlobalSpill * kMaxPersistentThreads));
     }
     const size_t want = bounces < (uint32_t)kMaxTimedBounces ? bounces : (uint32_t)kMaxTimedBounces;

@@ -21,7 +21,7 @@ void RendererHip::Check(int status)
 
 void RendererHip::Init(int deviceIndex, void *stream)
 {
-    PtxDeviceDesc desc = { deviceIndex, PTX_BACKEND_WAVEFRONT, stream };
+    PtxDeviceDesc desc = { deviceIndex, PTX_BACKEND_WAVEFRONT, stream, 0u, 0u };
     if (ptx_abi_version() != PTX_ABI_VERSION)
         throw error("RendererHip: libptx_hip.so was built against another ptx.h (ABI " + std::to_string(ptx_abi_version()) + ", expected " +
                     std::to_string(PTX_ABI_VERSION) + ")");

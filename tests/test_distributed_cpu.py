@@ -195,7 +195,8 @@ def test_bench_two_ranks_gather_the_single_rank_frame(pkg, tmp_path, backend):
     got = np.load(out)
     assert (got.view(np.uint32) == ref.view(np.uint32)).all()
     frames = np.load(tmp_path / f"frames_{backend}.npy")
-    assert frames.shape[0] == 8  # lcm(2 ranks, 8 frames in flight); frame j composed by rank j % 2
+    assert frames.shape[0] == 16  # lcm(2 ranks, 16 single-stream frames in flight); frame j composed by rank j % 2
+    assert line["config"]["frames_in_flight"] == 16 and "one stream" in line["config"]["parallelism"]
     for j in range(frames.shape[0]):
         assert (frames[j].view(np.uint32) == ref.view(np.uint32)).all(), f"frame {j} (owner: rank {j % 2}) differs from the single-rank frame"
 
