@@ -241,7 +241,11 @@ class Job:
         # chess_like 1.05 -> 0.95 ms, street_like 1.61 -> 1.60, atrium_like 2.69 -> 2.60, temple_like 2.29 -> 2.20; 20 in flight
         # fall off a cliff (3.4 ms); a whole frame loses 2 % with one stream (profiles/r06_single_stream*.txt).
         gathers = world > 1 or args.force_gather
-        self.single_stream = (args.streams_per_frame == 1) if args.streams_per_frame else gathers
+        # ... and so is any frame batch below a few million path slots: BASELINE configs[0] (512 x 512, 1 spp: 262 K slots) 591 -> 809
+        # Msamples/s with one stream x 16 frames (604 with one stream x 8, 626 x 18, 496 with two streams x 9)
+        slots_per_step = args.width * args.height * args.spp / (shard[1] if shard else max(world, 1))
+        thin = slots_per_step < 4.0e6
+        self.single_stream = (args.streams_per_frame == 1) if args.streams_per_frame else (gathers or thin)
         self.F = args.in_flight if args.in_flight > 0 else (16 if self.single_stream else 8)
         self.shard_rank, self.shard_world = shard if shard else (rank, world)
         self.u = self.scene.uniform(self.W, self.H, bounces=args.depth)
@@ -854,7 +858,8 @@ def main():
                          "(chess_like), 19.8 / 19.7 / 19.4 (atrium_like), 12.98 / 12.49 / 11.99 (street_like)")
     ap.add_argument("--streams-per-frame", type=int, default=0, choices=[0, 1, 2],
                     help="HIP streams of a frame in flight: 2 = main + auxiliary (shadow and tail kernels beside the next bounce), 1 = one "
-                         "(PTX_DEVICE_SINGLE_STREAM); 0 = 2 for a whole frame on one GPU, 1 for a rank's tile shard of an N-GPU job")
+                         "(PTX_DEVICE_SINGLE_STREAM); 0 = 2 for a whole frame on one GPU, 1 for thin frames: a rank's tile shard of an N-GPU job, "
+                         "or fewer than 4 M path slots per step")
     ap.add_argument("--backend", default="wavefront", choices=["wavefront", "megakernel"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")

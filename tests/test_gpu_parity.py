@@ -704,6 +704,44 @@ def test_tree_choice_does_not_change_images(pkg, monkeypatch):
         assert (images[0].view(np.uint32) == images[k].view(np.uint32)).all(), switches[k]
 
 
+def test_single_stream_handles_render_the_same_image(pkg, orc):
+    """PTX_DEVICE_SINGLE_STREAM (include/ptx.h): a handle whose shadow and tail kernels ride on its main stream -- what a rank of an
+    N-GPU job creates, sixteen of them in flight -- renders the image of the two-stream handle bit for bit, on
+    a textured scene with alpha-tested geometry and on an untextured one, whole frame and tile shard, several in flight."""
+    import torch  # noqa: F401
+
+    for name, detail, depth in (("chess_like", 0.05, 8), ("alpha_test", 1.0, 6)):
+        scene = pkg.Scene(name, detail)
+        W, H = 200, 120
+        u = scene.uniform(W, H, bounces=depth)
+        two = pkg.Renderer()
+        two.upload(scene)
+        two.resize(W, H)
+        two.render_frames(u, scene.lights, 0, 4)
+        ref = two.readback()
+        ones = [pkg.Renderer(single_stream=True) for _ in range(3)]
+        ones[0].upload(scene)
+        for r in ones[1:]:
+            r.share_scene(ones[0])
+        for r in ones:
+            r.resize(W, H)
+        for _ in range(2):            # twice: the first launch of a shape is driven from the host, the second is the hinted schedule
+            for r in ones:
+                r.reset()
+                r.render_frames(u, scene.lights, 0, 4)
+        for r in ones:
+            assert (r.readback().view(np.uint32) == ref.view(np.uint32)).all(), name
+        ones[0].set_tile_shard(1, 3, 32)
+        ones[0].reset()
+        ones[0].render_frames(u, scene.lights, 0, 4)
+        mask = pkg.shard_mask(W, H, 1, 3, 32)
+        img = ones[0].readback()
+        assert (img.view(np.uint32)[mask] == ref.view(np.uint32)[mask]).all() and (img[~mask] == 0).all()
+        for r in ones[::-1]:
+            r.close()
+        two.close()
+
+
 @pytest.mark.gpu
 def test_second_full_build_on_a_handle_does_not_reuse_the_level_lists_of_the_first(pkg, orc, monkeypatch):
     """A handle keeps its build state between ptx_build_accel calls.  With no reinsertion pass (PTX_REINSERT=0) nothing recomputes
